@@ -1,0 +1,87 @@
+/* libs2t_mi355.so -- C ABI of the MI355X (gfx950) ASR-training hot path.
+ *
+ * The reference (guangkun0818/speech2text) has no native layer: its hot path is
+ * Python calling torch / torchaudio / k2 ops.  Every entry point below replaces
+ * one of those call sites (cited per function, paths relative to the reference
+ * tree) and is what a maintainer would bind with ctypes from the same Python
+ * module.
+ *
+ * Conventions: all pointers are DEVICE pointers owned by the caller; fp32 data,
+ * int64 ("long") lengths / labels / ranges exactly as the reference's tensors;
+ * `stream` is a hipStream_t; nothing allocates or synchronises; the return value
+ * is 0 on success, a hipError_t (>0) from the launch, or -1 for invalid sizes.
+ */
+#ifndef S2T_MI355_H_
+#define S2T_MI355_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- frontend: dataset/frontend/frontend.py:85-94 (kaldi fbank), + optional
+ * model/layer/global_cmvn.py:30-38 fused.  pcm [batch][pcm_stride], num_samples
+ * [batch]; out [batch][max_frames][num_mel] (frames past an utterance's own
+ * count are the batch padding value 0, CMVN'd if CMVN is fused); out_frames
+ * [batch] (may be NULL).  Host-built tables: window400 = povey window,
+ * twiddle512 = exp(-2*pi*i*m/512) as (re,im), compact mel filterbank. */
+int s2t_fbank_f32(const float* pcm, long pcm_stride, const long* num_samples, int batch,
+                  const float* window400, const float* twiddle512, const int* mel_off,
+                  const int* mel_k0, const float* mel_w, int nnz, int num_mel, float eps,
+                  float scale_in, const float* cmvn_mean, const float* cmvn_istd, float* out,
+                  int max_frames, long* out_frames, void* stream);
+
+/* ---- CTC: model/loss/ctc_loss.py:35-41 (log_softmax + nn.CTCLoss).
+ * logits [B][T][V] batch-major; targets [B][tgt_stride]; loss_per_utt [B] (nll,
+ * or 0 where infinite and zero_infinity); grad_logits [B][T][V] =
+ * grad_scale[b] * d nll_b / d logits (NULL to skip). */
+long s2t_ctc_workspace_floats(int B, int T, int Umax);
+int s2t_ctc_loss_fwd_bwd(const float* logits, const long* targets, long tgt_stride,
+                         const long* in_len, const long* tgt_len, int B, int T, int V, int Umax,
+                         int blank, int zero_infinity, const float* grad_scale, float* workspace,
+                         float* loss_per_utt, float* grad_logits, void* stream);
+
+/* ---- RNN-T lattice.  k2 call sites: model/joiner/joiner.py:100-123,
+ * model/loss/pruned_rnnt_loss.py:39-48; torchaudio: model/loss/rnnt_loss.py:42-44.
+ * am [B][T][C], lm [B][S+1][C], symbols [B][S], boundary [B][4]=(0,0,S_b,T_b),
+ * px [B][S][T+1], py [B][S+1][T], p [B][S+1][T+1], ranges [B][T][R]. */
+int s2t_fill_f32(float* p, long n, float v, void* stream);
+int s2t_rnnt_row_exp(const float* x, long rows, int C, float* probs, float* rowmax, void* stream);
+int s2t_rnnt_simple_pxpy(const float* am, const float* lm, const float* am_max,
+                         const float* lm_max, const float* nrm, const long* symbols,
+                         const long* boundary, int B, int S, int T, int C, int blank, float* px,
+                         float* py, void* stream);
+int s2t_rnnt_simple_w(const float* dpx, const float* dpy, const float* nrm, const float* gscale,
+                      int B, int S, int T, float* W, void* stream);
+int s2t_rnnt_simple_bwd(const float* am_probs, const float* lm_probs, const float* G_am,
+                        const float* G_lm, const float* dpx, const float* dpy,
+                        const float* gscale, const long* symbols, int B, int S, int T, int C,
+                        int blank, float* d_am, float* d_lm, int accumulate, void* stream);
+int s2t_mutual_info_fwd(const float* px, const float* py, const long* boundary, int B, int S,
+                        int T, float* p, float* ans, void* stream);
+int s2t_mutual_info_bwd(const float* px, const float* py, const long* boundary, const float* p,
+                        const float* ans_grad, int B, int S, int T, float* px_grad,
+                        float* py_grad, void* stream);
+int s2t_rnnt_prune_ranges(const float* px_grad, const float* py_grad, const long* boundary, int B,
+                          int S, int T, int s_range, long* ranges, void* stream);
+/* fused joiner: logits[b,t,i,:] = act(am[b,t,:] + lm[b,ranges[b,t,0]+i,:]) is
+ * never materialised; act: 0 = relu, 1 = tanh.  lse [B][T][R]. */
+int s2t_rnnt_pruned_fwd(const float* am, const float* lm, const long* ranges,
+                        const long* symbols, const long* boundary, int B, int S, int T, int C,
+                        int R, int blank, int act, float* px, float* py, float* lse, void* stream);
+int s2t_rnnt_pruned_bwd(const float* am, const float* lm, const long* ranges,
+                        const long* symbols, const float* lse, const float* dpx, const float* dpy,
+                        const float* gscale, int B, int S, int T, int C, int R, int blank, int act,
+                        float* d_am, float* d_lm, int accumulate, void* stream);
+/* materialised lattice: logits [B][T][R][V]; ranges NULL => full lattice, R = S+1 */
+int s2t_rnnt_lattice_fwd(const float* logits, const long* ranges, const long* symbols,
+                         const long* boundary, int B, int S, int T, int V, int R, int blank,
+                         float* px, float* py, float* lse, void* stream);
+int s2t_rnnt_lattice_bwd(const float* logits, const long* ranges, const long* symbols,
+                         const float* lse, const float* dpx, const float* dpy,
+                         const float* gscale, int B, int S, int T, int V, int R, int blank,
+                         float* d_logits, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* S2T_MI355_H_ */

@@ -1,0 +1,87 @@
+"""ctypes binding of libs2t_mi355.so (the C ABI declared in include/s2t_mi355.h).
+
+There is no fallback: if the shared library is missing, or a tensor handed to a
+kernel is not a contiguous device tensor of the declared dtype, this raises.
+"""
+import ctypes
+import os
+import re
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libs2t_mi355.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "s2t_mi355.h")
+_lib = None
+
+_CT = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float}
+
+
+def parse_header(path=HEADER_PATH):
+    """Returns {name: (restype, [argtypes])} for every prototype in the header."""
+    txt = open(path).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(int|long)\s+(s2t_\w+)\s*\(([^)]*)\)\s*;", txt):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        ats = []
+        for a in args.split(","):
+            a = a.strip()
+            if not a or a == "void":
+                continue
+            if "*" in a:
+                ats.append(ctypes.c_void_p)
+            else:
+                ats.append(_CT[a.split()[-2] if len(a.split()) > 1 else a])
+        protos[name] = (_CT[ret], ats)
+    return protos
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m speech2text_amd.csrc.build` "
+                "(there is no CPU or eager fallback for the hot path)")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (ret, ats) in parse_header().items():
+            fn = getattr(l, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = ret
+            fn.argtypes = ats
+        _lib = l
+    return _lib
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t, dtype=None):
+    """Device pointer of a contiguous CUDA(HIP) tensor, or NULL for None."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("s2t kernels need device tensors (no CPU fallback)")
+    if not t.is_contiguous():
+        raise RuntimeError("s2t kernels need contiguous tensors")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"expected {dtype}, got {t.dtype}")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def fp(t):
+    return ptr(t, torch.float32)
+
+
+def lp(t):
+    return ptr(t, torch.int64)
+
+
+def ip(t):
+    return ptr(t, torch.int32)
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed with code {rc}")

@@ -1,0 +1,66 @@
+// Shared device helpers for the gfx950 kernels of libs2t_mi355.so.
+// Wavefront = 64 lanes everywhere (CDNA4); no 32-wide assumptions.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define S2T_WAVE 64
+#define S2T_NEG_INF (-__builtin_huge_valf())
+
+#define S2T_CHECK_LAUNCH()                         \
+  do {                                             \
+    hipError_t e__ = hipGetLastError();            \
+    if (e__ != hipSuccess) return (int)e__;        \
+  } while (0)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// log(exp(a)+exp(b)) with -inf handling (never produces NaN for -inf inputs).
+__device__ __forceinline__ float log_add(float a, float b) {
+  float m = fmaxf(a, b);
+  if (m == S2T_NEG_INF) return S2T_NEG_INF;
+  float d = fminf(a, b) - m;  // <= 0 or -inf
+  return m + log1pf(__expf(d));
+}
+__device__ __forceinline__ float log_add_precise(float a, float b) {
+  float m = fmaxf(a, b);
+  if (m == S2T_NEG_INF) return S2T_NEG_INF;
+  float d = fminf(a, b) - m;
+  return m + log1pf(expf(d));
+}
+
+// block-wide sum via LDS scratch (>= blockDim/64 floats); all threads get it.
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (l == 0) scratch[w] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int i = 0; i < nw; ++i) r += scratch[i];
+  return r;
+}
+__device__ __forceinline__ float block_max(float v, float* scratch) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (l == 0) scratch[w] = v;
+  __syncthreads();
+  float r = S2T_NEG_INF;
+  for (int i = 0; i < nw; ++i) r = fmaxf(r, scratch[i]);
+  return r;
+}

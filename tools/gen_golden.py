@@ -1,0 +1,115 @@
+"""Generate golden vectors under tests/golden/ by RUNNING the reference here.
+
+Runs only in the build container (needs /root/reference).  Writes plain arrays
+(inputs, parameters, expected outputs) -- never reference source.  Usage:
+    python tools/gen_golden.py [fbank] [ctc] [bestrq] [zipformer] [losses] ...
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import ref_import  # noqa: E402
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(REPO, "tests", "golden")
+
+
+def synth_pcm(rng, n):
+    t = np.arange(n) / 16000.0
+    x = 0.05 * rng.standard_normal(n)
+    for _ in range(3):
+        f = rng.uniform(100, 4000)
+        x += rng.uniform(0.02, 0.2) * np.sin(2 * np.pi * f * t + rng.uniform(0, 6.28))
+    return np.clip(x, -1, 1).astype(np.float32)
+
+
+def gen_fbank():
+    import torch
+    m = torch.jit.load("/root/reference/sample_data/model/frontend.script")
+    rng = np.random.default_rng(20241218)
+    out = {}
+    for i, n in enumerate([400, 559, 560, 12560, 54080, 16000 * 3 + 77]):
+        pcm = synth_pcm(rng, n)
+        y = m(torch.from_numpy(pcm)[None]).numpy()
+        out[f"pcm{i}"] = pcm
+        out[f"feat{i}"] = y
+    np.savez_compressed(os.path.join(OUT, "fbank_script64.npz"), **out)
+    print("fbank:", {k: v.shape for k, v in out.items()})
+
+
+def gen_ctc():
+    import torch
+    ref_import.install_stubs()
+    from model.loss.ctc_loss import CtcLoss, CtcLossConfig
+    rng = np.random.default_rng(7)
+    out = {}
+    cases = [(4, 30, 16, 8), (3, 50, 40, 12), (2, 12, 8, 10), (5, 64, 128, 20)]
+    for ci, (B, T, V, U) in enumerate(cases):
+        logits = torch.from_numpy(rng.standard_normal((B, T, V)).astype(np.float32) * 2.0)
+        tl = torch.from_numpy(rng.integers(1, U + 1, size=B)).long()
+        tl[0] = U
+        il = torch.from_numpy(rng.integers(T // 2, T + 1, size=B)).long()
+        il[0] = T
+        if ci == 2:
+            il[1] = 3  # infeasible: too few frames -> inf -> zero_infinity
+            tl[1] = 10
+        tg = torch.from_numpy(rng.integers(1, V, size=(B, U))).long()
+        if ci == 1:
+            tg[0, 1] = tg[0, 0]  # repeated label
+            tg[0, 2] = tg[0, 0]
+        for b in range(B):
+            tg[b, tl[b]:] = 0
+        logits.requires_grad_(True)
+        loss = CtcLoss(CtcLossConfig())(logits, tg, il, tl)
+        loss.backward()
+        out[f"logits{ci}"] = logits.detach().numpy()
+        out[f"targets{ci}"] = tg.numpy()
+        out[f"in_len{ci}"] = il.numpy()
+        out[f"tgt_len{ci}"] = tl.numpy()
+        out[f"loss{ci}"] = loss.detach().numpy()
+        out[f"grad{ci}"] = logits.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "ctc_ref.npz"), **out)
+    print("ctc losses:", [float(out[f"loss{i}"]) for i in range(len(cases))])
+
+
+def gen_bestrq():
+    import torch
+    ref_import.install_stubs()
+    from model.ssl.best_rq import BestRQLayer, BestRQLayerConfig, MaskingStrategyConfig
+    out = {}
+    for ci, (basis, K, D, ncb, B, T) in enumerate([("cosine", 256, 16, 1, 3, 203),
+                                                   ("euclidean", 64, 8, 2, 2, 131),
+                                                   ("cosine", 8192, 16, 1, 2, 399)]):
+        torch.manual_seed(1234 + ci)
+        np.random.seed(99 + ci)
+        layer = BestRQLayer(BestRQLayerConfig(feat_dim=80, num_codebooks=ncb, codebook_dim=D,
+                                              codebook_size=K, label_basis=basis),
+                            MaskingStrategyConfig(mask_proportion=0.5, mean_span_length=1,
+                                                  span_select_type="static", seed=5))
+        raw = torch.randn(B, T, 80) * 3.0
+        aug = raw + 0.1 * torch.randn(B, T, 80)
+        length = torch.tensor([T] + [T - 17 * (i + 1) for i in range(B - 1)])
+        aug_in = aug.clone()
+        res = layer(raw.clone(), aug_in, length)
+        out[f"projector{ci}"] = layer._projector.detach().numpy()
+        for j in range(ncb):
+            out[f"codebook{ci}_{j}"] = layer._codebooks[j].detach().numpy()
+        out[f"raw{ci}"] = raw.numpy()
+        out[f"aug{ci}"] = aug.numpy()
+        out[f"length{ci}"] = length.numpy()
+        out[f"labels{ci}"] = res["labels"].numpy()
+        out[f"masked_dim{ci}"] = res["masked_dim"].numpy()
+        out[f"basis{ci}"] = np.array(basis)
+        # masked positions of feats (values are random noise; only positions are pinned)
+        out[f"changed{ci}"] = (res["masked_feats"] != aug).any(-1).numpy()
+    np.savez_compressed(os.path.join(OUT, "bestrq_ref.npz"), **out)
+    print("bestrq:", {k: v.shape for k, v in out.items() if k.startswith("labels")})
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    which = sys.argv[1:] or ["fbank", "ctc", "bestrq"]
+    for w in which:
+        globals()["gen_" + w]()
