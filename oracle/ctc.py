@@ -40,7 +40,7 @@ def ctc_loss(logits, targets, logits_length, targets_length, blank=0, reduction=
         for t in range(1, Tb):
             a = al[t - 1]
             b1 = np.concatenate([[-np.inf], a[:-1]])
-            b2 = np.where(skip, np.concatenate([[-np.inf, -np.inf], a[:-2]]), -np.inf)
+            b2 = np.where(skip, np.concatenate([[-np.inf, -np.inf], a])[:S], -np.inf)
             al[t] = np.logaddexp(np.logaddexp(a, b1), b2) + lp[b, t, ext]
         ll = np.logaddexp(al[Tb - 1, S - 1], al[Tb - 1, S - 2] if S > 1 else -np.inf)
         nll[b] = -ll
@@ -51,11 +51,11 @@ def ctc_loss(logits, targets, logits_length, targets_length, blank=0, reduction=
         if S > 1:
             be[Tb - 1, S - 2] = lp[b, Tb - 1, ext[S - 2]]
         skipf = np.zeros(S, dtype=bool)
-        skipf[:-2] = skip[2:]
+        skipf[:max(S - 2, 0)] = skip[2:]
         for t in range(Tb - 2, -1, -1):
             c = be[t + 1]
             c1 = np.concatenate([c[1:], [-np.inf]])
-            c2 = np.where(skipf, np.concatenate([c[2:], [-np.inf, -np.inf]]), -np.inf)
+            c2 = np.where(skipf, np.concatenate([c, [-np.inf, -np.inf]])[2:], -np.inf)
             be[t] = np.logaddexp(np.logaddexp(c, c1), c2) + lp[b, t, ext]
         gamma = np.exp(al + be - lp[b, :Tb][:, ext] + nll[b])        # (Tb,S)
         occ = np.zeros((Tb, V))

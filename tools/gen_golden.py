@@ -108,8 +108,75 @@ def gen_bestrq():
     print("bestrq:", {k: v.shape for k, v in out.items() if k.startswith("labels")})
 
 
+
+
+ZIP_TINY = dict(feature_dim=80, downsampling_factor=(1, 2, 4), num_encoder_layers=(1, 1, 1),
+                feedforward_dim=(64, 96, 96), encoder_dim=(32, 48, 48),
+                encoder_unmasked_dim=(24, 32, 32), num_heads=(4, 4, 4), query_head_dim=(8,),
+                value_head_dim=(4,), pos_head_dim=(4,), pos_dim=16, cnn_module_kernel=(7, 5, 5),
+                causal=True)
+
+
+def gen_zipformer():
+    """Tiny Zipformer2: eval forward, and a deterministic training step (random.random == 0:
+    every Balancer / Whiten / limit_param_value / attention-score penalty fires) with grads."""
+    import random
+    import torch
+    ref_import.install_stubs()
+    from model.encoder.zipformer import Zipformer2, Zipformer2Config
+    for tag, chunk, left in [("full", (-1,), (-1,)), ("chunk8", (8,), (16,))]:
+        torch.manual_seed(1234)
+        cfg = Zipformer2Config(**ZIP_TINY, chunk_size=chunk, left_context_frames=left)
+        m = Zipformer2(cfg)
+        # move parameters away from their special initial values so every term matters
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if n.endswith("bypass_scale"):
+                    p.uniform_(0.2, 0.9)
+                elif n.endswith("chunkwise_conv_scale"):
+                    p.normal_(0, 0.3)
+                elif n.endswith("downsample.bias") or n.endswith("downsample_output.bias"):
+                    p.normal_(0, 0.5)
+                elif n.endswith("log_scale"):
+                    p.fill_(0.7)
+                elif "out_proj" in n or "pointwise_conv2" in n or "linear_pos" in n:
+                    p.mul_(8.0)
+        g = torch.Generator().manual_seed(99)
+        x = torch.randn(3, 77, 80, generator=g) * 2.0
+        lens = torch.tensor([77, 60, 41])
+        out = {"x": x.numpy(), "lens": lens.numpy()}
+        for k, v in m.state_dict().items():
+            out["sd." + k] = v.numpy()
+        m.eval()
+        with torch.no_grad():
+            y, yl = m(x, lens)
+        out["eval_out"] = y.numpy()
+        out["eval_lens"] = yl.numpy()
+        # deterministic training step
+        m.train()
+        real_random = random.random
+        random.random = lambda: 0.0
+        try:
+            torch.manual_seed(7)
+            xt = x.clone().requires_grad_(True)
+            y, yl = m(xt, lens)
+            wts = torch.randn(y.shape, generator=torch.Generator().manual_seed(5))
+            loss = (y * wts).sum()
+            loss.backward()
+        finally:
+            random.random = real_random
+        out["train_out"] = y.detach().numpy()
+        out["train_wts"] = wts.numpy()
+        out["train_loss"] = loss.detach().numpy()
+        out["grad.x"] = xt.grad.numpy()
+        for n, p in m.named_parameters():
+            out["grad." + n] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
+        np.savez_compressed(os.path.join(OUT, f"zipformer_tiny_{tag}.npz"), **out)
+        print("zipformer", tag, y.shape, float(loss))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["fbank", "ctc", "bestrq"]
+    which = sys.argv[1:] or ["fbank", "ctc", "bestrq", "zipformer"]
     for w in which:
         globals()["gen_" + w]()
