@@ -81,6 +81,23 @@ int s2t_rnnt_lattice_bwd(const float* logits, const long* ranges, const long* sy
                          const float* gscale, int B, int S, int T, int V, int R, int blank,
                          float* d_logits, void* stream);
 
+
+/* ---- zipformer streaming ops (model/layer/scaling.py: Swoosh :1340-1509, BiasNorm
+ * :347-476, Balancer backward :741-789 in closed form). */
+int s2t_swoosh_fwd(const float* x, float* y, long n, float offset, float constant, void* stream);
+int s2t_swoosh_bwd(const float* x, const float* g, float* d, long n, float offset, void* stream);
+int s2t_biasnorm_fwd(const float* x, const float* bias, const float* log_scale, long rows, int D,
+                     float* y, float* scales, void* stream);
+int s2t_biasnorm_bwd(const float* x, const float* bias, const float* scales, const float* g,
+                     long rows, int D, float* dx, float* dbias, float* dls, void* stream);
+int s2t_col_stats(const float* x, long rows, int C, long ld, float* sum, float* sumsq,
+                  void* stream);
+int s2t_balancer_coef(const float* sum, const float* sumsq, float n, int C, float min_mean,
+                      float max_mean, float min_rms, float max_rms, float grad_scale, float* a,
+                      float* b, void* stream);
+int s2t_balancer_apply(const float* x, long ldx, const float* g, long ldg, const float* a,
+                       const float* b, long rows, int C, float* out, long ldo, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,6 +70,15 @@ def ptr(t, dtype=None):
     return ctypes.c_void_p(t.data_ptr())
 
 
+def raw(t, dtype=None):
+    """Device pointer of a (possibly row-strided) tensor; the caller passes the strides."""
+    if not t.is_cuda:
+        raise RuntimeError("s2t kernels need device tensors (no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"expected {dtype}, got {t.dtype}")
+    return ctypes.c_void_p(t.data_ptr())
+
+
 def fp(t):
     return ptr(t, torch.float32)
 

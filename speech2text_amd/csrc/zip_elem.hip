@@ -1,0 +1,315 @@
+// Streaming (HBM-bound) zipformer kernels for gfx950: Swoosh activations, BiasNorm,
+// Balancer statistics / gradient update.  All are one-read one-write passes with
+// 16-byte per-lane accesses where the layout allows; reductions use 64-lane waves.
+//
+// Reference semantics: model/layer/scaling.py:1340-1343,1418-1423 (SwooshL/R),
+// :347-399 (BiasNormFunction), :741-789 (BalancerFunction.backward, closed form
+// derived in DESIGN.md), :1559-1578 (activation derivative recomputed in backward).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float swoosh_f(float x, float off, float c) {
+  const float z = x - off;
+  // log(1+exp(z)) = max(z,0) + log1p(exp(-|z|))
+  return fmaxf(z, 0.f) + log1pf(__expf(-fabsf(z))) - 0.08f * x - c;
+}
+__device__ __forceinline__ float swoosh_d(float x, float off) {
+  return 1.f / (1.f + __expf(off - x)) - 0.08f;
+}
+
+__global__ __launch_bounds__(256) void swoosh_fwd_kernel(const float* __restrict__ x,
+                                                         float* __restrict__ y, long n, float off,
+                                                         float c) {
+  const long n4 = n >> 2;
+  const long stride = (long)gridDim.x * blockDim.x;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  float4* y4 = reinterpret_cast<float4*>(y);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 v = x4[i];
+    v.x = swoosh_f(v.x, off, c);
+    v.y = swoosh_f(v.y, off, c);
+    v.z = swoosh_f(v.z, off, c);
+    v.w = swoosh_f(v.w, off, c);
+    y4[i] = v;
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    y[i] = swoosh_f(x[i], off, c);
+}
+
+__global__ __launch_bounds__(256) void swoosh_bwd_kernel(const float* __restrict__ x,
+                                                         const float* __restrict__ g,
+                                                         float* __restrict__ d, long n,
+                                                         float off) {
+  const long n4 = n >> 2;
+  const long stride = (long)gridDim.x * blockDim.x;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  float4* d4 = reinterpret_cast<float4*>(d);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 v = x4[i], gg = g4[i];
+    float4 o;
+    o.x = gg.x * swoosh_d(v.x, off);
+    o.y = gg.y * swoosh_d(v.y, off);
+    o.z = gg.z * swoosh_d(v.z, off);
+    o.w = gg.w * swoosh_d(v.w, off);
+    d4[i] = o;
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    d[i] = g[i] * swoosh_d(x[i], off);
+}
+
+// ---------------------------------------------------------------- BiasNorm
+// one wave per row of D channels; scales[row] = exp(ls) * mean((x-b)^2)^-0.5
+__global__ __launch_bounds__(256) void biasnorm_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ ls,
+    long rows, int D, float* __restrict__ y, float* __restrict__ scales) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + row * D;
+  float acc = 0.f;
+  for (int c = lane; c < D; c += 64) {
+    const float d = xr[c] - bias[c];
+    acc = fmaf(d, d, acc);
+  }
+  acc = wave_sum(acc);
+  const float s = rsqrtf(acc / D) * expf(ls[0]);
+  if (lane == 0) scales[row] = s;
+  float* yr = y + row * D;
+  for (int c = lane; c < D; c += 64) yr[c] = xr[c] * s;
+}
+
+// dx = s*g - s*(x-b)*A/(D*ms), A = sum_j g_j x_j, ms = mean((x-b)^2)
+// dbias += s*(x-b)*A/(D*ms) ; dls += A*s.   Persistent blocks keep per-column partial
+// sums in registers over all their rows, then one atomic per column per block.
+template <int CPL>  // columns per lane: D <= 64*CPL
+__global__ __launch_bounds__(256) void biasnorm_bwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ scales,
+    const float* __restrict__ g, long rows, int D, float* __restrict__ dx,
+    float* __restrict__ dbias, float* __restrict__ dls) {
+  const int lane = threadIdx.x & 63;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long nwaves = (long)gridDim.x * 4;
+  float b[CPL], db[CPL];
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) {
+    const int c = lane + 64 * j;
+    b[j] = c < D ? bias[c] : 0.f;
+    db[j] = 0.f;
+  }
+  float dl = 0.f;
+  for (long row = wave; row < rows; row += nwaves) {
+    const float* xr = x + row * D;
+    const float* gr = g + row * D;
+    float xv[CPL], gv[CPL];
+    float A = 0.f, ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const int c = lane + 64 * j;
+      xv[j] = c < D ? xr[c] : 0.f;
+      gv[j] = c < D ? gr[c] : 0.f;
+      A = fmaf(gv[j], xv[j], A);
+      const float d = c < D ? xv[j] - b[j] : 0.f;
+      ss = fmaf(d, d, ss);
+    }
+    A = wave_sum(A);
+    ss = wave_sum(ss);
+    const float s = scales[row];
+    const float coef = s * A / ss;  // ss = D*ms
+    dl += A * s;
+    float* dr = dx + row * D;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const int c = lane + 64 * j;
+      if (c < D) {
+        const float t = coef * (xv[j] - b[j]);
+        dr[c] = s * gv[j] - t;
+        db[j] += t;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) {
+    const int c = lane + 64 * j;
+    if (c < D && db[j] != 0.f) atomicAdd(&dbias[c], db[j]);
+  }
+  if (lane == 0 && dl != 0.f) atomicAdd(dls, dl);
+}
+
+// ---------------------------------------------------------------- column statistics
+// x viewed as [rows][ld] with C used columns: sum[c] += x, sumsq[c] += x^2 (atomics once per
+// block).  Each thread owns column (threadIdx.x % cols_per_pass) and strides over rows.
+__global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict__ x, long rows,
+                                                        int C, long ld, float* __restrict__ sum,
+                                                        float* __restrict__ sumsq) {
+  // blockDim = (64, 4): x-dim over columns (coalesced), y-dim over rows
+  for (int c0 = blockIdx.y * 64; c0 < C; c0 += gridDim.y * 64) {
+    const int c = c0 + threadIdx.x;
+    float s = 0.f, q = 0.f;
+    if (c < C) {
+      for (long r = (long)blockIdx.x * 4 + threadIdx.y; r < rows; r += (long)gridDim.x * 4) {
+        const float v = x[r * ld + c];
+        s += v;
+        q = fmaf(v, v, q);
+      }
+    }
+    __shared__ float sh[2][4][64];
+    sh[0][threadIdx.y][threadIdx.x] = s;
+    sh[1][threadIdx.y][threadIdx.x] = q;
+    __syncthreads();
+    if (threadIdx.y == 0 && c < C) {
+      s = sh[0][0][threadIdx.x] + sh[0][1][threadIdx.x] + sh[0][2][threadIdx.x] +
+          sh[0][3][threadIdx.x];
+      q = sh[1][0][threadIdx.x] + sh[1][1][threadIdx.x] + sh[1][2][threadIdx.x] +
+          sh[1][3][threadIdx.x];
+      atomicAdd(&sum[c], s);
+      atomicAdd(&sumsq[c], q);
+    }
+    __syncthreads();
+  }
+}
+
+// g_out[r][c] = g + |g| * (a[c] + b[c]*x)   (in-place allowed: g_out == g)
+__global__ __launch_bounds__(256) void balancer_apply_kernel(
+    const float* __restrict__ x, long ldx, const float* __restrict__ g, long ldg,
+    const float* __restrict__ a, const float* __restrict__ b, long rows, int C,
+    float* __restrict__ out, long ldo) {
+  const long total = rows * C;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long r = i / C;
+    const int c = (int)(i - r * C);
+    const float gv = g[r * ldg + c];
+    out[r * ldo + c] = gv + fabsf(gv) * fmaf(b[c], x[r * ldx + c], a[c]);
+  }
+}
+
+
+// per-channel coefficients of the Balancer gradient term from (sum, sumsq) over n rows:
+//   a' = coef*a, b' = coef*b with loss_grad = a + b*x  (see zip_kernels.balancer_backward)
+__global__ void balancer_coef_kernel(const float* __restrict__ sum, const float* __restrict__ sumsq,
+                                     float n, int C, float min_mean, float max_mean, float min_rms,
+                                     float max_rms, float grad_scale, float* __restrict__ a_out,
+                                     float* __restrict__ b_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float inv_n = 1.f / n;
+  const float mean = sum[c] * inv_n, uvar = sumsq[c] * inv_n;
+  const float raw_var = uvar - mean * mean;
+  const bool live_v = raw_var > 1.0e-20f, live_r = uvar > 1.0e-20f;
+  const float var = fmaxf(raw_var, 1.0e-20f);
+  const float sd = sqrtf(var);
+  const float rms = sqrtf(fmaxf(uvar, 1.0e-20f));
+  const float m = mean / sd;
+  const float mc = fminf(fmaxf(m, min_mean), max_mean);
+  const float s_m = (m > mc) ? 1.f : ((m < mc) ? -1.f : 0.f);
+  const float rc = fminf(fmaxf(rms, min_rms), max_rms);
+  const float lq = logf(rc / rms);
+  const float s_r = (lq > 0.f) ? -1.f : ((lq < 0.f) ? 1.f : 0.f);
+  float a = s_m * inv_n * (live_v ? (1.f / sd + mean * mean / (sd * var)) : 1.f / sd);
+  float b = (live_v ? -s_m * inv_n * mean / (sd * var) : 0.f) +
+            (live_r ? s_r * inv_n / (rms * rms) : 0.f);
+  const float lg_rms = fmaxf(sqrtf(fmaxf(a * a + 2.f * a * b * mean + b * b * uvar, 0.f)), 1.0e-20f);
+  const float coef = grad_scale / lg_rms;
+  a_out[c] = a * coef;
+  b_out[c] = b * coef;
+}
+
+inline unsigned grid_for(long n, int per_block) {
+  long b = (n + per_block - 1) / per_block;
+  if (b > 256 * 16) b = 256 * 16;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int s2t_swoosh_fwd(const float* x, float* y, long n, float offset, float constant,
+                              void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(swoosh_fwd_kernel, dim3(grid_for(n, 1024)), dim3(256), 0,
+                     (hipStream_t)stream, x, y, n, offset, constant);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int s2t_swoosh_bwd(const float* x, const float* g, float* d, long n, float offset,
+                              void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(swoosh_bwd_kernel, dim3(grid_for(n, 1024)), dim3(256), 0,
+                     (hipStream_t)stream, x, g, d, n, offset);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int s2t_biasnorm_fwd(const float* x, const float* bias, const float* log_scale,
+                                long rows, int D, float* y, float* scales, void* stream) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(biasnorm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                     (hipStream_t)stream, x, bias, log_scale, rows, D, y, scales);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int s2t_biasnorm_bwd(const float* x, const float* bias, const float* scales,
+                                const float* g, long rows, int D, float* dx, float* dbias,
+                                float* dls, void* stream) {
+  if (rows <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned nb = grid_for(rows, 4 * 8);
+  if (D <= 64)
+    hipLaunchKernelGGL(biasnorm_bwd_kernel<1>, dim3(nb), dim3(256), 0, st, x, bias, scales, g,
+                       rows, D, dx, dbias, dls);
+  else if (D <= 128)
+    hipLaunchKernelGGL(biasnorm_bwd_kernel<2>, dim3(nb), dim3(256), 0, st, x, bias, scales, g,
+                       rows, D, dx, dbias, dls);
+  else if (D <= 256)
+    hipLaunchKernelGGL(biasnorm_bwd_kernel<4>, dim3(nb), dim3(256), 0, st, x, bias, scales, g,
+                       rows, D, dx, dbias, dls);
+  else if (D <= 512)
+    hipLaunchKernelGGL(biasnorm_bwd_kernel<8>, dim3(nb), dim3(256), 0, st, x, bias, scales, g,
+                       rows, D, dx, dbias, dls);
+  else if (D <= 1024)
+    hipLaunchKernelGGL(biasnorm_bwd_kernel<16>, dim3(nb), dim3(256), 0, st, x, bias, scales, g,
+                       rows, D, dx, dbias, dls);
+  else
+    return -1;
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int s2t_col_stats(const float* x, long rows, int C, long ld, float* sum, float* sumsq,
+                             void* stream) {
+  if (rows <= 0 || C <= 0) return 0;
+  int gy = (C + 63) / 64;
+  if (gy > 16) gy = 16;
+  long gx = (rows + 4 * 16 - 1) / (4 * 16);
+  if (gx > 1024) gx = 1024;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(col_stats_kernel, dim3((unsigned)gx, gy), dim3(64, 4), 0,
+                     (hipStream_t)stream, x, rows, C, ld, sum, sumsq);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int s2t_balancer_apply(const float* x, long ldx, const float* g, long ldg,
+                                  const float* a, const float* b, long rows, int C, float* out,
+                                  long ldo, void* stream) {
+  if (rows <= 0 || C <= 0) return 0;
+  hipLaunchKernelGGL(balancer_apply_kernel, dim3(grid_for(rows * C, 1024)), dim3(256), 0,
+                     (hipStream_t)stream, x, ldx, g, ldg, a, b, rows, C, out, ldo);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int s2t_balancer_coef(const float* sum, const float* sumsq, float n, int C,
+                                 float min_mean, float max_mean, float min_rms, float max_rms,
+                                 float grad_scale, float* a, float* b, void* stream) {
+  if (C <= 0) return 0;
+  hipLaunchKernelGGL(balancer_coef_kernel, dim3((C + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, sum, sumsq, n, C, min_mean, max_mean, min_rms, max_rms,
+                     grad_scale, a, b);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,98 @@
+"""Zipformer frontend: Conv2dSubsampling + ConvNeXt (mirror of the reference's
+model/layer/subsampling.py; same parameter names, T' = (T-7)//2)."""
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from speech2text_amd.model.layer.scaling import (Balancer, BiasNorm, Dropout3, FloatLike,
+                                                 ScaledConv2d, ScaleGrad, ScheduledFloat, SwooshL,
+                                                 SwooshR, Whiten)
+
+
+class ConvNeXt(nn.Module):
+    """depthwise 7x7 -> pointwise (x3) -> SwooshL -> pointwise, plus bypass (reference :26-132)."""
+
+    def __init__(self, channels: int, hidden_ratio: int = 3, kernel_size: Tuple[int, int] = (7, 7),
+                 layerdrop_rate: FloatLike = None):
+        super().__init__()
+        self.padding = ((kernel_size[0] - 1) // 2, (kernel_size[1] - 1) // 2)
+        hidden = channels * hidden_ratio
+        if layerdrop_rate is None:
+            layerdrop_rate = ScheduledFloat((0.0, 0.2), (20000.0, 0.015))
+        self.layerdrop_rate = layerdrop_rate
+        self.depthwise_conv = nn.Conv2d(channels, channels, groups=channels,
+                                        kernel_size=kernel_size, padding=self.padding)
+        self.pointwise_conv1 = nn.Conv2d(channels, hidden, kernel_size=1)
+        self.hidden_balancer = Balancer(hidden, channel_dim=1, min_positive=0.3, max_positive=1.0,
+                                        min_abs=0.75, max_abs=5.0)
+        self.activation = SwooshL()
+        self.pointwise_conv2 = ScaledConv2d(hidden, channels, kernel_size=1, initial_scale=0.01)
+        self.out_balancer = Balancer(channels, channel_dim=1, min_positive=0.4, max_positive=0.6,
+                                     min_abs=1.0, max_abs=6.0)
+        self.out_whiten = Whiten(num_groups=1, whitening_limit=5.0, prob=(0.025, 0.25),
+                                 grad_scale=0.01)
+
+    def forward(self, x: Tensor) -> Tensor:
+        mask = None
+        if self.training:
+            rate = float(self.layerdrop_rate)
+            if rate != 0.0:
+                mask = torch.rand((x.shape[0], 1, 1, 1), dtype=x.dtype, device=x.device) > rate
+        bypass = x
+        x = self.depthwise_conv(x)
+        x = self.pointwise_conv1(x)
+        x = self.hidden_balancer(x)
+        x = self.activation(x)
+        x = self.pointwise_conv2(x)
+        if mask is not None:
+            x = x * mask
+        x = bypass + x
+        x = self.out_balancer(x)
+        if x.requires_grad:
+            x = self.out_whiten(x.transpose(1, 3)).transpose(1, 3)
+        return x
+
+
+class Conv2dSubsampling(nn.Module):
+    """(N,T,idim) -> (N,(T-7)//2,odim)   (reference :181-319)."""
+
+    def __init__(self, in_channels: int, out_channels: int, layer1_channels: int = 8,
+                 layer2_channels: int = 32, layer3_channels: int = 128,
+                 dropout: FloatLike = 0.1) -> None:
+        assert in_channels >= 7
+        super().__init__()
+        self.conv = nn.Sequential(
+            nn.Conv2d(1, layer1_channels, kernel_size=3, padding=(0, 1)),
+            ScaleGrad(0.2),
+            Balancer(layer1_channels, channel_dim=1, max_abs=1.0),
+            SwooshR(),
+            nn.Conv2d(layer1_channels, layer2_channels, kernel_size=3, stride=2, padding=0),
+            Balancer(layer2_channels, channel_dim=1, max_abs=4.0),
+            SwooshR(),
+            nn.Conv2d(layer2_channels, layer3_channels, kernel_size=3, stride=(1, 2)),
+            Balancer(layer3_channels, channel_dim=1, max_abs=4.0),
+            SwooshR(),
+        )
+        self.convnext = ConvNeXt(layer3_channels, kernel_size=(7, 7))
+        self.out_width = (((in_channels - 1) // 2) - 1) // 2
+        self.layer3_channels = layer3_channels
+        self.out = nn.Linear(self.out_width * layer3_channels, out_channels)
+        self.out_whiten = Whiten(num_groups=1,
+                                 whitening_limit=ScheduledFloat((0.0, 4.0), (20000.0, 8.0),
+                                                                default=4.0),
+                                 prob=(0.025, 0.25), grad_scale=0.02)
+        self.out_norm = BiasNorm(out_channels)
+        self.dropout = Dropout3(dropout, shared_dim=1)
+
+    def forward(self, x: Tensor, x_lens: Tensor) -> Tuple[Tensor, Tensor]:
+        x = self.conv(x.unsqueeze(1))
+        x = self.convnext(x)
+        b, c, t, f = x.size()
+        x = x.transpose(1, 2).reshape(b, t, c * f)
+        x = self.out(x)
+        x = self.out_whiten(x)
+        x = self.out_norm(x)
+        x = self.dropout(x)
+        x_lens = (x_lens - 7) // 2
+        return x, x_lens

@@ -1,0 +1,318 @@
+"""Zipformer hot-op entry points used by speech2text_amd.model.* (the seam to the HIP ABI).
+
+Each function is the single place a given fused op is launched from.  Ops are moved from
+torch-op compositions (rocBLAS GEMMs + elementwise) to hand-written gfx950 kernels one at a
+time; see DESIGN.md for the status table of each.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import _native as N
+
+_SW = {True: (4.0, 0.035), False: (1.0, 0.313261687)}   # SwooshL / SwooshR (offset, constant)
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("speech2text_amd zipformer kernels run on the GPU only "
+                               "(no CPU fallback); got a CPU tensor")
+
+
+def _c16(t):
+    """contiguous + 16-byte aligned (the streaming kernels use 16-byte lane accesses)."""
+    t = t.contiguous()
+    if t.data_ptr() % 16:
+        t = t.clone()
+    return t
+
+
+# ------------------------------------------------------------------ swoosh
+class _Swoosh(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, is_l):
+        ctx.save_for_backward(x)
+        ctx.is_l = is_l
+        return swoosh_forward(x, is_l)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return swoosh_backward(x, g, ctx.is_l), None
+
+
+def swoosh_forward(x, is_l):
+    """log(1+exp(x-off)) - 0.08x - c   (HIP: zip_elem.hip swoosh_fwd_kernel)"""
+    _dev(x)
+    off, c = _SW[is_l]
+    x = _c16(x.float())
+    y = torch.empty_like(x)
+    N.check(N.lib().s2t_swoosh_fwd(N.fp(x), N.fp(y), x.numel(), off, c, N.stream()), "swoosh")
+    return y
+
+
+def swoosh_backward(x, g, is_l, mask=None):
+    """g * (sigmoid(x - off) - 0.08) [* mask]   (HIP: swoosh_bwd_kernel)"""
+    _dev(x, g)
+    off, _ = _SW[is_l]
+    x = _c16(x.float())
+    g = _c16(g.float())
+    d = torch.empty_like(x)
+    N.check(N.lib().s2t_swoosh_bwd(N.fp(x), N.fp(g), N.fp(d), x.numel(), off, N.stream()),
+            "swoosh_bwd")
+    return d if mask is None else d * mask
+
+
+def swoosh(x, is_l):
+    return _Swoosh.apply(x, is_l)
+
+
+class _SwooshLinear(torch.autograd.Function):
+    """y = linear(swoosh(x) [* mask], W, b); only x is saved (activation recomputed), GEMMs
+    are plain rocBLAS/hipBLASLt calls."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, is_l, mask):
+        ctx.save_for_backward(x, weight, mask)
+        ctx.is_l = is_l
+        ctx.has_bias = bias is not None
+        h = swoosh_forward(x, is_l)
+        if mask is not None:
+            h = h * mask
+        return F.linear(h, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, mask = ctx.saved_tensors
+        h = swoosh_forward(x, ctx.is_l)
+        if mask is not None:
+            h = h * mask
+        g2 = g.reshape(-1, g.shape[-1])
+        dw = g2.t().mm(h.reshape(-1, h.shape[-1]))
+        db = g2.sum(dim=0) if ctx.has_bias else None
+        dh = g.matmul(weight)
+        dx = swoosh_backward(x, dh, ctx.is_l, mask)
+        return dx, dw, db, None, None
+
+
+def swoosh_linear(x, weight, bias, is_l, mask=None):
+    return _SwooshLinear.apply(x, weight, bias, is_l, mask)
+
+
+# ------------------------------------------------------------------ BiasNorm
+class _BiasNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bias, log_scale):
+        _dev(x, bias, log_scale)
+        D = x.shape[-1]
+        x = x.contiguous().float()
+        rows = x.numel() // D
+        y = torch.empty_like(x)
+        scales = torch.empty(rows, dtype=torch.float32, device=x.device)
+        bias = bias.contiguous().float()
+        N.check(N.lib().s2t_biasnorm_fwd(N.fp(x), N.fp(bias),
+                                         N.fp(log_scale.reshape(1).contiguous().float()), rows, D,
+                                         N.fp(y), N.fp(scales), N.stream()), "biasnorm_fwd")
+        ctx.save_for_backward(x, bias, scales)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, bias, scales = ctx.saved_tensors
+        D = x.shape[-1]
+        g = g.contiguous().float()
+        rows = x.numel() // D
+        dx = torch.empty_like(x)
+        acc = torch.zeros(D + 1, dtype=torch.float32, device=x.device)
+        N.check(N.lib().s2t_biasnorm_bwd(N.fp(x), N.fp(bias), N.fp(scales), N.fp(g), rows, D,
+                                         N.fp(dx), N.fp(acc), ctypes_off(acc, D), N.stream()),
+                "biasnorm_bwd")
+        return dx, acc[:D], acc[D].reshape(())
+
+
+def ctypes_off(t, n_elems):
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr() + 4 * n_elems)
+
+
+def bias_norm(x, bias, log_scale):
+    return _BiasNorm.apply(x, bias, log_scale)
+
+
+# ------------------------------------------------------------------ Balancer / Whiten backward
+def balancer_backward(x, g, min_mean, max_mean, min_rms, max_rms, grad_scale, channel_dim):
+    """Closed form of reference scaling.py:741-789: the autograd-inside-backward there reduces
+    to per-channel statistics (mean, E[x^2]) and a per-element affine term
+        g' = g + |g| * grad_scale * (a_c + b_c x) / rms_c(a + b x).
+    Channel-last tensors (the zipformer layers) run three HIP kernels: column statistics,
+    coefficient kernel, fused update.  Other layouts (NCHW frontend) use the same formulas as
+    torch reductions."""
+    _dev(x, g)
+    nd = x.ndim
+    if channel_dim == nd - 1 and x.dim() >= 2 and x.stride(-1) == 1 and g.dtype == torch.float32 \
+            and x.dtype == torch.float32:
+        C = x.shape[-1]
+        x2 = x.reshape(-1, C) if x.is_contiguous() else None
+        if x2 is None:
+            # row-strided 2-D slice of a wider contiguous tensor (e.g. the gate half of in_proj)
+            xs = x.flatten(0, -2) if x.dim() > 2 else x
+            if xs.stride(-1) != 1:
+                xs = x.contiguous().reshape(-1, C)
+            x2 = xs
+        g2 = g.contiguous().reshape(-1, C)
+        rows = x2.shape[0]
+        L = N.lib()
+        st = N.stream()
+        stats = torch.zeros(2, C, dtype=torch.float32, device=x.device)
+        coef = torch.empty(2, C, dtype=torch.float32, device=x.device)
+        out = torch.empty_like(g2)
+        N.check(L.s2t_col_stats(N.raw(x2, torch.float32), rows, C, x2.stride(0),
+                                N.fp(stats), ctypes_off(stats, C), st), "col_stats")
+        N.check(L.s2t_balancer_coef(N.fp(stats), ctypes_off(stats, C), float(rows), C, min_mean,
+                                    max_mean, min_rms, max_rms, grad_scale, N.fp(coef),
+                                    ctypes_off(coef, C), st), "balancer_coef")
+        N.check(L.s2t_balancer_apply(N.raw(x2, torch.float32), x2.stride(0), N.fp(g2), C,
+                                     N.fp(coef), ctypes_off(coef, C), rows, C, N.fp(out), C, st),
+                "balancer_apply")
+        return out.reshape(g.shape)
+    dims = [i for i in range(nd) if i != channel_dim]
+    xf = x.float()
+    n = xf.numel() // xf.shape[channel_dim]
+    mean = xf.mean(dim=dims, keepdim=True)
+    uvar = (xf * xf).mean(dim=dims, keepdim=True)
+    var = (uvar - mean * mean).clamp(min=1.0e-20)
+    std = var.sqrt()
+    rms = uvar.clamp(min=1.0e-20).sqrt()
+    m = mean / std
+    mc = m.clamp(min=min_mean, max=max_mean)
+    s_m = torch.sign(m - mc)
+    rc = rms.clamp(min=min_rms, max=max_rms)
+    s_r = -torch.sign((rc / rms).log())
+    # where the clamps on var/uvar were active the reference's autograd sees constants
+    live_v = (uvar - mean * mean) > 1.0e-20
+    live_r = uvar > 1.0e-20
+    inv_n = 1.0 / n
+    a = s_m * inv_n * torch.where(live_v, 1.0 / std + mean * mean / (std * var), 1.0 / std)
+    b = torch.where(live_v, -s_m * inv_n * mean / (std * var), torch.zeros_like(mean)) + \
+        torch.where(live_r, s_r * inv_n / (rms * rms), torch.zeros_like(rms))
+    lg_rms = (a * a + 2 * a * b * mean + b * b * uvar).clamp(min=0).sqrt().clamp(min=1.0e-20)
+    coef = grad_scale / lg_rms
+    gf = g.float()
+    return (gf + gf.abs() * ((a * coef) + (b * coef) * xf)).to(g.dtype)
+
+
+def whiten_backward(x, g, num_groups, limit, grad_scale):
+    """Closed form of reference scaling.py:949-1028.  Returns (grad, penalty_was_active)."""
+    shp = x.shape
+    C = shp[-1]
+    xf = x.reshape(-1, C).float()
+    nfr = xf.shape[0]
+    cg = C // num_groups
+    xg = xf.reshape(nfr, num_groups, cg).transpose(0, 1)            # (G,N,cg)
+    xc = xg - xg.mean(dim=1, keepdim=True)
+    cov = torch.matmul(xc.transpose(1, 2), xc)                      # (G,cg,cg)
+    md = torch.diagonal(cov, dim1=1, dim2=2).mean()
+    covsq = (cov * cov).sum() / (num_groups * cg)
+    denom = md * md + 1.0e-20
+    metric = covsq / denom
+    if not bool(metric >= limit):      # one scalar read-back, as the reference does
+        return g, False
+    eye = torch.eye(cg, device=x.device, dtype=torch.float32)
+    dcov = (2.0 / (num_groups * cg)) * (cov / denom - (covsq * md / (denom * denom)) * eye)
+    dxc = 2.0 * torch.matmul(xc, dcov)
+    dx = dxc - dxc.mean(dim=1, keepdim=True)
+    pg = dx.transpose(0, 1).reshape(shp)
+    scale = grad_scale * (g.float().norm() / (pg.norm() + 1.0e-20))
+    return g + (pg * scale).to(g.dtype), True
+
+
+# ------------------------------------------------------------------ conv module core
+def glu_chunk_causal_dwconv(x, s, key_padding_mask, conv, chunk_size):
+    """x (T,B,C) [, s (T,B,C) gate pre-activation] -> depthwise chunk-causal conv of
+    (x * sigmoid(s)) with padded frames zeroed, output (T,B,C).
+    conv: module holding causal_conv / chunkwise_conv / chunkwise_conv_scale (or nn.Conv1d).
+    torch-op composition (MIOpen depthwise conv); HIP kernel: see DESIGN.md status table."""
+    if s is not None:
+        x = x * torch.sigmoid(s)
+    x = x.permute(1, 2, 0)                                           # (B,C,T)
+    if key_padding_mask is not None:
+        x = x.masked_fill(key_padding_mask.unsqueeze(1).expand_as(x), 0.0)
+    if isinstance(conv, torch.nn.Conv1d):
+        return conv(x).permute(2, 0, 1)
+    B, C, T = x.shape
+    K = conv.kernel_size
+    left = K // 2
+    if chunk_size < 0 or chunk_size > T:
+        chunk_size = T
+    right = -T % chunk_size
+    xp = F.pad(x, (left, right))
+    y_c = F.conv1d(xp[..., :left + T], conv.causal_conv.weight, conv.causal_conv.bias, groups=C)
+    xc = xp[..., left:]
+    nch = xc.shape[2] // chunk_size
+    xc = xc.reshape(B, C, nch, chunk_size).permute(0, 2, 1, 3).reshape(B * nch, C, chunk_size)
+    xc = F.conv1d(xc, conv.chunkwise_conv.weight, conv.chunkwise_conv.bias, padding=K // 2,
+                  groups=C)
+    le, re = conv.chunkwise_conv_scale[0], conv.chunkwise_conv_scale[1]
+    if chunk_size < K:
+        le, re = le[:, :chunk_size], re[:, -chunk_size:]
+    else:
+        z = torch.zeros(C, chunk_size - K, device=x.device, dtype=x.dtype)
+        le, re = torch.cat((le, z), -1), torch.cat((z, re), -1)
+    xc = xc * (1.0 + (le + re))
+    xc = xc.reshape(B, nch, C, chunk_size).permute(0, 2, 1, 3).reshape(B, C, nch * chunk_size)
+    return (xc[..., :T] + y_c).permute(2, 0, 1)
+
+
+# ------------------------------------------------------------------ attention
+def relpos_attention_weights(qkp, pos_proj, num_heads, query_head_dim, pos_head_dim, attn_mask,
+                             key_padding_mask, penalize=None):
+    """qkp (T,B,H*(2*qd+pd)) = in_proj(x); pos_proj (2T-1, H*pd) = linear_pos(pos_emb) or None
+    -> softmax weights (H,B,T,T).  scores[h,b,i,j] = q_i.k_j + p_i.pos[(T-1)-i+j]; masked
+    entries are set to -1000 (reference zipformer.py:1966-2066)."""
+    T, B, _ = qkp.shape
+    H, qd, pd = num_heads, query_head_dim, pos_head_dim
+    q = qkp[..., :H * qd].reshape(T, B, H, qd).permute(2, 1, 0, 3)
+    k = qkp[..., H * qd:2 * H * qd].reshape(T, B, H, qd).permute(2, 1, 3, 0)
+    p = qkp[..., 2 * H * qd:].reshape(T, B, H, pd).permute(2, 1, 0, 3)
+    scores = torch.matmul(q, k)
+    if pos_proj is not None:
+        pe = pos_proj.reshape(1, 2 * T - 1, H, pd).permute(2, 0, 3, 1)
+        ps = torch.matmul(p, pe)
+        ps = ps.as_strided((H, B, T, T), (ps.stride(0), ps.stride(1), ps.stride(2) - ps.stride(3),
+                                          ps.stride(3)), storage_offset=ps.stride(3) * (T - 1))
+        scores = scores + ps
+    if penalize is not None:
+        scores = penalize(scores)
+    if attn_mask is not None:
+        scores = scores.masked_fill(attn_mask, -1000)
+    if key_padding_mask is not None:
+        scores = scores.masked_fill(key_padding_mask.unsqueeze(1), -1000)
+    return scores.softmax(dim=-1)
+
+
+def attention_apply(weights, v, num_heads):
+    """weights (H,B,T,T), v (T,B,H*dv) -> (T,B,H*dv)"""
+    T, B, _ = v.shape
+    x = v.reshape(T, B, num_heads, -1).permute(2, 1, 0, 3)
+    x = torch.matmul(weights, x)
+    return x.permute(2, 1, 0, 3).reshape(T, B, -1)
+
+
+# ------------------------------------------------------------------ misc streaming ops
+def bypass_combine(src_orig, src, scale):
+    return src_orig + (src - src_orig) * scale
+
+
+def simple_downsample(src, bias, ds):
+    T, B, C = src.shape
+    dT = (T + ds - 1) // ds
+    pad = dT * ds - T
+    if pad:
+        src = torch.cat((src, src[T - 1:].expand(pad, B, C)), dim=0)
+    w = bias.softmax(dim=0).reshape(1, ds, 1, 1)
+    return (src.reshape(dT, ds, B, C) * w).sum(dim=1)
+
+
+def simple_upsample(src, up, out_len):
+    T, B, C = src.shape
+    return src.unsqueeze(1).expand(T, up, B, C).reshape(T * up, B, C)[:out_len]
