@@ -37,6 +37,42 @@ def parse_header(path=HEADER_PATH):
     return protos
 
 
+class _Prof:
+    target = None        # C entry point being timed (HIP events on the launch stream)
+    events = []
+    algo_bytes = 0.0
+    algo_flops = 0.0
+
+
+class _LibProxy:
+    """Attribute access returns the ctypes function, wrapped so that launches of the entry
+    point selected by profile_begin() are bracketed by HIP events on the current stream."""
+
+    def __init__(self, cdll):
+        self._cdll = cdll
+        self._fns = {}
+
+    def __getattr__(self, name):
+        fn = self._fns.get(name)
+        if fn is None:
+            raw = getattr(self._cdll, name)
+
+            def call(*args, _raw=raw, _name=name):
+                if _Prof.target != _name:
+                    return _raw(*args)
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = _raw(*args)
+                e1.record()
+                _Prof.events.append((e0, e1))
+                return rc
+
+            fn = call
+            self._fns[name] = fn
+        return fn
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -49,8 +85,35 @@ def lib():
             fn = getattr(l, name)  # AttributeError if the library lacks a declared symbol
             fn.restype = ret
             fn.argtypes = ats
-        _lib = l
+        _lib = _LibProxy(l)
     return _lib
+
+
+def profile_begin(entry_point):
+    _Prof.target = entry_point
+    _Prof.events = []
+    _Prof.algo_bytes = 0.0
+    _Prof.algo_flops = 0.0
+
+
+def profile_note(entry_point, nbytes=0.0, flops=0.0):
+    """Call sites report the ALGORITHMIC bytes/flops of a launch (DESIGN.md formulas)."""
+    if _Prof.target == entry_point:
+        _Prof.algo_bytes += nbytes
+        _Prof.algo_flops += flops
+
+
+def profile_end():
+    tgt = _Prof.target
+    _Prof.target = None
+    if not _Prof.events:
+        return {"entry": tgt, "launches": 0, "total_ms": 0.0, "avg_ms": None,
+                "algo_bytes": 0.0, "algo_flops": 0.0}
+    torch.cuda.synchronize()
+    ms = [a.elapsed_time(b) for a, b in _Prof.events]
+    return {"entry": tgt, "launches": len(ms), "total_ms": float(sum(ms)),
+            "avg_ms": float(sum(ms) / len(ms)), "algo_bytes": _Prof.algo_bytes,
+            "algo_flops": _Prof.algo_flops}
 
 
 def stream():

@@ -254,6 +254,9 @@ class _PrunedJoinerLoss(torch.autograd.Function):
         px = torch.empty((B, S, T + 1), dtype=torch.float32, device=dev)
         py = torch.empty((B, S + 1, T), dtype=torch.float32, device=dev)
         lse = torch.empty((B, T, R), dtype=torch.float32, device=dev)
+        N.profile_note("s2t_rnnt_pruned_fwd",
+                       4.0 * (am.numel() + lm.numel() + px.numel() + py.numel() + lse.numel())
+                       + 8.0 * ranges.numel())
         N.check(L.s2t_rnnt_pruned_fwd(N.fp(am), N.fp(lm), N.lp(ranges), N.lp(symbols),
                                       N.lp(boundary), B, S, T, C, R, int(blank), _ACT[act],
                                       N.fp(px), N.fp(py), N.fp(lse), st), "pruned_fwd")

@@ -14,6 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch import Tensor
 
+from speech2text_amd import rng
 from speech2text_amd import zip_kernels as zk
 
 
@@ -343,7 +344,7 @@ class Dropout3(nn.Module):
             return _no_op(x)
         shape = list(x.shape)
         shape[self.shared_dim] = 1
-        mask = (torch.rand(*shape, device=x.device) > p).to(x.dtype) * (1.0 / (1 - p))
+        mask = (rng.rand(*shape, device=x.device) > p).to(x.dtype) * (1.0 / (1 - p))
         return x * mask
 
 
@@ -370,7 +371,7 @@ class ActivationDropoutAndLinear(nn.Module):
             shape = list(x.shape)
             if self.dropout_shared_dim is not None:
                 shape[self.dropout_shared_dim] = 1
-            mask = (1.0 / (1.0 - p)) * (torch.rand(*shape, device=x.device, dtype=x.dtype) > p)
+            mask = (1.0 / (1.0 - p)) * (rng.rand(*shape, device=x.device, dtype=x.dtype) > p)
         return zk.swoosh_linear(x, self.weight, self.bias, self.activation == "SwooshL", mask)
 
 

@@ -5,6 +5,8 @@ from typing import Optional, Tuple
 import torch
 from torch import Tensor, nn
 
+from speech2text_amd import rng
+
 from speech2text_amd.model.layer.scaling import (Balancer, BiasNorm, Dropout3, FloatLike,
                                                  ScaledConv2d, ScaleGrad, ScheduledFloat, SwooshL,
                                                  SwooshR, Whiten)
@@ -38,7 +40,7 @@ class ConvNeXt(nn.Module):
         if self.training:
             rate = float(self.layerdrop_rate)
             if rate != 0.0:
-                mask = torch.rand((x.shape[0], 1, 1, 1), dtype=x.dtype, device=x.device) > rate
+                mask = rng.rand(x.shape[0], 1, 1, 1, dtype=x.dtype, device=x.device) > rate
         bypass = x
         x = self.depthwise_conv(x)
         x = self.pointwise_conv1(x)

@@ -1,0 +1,118 @@
+"""RNN-T family tasks (reference task_factory/rnnt_task.py): the per-step call sequence
+cmvn -> encoder -> decoder -> predictor -> joiner -> loss and the loss-combination formulas
+(:349, :496-499) with the same attribute names (state_dict prefixes) and logged scalars."""
+import torch
+
+from speech2text_amd.model.decoder.decoder import Decoder
+from speech2text_amd.model.encoder.encoder import Encoder
+from speech2text_amd.model.joiner.joiner import Joiner, JoinerConfig
+from speech2text_amd.model.loss.loss import Loss
+from speech2text_amd.model.predictor.predictor import Predictor
+from speech2text_amd.task_factory.base import TaskBase
+
+
+class BaseRnntTask(TaskBase):
+    def __init__(self, config) -> None:
+        super().__init__(config)
+        self._encoder = Encoder(config["encoder"])
+        self._decoder = Decoder(config["decoder"])
+        self._predictor = Predictor(config["predictor"])
+        self._joiner = Joiner(config=JoinerConfig(**config["joiner"]))
+
+    def _optimizer_params(self):
+        sep = self._optim_config["seperate_lr"]
+        if sep["apply"]:
+            c = sep["config"]
+            return [{"params": self._encoder.parameters(), "name": "encoder_lr", "lr": c["encoder_lr"]},
+                    {"params": self._decoder.parameters(), "name": "decoder_lr", "lr": c["decoder_lr"]},
+                    {"params": self._predictor.parameters(), "name": "predictor_lr", "lr": c["predictor_lr"]},
+                    {"params": self._joiner.parameters(), "name": "joiner_lr", "lr": c["joiner_lr"]}]
+        return self.parameters()
+
+
+class RnntTask(BaseRnntTask):
+    def __init__(self, config) -> None:
+        super().__init__(config)
+        assert config["loss"]["model"] == "Rnnt"
+        self._loss = Loss(config["loss"])
+
+    def training_step(self, batch, batch_idx):
+        feat, feat_len = self.features(batch)
+        enc, enc_len = self._encoder(feat, feat_len)
+        dec, dec_len = self._decoder(enc, enc_len)
+        pred, pred_len, _ = self._predictor(batch["label"], batch["label_length"],
+                                            self._predictor.init_state())
+        joint, _, _, _ = self._joiner(dec, dec_len, pred, pred_len)
+        loss = self._loss({"logits": joint, "logits_length": dec_len, "targets": batch["label"],
+                           "targets_length": batch["label_length"]})
+        self.log("train_loss", loss, sync_dist=True, prog_bar=True, logger=True)
+        return loss.mean()
+
+
+class CtcHybridRnnt(BaseRnntTask):
+    """Shared encoder, CTC head on decoder_out, RNN-T branch on encoder_out (reference :287-420)."""
+
+    def __init__(self, config) -> None:
+        super().__init__(config)
+        self._rnnt_weight = config["loss"]["rnnt_weight"]
+        self._ctc_weight = config["loss"]["ctc_weight"]
+        self._ctc_loss = Loss(config["loss"]["ctc_loss"])
+        self._rnnt_loss = Loss(config["loss"]["rnnt_loss"])
+
+    def training_step(self, batch, batch_idx):
+        feat, feat_len = self.features(batch)
+        enc, enc_len = self._encoder(feat, feat_len)
+        dec, dec_len = self._decoder(enc, enc_len)
+        pred, pred_len, _ = self._predictor(batch["label"], batch["label_length"],
+                                            self._predictor.init_state())
+        joint, _, _, _ = self._joiner(enc, enc_len, pred, pred_len)
+        loss_rnnt = self._rnnt_loss({"logits": joint, "logits_length": enc_len,
+                                     "targets": batch["label"],
+                                     "targets_length": batch["label_length"]})
+        loss_ctc = self._ctc_loss({"logits": dec, "logits_length": dec_len,
+                                   "targets": batch["label"],
+                                   "targets_length": batch["label_length"]})
+        loss = self._rnnt_weight * loss_rnnt + self._ctc_weight * loss_ctc
+        self.log_dict({"train_loss": loss, "train_loss/loss_rnnt": loss_rnnt,
+                       "train_loss/loss_ctc": loss_ctc}, sync_dist=True, prog_bar=True,
+                      logger=True)
+        return loss.mean()
+
+
+class PrunedRnntTask(BaseRnntTask):
+    def __init__(self, config) -> None:
+        super().__init__(config)
+        assert config["loss"]["model"] == "Pruned_Rnnt"
+        self._loss_config = config["loss"]
+        self._simple_loss_scale = config["loss"]["simple_loss_scale"]
+        self._pruned_loss_scale = config["loss"]["pruned_loss_scale"]
+        self._loss = Loss(self._loss_config)
+        self._enable_ctc = self._loss_config["enable_ctc"]
+        if self._enable_ctc:
+            self._ctc_loss = Loss({"model": "CTC", "config": {**self._loss_config["ctc_config"]}})
+            self._ctc_projector = Decoder(config["ctc_projector"])
+
+    def training_step(self, batch, batch_idx):
+        feat, feat_len = self.features(batch)
+        enc, enc_len = self._encoder(feat, feat_len)
+        dec, dec_len = self._decoder(enc, enc_len)
+        pred, pred_len, _ = self._predictor(batch["label"], batch["label_length"],
+                                            self._predictor.init_state())
+        joint, boundary, ranges, simple_loss = self._joiner(dec, dec_len, pred, pred_len,
+                                                            batch["label"])
+        pruned_loss = self._loss({"logits": joint, "logits_length": dec_len,
+                                  "targets": batch["label"],
+                                  "targets_length": batch["label_length"],
+                                  "boundary": boundary, "ranges": ranges})
+        loss = self._simple_loss_scale * simple_loss + self._pruned_loss_scale * pruned_loss
+        ctc_loss = 0.0
+        if self._enable_ctc:
+            logits, logits_len = self._ctc_projector(dec, dec_len)
+            ctc_loss = self._ctc_loss({"logits": logits, "logits_length": logits_len,
+                                       "targets": batch["label"],
+                                       "targets_length": batch["label_length"]})
+            loss = loss + ctc_loss
+        self.log_dict({"train_loss": loss, "train_loss/simple_loss": simple_loss,
+                       "train_loss/pruned_loss": pruned_loss, "train_loss/ctc_loss": ctc_loss},
+                      sync_dist=True, prog_bar=True, logger=True)
+        return loss.mean()

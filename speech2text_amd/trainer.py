@@ -1,0 +1,95 @@
+"""Minimal trainer that drives a task the way pl.Trainer(**config["trainer"]).fit does in
+the reference (build_task.py:143-148), honouring the YAML `trainer:` keys that matter for
+the training hot path: devices/strategy (one process per GPU, RCCL), precision "32-true",
+accumulate_grad_batches, gradient_clip_val / gradient_clip_algorithm, max_epochs.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+from speech2text_amd.ddp import GradReducer, broadcast_parameters
+from speech2text_amd.flat import get_store
+
+
+class Trainer:
+    def __init__(self, accelerator="gpu", devices=1, strategy="ddp", precision="32-true",
+                 max_epochs=1, accumulate_grad_batches=1, gradient_clip_val=None,
+                 gradient_clip_algorithm="norm", bucket_mb=32, **unused):
+        if str(precision) not in ("32-true", "32"):
+            raise NotImplementedError("the reference trains in fp32 ('32-true'); other "
+                                      "precisions are not part of the parity target")
+        self.accum = int(accumulate_grad_batches)
+        self.clip_val = gradient_clip_val
+        self.clip_algo = gradient_clip_algorithm
+        self.max_epochs = max_epochs
+        self.bucket_bytes = int(bucket_mb) << 20
+        self.micro = 0
+        self.task = None
+
+    # ------------------------------------------------------------------
+    def setup(self, task, device=None):
+        if device is None:
+            device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0))) \
+                if torch.cuda.is_available() else torch.device("cpu")
+        self.device = device
+        task.to(device)
+        self.task = task
+        opt = task.configure_optimizers()
+        self.optimizer = opt["optimizer"]
+        self.scheduler = opt["lr_scheduler"]["scheduler"]
+        params = [p for p in task.parameters() if p.requires_grad]
+        self.store = get_store(params)
+        broadcast_parameters(self.store)
+        self.reducer = GradReducer(self.store, self.bucket_bytes)
+        return self
+
+    def _clip(self):
+        if not self.clip_val:
+            return
+        g = self.store.g()
+        if self.clip_algo == "value":
+            g.clamp_(-self.clip_val, self.clip_val)
+            return
+        norm = g.norm()
+        g.mul_(torch.clamp(self.clip_val / (norm + 1.0e-6), max=1.0))
+
+    def training_step(self, batch, batch_idx):
+        """One micro-batch: forward, backward (+ overlapped gradient all-reduce on the last
+        micro-batch of an accumulation window), then clip / optimizer / scheduler."""
+        task = self.task
+        last = (self.micro + 1) % self.accum == 0
+        if last:
+            self.reducer.prepare()
+            loss = task.training_step(batch, batch_idx)
+            (loss / self.accum).backward()
+        else:
+            with self.reducer.no_sync():
+                loss = task.training_step(batch, batch_idx)
+                (loss / self.accum).backward()
+        self.micro += 1
+        if last:
+            logged = None
+            if dist.is_initialized() and dist.get_world_size() > 1 and task.logged:
+                vals = [v.detach().float().reshape(()) if torch.is_tensor(v)
+                        else torch.tensor(float(v), device=loss.device) for v in task.logged.values()]
+                logged = torch.stack(vals)
+            logged = self.reducer.finish(logged)
+            if logged is not None:
+                task.logged = dict(zip(task.logged.keys(), logged.unbind(0)))
+            self._clip()
+            self.optimizer.step()
+            self.scheduler.step()
+            self.store.zero_grad()
+            task.global_step += 1
+        return loss.detach()
+
+    def fit(self, task, batches, device=None):
+        if self.task is None:
+            self.setup(task, device)
+        task.train()
+        for epoch in range(self.max_epochs):
+            task.current_epoch = epoch
+            for i, batch in enumerate(batches):
+                batch = {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+                self.training_step(batch, i)

@@ -1,0 +1,80 @@
+"""CPU, world_size 2 (gloo): the bucketed gradient reducer averages gradients like DDP,
+tolerates parameters that never get a gradient, and skips sync under no_sync()."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from speech2text_amd.ddp import GradReducer, broadcast_parameters
+    from speech2text_amd.flat import FlatStore
+    torch.manual_seed(100 + rank)                       # different init per rank on purpose
+    net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16),
+                              torch.nn.Tanh(), torch.nn.Linear(16, 3))
+    unused = torch.nn.Parameter(torch.ones(5))
+    params = list(net.parameters()) + [unused]
+    store = FlatStore(params)
+    broadcast_parameters(store)                         # rank 0's weights everywhere
+    red = GradReducer(store, bucket_bytes=4 * 200)      # several small buckets
+    g = torch.Generator().manual_seed(7)
+    xs = torch.randn(4, 8, 6, generator=g)
+    ys = torch.randn(4, 8, 3, generator=g)
+    outs = []
+    for step in range(3):
+        store.zero_grad()
+        # accumulation micro-step without sync, then a synced one
+        with red.no_sync():
+            ((net(xs[rank]) - ys[rank]) ** 2).mean().backward()
+        red.prepare()
+        ((net(xs[2 + rank]) - ys[2 + rank]) ** 2).mean().backward()
+        red.finish()
+        outs.append(store.g().clone())
+    # single-process oracle: accumulate both micro-batches, average over the two ranks
+    ref = []
+    for r in range(world):
+        for p in net.parameters():
+            p.grad = None
+        ((net(xs[r]) - ys[r]) ** 2).mean().backward()
+        first = [p.grad.clone() for p in net.parameters()]
+        for p in net.parameters():
+            p.grad = None
+        ((net(xs[2 + r]) - ys[2 + r]) ** 2).mean().backward()
+        ref.append((first, [p.grad.clone() for p in net.parameters()]))
+    # expected on rank: own first micro-batch grad (unsynced) is part of the buffer that gets
+    # all-reduced, so result = mean over ranks of (first + second)
+    exp = [sum(ref[r][0][i] + ref[r][1][i] for r in range(world)) / world
+           for i in range(len(ref[0][0]))]
+    exp_flat = torch.cat([e.reshape(-1) for e in exp] + [torch.zeros(5)])
+    ok = all(torch.allclose(o, exp_flat, atol=1e-6) for o in outs)
+    q.put((rank, ok, len(red.buckets), sorted(red._expected) == list(range(len(params) - 1))))
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, nb, learned in res:
+        assert ok, f"rank {rank}: gradients differ from the 2-replica average"
+        assert nb >= 3
+        assert learned, "unused parameter should be excluded from the expected set"

@@ -175,8 +175,38 @@ def gen_zipformer():
         print("zipformer", tag, y.shape, float(loss))
 
 
+def gen_scaledadam():
+    """30 steps of the reference ScaledAdam (+ Eden) on 5 small tensors, seeded grads."""
+    import torch
+    ref_import.install_stubs()
+    from optimizer.scaled_adam import ScaledAdam
+    from optimizer.optim_setup import Eden
+    torch.manual_seed(0)
+    shapes = [(5, 7), (3,), (), (5, 7), (4, 2, 3)]
+    ps = [torch.nn.Parameter(torch.randn(s) * (0.1 if i == 3 else 1.0)) for i, s in enumerate(shapes)]
+    out = {f"init{i}": p.detach().numpy().copy() for i, p in enumerate(ps)}
+    opt = ScaledAdam(ps, lr=0.045, clipping_scale=2.0, clipping_update_period=6)
+    sched = Eden(opt, lr_batches=10, warmup_batches=4)
+    g = torch.Generator().manual_seed(1)
+    lrs = []
+    for it in range(30):
+        for i, p in enumerate(ps):
+            gr = torch.randn(p.shape, generator=g) * (5.0 if it % 7 == 3 else 1.0)
+            out[f"grad{it}_{i}"] = gr.numpy()
+            p.grad = gr.clone()
+        opt.step()
+        sched.step()
+        lrs.append(opt.param_groups[0]["lr"])
+        if it in (0, 9, 29):
+            for i, p in enumerate(ps):
+                out[f"p{it}_{i}"] = p.detach().numpy().copy()
+    out["lrs"] = np.array(lrs)
+    np.savez_compressed(os.path.join(OUT, "scaledadam_ref.npz"), **out)
+    print("scaledadam lrs", lrs[:3], lrs[-1])
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["fbank", "ctc", "bestrq", "zipformer"]
+    which = sys.argv[1:] or ["fbank", "ctc", "bestrq", "zipformer", "scaledadam"]
     for w in which:
         globals()["gen_" + w]()
