@@ -91,6 +91,19 @@ def make_batch(rank, batch, seconds, n_labels, vocab, device):
 
 
 # ------------------------------------------------------------------ CPU baseline (oracle)
+def host_threads(cap=16):
+    """Threads this process may really use: affinity mask, cgroup quota, and the GPU box's
+    per-GPU CPU share (16) -- oversubscribing a quota-limited container stalls OpenMP."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per))))
+    except Exception:
+        pass
+    return max(1, min(n, cap))
+
+
 def cpu_baseline(cfg, seconds=10.0, batch=2, n_labels=50, vocab=500, steps=2):
     """Times the oracle (our CPU restatement of the reference path: numpy fbank, torch-CPU
     zipformer fwd+bwd, k2-style RNN-T losses) on the host cores.  Test infrastructure used as
@@ -103,7 +116,7 @@ def cpu_baseline(cfg, seconds=10.0, batch=2, n_labels=50, vocab=500, steps=2):
     from speech2text_amd.model.predictor.predictor import Predictor
 
     torch.manual_seed(1234)
-    nthreads = os.cpu_count() or 1
+    nthreads = host_threads()
     torch.set_num_threads(nthreads)
     ec = cfg["encoder"]["config"]
     enc = Zipformer2(Zipformer2Config(**ec))                # parameter container only
@@ -147,7 +160,7 @@ def cpu_baseline(cfg, seconds=10.0, batch=2, n_labels=50, vocab=500, steps=2):
             "kind": "port",
             "sample": f"{batch} x {seconds:g}s utterances, {steps} timed steps (median) of the "
                       f"oracle train step (numpy fbank + torch-CPU zipformer fwd/bwd + k2-style "
-                      f"losses), loss={float(loss):.4f}"}
+                      f"losses), loss={float(loss.detach()):.4f}"}
 
 
 # ------------------------------------------------------------------ main
@@ -179,10 +192,16 @@ def main():
     from speech2text_amd.task_factory.rnnt_task import PrunedRnntTask
     from speech2text_amd.trainer import Trainer
 
+    def note(msg):
+        if rank == 0:
+            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
     cfg = c3_config(args.vocab)
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
+        note("timing the CPU baseline (oracle) ...")
         cpu = cpu_baseline(cfg, args.seconds, args.cpu_batch, args.labels, args.vocab)
+        note(f"cpu baseline: {cpu['value']:.2f} audio-s/s on {cpu['cores']} threads")
 
     random.seed(1234 + rank)
     np.random.seed(1234 + rank)
@@ -198,9 +217,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    note("model + synthetic batch ready; warmup ...")
     loss = None
     for i in range(args.warmup):
+        tw = time.perf_counter()
         loss = trainer.training_step(batch, i)
+        torch.cuda.synchronize()
+        note(f"warmup step {i}: {time.perf_counter() - tw:.3f} s, loss {float(loss):.4f}")
     sync()
     _native.profile_begin(args.roofline_kernel)
     t0 = time.perf_counter()
