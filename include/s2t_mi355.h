@@ -98,6 +98,22 @@ int s2t_balancer_coef(const float* sum, const float* sumsq, float n, int C, floa
 int s2t_balancer_apply(const float* x, long ldx, const float* g, long ldg, const float* a,
                        const float* b, long rows, int C, float* out, long ldo, void* stream);
 
+
+/* ---- zipformer convolution module core (model/encoder/zipformer.py:2672-2690 +
+ * model/layer/scaling.py:622-681), time-major.  u (T,B,ld): x = u[..., 0:C], gate
+ * pre-activation = u[..., gate_off:gate_off+C] (gate_off < 0: no gate); mask (B,T) bytes,
+ * 1 = padded frame (may be NULL); wc (C,(K+1)/2), bc (C): causal taps (NULL for a plain
+ * depthwise conv); wk (C,K), bk (C): chunkwise/plain taps; scale (2,C,K) edge scales or NULL;
+ * chunk = chunk size in frames (>= T: one chunk).  y (T,B,C).  Backward: du (T,B,2C) (or
+ * (T,B,C) without gate) is written; the parameter gradients are ACCUMULATED (zero them). */
+int s2t_zipconv_fwd(const float* u, long ld, int gate_off, const unsigned char* mask, int T, int B,
+                    int C, int K, int chunk, const float* wc, const float* bc, const float* wk,
+                    const float* bk, const float* scale, float* y, void* stream);
+int s2t_zipconv_bwd(const float* u, long ld, int gate_off, const unsigned char* mask, int T, int B,
+                    int C, int K, int chunk, const float* wc, const float* wk, const float* bk,
+                    const float* scale, const float* dy, float* du, float* dwc, float* dbc,
+                    float* dwk, float* dbk, float* dscale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

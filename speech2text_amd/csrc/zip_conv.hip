@@ -1,0 +1,379 @@
+// Fused zipformer convolution-module core for gfx950, time-major (T,B,C):
+//   xg = x * sigmoid(s)   (GLU-style gate; x,s = the two halves of in_proj's output)
+//   xg = 0 on padded frames
+//   y  = causal_dwconv(xg) + chunkwise_dwconv(xg) * edge_scale        (causal=True)
+//   y  = dwconv(xg)                                                   (plain nn.Conv1d)
+// Reference: model/encoder/zipformer.py:2672-2690 (gate, permute, masked_fill, depthwise
+// conv) + model/layer/scaling.py:622-681 (ChunkCausalDepthwiseConv1d.forward, _get_chunk_scale).
+// The reference permutes to (B,C,T), pads, runs two cuDNN/MIOpen depthwise convs, reshapes
+// chunks and permutes back; here one kernel reads the (T,B,2C) projection once and writes
+// (T,B,C) once.  Tile = 64 frames x 64 channels of one utterance; gated inputs (+halo) and the
+// filter taps live in LDS; each thread slides a register window over 16 consecutive frames of
+// its channel, so LDS traffic is ~2 reads per 16 MACs.  Backward = one data kernel (transposed
+// taps, then back through the gate) and one weight kernel (per-thread tap partials, LDS
+// reduction over the 4 frame groups, one atomic per tap per block).
+#include "common.h"
+
+namespace {
+
+constexpr int TT = 64;   // frames per tile
+constexpr int FPT = 16;  // frames per thread
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// per-position scale of the chunkwise conv output (1 + left_edge + right_edge)
+__device__ __forceinline__ float edge_scale(const float* __restrict__ s_le,
+                                            const float* __restrict__ s_re, int c, int pos,
+                                            int chunk, int K) {
+  float sc = 1.f;
+  if (pos < K) sc += s_le[pos * 64 + c];
+  const int idx = pos - chunk + K;
+  if (idx >= 0 && idx < K) sc += s_re[idx * 64 + c];
+  return sc;
+}
+
+struct ConvArgs {
+  const float* u;       // (T,B,ld) projection; x at [0,C), gate at [gate_off, gate_off+C)
+  long ld;
+  int gate_off;         // <0: no gate
+  const unsigned char* mask;  // (B,T) 1 = padded frame, may be null
+  int T, B, C, chunk;
+  const float* wc;      // (C,Kh) causal taps or null
+  const float* bc;      // (C) or null
+  const float* wk;      // (C,K)
+  const float* bk;      // (C) or null
+  const float* scale;   // (2,C,K) or null
+};
+
+template <int K>
+__device__ __forceinline__ void stage_weights(const ConvArgs& a, int c0, float* s_wc, float* s_wk,
+                                              float* s_le, float* s_re) {
+  constexpr int Kh = (K + 1) / 2;
+  for (int i = threadIdx.x; i < 64 * K; i += 256) {
+    const int c = i / K, j = i % K;
+    const bool ok = c0 + c < a.C;
+    s_wk[j * 64 + c] = ok ? a.wk[(long)(c0 + c) * K + j] : 0.f;
+    s_le[j * 64 + c] = (ok && a.scale) ? a.scale[(long)(c0 + c) * K + j] : 0.f;
+    s_re[j * 64 + c] = (ok && a.scale) ? a.scale[((long)a.C + c0 + c) * K + j] : 0.f;
+  }
+  for (int i = threadIdx.x; i < 64 * Kh; i += 256) {
+    const int c = i / Kh, j = i % Kh;
+    s_wc[j * 64 + c] = (a.wc && c0 + c < a.C) ? a.wc[(long)(c0 + c) * Kh + j] : 0.f;
+  }
+}
+
+// gated, masked input tile: rows r <-> frame t0 - halo + r
+template <int K>
+__device__ __forceinline__ void stage_xg(const ConvArgs& a, int b, int t0, int c0, float* s_x) {
+  constexpr int halo = K / 2;
+  constexpr int rows = TT + 2 * halo;
+  for (int i = threadIdx.x; i < rows * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    const int t = t0 - halo + r;
+    float v = 0.f;
+    if (t >= 0 && t < a.T && c0 + c < a.C && !(a.mask && a.mask[(long)b * a.T + t])) {
+      const float* row = a.u + ((long)t * a.B + b) * a.ld;
+      v = row[c0 + c];
+      if (a.gate_off >= 0) v *= sigmoidf_(row[a.gate_off + c0 + c]);
+    }
+    s_x[i] = v;
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void zipconv_fwd_kernel(ConvArgs a, float* __restrict__ y) {
+  constexpr int Kh = (K + 1) / 2, halo = K / 2, W = FPT + 2 * halo;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* s_x = reinterpret_cast<float*>(smem_raw);
+  float* s_wc = s_x + (TT + 2 * halo) * 64;
+  float* s_wk = s_wc + Kh * 64;
+  float* s_le = s_wk + K * 64;
+  float* s_re = s_le + K * 64;
+  const int t0 = blockIdx.x * TT, b = blockIdx.y, c0 = blockIdx.z * 64;
+  const int c = threadIdx.x & 63, tg = threadIdx.x >> 6;
+  stage_weights<K>(a, c0, s_wc, s_wk, s_le, s_re);
+  stage_xg<K>(a, b, t0, c0, s_x);
+  __syncthreads();
+  if (c0 + c >= a.C) return;
+  float win[W];
+#pragma unroll
+  for (int w = 0; w < W; ++w) win[w] = s_x[(tg * FPT + w) * 64 + c];
+  const float bc = a.bc ? a.bc[c0 + c] : 0.f;
+  const float bk = a.bk ? a.bk[c0 + c] : 0.f;
+  const int tb = t0 + tg * FPT;
+  float accc[FPT], acck[FPT];
+#pragma unroll
+  for (int i = 0; i < FPT; ++i) {
+    accc[i] = bc;
+    acck[i] = bk;
+  }
+  const int chunk = a.chunk;
+  const bool one_chunk = (tb / chunk) == ((tb + FPT - 1) / chunk) &&
+                         (tb - halo) >= (tb / chunk) * chunk &&
+                         (tb + FPT - 1 + halo) < (tb / chunk + 1) * chunk;
+  if (a.wc) {
+#pragma unroll
+    for (int j = 0; j < Kh; ++j) {
+      const float w = s_wc[j * 64 + c];
+#pragma unroll
+      for (int i = 0; i < FPT; ++i) accc[i] = fmaf(w, win[i + j], accc[i]);
+    }
+  }
+  if (one_chunk || chunk >= a.T) {
+    // frames outside [0,T) are zero in the tile, which is exactly the conv's zero padding
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const float w = s_wk[j * 64 + c];
+#pragma unroll
+      for (int i = 0; i < FPT; ++i) acck[i] = fmaf(w, win[i + j], acck[i]);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const float w = s_wk[j * 64 + c];
+#pragma unroll
+      for (int i = 0; i < FPT; ++i) {
+        const int t = tb + i, tt = t - halo + j;
+        const int cs = (t / chunk) * chunk;
+        if (tt >= cs && tt < cs + chunk) acck[i] = fmaf(w, win[i + j], acck[i]);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < FPT; ++i) {
+    const int t = tb + i;
+    if (t < a.T) {
+      float v = acck[i];
+      if (a.scale) v *= edge_scale(s_le, s_re, c, t % chunk, chunk, K);
+      y[((long)t * a.B + b) * a.C + c0 + c] = v + accc[i];
+    }
+  }
+}
+
+// du[t'] : gradient w.r.t. the projection (x half and gate half)
+template <int K>
+__global__ __launch_bounds__(256) void zipconv_bwd_data_kernel(ConvArgs a,
+                                                               const float* __restrict__ dy,
+                                                               float* __restrict__ du) {
+  constexpr int Kh = (K + 1) / 2, halo = K / 2, W = FPT + 2 * halo;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* s_g = reinterpret_cast<float*>(smem_raw);  // dy tile with halo
+  float* s_wc = s_g + (TT + 2 * halo) * 64;
+  float* s_wk = s_wc + Kh * 64;
+  float* s_le = s_wk + K * 64;
+  float* s_re = s_le + K * 64;
+  const int t0 = blockIdx.x * TT, b = blockIdx.y, c0 = blockIdx.z * 64;
+  const int c = threadIdx.x & 63, tg = threadIdx.x >> 6;
+  stage_weights<K>(a, c0, s_wc, s_wk, s_le, s_re);
+  for (int i = threadIdx.x; i < (TT + 2 * halo) * 64; i += 256) {
+    const int r = i >> 6, cc = i & 63;
+    const int t = t0 - halo + r;
+    s_g[i] = (t >= 0 && t < a.T && c0 + cc < a.C) ? dy[((long)t * a.B + b) * a.C + c0 + cc] : 0.f;
+  }
+  __syncthreads();
+  if (c0 + c >= a.C) return;
+  const int chunk = a.chunk;
+  const int tb = t0 + tg * FPT;
+  float win[W], wins[W];   // dy and dy * edge_scale for frames tb-halo .. tb+FPT-1+halo
+#pragma unroll
+  for (int w = 0; w < W; ++w) {
+    win[w] = s_g[(tg * FPT + w) * 64 + c];
+    const int t = tb - halo + w;
+    float sc = 1.f;
+    if (a.scale && t >= 0 && t < a.T) sc = edge_scale(s_le, s_re, c, t % chunk, chunk, K);
+    wins[w] = win[w] * sc;
+  }
+  float acc[FPT];
+#pragma unroll
+  for (int i = 0; i < FPT; ++i) acc[i] = 0.f;
+  // causal: y[t] += wc[j] * xg[t - halo + j]  =>  dxg[t'] += wc[j] * dy[t' + halo - j]
+  if (a.wc) {
+#pragma unroll
+    for (int j = 0; j < Kh; ++j) {
+      const float w = s_wc[j * 64 + c];
+#pragma unroll
+      for (int i = 0; i < FPT; ++i) acc[i] = fmaf(w, win[i + 2 * halo - j], acc[i]);
+    }
+  }
+  // chunkwise: dxg[t'] += wk[j] * (dy*sc)[t' + halo - j] when frame t'+halo-j is in t's chunk
+  const bool one_chunk = (chunk >= a.T) ||
+                         ((tb - halo) >= (tb / chunk) * chunk &&
+                          (tb + FPT - 1 + halo) < (tb / chunk + 1) * chunk);
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const float w = s_wk[j * 64 + c];
+#pragma unroll
+    for (int i = 0; i < FPT; ++i) {
+      if (one_chunk) {
+        acc[i] = fmaf(w, wins[i + 2 * halo - j], acc[i]);
+      } else {
+        const int tp = tb + i, t = tp + halo - j;
+        if (t >= 0 && (t / chunk) == (tp / chunk)) acc[i] = fmaf(w, wins[i + 2 * halo - j], acc[i]);
+      }
+    }
+  }
+  const int nout = a.gate_off >= 0 ? 2 * a.C : a.C;
+#pragma unroll
+  for (int i = 0; i < FPT; ++i) {
+    const int t = tb + i;
+    if (t >= a.T) continue;
+    const bool pad = a.mask && a.mask[(long)b * a.T + t];
+    float* o = du + ((long)t * a.B + b) * nout;
+    if (a.gate_off >= 0) {
+      const float* row = a.u + ((long)t * a.B + b) * a.ld;
+      const float xv = row[c0 + c], sg = sigmoidf_(row[a.gate_off + c0 + c]);
+      o[c0 + c] = pad ? 0.f : acc[i] * sg;
+      o[a.C + c0 + c] = pad ? 0.f : acc[i] * xv * sg * (1.f - sg);
+    } else {
+      o[c0 + c] = pad ? 0.f : acc[i];
+    }
+  }
+}
+
+// weight / bias / edge-scale gradients; block = (t-tile, group of BB utterances, c-tile)
+template <int K>
+__global__ __launch_bounds__(256) void zipconv_bwd_w_kernel(
+    ConvArgs a, const float* __restrict__ dy, int BB, float* __restrict__ dwc,
+    float* __restrict__ dbc, float* __restrict__ dwk, float* __restrict__ dbk,
+    float* __restrict__ dscale) {
+  constexpr int Kh = (K + 1) / 2, halo = K / 2, W = FPT + 2 * halo;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* s_x = reinterpret_cast<float*>(smem_raw);
+  float* s_wc = s_x + (TT + 2 * halo) * 64;
+  float* s_wk = s_wc + Kh * 64;
+  float* s_le = s_wk + K * 64;
+  float* s_re = s_le + K * 64;
+  float* s_red = s_re + K * 64;  // [4][64] reduction scratch
+  const int t0 = blockIdx.x * TT, c0 = blockIdx.z * 64;
+  const int c = threadIdx.x & 63, tg = threadIdx.x >> 6;
+  const int tb = t0 + tg * FPT;
+  const int chunk = a.chunk;
+  stage_weights<K>(a, c0, s_wc, s_wk, s_le, s_re);
+  float pwc[Kh], pwk[K];
+#pragma unroll
+  for (int j = 0; j < Kh; ++j) pwc[j] = 0.f;
+#pragma unroll
+  for (int j = 0; j < K; ++j) pwk[j] = 0.f;
+  float pbc = 0.f, pbk = 0.f;
+  const bool chan_ok = c0 + c < a.C;
+  const float bk = (a.bk && chan_ok) ? a.bk[c0 + c] : 0.f;
+  const bool one_chunk = (chunk >= a.T) ||
+                         ((tb - halo) >= (tb / chunk) * chunk &&
+                          (tb + FPT - 1 + halo) < (tb / chunk + 1) * chunk);
+  const int b_end = min(a.B, (int)(blockIdx.y + 1) * BB);
+  for (int b = blockIdx.y * BB; b < b_end; ++b) {
+    __syncthreads();
+    stage_xg<K>(a, b, t0, c0, s_x);
+    __syncthreads();
+    if (!chan_ok) continue;
+    float win[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) win[w] = s_x[(tg * FPT + w) * 64 + c];
+#pragma unroll
+    for (int i = 0; i < FPT; ++i) {
+      const int t = tb + i;
+      const float g = (t < a.T) ? dy[((long)t * a.B + b) * a.C + c0 + c] : 0.f;
+      const int cs = (t / chunk) * chunk;
+      float sc = 1.f;
+      const int pos = t - cs;
+      if (a.scale) sc = edge_scale(s_le, s_re, c, pos, chunk, K);
+      const float gs = g * sc;
+      pbc += g;
+      pbk += gs;
+      if (a.wc) {
+#pragma unroll
+        for (int j = 0; j < Kh; ++j) pwc[j] = fmaf(g, win[i + j], pwc[j]);
+      }
+      float convk = bk;
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        const int tt = t - halo + j;
+        const bool in = one_chunk || (tt >= cs && tt < cs + chunk);
+        if (in) {
+          pwk[j] = fmaf(gs, win[i + j], pwk[j]);
+          convk = fmaf(s_wk[j * 64 + c], win[i + j], convk);
+        }
+      }
+      if (a.scale && t < a.T) {
+        // d(1 + le[pos] + re[idx]) : sparse (only frames near a chunk edge)
+        const float v = g * convk;
+        if (pos < K) atomicAdd(&dscale[(long)(c0 + c) * K + pos], v);
+        const int idx = pos - chunk + K;
+        if (idx >= 0 && idx < K) atomicAdd(&dscale[((long)a.C + c0 + c) * K + idx], v);
+      }
+    }
+  }
+  // reduce the 4 frame groups of each channel through LDS, then one atomic per value
+  auto reduce_add = [&](float v, float* dst) {
+    __syncthreads();
+    s_red[tg * 64 + c] = v;
+    __syncthreads();
+    if (tg == 0 && chan_ok) {
+      const float s = s_red[c] + s_red[64 + c] + s_red[128 + c] + s_red[192 + c];
+      if (s != 0.f) atomicAdd(dst, s);
+    }
+  };
+  if (a.wc) {
+#pragma unroll
+    for (int j = 0; j < Kh; ++j) reduce_add(pwc[j], dwc + (long)(c0 + c) * Kh + j);
+    reduce_add(pbc, dbc + c0 + c);
+  }
+#pragma unroll
+  for (int j = 0; j < K; ++j) reduce_add(pwk[j], dwk + (long)(c0 + c) * K + j);
+  if (dbk) reduce_add(pbk, dbk + c0 + c);
+}
+
+template <int K>
+size_t conv_smem(bool with_red) {
+  constexpr int Kh = (K + 1) / 2, halo = K / 2;
+  return sizeof(float) * ((TT + 2 * halo) * 64 + Kh * 64 + 3 * K * 64 + (with_red ? 256 : 0));
+}
+
+}  // namespace
+
+#define S2T_CONV_DISPATCH(K, BODY)  \
+  switch (K) {                      \
+    case 3: { constexpr int KK = 3; BODY; } break;   \
+    case 5: { constexpr int KK = 5; BODY; } break;   \
+    case 7: { constexpr int KK = 7; BODY; } break;   \
+    case 15: { constexpr int KK = 15; BODY; } break; \
+    case 31: { constexpr int KK = 31; BODY; } break; \
+    default: return -1;             \
+  }
+
+static int conv_args_ok(int T, int B, int C, int K, int chunk) {
+  return T > 0 && B > 0 && C > 0 && (K & 1) && chunk > 0;
+}
+
+extern "C" int s2t_zipconv_fwd(const float* u, long ld, int gate_off, const unsigned char* mask,
+                               int T, int B, int C, int K, int chunk, const float* wc,
+                               const float* bc, const float* wk, const float* bk,
+                               const float* scale, float* y, void* stream) {
+  if (!conv_args_ok(T, B, C, K, chunk)) return -1;
+  ConvArgs a{u, ld, gate_off, mask, T, B, C, chunk, wc, bc, wk, bk, scale};
+  dim3 grid((T + TT - 1) / TT, B, (C + 63) / 64);
+  S2T_CONV_DISPATCH(K, hipLaunchKernelGGL(zipconv_fwd_kernel<KK>, grid, dim3(256),
+                                          conv_smem<KK>(false), (hipStream_t)stream, a, y));
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int s2t_zipconv_bwd(const float* u, long ld, int gate_off, const unsigned char* mask,
+                               int T, int B, int C, int K, int chunk, const float* wc,
+                               const float* wk, const float* bk, const float* scale,
+                               const float* dy, float* du, float* dwc, float* dbc, float* dwk,
+                               float* dbk, float* dscale, void* stream) {
+  if (!conv_args_ok(T, B, C, K, chunk)) return -1;
+  ConvArgs a{u, ld, gate_off, mask, T, B, C, chunk, wc, nullptr, wk, bk, scale};
+  dim3 grid((T + TT - 1) / TT, B, (C + 63) / 64);
+  S2T_CONV_DISPATCH(K, hipLaunchKernelGGL(zipconv_bwd_data_kernel<KK>, grid, dim3(256),
+                                          conv_smem<KK>(false), (hipStream_t)stream, a, dy, du));
+  S2T_CHECK_LAUNCH();
+  const int BB = 8;
+  dim3 gridw((T + TT - 1) / TT, (B + BB - 1) / BB, (C + 63) / 64);
+  S2T_CONV_DISPATCH(K, hipLaunchKernelGGL(zipconv_bwd_w_kernel<KK>, gridw, dim3(256),
+                                          conv_smem<KK>(true), (hipStream_t)stream, a, dy, BB, dwc,
+                                          dbc, dwk, dbk, dscale));
+  S2T_CHECK_LAUNCH();
+  return 0;
+}

@@ -502,11 +502,14 @@ class ConvolutionModule(nn.Module):
 
     def forward(self, x: Tensor, src_key_padding_mask: Optional[Tensor] = None,
                 chunk_size: int = -1) -> Tensor:
-        x, s = self.in_proj(x).chunk(2, dim=2)
-        s = self.balancer1(s)
+        u = self.in_proj(x)                      # (T,B,2C): [x | gate pre-activation]
+        C = u.shape[-1] // 2
+        if self.balancer1.fires(u):
+            # gradient shaping of the gate half only (identity in forward)
+            u = torch.cat((u[..., :C], self.balancer1.shape_grad(u[..., C:])), dim=-1)
         if chunk_size >= 0:
             assert self.causal, "Must initialize model with causal=True if you use chunk_size"
-        x = zk.glu_chunk_causal_dwconv(x, s, src_key_padding_mask, self.depthwise_conv,
+        x = zk.glu_chunk_causal_dwconv(u, C, src_key_padding_mask, self.depthwise_conv,
                                        chunk_size)
         x = self.whiten(self.balancer2(x))
         return self.out_proj(x)

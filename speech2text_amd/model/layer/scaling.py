@@ -306,7 +306,8 @@ class ChunkCausalDepthwiseConv1d(nn.Module):
 
     def forward(self, x: Tensor, chunk_size: int = -1) -> Tensor:
         """x: (batch, channels, time) as in the reference."""
-        y = zk.glu_chunk_causal_dwconv(x.permute(2, 0, 1), None, None, self, chunk_size)
+        y = zk.glu_chunk_causal_dwconv(x.permute(2, 0, 1).contiguous(), None, None, self,
+                                       chunk_size)
         return y.permute(1, 2, 0)
 
 

@@ -227,40 +227,79 @@ def whiten_backward(x, g, num_groups, limit, grad_scale):
 
 
 # ------------------------------------------------------------------ conv module core
-def glu_chunk_causal_dwconv(x, s, key_padding_mask, conv, chunk_size):
-    """x (T,B,C) [, s (T,B,C) gate pre-activation] -> depthwise chunk-causal conv of
-    (x * sigmoid(s)) with padded frames zeroed, output (T,B,C).
-    conv: module holding causal_conv / chunkwise_conv / chunkwise_conv_scale (or nn.Conv1d).
-    torch-op composition (MIOpen depthwise conv); HIP kernel: see DESIGN.md status table."""
-    if s is not None:
-        x = x * torch.sigmoid(s)
-    x = x.permute(1, 2, 0)                                           # (B,C,T)
-    if key_padding_mask is not None:
-        x = x.masked_fill(key_padding_mask.unsqueeze(1).expand_as(x), 0.0)
+class _ZipConv(torch.autograd.Function):
+    """Fused gate + padding mask + (chunk-causal | plain) depthwise conv, time-major."""
+
+    @staticmethod
+    def forward(ctx, u, gate_off, mask, chunk, K, wc, bc, wk, bk, scale):
+        _dev(u, wk)
+        u = u.contiguous().float()
+        T, B, ld = u.shape
+        C = wk.shape[0]
+        y = torch.empty((T, B, C), dtype=torch.float32, device=u.device)
+        m8 = None if mask is None else mask.to(torch.uint8).contiguous()
+        args = dict(wc=None if wc is None else wc.contiguous(),
+                    bc=None if bc is None else bc.contiguous(), wk=wk.contiguous(),
+                    bk=None if bk is None else bk.contiguous(),
+                    scale=None if scale is None else scale.contiguous())
+        N.profile_note("s2t_zipconv_fwd", 4.0 * (u.numel() + y.numel()))
+        N.check(N.lib().s2t_zipconv_fwd(N.fp(u), ld, gate_off, N.ptr(m8), T, B, C, K, chunk,
+                                        N.fp(args["wc"]), N.fp(args["bc"]), N.fp(args["wk"]),
+                                        N.fp(args["bk"]), N.fp(args["scale"]), N.fp(y),
+                                        N.stream()), "s2t_zipconv_fwd")
+        ctx.save_for_backward(u, m8, args["wc"], args["wk"], args["bk"], args["scale"])
+        ctx.cfg = (gate_off, chunk, K, bc is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        u, m8, wc, wk, bk, scale = ctx.saved_tensors
+        gate_off, chunk, K, has_bc = ctx.cfg
+        dy = dy.contiguous().float()
+        T, B, ld = u.shape
+        C = wk.shape[0]
+        dev = u.device
+        du = torch.empty((T, B, 2 * C if gate_off >= 0 else C), dtype=torch.float32, device=dev)
+        Kh = (K + 1) // 2
+        # one zeroed buffer for all parameter gradients (they are accumulated with atomics)
+        sizes = [C * Kh if wc is not None else 0, C if wc is not None else 0, C * K,
+                 C if bk is not None else 0, 2 * C * K if scale is not None else 0]
+        buf = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        parts, o = [], 0
+        for n in sizes:
+            parts.append(buf[o:o + n] if n else None)
+            o += n
+        dwc, dbc, dwk, dbk, dsc = parts
+        N.check(N.lib().s2t_zipconv_bwd(N.fp(u), ld, gate_off, N.ptr(m8), T, B, C, K, chunk,
+                                        N.fp(wc), N.fp(wk), N.fp(bk), N.fp(scale), N.fp(dy),
+                                        N.fp(du), N.raw(dwc) if dwc is not None else None,
+                                        N.raw(dbc) if dbc is not None else None, N.raw(dwk),
+                                        N.raw(dbk) if dbk is not None else None,
+                                        N.raw(dsc) if dsc is not None else None, N.stream()),
+                "s2t_zipconv_bwd")
+        return (du, None, None, None, None,
+                None if dwc is None else dwc.view(C, 1, Kh),
+                dbc if has_bc else None, dwk.view(C, 1, K), dbk,
+                None if dsc is None else dsc.view(2, C, K))
+
+
+def glu_chunk_causal_dwconv(u, gate_off, key_padding_mask, conv, chunk_size):
+    """u (T,B,ld): x = u[..., :C], gate pre-activation = u[..., gate_off:gate_off+C]
+    (gate_off None: no gate) -> y (T,B,C) = dwconv((x * sigmoid(gate)) zeroed on padded frames).
+    conv: ChunkCausalDepthwiseConv1d-like module (causal_conv / chunkwise_conv /
+    chunkwise_conv_scale) or a depthwise nn.Conv1d.   HIP: zip_conv.hip."""
+    T = u.shape[0]
+    go = -1 if gate_off is None else int(gate_off)
     if isinstance(conv, torch.nn.Conv1d):
-        return conv(x).permute(2, 0, 1)
-    B, C, T = x.shape
+        K = conv.kernel_size[0]
+        assert conv.groups == conv.in_channels and conv.padding[0] == K // 2
+        return _ZipConv.apply(u, go, key_padding_mask, max(T, 1), K, None, None, conv.weight,
+                              conv.bias, None)
     K = conv.kernel_size
-    left = K // 2
-    if chunk_size < 0 or chunk_size > T:
-        chunk_size = T
-    right = -T % chunk_size
-    xp = F.pad(x, (left, right))
-    y_c = F.conv1d(xp[..., :left + T], conv.causal_conv.weight, conv.causal_conv.bias, groups=C)
-    xc = xp[..., left:]
-    nch = xc.shape[2] // chunk_size
-    xc = xc.reshape(B, C, nch, chunk_size).permute(0, 2, 1, 3).reshape(B * nch, C, chunk_size)
-    xc = F.conv1d(xc, conv.chunkwise_conv.weight, conv.chunkwise_conv.bias, padding=K // 2,
-                  groups=C)
-    le, re = conv.chunkwise_conv_scale[0], conv.chunkwise_conv_scale[1]
-    if chunk_size < K:
-        le, re = le[:, :chunk_size], re[:, -chunk_size:]
-    else:
-        z = torch.zeros(C, chunk_size - K, device=x.device, dtype=x.dtype)
-        le, re = torch.cat((le, z), -1), torch.cat((z, re), -1)
-    xc = xc * (1.0 + (le + re))
-    xc = xc.reshape(B, nch, C, chunk_size).permute(0, 2, 1, 3).reshape(B, C, nch * chunk_size)
-    return (xc[..., :T] + y_c).permute(2, 0, 1)
+    chunk = T if (chunk_size < 0 or chunk_size > T) else chunk_size
+    return _ZipConv.apply(u, go, key_padding_mask, chunk, K, conv.causal_conv.weight,
+                          conv.causal_conv.bias, conv.chunkwise_conv.weight,
+                          conv.chunkwise_conv.bias, conv.chunkwise_conv_scale)
 
 
 # ------------------------------------------------------------------ attention

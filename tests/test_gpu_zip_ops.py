@@ -1,0 +1,107 @@
+"""GPU parity of individual zipformer HIP ops against the oracle's plain-torch statements."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import zipformer as Z
+
+pytestmark = pytest.mark.gpu
+
+
+class _Conv(torch.nn.Module):
+    def __init__(self, C, K):
+        super().__init__()
+        Kh = (K + 1) // 2
+        self.kernel_size = K
+        self.causal_conv = torch.nn.Conv1d(C, C, Kh, groups=C)
+        self.chunkwise_conv = torch.nn.Conv1d(C, C, K, groups=C, padding=K // 2)
+        self.chunkwise_conv_scale = torch.nn.Parameter(torch.randn(2, C, K) * 0.3)
+
+
+@pytest.mark.parametrize("T,B,C,K,chunk", [(200, 3, 192, 31, -1), (130, 2, 96, 31, 32),
+                                           (77, 4, 70, 15, 16), (50, 2, 64, 7, 8),
+                                           (20, 2, 33, 31, -1), (64, 1, 64, 15, 4)])
+def test_glu_chunk_causal_dwconv(dev, T, B, C, K, chunk):
+    from speech2text_amd import zip_kernels as zk
+    torch.manual_seed(0)
+    conv = _Conv(C, K)
+    u = torch.randn(T, B, 2 * C)
+    lens = torch.randint(T // 2, T + 1, (B,)); lens[0] = T
+    mask = torch.arange(T).unsqueeze(0) >= lens.unsqueeze(1)
+    wts = torch.randn(T, B, C)
+    # oracle
+    uc = u.clone().requires_grad_(True)
+    sd = {"p.causal_conv.weight": conv.causal_conv.weight, "p.causal_conv.bias": conv.causal_conv.bias,
+          "p.chunkwise_conv.weight": conv.chunkwise_conv.weight,
+          "p.chunkwise_conv.bias": conv.chunkwise_conv.bias,
+          "p.chunkwise_conv_scale": conv.chunkwise_conv_scale}
+    x = uc[..., :C] * torch.sigmoid(uc[..., C:])
+    x = x.permute(1, 2, 0).masked_fill(mask.unsqueeze(1), 0.0)
+    yo = Z.chunk_causal_dwconv(sd, "p.", x, chunk, K).permute(2, 0, 1)
+    (yo * wts).sum().backward()
+    ref = {n: p.grad.clone() for n, p in conv.named_parameters()}
+    for p in conv.parameters():
+        p.grad = None
+    # HIP
+    conv_g = _Conv(C, K).to(dev)
+    conv_g.load_state_dict(conv.state_dict())
+    ug = u.to(dev).requires_grad_(True)
+    y = zk.glu_chunk_causal_dwconv(ug, C, mask.to(dev), conv_g, chunk)
+    (y * wts.to(dev)).sum().backward()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), yo.detach().numpy(), atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(ug.grad.cpu().numpy(), uc.grad.numpy(), atol=2e-5, rtol=1e-4)
+    for n, p in conv_g.named_parameters():
+        r = ref[n].numpy()
+        np.testing.assert_allclose(p.grad.cpu().numpy(), r, atol=2e-4 * max(1.0, np.abs(r).max()),
+                                   rtol=1e-3, err_msg=n)
+
+
+def test_plain_depthwise_conv1d(dev):
+    from speech2text_amd import zip_kernels as zk
+    torch.manual_seed(1)
+    T, B, C, K = 90, 3, 80, 15
+    conv = torch.nn.Conv1d(C, C, K, groups=C, padding=K // 2)
+    u = torch.randn(T, B, 2 * C)
+    uc = u.clone().requires_grad_(True)
+    x = (uc[..., :C] * torch.sigmoid(uc[..., C:])).permute(1, 2, 0)
+    yo = conv(x).permute(2, 0, 1)
+    yo.sum().backward()
+    cg = torch.nn.Conv1d(C, C, K, groups=C, padding=K // 2).to(dev)
+    cg.load_state_dict(conv.state_dict())
+    ug = u.to(dev).requires_grad_(True)
+    y = zk.glu_chunk_causal_dwconv(ug, C, None, cg, -1)
+    y.sum().backward()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), yo.detach().numpy(), atol=2e-5)
+    np.testing.assert_allclose(ug.grad.cpu().numpy(), uc.grad.numpy(), atol=2e-5)
+    np.testing.assert_allclose(cg.weight.grad.cpu().numpy(), conv.weight.grad.numpy(), atol=5e-4, rtol=1e-3)
+    np.testing.assert_allclose(cg.bias.grad.cpu().numpy(), conv.bias.grad.numpy(), atol=5e-4, rtol=1e-3)
+
+
+@pytest.mark.parametrize("is_l", [True, False])
+def test_swoosh_and_biasnorm(dev, is_l):
+    from speech2text_amd import zip_kernels as zk
+    torch.manual_seed(2)
+    x = torch.randn(37, 5, 203) * 4
+    xc = x.clone().requires_grad_(True)
+    yo = (Z.swoosh_l if is_l else Z.swoosh_r)(xc)
+    yo.sum().backward()
+    xg = x.to(dev).requires_grad_(True)
+    y = zk.swoosh(xg, is_l)
+    y.sum().backward()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), yo.detach().numpy(), atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xc.grad.numpy(), atol=2e-6, rtol=1e-5)
+    bias = torch.randn(203) * 0.1
+    ls = torch.tensor(0.7)
+    bc, lc = bias.clone().requires_grad_(True), ls.clone().requires_grad_(True)
+    xc = x.clone().requires_grad_(True)
+    w = torch.randn_like(x)
+    yo = Z.bias_norm(xc, bc, lc, Z.Ctl(False))
+    (yo * w).sum().backward()
+    bg, lg = bias.to(dev).requires_grad_(True), ls.to(dev).requires_grad_(True)
+    xg = x.to(dev).requires_grad_(True)
+    y = zk.bias_norm(xg, bg, lg)
+    (y * w.to(dev)).sum().backward()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), yo.detach().numpy(), atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xc.grad.numpy(), atol=1e-5, rtol=1e-4)
+    np.testing.assert_allclose(bg.grad.cpu().numpy(), bc.grad.numpy(), atol=1e-3, rtol=1e-3)
+    np.testing.assert_allclose(lg.grad.item(), lc.grad.item(), rtol=1e-4)
