@@ -114,6 +114,20 @@ int s2t_zipconv_bwd(const float* u, long ld, int gate_off, const unsigned char* 
                     const float* scale, const float* dy, float* du, float* dwc, float* dbc,
                     float* dwk, float* dbk, float* dscale, void* stream);
 
+
+/* ---- relative-position attention weights (model/encoder/zipformer.py:1966-2066).
+ * qkp (T,B,H*(2*qd+pd)) = in_proj output [q | k | p]; pos (2T-1, H*pd) = linear_pos(pos_emb)
+ * or NULL (position term skipped); kpm (B,T) bytes, 1 = padded key; amask (T,T) bytes,
+ * 1 = masked (either may be NULL); W (H,B,T,T) softmax weights.  Backward: delta_ws
+ * (H,B,T) scratch, dqkp (T,B,Dp) fully written, dpos (2T-1,H*pd) ACCUMULATED (zero it). */
+int s2t_relpos_attn_fwd(const float* qkp, const float* pos, const unsigned char* kpm,
+                        const unsigned char* amask, int T, int B, int H, int qd, int pd, float* W,
+                        void* stream);
+int s2t_relpos_attn_bwd(const float* qkp, const float* pos, const unsigned char* kpm,
+                        const unsigned char* amask, int T, int B, int H, int qd, int pd,
+                        const float* W, const float* dW, float* delta_ws, float* dqkp, float* dpos,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

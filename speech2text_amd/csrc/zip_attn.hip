@@ -1,0 +1,415 @@
+// Relative-position multi-head attention weights for gfx950 (zipformer), fused:
+//   s[h,b,i,j] = q[i].k[j] + p[i].pos[(T-1) - i + j]      (rel->abs shift by index arithmetic)
+//   s = -1000 where attn_mask[i][j] or key j is padding ;  W = softmax_j(s)
+// Reference: model/encoder/zipformer.py:1966-2066 (q/k/p split of in_proj, matmul, pos matmul,
+// as_strided rel->abs, two masked_fill(-1000), softmax).  The reference materialises the
+// (H,B,T,T) scores, the (H,B,T,2T-1) position scores and several masked copies; here the only
+// (H,B,T,T) HBM traffic is ONE write of W in forward and ONE read of W and of dW per backward
+// kernel.
+//
+// Layout: qkp (T,B,Dp) = in_proj output, Dp = H*(2*qd+pd): [q: H*qd | k: H*qd | p: H*pd];
+// pos (2T-1, H*pd) = linear_pos(pos_emb); W (H,B,T,T).
+// Forward: workgroup = (64 query rows, b, h); the key tile (<=512 keys) is staged TRANSPOSED
+// in LDS (Kt[d][j], conflict-free across lanes), lanes own keys j = lane + 64 m, each wave
+// register-blocks 4 query rows x 8 keys so every LDS operand feeds 4-8 FMAs; softmax statistics
+// are wave reductions.  One key tile (T <= 512, the 10 s utterances of the benchmark) is a
+// single pass with the scores held in registers; longer sequences use two passes
+// (statistics, then recompute + write) so LDS use is independent of T.
+#include "common.h"
+
+namespace {
+
+constexpr int JT = 512;       // keys per tile
+constexpr int JTP = JT + 1;   // padded LDS row (conflict-free transposed staging)
+constexpr int PWP = JT + 64 + 1;  // padded pos-window row
+constexpr int ROWS = 64;      // query rows per workgroup
+constexpr int MAXQD = 32;
+constexpr int MAXPD = 8;
+
+struct AttnArgs {
+  const float* qkp;   // (T,B,Dp)
+  const float* pos;   // (2T-1, H*pd) or null
+  const unsigned char* kpm;    // (B,T) 1 = padded key, or null
+  const unsigned char* amask;  // (T,T) 1 = masked, or null
+  int T, B, H, qd, pd;
+};
+
+__device__ __forceinline__ const float* q_row(const AttnArgs& a, int t, int b, int h) {
+  return a.qkp + ((long)t * a.B + b) * (a.H * (2 * a.qd + a.pd)) + h * a.qd;
+}
+__device__ __forceinline__ const float* k_row(const AttnArgs& a, int t, int b, int h) {
+  return a.qkp + ((long)t * a.B + b) * (a.H * (2 * a.qd + a.pd)) + a.H * a.qd + h * a.qd;
+}
+__device__ __forceinline__ const float* p_row(const AttnArgs& a, int t, int b, int h) {
+  return a.qkp + ((long)t * a.B + b) * (a.H * (2 * a.qd + a.pd)) + 2 * a.H * a.qd + h * a.pd;
+}
+
+// LDS carve-up shared by the kernels
+struct Smem {
+  float* Kt;    // [qd][JT]
+  float* Pt;    // [pd][JT + ROWS]   pos window, transposed
+  float* Q;     // [ROWS][MAXQD]
+  float* P;     // [ROWS][MAXPD]
+};
+__device__ __forceinline__ Smem carve(unsigned char* raw, int qd, int pd) {
+  Smem s;
+  s.Kt = reinterpret_cast<float*>(raw);
+  s.Pt = s.Kt + qd * JTP;
+  s.Q = s.Pt + pd * PWP;
+  s.P = s.Q + ROWS * MAXQD;
+  return s;
+}
+inline size_t attn_smem(int qd, int pd) {
+  return sizeof(float) * ((size_t)qd * JTP + (size_t)pd * PWP + ROWS * MAXQD + ROWS * MAXPD);
+}
+
+// stage K^T tile (keys j0..j0+JT) and the pos window for (i0, j0)
+__device__ __forceinline__ void stage_tile(const AttnArgs& a, const Smem& s, int b, int h, int i0,
+                                           int j0) {
+  const int qd = a.qd, pd = a.pd;
+  for (int idx = threadIdx.x; idx < JT * qd; idx += blockDim.x) {
+    const int j = idx / qd, d = idx % qd;   // consecutive threads: consecutive d of one key row
+    const int t = j0 + j;
+    s.Kt[d * JTP + j] = t < a.T ? k_row(a, t, b, h)[d] : 0.f;
+  }
+  if (a.pos) {
+    // window entry w <-> rel index (T-1) - (i0 + ROWS-1) + j0 + w
+    const int base = (a.T - 1) - (i0 + ROWS - 1) + j0;
+    for (int idx = threadIdx.x; idx < (JT + ROWS) * pd; idx += blockDim.x) {
+      const int w = idx / pd, d = idx % pd;
+      const int r = base + w;
+      s.Pt[d * PWP + w] = (r >= 0 && r < 2 * a.T - 1) ? a.pos[(long)r * a.H * pd + h * pd + d] : 0.f;
+    }
+  }
+}
+
+// scores of 4 rows (ib..ib+3) x 8 keys per lane for the staged tile
+__device__ __forceinline__ void tile_scores(const AttnArgs& a, const Smem& s, int b, int i0, int ib,
+                                            int j0, int lane, float acc[4][8]) {
+  const int qd = a.qd, pd = a.pd;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc[r][m] = 0.f;
+  for (int d = 0; d < qd; ++d) {
+    float kv[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) kv[m] = s.Kt[d * JTP + lane + 64 * m];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float qv = s.Q[(ib - i0 + r) * MAXQD + d];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) acc[r][m] = fmaf(qv, kv[m], acc[r][m]);
+    }
+  }
+  if (a.pos) {
+    for (int d = 0; d < pd; ++d) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pv = s.P[(ib - i0 + r) * MAXPD + d];
+        const int off = (ROWS - 1) - (ib - i0 + r) + lane;
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+          acc[r][m] = fmaf(pv, s.Pt[d * PWP + off + 64 * m], acc[r][m]);
+      }
+    }
+  }
+  // masks (-1000 replaces the score) and out-of-range keys (-inf: no contribution)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = ib + r;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int j = j0 + lane + 64 * m;
+      if (j >= a.T || i >= a.T) {
+        acc[r][m] = S2T_NEG_INF;
+      } else if ((a.kpm && a.kpm[(long)b * a.T + j]) || (a.amask && a.amask[(long)i * a.T + j])) {
+        acc[r][m] = -1000.f;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void stage_rows(const AttnArgs& a, const Smem& s, int b, int h, int i0) {
+  for (int idx = threadIdx.x; idx < ROWS * a.qd; idx += blockDim.x) {
+    const int r = idx / a.qd, d = idx % a.qd;
+    s.Q[r * MAXQD + d] = (i0 + r < a.T) ? q_row(a, i0 + r, b, h)[d] : 0.f;
+  }
+  for (int idx = threadIdx.x; idx < ROWS * a.pd; idx += blockDim.x) {
+    const int r = idx / a.pd, d = idx % a.pd;
+    s.P[r * MAXPD + d] = (i0 + r < a.T) ? p_row(a, i0 + r, b, h)[d] : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a, float* __restrict__ W) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const Smem s = carve(smem_raw, a.qd, a.pd);
+  const int i0 = blockIdx.x * ROWS, b = blockIdx.y, h = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ntiles = (a.T + JT - 1) / JT;
+  stage_rows(a, s, b, h, i0);
+  float* Wb = W + ((long)h * a.B + b) * a.T * a.T;
+  float rmax[4][4], rsum[4][4];   // [group][row] running statistics (multi-tile case)
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      rmax[g][r] = S2T_NEG_INF;
+      rsum[g][r] = 0.f;
+    }
+  for (int pass = 0; pass < (ntiles == 1 ? 1 : 2); ++pass) {
+    for (int tile = 0; tile < ntiles; ++tile) {
+      const int j0 = tile * JT;
+      __syncthreads();
+      stage_tile(a, s, b, h, i0, j0);
+      __syncthreads();
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int ib = i0 + wave * 16 + g * 4;
+        if (ib >= a.T) continue;
+        float acc[4][8];
+        tile_scores(a, s, b, i0, ib, j0, lane, acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (pass == 0) {
+            float m = acc[r][0];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) m = fmaxf(m, acc[r][q]);
+            m = wave_max(m);
+            const float mnew = fmaxf(rmax[g][r], m);
+            float e = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) e += (acc[r][q] == S2T_NEG_INF) ? 0.f : __expf(acc[r][q] - mnew);
+            e = wave_sum(e);
+            rsum[g][r] = rsum[g][r] * ((rmax[g][r] == S2T_NEG_INF) ? 0.f : __expf(rmax[g][r] - mnew)) + e;
+            rmax[g][r] = mnew;
+          }
+          if (pass == 1 || ntiles == 1) {
+            const int i = ib + r;
+            if (i < a.T) {
+              const float inv = 1.f / rsum[g][r], mx = rmax[g][r];
+#pragma unroll
+              for (int q = 0; q < 8; ++q) {
+                const int j = j0 + lane + 64 * q;
+                if (j < a.T) Wb[(long)i * a.T + j] = __expf(acc[r][q] - mx) * inv;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- backward
+// dS_ij = W_ij (dW_ij - delta_i) on unmasked entries, delta_i = sum_j W_ij dW_ij.
+// bwd_q: workgroup = (64 rows, b, h): delta, dq_i = sum_j dS_ij k_j, dp_i = sum_j dS_ij pos[rel].
+//        thread = (row = tid/4, dgrp = tid%4) accumulates qd/4 dims of dq and one dim of dp.
+__global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a, const float* __restrict__ W,
+                                                         const float* __restrict__ dW,
+                                                         float* __restrict__ delta,
+                                                         float* __restrict__ dqkp) {
+  constexpr int JC = 64;   // key chunk
+  __shared__ float s_dS[ROWS][JC + 1];
+  __shared__ float s_K[JC][MAXQD + 1];
+  __shared__ float s_pos[MAXPD][JC + ROWS];
+  __shared__ float s_delta[ROWS];
+  const int i0 = blockIdx.x * ROWS, b = blockIdx.y, h = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* Wb = W + ((long)h * a.B + b) * a.T * a.T;
+  const float* dWb = dW + ((long)h * a.B + b) * a.T * a.T;
+  // pass 0: delta for the 64 rows (wave per row, coalesced)
+  for (int r = wave; r < ROWS; r += 4) {
+    const int i = i0 + r;
+    float acc = 0.f;
+    if (i < a.T)
+      for (int j = lane; j < a.T; j += 64) acc = fmaf(Wb[(long)i * a.T + j], dWb[(long)i * a.T + j], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      s_delta[r] = acc;
+      if (i < a.T) delta[((long)h * a.B + b) * a.T + i] = acc;
+    }
+  }
+  __syncthreads();
+  const int row = tid >> 2, dg = tid & 3;
+  const int qd = a.qd, pd = a.pd;
+  const int dper = (qd + 3) / 4;   // dims of dq per thread (<= 8)
+  float accq[8];
+#pragma unroll
+  for (int d = 0; d < 8; ++d) accq[d] = 0.f;
+  float accp0 = 0.f, accp1 = 0.f;  // pos dims dg and dg+4
+  for (int j0 = 0; j0 < a.T; j0 += JC) {
+    __syncthreads();
+    // stage dS chunk (coalesced over j), K chunk, pos window
+    for (int idx = tid; idx < ROWS * JC; idx += 256) {
+      const int r = idx / JC, jj = idx % JC;
+      const int i = i0 + r, j = j0 + jj;
+      float v = 0.f;
+      if (i < a.T && j < a.T) {
+        const bool masked = (a.kpm && a.kpm[(long)b * a.T + j]) || (a.amask && a.amask[(long)i * a.T + j]);
+        if (!masked) {
+          const float w = Wb[(long)i * a.T + j];
+          v = w * (dWb[(long)i * a.T + j] - s_delta[r]);
+        }
+      }
+      s_dS[r][jj] = v;
+    }
+    for (int idx = tid; idx < JC * qd; idx += 256) {
+      const int jj = idx / qd, d = idx % qd;
+      s_K[jj][d] = (j0 + jj < a.T) ? k_row(a, j0 + jj, b, h)[d] : 0.f;
+    }
+    if (a.pos) {
+      const int base = (a.T - 1) - (i0 + ROWS - 1) + j0;
+      for (int idx = tid; idx < (JC + ROWS) * pd; idx += 256) {
+        const int w = idx / pd, d = idx % pd;
+        const int r = base + w;
+        s_pos[d][w] = (r >= 0 && r < 2 * a.T - 1) ? a.pos[(long)r * a.H * pd + h * pd + d] : 0.f;
+      }
+    }
+    __syncthreads();
+    for (int jj = 0; jj < JC; ++jj) {
+      const float ds = s_dS[row][jj];
+#pragma unroll
+      for (int d = 0; d < 8; ++d)
+        if (d < dper) accq[d] = fmaf(ds, s_K[jj][dg * dper + d], accq[d]);
+      if (a.pos) {
+        const int w = (ROWS - 1) - row + jj;
+        if (dg < pd) accp0 = fmaf(ds, s_pos[dg][w], accp0);
+        if (dg + 4 < pd) accp1 = fmaf(ds, s_pos[dg + 4][w], accp1);
+      }
+    }
+  }
+  const int i = i0 + row;
+  if (i < a.T) {
+    float* o = dqkp + ((long)i * a.B + b) * (a.H * (2 * qd + pd));
+    for (int d = 0; d < dper; ++d)
+      if (dg * dper + d < qd) o[h * qd + dg * dper + d] = accq[d];
+    if (dg < pd) o[2 * a.H * qd + h * pd + dg] = a.pos ? accp0 : 0.f;
+    if (dg + 4 < pd) o[2 * a.H * qd + h * pd + dg + 4] = a.pos ? accp1 : 0.f;
+  }
+}
+
+// bwd_k: workgroup = (64 keys, b, h): dk_j = sum_i dS_ij q_i ; dpos[rel] += sum dS_ij p_i
+__global__ __launch_bounds__(256) void attn_bwd_k_kernel(AttnArgs a, const float* __restrict__ W,
+                                                         const float* __restrict__ dW,
+                                                         const float* __restrict__ delta,
+                                                         float* __restrict__ dqkp,
+                                                         float* __restrict__ dpos) {
+  constexpr int IC = 64;   // query chunk
+  __shared__ float s_dS[IC][ROWS + 1];       // [i][j]
+  __shared__ float s_Q[IC][MAXQD + 1];
+  __shared__ float s_P[IC][MAXPD];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* s_acc = reinterpret_cast<float*>(smem_raw);   // [pd][T + ROWS]: dpos for rel = j0 + u
+  const int j0 = blockIdx.x * ROWS, b = blockIdx.y, h = blockIdx.z;
+  const int tid = threadIdx.x;
+  const float* Wb = W + ((long)h * a.B + b) * a.T * a.T;
+  const float* dWb = dW + ((long)h * a.B + b) * a.T * a.T;
+  const float* dl = delta + ((long)h * a.B + b) * a.T;
+  const int col = tid >> 2, dg = tid & 3;
+  const int qd = a.qd, pd = a.pd;
+  const int dper = (qd + 3) / 4;
+  float acck[8];
+#pragma unroll
+  for (int d = 0; d < 8; ++d) acck[d] = 0.f;
+  const int accw = a.T + ROWS;
+  if (dpos)
+    for (int idx = tid; idx < accw * pd; idx += 256) s_acc[idx] = 0.f;
+  for (int i0 = 0; i0 < a.T; i0 += IC) {
+    __syncthreads();
+    for (int idx = tid; idx < IC * ROWS; idx += 256) {
+      const int ii = idx / ROWS, jj = idx % ROWS;
+      const int i = i0 + ii, j = j0 + jj;
+      float v = 0.f;
+      if (i < a.T && j < a.T) {
+        const bool masked = (a.kpm && a.kpm[(long)b * a.T + j]) || (a.amask && a.amask[(long)i * a.T + j]);
+        if (!masked) v = Wb[(long)i * a.T + j] * (dWb[(long)i * a.T + j] - dl[i]);
+      }
+      s_dS[ii][jj] = v;
+    }
+    for (int idx = tid; idx < IC * qd; idx += 256) {
+      const int ii = idx / qd, d = idx % qd;
+      s_Q[ii][d] = (i0 + ii < a.T) ? q_row(a, i0 + ii, b, h)[d] : 0.f;
+    }
+    for (int idx = tid; idx < IC * pd; idx += 256) {
+      const int ii = idx / pd, d = idx % pd;
+      s_P[ii][d] = (i0 + ii < a.T) ? p_row(a, i0 + ii, b, h)[d] : 0.f;
+    }
+    __syncthreads();
+    for (int ii = 0; ii < IC; ++ii) {
+      const float ds = s_dS[ii][col];
+#pragma unroll
+      for (int d = 0; d < 8; ++d)
+        if (d < dper) acck[d] = fmaf(ds, s_Q[ii][dg * dper + d], acck[d]);
+    }
+    if (dpos) {
+      // diagonals of the chunk: w = (IC-1) - ii + jj in [0, IC+ROWS-2]; thread per (w, dim)
+      for (int idx = tid; idx < (IC + ROWS - 1) * pd; idx += 256) {
+        const int w = idx / pd, d = idx % pd;
+        float acc = 0.f;
+        const int ii_lo = max(0, (IC - 1) - w), ii_hi = min(IC - 1, (IC - 1) - w + ROWS - 1);
+        for (int ii = ii_lo; ii <= ii_hi; ++ii) acc = fmaf(s_dS[ii][w - (IC - 1) + ii], s_P[ii][d], acc);
+        // u = rel - j0 = (T-1) - (i0 + IC-1) + w ; one thread per (u,d): no LDS atomics needed
+        const int u = (a.T - 1) - (i0 + IC - 1) + w;
+        if (u >= 0 && u < accw) s_acc[d * accw + u] += acc;
+      }
+    }
+  }
+  if (dpos) {
+    __syncthreads();
+    for (int idx = tid; idx < accw * pd; idx += 256) {
+      const int d = idx / accw, u = idx % accw;
+      const int r = j0 + u;
+      const float v = s_acc[idx];
+      if (r < 2 * a.T - 1 && v != 0.f) atomicAdd(&dpos[(long)r * a.H * pd + h * pd + d], v);
+    }
+  }
+  const int j = j0 + col;
+  if (j < a.T) {
+    float* o = dqkp + ((long)j * a.B + b) * (a.H * (2 * qd + pd)) + a.H * qd + h * qd;
+    for (int d = 0; d < dper; ++d)
+      if (dg * dper + d < qd) o[dg * dper + d] = acck[d];
+  }
+}
+
+}  // namespace
+
+extern "C" int s2t_relpos_attn_fwd(const float* qkp, const float* pos, const unsigned char* kpm,
+                                   const unsigned char* amask, int T, int B, int H, int qd, int pd,
+                                   float* W, void* stream) {
+  if (T <= 0 || B <= 0 || H <= 0) return 0;
+  if (qd <= 0 || qd > MAXQD || pd < 0 || pd > MAXPD) return -1;
+  AttnArgs a{qkp, pos, kpm, amask, T, B, H, qd, pd};
+  dim3 grid((T + ROWS - 1) / ROWS, B, H);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), attn_smem(qd, pd), (hipStream_t)stream, a,
+                     W);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+// dqkp (T,B,Dp) is fully written (q, k and p parts); dpos (2T-1, H*pd) must be zeroed by the
+// caller (accumulated with atomics) or NULL when the position term was skipped.
+extern "C" int s2t_relpos_attn_bwd(const float* qkp, const float* pos, const unsigned char* kpm,
+                                   const unsigned char* amask, int T, int B, int H, int qd, int pd,
+                                   const float* W, const float* dW, float* delta_ws, float* dqkp,
+                                   float* dpos, void* stream) {
+  if (T <= 0 || B <= 0 || H <= 0) return 0;
+  if (qd <= 0 || qd > MAXQD || pd < 0 || pd > MAXPD) return -1;
+  AttnArgs a{qkp, pos, kpm, amask, T, B, H, qd, pd};
+  dim3 grid((T + ROWS - 1) / ROWS, B, H);
+  hipLaunchKernelGGL(attn_bwd_q_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, W, dW,
+                     delta_ws, dqkp);
+  S2T_CHECK_LAUNCH();
+  const size_t sm = pos ? sizeof(float) * (size_t)(T + ROWS) * pd : 0;
+  if (sm > 96 * 1024) return -1;
+  hipLaunchKernelGGL(attn_bwd_k_kernel, grid, dim3(256), sm, (hipStream_t)stream, a, W, dW,
+                     delta_ws, dqkp, pos ? dpos : nullptr);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}

@@ -303,11 +303,50 @@ def glu_chunk_causal_dwconv(u, gate_off, key_padding_mask, conv, chunk_size):
 
 
 # ------------------------------------------------------------------ attention
+class _RelPosAttn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkp, pos_proj, kpm, amask, H, qd, pd):
+        _dev(qkp, pos_proj)
+        qkp = qkp.contiguous().float()
+        T, B, _ = qkp.shape
+        pos = None if pos_proj is None else pos_proj.contiguous().float()
+        k8 = None if kpm is None else kpm.to(torch.uint8).contiguous()
+        a8 = None if amask is None else amask.to(torch.uint8).contiguous()
+        W = torch.empty((H, B, T, T), dtype=torch.float32, device=qkp.device)
+        N.profile_note("s2t_relpos_attn_fwd", 4.0 * (qkp.numel() + W.numel()))
+        N.check(N.lib().s2t_relpos_attn_fwd(N.fp(qkp), N.fp(pos), N.ptr(k8), N.ptr(a8), T, B, H,
+                                            qd, pd, N.fp(W), N.stream()), "s2t_relpos_attn_fwd")
+        ctx.save_for_backward(qkp, pos, k8, a8, W)
+        ctx.cfg = (H, qd, pd)
+        return W
+
+    @staticmethod
+    def backward(ctx, dW):
+        qkp, pos, k8, a8, W = ctx.saved_tensors
+        H, qd, pd = ctx.cfg
+        T, B, _ = qkp.shape
+        dW = dW.contiguous().float()
+        dev = qkp.device
+        delta = torch.empty((H, B, T), dtype=torch.float32, device=dev)
+        dqkp = torch.empty_like(qkp)
+        dpos = None if pos is None else torch.zeros_like(pos)
+        N.check(N.lib().s2t_relpos_attn_bwd(N.fp(qkp), N.fp(pos), N.ptr(k8), N.ptr(a8), T, B, H, qd,
+                                            pd, N.fp(W), N.fp(dW), N.fp(delta), N.fp(dqkp),
+                                            N.fp(dpos), N.stream()), "s2t_relpos_attn_bwd")
+        return dqkp, dpos, None, None, None, None, None
+
+
 def relpos_attention_weights(qkp, pos_proj, num_heads, query_head_dim, pos_head_dim, attn_mask,
                              key_padding_mask, penalize=None):
     """qkp (T,B,H*(2*qd+pd)) = in_proj(x); pos_proj (2T-1, H*pd) = linear_pos(pos_emb) or None
     -> softmax weights (H,B,T,T).  scores[h,b,i,j] = q_i.k_j + p_i.pos[(T-1)-i+j]; masked
-    entries are set to -1000 (reference zipformer.py:1966-2066)."""
+    entries are set to -1000 (reference zipformer.py:1966-2066).   HIP: zip_attn.hip.
+    `penalize` (the reference's 10%-of-calls penalize_abs_values_gt on the raw scores, a
+    backward-only term) needs the raw scores as an autograd node, so that branch keeps the
+    materialised torch composition."""
+    if penalize is None:
+        return _RelPosAttn.apply(qkp, pos_proj, key_padding_mask, attn_mask, num_heads,
+                                 query_head_dim, pos_head_dim)
     T, B, _ = qkp.shape
     H, qd, pd = num_heads, query_head_dim, pos_head_dim
     q = qkp[..., :H * qd].reshape(T, B, H, qd).permute(2, 1, 0, 3)
@@ -320,8 +359,7 @@ def relpos_attention_weights(qkp, pos_proj, num_heads, query_head_dim, pos_head_
         ps = ps.as_strided((H, B, T, T), (ps.stride(0), ps.stride(1), ps.stride(2) - ps.stride(3),
                                           ps.stride(3)), storage_offset=ps.stride(3) * (T - 1))
         scores = scores + ps
-    if penalize is not None:
-        scores = penalize(scores)
+    scores = penalize(scores)
     if attn_mask is not None:
         scores = scores.masked_fill(attn_mask, -1000)
     if key_padding_mask is not None:

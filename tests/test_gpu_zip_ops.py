@@ -105,3 +105,55 @@ def test_swoosh_and_biasnorm(dev, is_l):
     np.testing.assert_allclose(xg.grad.cpu().numpy(), xc.grad.numpy(), atol=1e-5, rtol=1e-4)
     np.testing.assert_allclose(bg.grad.cpu().numpy(), bc.grad.numpy(), atol=1e-3, rtol=1e-3)
     np.testing.assert_allclose(lg.grad.item(), lc.grad.item(), rtol=1e-4)
+
+
+def _attn_ref(qkp, pos, H, qd, pd, amask, kpm):
+    T, B, _ = qkp.shape
+    q = qkp[..., :H * qd].reshape(T, B, H, qd).permute(2, 1, 0, 3)
+    k = qkp[..., H * qd:2 * H * qd].reshape(T, B, H, qd).permute(2, 1, 3, 0)
+    p = qkp[..., 2 * H * qd:].reshape(T, B, H, pd).permute(2, 1, 0, 3)
+    s = torch.matmul(q, k)
+    if pos is not None:
+        pe = pos.reshape(1, 2 * T - 1, H, pd).permute(2, 0, 3, 1)
+        ps = torch.matmul(p, pe)
+        idx = (T - 1) - torch.arange(T).unsqueeze(1) + torch.arange(T).unsqueeze(0)
+        s = s + ps[:, :, torch.arange(T).unsqueeze(1), idx]
+    if amask is not None:
+        s = s.masked_fill(amask, -1000)
+    if kpm is not None:
+        s = s.masked_fill(kpm.unsqueeze(1), -1000)
+    return s.softmax(dim=-1)
+
+
+@pytest.mark.parametrize("T,B,H,qd,pd,use_pos,use_am", [
+    (50, 2, 4, 8, 4, True, True), (130, 3, 8, 32, 4, True, False), (64, 2, 2, 16, 4, True, True),
+    (530, 2, 2, 32, 4, True, False), (1, 2, 2, 8, 4, True, False), (77, 2, 4, 24, 4, False, True),
+    (200, 2, 4, 32, 8, True, True)])
+def test_relpos_attention_weights(dev, T, B, H, qd, pd, use_pos, use_am):
+    from speech2text_amd import zip_kernels as zk
+    torch.manual_seed(T)
+    Dp = H * (2 * qd + pd)
+    qkp = torch.randn(T, B, Dp, dtype=torch.float64) * 0.7
+    pos = torch.randn(2 * T - 1, H * pd, dtype=torch.float64) if use_pos else None
+    lens = torch.randint(max(1, T // 2), T + 1, (B,)); lens[0] = T
+    kpm = torch.arange(T).unsqueeze(0) >= lens.unsqueeze(1)
+    amask = None
+    if use_am:
+        c = torch.arange(T) // 16
+        amask = torch.logical_or(c.unsqueeze(0) > c.unsqueeze(1), c.unsqueeze(0) < c.unsqueeze(1) - 2)
+    wts = torch.randn(H, B, T, T, dtype=torch.float64)
+    qc = qkp.clone().requires_grad_(True)
+    pc = pos.clone().requires_grad_(True) if use_pos else None
+    Wr = _attn_ref(qc, pc, H, qd, pd, amask, kpm)
+    (Wr * wts).sum().backward()
+    qg = qkp.float().to(dev).requires_grad_(True)
+    pg = pos.float().to(dev).requires_grad_(True) if use_pos else None
+    W = zk.relpos_attention_weights(qg, pg, H, qd, pd, None if amask is None else amask.to(dev),
+                                    kpm.to(dev))
+    (W * wts.float().to(dev)).sum().backward()
+    np.testing.assert_allclose(W.detach().cpu().numpy(), Wr.detach().numpy(), atol=2e-6, rtol=2e-4)
+    gq = qc.grad.numpy()
+    np.testing.assert_allclose(qg.grad.cpu().numpy(), gq, atol=3e-5 * max(1.0, np.abs(gq).max()), rtol=2e-3)
+    if use_pos:
+        gp = pc.grad.numpy()
+        np.testing.assert_allclose(pg.grad.cpu().numpy(), gp, atol=3e-5 * max(1.0, np.abs(gp).max()), rtol=2e-3)
