@@ -19,9 +19,11 @@
 
 namespace {
 
-constexpr int JT = 512;       // keys per tile
-constexpr int JTP = JT + 1;   // padded LDS row (conflict-free transposed staging)
-constexpr int PWP = JT + 64 + 1;  // padded pos-window row
+// keys per tile = 64 * NM (NM = keys per lane, chosen from T); LDS rows are padded by one
+// float so that the transposed staging writes are bank-conflict free
+#define JT (64 * NM)
+#define JTP (JT + 1)
+#define PWP (JT + 64 + 1)
 constexpr int ROWS = 64;      // query rows per workgroup
 constexpr int MAXQD = 32;
 constexpr int MAXPD = 8;
@@ -51,6 +53,7 @@ struct Smem {
   float* Q;     // [ROWS][MAXQD]
   float* P;     // [ROWS][MAXPD]
 };
+template <int NM>
 __device__ __forceinline__ Smem carve(unsigned char* raw, int qd, int pd) {
   Smem s;
   s.Kt = reinterpret_cast<float*>(raw);
@@ -59,47 +62,69 @@ __device__ __forceinline__ Smem carve(unsigned char* raw, int qd, int pd) {
   s.P = s.Q + ROWS * MAXQD;
   return s;
 }
+template <int NM>
 inline size_t attn_smem(int qd, int pd) {
   return sizeof(float) * ((size_t)qd * JTP + (size_t)pd * PWP + ROWS * MAXQD + ROWS * MAXPD);
 }
 
-// stage K^T tile (keys j0..j0+JT) and the pos window for (i0, j0)
+// stage K^T tile (keys j0..j0+JT) and the pos window for (i0, j0).  (j,d) are advanced
+// incrementally: no per-element integer division.
+template <int NM>
 __device__ __forceinline__ void stage_tile(const AttnArgs& a, const Smem& s, int b, int h, int i0,
                                            int j0) {
   const int qd = a.qd, pd = a.pd;
-  for (int idx = threadIdx.x; idx < JT * qd; idx += blockDim.x) {
-    const int j = idx / qd, d = idx % qd;   // consecutive threads: consecutive d of one key row
-    const int t = j0 + j;
-    s.Kt[d * JTP + j] = t < a.T ? k_row(a, t, b, h)[d] : 0.f;
+  {
+    int j = threadIdx.x / qd, d = threadIdx.x % qd;
+    const int dj = 256 / qd, dd = 256 % qd;
+    const long rs = (long)a.B * (a.H * (2 * qd + pd));
+    const float* kb = k_row(a, 0, b, h);
+    while (j < JT) {
+      const int t = j0 + j;
+      s.Kt[d * JTP + j] = t < a.T ? kb[(long)t * rs + d] : 0.f;
+      j += dj;
+      d += dd;
+      if (d >= qd) {
+        d -= qd;
+        ++j;
+      }
+    }
   }
   if (a.pos) {
     // window entry w <-> rel index (T-1) - (i0 + ROWS-1) + j0 + w
     const int base = (a.T - 1) - (i0 + ROWS - 1) + j0;
-    for (int idx = threadIdx.x; idx < (JT + ROWS) * pd; idx += blockDim.x) {
-      const int w = idx / pd, d = idx % pd;
+    int w = threadIdx.x / pd, d = threadIdx.x % pd;
+    const int dw = 256 / pd, dd = 256 % pd;
+    while (w < JT + ROWS) {
       const int r = base + w;
       s.Pt[d * PWP + w] = (r >= 0 && r < 2 * a.T - 1) ? a.pos[(long)r * a.H * pd + h * pd + d] : 0.f;
+      w += dw;
+      d += dd;
+      if (d >= pd) {
+        d -= pd;
+        ++w;
+      }
     }
   }
 }
 
-// scores of 4 rows (ib..ib+3) x 8 keys per lane for the staged tile
+// scores of 4 rows (ib..ib+3) x NM keys per lane for the staged tile
+template <int NM>
 __device__ __forceinline__ void tile_scores(const AttnArgs& a, const Smem& s, int b, int i0, int ib,
-                                            int j0, int lane, float acc[4][8]) {
+                                            int j0, int lane, float acc[4][NM]) {
   const int qd = a.qd, pd = a.pd;
 #pragma unroll
   for (int r = 0; r < 4; ++r)
 #pragma unroll
-    for (int m = 0; m < 8; ++m) acc[r][m] = 0.f;
+    for (int m = 0; m < NM; ++m) acc[r][m] = 0.f;
   for (int d = 0; d < qd; ++d) {
-    float kv[8];
+    float kv[NM];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) kv[m] = s.Kt[d * JTP + lane + 64 * m];
+    for (int m = 0; m < NM; ++m) kv[m] = s.Kt[d * JTP + lane + 64 * m];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float qv = s.Q[(ib - i0 + r) * MAXQD + d];
 #pragma unroll
-      for (int m = 0; m < 8; ++m) acc[r][m] = fmaf(qv, kv[m], acc[r][m]);
+      for (int m = 0; m < NM; ++m) acc[r][m] = fmaf(qv, kv[m], acc[r][m]);
     }
   }
   if (a.pos) {
@@ -109,7 +134,7 @@ __device__ __forceinline__ void tile_scores(const AttnArgs& a, const Smem& s, in
         const float pv = s.P[(ib - i0 + r) * MAXPD + d];
         const int off = (ROWS - 1) - (ib - i0 + r) + lane;
 #pragma unroll
-        for (int m = 0; m < 8; ++m)
+        for (int m = 0; m < NM; ++m)
           acc[r][m] = fmaf(pv, s.Pt[d * PWP + off + 64 * m], acc[r][m]);
       }
     }
@@ -119,7 +144,7 @@ __device__ __forceinline__ void tile_scores(const AttnArgs& a, const Smem& s, in
   for (int r = 0; r < 4; ++r) {
     const int i = ib + r;
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
+    for (int m = 0; m < NM; ++m) {
       const int j = j0 + lane + 64 * m;
       if (j >= a.T || i >= a.T) {
         acc[r][m] = S2T_NEG_INF;
@@ -141,9 +166,10 @@ __device__ __forceinline__ void stage_rows(const AttnArgs& a, const Smem& s, int
   }
 }
 
+template <int NM>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a, float* __restrict__ W) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const Smem s = carve(smem_raw, a.qd, a.pd);
+  const Smem s = carve<NM>(smem_raw, a.qd, a.pd);
   const int i0 = blockIdx.x * ROWS, b = blockIdx.y, h = blockIdx.z;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ntiles = (a.T + JT - 1) / JT;
@@ -161,25 +187,25 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a, float* __rest
     for (int tile = 0; tile < ntiles; ++tile) {
       const int j0 = tile * JT;
       __syncthreads();
-      stage_tile(a, s, b, h, i0, j0);
+      stage_tile<NM>(a, s, b, h, i0, j0);
       __syncthreads();
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int ib = i0 + wave * 16 + g * 4;
         if (ib >= a.T) continue;
-        float acc[4][8];
-        tile_scores(a, s, b, i0, ib, j0, lane, acc);
+        float acc[4][NM];
+        tile_scores<NM>(a, s, b, i0, ib, j0, lane, acc);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           if (pass == 0) {
             float m = acc[r][0];
 #pragma unroll
-            for (int q = 1; q < 8; ++q) m = fmaxf(m, acc[r][q]);
+            for (int q = 1; q < NM; ++q) m = fmaxf(m, acc[r][q]);
             m = wave_max(m);
             const float mnew = fmaxf(rmax[g][r], m);
             float e = 0.f;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) e += (acc[r][q] == S2T_NEG_INF) ? 0.f : __expf(acc[r][q] - mnew);
+            for (int q = 0; q < NM; ++q) e += (acc[r][q] == S2T_NEG_INF) ? 0.f : __expf(acc[r][q] - mnew);
             e = wave_sum(e);
             rsum[g][r] = rsum[g][r] * ((rmax[g][r] == S2T_NEG_INF) ? 0.f : __expf(rmax[g][r] - mnew)) + e;
             rmax[g][r] = mnew;
@@ -189,7 +215,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a, float* __rest
             if (i < a.T) {
               const float inv = 1.f / rsum[g][r], mx = rmax[g][r];
 #pragma unroll
-              for (int q = 0; q < 8; ++q) {
+              for (int q = 0; q < NM; ++q) {
                 const int j = j0 + lane + 64 * q;
                 if (j < a.T) Wb[(long)i * a.T + j] = __expf(acc[r][q] - mx) * inv;
               }
@@ -383,12 +409,17 @@ extern "C" int s2t_relpos_attn_fwd(const float* qkp, const float* pos, const uns
   dim3 grid((T + ROWS - 1) / ROWS, B, H);
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<8>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), attn_smem(qd, pd), (hipStream_t)stream, a,
-                     W);
+  hipStream_t st = (hipStream_t)stream;
+  if (T <= 128)
+    hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, dim3(256), attn_smem<2>(qd, pd), st, a, W);
+  else if (T <= 256)
+    hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, dim3(256), attn_smem<4>(qd, pd), st, a, W);
+  else
+    hipLaunchKernelGGL(attn_fwd_kernel<8>, grid, dim3(256), attn_smem<8>(qd, pd), st, a, W);
   S2T_CHECK_LAUNCH();
   return 0;
 }

@@ -44,6 +44,7 @@ class ScaledAdam(Optimizer):
         P = group["size_update_period"]
         lens = st.seg_lengths.to(torch.float32)
         s = dict(store=st, step=0, lens=lens, scalar=(st.seg_lengths == 1),
+                 has_scalar=any(n == 1 for n in st.lengths),
                  delta=torch.zeros(st.numel, device=dev),
                  exp_avg_sq=torch.zeros(st.numel, device=dev),
                  scale_exp_avg_sq=torch.zeros(n, device=dev),
@@ -145,7 +146,7 @@ class ScaledAdam(Optimizer):
         denom = (eas / bc_vec[seg]).sqrt_().add_(eps)
         delta.add_(g / denom * coef[seg])
         # scalar parameters are clamped before the update, as in the reference
-        if bool(scalar.any()):
+        if s["has_scalar"]:
             lim = torch.where(scalar, torch.full_like(s["lens"], group["scalar_max"]),
                               torch.full_like(s["lens"], float("inf")))[seg]
             torch.minimum(p, lim, out=p)

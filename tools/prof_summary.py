@@ -1,0 +1,36 @@
+"""Summarise a rocprofv3 --kernel-trace --stats (csv) output directory into profiles/."""
+import collections, csv, glob, os, sys
+
+
+def main(src, tag, steps, ms_per_step):
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    os.makedirs(out, exist_ok=True)
+    stats = glob.glob(os.path.join(src, "**", "*_kernel_stats.csv"), recursive=True)[0]
+    rows = list(csv.DictReader(open(stats)))
+    with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        for r in rows[:80]:
+            w.writerow(r)
+    trace = glob.glob(os.path.join(src, "**", "*_kernel_trace.csv"), recursive=True)[0]
+    tr = list(csv.DictReader(open(trace)))
+    tend = max(int(r["End_Timestamp"]) for r in tr)
+    win = steps * ms_per_step * 1e6
+    sel = [r for r in tr if int(r["Start_Timestamp"]) >= tend - win]
+    agg = collections.defaultdict(lambda: [0, 0])
+    for r in sel:
+        a = agg[r["Kernel_Name"]]
+        a[0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        a[1] += 1
+    tot = sum(a[0] for a in agg.values())
+    with open(os.path.join(out, f"{tag}_timed_region.txt"), "w") as f:
+        f.write(f"# kernels whose start lies in the last {steps} steps ({ms_per_step:.1f} ms each) of the trace\n")
+        f.write(f"# GPU busy {tot/steps/1e6:.2f} ms/step, {len(sel)/steps:.0f} launches/step\n")
+        for k, (d, n) in sorted(agg.items(), key=lambda x: -x[1][0])[:70]:
+            f.write(f"{d/steps/1e6:8.3f} ms/step {100*d/tot:5.1f}% {n/steps:8.1f} calls/step "
+                    f"{d/n/1e3:9.1f} us avg  {k[:140]}\n")
+    print("wrote", out)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]), float(sys.argv[4]))
