@@ -112,7 +112,8 @@ int s2t_zipconv_fwd(const float* u, long ld, int gate_off, const unsigned char* 
 int s2t_zipconv_bwd(const float* u, long ld, int gate_off, const unsigned char* mask, int T, int B,
                     int C, int K, int chunk, const float* wc, const float* wk, const float* bk,
                     const float* scale, const float* dy, float* du, float* dwc, float* dbc,
-                    float* dwk, float* dbk, float* dscale, void* stream);
+                    float* dwk, float* dbk, float* dscale, float* workspace, void* stream);
+long s2t_zipconv_bwd_workspace_floats(int T, int B, int C, int K);
 
 
 /* ---- relative-position attention weights (model/encoder/zipformer.py:1966-2066).
@@ -127,6 +128,13 @@ int s2t_relpos_attn_bwd(const float* qkp, const float* pos, const unsigned char*
                         const unsigned char* amask, int T, int B, int H, int qd, int pd,
                         const float* W, const float* dW, float* delta_ws, float* dqkp, float* dpos,
                         void* stream);
+
+
+/* ---- BEST-RQ labels (model/ssl/best_rq.py:168-217,259-294): stack 9 taps (kernel (3,3),
+ * stride (2,2)) -> projection (F*9 -> D) -> nearest code (cosine == euclidean on normalised
+ * vectors), label = index + 1, first index on ties.  fp64 internally; bit-exact integer output. */
+int s2t_bestrq_labels(const float* feats, int B, int T, int F, const float* proj, int D,
+                      const float* codebooks, int ncb, int K, int T2, long* labels, void* stream);
 
 #ifdef __cplusplus
 }

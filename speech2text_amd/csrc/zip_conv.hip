@@ -80,8 +80,10 @@ __device__ __forceinline__ void stage_xg(const ConvArgs& a, int b, int t0, int c
   }
 }
 
-template <int K>
-__global__ __launch_bounds__(256) void zipconv_fwd_kernel(ConvArgs a, float* __restrict__ y) {
+template <int K, int MODE, bool GEN>
+__global__ __launch_bounds__(256) void zipconv_fwd_kernel(ConvArgs a, float* __restrict__ y,
+                                                          const float* __restrict__ dy,
+                                                          float* __restrict__ dscale) {
   constexpr int Kh = (K + 1) / 2, halo = K / 2, W = FPT + 2 * halo;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* s_x = reinterpret_cast<float*>(smem_raw);
@@ -91,6 +93,12 @@ __global__ __launch_bounds__(256) void zipconv_fwd_kernel(ConvArgs a, float* __r
   float* s_re = s_le + K * 64;
   const int t0 = blockIdx.x * TT, b = blockIdx.y, c0 = blockIdx.z * 64;
   const int c = threadIdx.x & 63, tg = threadIdx.x >> 6;
+  if (MODE == 1) {
+    // only tiles that contain a frame within K of a chunk edge contribute to d(edge scale)
+    const int p0 = t0 % a.chunk;
+    const bool has_edge = (p0 < K) || (p0 + TT - 1 >= a.chunk - K);
+    if (!has_edge) return;
+  }
   stage_weights<K>(a, c0, s_wc, s_wk, s_le, s_re);
   stage_xg<K>(a, b, t0, c0, s_x);
   __syncthreads();
@@ -108,10 +116,7 @@ __global__ __launch_bounds__(256) void zipconv_fwd_kernel(ConvArgs a, float* __r
     acck[i] = bk;
   }
   const int chunk = a.chunk;
-  const bool one_chunk = (tb / chunk) == ((tb + FPT - 1) / chunk) &&
-                         (tb - halo) >= (tb / chunk) * chunk &&
-                         (tb + FPT - 1 + halo) < (tb / chunk + 1) * chunk;
-  if (a.wc) {
+  if (a.wc && MODE == 0) {
 #pragma unroll
     for (int j = 0; j < Kh; ++j) {
       const float w = s_wc[j * 64 + c];
@@ -119,8 +124,8 @@ __global__ __launch_bounds__(256) void zipconv_fwd_kernel(ConvArgs a, float* __r
       for (int i = 0; i < FPT; ++i) accc[i] = fmaf(w, win[i + j], accc[i]);
     }
   }
-  if (one_chunk || chunk >= a.T) {
-    // frames outside [0,T) are zero in the tile, which is exactly the conv's zero padding
+  if (!GEN) {
+    // single chunk: frames outside [0,T) are zero in the tile = the conv's zero padding
 #pragma unroll
     for (int j = 0; j < K; ++j) {
       const float w = s_wk[j * 64 + c];
@@ -128,14 +133,16 @@ __global__ __launch_bounds__(256) void zipconv_fwd_kernel(ConvArgs a, float* __r
       for (int i = 0; i < FPT; ++i) acck[i] = fmaf(w, win[i + j], acck[i]);
     }
   } else {
+    int cs[FPT];
+#pragma unroll
+    for (int i = 0; i < FPT; ++i) cs[i] = ((tb + i) / chunk) * chunk;
 #pragma unroll
     for (int j = 0; j < K; ++j) {
       const float w = s_wk[j * 64 + c];
 #pragma unroll
       for (int i = 0; i < FPT; ++i) {
-        const int t = tb + i, tt = t - halo + j;
-        const int cs = (t / chunk) * chunk;
-        if (tt >= cs && tt < cs + chunk) acck[i] = fmaf(w, win[i + j], acck[i]);
+        const int tt = tb + i - halo + j;
+        if (tt >= cs[i] && tt < cs[i] + chunk) acck[i] = fmaf(w, win[i + j], acck[i]);
       }
     }
   }
@@ -143,51 +150,63 @@ __global__ __launch_bounds__(256) void zipconv_fwd_kernel(ConvArgs a, float* __r
   for (int i = 0; i < FPT; ++i) {
     const int t = tb + i;
     if (t < a.T) {
-      float v = acck[i];
-      if (a.scale) v *= edge_scale(s_le, s_re, c, t % chunk, chunk, K);
-      y[((long)t * a.B + b) * a.C + c0 + c] = v + accc[i];
+      if (MODE == 0) {
+        float v = acck[i];
+        if (a.scale) v *= edge_scale(s_le, s_re, c, t % chunk, chunk, K);
+        y[((long)t * a.B + b) * a.C + c0 + c] = v + accc[i];
+      } else {
+        const int pos = t % chunk, idx = pos - chunk + K;
+        if (pos < K || (idx >= 0 && idx < K)) {
+          const float v = dy[((long)t * a.B + b) * a.C + c0 + c] * acck[i];
+          if (pos < K) atomicAdd(&dscale[(long)(c0 + c) * K + pos], v);
+          if (idx >= 0 && idx < K) atomicAdd(&dscale[((long)a.C + c0 + c) * K + idx], v);
+        }
+      }
     }
   }
 }
 
 // du[t'] : gradient w.r.t. the projection (x half and gate half)
-template <int K>
+template <int K, bool GEN>
 __global__ __launch_bounds__(256) void zipconv_bwd_data_kernel(ConvArgs a,
                                                                const float* __restrict__ dy,
                                                                float* __restrict__ du) {
   constexpr int Kh = (K + 1) / 2, halo = K / 2, W = FPT + 2 * halo;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* s_g = reinterpret_cast<float*>(smem_raw);  // dy tile with halo
-  float* s_wc = s_g + (TT + 2 * halo) * 64;
+  float* s_gs = s_g + (TT + 2 * halo) * 64;         // dy * edge_scale
+  float* s_wc = s_gs + (TT + 2 * halo) * 64;
   float* s_wk = s_wc + Kh * 64;
   float* s_le = s_wk + K * 64;
   float* s_re = s_le + K * 64;
   const int t0 = blockIdx.x * TT, b = blockIdx.y, c0 = blockIdx.z * 64;
   const int c = threadIdx.x & 63, tg = threadIdx.x >> 6;
   stage_weights<K>(a, c0, s_wc, s_wk, s_le, s_re);
+  __syncthreads();
+  const int chunk = a.chunk;
+  // two tiles: raw dy (causal taps) and dy * edge_scale (chunkwise taps)
   for (int i = threadIdx.x; i < (TT + 2 * halo) * 64; i += 256) {
     const int r = i >> 6, cc = i & 63;
     const int t = t0 - halo + r;
-    s_g[i] = (t >= 0 && t < a.T && c0 + cc < a.C) ? dy[((long)t * a.B + b) * a.C + c0 + cc] : 0.f;
+    float v = 0.f, vs = 0.f;
+    if (t >= 0 && t < a.T && c0 + cc < a.C) {
+      v = dy[((long)t * a.B + b) * a.C + c0 + cc];
+      vs = a.scale ? v * edge_scale(s_le, s_re, cc, t % chunk, chunk, K) : v;
+    }
+    s_g[i] = v;
+    s_gs[i] = vs;
   }
   __syncthreads();
   if (c0 + c >= a.C) return;
-  const int chunk = a.chunk;
   const int tb = t0 + tg * FPT;
-  float win[W], wins[W];   // dy and dy * edge_scale for frames tb-halo .. tb+FPT-1+halo
-#pragma unroll
-  for (int w = 0; w < W; ++w) {
-    win[w] = s_g[(tg * FPT + w) * 64 + c];
-    const int t = tb - halo + w;
-    float sc = 1.f;
-    if (a.scale && t >= 0 && t < a.T) sc = edge_scale(s_le, s_re, c, t % chunk, chunk, K);
-    wins[w] = win[w] * sc;
-  }
+  float win[W];   // frames tb-halo .. tb+FPT-1+halo
   float acc[FPT];
 #pragma unroll
   for (int i = 0; i < FPT; ++i) acc[i] = 0.f;
   // causal: y[t] += wc[j] * xg[t - halo + j]  =>  dxg[t'] += wc[j] * dy[t' + halo - j]
   if (a.wc) {
+#pragma unroll
+    for (int w = 0; w < W; ++w) win[w] = s_g[(tg * FPT + w) * 64 + c];
 #pragma unroll
     for (int j = 0; j < Kh; ++j) {
       const float w = s_wc[j * 64 + c];
@@ -196,19 +215,26 @@ __global__ __launch_bounds__(256) void zipconv_bwd_data_kernel(ConvArgs a,
     }
   }
   // chunkwise: dxg[t'] += wk[j] * (dy*sc)[t' + halo - j] when frame t'+halo-j is in t's chunk
-  const bool one_chunk = (chunk >= a.T) ||
-                         ((tb - halo) >= (tb / chunk) * chunk &&
-                          (tb + FPT - 1 + halo) < (tb / chunk + 1) * chunk);
 #pragma unroll
-  for (int j = 0; j < K; ++j) {
-    const float w = s_wk[j * 64 + c];
+  for (int w = 0; w < W; ++w) win[w] = s_gs[(tg * FPT + w) * 64 + c];
+  if (!GEN) {
 #pragma unroll
-    for (int i = 0; i < FPT; ++i) {
-      if (one_chunk) {
-        acc[i] = fmaf(w, wins[i + 2 * halo - j], acc[i]);
-      } else {
-        const int tp = tb + i, t = tp + halo - j;
-        if (t >= 0 && (t / chunk) == (tp / chunk)) acc[i] = fmaf(w, wins[i + 2 * halo - j], acc[i]);
+    for (int j = 0; j < K; ++j) {
+      const float w = s_wk[j * 64 + c];
+#pragma unroll
+      for (int i = 0; i < FPT; ++i) acc[i] = fmaf(w, win[i + 2 * halo - j], acc[i]);
+    }
+  } else {
+    int cs[FPT];
+#pragma unroll
+    for (int i = 0; i < FPT; ++i) cs[i] = ((tb + i) / chunk) * chunk;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const float w = s_wk[j * 64 + c];
+#pragma unroll
+      for (int i = 0; i < FPT; ++i) {
+        const int t = tb + i + halo - j;
+        if (t >= cs[i] && t < cs[i] + chunk) acc[i] = fmaf(w, win[i + 2 * halo - j], acc[i]);
       }
     }
   }
@@ -216,27 +242,29 @@ __global__ __launch_bounds__(256) void zipconv_bwd_data_kernel(ConvArgs a,
 #pragma unroll
   for (int i = 0; i < FPT; ++i) {
     const int t = tb + i;
-    if (t >= a.T) continue;
-    const bool pad = a.mask && a.mask[(long)b * a.T + t];
-    float* o = du + ((long)t * a.B + b) * nout;
-    if (a.gate_off >= 0) {
-      const float* row = a.u + ((long)t * a.B + b) * a.ld;
-      const float xv = row[c0 + c], sg = sigmoidf_(row[a.gate_off + c0 + c]);
-      o[c0 + c] = pad ? 0.f : acc[i] * sg;
-      o[a.C + c0 + c] = pad ? 0.f : acc[i] * xv * sg * (1.f - sg);
-    } else {
-      o[c0 + c] = pad ? 0.f : acc[i];
+    if (t < a.T) {
+      const bool pad = a.mask && a.mask[(long)b * a.T + t];
+      float* o = du + ((long)t * a.B + b) * nout;
+      if (a.gate_off >= 0) {
+        const float* row = a.u + ((long)t * a.B + b) * a.ld;
+        const float xv = row[c0 + c], sg = sigmoidf_(row[a.gate_off + c0 + c]);
+        o[c0 + c] = pad ? 0.f : acc[i] * sg;
+        o[a.C + c0 + c] = pad ? 0.f : acc[i] * xv * sg * (1.f - sg);
+      } else {
+        o[c0 + c] = pad ? 0.f : acc[i];
+      }
     }
   }
 }
 
-// weight / bias / edge-scale gradients; block = (t-tile, group of BB utterances, c-tile)
-template <int K>
-__global__ __launch_bounds__(256) void zipconv_bwd_w_kernel(
-    ConvArgs a, const float* __restrict__ dy, int BB, float* __restrict__ dwc,
-    float* __restrict__ dbc, float* __restrict__ dwk, float* __restrict__ dbk,
-    float* __restrict__ dscale) {
-  constexpr int Kh = (K + 1) / 2, halo = K / 2, W = FPT + 2 * halo;
+// weight / bias gradients; block = (t-tile, group of BB utterances, c-tile).  Each block
+// writes its partial sums to part[block][c][NV] (NV = Kh + 1 + K + 1); zipconv_reduce_w_kernel
+// sums over blocks -- no atomics (contended float atomics on a few KB run ~14x slower).
+template <int K, bool GEN>
+__global__ __launch_bounds__(256) void zipconv_bwd_w_kernel(ConvArgs a,
+                                                            const float* __restrict__ dy, int BB,
+                                                            float* __restrict__ part) {
+  constexpr int Kh = (K + 1) / 2, halo = K / 2, W = FPT + 2 * halo, NV = Kh + K + 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* s_x = reinterpret_cast<float*>(smem_raw);
   float* s_wc = s_x + (TT + 2 * halo) * 64;
@@ -256,10 +284,19 @@ __global__ __launch_bounds__(256) void zipconv_bwd_w_kernel(
   for (int j = 0; j < K; ++j) pwk[j] = 0.f;
   float pbc = 0.f, pbk = 0.f;
   const bool chan_ok = c0 + c < a.C;
-  const float bk = (a.bk && chan_ok) ? a.bk[c0 + c] : 0.f;
-  const bool one_chunk = (chunk >= a.T) ||
-                         ((tb - halo) >= (tb / chunk) * chunk &&
-                          (tb + FPT - 1 + halo) < (tb / chunk + 1) * chunk);
+  int cs[FPT];
+  float sc[FPT];
+#pragma unroll
+  for (int i = 0; i < FPT; ++i) {
+    cs[i] = GEN ? ((tb + i) / chunk) * chunk : 0;
+    sc[i] = 1.f;
+  }
+  __syncthreads();
+  if (a.scale) {
+#pragma unroll
+    for (int i = 0; i < FPT; ++i)
+      if (tb + i < a.T) sc[i] = edge_scale(s_le, s_re, c, tb + i - cs[i], chunk, K);
+  }
   const int b_end = min(a.B, (int)(blockIdx.y + 1) * BB);
   for (int b = blockIdx.y * BB; b < b_end; ++b) {
     __syncthreads();
@@ -273,60 +310,76 @@ __global__ __launch_bounds__(256) void zipconv_bwd_w_kernel(
     for (int i = 0; i < FPT; ++i) {
       const int t = tb + i;
       const float g = (t < a.T) ? dy[((long)t * a.B + b) * a.C + c0 + c] : 0.f;
-      const int cs = (t / chunk) * chunk;
-      float sc = 1.f;
-      const int pos = t - cs;
-      if (a.scale) sc = edge_scale(s_le, s_re, c, pos, chunk, K);
-      const float gs = g * sc;
+      const float gs = g * sc[i];
       pbc += g;
       pbk += gs;
       if (a.wc) {
 #pragma unroll
         for (int j = 0; j < Kh; ++j) pwc[j] = fmaf(g, win[i + j], pwc[j]);
       }
-      float convk = bk;
 #pragma unroll
       for (int j = 0; j < K; ++j) {
-        const int tt = t - halo + j;
-        const bool in = one_chunk || (tt >= cs && tt < cs + chunk);
-        if (in) {
+        if (!GEN) {
           pwk[j] = fmaf(gs, win[i + j], pwk[j]);
-          convk = fmaf(s_wk[j * 64 + c], win[i + j], convk);
+        } else {
+          const int tt = t - halo + j;
+          if (tt >= cs[i] && tt < cs[i] + chunk) pwk[j] = fmaf(gs, win[i + j], pwk[j]);
         }
-      }
-      if (a.scale && t < a.T) {
-        // d(1 + le[pos] + re[idx]) : sparse (only frames near a chunk edge)
-        const float v = g * convk;
-        if (pos < K) atomicAdd(&dscale[(long)(c0 + c) * K + pos], v);
-        const int idx = pos - chunk + K;
-        if (idx >= 0 && idx < K) atomicAdd(&dscale[((long)a.C + c0 + c) * K + idx], v);
       }
     }
   }
-  // reduce the 4 frame groups of each channel through LDS, then one atomic per value
-  auto reduce_add = [&](float v, float* dst) {
+  // reduce the 4 frame groups of each channel through LDS, then one store per value
+  const long blk = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  float* dst = part + (blk * 64 + c) * NV;
+  auto reduce_store = [&](float v, int slot) {
     __syncthreads();
     s_red[tg * 64 + c] = v;
     __syncthreads();
-    if (tg == 0 && chan_ok) {
-      const float s = s_red[c] + s_red[64 + c] + s_red[128 + c] + s_red[192 + c];
-      if (s != 0.f) atomicAdd(dst, s);
-    }
+    if (tg == 0) dst[slot] = s_red[c] + s_red[64 + c] + s_red[128 + c] + s_red[192 + c];
   };
-  if (a.wc) {
 #pragma unroll
-    for (int j = 0; j < Kh; ++j) reduce_add(pwc[j], dwc + (long)(c0 + c) * Kh + j);
-    reduce_add(pbc, dbc + c0 + c);
+  for (int j = 0; j < Kh; ++j) reduce_store(pwc[j], j);
+  reduce_store(pbc, Kh);
+#pragma unroll
+  for (int j = 0; j < K; ++j) reduce_store(pwk[j], Kh + 1 + j);
+  reduce_store(pbk, Kh + 1 + K);
+}
+
+// out[c][slot] = sum over the (t-tile, b-group) blocks of part.  One workgroup per channel:
+// thread = (slot = tid & 63, k-group = tid >> 6); rows of NV floats are read contiguously.
+__global__ __launch_bounds__(256) void zipconv_reduce_w_kernel(
+    const float* __restrict__ part, int nblk_per_ctile, int C, int Kh, int K,
+    float* __restrict__ dwc, float* __restrict__ dbc, float* __restrict__ dwk,
+    float* __restrict__ dbk) {
+  __shared__ float s_red[4][64];
+  const int NV = Kh + K + 2;
+  const int cg = blockIdx.x, ct = cg >> 6, c = cg & 63;
+  const int slot = threadIdx.x & 63, kg = threadIdx.x >> 6;
+  float s = 0.f;
+  if (slot < NV)
+    for (int k = kg; k < nblk_per_ctile; k += 4)
+      s += part[(((long)ct * nblk_per_ctile + k) * 64 + c) * NV + slot];
+  s_red[kg][slot] = s;
+  __syncthreads();
+  if (kg == 0 && slot < NV) {
+    s = s_red[0][slot] + s_red[1][slot] + s_red[2][slot] + s_red[3][slot];
+    if (slot < Kh) {
+      if (dwc) dwc[(long)cg * Kh + slot] += s;
+    } else if (slot == Kh) {
+      if (dbc) dbc[cg] += s;
+    } else if (slot < Kh + 1 + K) {
+      dwk[(long)cg * K + slot - Kh - 1] += s;
+    } else if (dbk) {
+      dbk[cg] += s;
+    }
   }
-#pragma unroll
-  for (int j = 0; j < K; ++j) reduce_add(pwk[j], dwk + (long)(c0 + c) * K + j);
-  if (dbk) reduce_add(pbk, dbk + c0 + c);
 }
 
 template <int K>
-size_t conv_smem(bool with_red) {
+size_t conv_smem(bool with_red, int tiles = 1) {
   constexpr int Kh = (K + 1) / 2, halo = K / 2;
-  return sizeof(float) * ((TT + 2 * halo) * 64 + Kh * 64 + 3 * K * 64 + (with_red ? 256 : 0));
+  return sizeof(float) *
+         (tiles * (TT + 2 * halo) * 64 + Kh * 64 + 3 * K * 64 + (with_red ? 256 : 0));
 }
 
 }  // namespace
@@ -352,28 +405,73 @@ extern "C" int s2t_zipconv_fwd(const float* u, long ld, int gate_off, const unsi
   if (!conv_args_ok(T, B, C, K, chunk)) return -1;
   ConvArgs a{u, ld, gate_off, mask, T, B, C, chunk, wc, bc, wk, bk, scale};
   dim3 grid((T + TT - 1) / TT, B, (C + 63) / 64);
-  S2T_CONV_DISPATCH(K, hipLaunchKernelGGL(zipconv_fwd_kernel<KK>, grid, dim3(256),
-                                          conv_smem<KK>(false), (hipStream_t)stream, a, y));
+  hipStream_t st = (hipStream_t)stream;
+  const float* nf = nullptr;
+  float* nfm = nullptr;
+  if (chunk >= T) {
+    S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_fwd_kernel<KK, 0, false>), grid, dim3(256),
+                                            conv_smem<KK>(false), st, a, y, nf, nfm));
+  } else {
+    S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_fwd_kernel<KK, 0, true>), grid, dim3(256),
+                                            conv_smem<KK>(false), st, a, y, nf, nfm));
+  }
   S2T_CHECK_LAUNCH();
   return 0;
+}
+
+// floats of scratch s2t_zipconv_bwd needs for the per-block partial sums
+extern "C" long s2t_zipconv_bwd_workspace_floats(int T, int B, int C, int K) {
+  const long tiles = (long)((T + TT - 1) / TT) * ((C + 63) / 64);
+  return tiles * B * 64 * ((K + 1) / 2 + K + 2);
 }
 
 extern "C" int s2t_zipconv_bwd(const float* u, long ld, int gate_off, const unsigned char* mask,
                                int T, int B, int C, int K, int chunk, const float* wc,
                                const float* wk, const float* bk, const float* scale,
                                const float* dy, float* du, float* dwc, float* dbc, float* dwk,
-                               float* dbk, float* dscale, void* stream) {
+                               float* dbk, float* dscale, float* workspace, void* stream) {
   if (!conv_args_ok(T, B, C, K, chunk)) return -1;
+  hipStream_t st = (hipStream_t)stream;
   ConvArgs a{u, ld, gate_off, mask, T, B, C, chunk, wc, nullptr, wk, bk, scale};
   dim3 grid((T + TT - 1) / TT, B, (C + 63) / 64);
-  S2T_CONV_DISPATCH(K, hipLaunchKernelGGL(zipconv_bwd_data_kernel<KK>, grid, dim3(256),
-                                          conv_smem<KK>(false), (hipStream_t)stream, a, dy, du));
+  const bool gen = chunk < T;
+  if (!gen) {
+    S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_data_kernel<KK, false>), grid, dim3(256),
+                                            conv_smem<KK>(false, 2), st, a, dy, du));
+  } else {
+    S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_data_kernel<KK, true>), grid, dim3(256),
+                                            conv_smem<KK>(false, 2), st, a, dy, du));
+  }
   S2T_CHECK_LAUNCH();
-  const int BB = 8;
-  dim3 gridw((T + TT - 1) / TT, (B + BB - 1) / BB, (C + 63) / 64);
-  S2T_CONV_DISPATCH(K, hipLaunchKernelGGL(zipconv_bwd_w_kernel<KK>, gridw, dim3(256),
-                                          conv_smem<KK>(true), (hipStream_t)stream, a, dy, BB, dwc,
-                                          dbc, dwk, dbk, dscale));
+  // utterances per block: enough workgroups to hide the staging latency
+  const long tiles = (long)grid.x * grid.z;
+  int BB = (int)((tiles * B) / 1536);
+  if (BB < 1) BB = 1;
+  if (BB > 8) BB = 8;
+  dim3 gridw(grid.x, (B + BB - 1) / BB, grid.z);
+  if (!gen) {
+    S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_w_kernel<KK, false>), gridw, dim3(256),
+                                            conv_smem<KK>(true), st, a, dy, BB, workspace));
+  } else {
+    S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_w_kernel<KK, true>), gridw, dim3(256),
+                                            conv_smem<KK>(true), st, a, dy, BB, workspace));
+  }
   S2T_CHECK_LAUNCH();
+  hipLaunchKernelGGL(zipconv_reduce_w_kernel, dim3(C), dim3(256), 0, st, workspace,
+                     (int)(gridw.x * gridw.y), C, (K + 1) / 2, K, wc ? dwc : nullptr,
+                     wc ? dbc : nullptr, dwk, dbk);
+  S2T_CHECK_LAUNCH();
+  if (scale && dscale) {
+    ConvArgs af{u, ld, gate_off, mask, T, B, C, chunk, nullptr, nullptr, wk, bk, scale};
+    float* nfm = nullptr;
+    if (!gen) {
+      S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_fwd_kernel<KK, 1, false>), grid, dim3(256),
+                                              conv_smem<KK>(false), st, af, nfm, dy, dscale));
+    } else {
+      S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_fwd_kernel<KK, 1, true>), grid, dim3(256),
+                                              conv_smem<KK>(false), st, af, nfm, dy, dscale));
+    }
+    S2T_CHECK_LAUNCH();
+  }
   return 0;
 }

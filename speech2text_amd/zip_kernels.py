@@ -270,13 +270,16 @@ class _ZipConv(torch.autograd.Function):
             parts.append(buf[o:o + n] if n else None)
             o += n
         dwc, dbc, dwk, dbk, dsc = parts
+        ws = torch.empty(N.lib().s2t_zipconv_bwd_workspace_floats(T, B, C, K), dtype=torch.float32,
+                         device=dev)
+        N.profile_note("s2t_zipconv_bwd", 4.0 * (2 * u.numel() + 2 * dy.numel()))
         N.check(N.lib().s2t_zipconv_bwd(N.fp(u), ld, gate_off, N.ptr(m8), T, B, C, K, chunk,
                                         N.fp(wc), N.fp(wk), N.fp(bk), N.fp(scale), N.fp(dy),
                                         N.fp(du), N.raw(dwc) if dwc is not None else None,
                                         N.raw(dbc) if dbc is not None else None, N.raw(dwk),
                                         N.raw(dbk) if dbk is not None else None,
-                                        N.raw(dsc) if dsc is not None else None, N.stream()),
-                "s2t_zipconv_bwd")
+                                        N.raw(dsc) if dsc is not None else None, N.fp(ws),
+                                        N.stream()), "s2t_zipconv_bwd")
         return (du, None, None, None, None,
                 None if dwc is None else dwc.view(C, 1, Kh),
                 dbc if has_bc else None, dwk.view(C, 1, K), dbk,

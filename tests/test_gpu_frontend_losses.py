@@ -175,3 +175,47 @@ def test_full_rnnt_loss_vs_oracle(dev):
     out.backward()
     np.testing.assert_allclose(out.item(), ref.item(), rtol=1e-5)
     np.testing.assert_allclose(lg.grad.cpu().numpy(), lc.grad.numpy(), atol=2e-5, rtol=2e-3)
+
+
+# ------------------------------------------------------------------ BEST-RQ
+def test_bestrq_labels_bit_exact_and_masks(golden_dir, dev):
+    from oracle import best_rq as obr
+    from speech2text_amd.model.ssl.best_rq import (BestRQLayer, BestRQLayerConfig,
+                                                   MaskingStrategyConfig)
+    g = np.load(os.path.join(golden_dir, "bestrq_ref.npz"))
+    for ci, (K, D, ncb) in enumerate([(256, 16, 1), (64, 8, 2), (8192, 16, 1)]):
+        basis = str(g[f"basis{ci}"])
+        layer = BestRQLayer(BestRQLayerConfig(feat_dim=80, num_codebooks=ncb, codebook_dim=D,
+                                              codebook_size=K, label_basis=basis),
+                            MaskingStrategyConfig(mask_proportion=0.5, mean_span_length=1,
+                                                  span_select_type="static", seed=5)).to(dev)
+        with torch.no_grad():
+            layer._projector.copy_(torch.from_numpy(g[f"projector{ci}"]))
+            for j in range(ncb):
+                layer._codebooks[j].copy_(torch.from_numpy(g[f"codebook{ci}_{j}"]))
+        raw = torch.from_numpy(g[f"raw{ci}"]).to(dev)
+        aug = torch.from_numpy(g[f"aug{ci}"]).to(dev)
+        np.random.seed(99 + ci)                       # the reference's global np.random.rand() draw
+        out = layer(raw, aug.clone(), torch.from_numpy(g[f"length{ci}"]))
+        lab = out["labels"].cpu().numpy()
+        ora = obr.make_labels(g[f"raw{ci}"], g[f"projector{ci}"],
+                              [g[f"codebook{ci}_{j}"] for j in range(ncb)])
+        assert (lab == ora).all()                     # bit-exact vs oracle
+        assert (lab == g[f"labels{ci}"]).all()        # and vs the reference's own labels
+        assert (out["masked_dim"].cpu().numpy() == g[f"masked_dim{ci}"]).all()
+        changed = (out["masked_feats"] != aug).any(-1).cpu().numpy()
+        assert (changed == g[f"changed{ci}"]).all()   # same frames overwritten with noise
+
+
+def test_bestrq_labels_c5_shape(dev):
+    from oracle import best_rq as obr
+    from speech2text_amd.model.ssl.best_rq import (BestRQLayer, BestRQLayerConfig,
+                                                   MaskingStrategyConfig)
+    torch.manual_seed(3)
+    layer = BestRQLayer(BestRQLayerConfig(codebook_dim=16, codebook_size=8192, label_basis="cosine"),
+                        MaskingStrategyConfig(mask_proportion=0.5)).to(dev)
+    feats = torch.randn(2, 2998, 80) * 3
+    lab = layer.make_labels(feats.to(dev)).cpu().numpy()
+    assert lab.shape == (1, 2, 748)
+    ora = obr.make_labels(feats.numpy(), layer._projector.cpu().numpy(), [layer._codebooks[0].cpu().numpy()])
+    assert (lab == ora).all()

@@ -67,6 +67,13 @@ def conv(T, B, C, Kk):
 
 if __name__ == "__main__":
     B = 64
+    only = sys.argv[1] if len(sys.argv) > 1 else ""
+    if only == "conv":
+        conv(495, B, 192, 31)
+        sys.exit(0)
+    if only == "attn":
+        attn(495, B, 4)
+        sys.exit(0)
     for T, H in [(495, 4), (248, 4), (124, 4), (62, 8)]:
         attn(T, B, H)
     conv(495, B, 192, 31)
