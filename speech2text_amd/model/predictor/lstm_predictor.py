@@ -1,0 +1,101 @@
+"""LSTM predictor (reference model/predictor/lstm_predictor.py:28-109 wrapping
+torchaudio.models.rnnt._Predictor; torchaudio 0.13.1 not vendored, structure restated:
+Embedding -> LayerNorm -> N x layer-norm LSTM (x2g/p2g gates, c_norm/g_norm) -> dropout ->
+Linear -> LayerNorm; PARITY UNPINNED).  Parameter names follow torchaudio's."""
+import dataclasses
+from typing import List, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+@dataclasses.dataclass
+class LstmPredictorConfig:
+    num_symbols: int = 128
+    output_dim: int = 1024
+    symbol_embedding_dim: int = 512
+    num_lstm_layers: int = 3
+    lstm_hidden_dim: int = 512
+    lstm_layer_norm: bool = True
+    lstm_layer_norm_epsilon: float = 1e-3
+    lstm_dropout: float = 0.3
+
+
+class _CustomLSTM(nn.Module):
+    def __init__(self, input_dim, hidden_dim, layer_norm=False, layer_norm_epsilon=1e-5):
+        super().__init__()
+        self.x2g = nn.Linear(input_dim, 4 * hidden_dim, bias=(not layer_norm))
+        self.p2g = nn.Linear(hidden_dim, 4 * hidden_dim, bias=False)
+        if layer_norm:
+            self.c_norm = nn.LayerNorm(hidden_dim, eps=layer_norm_epsilon)
+            self.g_norm = nn.LayerNorm(4 * hidden_dim, eps=layer_norm_epsilon)
+        else:
+            self.c_norm = nn.Identity()
+            self.g_norm = nn.Identity()
+        self.hidden_dim = hidden_dim
+
+    def forward(self, x, state):
+        if state is None:
+            B = x.size(1)
+            h = torch.zeros(B, self.hidden_dim, device=x.device, dtype=x.dtype)
+            c = torch.zeros(B, self.hidden_dim, device=x.device, dtype=x.dtype)
+        else:
+            h, c = state
+        gated = self.x2g(x)
+        outs = []
+        for g in gated.unbind(0):
+            g = self.g_norm(g + self.p2g(h))
+            i, f, cell, o = g.chunk(4, 1)
+            c = self.c_norm(f.sigmoid() * c + i.sigmoid() * cell.tanh())
+            h = o.sigmoid() * c.tanh()
+            outs.append(h)
+        return torch.stack(outs, dim=0), [h, c]
+
+
+class _Predictor(nn.Module):
+    def __init__(self, num_symbols, output_dim, symbol_embedding_dim, num_lstm_layers,
+                 lstm_hidden_dim, lstm_layer_norm=False, lstm_layer_norm_epsilon=1e-5,
+                 lstm_dropout=0.0):
+        super().__init__()
+        self.embedding = nn.Embedding(num_symbols, symbol_embedding_dim)
+        self.input_layer_norm = nn.LayerNorm(symbol_embedding_dim)
+        self.lstm_layers = nn.ModuleList([
+            _CustomLSTM(symbol_embedding_dim if i == 0 else lstm_hidden_dim, lstm_hidden_dim,
+                        lstm_layer_norm, lstm_layer_norm_epsilon) for i in range(num_lstm_layers)])
+        self.dropout = nn.Dropout(p=lstm_dropout)
+        self.linear = nn.Linear(lstm_hidden_dim, output_dim)
+        self.output_layer_norm = nn.LayerNorm(output_dim)
+
+    def forward(self, input, lengths, state=None):
+        x = self.input_layer_norm(self.embedding(input.permute(1, 0)))
+        state_out = []
+        for i, lstm in enumerate(self.lstm_layers):
+            x, s = lstm(x, None if state is None else state[i])
+            x = self.dropout(x)
+            state_out.append(s)
+        x = self.output_layer_norm(self.linear(x))
+        return x.permute(1, 0, 2), lengths, state_out
+
+
+class LstmPredictor(nn.Module):
+    def __init__(self, config: LstmPredictorConfig) -> None:
+        super().__init__()
+        self._sos_token = config.num_symbols - 1
+        self._blank_token = 0
+        self._predictor = _Predictor(**dataclasses.asdict(config))
+
+    @property
+    def sos_token(self) -> int:
+        return self._sos_token
+
+    @property
+    def blank_token(self) -> int:
+        return self._blank_token
+
+    def init_state(self):
+        return []
+
+    def forward(self, input: torch.Tensor, lengths: torch.Tensor, state: List[List[torch.Tensor]]):
+        x = F.pad(input.to(torch.int32), (1, 0), value=self._blank_token)     # (B, 1+U)
+        return self._predictor(x, lengths, None if len(state) == 0 else state)

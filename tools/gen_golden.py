@@ -205,6 +205,34 @@ def gen_scaledadam():
     print("scaledadam lrs", lrs[:3], lrs[-1])
 
 
+def gen_subsampling():
+    """Reference conformer Subsampling (rates 4/6/8); torchaudio is stubbed (third-party)."""
+    import sys, types, importlib.machinery
+    import torch
+    ref_import.install_stubs()
+    if "torchaudio" not in sys.modules:
+        ta = types.ModuleType("torchaudio")
+        ta.__spec__ = importlib.machinery.ModuleSpec("torchaudio", None)
+        ta.models = types.SimpleNamespace(Conformer=None)
+        sys.modules["torchaudio"] = ta
+    from model.encoder.conformer import Subsampling
+    out = {}
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(3, 120, 80, generator=g)
+    lens = torch.tensor([120, 97, 50])
+    out["x"], out["lens"] = x.numpy(), lens.numpy()
+    for rate in (4, 6, 8):
+        torch.manual_seed(rate)
+        m = Subsampling(80, 32, rate)
+        y, yl = m(x, lens)
+        for k, v in m.state_dict().items():
+            out[f"sd{rate}.{k}"] = v.numpy()
+        out[f"out{rate}"] = y.detach().numpy()
+        out[f"len{rate}"] = yl.numpy()
+    np.savez_compressed(os.path.join(OUT, "subsampling_ref.npz"), **out)
+    print("subsampling", {r: out[f"out{r}"].shape for r in (4, 6, 8)})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ["fbank", "ctc", "bestrq", "zipformer", "scaledadam"]
