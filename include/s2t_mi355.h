@@ -136,6 +136,16 @@ int s2t_relpos_attn_bwd(const float* qkp, const float* pos, const unsigned char*
 int s2t_bestrq_labels(const float* feats, int B, int T, int F, const float* proj, int D,
                       const float* codebooks, int ncb, int K, int T2, long* labels, void* stream);
 
+
+/* ---- channel-last depthwise conv2d of the zipformer frontend (ConvNeXt 7x7,
+ * model/layer/subsampling.py:47-53,121).  x,y (N,H,W,C); wgt (C,KH,KW); "same" zero padding.
+ * flip=1 applies the flipped taps (= backward data).  wgrad writes dw (C,KH,KW) and db (C). */
+int s2t_dwconv2d_nhwc_fwd(const float* x, const float* wgt, const float* bias, int N, int H, int W,
+                          int C, int KH, int KW, int flip, float* y, void* stream);
+long s2t_dwconv2d_wgrad_workspace_floats(int N, int H, int C, int KH, int KW);
+int s2t_dwconv2d_nhwc_wgrad(const float* x, const float* dy, int N, int H, int W, int C, int KH,
+                            int KW, float* workspace, float* dw, float* db, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

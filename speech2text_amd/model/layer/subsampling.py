@@ -3,9 +3,11 @@ model/layer/subsampling.py; same parameter names, T' = (T-7)//2)."""
 from typing import Optional, Tuple
 
 import torch
+import torch.nn.functional as F
 from torch import Tensor, nn
 
 from speech2text_amd import rng
+from speech2text_amd import zip_kernels as zk
 
 from speech2text_amd.model.layer.scaling import (Balancer, BiasNorm, Dropout3, FloatLike,
                                                  ScaledConv2d, ScaleGrad, ScheduledFloat, SwooshL,
@@ -13,7 +15,9 @@ from speech2text_amd.model.layer.scaling import (Balancer, BiasNorm, Dropout3, F
 
 
 class ConvNeXt(nn.Module):
-    """depthwise 7x7 -> pointwise (x3) -> SwooshL -> pointwise, plus bypass (reference :26-132)."""
+    """depthwise 7x7 -> pointwise (x3) -> SwooshL -> pointwise, plus bypass (reference :26-132).
+    Works on channel-last (N,H,W,C) activations: the pointwise convs are plain GEMMs over the
+    last dim, the depthwise conv is the HIP NHWC stencil; parameters keep nn.Conv2d shapes."""
 
     def __init__(self, channels: int, hidden_ratio: int = 3, kernel_size: Tuple[int, int] = (7, 7),
                  layerdrop_rate: FloatLike = None):
@@ -26,38 +30,41 @@ class ConvNeXt(nn.Module):
         self.depthwise_conv = nn.Conv2d(channels, channels, groups=channels,
                                         kernel_size=kernel_size, padding=self.padding)
         self.pointwise_conv1 = nn.Conv2d(channels, hidden, kernel_size=1)
-        self.hidden_balancer = Balancer(hidden, channel_dim=1, min_positive=0.3, max_positive=1.0,
+        self.hidden_balancer = Balancer(hidden, channel_dim=-1, min_positive=0.3, max_positive=1.0,
                                         min_abs=0.75, max_abs=5.0)
         self.activation = SwooshL()
         self.pointwise_conv2 = ScaledConv2d(hidden, channels, kernel_size=1, initial_scale=0.01)
-        self.out_balancer = Balancer(channels, channel_dim=1, min_positive=0.4, max_positive=0.6,
+        self.out_balancer = Balancer(channels, channel_dim=-1, min_positive=0.4, max_positive=0.6,
                                      min_abs=1.0, max_abs=6.0)
         self.out_whiten = Whiten(num_groups=1, whitening_limit=5.0, prob=(0.025, 0.25),
                                  grad_scale=0.01)
 
     def forward(self, x: Tensor) -> Tensor:
+        """x: (N,H,W,C) channel-last."""
         mask = None
         if self.training:
             rate = float(self.layerdrop_rate)
             if rate != 0.0:
                 mask = rng.rand(x.shape[0], 1, 1, 1, dtype=x.dtype, device=x.device) > rate
         bypass = x
-        x = self.depthwise_conv(x)
-        x = self.pointwise_conv1(x)
+        x = zk.dwconv2d_nhwc(x, self.depthwise_conv.weight, self.depthwise_conv.bias)
+        x = zk.linear_big_m(x, self.pointwise_conv1.weight.flatten(1), self.pointwise_conv1.bias)
         x = self.hidden_balancer(x)
         x = self.activation(x)
-        x = self.pointwise_conv2(x)
+        x = zk.linear_big_m(x, self.pointwise_conv2.weight.flatten(1), self.pointwise_conv2.bias)
         if mask is not None:
             x = x * mask
         x = bypass + x
         x = self.out_balancer(x)
         if x.requires_grad:
-            x = self.out_whiten(x.transpose(1, 3)).transpose(1, 3)
+            x = self.out_whiten(x)
         return x
 
 
 class Conv2dSubsampling(nn.Module):
-    """(N,T,idim) -> (N,(T-7)//2,odim)   (reference :181-319)."""
+    """(N,T,idim) -> (N,(T-7)//2,odim)   (reference :181-319).  Same parameters as the
+    reference (nn.Conv2d weights in (Cout,Cin,kh,kw)), computed channel-last: the 3x3 convs are
+    im2col + GEMM, everything elementwise streams over (N,T,F,C)."""
 
     def __init__(self, in_channels: int, out_channels: int, layer1_channels: int = 8,
                  layer2_channels: int = 32, layer3_channels: int = 128,
@@ -67,13 +74,13 @@ class Conv2dSubsampling(nn.Module):
         self.conv = nn.Sequential(
             nn.Conv2d(1, layer1_channels, kernel_size=3, padding=(0, 1)),
             ScaleGrad(0.2),
-            Balancer(layer1_channels, channel_dim=1, max_abs=1.0),
+            Balancer(layer1_channels, channel_dim=-1, max_abs=1.0),
             SwooshR(),
             nn.Conv2d(layer1_channels, layer2_channels, kernel_size=3, stride=2, padding=0),
-            Balancer(layer2_channels, channel_dim=1, max_abs=4.0),
+            Balancer(layer2_channels, channel_dim=-1, max_abs=4.0),
             SwooshR(),
             nn.Conv2d(layer2_channels, layer3_channels, kernel_size=3, stride=(1, 2)),
-            Balancer(layer3_channels, channel_dim=1, max_abs=4.0),
+            Balancer(layer3_channels, channel_dim=-1, max_abs=4.0),
             SwooshR(),
         )
         self.convnext = ConvNeXt(layer3_channels, kernel_size=(7, 7))
@@ -88,11 +95,19 @@ class Conv2dSubsampling(nn.Module):
         self.dropout = Dropout3(dropout, shared_dim=1)
 
     def forward(self, x: Tensor, x_lens: Tensor) -> Tuple[Tensor, Tensor]:
-        x = self.conv(x.unsqueeze(1))
-        x = self.convnext(x)
-        b, c, t, f = x.size()
-        x = x.transpose(1, 2).reshape(b, t, c * f)
-        x = self.out(x)
+        x = x.unsqueeze(-1)                                     # (N,T,F,1) channel-last
+        for m in self.conv:
+            if isinstance(m, nn.Conv2d):
+                if m.padding[1]:
+                    x = F.pad(x, (0, 0, m.padding[1], m.padding[1]))   # freq axis only
+                x = zk.conv3x3_nhwc(x, m.weight, m.bias, m.stride)
+            else:
+                x = m(x)
+        x = self.convnext(x)                                    # (N,T',F',C)
+        b, t, f, c = x.shape
+        # reference flattens (c,f) c-major: out.weight columns are indexed c*F' + f
+        w = self.out.weight.view(-1, c, f).permute(0, 2, 1).reshape(-1, f * c)
+        x = F.linear(x.reshape(b, t, f * c), w, self.out.bias)
         x = self.out_whiten(x)
         x = self.out_norm(x)
         x = self.dropout(x)

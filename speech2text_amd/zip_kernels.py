@@ -396,3 +396,129 @@ def simple_downsample(src, bias, ds):
 def simple_upsample(src, up, out_len):
     T, B, C = src.shape
     return src.unsqueeze(1).expand(T, up, B, C).reshape(T * up, B, C)[:out_len]
+
+
+# ------------------------------------------------------------------ channel-last frontend convs
+def _wgrad_splitk(a, g, chunk=16384):
+    """a (R,M), g (R,N) -> a^T g (M,N) for R >> M,N: hipBLASLt gets only a handful of output
+    tiles for such shapes, so the reduction dimension is split into a batch of GEMMs."""
+    R = a.shape[0]
+    S = R // chunk
+    if S < 4:
+        return a.t().mm(g)
+    main = torch.bmm(a[:S * chunk].view(S, chunk, -1).transpose(1, 2),
+                     g[:S * chunk].view(S, chunk, -1)).sum(dim=0)
+    if S * chunk < R:
+        main = main + a[S * chunk:].t().mm(g[S * chunk:])
+    return main
+
+
+class _LinearBigM(torch.autograd.Function):
+    """F.linear for (rows >> features) activations with a split-K weight gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g2 = g.reshape(-1, g.shape[-1])
+        dx = g.matmul(weight) if ctx.needs_input_grad[0] else None
+        dw = _wgrad_splitk(g2, x.reshape(-1, x.shape[-1]))
+        db = g2.sum(dim=0) if ctx.has_bias else None
+        return dx, dw, db
+
+
+def linear_big_m(x, weight, bias):
+    return _LinearBigM.apply(x, weight, bias)
+
+
+class _Conv3x3Nhwc(torch.autograd.Function):
+    """3x3 conv on channel-last (N,H,W,Cin) as im2col (one strided copy; each patch row is 3
+    contiguous runs of 3*Cin floats in NHWC) + one plain GEMM (hipBLASLt).  Backward: two
+    GEMMs + col2im as 9 strided slice-adds.  weight keeps nn.Conv2d's (Cout,Cin,3,3) layout."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, sh, sw):
+        _dev(x, weight)
+        x = x.contiguous()
+        B, H, W, C = x.shape
+        Ho, Wo = (H - 3) // sh + 1, (W - 3) // sw + 1
+        s = x.stride()
+        cols = x.as_strided((B, Ho, Wo, 3, 3 * C), (s[0], s[1] * sh, s[2] * sw, s[1], 1)) \
+            .reshape(B * Ho * Wo, 9 * C)
+        wmat = weight.permute(2, 3, 1, 0).reshape(9 * C, weight.shape[0])       # (kh,kw,cin) x cout
+        y = torch.addmm(bias, cols, wmat) if bias is not None else cols.mm(wmat)
+        ctx.save_for_backward(cols, weight)
+        ctx.cfg = (B, H, W, C, Ho, Wo, sh, sw, bias is not None)
+        return y.view(B, Ho, Wo, weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        cols, weight = ctx.saved_tensors
+        B, H, W, C, Ho, Wo, sh, sw, has_bias = ctx.cfg
+        Cout = weight.shape[0]
+        g = dy.reshape(B * Ho * Wo, Cout)
+        dwmat = _wgrad_splitk(cols, g)                                           # (9C, Cout)
+        dweight = dwmat.view(3, 3, C, Cout).permute(3, 2, 0, 1)
+        db = g.sum(dim=0) if has_bias else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wmat = weight.permute(2, 3, 1, 0).reshape(9 * C, Cout)
+            dc = g.mm(wmat.t()).view(B, Ho, Wo, 3, 3, C)
+            dx = torch.zeros((B, H, W, C), dtype=dy.dtype, device=dy.device)
+            for kh in range(3):
+                for kw in range(3):
+                    dx[:, kh:kh + (Ho - 1) * sh + 1:sh, kw:kw + (Wo - 1) * sw + 1:sw, :] += \
+                        dc[:, :, :, kh, kw, :]
+        return dx, dweight, db, None, None
+
+
+def conv3x3_nhwc(x, weight, bias, stride=(1, 1)):
+    return _Conv3x3Nhwc.apply(x, weight, bias, int(stride[0]), int(stride[1]))
+
+
+class _DwConv2dNhwc(torch.autograd.Function):
+    """Depthwise 'same' conv on (N,H,W,C); HIP: zip_front.hip."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _dev(x, weight)
+        x = x.contiguous().float()
+        Nn, H, W, C = x.shape
+        KH, KW = weight.shape[-2], weight.shape[-1]
+        w = weight.reshape(C, KH, KW).contiguous()
+        y = torch.empty_like(x)
+        N.check(N.lib().s2t_dwconv2d_nhwc_fwd(N.fp(x), N.fp(w), N.fp(bias), Nn, H, W, C, KH, KW, 0,
+                                              N.fp(y), N.stream()), "s2t_dwconv2d_nhwc_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        ctx.wshape = weight.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        Nn, H, W, C = x.shape
+        KH, KW = w.shape[1], w.shape[2]
+        dy = dy.contiguous().float()
+        L = N.lib()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            N.check(L.s2t_dwconv2d_nhwc_fwd(N.fp(dy), N.fp(w), None, Nn, H, W, C, KH, KW, 1,
+                                            N.fp(dx), N.stream()), "s2t_dwconv2d_nhwc_bwd_data")
+        ws = torch.empty(L.s2t_dwconv2d_wgrad_workspace_floats(Nn, H, C, KH, KW),
+                         dtype=torch.float32, device=x.device)
+        dw = torch.empty_like(w)
+        db = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        N.check(L.s2t_dwconv2d_nhwc_wgrad(N.fp(x), N.fp(dy), Nn, H, W, C, KH, KW, N.fp(ws),
+                                          N.fp(dw), N.fp(db), N.stream()), "s2t_dwconv2d_nhwc_wgrad")
+        return dx, dw.view(ctx.wshape), db
+
+
+def dwconv2d_nhwc(x, weight, bias):
+    return _DwConv2dNhwc.apply(x, weight, bias)
