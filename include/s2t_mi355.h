@@ -119,15 +119,23 @@ long s2t_zipconv_bwd_workspace_floats(int T, int B, int C, int K);
 /* ---- relative-position attention weights (model/encoder/zipformer.py:1966-2066).
  * qkp (T,B,H*(2*qd+pd)) = in_proj output [q | k | p]; pos (2T-1, H*pd) = linear_pos(pos_emb)
  * or NULL (position term skipped); kpm (B,T) bytes, 1 = padded key; amask (T,T) bytes,
- * 1 = masked (either may be NULL); W (H,B,T,T) softmax weights.  Backward: delta_ws
- * (H,B,T) scratch, dqkp (T,B,Dp) fully written, dpos (2T-1,H*pd) ACCUMULATED (zero it). */
+ * 1 = masked (either may be NULL); W (H,B,T,T) softmax weights.  Backward: the gradient
+ * of W is passed materialised (dW) and/or factored -- dW0 (B,T,T) for head 0 and up to two
+ * (dO_c, V_c) pairs (T,B,H*dv_c) whose outer products are contracted on the fly, so the
+ * consumers' (H,B,T,T) gradients are never written; with factors, delta_ws (H,B,T) must hold
+ * sum_j W*dW on entry (delta_given=1).  dqkp (T,B,Dp) fully written, dpos ACCUMULATED. */
 int s2t_relpos_attn_fwd(const float* qkp, const float* pos, const unsigned char* kpm,
                         const unsigned char* amask, int T, int B, int H, int qd, int pd, float* W,
                         void* stream);
 int s2t_relpos_attn_bwd(const float* qkp, const float* pos, const unsigned char* kpm,
                         const unsigned char* amask, int T, int B, int H, int qd, int pd,
-                        const float* W, const float* dW, float* delta_ws, float* dqkp, float* dpos,
-                        void* stream);
+                        const float* W, const float* dW, const float* dW0, const float* dO1,
+                        const float* V1, int dv1, const float* dO2, const float* V2, int dv2,
+                        int delta_given, float* delta_ws, float* dqkp, float* dpos, void* stream);
+/* attention apply (model/encoder/zipformer.py:2269): transpose=0: out[i] = sum_j W[i,j] v[j];
+ * transpose=1: out[j] = sum_i W[i,j] v[i] (gradient w.r.t. the values).  v,out (T,B,H*dv). */
+int s2t_attn_apply(const float* W, const float* v, int T, int B, int H, int dv, int transpose,
+                   float* out, void* stream);
 
 
 /* ---- BEST-RQ labels (model/ssl/best_rq.py:168-217,259-294): stack 9 taps (kernel (3,3),

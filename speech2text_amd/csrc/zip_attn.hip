@@ -34,6 +34,13 @@ struct AttnArgs {
   const unsigned char* kpm;    // (B,T) 1 = padded key, or null
   const unsigned char* amask;  // (T,T) 1 = masked, or null
   int T, B, H, qd, pd;
+  // gradient of W, supplied either materialised (dW) and/or as factors that are contracted
+  // on the fly: dW[h,b,i,j] = dW[...] + (h==0) dW0[b,i,j] + sum_c sum_d dO_c[i,b,h,d] V_c[j,b,h,d]
+  const float* dW;     // (H,B,T,T) or null
+  const float* dW0;    // (B,T,T) head-0 extra or null
+  const float* pdO[2]; // (T,B,H*dv_c) each, or null
+  const float* pV[2];
+  int pdv[2];
 };
 
 __device__ __forceinline__ const float* q_row(const AttnArgs& a, int t, int b, int h) {
@@ -155,6 +162,28 @@ __device__ __forceinline__ void tile_scores(const AttnArgs& a, const Smem& s, in
   }
 }
 
+constexpr int MAXCD = 32;  // concatenated value dims of the deferred-dW factors
+
+__device__ __forceinline__ int pair_dims(const AttnArgs& a) {
+  return (a.pdO[0] ? a.pdv[0] : 0) + (a.pdO[1] ? a.pdv[1] : 0);
+}
+// dst[r][k] = src_c[t0 + r, b, h*dv_c + d] for the concatenated (c,d) index k
+__device__ __forceinline__ void stage_pairs(const AttnArgs& a, const float* const src[2], int b,
+                                            int h, int t0, int nrows, float (*dst)[MAXCD + 1]) {
+  int k0 = 0;
+  for (int c = 0; c < 2; ++c) {
+    if (!a.pdO[c]) continue;
+    const int dv = a.pdv[c];
+    const long ld = (long)a.H * dv;
+    for (int idx = threadIdx.x; idx < nrows * dv; idx += blockDim.x) {
+      const int r = idx / dv, d = idx % dv;
+      const int t = t0 + r;
+      dst[r][k0 + d] = (t < a.T) ? src[c][((long)t * a.B + b) * ld + h * dv + d] : 0.f;
+    }
+    k0 += dv;
+  }
+}
+
 __device__ __forceinline__ void stage_rows(const AttnArgs& a, const Smem& s, int b, int h, int i0) {
   for (int idx = threadIdx.x; idx < ROWS * a.qd; idx += blockDim.x) {
     const int r = idx / a.qd, d = idx % a.qd;
@@ -232,7 +261,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a, float* __rest
 // bwd_q: workgroup = (64 rows, b, h): delta, dq_i = sum_j dS_ij k_j, dp_i = sum_j dS_ij pos[rel].
 //        thread = (row = tid/4, dgrp = tid%4) accumulates qd/4 dims of dq and one dim of dp.
 __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a, const float* __restrict__ W,
-                                                         const float* __restrict__ dW,
+                                                         int delta_given,
                                                          float* __restrict__ delta,
                                                          float* __restrict__ dqkp) {
   constexpr int JC = 64;   // key chunk
@@ -240,22 +269,33 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a, const float
   __shared__ float s_K[JC][MAXQD + 1];
   __shared__ float s_pos[MAXPD][JC + ROWS];
   __shared__ float s_delta[ROWS];
+  __shared__ float s_dO[ROWS][MAXCD + 1];
+  __shared__ float s_Vc[JC][MAXCD + 1];
+  const float* dW = a.dW;
+  const int cd = pair_dims(a);
   const int i0 = blockIdx.x * ROWS, b = blockIdx.y, h = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* Wb = W + ((long)h * a.B + b) * a.T * a.T;
-  const float* dWb = dW + ((long)h * a.B + b) * a.T * a.T;
-  // pass 0: delta for the 64 rows (wave per row, coalesced)
-  for (int r = wave; r < ROWS; r += 4) {
-    const int i = i0 + r;
-    float acc = 0.f;
-    if (i < a.T)
-      for (int j = lane; j < a.T; j += 64) acc = fmaf(Wb[(long)i * a.T + j], dWb[(long)i * a.T + j], acc);
-    acc = wave_sum(acc);
-    if (lane == 0) {
-      s_delta[r] = acc;
-      if (i < a.T) delta[((long)h * a.B + b) * a.T + i] = acc;
+  const float* dWb = dW ? dW + ((long)h * a.B + b) * a.T * a.T : nullptr;
+  const float* dW0b = (a.dW0 && h == 0) ? a.dW0 + (long)b * a.T * a.T : nullptr;
+  if (delta_given) {
+    for (int r = threadIdx.x; r < ROWS; r += 256)
+      s_delta[r] = (i0 + r < a.T) ? delta[((long)h * a.B + b) * a.T + i0 + r] : 0.f;
+  } else {
+    // pass 0: delta for the 64 rows from the materialised dW (wave per row, coalesced)
+    for (int r = wave; r < ROWS; r += 4) {
+      const int i = i0 + r;
+      float acc = 0.f;
+      if (i < a.T)
+        for (int j = lane; j < a.T; j += 64) acc = fmaf(Wb[(long)i * a.T + j], dWb[(long)i * a.T + j], acc);
+      acc = wave_sum(acc);
+      if (lane == 0) {
+        s_delta[r] = acc;
+        if (i < a.T) delta[((long)h * a.B + b) * a.T + i] = acc;
+      }
     }
   }
+  if (cd) stage_pairs(a, a.pdO, b, h, i0, ROWS, s_dO);
   __syncthreads();
   const int row = tid >> 2, dg = tid & 3;
   const int qd = a.qd, pd = a.pd;
@@ -266,6 +306,10 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a, const float
   float accp0 = 0.f, accp1 = 0.f;  // pos dims dg and dg+4
   for (int j0 = 0; j0 < a.T; j0 += JC) {
     __syncthreads();
+    if (cd) {
+      stage_pairs(a, a.pV, b, h, j0, JC, s_Vc);
+      __syncthreads();
+    }
     // stage dS chunk (coalesced over j), K chunk, pos window
     for (int idx = tid; idx < ROWS * JC; idx += 256) {
       const int r = idx / JC, jj = idx % JC;
@@ -275,7 +319,10 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a, const float
         const bool masked = (a.kpm && a.kpm[(long)b * a.T + j]) || (a.amask && a.amask[(long)i * a.T + j]);
         if (!masked) {
           const float w = Wb[(long)i * a.T + j];
-          v = w * (dWb[(long)i * a.T + j] - s_delta[r]);
+          float dw = dWb ? dWb[(long)i * a.T + j] : 0.f;
+          if (dW0b) dw += dW0b[(long)i * a.T + j];
+          for (int d = 0; d < cd; ++d) dw = fmaf(s_dO[r][d], s_Vc[jj][d], dw);
+          v = w * (dw - s_delta[r]);
         }
       }
       s_dS[r][jj] = v;
@@ -317,7 +364,6 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a, const float
 
 // bwd_k: workgroup = (64 keys, b, h): dk_j = sum_i dS_ij q_i ; dpos[rel] += sum dS_ij p_i
 __global__ __launch_bounds__(256) void attn_bwd_k_kernel(AttnArgs a, const float* __restrict__ W,
-                                                         const float* __restrict__ dW,
                                                          const float* __restrict__ delta,
                                                          float* __restrict__ dqkp,
                                                          float* __restrict__ dpos) {
@@ -325,13 +371,19 @@ __global__ __launch_bounds__(256) void attn_bwd_k_kernel(AttnArgs a, const float
   __shared__ float s_dS[IC][ROWS + 1];       // [i][j]
   __shared__ float s_Q[IC][MAXQD + 1];
   __shared__ float s_P[IC][MAXPD];
+  __shared__ float s_dOc[IC][MAXCD + 1];
+  __shared__ float s_Vk[ROWS][MAXCD + 1];
+  const float* dW = a.dW;
+  const int cd = pair_dims(a);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* s_acc = reinterpret_cast<float*>(smem_raw);   // [pd][T + ROWS]: dpos for rel = j0 + u
   const int j0 = blockIdx.x * ROWS, b = blockIdx.y, h = blockIdx.z;
   const int tid = threadIdx.x;
   const float* Wb = W + ((long)h * a.B + b) * a.T * a.T;
-  const float* dWb = dW + ((long)h * a.B + b) * a.T * a.T;
+  const float* dWb = dW ? dW + ((long)h * a.B + b) * a.T * a.T : nullptr;
+  const float* dW0b = (a.dW0 && h == 0) ? a.dW0 + (long)b * a.T * a.T : nullptr;
   const float* dl = delta + ((long)h * a.B + b) * a.T;
+  if (cd) stage_pairs(a, a.pV, b, h, j0, ROWS, s_Vk);
   const int col = tid >> 2, dg = tid & 3;
   const int qd = a.qd, pd = a.pd;
   const int dper = (qd + 3) / 4;
@@ -343,13 +395,22 @@ __global__ __launch_bounds__(256) void attn_bwd_k_kernel(AttnArgs a, const float
     for (int idx = tid; idx < accw * pd; idx += 256) s_acc[idx] = 0.f;
   for (int i0 = 0; i0 < a.T; i0 += IC) {
     __syncthreads();
+    if (cd) {
+      stage_pairs(a, a.pdO, b, h, i0, IC, s_dOc);
+      __syncthreads();
+    }
     for (int idx = tid; idx < IC * ROWS; idx += 256) {
       const int ii = idx / ROWS, jj = idx % ROWS;
       const int i = i0 + ii, j = j0 + jj;
       float v = 0.f;
       if (i < a.T && j < a.T) {
         const bool masked = (a.kpm && a.kpm[(long)b * a.T + j]) || (a.amask && a.amask[(long)i * a.T + j]);
-        if (!masked) v = Wb[(long)i * a.T + j] * (dWb[(long)i * a.T + j] - dl[i]);
+        if (!masked) {
+          float dw = dWb ? dWb[(long)i * a.T + j] : 0.f;
+          if (dW0b) dw += dW0b[(long)i * a.T + j];
+          for (int d = 0; d < cd; ++d) dw = fmaf(s_dOc[ii][d], s_Vk[jj][d], dw);
+          v = Wb[(long)i * a.T + j] * (dw - dl[i]);
+        }
       }
       s_dS[ii][jj] = v;
     }
@@ -398,14 +459,92 @@ __global__ __launch_bounds__(256) void attn_bwd_k_kernel(AttnArgs a, const float
   }
 }
 
+// ---------------------------------------------------------------- attention apply
+// out[i,b,h*dv+d] = sum_j W[h,b,i,j] v[j,b,h*dv+d]  (TRANS=false, reference zipformer.py:2269)
+// dv[j,b,h*dv+d]  = sum_i W[h,b,i,j] g[i,b,h*dv+d]  (TRANS=true, its gradient w.r.t. v)
+// workgroup = (128 output rows, b, h); the W tile is staged in LDS with coalesced row reads;
+// thread = (row pair, d-group): 8 FMAs per 6 LDS reads; dv <= 16.
+template <bool TRANS>
+__global__ __launch_bounds__(256) void attn_apply_kernel(const float* __restrict__ W,
+                                                         const float* __restrict__ v, int T, int B,
+                                                         int H, int dv, float* __restrict__ out) {
+  constexpr int RT = 128, CT = 64;
+  __shared__ float s_W[TRANS ? CT : RT][(TRANS ? RT : CT) + 1];
+  __shared__ float s_v[CT][17];
+  const int o0 = blockIdx.x * RT, b = blockIdx.y, h = blockIdx.z;
+  const int tid = threadIdx.x, row = tid >> 2, dg = tid & 3;
+  const float* Wb = W + ((long)h * B + b) * T * T;
+  const long ld = (long)H * dv;
+  float acc0[4] = {0.f, 0.f, 0.f, 0.f}, acc1[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int c0 = 0; c0 < T; c0 += CT) {
+    __syncthreads();
+    if (!TRANS) {
+      // rows = outputs i (o0..), cols = contraction j (c0..)
+      for (int idx = tid; idx < RT * CT; idx += 256) {
+        const int r = idx / CT, cc = idx % CT;
+        const int i = o0 + r, j = c0 + cc;
+        s_W[r][cc] = (i < T && j < T) ? Wb[(long)i * T + j] : 0.f;
+      }
+    } else {
+      // contraction over i (c0..) rows of W, outputs j (o0..) along the row
+      for (int idx = tid; idx < CT * RT; idx += 256) {
+        const int r = idx / RT, cc = idx % RT;
+        const int i = c0 + r, j = o0 + cc;
+        s_W[r][cc] = (i < T && j < T) ? Wb[(long)i * T + j] : 0.f;
+      }
+    }
+    for (int idx = tid; idx < CT * dv; idx += 256) {
+      const int r = idx / dv, d = idx % dv;
+      const int t = c0 + r;
+      s_v[r][d] = (t < T) ? v[((long)t * B + b) * ld + h * dv + d] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int cc = 0; cc < CT; ++cc) {
+      const float w0 = TRANS ? s_W[cc][row] : s_W[row][cc];
+      const float w1 = TRANS ? s_W[cc][row + 64] : s_W[row + 64][cc];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float vv = s_v[cc][dg + 4 * k];
+        acc0[k] = fmaf(w0, vv, acc0[k]);
+        acc1[k] = fmaf(w1, vv, acc1[k]);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int d = dg + 4 * k;
+    if (d < dv) {
+      if (o0 + row < T) out[((long)(o0 + row) * B + b) * ld + h * dv + d] = acc0[k];
+      if (o0 + row + 64 < T) out[((long)(o0 + row + 64) * B + b) * ld + h * dv + d] = acc1[k];
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int s2t_attn_apply(const float* W, const float* v, int T, int B, int H, int dv,
+                              int transpose, float* out, void* stream) {
+  if (T <= 0 || B <= 0 || H <= 0) return 0;
+  if (dv <= 0 || dv > 16) return -1;
+  dim3 grid((T + 127) / 128, B, H);
+  if (transpose)
+    hipLaunchKernelGGL(attn_apply_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, W, v, T,
+                       B, H, dv, out);
+  else
+    hipLaunchKernelGGL(attn_apply_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, W, v, T,
+                       B, H, dv, out);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
 
 extern "C" int s2t_relpos_attn_fwd(const float* qkp, const float* pos, const unsigned char* kpm,
                                    const unsigned char* amask, int T, int B, int H, int qd, int pd,
                                    float* W, void* stream) {
   if (T <= 0 || B <= 0 || H <= 0) return 0;
   if (qd <= 0 || qd > MAXQD || pd < 0 || pd > MAXPD) return -1;
-  AttnArgs a{qkp, pos, kpm, amask, T, B, H, qd, pd};
+  AttnArgs a{qkp, pos, kpm, amask, T, B, H, qd, pd, nullptr, nullptr, {nullptr, nullptr},
+             {nullptr, nullptr}, {0, 0}};
   dim3 grid((T + ROWS - 1) / ROWS, B, H);
   static bool attr_done = false;
   if (!attr_done) {
@@ -424,23 +563,30 @@ extern "C" int s2t_relpos_attn_fwd(const float* qkp, const float* pos, const uns
   return 0;
 }
 
-// dqkp (T,B,Dp) is fully written (q, k and p parts); dpos (2T-1, H*pd) must be zeroed by the
-// caller (accumulated with atomics) or NULL when the position term was skipped.
+// Gradient of W is given materialised (dW) and/or as factors (see AttnArgs): dW0 (B,T,T) for
+// head 0, and up to two (dO_c, V_c) pairs of (T,B,H*dv_c) tensors.  When any factor is used,
+// `delta_ws` must hold delta[h,b,i] = sum_j W dW on entry (delta_given = 1; for the pairs it is
+// sum_d dO_c * O_c, O_c = the apply's forward output).  dqkp (T,B,Dp) is fully written; dpos
+// (2T-1, H*pd) must be zeroed by the caller (accumulated) or NULL when pos was skipped.
 extern "C" int s2t_relpos_attn_bwd(const float* qkp, const float* pos, const unsigned char* kpm,
                                    const unsigned char* amask, int T, int B, int H, int qd, int pd,
-                                   const float* W, const float* dW, float* delta_ws, float* dqkp,
-                                   float* dpos, void* stream) {
+                                   const float* W, const float* dW, const float* dW0,
+                                   const float* dO1, const float* V1, int dv1, const float* dO2,
+                                   const float* V2, int dv2, int delta_given, float* delta_ws,
+                                   float* dqkp, float* dpos, void* stream) {
   if (T <= 0 || B <= 0 || H <= 0) return 0;
   if (qd <= 0 || qd > MAXQD || pd < 0 || pd > MAXPD) return -1;
-  AttnArgs a{qkp, pos, kpm, amask, T, B, H, qd, pd};
+  if ((dO1 ? dv1 : 0) + (dO2 ? dv2 : 0) > MAXCD) return -1;
+  if (!dW && !delta_given) return -1;
+  AttnArgs a{qkp, pos, kpm, amask, T, B, H, qd, pd, dW, dW0, {dO1, dO2}, {V1, V2}, {dv1, dv2}};
   dim3 grid((T + ROWS - 1) / ROWS, B, H);
-  hipLaunchKernelGGL(attn_bwd_q_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, W, dW,
+  hipLaunchKernelGGL(attn_bwd_q_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, W, delta_given,
                      delta_ws, dqkp);
   S2T_CHECK_LAUNCH();
   const size_t sm = pos ? sizeof(float) * (size_t)(T + ROWS) * pd : 0;
-  if (sm > 96 * 1024) return -1;
-  hipLaunchKernelGGL(attn_bwd_k_kernel, grid, dim3(256), sm, (hipStream_t)stream, a, W, dW,
-                     delta_ws, dqkp, pos ? dpos : nullptr);
+  if (sm > 64 * 1024) return -1;
+  hipLaunchKernelGGL(attn_bwd_k_kernel, grid, dim3(256), sm, (hipStream_t)stream, a, W, delta_ws,
+                     dqkp, pos ? dpos : nullptr);
   S2T_CHECK_LAUNCH();
   return 0;
 }

@@ -380,10 +380,12 @@ class RelPositionMultiheadAttentionWeights(nn.Module):
                                      max_positive=0.6, min_abs=0.0, max_abs=100.0, prob=0.025)
         self.linear_pos = ScaledLinear(pos_dim, num_heads * pos_head_dim, bias=False,
                                        initial_scale=0.05)
+        self._next_shared = None
 
     def forward(self, x: Tensor, pos_emb: Tensor, key_padding_mask: Optional[Tensor] = None,
                 attn_mask: Optional[Tensor] = None) -> Tensor:
         H, qd, pd = self.num_heads, self.query_head_dim, self.pos_head_dim
+        self.last_deferrable = False
         qkp = self.in_proj(x)
         T, B, _ = qkp.shape
         # gradient shaping of the key slice (identity in forward): only when one of them fires
@@ -404,8 +406,15 @@ class RelPositionMultiheadAttentionWeights(nn.Module):
         if self.training and random.random() < 0.1:
             penalize = lambda s: penalize_abs_values_gt(s, limit=25.0, penalty=1.0e-04,  # noqa
                                                         name=self.name)
+        if penalize is None and self.dropout == 0.0:
+            # the consumers' gradients w.r.t. W can be contracted inside our backward
+            self._next_shared = zk.AttnShared()
+            self._next_shared.device = qkp.device
+            self.last_deferrable = True
+            self.last_shared = self._next_shared
         w = zk.relpos_attention_weights(qkp, pos_proj, H, qd, pd, attn_mask, key_padding_mask,
-                                        penalize)
+                                        penalize, shared=self._next_shared)
+        self._next_shared = None
         if self.dropout != 0.0:
             w = nn.functional.dropout(w, p=self.dropout, training=self.training)
         return w
@@ -585,13 +594,22 @@ class Zipformer2EncoderLayer(nn.Module):
                                    key_padding_mask=src_key_padding_mask)
         src = src + self.feed_forward1(src)
         amask = self._seq_mask(src, attn_skip)
-        w0 = w[0:1]
-        if train and random.random() < float(self.const_attention_rate):
-            w0 = (w0 > 0.0).to(w0.dtype)
-            w0 = w0 * (1.0 / w0.sum(dim=-1, keepdim=True))
+        const_attn = train and random.random() < float(self.const_attention_rate)
+        if self.self_attn_weights.last_deferrable and not const_attn:
+            # one autograd edge into the weights; consumers hand their gradient factors over
+            shared = self.self_attn_weights.last_shared
+            w_na, w_a1, w_a2 = (zk.DeferredWeights(a, shared)
+                                for a in zk._AttnFanout.apply(w, shared, 3))
+            w0 = zk.attn_head0(w_na)
+        else:
+            w_a1 = w_a2 = w
+            w0 = w[0:1]
+            if const_attn:
+                w0 = (w0 > 0.0).to(w0.dtype)
+                w0 = w0 * (1.0 / w0.sum(dim=-1, keepdim=True))
         na = self.balancer_na(self.nonlin_attention(src, w0))
         src = src + (na if amask is None else na * amask)
-        sa = self.self_attn1(src, w)
+        sa = self.self_attn1(src, w_a1)
         src = src + (sa if amask is None else sa * amask)
         conv_skip = float(self.conv_skip_rate) if train else 0.0
         cv = self.conv_module1(src, chunk_size=chunk_size,
@@ -602,7 +620,7 @@ class Zipformer2EncoderLayer(nn.Module):
         fm = self._seq_mask(src, float(self.ff2_skip_rate) if train else 0.0)
         src = src + (ff if fm is None else ff * fm)
         src = self.bypass_mid(src_orig, src)
-        sa = self.self_attn2(src, w)
+        sa = self.self_attn2(src, w_a2)
         src = src + (sa if amask is None else sa * amask)
         cv = self.conv_module2(src, chunk_size=chunk_size,
                                src_key_padding_mask=src_key_padding_mask)

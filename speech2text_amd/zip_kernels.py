@@ -306,9 +306,50 @@ def glu_chunk_causal_dwconv(u, gate_off, key_padding_mask, conv, chunk_size):
 
 
 # ------------------------------------------------------------------ attention
+class AttnShared:
+    """Per layer-call scratch that lets the attention-weights backward contract its consumers'
+    gradients on the fly instead of receiving three materialised (H,B,T,T) tensors:
+    `pairs` = [(dO, v, O, dv)] from the value-apply consumers, `dW0` = (B,T,T) gradient of the
+    head-0 slice (nonlinear attention), `real` = any ordinary (materialised) gradient."""
+
+    def __init__(self):
+        self.pairs = []
+        self.dW0 = None
+        self.real = None
+
+
+class DeferredWeights:
+    """An alias of W handed to one consumer, plus the shared scratch."""
+
+    def __init__(self, w, shared):
+        self.w, self.shared = w, shared
+
+    @property
+    def shape(self):
+        return self.w.shape
+
+
+def _attn_bwd_call(qkp, pos, k8, a8, H, qd, pd, W, dW, dW0, pairs, delta):
+    T, B, _ = qkp.shape
+    dev = qkp.device
+    dqkp = torch.empty_like(qkp)
+    dpos = None if pos is None else torch.zeros_like(pos)
+    given = delta is not None
+    if delta is None:
+        delta = torch.empty((H, B, T), dtype=torch.float32, device=dev)
+    p = list(pairs) + [(None, None, None, 0)] * (2 - len(pairs))
+    N.profile_note("s2t_relpos_attn_bwd", 4.0 * (2 * qkp.numel() + 2 * W.numel()))
+    N.check(N.lib().s2t_relpos_attn_bwd(N.fp(qkp), N.fp(pos), N.ptr(k8), N.ptr(a8), T, B, H, qd, pd,
+                                        N.fp(W), N.fp(dW), N.fp(dW0), N.fp(p[0][0]), N.fp(p[0][1]),
+                                        p[0][3], N.fp(p[1][0]), N.fp(p[1][1]), p[1][3], int(given),
+                                        N.fp(delta), N.fp(dqkp), N.fp(dpos), N.stream()),
+            "s2t_relpos_attn_bwd")
+    return dqkp, dpos
+
+
 class _RelPosAttn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkp, pos_proj, kpm, amask, H, qd, pd):
+    def forward(ctx, qkp, pos_proj, kpm, amask, H, qd, pd, shared):
         _dev(qkp, pos_proj)
         qkp = qkp.contiguous().float()
         T, B, _ = qkp.shape
@@ -321,26 +362,122 @@ class _RelPosAttn(torch.autograd.Function):
                                             qd, pd, N.fp(W), N.stream()), "s2t_relpos_attn_fwd")
         ctx.save_for_backward(qkp, pos, k8, a8, W)
         ctx.cfg = (H, qd, pd)
+        ctx.shared = shared
         return W
 
     @staticmethod
     def backward(ctx, dW):
         qkp, pos, k8, a8, W = ctx.saved_tensors
         H, qd, pd = ctx.cfg
+        sh = ctx.shared
+        if sh is None:
+            dqkp, dpos = _attn_bwd_call(qkp, pos, k8, a8, H, qd, pd, W, dW.contiguous().float(),
+                                        None, [], None)
+            return dqkp, dpos, None, None, None, None, None, None
+        # deferred: the incoming gradient is the fan-out's stride-0 placeholder (ignored) unless
+        # W was consumed directly by ordinary ops; contract the stashed factors
         T, B, _ = qkp.shape
-        dW = dW.contiguous().float()
-        dev = qkp.device
-        delta = torch.empty((H, B, T), dtype=torch.float32, device=dev)
-        dqkp = torch.empty_like(qkp)
-        dpos = None if pos is None else torch.zeros_like(pos)
-        N.check(N.lib().s2t_relpos_attn_bwd(N.fp(qkp), N.fp(pos), N.ptr(k8), N.ptr(a8), T, B, H, qd,
-                                            pd, N.fp(W), N.fp(dW), N.fp(delta), N.fp(dqkp),
-                                            N.fp(dpos), N.stream()), "s2t_relpos_attn_bwd")
-        return dqkp, dpos, None, None, None, None, None
+        if dW is not None and any(st != 0 for st in dW.stride()):
+            sh.real = dW if sh.real is None else sh.real + dW
+        real = None if sh.real is None else sh.real.contiguous().float()
+        delta = torch.zeros((H, B, T), dtype=torch.float32, device=qkp.device)
+        for dO, v, O, dv in sh.pairs:
+            delta += (dO * O).view(T, B, H, dv).sum(dim=-1).permute(2, 1, 0)
+        if sh.dW0 is not None:
+            delta[0] += (W[0] * sh.dW0).sum(dim=-1)
+        if real is not None:
+            delta += (W * real).sum(dim=-1)
+        dqkp, dpos = _attn_bwd_call(qkp, pos, k8, a8, H, qd, pd, W, real, sh.dW0, sh.pairs, delta)
+        sh.pairs, sh.dW0, sh.real = [], None, None
+        return dqkp, dpos, None, None, None, None, None, None
+
+
+class _AttnFanout(torch.autograd.Function):
+    """W -> n aliases with ONE autograd edge back into the weights node.  Consumers that defer
+    their gradient return None; anything else is summed into shared.real."""
+
+    @staticmethod
+    def forward(ctx, W, shared, n):
+        ctx.shared = shared
+        ctx.shape = W.shape
+        ctx.set_materialize_grads(False)
+        return tuple(W.view_as(W) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        real = None
+        for g in grads:
+            if g is not None:
+                real = g if real is None else real + g
+        ctx.shared.real = real
+        ref = grads[0] if grads[0] is not None else None
+        dev = ref.device if ref is not None else ctx.shared.device
+        return torch.zeros((), dtype=torch.float32, device=dev).expand(ctx.shape), None, None
+
+
+def attn_fanout(W, n=3):
+    shared = AttnShared()
+    shared.device = W.device
+    aliases = _AttnFanout.apply(W, shared, n)
+    return [DeferredWeights(a, shared) for a in aliases], shared
+
+
+class _AttnHead0(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, W, shared):
+        ctx.shared = shared
+        return W[0:1]
+
+    @staticmethod
+    def backward(ctx, g):
+        g0 = g[0].contiguous().float()
+        sh = ctx.shared
+        sh.dW0 = g0 if sh.dW0 is None else sh.dW0 + g0
+        return None, None
+
+
+def attn_head0(dw: DeferredWeights):
+    """W[0:1] for the nonlinear-attention module; its gradient is stashed as dW0."""
+    return _AttnHead0.apply(dw.w, dw.shared)
+
+
+class _AttnApplyDeferred(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, W, v, shared, H):
+        _dev(W, v)
+        v = v.contiguous().float()
+        T, B, HD = v.shape
+        dv = HD // H
+        out = torch.empty_like(v)
+        N.profile_note("s2t_attn_apply", 4.0 * (W.numel() + 2 * v.numel()))
+        N.check(N.lib().s2t_attn_apply(N.fp(W), N.fp(v), T, B, H, dv, 0, N.fp(out), N.stream()),
+                "s2t_attn_apply")
+        ctx.save_for_backward(W, v, out)
+        ctx.shared, ctx.H = shared, H
+        return out
+
+    @staticmethod
+    def backward(ctx, dO):
+        W, v, out = ctx.saved_tensors
+        H = ctx.H
+        T, B, HD = v.shape
+        dv = HD // H
+        dO = dO.contiguous().float()
+        dV = torch.empty_like(v)
+        N.check(N.lib().s2t_attn_apply(N.fp(W), N.fp(dO), T, B, H, dv, 1, N.fp(dV), N.stream()),
+                "s2t_attn_apply(T)")
+        sh = ctx.shared
+        if len(sh.pairs) < 2 and sum(p[3] for p in sh.pairs) + dv <= 32:
+            sh.pairs.append((dO, v, out, dv))
+            return None, dV, None, None
+        # no room to defer: materialise this consumer's dW = dO . v^T
+        g = torch.matmul(dO.view(T, B, H, dv).permute(2, 1, 0, 3),
+                         v.view(T, B, H, dv).permute(2, 1, 3, 0))
+        return g, dV, None, None
 
 
 def relpos_attention_weights(qkp, pos_proj, num_heads, query_head_dim, pos_head_dim, attn_mask,
-                             key_padding_mask, penalize=None):
+                             key_padding_mask, penalize=None, shared=None):
     """qkp (T,B,H*(2*qd+pd)) = in_proj(x); pos_proj (2T-1, H*pd) = linear_pos(pos_emb) or None
     -> softmax weights (H,B,T,T).  scores[h,b,i,j] = q_i.k_j + p_i.pos[(T-1)-i+j]; masked
     entries are set to -1000 (reference zipformer.py:1966-2066).   HIP: zip_attn.hip.
@@ -349,7 +486,7 @@ def relpos_attention_weights(qkp, pos_proj, num_heads, query_head_dim, pos_head_
     materialised torch composition."""
     if penalize is None:
         return _RelPosAttn.apply(qkp, pos_proj, key_padding_mask, attn_mask, num_heads,
-                                 query_head_dim, pos_head_dim)
+                                 query_head_dim, pos_head_dim, shared)
     T, B, _ = qkp.shape
     H, qd, pd = num_heads, query_head_dim, pos_head_dim
     q = qkp[..., :H * qd].reshape(T, B, H, qd).permute(2, 1, 0, 3)
@@ -371,7 +508,13 @@ def relpos_attention_weights(qkp, pos_proj, num_heads, query_head_dim, pos_head_
 
 
 def attention_apply(weights, v, num_heads):
-    """weights (H,B,T,T), v (T,B,H*dv) -> (T,B,H*dv)"""
+    """weights (H,B,T,T) [Tensor or DeferredWeights], v (T,B,H*dv) -> (T,B,H*dv).
+    DeferredWeights + dv <= 16: HIP apply kernel, gradient w.r.t. W deferred to the weights'
+    backward (never materialised).  Otherwise a plain batched GEMM (rocBLAS)."""
+    if isinstance(weights, DeferredWeights):
+        if v.shape[-1] // num_heads <= 16:
+            return _AttnApplyDeferred.apply(weights.w, v, weights.shared, num_heads)
+        weights = weights.w
     T, B, _ = v.shape
     x = v.reshape(T, B, num_heads, -1).permute(2, 1, 0, 3)
     x = torch.matmul(weights, x)

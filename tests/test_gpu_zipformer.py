@@ -43,9 +43,9 @@ def cpu_rng(monkeypatch):
                         torch.rand(*s, dtype=dtype).to(device))
 
 
-def _train_step(m, x, lens, wts):
+def _train_step(m, x, lens, wts, rv=0.0):
     real = random.random
-    random.random = lambda: 0.0          # every Balancer / Whiten / limit / penalty fires
+    random.random = lambda: rv           # 0.0: every Balancer / Whiten / limit / penalty fires
     try:
         torch.manual_seed(7)
         y, yl = m(x, lens)
@@ -95,7 +95,11 @@ def test_tiny_vs_reference_goldens(golden_dir, dev, cpu_rng, tag, chunk, left):
         assert np.abs(got - ref).max() / denom < 5e-3, (n, np.abs(got - ref).max(), denom)
 
 
-def test_mid_ragged_vs_oracle(dev, cpu_rng):
+@pytest.mark.parametrize("rv", [0.0, 0.5])
+def test_mid_ragged_vs_oracle(dev, cpu_rng, rv):
+    """rv = value returned by random.random(): 0.0 -> all gradient shaping + the score penalty
+    (materialised attention path); 0.5 -> no Balancer/Whiten/penalty, limit_param_value only,
+    which exercises the fused attention path with deferred (never materialised) dW."""
     torch.manual_seed(11)
     m = _model(MID, (-1,), (-1,), dev)
     with torch.no_grad():
@@ -124,10 +128,10 @@ def test_mid_ragged_vs_oracle(dev, cpu_rng):
     wts = torch.randn(yo.shape, generator=g)
     xc = x.clone().requires_grad_(True)
     torch.manual_seed(7)
-    yo, _ = Z.zipformer_forward(sd, _zcfg(MID), xc, lens, Z.Ctl(True, lambda: 0.0, pos_dropout=0.0))
+    yo, _ = Z.zipformer_forward(sd, _zcfg(MID), xc, lens, Z.Ctl(True, lambda: rv, pos_dropout=0.0))
     (yo * wts).sum().backward()
     xg = x.to(dev).requires_grad_(True)
-    y, _ = _train_step(m, xg, lens.to(dev), wts.to(dev))
+    y, _ = _train_step(m, xg, lens.to(dev), wts.to(dev), rv)
     np.testing.assert_allclose(y.detach().cpu().numpy(), yo.detach().numpy(), atol=1e-4, rtol=2e-3)
     np.testing.assert_allclose(xg.grad.cpu().numpy(), xc.grad.numpy(), atol=5e-5, rtol=1e-2)
     worst = 0.0
