@@ -126,13 +126,14 @@ class _WhitenFn(torch.autograd.Function):
     def forward(ctx, x, module):
         ctx.save_for_backward(x)
         ctx.module = module
+        ctx.stats = zk.WhitenStats(x, module.num_groups)
         return x.view_as(x)
 
     @staticmethod
     def backward(ctx, g):
         (x,) = ctx.saved_tensors
         w = ctx.module
-        out, active = zk.whiten_backward(x, g, w.num_groups, float(w.whitening_limit),
+        out, active = zk.whiten_backward(x, g, ctx.stats, float(w.whitening_limit),
                                          float(w.grad_scale))
         w.prob = w.max_prob if active else w.min_prob
         return out, None

@@ -201,24 +201,52 @@ def balancer_backward(x, g, min_mean, max_mean, min_rms, max_rms, grad_scale, ch
     return (gf + gf.abs() * ((a * coef) + (b * coef) * xf)).to(g.dtype)
 
 
-def whiten_backward(x, g, num_groups, limit, grad_scale):
+class WhitenStats:
+    """Whitening statistics of x, computed when the module fires in FORWARD (they depend on x
+    only) so that the scalar `metric` reaches the host through pinned memory long before the
+    backward pass needs it: no pipeline-draining read-back inside backward (the reference calls
+    .item()-style comparisons there, scaling.py:1012)."""
+
+    def __init__(self, x, num_groups):
+        C = x.shape[-1]
+        xf = x.detach().reshape(-1, C).float()
+        cg = C // num_groups
+        xg = xf.reshape(xf.shape[0], num_groups, cg).transpose(0, 1)          # (G,N,cg)
+        self.mean = xg.mean(dim=1, keepdim=True)
+        xc = xg - self.mean
+        self.cov = torch.matmul(xc.transpose(1, 2), xc)                        # (G,cg,cg)
+        self.md = torch.diagonal(self.cov, dim1=1, dim2=2).mean()
+        self.covsq = (self.cov * self.cov).sum() / (num_groups * cg)
+        self.denom = self.md * self.md + 1.0e-20
+        metric = self.covsq / self.denom
+        if x.is_cuda:
+            self.host = torch.empty(1, dtype=torch.float32, pin_memory=True)
+            self.host.copy_(metric.reshape(1), non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record()
+        else:
+            self.host = metric.reshape(1)
+            self.event = None
+        self.num_groups, self.cg = num_groups, cg
+
+    def metric(self):
+        if self.event is not None:
+            self.event.synchronize()
+        return float(self.host[0])
+
+
+def whiten_backward(x, g, stats, limit, grad_scale):
     """Closed form of reference scaling.py:949-1028.  Returns (grad, penalty_was_active)."""
+    if not (stats.metric() >= limit):
+        return g, False
     shp = x.shape
     C = shp[-1]
+    G, cg = stats.num_groups, stats.cg
     xf = x.reshape(-1, C).float()
-    nfr = xf.shape[0]
-    cg = C // num_groups
-    xg = xf.reshape(nfr, num_groups, cg).transpose(0, 1)            # (G,N,cg)
-    xc = xg - xg.mean(dim=1, keepdim=True)
-    cov = torch.matmul(xc.transpose(1, 2), xc)                      # (G,cg,cg)
-    md = torch.diagonal(cov, dim1=1, dim2=2).mean()
-    covsq = (cov * cov).sum() / (num_groups * cg)
-    denom = md * md + 1.0e-20
-    metric = covsq / denom
-    if not bool(metric >= limit):      # one scalar read-back, as the reference does
-        return g, False
+    xc = xf.reshape(xf.shape[0], G, cg).transpose(0, 1) - stats.mean
     eye = torch.eye(cg, device=x.device, dtype=torch.float32)
-    dcov = (2.0 / (num_groups * cg)) * (cov / denom - (covsq * md / (denom * denom)) * eye)
+    dcov = (2.0 / (G * cg)) * (stats.cov / stats.denom
+                               - (stats.covsq * stats.md / (stats.denom * stats.denom)) * eye)
     dxc = 2.0 * torch.matmul(xc, dcov)
     dx = dxc - dxc.mean(dim=1, keepdim=True)
     pg = dx.transpose(0, 1).reshape(shp)
