@@ -186,7 +186,7 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
 
     from speech2text_amd import _native
     from speech2text_amd.task_factory.rnnt_task import PrunedRnntTask

@@ -23,7 +23,7 @@ class Trainer:
         self.clip_val = gradient_clip_val
         self.clip_algo = gradient_clip_algorithm
         self.max_epochs = max_epochs
-        self.bucket_bytes = int(bucket_mb) << 20
+        self.bucket_bytes = int(float(bucket_mb) * (1 << 20))
         self.micro = 0
         self.task = None
 

@@ -1,0 +1,80 @@
+"""GPU: two ranks sharing cuda:0 (gloo transport) run the full trainer path -- flat gradient
+buffer, bucket hooks firing from the autograd thread, side HIP stream, scalar sync, flat
+ScaledAdam -- and must stay bit-identical replicas that follow the same trajectory as a
+single process fed the averaged gradient."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import random
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from speech2text_amd.build_task import TaskFactory
+    from speech2text_amd.trainer import Trainer
+    dev = torch.device("cuda", 0)
+    cfg = bench.c3_config(64)
+    cfg["encoder"]["config"].update({"downsampling_factor": [1, 2], "num_encoder_layers": [1, 1],
+                                     "feedforward_dim": [96, 128], "encoder_dim": [48, 64],
+                                     "encoder_unmasked_dim": [32, 48], "num_heads": [4, 4],
+                                     "query_head_dim": 8, "value_head_dim": 4, "pos_dim": 16,
+                                     "cnn_module_kernel": [15, 7]})
+    cfg["predictor"]["config"].update({"output_dim": 64, "symbol_embedding_dim": 32})
+    cfg["joiner"].update({"input_dim": 64})
+    cfg["trainer"]["accumulate_grad_batches"] = 2
+    random.seed(5)
+    torch.manual_seed(1234 + 17 * rank)            # different init: broadcast must fix it
+    task = TaskFactory.get("Pruned_Rnnt")(cfg)
+    tr = Trainer(bucket_mb=0.05, **cfg["trainer"]).setup(task, dev)
+    task.train()
+    nb = len(tr.reducer.buckets)
+    losses = []
+    for i in range(4):
+        batch = bench.make_batch(rank * 10 + i, 2, 2.0, 5, 64, dev)
+        random.seed(100 + i)                       # same python-random decisions on both ranks
+        torch.manual_seed(200 + i)
+        losses.append(float(tr.training_step(batch, i)))
+    torch.cuda.synchronize()
+    flat = tr.store.p().detach().cpu()
+    q.put((rank, losses, flat, nb, {k: float(v) for k, v in task.logged.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_stay_identical(dev):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+    (r0, l0, f0, nb, lg0), (r1, l1, f1, _, lg1) = res
+    assert nb >= 3
+    assert all(x == x for x in l0 + l1)                       # finite
+    assert torch.equal(f0, f1), "replicas diverged"           # same params after 2 optimizer steps
+    assert lg0.keys() == lg1.keys()
+    for k in lg0:                                             # synced scalars are the rank mean
+        assert abs(lg0[k] - lg1[k]) < 1e-5 * max(1.0, abs(lg0[k])), k
