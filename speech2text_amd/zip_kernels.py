@@ -205,18 +205,25 @@ class WhitenStats:
     """Whitening statistics of x, computed when the module fires in FORWARD (they depend on x
     only) so that the scalar `metric` reaches the host through pinned memory long before the
     backward pass needs it: no pipeline-draining read-back inside backward (the reference calls
-    .item()-style comparisons there, scaling.py:1012)."""
+    .item()-style comparisons there, scaling.py:1012).
+    cov = x^T x - N mean mean^T per group (one GEMM on the raw activations, no centred copy)."""
 
     def __init__(self, x, num_groups):
         C = x.shape[-1]
         xf = x.detach().reshape(-1, C).float()
-        cg = C // num_groups
-        xg = xf.reshape(xf.shape[0], num_groups, cg).transpose(0, 1)          # (G,N,cg)
-        self.mean = xg.mean(dim=1, keepdim=True)
-        xc = xg - self.mean
-        self.cov = torch.matmul(xc.transpose(1, 2), xc)                        # (G,cg,cg)
-        self.md = torch.diagonal(self.cov, dim1=1, dim2=2).mean()
-        self.covsq = (self.cov * self.cov).sum() / (num_groups * cg)
+        n = xf.shape[0]
+        G, cg = num_groups, C // num_groups
+        mean = xf.mean(dim=0)                                                   # (C,)
+        if G == 1:
+            cov = torch.addmm(torch.outer(mean, mean), xf.t(), xf, beta=-float(n)).unsqueeze(0)
+        else:
+            xg = xf.view(n, G, cg).transpose(0, 1)                              # (G,N,cg)
+            mg = mean.view(G, cg, 1)
+            cov = torch.baddbmm(torch.bmm(mg, mg.transpose(1, 2)), xg.transpose(1, 2), xg,
+                                beta=-float(n))
+        self.mean, self.cov = mean, cov
+        self.md = torch.diagonal(cov, dim1=1, dim2=2).mean()
+        self.covsq = (cov * cov).sum() / (G * cg)
         self.denom = self.md * self.md + 1.0e-20
         metric = self.covsq / self.denom
         if x.is_cuda:
@@ -227,7 +234,7 @@ class WhitenStats:
         else:
             self.host = metric.reshape(1)
             self.event = None
-        self.num_groups, self.cg = num_groups, cg
+        self.num_groups, self.cg = G, cg
 
     def metric(self):
         if self.event is not None:
@@ -235,23 +242,34 @@ class WhitenStats:
         return float(self.host[0])
 
 
+_EYES = {}
+
+
 def whiten_backward(x, g, stats, limit, grad_scale):
-    """Closed form of reference scaling.py:949-1028.  Returns (grad, penalty_was_active)."""
+    """Closed form of reference scaling.py:949-1028.  Returns (grad, penalty_was_active).
+    d metric/d x = 2 (x - mean) dcov  (the centring's own Jacobian vanishes because the centred
+    columns sum to zero), i.e. ONE GEMM with a bias row."""
     if not (stats.metric() >= limit):
         return g, False
     shp = x.shape
     C = shp[-1]
     G, cg = stats.num_groups, stats.cg
-    xf = x.reshape(-1, C).float()
-    xc = xf.reshape(xf.shape[0], G, cg).transpose(0, 1) - stats.mean
-    eye = torch.eye(cg, device=x.device, dtype=torch.float32)
-    dcov = (2.0 / (G * cg)) * (stats.cov / stats.denom
+    key = (cg, str(x.device))
+    eye = _EYES.get(key)
+    if eye is None:
+        eye = _EYES[key] = torch.eye(cg, device=x.device, dtype=torch.float32)
+    dcov = (4.0 / (G * cg)) * (stats.cov / stats.denom
                                - (stats.covsq * stats.md / (stats.denom * stats.denom)) * eye)
-    dxc = 2.0 * torch.matmul(xc, dcov)
-    dx = dxc - dxc.mean(dim=1, keepdim=True)
-    pg = dx.transpose(0, 1).reshape(shp)
+    xf = x.reshape(-1, C).float()
+    if G == 1:
+        pg = torch.addmm(-(stats.mean @ dcov[0]), xf, dcov[0])
+    else:
+        xg = xf.view(xf.shape[0], G, cg).transpose(0, 1)
+        bias = -torch.bmm(stats.mean.view(G, 1, cg), dcov)
+        pg = torch.baddbmm(bias, xg, dcov).transpose(0, 1)
+    pg = pg.reshape(shp)
     scale = grad_scale * (g.float().norm() / (pg.norm() + 1.0e-20))
-    return g + (pg * scale).to(g.dtype), True
+    return g + pg * scale, True
 
 
 # ------------------------------------------------------------------ conv module core
