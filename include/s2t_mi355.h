@@ -131,7 +131,11 @@ int s2t_relpos_attn_bwd(const float* qkp, const float* pos, const unsigned char*
                         const unsigned char* amask, int T, int B, int H, int qd, int pd,
                         const float* W, const float* dW, const float* dW0, const float* dO1,
                         const float* V1, int dv1, const float* dO2, const float* V2, int dv2,
-                        int delta_given, float* delta_ws, float* dqkp, float* dpos, void* stream);
+                        int delta_given, float* delta_ws, float* dqkp, float* dpos,
+                        float* workspace, void* stream);
+/* floats of `workspace` (per-(b,h,query block) partial sums of dpos, reduced in a second pass
+ * instead of contended atomics); may be NULL when pos is NULL. */
+long s2t_relpos_attn_bwd_workspace_floats(int T, int B, int H, int pd);
 /* attention apply (model/encoder/zipformer.py:2269): transpose=0: out[i] = sum_j W[i,j] v[j];
  * transpose=1: out[j] = sum_i W[i,j] v[i] (gradient w.r.t. the values).  v,out (T,B,H*dv). */
 int s2t_attn_apply(const float* W, const float* v, int T, int B, int H, int dv, int transpose,

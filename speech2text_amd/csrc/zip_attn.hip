@@ -16,6 +16,7 @@
 // single pass with the scores held in registers; longer sequences use two passes
 // (statistics, then recompute + write) so LDS use is independent of T.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -459,6 +460,367 @@ __global__ __launch_bounds__(256) void attn_bwd_k_kernel(AttnArgs a, const float
   }
 }
 
+// ---------------------------------------------------------------- backward on the matrix cores
+// Per 32x32 score tile:  dW = dOcat . Vcat^T  (+ materialised terms),  dS = W o (dW - delta_i),
+//   dq += dS . K   and   dk += dS^T . Q   on v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate).
+// Accumulator layout of a 32x32 tile: column = lane&31, rows (r&3)+8(r>>2)+4(lane>>5) in the 16
+// registers.  dS^T.Q takes the dS accumulator registers directly as the A operand (k permuted
+// consistently with the B rows); dS.K needs the row on the lane and goes through a wave-private
+// LDS tile, which the position-gradient sums then read by diagonals.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// element k (0..cd-1) of the concatenated factor row t (dO_c or V_c rows)
+__device__ __forceinline__ float pair_elem(const AttnArgs& a, const float* const src[2], int t,
+                                           int b, int h, int k) {
+  if (t >= a.T) return 0.f;
+  if (a.pdO[0]) {
+    if (k < a.pdv[0]) return src[0][((long)t * a.B + b) * ((long)a.H * a.pdv[0]) + h * a.pdv[0] + k];
+    k -= a.pdv[0];
+  }
+  if (a.pdO[1] && k < a.pdv[1])
+    return src[1][((long)t * a.B + b) * ((long)a.H * a.pdv[1]) + h * a.pdv[1] + k];
+  return 0.f;
+}
+
+// 32x32 tile of a (T,T) matrix in accumulator layout, indices clamped (validity is in tile_ok)
+__device__ __forceinline__ void load_tile16(const float* __restrict__ base, int T, int i0, int j0,
+                                            int lo, int hi, float (&w)[16]) {
+  // 32-bit offsets from a wave-uniform base (T*T < 2^31 checked by the launcher); rows beyond
+  // T clamp to the last element
+  const unsigned last = (unsigned)T * (unsigned)T - 1u;
+  const unsigned o0 = (unsigned)(i0 + 4 * hi) * (unsigned)T + (unsigned)min(j0 + lo, T - 1);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const unsigned off = min(o0 + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)T, last);
+    w[r] = base[off];
+  }
+}
+
+// bit r set <=> element (i0 + acc_row(r,hi), j0 + lo) takes part in the softmax
+__device__ __forceinline__ unsigned tile_ok(const AttnArgs& a, int b, int i0, int j0, int lo,
+                                            int hi) {
+  const int j = j0 + lo;
+  const int jc = min(j, a.T - 1);
+  bool jok = j < a.T;
+  if (a.kpm) jok = jok && !a.kpm[(long)b * a.T + jc];
+  unsigned ok = 0;
+  const unsigned last = (unsigned)a.T * (unsigned)a.T - 1u;
+  const unsigned o0 = (unsigned)(i0 + 4 * hi) * (unsigned)a.T + (unsigned)jc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = i0 + acc_row(r, hi);
+    bool v = jok && i < a.T;
+    if (a.amask)
+      v = v && !a.amask[min(o0 + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)a.T, last)];
+    ok |= (v ? 1u : 0u) << r;
+  }
+  return ok;
+}
+
+template <int NS>
+__device__ __forceinline__ f32x16 ds_tile(const AttnArgs& a, const float* __restrict__ dWb,
+                                          const float* __restrict__ dW0b, int b, int i0, int j0,
+                                          int lo, int hi, const float* af, const float* bf,
+                                          const float (&w)[16], f32x16 acc) {
+  // acc enters as -delta_i (row constants as the initial accumulator)
+#pragma unroll
+  for (int s = 0; s < NS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[s], acc, 0, 0, 0);
+  if (dWb) {
+    float t[16];
+    load_tile16(dWb, a.T, i0, j0, lo, hi, t);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += t[r];
+  }
+  if (dW0b) {
+    float t[16];
+    load_tile16(dW0b, a.T, i0, j0, lo, hi, t);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += t[r];
+  }
+  const unsigned ok = tile_ok(a, b, i0, j0, lo, hi);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = ((ok >> r) & 1u) ? w[r] * acc[r] : 0.f;
+  return acc;
+}
+
+// dk: workgroup = (32 keys, b, h); the 4 waves split the query blocks and their partial
+// sums meet in LDS.
+template <int NS>
+__global__ __launch_bounds__(256, 2) void attn_bwd_k_mfma_kernel(AttnArgs a,
+                                                              const float* __restrict__ W,
+                                                              const float* __restrict__ delta,
+                                                              float* __restrict__ dqkp) {
+  constexpr int NSA = NS > 0 ? NS : 1;
+  __shared__ float s_red[4][32][33];   // first the per-wave dO_cat staging, then the dk partials
+  const int j0 = blockIdx.x * 32, b = blockIdx.y, h = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
+  const float* Wb = W + ((long)h * a.B + b) * a.T * a.T;
+  const float* dWb = a.dW ? a.dW + ((long)h * a.B + b) * a.T * a.T : nullptr;
+  const float* dW0b = (a.dW0 && h == 0) ? a.dW0 + (long)b * a.T * a.T : nullptr;
+  const float* dlb = delta + ((long)h * a.B + b) * a.T;
+  const int qd = a.qd;
+  float bf[NSA];   // V_cat[j0+lo][hi + 2s]
+#pragma unroll
+  for (int s = 0; s < NS; ++s) bf[s] = pair_elem(a, a.pV, j0 + lo, b, h, hi + 2 * s);
+  f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int nib = (a.T + 31) / 32;
+  float wn[16];
+  if (wave < nib) load_tile16(Wb, a.T, wave * 32, j0, lo, hi, wn);
+  for (int ib = wave; ib < nib; ib += 4) {
+    const int i0 = ib * 32;
+    float af[NSA], qv[16];
+    f32x16 ndl;
+    if (NS > 0) {
+      // dO_cat rows of this query block: coalesced load -> wave-private LDS -> A fragments
+      constexpr int CDP = 2 * NSA;
+#pragma unroll 4
+      for (int q = 0; q < (32 * CDP + 63) / 64; ++q) {
+        const int idx = lane + 64 * q;
+        const int rr = idx / CDP, k = idx % CDP;
+        if (rr < 32) s_red[wave][rr][k] = pair_elem(a, a.pdO, i0 + rr, b, h, k);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int s = 0; s < NS; ++s) af[s] = s_red[wave][lo][hi + 2 * s];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+    }
+    const unsigned Dp = (unsigned)(a.H * (2 * qd + a.pd));
+    const unsigned qcol = (unsigned)b * Dp + (unsigned)(h * qd + min(lo, qd - 1));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const unsigned i = (unsigned)min(i0 + acc_row(r, hi), a.T - 1);   // rows beyond T meet dS = 0
+      ndl[r] = -dlb[i];
+      const float q = a.qkp[i * ((unsigned)a.B * Dp) + qcol];
+      qv[r] = lo < qd ? q : 0.f;
+    }
+    f32x16 ds = ds_tile<NS>(a, dWb, dW0b, b, i0, j0, lo, hi, af, bf, wn, ndl);
+    if (ib + 4 < nib) load_tile16(Wb, a.T, i0 + 128, j0, lo, hi, wn);
+    // dk[j][d] += sum_i dS[i][j] q[i][d]: A = dS registers (k = query row), B[k][n = d]
+#pragma unroll
+    for (int s = 0; s < 16; ++s) z = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[s], qv[s], z, 0, 0, 0);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s_red[wave][acc_row(r, hi)][lo] = z[r];
+  __syncthreads();
+  for (int idx = tid; idx < 32 * 32; idx += 256) {
+    const int jj = idx >> 5, d = idx & 31;
+    const int j = j0 + jj;
+    if (j < a.T && d < qd) {
+      const float v = s_red[0][jj][d] + s_red[1][jj][d] + s_red[2][jj][d] + s_red[3][jj][d];
+      dqkp[((long)j * a.B + b) * (a.H * (2 * qd + a.pd)) + a.H * qd + h * qd + d] = v;
+    }
+  }
+}
+
+// dq, dp and the per-(b,h,query block) partial sums of dpos: workgroup = (128 query rows, b, h),
+// one 32-row block per wave, loop over key blocks.  ws: [b][h][ib][(nj+1)*32][pd]; row u of
+// query block ib belongs to rel = (T-1) - (32 ib + 31) + u.
+template <int NS, int PD>
+__global__ __launch_bounds__(256, 2) void attn_bwd_q_mfma_kernel(AttnArgs a,
+                                                              const float* __restrict__ W,
+                                                              const float* __restrict__ delta,
+                                                              float* __restrict__ dqkp,
+                                                              float* __restrict__ ws) {
+  constexpr int NSA = NS > 0 ? NS : 1;
+  constexpr int NPQ = (160 * PD + 255) / 256;
+  __shared__ float s_K[32][33];                                        // K[j0+jj][d]
+  __shared__ float s_V[32][33];                                        // V_cat[j0+jj][k]
+  __shared__ __attribute__((aligned(16))) float s_pos[160][PD];        // pos window
+  __shared__ float s_t[4][32][33];                                     // per-wave dS tile [i][j]
+  __shared__ __attribute__((aligned(16))) float s_P[4][32][PD];        // per-wave p rows
+  const int ib0 = blockIdx.x * 128, b = blockIdx.y, h = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
+  const int i0 = ib0 + wave * 32;
+  const bool live = i0 < a.T;
+  const float* Wb = W + ((long)h * a.B + b) * a.T * a.T;
+  const float* dWb = a.dW ? a.dW + ((long)h * a.B + b) * a.T * a.T : nullptr;
+  const float* dW0b = (a.dW0 && h == 0) ? a.dW0 + (long)b * a.T * a.T : nullptr;
+  const float* dlb = delta + ((long)h * a.B + b) * a.T;
+  const int qd = a.qd, pd = a.pd;
+  const int nj = (a.T + 31) / 32;
+  const bool want_pos = a.pos != nullptr;
+  float af[NSA];
+  f32x16 ndl;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) af[s] = pair_elem(a, a.pdO, i0 + lo, b, h, hi + 2 * s);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) ndl[r] = -dlb[min(i0 + acc_row(r, hi), a.T - 1)];
+  for (int idx = lane; idx < 32 * PD; idx += 64) {
+    const int rr = idx / PD, d = idx % PD;
+    s_P[wave][rr][d] = (i0 + rr < a.T && d < pd) ? p_row(a, i0 + rr, b, h)[d] : 0.f;
+  }
+  f32x16 zq = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float dp[PD], dacc[PD];
+#pragma unroll
+  for (int d = 0; d < PD; ++d) dp[d] = dacc[d] = 0.f;
+  // register staging of the next key block
+  float rk[4], rv[4], rp[NPQ], wn[16];
+  auto fetch = [&](int j0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = tid + 256 * q, jj = idx >> 5, d = idx & 31;
+      rk[q] = (j0 + jj < a.T && d < qd) ? k_row(a, j0 + jj, b, h)[d] : 0.f;
+      rv[q] = (NS > 0 && d < 2 * NS) ? pair_elem(a, a.pV, j0 + jj, b, h, d) : 0.f;
+    }
+    if (want_pos) {
+      // window entry w <-> rel (T-1) - (ib0 + 127) + j0 + w
+      const int base = (a.T - 1) - (ib0 + 127) + j0;
+#pragma unroll
+      for (int q = 0; q < NPQ; ++q) {
+        const int idx = tid + 256 * q, w = idx / PD, d = idx % PD;
+        const int rel = base + w;
+        rp[q] = (w < 160 && d < pd && rel >= 0 && rel < 2 * a.T - 1)
+                    ? a.pos[(long)rel * a.H * pd + h * pd + d] : 0.f;
+      }
+    }
+    if (live) load_tile16(Wb, a.T, i0, j0, lo, hi, wn);
+  };
+  fetch(0);
+  float* wsb = nullptr;
+  if (ws && live)
+    wsb = ws + ((((long)b * a.H + h) * nj + (i0 >> 5)) * (nj + 1)) * 32 * pd;
+  for (int jb = 0; jb < nj; ++jb) {
+    const int j0 = jb * 32;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = tid + 256 * q, jj = idx >> 5, d = idx & 31;
+      s_K[jj][d] = rk[q];
+      s_V[jj][d] = rv[q];
+    }
+    if (want_pos) {
+#pragma unroll
+      for (int q = 0; q < NPQ; ++q) {
+        const int idx = tid + 256 * q;
+        if (idx < 160 * PD) s_pos[idx / PD][idx % PD] = rp[q];
+      }
+    }
+    __syncthreads();
+    f32x16 ds;
+    if (live) {
+      float bf[NSA];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) bf[s] = s_V[lo][hi + 2 * s];
+      ds = ds_tile<NS>(a, dWb, dW0b, b, i0, j0, lo, hi, af, bf, wn, ndl);
+    }
+    if (jb + 1 < nj) fetch(j0 + 32);   // lands while this tile's products run
+    if (!live) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s_t[wave][acc_row(r, hi)][lo] = ds[r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    float at[16];   // dS[i = lo][j = hi + 2s]
+#pragma unroll
+    for (int s = 0; s < 16; ++s) at[s] = s_t[wave][lo][hi + 2 * s];
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+      zq = __builtin_amdgcn_mfma_f32_32x32x2f32(at[s], s_K[hi + 2 * s][lo], zq, 0, 0, 0);
+    if (want_pos) {
+      // dp[i][d] += dS[i][j] pos[(T-1) - i + j][d]; window row = 127 - (i - ib0) + (j - j0)
+      const int w0 = 127 - (wave * 32 + lo) + hi;
+#pragma unroll 4
+      for (int s = 0; s < 16; ++s) {
+#pragma unroll
+        for (int d = 0; d < PD; ++d) dp[d] = fmaf(at[s], s_pos[w0 + 2 * s][d], dp[d]);
+      }
+      // dpos partial: lane u owns the diagonal j - i + 31 = u of this tile
+#pragma unroll 4
+      for (int ii = 0; ii < 32; ++ii) {
+        const int jj = ii + lane - 31;
+        float v = s_t[wave][ii][min(max(jj, 0), 31)];
+        v = (jj >= 0 && jj < 32) ? v : 0.f;
+#pragma unroll
+        for (int d = 0; d < PD; ++d) dacc[d] = fmaf(v, s_P[wave][ii][d], dacc[d]);
+      }
+      if (wsb) {
+        if (lane < 32)
+          for (int d = 0; d < pd; ++d) wsb[((long)jb * 32 + lane) * pd + d] = dacc[d];
+#pragma unroll
+        for (int d = 0; d < PD; ++d) {
+          const float up = __shfl(dacc[d], (lane + 32) & 63, 64);
+          dacc[d] = lane < 32 ? up : 0.f;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (!live) return;
+  if (want_pos && wsb && lane < 32)
+    for (int d = 0; d < pd; ++d) wsb[((long)nj * 32 + lane) * pd + d] = dacc[d];
+  const int Dp = a.H * (2 * qd + pd);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = i0 + acc_row(r, hi);
+    if (i < a.T && lo < qd) dqkp[((long)i * a.B + b) * Dp + h * qd + lo] = zq[r];
+  }
+#pragma unroll
+  for (int d = 0; d < PD; ++d) dp[d] += __shfl_xor(dp[d], 32, 64);
+  if (hi == 0 && i0 + lo < a.T) {
+    float* o = dqkp + ((long)(i0 + lo) * a.B + b) * Dp + 2 * a.H * qd + h * pd;
+    for (int d = 0; d < pd; ++d) o[d] = want_pos ? dp[d] : 0.f;
+  }
+}
+
+// dpos[rel][h][d] += sum over (b, query block) of the partial rows that map to rel
+__global__ __launch_bounds__(256) void attn_dpos_reduce_kernel(const float* __restrict__ ws, int T,
+                                                               int B, int H, int pd,
+                                                               float* __restrict__ dpos) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int rel = idx / pd, d = idx % pd, h = blockIdx.y;
+  if (rel >= 2 * T - 1) return;
+  const int nj = (T + 31) / 32, rows = (nj + 1) * 32;
+  float acc = 0.f;
+  for (int b = blockIdx.z; b < B; b += gridDim.z) {
+    const float* base = ws + (((long)b * H + h) * nj) * rows * pd;
+    for (int ib = 0; ib < nj; ++ib) {
+      const int u = rel - ((T - 1) - (32 * ib + 31));
+      if (u >= 0 && u < rows) acc += base[((long)ib * rows + u) * pd + d];
+    }
+  }
+  atomicAdd(&dpos[(long)rel * H * pd + h * pd + d], acc);
+}
+
+// delta[h,b,i] = sum_j W dW for a materialised dW (one wave per row)
+__global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ W,
+                                                         const float* __restrict__ dW, long rows,
+                                                         int T, float* __restrict__ delta) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float acc = 0.f;
+  for (int j = lane; j < T; j += 64) acc = fmaf(W[row * T + j], dW[row * T + j], acc);
+  acc = wave_sum(acc);
+  if (lane == 0) delta[row] = acc;
+}
+
+template <int NS>
+int launch_attn_bwd_mfma(const AttnArgs& a, const float* W, const float* delta, float* dqkp,
+                         float* dpos, float* ws, hipStream_t st) {
+  const dim3 gq((a.T + 127) / 128, a.B, a.H), gk((a.T + 31) / 32, a.B, a.H);
+  if (a.pd <= 4)
+    hipLaunchKernelGGL((attn_bwd_q_mfma_kernel<NS, 4>), gq, dim3(256), 0, st, a, W, delta, dqkp,
+                       a.pos ? ws : nullptr);
+  else
+    hipLaunchKernelGGL((attn_bwd_q_mfma_kernel<NS, 8>), gq, dim3(256), 0, st, a, W, delta, dqkp,
+                       a.pos ? ws : nullptr);
+  S2T_CHECK_LAUNCH();
+  hipLaunchKernelGGL((attn_bwd_k_mfma_kernel<NS>), gk, dim3(256), 0, st, a, W, delta, dqkp);
+  S2T_CHECK_LAUNCH();
+  if (a.pos && a.pd > 0) {
+    const int n = (2 * a.T - 1) * a.pd;
+    hipLaunchKernelGGL(attn_dpos_reduce_kernel, dim3((n + 255) / 256, a.H, a.B < 8 ? a.B : 8),
+                       dim3(256), 0, st, ws, a.T, a.B, a.H, a.pd, dpos);
+    S2T_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
 // ---------------------------------------------------------------- attention apply
 // out[i,b,h*dv+d] = sum_j W[h,b,i,j] v[j,b,h*dv+d]  (TRANS=false, reference zipformer.py:2269)
 // dv[j,b,h*dv+d]  = sum_i W[h,b,i,j] g[i,b,h*dv+d]  (TRANS=true, its gradient w.r.t. v)
@@ -568,17 +930,39 @@ extern "C" int s2t_relpos_attn_fwd(const float* qkp, const float* pos, const uns
 // `delta_ws` must hold delta[h,b,i] = sum_j W dW on entry (delta_given = 1; for the pairs it is
 // sum_d dO_c * O_c, O_c = the apply's forward output).  dqkp (T,B,Dp) is fully written; dpos
 // (2T-1, H*pd) must be zeroed by the caller (accumulated) or NULL when pos was skipped.
+extern "C" long s2t_relpos_attn_bwd_workspace_floats(int T, int B, int H, int pd) {
+  const long nj = (T + 31) / 32;
+  return (long)B * H * nj * (nj + 1) * 32 * pd;
+}
+
 extern "C" int s2t_relpos_attn_bwd(const float* qkp, const float* pos, const unsigned char* kpm,
                                    const unsigned char* amask, int T, int B, int H, int qd, int pd,
                                    const float* W, const float* dW, const float* dW0,
                                    const float* dO1, const float* V1, int dv1, const float* dO2,
                                    const float* V2, int dv2, int delta_given, float* delta_ws,
-                                   float* dqkp, float* dpos, void* stream) {
+                                   float* dqkp, float* dpos, float* workspace, void* stream) {
   if (T <= 0 || B <= 0 || H <= 0) return 0;
   if (qd <= 0 || qd > MAXQD || pd < 0 || pd > MAXPD) return -1;
   if ((dO1 ? dv1 : 0) + (dO2 ? dv2 : 0) > MAXCD) return -1;
+  if ((long)T * T >= (1L << 31) || (long)T * B * H * (2 * qd + pd) >= (1L << 31)) return -1;
   if (!dW && !delta_given) return -1;
   AttnArgs a{qkp, pos, kpm, amask, T, B, H, qd, pd, dW, dW0, {dO1, dO2}, {V1, V2}, {dv1, dv2}};
+  static const bool use_valu = getenv("S2T_ATTN_BWD_VALU") != nullptr;
+  if (!use_valu) {
+    hipStream_t st = (hipStream_t)stream;
+    if (pos && pd > 0 && !workspace) return -1;
+    if (!delta_given) {
+      const long rows = (long)H * B * T;
+      hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, W,
+                         dW, rows, T, delta_ws);
+      S2T_CHECK_LAUNCH();
+    }
+    const int cd = (dO1 ? dv1 : 0) + (dO2 ? dv2 : 0);
+    if (cd == 0) return launch_attn_bwd_mfma<0>(a, W, delta_ws, dqkp, dpos, workspace, st);
+    if (cd <= 12) return launch_attn_bwd_mfma<6>(a, W, delta_ws, dqkp, dpos, workspace, st);
+    if (cd <= 24) return launch_attn_bwd_mfma<12>(a, W, delta_ws, dqkp, dpos, workspace, st);
+    return launch_attn_bwd_mfma<16>(a, W, delta_ws, dqkp, dpos, workspace, st);
+  }
   dim3 grid((T + ROWS - 1) / ROWS, B, H);
   hipLaunchKernelGGL(attn_bwd_q_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, W, delta_given,
                      delta_ws, dqkp);

@@ -384,11 +384,15 @@ def _attn_bwd_call(qkp, pos, k8, a8, H, qd, pd, W, dW, dW0, pairs, delta):
     if delta is None:
         delta = torch.empty((H, B, T), dtype=torch.float32, device=dev)
     p = list(pairs) + [(None, None, None, 0)] * (2 - len(pairs))
+    ws = None
+    if pos is not None:
+        ws = torch.empty(N.lib().s2t_relpos_attn_bwd_workspace_floats(T, B, H, pd),
+                         dtype=torch.float32, device=dev)
     N.profile_note("s2t_relpos_attn_bwd", 4.0 * (2 * qkp.numel() + 2 * W.numel()))
     N.check(N.lib().s2t_relpos_attn_bwd(N.fp(qkp), N.fp(pos), N.ptr(k8), N.ptr(a8), T, B, H, qd, pd,
                                         N.fp(W), N.fp(dW), N.fp(dW0), N.fp(p[0][0]), N.fp(p[0][1]),
                                         p[0][3], N.fp(p[1][0]), N.fp(p[1][1]), p[1][3], int(given),
-                                        N.fp(delta), N.fp(dqkp), N.fp(dpos), N.stream()),
+                                        N.fp(delta), N.fp(dqkp), N.fp(dpos), N.fp(ws), N.stream()),
             "s2t_relpos_attn_bwd")
     return dqkp, dpos
 

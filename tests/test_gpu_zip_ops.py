@@ -125,6 +125,54 @@ def _attn_ref(qkp, pos, H, qd, pd, amask, kpm):
     return s.softmax(dim=-1)
 
 
+@pytest.mark.parametrize("T,B,H,qd,pd,dvs,use_dw0,use_am", [
+    (50, 2, 4, 8, 4, (12,), False, True), (130, 3, 4, 32, 4, (12, 12), True, False),
+    (530, 2, 2, 32, 4, (16, 16), True, False), (77, 2, 4, 24, 4, (12, 12), True, True),
+    (1, 2, 2, 8, 4, (12,), True, False), (33, 1, 8, 4, 4, (4, 12), False, False)])
+def test_relpos_attention_backward_factored(dev, T, B, H, qd, pd, dvs, use_dw0, use_am):
+    """s2t_relpos_attn_bwd with dW given as factors (dO_c, V_c) + head-0 term + delta, against the
+    float64 autograd of the composed op with the same dW materialised."""
+    from speech2text_amd import zip_kernels as zk
+    torch.manual_seed(T + 7)
+    Dp = H * (2 * qd + pd)
+    qkp = torch.randn(T, B, Dp, dtype=torch.float64) * 0.7
+    pos = torch.randn(2 * T - 1, H * pd, dtype=torch.float64)
+    lens = torch.randint(max(1, T // 2), T + 1, (B,)); lens[0] = T
+    kpm = torch.arange(T).unsqueeze(0) >= lens.unsqueeze(1)
+    amask = None
+    if use_am:
+        c = torch.arange(T) // 16
+        amask = torch.logical_or(c.unsqueeze(0) > c.unsqueeze(1), c.unsqueeze(0) < c.unsqueeze(1) - 2)
+    facs = [(torch.randn(T, B, H * dv, dtype=torch.float64), torch.randn(T, B, H * dv, dtype=torch.float64), dv)
+            for dv in dvs]
+    dW0 = torch.randn(B, T, T, dtype=torch.float64) if use_dw0 else None
+    dWm = torch.zeros(H, B, T, T, dtype=torch.float64)
+    for dO, V, dv in facs:
+        dWm += torch.einsum("ibhd,jbhd->hbij", dO.view(T, B, H, dv), V.view(T, B, H, dv))
+    if use_dw0:
+        dWm[0] += dW0
+    qc = qkp.clone().requires_grad_(True); pc = pos.clone().requires_grad_(True)
+    Wr = _attn_ref(qc, pc, H, qd, pd, amask, kpm)
+    (Wr * dWm).sum().backward()
+    f = lambda t: None if t is None else t.float().to(dev).contiguous()
+    qg, pg = f(qkp), f(pos)
+    k8 = kpm.to(torch.uint8).to(dev); a8 = None if amask is None else amask.to(torch.uint8).to(dev)
+    W = zk.relpos_attention_weights(qg, pg, H, qd, pd, None if amask is None else amask.to(dev), kpm.to(dev))
+    delta = (W.double() * dWm.to(dev)).sum(-1).float().contiguous()
+    pairs = [(f(dO), f(V), None, dv) for dO, V, dv in facs]
+    dq, dp = zk._attn_bwd_call(qg, pg, k8, a8, H, qd, pd, W, None, f(dW0), pairs, delta)
+    gq, gp = qc.grad.numpy(), pc.grad.numpy()
+    np.testing.assert_allclose(dq.cpu().numpy(), gq, atol=3e-5 * max(1.0, np.abs(gq).max()), rtol=2e-3)
+    np.testing.assert_allclose(dp.cpu().numpy(), gp, atol=3e-5 * max(1.0, np.abs(gp).max()), rtol=2e-3)
+    # mixed: one factor pair + the rest materialised, delta recomputed by the library
+    rest = dWm.clone()
+    dO, V, dv = facs[0]
+    rest -= torch.einsum("ibhd,jbhd->hbij", dO.view(T, B, H, dv), V.view(T, B, H, dv))
+    dq2, dp2 = zk._attn_bwd_call(qg, pg, k8, a8, H, qd, pd, W, f(rest), None, pairs[:1], delta)
+    np.testing.assert_allclose(dq2.cpu().numpy(), gq, atol=3e-5 * max(1.0, np.abs(gq).max()), rtol=2e-3)
+    np.testing.assert_allclose(dp2.cpu().numpy(), gp, atol=3e-5 * max(1.0, np.abs(gp).max()), rtol=2e-3)
+
+
 @pytest.mark.parametrize("T,B,H,qd,pd,use_pos,use_am", [
     (50, 2, 4, 8, 4, True, True), (130, 3, 8, 32, 4, True, False), (64, 2, 2, 16, 4, True, True),
     (530, 2, 2, 32, 4, True, False), (1, 2, 2, 8, 4, True, False), (77, 2, 4, 24, 4, False, True),

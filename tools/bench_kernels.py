@@ -41,6 +41,15 @@ def attn(T, B, H, qd=32, pd=4):
         qkp.grad = None; pos.grad = None
     ms2 = timeit(fb)
     report(f"relpos_attn fwd+bwd T={T}", ms2, 4.0 * (2 * qkp.numel() + 3 * W.numel()))
+    # the training-step mode: dW as factors (two value applies, dv=12) + head-0 term + delta
+    qd_, pd_ = qkp.detach(), pos.detach()
+    k8 = kpm.to(torch.uint8)
+    pairs = [(torch.randn(T, B, H * 12, device=dev), torch.randn(T, B, H * 12, device=dev), None, 12)
+             for _ in range(2)]
+    dW0 = torch.randn(B, T, T, device=dev)
+    delta = torch.randn(H, B, T, device=dev)
+    ms3 = timeit(lambda: zk._attn_bwd_call(qd_, pd_, k8, None, H, qd, pd, W.detach(), None, dW0, pairs, delta))
+    report(f"relpos_attn_bwd factored T={T}", ms3, 4.0 * (2 * qkp.numel() + 2 * W.numel()))
 
 
 def conv(T, B, C, Kk):
