@@ -142,6 +142,35 @@ int s2t_attn_apply(const float* W, const float* v, int T, int B, int H, int dv, 
                    float* out, void* stream);
 
 
+/* ---- weight / bias gradient of the linear layers (torch.nn.Linear under loss.backward();
+ * model/encoder/zipformer.py:1573-1593 FeedforwardModule, 1966-1992 in_proj, scaling.py
+ * ScaledLinear): dW (N,M) = g^T a, db (N) = column sums of g (db may be NULL), for g (R,N) and
+ * a (R,M) with row strides ldg/lda (floats), R >> N,M.  The rows are split over the chip and
+ * the partial sums land in `workspace` (s2t_linear_wgrad_workspace_floats) before a reduce
+ * pass; accumulate=1 adds to dW/db instead of overwriting.  N, M, ldg, lda must be even and
+ * the bases 8-byte aligned (-1 otherwise). */
+long s2t_linear_wgrad_workspace_floats(int R, int N, int M);
+int s2t_linear_wgrad(const float* g, long ldg, const float* a, long lda, int R, int N, int M,
+                     float* dW, float* db, int accumulate, float* workspace, void* stream);
+
+/* ---- Whiten gradient shaping (model/layer/scaling.py:949-1095).  Forward, when the module
+ * fires: xtx (C,C) = x^T x and colsum (C) (both from s2t_linear_wgrad(x, x)) -> per-group centred
+ * covariance cov (G,cg,cg), mean (C), scal = [mean diag, sum cov^2 / C, denom, metric]; the
+ * metric is also stored to host_metric (pinned host memory, may be NULL) so the host can read
+ * it after an event without draining the stream.  Backward: dcov (C,C, block diagonal) =
+ * d metric / d cov, bias (C) = -mean . dcov, sums[2] zeroed; the caller forms pg = x dcov + bias
+ * with a plain GEMM; s2t_whiten_apply writes out = g + pg * grad_scale * |g| / (|pg| + 1e-20). */
+int s2t_whiten_metric(const float* xtx, const float* colsum, long n, int G, int cg, float* cov,
+                      float* mean, float* scal, float* host_metric, void* stream);
+int s2t_whiten_dcov(const float* cov, const float* mean, const float* scal, int G, int cg,
+                    float* dcov, float* bias, float* sums, void* stream);
+int s2t_whiten_apply(const float* g, const float* pg, long numel, float grad_scale, float* sums,
+                     float* out, void* stream);
+/* limit_param_value backward (model/layer/scaling.py:1153-1190): out = g with the sign flipped
+ * where (g > 0 and x < lo), then where (g < 0 and x > hi). */
+int s2t_limit_param_grad(const float* x, const float* g, float lo, float hi, long n, float* out,
+                         void* stream);
+
 /* ---- BEST-RQ labels (model/ssl/best_rq.py:168-217,259-294): stack 9 taps (kernel (3,3),
  * stride (2,2)) -> projection (F*9 -> D) -> nearest code (cosine == euclidean on normalised
  * vectors), label = index + 1, first index on ties.  fp64 internally; bit-exact integer output. */

@@ -1,0 +1,217 @@
+// Whiten / limit_param_value gradient shaping (reference model/layer/scaling.py:949-1095 Whiten +
+// WhiteningPenaltyFunction, 1153-1190 limit_param_value) as a handful of launches:
+//   forward (when the module fires):  x^T x and column sums come from s2t_linear_wgrad; one
+//     kernel turns them into the covariance, its whitening metric and the host-visible flag;
+//   backward: one kernel builds d metric / d cov and the bias row, a plain GEMM applies it to x,
+//     a two-tensor sum-of-squares pass and a fused  g + pg * (grad_scale |g| / |pg|)  finish.
+// The C x C work is tiny (C <= 512), so those kernels are single-workgroup on purpose.
+#include "common.h"
+#include <algorithm>
+#include <cstdint>
+
+namespace {
+
+constexpr int NT = 1024;
+
+__device__ __forceinline__ float block_sum(float v, float* s_tmp) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) s_tmp[wave] = v;
+  __syncthreads();
+  float t = (threadIdx.x < (NT >> 6)) ? s_tmp[threadIdx.x] : 0.f;
+  if (wave == 0) {
+    t = wave_sum(t);
+    if (lane == 0) s_tmp[0] = t;
+  }
+  __syncthreads();
+  return s_tmp[0];
+}
+
+// xtx: (C,C) = x^T x over all groups' channels; cov: (G,cg,cg) per-group centred covariance
+// scal: [md, covsq, denom, metric]
+__global__ __launch_bounds__(NT) void whiten_metric_kernel(const float* __restrict__ xtx,
+                                                           const float* __restrict__ colsum,
+                                                           float n, int G, int cg,
+                                                           float* __restrict__ cov,
+                                                           float* __restrict__ mean,
+                                                           float* __restrict__ scal,
+                                                           float* host_metric) {
+  __shared__ float s_tmp[NT >> 6];
+  const int C = G * cg;
+  const float inv_n = 1.f / n;
+  float dsum = 0.f, sq = 0.f;
+  const long total = (long)G * cg * cg;
+  for (long e = threadIdx.x; e < total; e += NT) {
+    const int g = (int)(e / ((long)cg * cg));
+    const int r = (int)(e % ((long)cg * cg));
+    const int i = r / cg, j = r % cg;
+    const int ci = g * cg + i, cj = g * cg + j;
+    const float v = xtx[(long)ci * C + cj] - colsum[ci] * colsum[cj] * inv_n;
+    cov[e] = v;
+    sq = fmaf(v, v, sq);
+    if (i == j) dsum += v;
+  }
+  for (int c = threadIdx.x; c < C; c += NT) mean[c] = colsum[c] * inv_n;
+  const float dtot = block_sum(dsum, s_tmp);
+  const float sqtot = block_sum(sq, s_tmp);
+  if (threadIdx.x == 0) {
+    const float md = dtot / (float)C;
+    const float covsq = sqtot / (float)C;
+    const float denom = md * md + 1.0e-20f;
+    const float metric = covsq / denom;
+    scal[0] = md;
+    scal[1] = covsq;
+    scal[2] = denom;
+    scal[3] = metric;
+    if (host_metric)
+      __hip_atomic_store(host_metric, metric, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// dcov (C,C) block diagonal = 4/(G cg) (cov/denom - covsq md/denom^2 I); bias = -mean . dcov
+__global__ __launch_bounds__(NT) void whiten_dcov_kernel(const float* __restrict__ cov,
+                                                         const float* __restrict__ mean,
+                                                         const float* __restrict__ scal, int G,
+                                                         int cg, float* __restrict__ dcov,
+                                                         float* __restrict__ bias,
+                                                         float* __restrict__ sums) {
+  const int C = G * cg;
+  const float md = scal[0], covsq = scal[1], denom = scal[2];
+  const float k = 4.f / (float)C;
+  const float a = 1.f / denom, d = covsq * md / (denom * denom);
+  for (long e = threadIdx.x; e < (long)C * C; e += NT) {
+    const int ci = (int)(e / C), cj = (int)(e % C);
+    const int g = ci / cg;
+    float v = 0.f;
+    if (cj / cg == g) {
+      v = cov[((long)g * cg + (ci - g * cg)) * cg + (cj - g * cg)] * a;
+      if (ci == cj) v -= d;
+      v *= k;
+    }
+    dcov[e] = v;
+  }
+  if (threadIdx.x < 2) sums[threadIdx.x] = 0.f;
+  __threadfence_block();
+  __syncthreads();
+  for (int cj = threadIdx.x; cj < C; cj += NT) {
+    const int g = cj / cg;
+    float acc = 0.f;
+    for (int i = 0; i < cg; ++i) {
+      const int ci = g * cg + i;
+      acc = fmaf(mean[ci], dcov[(long)ci * C + cj], acc);
+    }
+    bias[cj] = -acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void sumsq2_kernel(const float* __restrict__ a,
+                                                     const float* __restrict__ b, long n,
+                                                     float* __restrict__ sums) {
+  __shared__ float s_a[4], s_b[4];
+  float sa = 0.f, sb = 0.f;
+  const long n4 = n >> 2;
+  const float4* a4 = reinterpret_cast<const float4*>(a);
+  const float4* b4 = reinterpret_cast<const float4*>(b);
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
+    const float4 x = a4[e], y = b4[e];
+    sa += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+    sb += y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w;
+  }
+  if (blockIdx.x == 0)
+    for (long e = (n4 << 2) + threadIdx.x; e < n; e += 256) {
+      sa = fmaf(a[e], a[e], sa);
+      sb = fmaf(b[e], b[e], sb);
+    }
+  sa = wave_sum(sa);
+  sb = wave_sum(sb);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { s_a[wave] = sa; s_b[wave] = sb; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&sums[0], s_a[0] + s_a[1] + s_a[2] + s_a[3]);
+    atomicAdd(&sums[1], s_b[0] + s_b[1] + s_b[2] + s_b[3]);
+  }
+}
+
+// out = g + pg * grad_scale * |g| / (|pg| + 1e-20)
+__global__ __launch_bounds__(256) void whiten_apply_kernel(const float* __restrict__ g,
+                                                           const float* __restrict__ pg, long n,
+                                                           float grad_scale,
+                                                           const float* __restrict__ sums,
+                                                           float* __restrict__ out) {
+  const float scale = grad_scale * (sqrtf(sums[0]) / (sqrtf(sums[1]) + 1.0e-20f));
+  const long n4 = n >> 2;
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  const float4* p4 = reinterpret_cast<const float4*>(pg);
+  float4* o4 = reinterpret_cast<float4*>(out);
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
+    const float4 x = g4[e], y = p4[e];
+    o4[e] = make_float4(fmaf(y.x, scale, x.x), fmaf(y.y, scale, x.y), fmaf(y.z, scale, x.z),
+                        fmaf(y.w, scale, x.w));
+  }
+  if (blockIdx.x == 0)
+    for (long e = (n4 << 2) + threadIdx.x; e < n; e += 256) out[e] = fmaf(pg[e], scale, g[e]);
+}
+
+// limit_param_value backward: flip the sign of gradient entries that push an out-of-range
+// parameter further out (first the lower bound, then the upper bound on the updated value)
+__global__ __launch_bounds__(256) void limit_param_grad_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ g,
+                                                               float lo, float hi, long n,
+                                                               float* __restrict__ out) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  float v = g[e];
+  const float xv = x[e];
+  if (v > 0.f && xv < lo) v = -v;
+  if (v < 0.f && xv > hi) v = -v;
+  out[e] = v;
+}
+
+}  // namespace
+
+extern "C" int s2t_whiten_metric(const float* xtx, const float* colsum, long n, int G, int cg,
+                                 float* cov, float* mean, float* scal, float* host_metric,
+                                 void* stream) {
+  if (G <= 0 || cg <= 0 || n <= 0) return -1;
+  hipLaunchKernelGGL(whiten_metric_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, xtx, colsum,
+                     (float)n, G, cg, cov, mean, scal, host_metric);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int s2t_whiten_dcov(const float* cov, const float* mean, const float* scal, int G,
+                               int cg, float* dcov, float* bias, float* sums, void* stream) {
+  if (G <= 0 || cg <= 0) return -1;
+  hipLaunchKernelGGL(whiten_dcov_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, cov, mean,
+                     scal, G, cg, dcov, bias, sums);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int s2t_whiten_apply(const float* g, const float* pg, long numel, float grad_scale,
+                                float* sums, float* out, void* stream) {
+  if (numel <= 0) return 0;
+  if ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(pg) |
+       reinterpret_cast<uintptr_t>(out)) & 15)
+    return -1;
+  const long n4 = numel >> 2;
+  const unsigned blocks = (unsigned)std::min<long>(2048, std::max<long>(1, (n4 + 255) / 256));
+  hipLaunchKernelGGL(sumsq2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, pg, numel,
+                     sums);
+  S2T_CHECK_LAUNCH();
+  hipLaunchKernelGGL(whiten_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, pg,
+                     numel, grad_scale, sums, out);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int s2t_limit_param_grad(const float* x, const float* g, float lo, float hi, long n,
+                                    float* out, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(limit_param_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, x, g, lo, hi, n, out);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}

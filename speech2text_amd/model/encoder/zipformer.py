@@ -21,7 +21,7 @@ from torch import Tensor, nn
 from speech2text_amd import rng
 from speech2text_amd import zip_kernels as zk
 from speech2text_amd.model.functions.masking import make_pad_mask
-from speech2text_amd.model.layer.scaling import (ActivationDropoutAndLinear, Balancer, BiasNorm,
+from speech2text_amd.model.layer.scaling import (Linear, ActivationDropoutAndLinear, Balancer, BiasNorm,
                                                  ChunkCausalDepthwiseConv1d, Dropout2, FloatLike,
                                                  Identity, ScaledLinear, ScheduledFloat, Whiten,
                                                  convert_num_channels, limit_param_value,
@@ -122,7 +122,7 @@ class Zipformer2(nn.Module):
                                                   downsample=config.output_downsampling_factor,
                                                   dropout=dropout)
         self._for_ctc = config.for_ctc
-        self._ctc_projection = nn.Linear(max(self.encoder_dim), config.num_tokens) \
+        self._ctc_projection = Linear(max(self.encoder_dim), config.num_tokens) \
             if config.for_ctc else nn.Identity()
 
     # -- randomness that is drawn once per forward (reference zipformer.py:229-317)
@@ -423,7 +423,7 @@ class RelPositionMultiheadAttentionWeights(nn.Module):
 class SelfAttention(nn.Module):
     def __init__(self, embed_dim: int, num_heads: int, value_head_dim: int) -> None:
         super().__init__()
-        self.in_proj = nn.Linear(embed_dim, num_heads * value_head_dim, bias=True)
+        self.in_proj = Linear(embed_dim, num_heads * value_head_dim, bias=True)
         self.out_proj = ScaledLinear(num_heads * value_head_dim, embed_dim, bias=True,
                                      initial_scale=0.05)
         self.whiten = Whiten(num_groups=1, whitening_limit=_whitening_schedule(7.5, ratio=3.0),
@@ -438,7 +438,7 @@ class SelfAttention(nn.Module):
 class FeedforwardModule(nn.Module):
     def __init__(self, embed_dim: int, feedforward_dim: int, dropout: FloatLike):
         super().__init__()
-        self.in_proj = nn.Linear(embed_dim, feedforward_dim)
+        self.in_proj = Linear(embed_dim, feedforward_dim)
         self.hidden_balancer = Balancer(feedforward_dim, channel_dim=-1, min_positive=0.3,
                                         max_positive=1.0, min_abs=0.75, max_abs=5.0)
         self.out_proj = ActivationDropoutAndLinear(feedforward_dim, embed_dim,
@@ -459,7 +459,7 @@ class NonlinAttention(nn.Module):
     def __init__(self, channels: int, hidden_channels: int) -> None:
         super().__init__()
         self.hidden_channels = hidden_channels
-        self.in_proj = nn.Linear(channels, hidden_channels * 3, bias=True)
+        self.in_proj = Linear(channels, hidden_channels * 3, bias=True)
         self.balancer = Balancer(hidden_channels, channel_dim=-1,
                                  min_positive=ScheduledFloat((0.0, 0.25), (20000.0, 0.05)),
                                  max_positive=ScheduledFloat((0.0, 0.75), (20000.0, 0.95)),
@@ -487,7 +487,7 @@ class ConvolutionModule(nn.Module):
         super().__init__()
         assert (kernel_size - 1) % 2 == 0
         self.causal = causal
-        self.in_proj = nn.Linear(channels, 2 * channels)
+        self.in_proj = Linear(channels, 2 * channels)
         self.balancer1 = Balancer(channels, channel_dim=-1,
                                   min_positive=ScheduledFloat((0.0, 0.05), (8000.0, 0.025)),
                                   max_positive=1.0, min_abs=1.5,

@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 
 from speech2text_amd import kernels as K
+from speech2text_amd.model.layer.scaling import Linear
 
 
 @dataclasses.dataclass
@@ -56,16 +57,16 @@ class Joiner(nn.Module):
         self._input_dim = config.input_dim
         self._output_dim = config.output_dim
         self._inner_dim = config.inner_dim
-        self._enc_proj = nn.Linear(self._input_dim, self._output_dim, bias=True)
-        self._pre_proj = nn.Linear(self._input_dim, self._output_dim, bias=True)
+        self._enc_proj = Linear(self._input_dim, self._output_dim, bias=True)
+        self._pre_proj = Linear(self._input_dim, self._output_dim, bias=True)
         if config.activation not in ("relu", "tanh"):
             raise ValueError(f"Unsupported activation {config.activation}")
         self._act_name = config.activation
         self._activation = nn.ReLU() if config.activation == "relu" else nn.Tanh()
         self._use_out_project = config.use_out_project
         if self._use_out_project:
-            self._out_projection = nn.Sequential(nn.Linear(self._output_dim, self._inner_dim),
-                                                 nn.Linear(self._inner_dim, self._output_dim))
+            self._out_projection = nn.Sequential(Linear(self._output_dim, self._inner_dim),
+                                                 Linear(self._inner_dim, self._output_dim))
         else:
             self._out_projection = nn.Identity()
         self._blank_token = 0

@@ -178,9 +178,7 @@ class _LimitParamFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (x,) = ctx.saved_tensors
-        g = g * torch.where(torch.logical_and(g > 0, x < ctx.lo), -1.0, 1.0)
-        g = g * torch.where(torch.logical_and(g < 0, x > ctx.hi), -1.0, 1.0)
-        return g, None, None
+        return zk.limit_param_grad(x, g, ctx.lo, ctx.hi), None, None
 
 
 def limit_param_value(x: Tensor, min: float, max: float, prob: float = 0.6,
@@ -263,8 +261,16 @@ class BiasNorm(nn.Module):
         return zk.bias_norm(xt, self.bias, log_scale).transpose(self.channel_dim, -1)
 
 
+class Linear(nn.Linear):
+    """nn.Linear (same parameters, same init) whose weight/bias gradients come from the
+    split-row MFMA kernel (zip_kernels.linear_wgrad) when the shape is tall."""
+
+    def forward(self, x: Tensor) -> Tensor:
+        return zk.linear(x, self.weight, self.bias)
+
+
 def ScaledLinear(*args, initial_scale: float = 1.0, **kwargs) -> nn.Linear:
-    ans = nn.Linear(*args, **kwargs)
+    ans = Linear(*args, **kwargs)
     with torch.no_grad():
         ans.weight[:] *= initial_scale
         if ans.bias is not None:

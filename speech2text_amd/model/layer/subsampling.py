@@ -9,7 +9,7 @@ from torch import Tensor, nn
 from speech2text_amd import rng
 from speech2text_amd import zip_kernels as zk
 
-from speech2text_amd.model.layer.scaling import (Balancer, BiasNorm, Dropout3, FloatLike,
+from speech2text_amd.model.layer.scaling import (Linear, Balancer, BiasNorm, Dropout3, FloatLike,
                                                  ScaledConv2d, ScaleGrad, ScheduledFloat, SwooshL,
                                                  SwooshR, Whiten)
 
@@ -86,7 +86,7 @@ class Conv2dSubsampling(nn.Module):
         self.convnext = ConvNeXt(layer3_channels, kernel_size=(7, 7))
         self.out_width = (((in_channels - 1) // 2) - 1) // 2
         self.layer3_channels = layer3_channels
-        self.out = nn.Linear(self.out_width * layer3_channels, out_channels)
+        self.out = Linear(self.out_width * layer3_channels, out_channels)
         self.out_whiten = Whiten(num_groups=1,
                                  whitening_limit=ScheduledFloat((0.0, 4.0), (20000.0, 8.0),
                                                                 default=4.0),
@@ -107,7 +107,7 @@ class Conv2dSubsampling(nn.Module):
         b, t, f, c = x.shape
         # reference flattens (c,f) c-major: out.weight columns are indexed c*F' + f
         w = self.out.weight.view(-1, c, f).permute(0, 2, 1).reshape(-1, f * c)
-        x = F.linear(x.reshape(b, t, f * c), w, self.out.bias)
+        x = zk.linear(x.reshape(b, t, f * c), w, self.out.bias)
         x = self.out_whiten(x)
         x = self.out_norm(x)
         x = self.dropout(x)

@@ -107,7 +107,7 @@ class MaskedCELoss(nn.Module):
     def forward(self, logits, ori_labels, mask=None):
         max_len = logits.size(1)
         logits = logits.contiguous().reshape(-1, self._num_classes)
-        logits *= self._scale_factor                       # in place, as the reference
+        logits = logits * self._scale_factor
         loss = self._ce(logits, ori_labels.contiguous().reshape(-1))
         if mask is not None:
             if mask.dim() == 1:
@@ -117,7 +117,7 @@ class MaskedCELoss(nn.Module):
         return loss.mean()
 
     def predict(self, logits):
-        logits *= self._scale_factor
+        logits = logits * self._scale_factor
         return logits.softmax(dim=-1)
 
 
@@ -143,7 +143,7 @@ class MaskedKLDivergence(nn.Module):
         else:
             mask = torch.ones_like(ori_labels).reshape(-1)
         logits = logits.contiguous().reshape(-1, self._num_classes)
-        logits *= self._scale_factor
+        logits = logits * self._scale_factor
         lab = ori_labels.contiguous().reshape(-1)
         # KL(smoothed one-hot || softmax) summed over classes, without materialising the
         # smoothed-label tensor: sum_c t_c (log t_c - logp_c)
@@ -161,7 +161,7 @@ class MaskedKLDivergence(nn.Module):
         return row.sum() / mask.sum()
 
     def predict(self, logits):
-        logits *= self._scale_factor
+        logits = logits * self._scale_factor
         return logits.log_softmax(dim=-1)
 
 

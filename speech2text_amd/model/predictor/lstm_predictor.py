@@ -8,6 +8,7 @@ from typing import List, Tuple
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+from speech2text_amd.model.layer.scaling import Linear
 
 
 @dataclasses.dataclass
@@ -25,8 +26,8 @@ class LstmPredictorConfig:
 class _CustomLSTM(nn.Module):
     def __init__(self, input_dim, hidden_dim, layer_norm=False, layer_norm_epsilon=1e-5):
         super().__init__()
-        self.x2g = nn.Linear(input_dim, 4 * hidden_dim, bias=(not layer_norm))
-        self.p2g = nn.Linear(hidden_dim, 4 * hidden_dim, bias=False)
+        self.x2g = Linear(input_dim, 4 * hidden_dim, bias=(not layer_norm))
+        self.p2g = Linear(hidden_dim, 4 * hidden_dim, bias=False)
         if layer_norm:
             self.c_norm = nn.LayerNorm(hidden_dim, eps=layer_norm_epsilon)
             self.g_norm = nn.LayerNorm(4 * hidden_dim, eps=layer_norm_epsilon)
@@ -64,7 +65,7 @@ class _Predictor(nn.Module):
             _CustomLSTM(symbol_embedding_dim if i == 0 else lstm_hidden_dim, lstm_hidden_dim,
                         lstm_layer_norm, lstm_layer_norm_epsilon) for i in range(num_lstm_layers)])
         self.dropout = nn.Dropout(p=lstm_dropout)
-        self.linear = nn.Linear(lstm_hidden_dim, output_dim)
+        self.linear = Linear(lstm_hidden_dim, output_dim)
         self.output_layer_norm = nn.LayerNorm(output_dim)
 
     def forward(self, input, lengths, state=None):

@@ -7,6 +7,7 @@ from typing import Tuple
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+from speech2text_amd.model.layer.scaling import Linear
 
 
 @dataclasses.dataclass
@@ -31,7 +32,7 @@ class StatelessPredictor(nn.Module):
         self._conv = nn.Conv1d(self._embedding_dim, self._embedding_dim,
                                kernel_size=self._context_size, stride=1, padding=0,
                                groups=self._embedding_dim, bias=False)
-        self._output_linear = nn.Linear(self._embedding_dim, self._output_dim)
+        self._output_linear = Linear(self._embedding_dim, self._output_dim)
 
     @property
     def sos_token(self) -> int:

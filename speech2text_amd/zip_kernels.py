@@ -4,6 +4,8 @@ Each function is the single place a given fused op is launched from.  Ops are mo
 torch-op compositions (rocBLAS GEMMs + elementwise) to hand-written gfx950 kernels one at a
 time; see DESIGN.md for the status table of each.
 """
+import ctypes
+
 import torch
 import torch.nn.functional as F
 
@@ -88,8 +90,7 @@ class _SwooshLinear(torch.autograd.Function):
         if mask is not None:
             h = h * mask
         g2 = g.reshape(-1, g.shape[-1])
-        dw = g2.t().mm(h.reshape(-1, h.shape[-1]))
-        db = g2.sum(dim=0) if ctx.has_bias else None
+        dw, db = linear_wgrad(g2, h.reshape(-1, h.shape[-1]), ctx.has_bias)
         dh = g.matmul(weight)
         dx = swoosh_backward(x, dh, ctx.is_l, mask)
         return dx, dw, db, None, None
@@ -201,75 +202,90 @@ def balancer_backward(x, g, min_mean, max_mean, min_rms, max_rms, grad_scale, ch
     return (gf + gf.abs() * ((a * coef) + (b * coef) * xf)).to(g.dtype)
 
 
+_PINNED = [None, 0]
+
+
+def _pinned_slot():
+    """One float of pinned host memory from a ring (allocated once: hipHostMalloc is slow)."""
+    if _PINNED[0] is None:
+        _PINNED[0] = torch.zeros(4096, dtype=torch.float32, pin_memory=True)
+    i = _PINNED[1]
+    _PINNED[1] = (i + 1) % 4096
+    return _PINNED[0][i:i + 1]
+
+
 class WhitenStats:
     """Whitening statistics of x, computed when the module fires in FORWARD (they depend on x
     only) so that the scalar `metric` reaches the host through pinned memory long before the
     backward pass needs it: no pipeline-draining read-back inside backward (the reference calls
     .item()-style comparisons there, scaling.py:1012).
-    cov = x^T x - N mean mean^T per group (one GEMM on the raw activations, no centred copy)."""
+    x^T x and the column sums come from one pass of the split-row MFMA kernel; cov = x^T x -
+    N mean mean^T per group and the metric from one small kernel (whiten.hip)."""
 
     def __init__(self, x, num_groups):
+        _dev(x)
         C = x.shape[-1]
-        xf = x.detach().reshape(-1, C).float()
+        xf = x.detach().reshape(-1, C)
+        if xf.dtype != torch.float32:
+            xf = xf.float()
         n = xf.shape[0]
         G, cg = num_groups, C // num_groups
-        mean = xf.mean(dim=0)                                                   # (C,)
-        if G == 1:
-            cov = torch.addmm(torch.outer(mean, mean), xf.t(), xf, beta=-float(n)).unsqueeze(0)
-        else:
-            xg = xf.view(n, G, cg).transpose(0, 1)                              # (G,N,cg)
-            mg = mean.view(G, cg, 1)
-            cov = torch.baddbmm(torch.bmm(mg, mg.transpose(1, 2)), xg.transpose(1, 2), xg,
-                                beta=-float(n))
-        self.mean, self.cov = mean, cov
-        self.md = torch.diagonal(cov, dim1=1, dim2=2).mean()
-        self.covsq = (cov * cov).sum() / (G * cg)
-        self.denom = self.md * self.md + 1.0e-20
-        metric = self.covsq / self.denom
-        if x.is_cuda:
-            self.host = torch.empty(1, dtype=torch.float32, pin_memory=True)
-            self.host.copy_(metric.reshape(1), non_blocking=True)
-            self.event = torch.cuda.Event()
-            self.event.record()
-        else:
-            self.host = metric.reshape(1)
-            self.event = None
+        dev = x.device
+        xtx, colsum = linear_wgrad(xf, xf, True)
+        self.cov = torch.empty((G, cg, cg), dtype=torch.float32, device=dev)
+        self.mean = torch.empty((C,), dtype=torch.float32, device=dev)
+        self.scal = torch.empty((4,), dtype=torch.float32, device=dev)
+        self.host = _pinned_slot()
+        N.check(N.lib().s2t_whiten_metric(N.fp(xtx), N.fp(colsum), n, G, cg, N.fp(self.cov),
+                                          N.fp(self.mean), N.fp(self.scal),
+                                          ctypes.c_void_p(self.host.data_ptr()), N.stream()),
+                "s2t_whiten_metric")
+        self.event = torch.cuda.Event()
+        self.event.record()
         self.num_groups, self.cg = G, cg
 
     def metric(self):
-        if self.event is not None:
-            self.event.synchronize()
+        self.event.synchronize()
         return float(self.host[0])
-
-
-_EYES = {}
 
 
 def whiten_backward(x, g, stats, limit, grad_scale):
     """Closed form of reference scaling.py:949-1028.  Returns (grad, penalty_was_active).
     d metric/d x = 2 (x - mean) dcov  (the centring's own Jacobian vanishes because the centred
-    columns sum to zero), i.e. ONE GEMM with a bias row."""
+    columns sum to zero), i.e. ONE GEMM with a bias row; the norm ratio and the final axpy are
+    two more launches."""
     if not (stats.metric() >= limit):
         return g, False
     shp = x.shape
     C = shp[-1]
     G, cg = stats.num_groups, stats.cg
-    key = (cg, str(x.device))
-    eye = _EYES.get(key)
-    if eye is None:
-        eye = _EYES[key] = torch.eye(cg, device=x.device, dtype=torch.float32)
-    dcov = (4.0 / (G * cg)) * (stats.cov / stats.denom
-                               - (stats.covsq * stats.md / (stats.denom * stats.denom)) * eye)
-    xf = x.reshape(-1, C).float()
-    if G == 1:
-        pg = torch.addmm(-(stats.mean @ dcov[0]), xf, dcov[0])
-    else:
-        xg = xf.view(xf.shape[0], G, cg).transpose(0, 1)
-        bias = -torch.bmm(stats.mean.view(G, 1, cg), dcov)
-        pg = torch.baddbmm(bias, xg, dcov).transpose(0, 1)
-    pg = pg.reshape(shp)
-    scale = grad_scale * (g.float().norm() / (pg.norm() + 1.0e-20))
-    return g + pg * scale, True
+    dev = x.device
+    dcov = torch.empty((C, C), dtype=torch.float32, device=dev)
+    bias = torch.empty((C,), dtype=torch.float32, device=dev)
+    sums = torch.empty((2,), dtype=torch.float32, device=dev)
+    N.check(N.lib().s2t_whiten_dcov(N.fp(stats.cov), N.fp(stats.mean), N.fp(stats.scal), G, cg,
+                                    N.fp(dcov), N.fp(bias), N.fp(sums), N.stream()),
+            "s2t_whiten_dcov")
+    xf = x.reshape(-1, C)
+    if xf.dtype != torch.float32:
+        xf = xf.float()
+    pg = torch.addmm(bias, xf, dcov)
+    g2 = g.contiguous().float()
+    if g2.data_ptr() % 16:
+        g2 = g2.clone()
+    out = torch.empty_like(g2)
+    N.check(N.lib().s2t_whiten_apply(N.fp(g2), N.fp(pg), g2.numel(), float(grad_scale), N.fp(sums),
+                                     N.fp(out), N.stream()), "s2t_whiten_apply")
+    return out.view(shp), True
+
+
+def limit_param_grad(x, g, lo, hi):
+    _dev(x, g)
+    xc, gc = x.contiguous().float(), g.contiguous().float()
+    out = torch.empty_like(gc)
+    N.check(N.lib().s2t_limit_param_grad(N.fp(xc), N.fp(gc), float(lo), float(hi), gc.numel(),
+                                         N.fp(out), N.stream()), "s2t_limit_param_grad")
+    return out.view(g.shape)
 
 
 # ------------------------------------------------------------------ conv module core
@@ -591,6 +607,63 @@ def simple_upsample(src, up, out_len):
     return src.unsqueeze(1).expand(T, up, B, C).reshape(T * up, B, C)[:out_len]
 
 
+# ------------------------------------------------------------------ linear layers
+def _wgrad_ok(g2, a2):
+    return (g2.dtype == torch.float32 and a2.dtype == torch.float32 and g2.stride(1) == 1
+            and a2.stride(1) == 1 and g2.shape[1] % 2 == 0 and a2.shape[1] % 2 == 0
+            and g2.stride(0) % 2 == 0 and a2.stride(0) % 2 == 0 and g2.shape[1] >= 2
+            and a2.shape[1] >= 2 and g2.data_ptr() % 8 == 0 and a2.data_ptr() % 8 == 0)
+
+
+def linear_wgrad(g2, a2, want_bias):
+    """g2 (R,N), a2 (R,M) -> dW (N,M) = g2^T a2 and db (N) = column sums (or None).  The
+    split-row MFMA kernel serves the tall shapes (R >> N,M: a handful of output tiles, where a
+    library GEMM leaves most of the chip idle); big outputs stay with hipBLASLt."""
+    _dev(g2, a2)
+    R, Nf = g2.shape
+    Mf = a2.shape[1]
+    tiles = ((Nf + 63) // 64) * ((Mf + 63) // 64)
+    if R >= 3000 and tiles <= WGRAD_MAX_TILES and _wgrad_ok(g2, a2):
+        dW = torch.empty((Nf, Mf), dtype=torch.float32, device=g2.device)
+        db = torch.empty((Nf,), dtype=torch.float32, device=g2.device) if want_bias else None
+        ws = torch.empty(N.lib().s2t_linear_wgrad_workspace_floats(R, Nf, Mf), dtype=torch.float32,
+                         device=g2.device)
+        N.profile_note("s2t_linear_wgrad", 4.0 * (g2.numel() + a2.numel() + dW.numel()))
+        N.check(N.lib().s2t_linear_wgrad(N.raw(g2, torch.float32), g2.stride(0),
+                                         N.raw(a2, torch.float32), a2.stride(0), R, Nf, Mf,
+                                         N.fp(dW), N.fp(db), 0, N.fp(ws), N.stream()),
+                "s2t_linear_wgrad")
+        return dW, db
+    return _wgrad_splitk(g2, a2), (g2.sum(dim=0) if want_bias else None)
+
+
+WGRAD_MAX_TILES = 64   # measured crossover against hipBLASLt (tools/bench_kernels.py wgrad)
+
+
+class _Linear(torch.autograd.Function):
+    """F.linear whose weight and bias gradients come from one pass over (g, x)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g2 = g.reshape(-1, g.shape[-1])
+        dx = g.matmul(weight) if ctx.needs_input_grad[0] else None
+        dw, db = linear_wgrad(g2, x.reshape(-1, x.shape[-1]), ctx.has_bias)
+        return dx, dw, db
+
+
+def linear(x, weight, bias=None):
+    if not x.is_cuda:
+        raise RuntimeError("speech2text_amd.linear needs device tensors (HIP path only)")
+    return _Linear.apply(x, weight, bias)
+
+
 # ------------------------------------------------------------------ channel-last frontend convs
 def _wgrad_splitk(a, g, chunk=16384):
     """a (R,M), g (R,N) -> a^T g (M,N) for R >> M,N: hipBLASLt gets only a handful of output
@@ -620,8 +693,7 @@ class _LinearBigM(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         g2 = g.reshape(-1, g.shape[-1])
         dx = g.matmul(weight) if ctx.needs_input_grad[0] else None
-        dw = _wgrad_splitk(g2, x.reshape(-1, x.shape[-1]))
-        db = g2.sum(dim=0) if ctx.has_bias else None
+        dw, db = linear_wgrad(g2, x.reshape(-1, x.shape[-1]), ctx.has_bias)
         return dx, dw, db
 
 
@@ -655,9 +727,8 @@ class _Conv3x3Nhwc(torch.autograd.Function):
         B, H, W, C, Ho, Wo, sh, sw, has_bias = ctx.cfg
         Cout = weight.shape[0]
         g = dy.reshape(B * Ho * Wo, Cout)
-        dwmat = _wgrad_splitk(cols, g)                                           # (9C, Cout)
-        dweight = dwmat.view(3, 3, C, Cout).permute(3, 2, 0, 1)
-        db = g.sum(dim=0) if has_bias else None
+        dwmat, db = linear_wgrad(g, cols, has_bias)                              # (Cout, 9C)
+        dweight = dwmat.view(Cout, 3, 3, C).permute(0, 3, 1, 2)
         dx = None
         if ctx.needs_input_grad[0]:
             wmat = weight.permute(2, 3, 1, 0).reshape(9 * C, Cout)

@@ -205,3 +205,44 @@ def test_relpos_attention_weights(dev, T, B, H, qd, pd, use_pos, use_am):
     if use_pos:
         gp = pc.grad.numpy()
         np.testing.assert_allclose(pg.grad.cpu().numpy(), gp, atol=3e-5 * max(1.0, np.abs(gp).max()), rtol=2e-3)
+
+
+@pytest.mark.parametrize("R,Nf,Mf,bias,stride_pad", [
+    (4096, 192, 192, True, 0), (31680, 576, 192, True, 0), (3001, 64, 130, False, 0),
+    (2049, 48, 256, True, 0), (5000, 500, 512, True, 0), (1500, 2, 2, True, 0),
+    (4096, 128, 64, True, 64), (15872, 256, 768, True, 0)])
+def test_linear_wgrad(dev, R, Nf, Mf, bias, stride_pad):
+    """s2t_linear_wgrad against the float64 product (weight / bias gradient of nn.Linear)."""
+    from speech2text_amd import zip_kernels as zk, _native as N
+    torch.manual_seed(R + Nf)
+    gfull = torch.randn(R, Nf + stride_pad, device=dev)
+    afull = torch.randn(R, Mf + stride_pad, device=dev)
+    g, a = gfull[:, :Nf], afull[:, :Mf]
+    dW = torch.full((Nf, Mf), float("nan"), device=dev)
+    db = torch.full((Nf,), float("nan"), device=dev) if bias else None
+    ws = torch.empty(N.lib().s2t_linear_wgrad_workspace_floats(R, Nf, Mf), device=dev)
+    gp, ap = N.raw(g, torch.float32), N.raw(a, torch.float32)
+    N.check(N.lib().s2t_linear_wgrad(gp, g.stride(0), ap, a.stride(0), R, Nf, Mf, N.fp(dW),
+                                     N.fp(db), 0, N.fp(ws), N.stream()), "s2t_linear_wgrad")
+    ref = g.double().t() @ a.double()
+    tol = 2e-6 * R ** 0.5 * 4
+    np.testing.assert_allclose(dW.cpu().numpy(), ref.cpu().numpy(), atol=tol, rtol=1e-5)
+    if bias:
+        np.testing.assert_allclose(db.cpu().numpy(), g.double().sum(0).cpu().numpy(), atol=tol, rtol=1e-5)
+    # accumulate=1 adds on top
+    N.check(N.lib().s2t_linear_wgrad(gp, g.stride(0), ap, a.stride(0), R, Nf, Mf, N.fp(dW),
+                                     N.fp(db), 1, N.fp(ws), N.stream()), "s2t_linear_wgrad")
+    np.testing.assert_allclose(dW.cpu().numpy(), 2 * ref.cpu().numpy(), atol=2 * tol, rtol=1e-5)
+    # the autograd wrapper
+    x = torch.randn(7, R // 7, Mf, device=dev, requires_grad=True)
+    w = torch.randn(Nf, Mf, device=dev, requires_grad=True)
+    b = torch.randn(Nf, device=dev, requires_grad=True) if bias else None
+    gy = torch.randn(7, R // 7, Nf, device=dev)
+    zk.linear(x, w, b).backward(gy)
+    x2, w2 = x.detach().clone().requires_grad_(True), w.detach().clone().requires_grad_(True)
+    b2 = b.detach().clone().requires_grad_(True) if bias else None
+    torch.nn.functional.linear(x2, w2, b2).backward(gy)
+    np.testing.assert_allclose(w.grad.cpu().numpy(), w2.grad.cpu().numpy(), atol=2 * tol, rtol=1e-4)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), x2.grad.cpu().numpy(), atol=1e-4, rtol=1e-4)
+    if bias:
+        np.testing.assert_allclose(b.grad.cpu().numpy(), b2.grad.cpu().numpy(), atol=2 * tol, rtol=1e-4)

@@ -74,9 +74,32 @@ def conv(T, B, C, Kk):
     report(f"zipconv fwd+bwd", ms2, 4.0 * (3 * u.numel() + 3 * T * B * C))
 
 
+def wgrad():
+    shapes = [(31680, 192, 192), (31680, 576, 192), (31680, 192, 576), (31680, 512, 192), (31680, 272, 192),
+              (15872, 256, 256), (15872, 768, 256), (15872, 256, 768), (15872, 48, 256), (15872, 576, 256),
+              (7936, 384, 384), (7936, 1024, 384), (7936, 384, 1024), (7936, 1152, 384),
+              (3968, 512, 512), (3968, 1536, 512), (3968, 512, 1536), (32000, 512, 512), (32000, 500, 512)]
+    for R, Nf, Mf in shapes:
+        g = torch.randn(R, Nf, device=dev); a = torch.randn(R, Mf, device=dev)
+        ws = torch.empty(N.lib().s2t_linear_wgrad_workspace_floats(R, Nf, Mf), device=dev)
+        dW = torch.empty(Nf, Mf, device=dev); db = torch.empty(Nf, device=dev)
+        def ours():
+            N.check(N.lib().s2t_linear_wgrad(N.fp(g), g.stride(0), N.fp(a), a.stride(0), R, Nf, Mf, N.fp(dW),
+                                             N.fp(db), 0, N.fp(ws), N.stream()), "wgrad")
+        def lib():
+            g.t().mm(a); g.sum(dim=0)
+        m1 = timeit(ours); m2 = timeit(lib); m3 = timeit(lambda: g.t().mm(a))
+        fl = 2.0 * R * Nf * Mf
+        print(f"wgrad R={R:6d} N={Nf:5d} M={Mf:5d}  ours {m1*1e3:7.1f} us ({fl/m1/1e9:6.1f} TF)   "
+              f"mm+sum {m2*1e3:7.1f} us   mm {m3*1e3:7.1f} us ({fl/m3/1e9:6.1f} TF)", flush=True)
+
+
 if __name__ == "__main__":
     B = 64
     only = sys.argv[1] if len(sys.argv) > 1 else ""
+    if only == "wgrad":
+        wgrad()
+        sys.exit(0)
     if only == "conv":
         conv(495, B, 192, 31)
         sys.exit(0)
