@@ -82,6 +82,7 @@ class GradReducer:
         s, e = self.buckets[b]
         buf = self.store.flat_g[s:e]
         self._launched[b] = True
+        self.store.gather(self.bucket_members[b])
         if self._is_cuda:
             self._stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._stream):
@@ -106,6 +107,7 @@ class GradReducer:
         """After backward: reduce whatever was not launched by the hooks, wait, average.
         `extra` (1-D tensor of logged scalars) is mean-reduced along with the gradients."""
         if self.world == 1:
+            self.store.gather()
             return extra
         for b in range(len(self.buckets)):
             if not self._launched[b]:

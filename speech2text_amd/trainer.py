@@ -39,7 +39,8 @@ class Trainer:
         self.optimizer = opt["optimizer"]
         self.scheduler = opt["lr_scheduler"]["scheduler"]
         params = [p for p in task.parameters() if p.requires_grad]
-        self.store = get_store(params)
+        # parked-gradient mode is opt-in: measured slower than in-place accumulation so far
+        self.store = get_store(params, steal=os.environ.get("S2T_STEAL_GRADS", "0") == "1")
         broadcast_parameters(self.store)
         self.reducer = GradReducer(self.store, self.bucket_bytes)
         return self
@@ -67,6 +68,7 @@ class Trainer:
             with self.reducer.no_sync():
                 loss = task.training_step(batch, batch_idx)
                 (loss / self.accum).backward()
+            self.store.gather()
         self.micro += 1
         if last:
             logged = None

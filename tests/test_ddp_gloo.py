@@ -16,7 +16,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, steal):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -27,7 +27,7 @@ def _worker(rank, world, port, q):
                               torch.nn.Tanh(), torch.nn.Linear(16, 3))
     unused = torch.nn.Parameter(torch.ones(5))
     params = list(net.parameters()) + [unused]
-    store = FlatStore(params)
+    store = FlatStore(params, steal=steal)
     broadcast_parameters(store)                         # rank 0's weights everywhere
     red = GradReducer(store, bucket_bytes=4 * 200)      # several small buckets
     g = torch.Generator().manual_seed(7)
@@ -39,6 +39,7 @@ def _worker(rank, world, port, q):
         # accumulation micro-step without sync, then a synced one
         with red.no_sync():
             ((net(xs[rank]) - ys[rank]) ** 2).mean().backward()
+        store.gather()                                  # no-op unless steal mode
         red.prepare()
         ((net(xs[2 + rank]) - ys[2 + rank]) ** 2).mean().backward()
         red.finish()
@@ -64,11 +65,17 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_grad_reducer_world2_gloo():
+import pytest
+
+
+@pytest.mark.parametrize("steal", [False, True])
+def test_grad_reducer_world2_gloo(steal):
+    """steal=False: p.grad are views of the flat buffer; steal=True: gradients are parked on the
+    parameters by autograd and added into the flat buffer per bucket (FlatStore.gather)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, steal)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
