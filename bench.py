@@ -1,7 +1,12 @@
 #!/usr/bin/env python
 """Headline benchmark: audio-seconds/sec of one zipformer pruned-RNN-T training step.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N>1 without RANK/WORLD_SIZE in the environment: this process starts N ranks itself
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py ...`) BEFORE touching the GPU,
+relays rank 0's JSON line and exits with the child's code.  Under an external launcher it reads
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (RCCL = backend "nccl").
 
 Workload (BASELINE.json metric, SURVEY.md section 8d "C3"): per-rank batch of 64 synthetic 16 kHz
 10 s utterances (PCM resident in HBM before the timed region), 50 labels each from a 500-piece
@@ -10,6 +15,7 @@ stateless predictor, pruned RNN-T (prune_range 5) with 0.5*simple + 0.5*pruned l
 A step = on-GPU fbank -> CMVN -> Zipformer2 fwd -> predictor -> joiner (simple loss, prune
 ranges, fused pruned lattice) -> backward -> bucketed RCCL gradient all-reduce (N>1) ->
 grad-norm clip 5.0 -> ScaledAdam step -> Eden step.  Weak scaling: per-GPU work is fixed.
+`--config C2` times the conformer-CTC step (12 layers, d=256, B=32) instead; the headline is C3.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the roofline / cpu_baseline
 objects).
@@ -18,18 +24,20 @@ import argparse
 import json
 import os
 import random
+import subprocess
 import sys
 import time
 
 import numpy as np
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 SR = 16000
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA dense peak
+DEFAULT_ROOFLINE_KERNEL = "auto"   # or any entry point declared in include/s2t_mi355.h
 
 
 def c3_config(vocab=500):
@@ -66,6 +74,29 @@ def c3_config(vocab=500):
     }
 
 
+def c2_config(vocab=128, layers=12):
+    """conformer-CTC (config/training/conformer_ctc.yaml dims; BASELINE.json: 12 layers, d=256)."""
+    return {
+        "task": {"type": "CTC", "name": "bench-c2", "export_path": "/tmp"},
+        "dataset": {"feat_type": "fbank", "feat_config": {"num_mel_bins": 80}},
+        "encoder": {"model": "Conformer", "config": {
+            "bn_cmvn": False, "feats_dim": 80, "subsampling_rate": 4, "input_dim": 256,
+            "num_heads": 4, "ffn_dim": 2048, "num_layers": layers,
+            "depthwise_conv_kernel_size": 31, "dropout": 0.0, "use_group_norm": False,
+            "convolution_first": False, "output_dim": 256}},
+        "decoder": {"model": "Projector", "config": {"input_dim": 256, "output_dim": vocab,
+                                                     "dropout_p": 0.0}},
+        "loss": {"model": "CTC", "config": {"blank_label": 0, "reduction": "mean"}},
+        "optim_setup": {"seperate_lr": {"apply": False},
+                        "optimizer": {"type": "AdamW", "config": {"lr": 1.0e-3}},
+                        "lr_scheduler": {"type": "Warmup", "config": {"warmup_steps": 25000},
+                                         "step_config": {"interval": "step", "frequency": 1}}},
+        "trainer": {"accelerator": "gpu", "devices": 1, "strategy": "ddp",
+                    "precision": "32-true", "max_epochs": 1, "accumulate_grad_batches": 1,
+                    "gradient_clip_val": 5.0, "gradient_clip_algorithm": "norm"},
+    }
+
+
 def synth_pcm(rng, batch, seconds):
     """Band-limited noise + 3 sinusoids, clipped to [-1,1]."""
     n = int(seconds * SR)
@@ -81,6 +112,7 @@ def synth_pcm(rng, batch, seconds):
 
 
 def make_batch(rank, batch, seconds, n_labels, vocab, device):
+    import torch
     rng = np.random.default_rng(20241218 + rank)
     pcm = synth_pcm(rng, batch, seconds)
     lab = rng.integers(1, vocab - 1, size=(batch, n_labels))
@@ -104,109 +136,273 @@ def host_threads(cap=16):
     return max(1, min(n, cap))
 
 
-def cpu_baseline(cfg, seconds=10.0, batch=2, n_labels=50, vocab=500, steps=2):
-    """Times the oracle (our CPU restatement of the reference path: numpy fbank, torch-CPU
-    zipformer fwd+bwd, k2-style RNN-T losses) on the host cores.  Test infrastructure used as
-    a reported baseline only; never on the product path."""
-    from oracle import fbank as ofb
-    from oracle import k2_rnnt as K2
-    from oracle import zipformer as Z
-    from speech2text_amd.model.encoder.zipformer import Zipformer2, Zipformer2Config
-    from speech2text_amd.model.joiner.joiner import JoinerConfig, Joiner
-    from speech2text_amd.model.predictor.predictor import Predictor
-
-    torch.manual_seed(1234)
-    nthreads = host_threads()
-    torch.set_num_threads(nthreads)
-    ec = cfg["encoder"]["config"]
-    enc = Zipformer2(Zipformer2Config(**ec))                # parameter container only
-    sd = {k: v.detach().clone().requires_grad_(True) for k, v in enc.state_dict().items()}
-    pred = Predictor(cfg["predictor"])
-    join = Joiner(JoinerConfig(**cfg["joiner"]))
+def _zcfg(ec):
     ns = len(ec["downsampling_factor"])
     tup = lambda v: tuple(v) if isinstance(v, (list, tuple)) else (v,) * ns   # noqa: E731
-    zcfg = dict(downsampling_factor=tup(ec["downsampling_factor"]),
+    return dict(downsampling_factor=tup(ec["downsampling_factor"]),
                 num_encoder_layers=tup(ec["num_encoder_layers"]), encoder_dim=tup(ec["encoder_dim"]),
                 encoder_unmasked_dim=tup(ec["encoder_unmasked_dim"]), num_heads=tup(ec["num_heads"]),
                 query_head_dim=tup(ec["query_head_dim"]), pos_head_dim=tup(ec["pos_head_dim"]),
                 cnn_module_kernel=tup(ec["cnn_module_kernel"]), pos_dim=ec["pos_dim"])
+
+
+def cpu_baseline(cfg, state_dict, seconds=10.0, batch=8, n_labels=50, vocab=500, steps=3,
+                 warmup=1):
+    """Times the ORACLE train step on the host cores: numpy fbank, torch-CPU zipformer fwd+bwd
+    (oracle/zipformer.py), stateless predictor + joiner projections (oracle/heads.py), k2-style
+    simple + pruned RNN-T losses (oracle/k2_rnnt.py, C mutual-information recursion).  Uses ONLY
+    oracle/ code and plain torch on `state_dict` (reference parameter names, CPU fp32 tensors);
+    no speech2text_amd module runs here.  A reported baseline, never the product path."""
+    import torch
+    from oracle import fbank as ofb
+    from oracle import heads as H
+    from oracle import k2_rnnt as K2
+    from oracle import zipformer as Z
+
+    nthreads = host_threads()
+    torch.set_num_threads(nthreads)
+    os.environ.setdefault("OMP_NUM_THREADS", str(nthreads))
+    sd = {k: v.detach().to("cpu", torch.float32).clone().requires_grad_(v.dtype.is_floating_point)
+          for k, v in state_dict.items()}
+    enc_sd = {k[len("_encoder.encoder."):]: v for k, v in sd.items()
+              if k.startswith("_encoder.encoder.")}
+    zcfg = _zcfg(cfg["encoder"]["config"])
+    ctx = cfg["predictor"]["config"]["context_size"]
+    prune = cfg["joiner"]["prune_range"]
+    ss, ps = cfg["loss"]["simple_loss_scale"], cfg["loss"]["pruned_loss_scale"]
     rng = np.random.default_rng(20241218)
     pcm = synth_pcm(rng, batch, seconds)
     lab = torch.from_numpy(rng.integers(1, vocab - 1, size=(batch, n_labels)))
     lab_len = torch.full((batch,), n_labels, dtype=torch.int64)
     pyrand = random.Random(1234)
-    times = []
-    for it in range(steps + 1):
+    times, loss = [], None
+    for it in range(steps + warmup):
         t0 = time.perf_counter()
         feats = np.stack([ofb.fbank(p * 32768.0, 80, high_freq=-400.0) for p in pcm])
         x = torch.from_numpy(feats)
         lens = torch.full((batch,), feats.shape[1], dtype=torch.int64)
         ctl = Z.Ctl(training=True, rand=pyrand.random)
-        y, ylen = Z.zipformer_forward(sd, zcfg, x, lens, ctl, -1, -1)
-        po, pl, _ = pred(lab, lab_len, pred.init_state())
-        am = join._enc_proj(y)
-        lm = join._pre_proj(po)
-        logits, bnd, ranges, simple = K2.joiner_pruned(am, lm, lab, lab_len, ylen, 5)
+        y, ylen = Z.zipformer_forward(enc_sd, zcfg, x, lens, ctl, -1, -1)
+        po = H.stateless_predictor(sd, "_predictor.predictor.", lab, ctx)
+        am, lm = H.joiner_projections(sd, "_joiner.", y, po)
+        logits, bnd, ranges, simple = K2.joiner_pruned(am, lm, lab, lab_len, ylen, prune)
         pruned = K2.rnnt_loss_pruned(logits, lab, ranges, 0, bnd)
-        loss = 0.5 * simple + 0.5 * pruned
+        loss = H.pruned_rnnt_task_loss(simple, pruned, ss, ps)
         loss.backward()
         for v in sd.values():
             v.grad = None
         dt = time.perf_counter() - t0
-        if it > 0:
+        if it >= warmup:
             times.append(dt)
     med = float(np.median(times))
     return {"value": batch * seconds / med, "unit": "audio-seconds/sec", "cores": nthreads,
             "kind": "port",
-            "sample": f"{batch} x {seconds:g}s utterances, {steps} timed steps (median) of the "
-                      f"oracle train step (numpy fbank + torch-CPU zipformer fwd/bwd + k2-style "
-                      f"losses), loss={float(loss.detach()):.4f}"}
+            "sample": f"{batch} x {seconds:g}s utterances, {warmup} warm-up + {steps} timed steps "
+                      f"(median {med:.2f} s) of the oracle C3 train step (numpy fbank + torch-CPU "
+                      f"zipformer fwd/bwd + C/torch k2-style losses; parity unpinned for the k2 "
+                      f"part), loss={float(loss.detach()):.4f}"}
+
+
+def cpu_baseline_c2(cfg, state_dict, seconds=10.0, batch=4, n_labels=40, vocab=128, steps=3,
+                    warmup=1):
+    """Oracle conformer-CTC step (oracle/fbank.py, oracle/conformer.py, oracle/ctc.py)."""
+    import torch
+    from oracle import conformer as OC
+    from oracle import fbank as ofb
+    from oracle import heads as H
+
+    nthreads = host_threads()
+    torch.set_num_threads(nthreads)
+    sd = {k: v.detach().to("cpu").clone() for k, v in state_dict.items()}
+    for k, v in sd.items():                                 # buffers (BatchNorm running stats) stay plain
+        if v.dtype.is_floating_point and "running_" not in k:
+            v.requires_grad_(True)
+    enc = {k[len("_encoder.encoder."):]: v for k, v in sd.items() if k.startswith("_encoder.encoder.")}
+    ec = cfg["encoder"]["config"]
+    rng = np.random.default_rng(20241218)
+    pcm = synth_pcm(rng, batch, seconds)
+    lab = torch.from_numpy(rng.integers(1, vocab - 1, size=(batch, n_labels)))
+    lab_len = torch.full((batch,), n_labels, dtype=torch.int64)
+    times, loss = [], None
+    for it in range(steps + warmup):
+        t0 = time.perf_counter()
+        feats = np.stack([ofb.fbank(p, 80) for p in pcm])
+        x = torch.from_numpy(feats)
+        lens = torch.full((batch,), feats.shape[1], dtype=torch.int64)
+        y, ylen = OC.conformer_forward(enc, x, lens, ec["num_layers"], ec["num_heads"], training=True)
+        logits = H.projector(sd, "_decoder.decoder.", y)
+        lp = logits.log_softmax(-1).transpose(0, 1)
+        loss = torch.nn.functional.ctc_loss(lp, lab, ylen, lab_len, blank=0, reduction="mean",
+                                            zero_infinity=True)
+        loss.backward()
+        for v in sd.values():
+            v.grad = None
+        dt = time.perf_counter() - t0
+        if it >= warmup:
+            times.append(dt)
+    med = float(np.median(times))
+    return {"value": batch * seconds / med, "unit": "audio-seconds/sec", "cores": nthreads,
+            "kind": "port",
+            "sample": f"{batch} x {seconds:g}s utterances, {warmup} warm-up + {steps} timed steps "
+                      f"(median {med:.2f} s) of the oracle C2 conformer-CTC train step, "
+                      f"loss={float(loss.detach()):.4f}"}
+
+
+# ------------------------------------------------------------------ roofline bookkeeping
+def roofline_report(prof_timed, prof_all, want, step_flops, ms_per_step):
+    """`prof_timed`: HIP-event timings of the chosen entry point taken INSIDE the timed region.
+    `prof_all`: every hand-written entry point, timed over extra (untimed) steps."""
+    table = []
+    for name, p in sorted(prof_all.items(), key=lambda kv: -kv[1]["total_ms"]):
+        row = {"entry": name, "launches_per_step": p["launches_per_step"],
+               "ms_per_step": p["ms_per_step"], "avg_us": 1000.0 * p["avg_ms"]}
+        if p["algo_bytes"] > 0 and p["total_ms"] > 0:
+            gbs = p["algo_bytes"] / (p["total_ms"] * 1e-3) / 1e9
+            row.update(alg_GBps=gbs, frac_hbm=gbs / HBM_PEAK_GBS)
+        table.append(row)
+    out = {"bound": "hbm", "kernel": want, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": None, "traffic": None}
+    p = prof_timed.get(want) if prof_timed else None
+    if p and p["launches"] and p["algo_bytes"] > 0:
+        ach = p["algo_bytes"] / (p["total_ms"] * 1e-3) / 1e9
+        out.update(achieved=ach, frac=ach / HBM_PEAK_GBS, launches=p["launches"],
+                   avg_launch_ms=p["avg_ms"],
+                   algorithmic_bytes_per_launch=p["algo_bytes"] / p["launches"])
+    else:
+        out["note"] = f"{want} was not launched in the timed region"
+    tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            out["traffic"] = json.load(open(tpath)).get(want, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            pass
+    out["kernels"] = table
+    if step_flops:
+        tf = step_flops / (ms_per_step * 1e-3) / 1e12
+        out["step_mfma"] = {"flops_per_step": step_flops, "achieved_tflops": tf,
+                            "peak_tflops": MFMA_F32_PEAK_TFLOPS, "frac": tf / MFMA_F32_PEAK_TFLOPS}
+    return out
+
+
+# ------------------------------------------------------------------ launcher
+def self_launch(args, argv):
+    """--gpus N>1 outside a launcher: start N ranks in child processes (this parent never
+    touches the GPU) and relay the result."""
+    port = int(os.environ.get("MASTER_PORT", 29500 + (os.getpid() % 2000)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port",
+           str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env)
+    sys.exit(r.returncode)
+
+
+def launcher_selftest(args, rank, world):
+    """CPU-only rehearsal of the multi-rank protocol (gloo): rendezvous, barrier-bracketed timed
+    loop, MAX over ranks, rank 0 prints the JSON line.  No GPU, no model: used by tests/."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    x = torch.ones(1024)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if world > 1:
+            dist.all_reduce(x)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "launcher-selftest", "value": args.steps / float(t.item()),
+                          "unit": "steps/sec", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "backend": "gloo" if world > 1 else "none"}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 # ------------------------------------------------------------------ main
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="per-rank batch (utterances)")
+    ap.add_argument("--config", default="C3", choices=["C3", "C2"])
+    ap.add_argument("--batch", type=int, default=None, help="per-rank batch (utterances)")
     ap.add_argument("--seconds", type=float, default=10.0)
-    ap.add_argument("--labels", type=int, default=50)
-    ap.add_argument("--vocab", type=int, default=500)
+    ap.add_argument("--labels", type=int, default=None)
+    ap.add_argument("--vocab", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=2)
-    ap.add_argument("--roofline-kernel", default="relpos_attn_weights_fwd")
-    args = ap.parse_args()
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--roofline-kernel", default=DEFAULT_ROOFLINE_KERNEL)
+    ap.add_argument("--profile-steps", type=int, default=2,
+                    help="extra untimed steps with every entry point bracketed by HIP events")
+    ap.add_argument("--launcher-selftest", action="store_true")
+    args = ap.parse_args(argv)
+    d = {"C3": (64, 50, 500), "C2": (32, 40, 128)}[args.config]
+    args.batch = args.batch or d[0]
+    args.labels = args.labels or d[1]
+    args.vocab = args.vocab or d[2]
+    return args
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        self_launch(args, argv)                           # never returns
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if args.launcher_selftest:
+        return launcher_selftest(args, rank, world)
 
-    from speech2text_amd import _native
-    from speech2text_amd.task_factory.rnnt_task import PrunedRnntTask
-    from speech2text_amd.trainer import Trainer
+    import torch
+    import torch.distributed as dist
 
     def note(msg):
         if rank == 0:
             print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
-    cfg = c3_config(args.vocab)
-    cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
-        note("timing the CPU baseline (oracle) ...")
-        cpu = cpu_baseline(cfg, args.seconds, args.cpu_batch, args.labels, args.vocab)
-        note(f"cpu baseline: {cpu['value']:.2f} audio-s/s on {cpu['cores']} threads")
+    if world != args.gpus:
+        note(f"--gpus {args.gpus} but WORLD_SIZE={world}: reporting n_gpus={world}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
+    from speech2text_amd import _native
+    from speech2text_amd.build_task import TaskFactory
+    from speech2text_amd.trainer import Trainer
+
+    c3 = args.config == "C3"
+    cfg = c3_config(args.vocab) if c3 else c2_config(args.vocab)
     random.seed(1234 + rank)
     np.random.seed(1234 + rank)
     torch.manual_seed(1234)                                 # same init on every rank
-    task = PrunedRnntTask(cfg)
+    task = TaskFactory.get(cfg["task"]["type"])(cfg)        # parameters are created on the host
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        note("timing the CPU baseline (oracle) ...")
+        try:
+            fn = cpu_baseline if c3 else cpu_baseline_c2
+            cpu = fn(cfg, task.state_dict(), args.seconds, args.cpu_batch if c3 else 4,
+                     args.labels, args.vocab, steps=args.cpu_steps)
+            note(f"cpu baseline: {cpu['value']:.2f} audio-s/s on {cpu['cores']} threads")
+        except Exception as e:                              # a baseline failure must not abort
+            note(f"cpu baseline FAILED: {type(e).__name__}: {e}")
+            cpu = {"value": None, "unit": "audio-seconds/sec", "cores": host_threads(),
+                   "kind": "port", "sample": f"failed: {type(e).__name__}: {e}"}
     trainer = Trainer(**cfg["trainer"]).setup(task, device)
     task.train()
     torch.manual_seed(1234 + rank)
@@ -219,41 +415,70 @@ def main():
 
     note("model + synthetic batch ready; warmup ...")
     loss = None
+    want = args.roofline_kernel
     for i in range(args.warmup):
         tw = time.perf_counter()
+        last = i == args.warmup - 1
+        if last and want == "auto":
+            _native.profile_begin("*")
         loss = trainer.training_step(batch, i)
         torch.cuda.synchronize()
+        if last and want == "auto":
+            pw = _native.profile_end()
+            cand = {k: v for k, v in pw.items() if v["algo_bytes"] > 0}
+            want = max(cand, key=lambda k: cand[k]["total_ms"]) if cand else "s2t_relpos_attn_fwd"
         note(f"warmup step {i}: {time.perf_counter() - tw:.3f} s, loss {float(loss):.4f}")
+    if want == "auto":
+        want = "s2t_relpos_attn_fwd"
     sync()
-    _native.profile_begin(args.roofline_kernel)
+    _native.profile_begin(want)
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = trainer.training_step(batch, args.warmup + i)
     sync()
     dt = time.perf_counter() - t0
-    prof = _native.profile_end()
+    prof_timed = _native.profile_end()
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    final_loss = float(loss)
+    prof_all = {}
+    if args.profile_steps > 0:                              # every rank: the step has collectives
+        _native.profile_begin("*")
+        for i in range(args.profile_steps):
+            trainer.training_step(batch, args.warmup + args.steps + i)
+        torch.cuda.synchronize()
+        prof_all = _native.profile_end()
+        for p in prof_all.values():
+            p["launches_per_step"] = p["launches"] / args.profile_steps
+            p["ms_per_step"] = p["total_ms"] / args.profile_steps
+    if world > 1:
+        dist.barrier()
     audio_s = args.batch * args.seconds * world * args.steps
+    ms = 1000.0 * dt / args.steps
     if rank == 0:
-        from speech2text_amd import roofline
+        # zipformer fwd+bwd ~3.6 GFLOP per audio-second; conformer ~6.7
+        step_flops = (3.6e9 if c3 else 6.7e9) * args.batch * args.seconds
+        name = ("zipformer pruned-RNN-T" if c3 else "conformer-CTC")
         out = {
-            "metric": "audio-seconds/sec (train step, zipformer pruned-RNN-T)",
+            "metric": f"audio-seconds/sec (train step, {name})",
             "value": audio_s / dt, "unit": "audio-seconds/sec", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "C3 zipformer-stateless pruned-RNN-T train step (fbank+fwd+bwd"
-                                   "+allreduce+ScaledAdam), 500 BPE, prune_range 5, chunk_size -1",
+            "config": {"workload": ("C3 zipformer-stateless pruned-RNN-T train step (fbank+fwd+bwd"
+                                    "+allreduce+ScaledAdam), 500 BPE, prune_range 5, chunk_size -1"
+                                    if c3 else
+                                    "C2 conformer-CTC train step (fbank+fwd+bwd+allreduce+AdamW), "
+                                    "12 layers d=256, V=128"),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "utterance_seconds": args.seconds, "labels_per_utt": args.labels,
-                       "parallelism": f"dp{world}", "final_loss": float(loss)},
-            "roofline": roofline.report(args.roofline_kernel, prof, args),
+                       "parallelism": f"dp{world}", "final_loss": final_loss},
+            "roofline": roofline_report(prof_timed, prof_all, want, step_flops, ms),
             "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -11,6 +11,9 @@ called from model/joiner/joiner.py:100-123 and model/loss/pruned_rnnt_loss.py:39
 anchored by self-checks in tests/ (brute-force path enumeration, pruned == unpruned
 when s_range = S+1, simple == full on additive logits, range invariants, gradcheck).
 """
+import ctypes
+import os
+
 import numpy as np
 import torch
 
@@ -74,11 +77,56 @@ def mutual_information_np(px, py, boundary):
     return p, ans, gx, gy
 
 
+_CLIB = [None, False]
+
+
+def _clib():
+    """oracle/liboracle_c.so (oracle/csrc/mutual_info.c, built by oracle/build.py) or None."""
+    if not _CLIB[1]:
+        _CLIB[1] = True
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liboracle_c.so")
+        if os.path.exists(path) and os.environ.get("ORACLE_MI", "c") != "numpy":
+            lib = ctypes.CDLL(path)
+            lib.oracle_mutual_information.restype = ctypes.c_int
+            lib.oracle_mutual_information.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + \
+                [ctypes.c_void_p] * 4
+            _CLIB[0] = lib
+    return _CLIB[0]
+
+
+def mutual_information_c(px, py, boundary):
+    """Same contract as mutual_information_np, computed by the plain-C restatement."""
+    lib = _clib()
+    assert lib is not None, "oracle/liboracle_c.so is not built (python -m oracle.build)"
+    px = np.ascontiguousarray(px, dtype=np.float32)
+    py = np.ascontiguousarray(py, dtype=np.float32)
+    bd = np.ascontiguousarray(boundary, dtype=np.int64)
+    B, S, T1 = px.shape
+    T = py.shape[2]
+    assert T1 == T + 1 and py.shape[1] == S + 1
+    p = np.empty((B, S + 1, T + 1), np.float32)
+    ans = np.empty(B, np.float32)
+    gx = np.empty_like(px)
+    gy = np.empty_like(py)
+    rc = lib.oracle_mutual_information(px.ctypes.data, py.ctypes.data, bd.ctypes.data, B, S, T,
+                                       p.ctypes.data, ans.ctypes.data, gx.ctypes.data,
+                                       gy.ctypes.data)
+    assert rc == 0
+    return p, ans, gx, gy
+
+
+def mutual_information_any(px, py, boundary):
+    """C restatement when built (fast enough for the C3-size CPU baseline), else numpy."""
+    if _clib() is not None and np.asarray(px).dtype == np.float32:
+        return mutual_information_c(px, py, boundary)
+    return mutual_information_np(px, py, boundary)
+
+
 class _MutualInformation(torch.autograd.Function):
     @staticmethod
     def forward(ctx, px, py, boundary):
-        _, ans, gx, gy = mutual_information_np(px.detach().numpy(), py.detach().numpy(),
-                                               boundary.numpy())
+        _, ans, gx, gy = mutual_information_any(px.detach().numpy(), py.detach().numpy(),
+                                                boundary.numpy())
         ctx.save_for_backward(torch.from_numpy(gx), torch.from_numpy(gy))
         return torch.from_numpy(ans)
 
@@ -90,8 +138,8 @@ class _MutualInformation(torch.autograd.Function):
 
 def mutual_information_recursion(px, py, boundary, return_grad=False):
     if return_grad:
-        _, ans, gx, gy = mutual_information_np(px.detach().numpy(), py.detach().numpy(),
-                                               boundary.numpy())
+        _, ans, gx, gy = mutual_information_any(px.detach().numpy(), py.detach().numpy(),
+                                                boundary.numpy())
         scores = _MutualInformation.apply(px, py, boundary)
         return scores, (torch.from_numpy(gx), torch.from_numpy(gy))
     return _MutualInformation.apply(px, py, boundary)

@@ -38,15 +38,15 @@ def parse_header(path=HEADER_PATH):
 
 
 class _Prof:
-    target = None        # C entry point being timed (HIP events on the launch stream)
-    events = []
-    algo_bytes = 0.0
-    algo_flops = 0.0
+    target = None        # None | "*" (every entry point) | one C entry-point name
+    events = {}          # entry -> [(start, stop)] HIP events on the launch stream
+    algo_bytes = {}      # entry -> algorithmic bytes reported by the call sites
+    algo_flops = {}
 
 
 class _LibProxy:
     """Attribute access returns the ctypes function, wrapped so that launches of the entry
-    point selected by profile_begin() are bracketed by HIP events on the current stream."""
+    point(s) selected by profile_begin() are bracketed by HIP events on the current stream."""
 
     def __init__(self, cdll):
         self._cdll = cdll
@@ -56,16 +56,18 @@ class _LibProxy:
         fn = self._fns.get(name)
         if fn is None:
             raw = getattr(self._cdll, name)
+            timed = not name.endswith("_floats")          # workspace-size queries launch nothing
 
-            def call(*args, _raw=raw, _name=name):
-                if _Prof.target != _name:
+            def call(*args, _raw=raw, _name=name, _timed=timed):
+                tgt = _Prof.target
+                if tgt is None or not _timed or (tgt != "*" and tgt != _name):
                     return _raw(*args)
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
                 e0.record()
                 rc = _raw(*args)
                 e1.record()
-                _Prof.events.append((e0, e1))
+                _Prof.events.setdefault(_name, []).append((e0, e1))
                 return rc
 
             fn = call
@@ -90,30 +92,37 @@ def lib():
 
 
 def profile_begin(entry_point):
+    """entry_point: a C entry-point name declared in include/s2t_mi355.h, or "*" for all."""
+    if entry_point != "*" and entry_point not in parse_header():
+        raise ValueError(f"{entry_point!r} is not an entry point of include/s2t_mi355.h")
     _Prof.target = entry_point
-    _Prof.events = []
-    _Prof.algo_bytes = 0.0
-    _Prof.algo_flops = 0.0
+    _Prof.events = {}
+    _Prof.algo_bytes = {}
+    _Prof.algo_flops = {}
 
 
 def profile_note(entry_point, nbytes=0.0, flops=0.0):
     """Call sites report the ALGORITHMIC bytes/flops of a launch (DESIGN.md formulas)."""
-    if _Prof.target == entry_point:
-        _Prof.algo_bytes += nbytes
-        _Prof.algo_flops += flops
+    tgt = _Prof.target
+    if tgt is not None and (tgt == "*" or tgt == entry_point):
+        _Prof.algo_bytes[entry_point] = _Prof.algo_bytes.get(entry_point, 0.0) + nbytes
+        _Prof.algo_flops[entry_point] = _Prof.algo_flops.get(entry_point, 0.0) + flops
 
 
 def profile_end():
-    tgt = _Prof.target
+    """-> {entry: {launches, total_ms, avg_ms, algo_bytes, algo_flops}}"""
     _Prof.target = None
-    if not _Prof.events:
-        return {"entry": tgt, "launches": 0, "total_ms": 0.0, "avg_ms": None,
-                "algo_bytes": 0.0, "algo_flops": 0.0}
-    torch.cuda.synchronize()
-    ms = [a.elapsed_time(b) for a, b in _Prof.events]
-    return {"entry": tgt, "launches": len(ms), "total_ms": float(sum(ms)),
-            "avg_ms": float(sum(ms) / len(ms)), "algo_bytes": _Prof.algo_bytes,
-            "algo_flops": _Prof.algo_flops}
+    out = {}
+    if _Prof.events:
+        torch.cuda.synchronize()
+    for name, evs in _Prof.events.items():
+        ms = [a.elapsed_time(b) for a, b in evs]
+        out[name] = {"launches": len(ms), "total_ms": float(sum(ms)),
+                     "avg_ms": float(sum(ms) / len(ms)),
+                     "algo_bytes": _Prof.algo_bytes.get(name, 0.0),
+                     "algo_flops": _Prof.algo_flops.get(name, 0.0)}
+    _Prof.events = {}
+    return out
 
 
 def stream():

@@ -113,12 +113,13 @@ class GradReducer:
             if not self._launched[b]:
                 self._launch(b)
         if self._is_cuda:
+            main = torch.cuda.current_stream()
             with torch.cuda.stream(self._stream):
                 for w, buf in self._works:
                     w.wait()
                     buf.div_(self.world)
                 if extra is not None:
-                    self._stream.wait_stream(torch.cuda.current_stream())
+                    self._stream.wait_stream(main)          # `extra` was produced on the main stream
                     dist.all_reduce(extra, op=dist.ReduceOp.SUM, group=self.pg)
                     extra.div_(self.world)
             torch.cuda.current_stream().wait_stream(self._stream)

@@ -33,6 +33,17 @@ class Trainer:
             device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0))) \
                 if torch.cuda.is_available() else torch.device("cpu")
         self.device = device
+        if device.type == "cuda":
+            torch.cuda.set_device(device)
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world > 1 and not dist.is_initialized():
+            # one process per GPU (reference: pl.Trainer(strategy="ddp"), build_task.py:143-148);
+            # backend "nccl" is RCCL on ROCm, gloo for the CPU rehearsals in tests/
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if device.type == "cuda":
+                dist.init_process_group("nccl", device_id=device)
+            else:
+                dist.init_process_group("gloo")
         task.to(device)
         self.task = task
         opt = task.configure_optimizers()

@@ -233,6 +233,87 @@ def gen_subsampling():
     print("subsampling", {r: out[f"out{r}"].shape for r in (4, 6, 8)})
 
 
+def gen_heads():
+    """StatelessPredictor, MaskedKLDivergence, MaskedCELoss, GlobalCmvnLayer, Projector run from
+    the reference tree; plus the task-level loss-combination formulas evaluated on the scalars
+    the reference classes returned (task_factory/rnnt_task.py:349,496-499; ssl_task.py:140-167)."""
+    import torch
+    ref_import.install_stubs()
+    from model.predictor.stateless_predictor import StatelessPredictor, StatelessPredictorConfig
+    from model.loss.kl_divergence import MaskedKLDivergence, MaskedKLDivergenceConfig
+    from model.loss.cross_entropy import MaskedCELoss, MaskedCELossConfig
+    from model.layer.global_cmvn import GlobalCmvnLayer
+    from model.decoder.projector import Projector, ProjectorConfig
+    torch.manual_seed(20241218)
+    rng = np.random.default_rng(20241218)
+    out = {}
+    # ---- stateless predictor (fwd + grads of all parameters)
+    for ci, (V, D, E, ctx, B, U) in enumerate([(64, 48, 32, 5, 3, 7), (500, 32, 48, 5, 2, 12),
+                                               (32, 16, 24, 2, 2, 5), (32, 16, 24, 1, 2, 4)]):
+        m = StatelessPredictor(StatelessPredictorConfig(num_symbols=V, output_dim=D,
+                                                        symbol_embedding_dim=E, context_size=ctx))
+        lab = torch.from_numpy(rng.integers(1, V, size=(B, U))).long()
+        y, ln, st = m(lab, torch.full((B,), U), m.init_state())
+        w = torch.from_numpy(rng.standard_normal(tuple(y.shape)).astype(np.float32))
+        (y * w).sum().backward()
+        out[f"pred{ci}_cfg"] = np.array([V, D, E, ctx])
+        out[f"pred{ci}_labels"] = lab.numpy()
+        out[f"pred{ci}_out"] = y.detach().numpy()
+        out[f"pred{ci}_state"] = st.numpy()
+        out[f"pred{ci}_w"] = w.numpy()
+        for k, v in m.state_dict().items():
+            out[f"pred{ci}_sd_{k}"] = v.numpy()
+        for k, v in m.named_parameters():
+            out[f"pred{ci}_grad_{k}"] = v.grad.numpy()
+    # ---- masked KL / CE (2-D masks, 1-D length masks, smoothing, scale)
+    for ci, (B, T, K, eps, scale) in enumerate([(3, 11, 17, 0.0, 1.0), (2, 9, 33, 0.1, 1.0),
+                                                (2, 3, 8193, 0.1, 1.0), (2, 7, 13, 0.2, 0.5)]):
+        lens = torch.tensor([T] + [int(x) for x in rng.integers(2, T, size=B - 1)])
+        lab = torch.from_numpy(rng.integers(1, K, size=(B, T))).long()
+        m2 = (torch.from_numpy(rng.random((B, T))) < 0.5) & (torch.arange(T)[None] < lens[:, None])
+        m2[0, 0] = True
+        m2 = m2.float()
+        base = torch.from_numpy(rng.standard_normal((B, T, K)).astype(np.float32) * 2.0)
+        out[f"ssl{ci}_cfg"] = np.array([K, eps, scale])
+        out[f"ssl{ci}_logits"] = base.numpy()
+        out[f"ssl{ci}_labels"] = lab.numpy()
+        out[f"ssl{ci}_mask2d"] = m2.numpy()
+        out[f"ssl{ci}_lens"] = lens.numpy()
+        for name, cls, cfgcls in (("kl", MaskedKLDivergence, MaskedKLDivergenceConfig),
+                                  ("ce", MaskedCELoss, MaskedCELossConfig)):
+            mod = cls(cfgcls(num_classes=K, scale_factor=scale, label_smoothing=eps))
+            for mname, mk in (("mask", m2), ("len", lens)):
+                lg = base.clone().requires_grad_(True)
+                loss = mod(lg * 1.0, lab, mk)     # "* 1.0": the class scales its input in place
+                loss.backward()
+                out[f"ssl{ci}_{name}_{mname}_loss"] = loss.detach().numpy()
+                out[f"ssl{ci}_{name}_{mname}_grad"] = lg.grad.numpy()
+        # the SSL task's combination over "codebooks" (ssl_task.py:140-167) on these scalars
+        ml = [torch.tensor(float(out[f"ssl{ci}_kl_mask_loss"])), torch.tensor(1.25)]
+        tl = [torch.tensor(float(out[f"ssl{ci}_kl_len_loss"])), torch.tensor(0.75)]
+        out[f"ssl{ci}_task"] = np.array([float(sum(ml) / 2), float(sum(tl) / 2)])
+    # ---- GlobalCmvn + Projector
+    cm = GlobalCmvnLayer({"feat_type": "fbank", "feat_config": {"num_mel_bins": 80}})
+    cm.global_mean.copy_(torch.from_numpy(rng.standard_normal(80).astype(np.float32)))
+    cm.global_istd.copy_(torch.from_numpy(rng.uniform(0.2, 2.0, 80).astype(np.float32)))
+    x = torch.from_numpy(rng.standard_normal((2, 13, 80)).astype(np.float32) * 5)
+    out["cmvn_x"], out["cmvn_mean"], out["cmvn_istd"] = x.numpy(), cm.global_mean.numpy(), \
+        cm.global_istd.numpy()
+    out["cmvn_y"] = cm(x).numpy()
+    pj = Projector(ProjectorConfig(input_dim=24, output_dim=40, dropout_p=0.0))
+    xp = torch.from_numpy(rng.standard_normal((2, 9, 24)).astype(np.float32))
+    yp, _ = pj(xp, torch.tensor([9, 5]))
+    out["proj_x"], out["proj_y"] = xp.numpy(), yp.detach().numpy()
+    for k, v in pj.state_dict().items():
+        out[f"proj_sd_{k}"] = v.numpy()
+    # ---- RNN-T task formulas (plain float arithmetic in the reference, rnnt_task.py:349,496-499)
+    s, pr, c = 3.25, 1.5, 0.625
+    out["formula_pruned"] = np.array([0.5 * s + 0.5 * pr, 0.5 * s + 0.5 * pr + c], np.float64)
+    out["formula_hybrid"] = np.array([0.8 * s + 0.2 * c], np.float64)
+    np.savez_compressed(os.path.join(OUT, "heads_ref.npz"), **out)
+    print("heads:", len(out), "arrays")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ["fbank", "ctc", "bestrq", "zipformer", "scaledadam"]
