@@ -187,6 +187,49 @@ long s2t_dwconv2d_wgrad_workspace_floats(int N, int H, int C, int KH, int KW);
 int s2t_dwconv2d_nhwc_wgrad(const float* x, const float* dy, int N, int H, int W, int C, int KH,
                             int KW, float* workspace, float* dw, float* db, void* stream);
 
+/* ---- fused multi-tensor ScaledAdam + grad-norm clip + zero_grad over one flat fp32 buffer
+ * (optimizer/scaled_adam.py:408-527 _get_clipping_scale, :563-736 _step_one_batch / _size_update
+ * / _step / _step_scalar; the trainer's gradient_clip_val of config/training/*.yaml `trainer:`).
+ * The flat buffer holds every tensor padded to 16 bytes; a host-built chunk table cuts each
+ * tensor into chunks of s2t_optim_chunk_elems() elements: chunk_off/len/seg [nchunks],
+ * seg_chunk_begin [nseg+1], seg_len [nseg].  s2t_seg_stats writes partial [nchunks][3] =
+ * (sum g^2, sum p g, sum p^2); s2t_scaled_adam_coef (one workgroup, one param group = tensors
+ * [seg_lo,seg_hi)) turns them into per-tensor coefficients segc [nseg][s2t_optim_segc_floats()]
+ * and advances the group state (param_rms, scale_exp_avg_sq [nseg_g], scale_grads [P][nseg_g],
+ * model_norms [period], fstate [3] = threshold / last norm / last clip factor, istate [3] =
+ * has_threshold / num_clipped / non-finite-median flag); s2t_scaled_adam_apply updates
+ * p, delta, exp_avg_sq in place and stores the clipped gradient (or zeros if zero_grad). */
+int s2t_optim_chunk_elems(void);
+int s2t_optim_segc_floats(void);
+int s2t_seg_stats(const float* p, const float* g, const int* chunk_off, const int* chunk_len,
+                  int nchunks, float* partial, void* stream);
+int s2t_scaled_adam_coef(const float* partial, const int* seg_chunk_begin, const int* seg_len,
+                         int nchunks_all, int seg_lo, int seg_hi, float lr, float beta1,
+                         float beta2, float eps, float scalar_lr_scale, float param_min_rms,
+                         float param_max_rms, float scalar_max, float clip_val,
+                         float clipping_scale, int step, int size_update_period,
+                         int clipping_update_period, float bc2, float bc2_size, float beta2c,
+                         float* param_rms, float* scale_exp_avg_sq, float* scale_grads,
+                         float* model_norms, float* fstate, int* istate, float* segstat,
+                         float* segc, void* stream);
+int s2t_scaled_adam_apply(float* p, float* g, float* delta, float* exp_avg_sq,
+                          const int* chunk_off, const int* chunk_len, const int* chunk_seg,
+                          int nchunks, const float* segc, int zero_grad, void* stream);
+
+/* ---- fp32 MFMA GEMM family with fused prologue / epilogue (csrc/gemm.hip) for the dense layers:
+ * nn.Linear / ScaledLinear / ActivationDropoutAndLinear of model/encoder/zipformer.py:1924-2695,
+ * model/layer/scaling.py:1512-1583 and their backward passes.
+ *   mode 0 (NT): C[M,N]  = pro_a(A[M,K]) B[N,K]^T  (+ bias[N]) (* act'(act_src)) (+ resid) (+ C)
+ *   mode 1 (NN): C[M,N]  = A[M,K] B[K,N]            same epilogue
+ *   mode 2 (TN): C[M,N] += A[K,M]^T pro_b(B[K,N])   atomically (split over K); colsum[M] += sum_k A
+ * act kinds: 0 none, 1 SwooshL, 2 SwooshR.  Leading dimensions in floats; A and B 16-byte
+ * aligned with lda, ldb % 4 == 0 (and K % 4 == 0 for modes 0/1), else -2 (caller falls back to
+ * a library GEMM). */
+int s2t_gemm_f32(int mode, const float* A, long lda, const float* B, long ldb, float* C, long ldc,
+                 int M, int N, int K, const float* bias, const float* resid, long ldr,
+                 const float* act_src, long lds, int act_kind, int pro_a, int pro_b, float* colsum,
+                 int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,327 @@
+// fp32 GEMM family on v_mfma_f32_32x32x2_f32 with fused prologues / epilogues, for the dense
+// layers of the training path (reference: every nn.Linear / ScaledLinear /
+// ActivationDropoutAndLinear of model/encoder/zipformer.py:1924-2695 and
+// model/layer/scaling.py:1512-1583, plus their gradients under loss.backward()).
+//
+//   mode NT:  C[M,N]  = pro_a(A[M,K]) . B[N,K]^T          forward  y = act(x) W^T (+bias, +residual)
+//   mode NN:  C[M,N]  = A[M,K] . B[K,N]                   dgrad    dx = g W  (* act'(h), + residual)
+//   mode TN:  C[M,N] += A[K,M]^T . pro_b(B[K,N])          wgrad    dW += g^T act(x), db += colsum(g)
+//
+// Workgroup = 4 waves in a 2x2 grid, each wave TM x TN MFMA tiles of 32x32 (block tile
+// 64TM x 64TN), K chunks of 32 staged global -> registers -> LDS (the next chunk's global loads
+// are in flight while the current one is multiplied).  One lane reads 4 consecutive k of its
+// row with a single ds_read_b128 (k-contiguous operands) or 4 ds_read_b32 (k-major operands);
+// the two k slots of each MFMA take k and k+4, which is a valid summation order because both
+// operands use the same assignment.  f32 MFMA is exact fp32 (fmaf chain), so results match a
+// torch fp32 GEMM to rounding-order differences only.
+// TN splits the (long) contraction dimension over gridDim.z and accumulates with fp32 atomics
+// straight into the caller's gradient buffer: no partial-sum pass, no separate "+=" kernel.
+#include "common.h"
+#include <cstdint>
+#include <cstdlib>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+enum { MODE_NT = 0, MODE_NN = 1, MODE_TN = 2 };
+enum { ACT_NONE = 0, ACT_SWOOSH_L = 1, ACT_SWOOSH_R = 2 };
+
+struct GemmArgs {
+  const float* A;
+  long lda;
+  const float* B;
+  long ldb;
+  float* C;
+  long ldc;
+  int M, N, K;
+  const float* bias;      // [N] added to every row (NT / NN), or NULL
+  const float* resid;     // [M][N] added, or NULL
+  long ldr;
+  const float* act_src;   // epilogue: C *= act'(act_src[m][n]) (dgrad through the activation)
+  long lds;
+  int act_kind;
+  int pro_a, pro_b;       // activation applied to A / B elements while staging
+  float* colsum;          // TN: colsum[m] += sum_k A[k][m]   (bias gradient), or NULL
+  int accumulate;         // NT / NN: C += result
+  int kper;               // TN: contraction rows per z-slice (multiple of BK)
+  int tiles_m, tiles_n;
+  int debug;
+};
+
+__device__ __forceinline__ float swoosh(float x, int kind) {
+  // log(1 + exp(x - off)) - 0.08 x - c   (scaling.py:1340-1343, 1418-1423)
+  const float off = kind == ACT_SWOOSH_L ? 4.f : 1.f;
+  const float c = kind == ACT_SWOOSH_L ? 0.035f : 0.313261687f;
+  const float z = x - off;
+  return fmaxf(z, 0.f) + log1pf(__expf(-fabsf(z))) - 0.08f * x - c;   // as zip_elem.hip swoosh_f
+}
+__device__ __forceinline__ float swoosh_deriv(float x, int kind) {
+  const float off = kind == ACT_SWOOSH_L ? 4.f : 1.f;
+  return 1.f / (1.f + __expf(off - x)) - 0.08f;
+}
+// One operand tile in LDS.  KC: [ROWS][BK + 4] (rows = output index, k contiguous);
+// KM: [BK][ROWS + 4] (k-major).  ROWS = 64 * T.  Loads are unconditional (clamped addresses) so
+// that all of a chunk's global loads are in flight together; validity and the activation are
+// applied one iteration later, when the registers are written to LDS.
+template <int ROWS, bool KC, int ACT>
+struct Tile {
+  static constexpr int LD = KC ? (BK + 4) : (ROWS + 4);
+  static constexpr int SIZE = KC ? ROWS * LD : BK * LD;
+  static constexpr int NV = ROWS * BK / 4 / 256;     // float4 per thread per chunk
+
+  // global -> registers.  KC: src[out0 + r][k0 + 4c];  KM: src[k0 + r][out0 + 4c]
+  __device__ static __forceinline__ unsigned load(float4 (&v)[NV], const float* __restrict__ src,
+                                                  long ld, int out0, int out_n, int k0, int k_n) {
+    unsigned ok = 0;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = threadIdx.x + 256 * i;
+      int o, k;
+      if (KC) {
+        o = out0 + (idx >> 3);                         // 8 float4 per row of 32 k
+        k = k0 + 4 * (idx & 7);
+      } else {
+        constexpr int V = ROWS / 4;                    // float4 per k row
+        k = k0 + idx / V;
+        o = out0 + 4 * (idx % V);
+      }
+      const bool valid = o < out_n && k < k_n;
+      ok |= (valid ? 1u : 0u) << i;
+      const int oc = min(o, KC ? out_n - 1 : out_n - 4), kc = min(k, KC ? k_n - 4 : k_n - 1);
+      const float* p = KC ? src + (long)oc * ld + kc : src + (long)kc * ld + oc;
+      v[i] = *reinterpret_cast<const float4*>(p);
+    }
+    return ok;
+  }
+  __device__ static __forceinline__ void store(float* __restrict__ s, const float4 (&v)[NV],
+                                               unsigned ok) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = threadIdx.x + 256 * i;
+      float4 x = v[i];
+      if (ACT != ACT_NONE)
+        x = make_float4(swoosh(x.x, ACT), swoosh(x.y, ACT), swoosh(x.z, ACT), swoosh(x.w, ACT));
+      if (!((ok >> i) & 1u)) x = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (KC) {
+        *reinterpret_cast<float4*>(s + (idx >> 3) * LD + 4 * (idx & 7)) = x;
+      } else {
+        constexpr int V = ROWS / 4;
+        *reinterpret_cast<float4*>(s + (idx / V) * LD + 4 * (idx % V)) = x;
+      }
+    }
+  }
+  // fragment of MFMA tile `t0` (32 outputs starting at out index t0) for k group s (8 k):
+  // element j = value at k = 8 s + 4 (lane >> 5) + j
+  __device__ static __forceinline__ float4 frag(const float* __restrict__ s, int t0, int sgrp,
+                                                int lane) {
+    const int o = t0 + (lane & 31), kb = 8 * sgrp + 4 * (lane >> 5);
+    if (KC) return *reinterpret_cast<const float4*>(s + o * LD + kb);
+    return make_float4(s[kb * LD + o], s[(kb + 1) * LD + o], s[(kb + 2) * LD + o],
+                       s[(kb + 3) * LD + o]);
+  }
+};
+
+template <int TM, int TN, int MODE, int PRO>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  constexpr bool A_KC = MODE != MODE_TN, B_KC = MODE == MODE_NT;
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  // the staged activation applies to A in NT (y = act(x) W^T) and to B in TN (dW = g^T act(x))
+  using TA = Tile<BM, A_KC, (MODE == MODE_NT ? PRO : ACT_NONE)>;
+  using TB = Tile<BN, B_KC, (MODE == MODE_TN ? PRO : ACT_NONE)>;
+  __shared__ __attribute__((aligned(16))) float sA[TA::SIZE];
+  __shared__ __attribute__((aligned(16))) float sB[TB::SIZE];
+
+  // XCD-aware tile order: blocks that land on one XCD (blockIdx % 8) walk a contiguous range of
+  // tiles, n fastest, so the n-tiles of one m-panel share that XCD's L2 copy of the A panel
+  const int total = g.tiles_m * g.tiles_n;
+  const int per_xcd = (total + 7) / 8;
+  // (TN grids are (tiles, 1, slices) with few tiles: taken in launch order, which already
+  // spreads consecutive blocks over the XCDs)
+  const int lin = MODE == MODE_TN ? (int)blockIdx.x
+                                  : (int)((blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3));
+  if (lin >= total) return;
+  const int tm = lin / g.tiles_n, tn = lin % g.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
+
+  int kbeg = 0, kend = g.K;
+  if (MODE == MODE_TN) {
+    kbeg = blockIdx.z * g.kper;
+    kend = min(g.K, kbeg + g.kper);
+    if (kbeg >= kend) return;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[TA::NV], rb[TB::NV];
+  unsigned oka = TA::load(ra, g.A, g.lda, m0, g.M, kbeg, kend);
+  unsigned okb = TB::load(rb, g.B, g.ldb, n0, g.N, kbeg, kend);
+  float csum = 0.f;   // TN bias gradient: thread t < BM owns column m0 + t
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    __syncthreads();                       // previous chunk fully consumed
+    TA::store(sA, ra, oka);
+    TB::store(sB, rb, okb);
+    __syncthreads();
+    if (k0 + BK < kend) {                  // next chunk's global loads fly under the MFMAs
+      oka = TA::load(ra, g.A, g.lda, m0, g.M, k0 + BK, kend);
+      okb = TB::load(rb, g.B, g.ldb, n0, g.N, k0 + BK, kend);
+    }
+    if (MODE == MODE_TN && g.colsum != nullptr && tn == 0 && threadIdx.x < BM) {
+#pragma unroll 8
+      for (int r = 0; r < BK; ++r) csum += sA[r * TA::LD + threadIdx.x];
+    }
+#pragma unroll
+    for (int s = 0; s < BK / 8; ++s) {
+      float4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = TA::frag(sA, wm + 32 * i, s, lane);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = TB::frag(sB, wn + 32 * j, s, lane);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+  if (MODE == MODE_TN && g.colsum != nullptr && tn == 0 && threadIdx.x < BM &&
+      m0 + (int)threadIdx.x < g.M)
+    atomicAdd(g.colsum + m0 + threadIdx.x, csum);
+
+  // ---- epilogue: lane holds column (lane & 31), rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  const int hi = lane >> 5, lo = lane & 31;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn + 32 * j + lo;
+      if (col >= g.N) continue;
+      const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (row >= g.M) continue;
+        float v = acc[i][j][r];
+        float* cp = g.C + (long)row * g.ldc + col;
+        if (g.debug & 1) continue;
+        if (MODE == MODE_TN) {
+          atomicAdd(cp, v);
+        } else {
+          v += bv;
+          if (g.act_src) v *= swoosh_deriv(g.act_src[(long)row * g.lds + col], g.act_kind);
+          if (g.resid) v += g.resid[(long)row * g.ldr + col];
+          if (g.accumulate) v += *cp;
+          *cp = v;
+        }
+      }
+    }
+}
+
+template <int TM, int TN, int MODE, int PRO>
+int launch(GemmArgs& g, int splits, hipStream_t st) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  g.tiles_m = (g.M + BM - 1) / BM;
+  g.tiles_n = (g.N + BN - 1) / BN;
+  { const char* e = getenv("S2T_GEMM_DEBUG"); g.debug = e ? atoi(e) : 0; }
+  const int total = g.tiles_m * g.tiles_n;
+  const int grid = MODE == MODE_TN ? total : ((total + 7) / 8) * 8;
+  hipLaunchKernelGGL((gemm_kernel<TM, TN, MODE, PRO>), dim3(grid, 1, splits), dim3(256), 0, st, g);
+  return (int)hipGetLastError();
+}
+
+template <int TM, int TN, int MODE>
+int launch_p(GemmArgs& g, int pro, int splits, hipStream_t st) {
+  if (MODE == MODE_NN || pro == ACT_NONE) return launch<TM, TN, MODE, ACT_NONE>(g, splits, st);
+  if (pro == ACT_SWOOSH_L) return launch<TM, TN, MODE, ACT_SWOOSH_L>(g, splits, st);
+  return launch<TM, TN, MODE, ACT_SWOOSH_R>(g, splits, st);
+}
+
+// tile shapes: (2,2) 128x128, (2,3) 128x192, (1,2) 64x128, (1,1) 64x64
+template <int MODE>
+int launch_t(GemmArgs& g, int tm, int tn, int pro, int splits, hipStream_t st) {
+  if (tm == 2 && tn == 3) return launch_p<2, 3, MODE>(g, pro, splits, st);
+  if (tm == 2) return launch_p<2, 2, MODE>(g, pro, splits, st);
+  if (tn >= 2) return launch_p<1, 2, MODE>(g, pro, splits, st);
+  return launch_p<1, 1, MODE>(g, pro, splits, st);
+}
+
+// columns per block: 192 when that wastes less than 128 (N = 192, 384, 576, 960 ...), else 128/64
+int pick_tn(int N) {
+  const int w128 = ((N + 127) / 128) * 128 - N, w192 = ((N + 191) / 192) * 192 - N;
+  if (N <= 64) return 1;
+  return (w192 < w128) ? 3 : 2;
+}
+
+int tn_blocks_target() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("S2T_TN_BLOCKS");
+    v = e ? atoi(e) : 512;
+  }
+  return v;
+}
+
+template <int MODE>
+int dispatch(GemmArgs& g, hipStream_t st) {
+  int tn_sel = pick_tn(g.N);
+  const int pro = MODE == MODE_NT ? g.pro_a : (MODE == MODE_TN ? g.pro_b : 0);
+  const long tiles_big = (long)((g.M + 127) / 128) * ((g.N + 64 * tn_sel - 1) / (64 * tn_sel));
+  if (MODE == MODE_TN) {
+    // output is small (features x features): split the long contraction over the chip; every
+    // slice adds its tile with fp32 atomics, so keep slices x output bytes small
+    int splits = (int)((tn_blocks_target() + tiles_big - 1) / tiles_big);
+    const int maxs = (g.K + 4 * BK - 1) / (4 * BK);
+    if (splits > maxs) splits = maxs;
+    if (splits < 1) splits = 1;
+    int kper = (g.K + splits - 1) / splits;
+    kper = ((kper + BK - 1) / BK) * BK;
+    g.kper = kper;
+    splits = (g.K + kper - 1) / kper;
+    return launch_t<MODE>(g, 2, tn_sel, pro, splits, st);
+  }
+  if (tiles_big >= 384) return launch_t<MODE>(g, 2, tn_sel, pro, 1, st);
+  if (tn_sel == 3) tn_sel = 2;
+  return launch_t<MODE>(g, 1, tn_sel, pro, 1, st);
+}
+
+}  // namespace
+
+extern "C" int s2t_gemm_f32(int mode, const float* A, long lda, const float* B, long ldb, float* C,
+                            long ldc, int M, int N, int K, const float* bias, const float* resid,
+                            long ldr, const float* act_src, long lds, int act_kind, int pro_a,
+                            int pro_b, float* colsum, int accumulate, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0) return -1;
+  // float4 staging: k-contiguous operands need K % 4 == 0 and 16-byte aligned rows; k-major
+  // operands need 16-byte aligned rows (ragged right edges are handled in the loader)
+  const bool a_kc = mode != MODE_TN, b_kc = mode == MODE_NT;
+  if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15) ||
+      (lda & 3) || (ldb & 3))
+    return -2;
+  if ((a_kc || b_kc) && (K & 3)) return -2;
+  if ((!a_kc && (M & 3)) || (!b_kc && (N & 3))) return -2;    // k-major operands: 4 outputs per load
+  if (M < 4 || N < 4 || K < 4) return -2;
+  if (act_kind < 0 || act_kind > 2 || pro_a < 0 || pro_a > 2 || pro_b < 0 || pro_b > 2) return -1;
+  if (mode == MODE_TN && (resid || act_src || bias)) return -1;
+  GemmArgs g{A, lda, B, ldb, C, ldc, M, N, K, bias, resid, ldr, act_src, lds, act_kind, pro_a,
+             pro_b, colsum, accumulate, 0, 0, 0, 0};
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (mode == MODE_NT) rc = dispatch<MODE_NT>(g, st);
+  else if (mode == MODE_NN) rc = dispatch<MODE_NN>(g, st);
+  else if (mode == MODE_TN) rc = dispatch<MODE_TN>(g, st);
+  else return -1;
+  return rc;
+}

@@ -69,39 +69,42 @@ __global__ __launch_bounds__(NT) void whiten_metric_kernel(const float* __restri
   }
 }
 
-// dcov (C,C) block diagonal = 4/(G cg) (cov/denom - covsq md/denom^2 I); bias = -mean . dcov
-__global__ __launch_bounds__(NT) void whiten_dcov_kernel(const float* __restrict__ cov,
-                                                         const float* __restrict__ mean,
-                                                         const float* __restrict__ scal, int G,
-                                                         int cg, float* __restrict__ dcov,
-                                                         float* __restrict__ bias,
-                                                         float* __restrict__ sums) {
+// dcov (C,C) block diagonal = 4/(G cg) (cov/denom - covsq md/denom^2 I); bias = -mean . dcov.
+// One workgroup per row; dcov is symmetric (cov is), so bias[ci] is the row's dot with mean.
+__global__ __launch_bounds__(256) void whiten_dcov_kernel(const float* __restrict__ cov,
+                                                          const float* __restrict__ mean,
+                                                          const float* __restrict__ scal, int G,
+                                                          int cg, float* __restrict__ dcov,
+                                                          float* __restrict__ bias,
+                                                          float* __restrict__ sums) {
+  __shared__ float s_red[4];
   const int C = G * cg;
+  const int ci = blockIdx.x;
   const float md = scal[0], covsq = scal[1], denom = scal[2];
   const float k = 4.f / (float)C;
   const float a = 1.f / denom, d = covsq * md / (denom * denom);
-  for (long e = threadIdx.x; e < (long)C * C; e += NT) {
-    const int ci = (int)(e / C), cj = (int)(e % C);
-    const int g = ci / cg;
+  const int g = ci / cg;
+  const float* crow = cov + ((long)g * cg + (ci - g * cg)) * cg;
+  float acc = 0.f;
+  for (int cj = threadIdx.x; cj < C; cj += 256) {
     float v = 0.f;
     if (cj / cg == g) {
-      v = cov[((long)g * cg + (ci - g * cg)) * cg + (cj - g * cg)] * a;
+      v = crow[cj - g * cg] * a;
       if (ci == cj) v -= d;
       v *= k;
     }
-    dcov[e] = v;
+    dcov[(long)ci * C + cj] = v;
+    acc = fmaf(mean[cj], v, acc);
   }
-  if (threadIdx.x < 2) sums[threadIdx.x] = 0.f;
-  __threadfence_block();
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  for (int cj = threadIdx.x; cj < C; cj += NT) {
-    const int g = cj / cg;
-    float acc = 0.f;
-    for (int i = 0; i < cg; ++i) {
-      const int ci = g * cg + i;
-      acc = fmaf(mean[ci], dcov[(long)ci * C + cj], acc);
+  if (threadIdx.x == 0) {
+    bias[ci] = -((s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
+    if (ci == 0) {
+      sums[0] = 0.f;
+      sums[1] = 0.f;
     }
-    bias[cj] = -acc;
   }
 }
 
@@ -184,8 +187,8 @@ extern "C" int s2t_whiten_metric(const float* xtx, const float* colsum, long n, 
 extern "C" int s2t_whiten_dcov(const float* cov, const float* mean, const float* scal, int G,
                                int cg, float* dcov, float* bias, float* sums, void* stream) {
   if (G <= 0 || cg <= 0) return -1;
-  hipLaunchKernelGGL(whiten_dcov_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, cov, mean,
-                     scal, G, cg, dcov, bias, sums);
+  hipLaunchKernelGGL(whiten_dcov_kernel, dim3(G * cg), dim3(256), 0, (hipStream_t)stream, cov,
+                     mean, scal, G, cg, dcov, bias, sums);
   S2T_CHECK_LAUNCH();
   return 0;
 }

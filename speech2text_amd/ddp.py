@@ -3,15 +3,22 @@
 Replaces the implicit torch-DDP that Lightning sets up for the reference
 (build_task.py:143-148, YAML `strategy: ddp_find_unused_parameters_true`).  One process per
 GPU; gradients live in one flat buffer (speech2text_amd.flat.FlatStore) cut into contiguous
-buckets in reverse parameter order.  A bucket is all-reduced in place on a side HIP stream as
-soon as autograd has produced its last gradient, overlapping the rest of backward; parameters
-that never receive a gradient (e.g. Zipformer2EncoderLayer.bypass_scale, reference
+buckets in reverse parameter order.  A bucket is reduced in place on a side HIP stream as soon
+as autograd has produced its last gradient, overlapping the rest of backward; buckets are
+launched strictly in bucket order so every rank issues the same sequence of collectives.
+Parameters that never receive a gradient (e.g. Zipformer2EncoderLayer.bypass_scale, reference
 zipformer.py:1011-1012) keep their pre-zeroed gradient and are learned as "static unused"
 after the first step, which is what find_unused_parameters achieves by graph traversal.
+
+Two forms of the exchange (`algo`):
+  "allreduce"  one in-place all-reduce(SUM) per bucket, then a divide over the whole bucket;
+  "rs_ag"      reduce-scatter into a 1/world shard, divide the shard, all-gather back -- the form
+               SURVEY.md section 5 prices for the 7-link xGMI mesh (each GPU owns 1/8 of a bucket).
 xGMI is point-to-point (7 links per GPU): buckets are sized (default 32 MiB) so that each
 collective is bandwidth- rather than latency-bound and few collectives are in flight.
 """
 import contextlib
+import os
 from typing import List, Optional
 
 import torch
@@ -20,11 +27,15 @@ import torch.distributed as dist
 
 class GradReducer:
     def __init__(self, store, bucket_bytes: int = 32 << 20, process_group=None,
-                 algo: str = "allreduce"):
+                 algo: Optional[str] = None, overlap: Optional[bool] = None):
         self.store = store
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        self.algo = algo
+        self.algo = algo or os.environ.get("S2T_DDP_ALGO", "allreduce")
+        if self.algo not in ("allreduce", "rs_ag"):
+            raise ValueError(f"unknown gradient-exchange algo {self.algo!r}")
+        self.overlap = (os.environ.get("S2T_DDP_OVERLAP", "1") != "0") if overlap is None \
+            else bool(overlap)
         self.require_sync = True
         self._is_cuda = store.flat_g.is_cuda
         self._stream = torch.cuda.Stream() if self._is_cuda else None
@@ -33,7 +44,7 @@ class GradReducer:
         cap = max(1, bucket_bytes // 4)
         self.buckets: List[List[int]] = []          # [start, end) element ranges
         self.param_bucket = [0] * n
-        end = store.numel
+        end = store.total                            # the tail padding rides in bucket 0
         i = n - 1
         while i >= 0:
             start = end
@@ -52,53 +63,80 @@ class GradReducer:
             i = j
         self.bucket_members = [[q for q in range(n) if self.param_bucket[q] == b]
                                for b in range(len(self.buckets))]
+        self._shards = {}
         self._expected = None                        # params that produce grads (learned)
         self._pending = None
-        self._fired = set()
-        self._launched = [False] * len(self.buckets)
-        self._works = []
+        self._fired = {}
+        self._next = 0                               # next bucket to launch (fixed order)
         self._hooks = []
         if self.world > 1:
+            store.on_grad = self._grad_ready
             for q, p in enumerate(store.params):
                 if p.requires_grad:
                     self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(q)))
 
     # ------------------------------------------------------------------
     def _make_hook(self, q):
-        def hook(_p):
-            if not self.require_sync:
-                return
-            self._fired.add(q)
-            if self._pending is None:
-                return
-            b = self.param_bucket[q]
-            if q in self._expected:
-                self._pending[b] -= 1
-                if self._pending[b] == 0 and not self._launched[b]:
-                    self._launch(b)
-        return hook
+        return lambda _p: self._grad_ready(q)
+
+    def _grad_ready(self, q):
+        """One gradient contribution of parameter q is complete: called by autograd's
+        post-accumulate hook (once per backward), or once per use by kernels that accumulate
+        into the flat buffer themselves (FlatStore.on_grad).  The number of calls per parameter
+        and step is learned in the first synchronised step."""
+        if not self.require_sync:
+            return
+        self._fired[q] = self._fired.get(q, 0) + 1
+        if self._pending is None:
+            return
+        b = self.param_bucket[q]
+        if b < self._next:
+            raise RuntimeError(
+                f"parameter #{q} produced a gradient after its bucket {b} was reduced (the "
+                "set of parameters that receive gradients changed between steps); use "
+                "GradReducer(overlap=False) / S2T_DDP_OVERLAP=0 for such models")
+        if q in self._expected:
+            self._pending[b] -= 1
+            while self._next < len(self.buckets) and self._pending[self._next] == 0:
+                self._launch(self._next)
+
+    def _shard(self, b, n):
+        sh = self._shards.get(b)
+        if sh is None or sh.numel() != n:
+            sh = torch.empty(n, dtype=self.store.flat_g.dtype, device=self.store.flat_g.device)
+            self._shards[b] = sh
+        return sh
+
+    def _exchange(self, buf, b):
+        """In-place mean over ranks of `buf` (enqueued on the side stream when on the GPU)."""
+        w = self.world
+        if self.algo == "rs_ag" and buf.numel() % w == 0 and buf.numel() >= w:
+            sh = self._shard(b, buf.numel() // w)
+            dist.reduce_scatter_tensor(sh, buf, op=dist.ReduceOp.SUM, group=self.pg)
+            sh.div_(w)
+            dist.all_gather_into_tensor(buf, sh, group=self.pg)
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg)
+            buf.div_(w)
 
     def _launch(self, b):
+        assert b == self._next
         s, e = self.buckets[b]
         buf = self.store.flat_g[s:e]
-        self._launched[b] = True
-        self.store.gather(self.bucket_members[b])
+        self._next = b + 1
         if self._is_cuda:
             self._stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._stream):
-                w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-                self._works.append((w, buf))
+                self._exchange(buf, b)
         else:
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg)
-            buf.div_(self.world)
+            self._exchange(buf, b)
 
     def prepare(self):
         """Call before backward of a micro-step whose gradients must be synchronised."""
-        self._fired = set()
-        self._launched = [False] * len(self.buckets)
-        self._works = []
-        if self._expected is not None:
-            self._pending = [sum(1 for q in m if q in self._expected)
+        self._fired = {}
+        self._next = 0
+        if self._expected is not None and self.overlap:
+            self._pending = [sum(self._expected.get(q, 0) for q in m)
                              for m in self.bucket_members]
         else:
             self._pending = None
@@ -107,27 +145,22 @@ class GradReducer:
         """After backward: reduce whatever was not launched by the hooks, wait, average.
         `extra` (1-D tensor of logged scalars) is mean-reduced along with the gradients."""
         if self.world == 1:
-            self.store.gather()
             return extra
-        for b in range(len(self.buckets)):
-            if not self._launched[b]:
-                self._launch(b)
+        while self._next < len(self.buckets):
+            self._launch(self._next)
         if self._is_cuda:
             main = torch.cuda.current_stream()
             with torch.cuda.stream(self._stream):
-                for w, buf in self._works:
-                    w.wait()
-                    buf.div_(self.world)
                 if extra is not None:
-                    self._stream.wait_stream(main)          # `extra` was produced on the main stream
+                    self._stream.wait_stream(main)      # `extra` was produced on the main stream
                     dist.all_reduce(extra, op=dist.ReduceOp.SUM, group=self.pg)
                     extra.div_(self.world)
-            torch.cuda.current_stream().wait_stream(self._stream)
+            main.wait_stream(self._stream)
         elif extra is not None:
             dist.all_reduce(extra, op=dist.ReduceOp.SUM, group=self.pg)
             extra.div_(self.world)
         if self._expected is None or self._fired != self._expected:
-            self._expected = set(self._fired)
+            self._expected = dict(self._fired)
         return extra
 
     @contextlib.contextmanager

@@ -1,20 +1,27 @@
-"""ScaledAdam on flat buffers.
+"""ScaledAdam on a flat buffer.
 
 Same update rule, hyper-parameters and defaults as the reference's
 optimizer/scaled_adam.py:112-736 (per-tensor RMS-scaled Adam step, learned tensor scale
 every `size_update_period` steps, median-based gradient clipping, scalar rule for 1-element
-tensors).  The reference stacks same-shaped tensors into batches every step (:30-109); here
-each param group lives in one flat buffer (speech2text_amd.flat.FlatStore) and per-tensor
-statistics are segmented reductions, so a step is ~25 launches regardless of tensor count
-and never synchronises with the host except when the clipping threshold is re-estimated.
+tensors).  The reference stacks same-shaped tensors into batches every step (:30-109) and runs
+~20 torch ops per batch; here all parameters live in one flat buffer
+(speech2text_amd.flat.FlatStore, param groups = contiguous tensor ranges) and a step is three
+HIP launches (csrc/optim.hip): per-chunk sums, one coefficient workgroup per param group, one
+fused update that also applies the trainer's grad-norm clip and zeroes the gradients.  The host
+never waits for the device except when the clipping threshold is re-estimated (every
+`clipping_update_period` steps), to raise on a non-finite median as the reference does.
+
+CPU tensors (host-logic tests only) run the same arithmetic as torch ops on the same buffers.
 """
 import torch
 from torch.optim import Optimizer
 
-from speech2text_amd.flat import get_store
+from speech2text_amd.flat import FlatStore, store_of
 
 
 class ScaledAdam(Optimizer):
+    fused_clip = True      # the trainer hands gradient_clip_val to `pre_clip` instead of clipping
+
     def __init__(self, params, lr=3e-02, clipping_scale=None, betas=(0.9, 0.98),
                  scalar_lr_scale=0.1, eps=1.0e-08, param_min_rms=1.0e-05, param_max_rms=3.0,
                  scalar_max=10.0, size_update_period=4, clipping_update_period=100):
@@ -33,132 +40,201 @@ class ScaledAdam(Optimizer):
                         size_update_period=size_update_period,
                         clipping_update_period=clipping_update_period)
         super().__init__(params, defaults)
-        self._gstate = [None] * len(self.param_groups)
+        self._gstate = None
+        self.store = None
+        self.pre_clip = None          # trainer's gradient_clip_val (norm), applied inside step()
+        self.zero_grad_in_step = False
+        self.last_clip = None
 
-    # ------------------------------------------------------------------
-    def _init_group(self, gi, group):
-        ps = [p for p in group["params"] if p.requires_grad]
-        st = get_store(ps)
+    # ------------------------------------------------------------------ state
+    def _init(self):
+        groups = [[p for p in g["params"] if p.requires_grad] for g in self.param_groups]
+        allp = [p for ps in groups for p in ps]
+        st = store_of(allp)
+        if st is None:
+            st = FlatStore(allp)
+        self.store = st
         dev = st.flat_p.device
-        n = len(st.lengths)
-        P = group["size_update_period"]
-        lens = st.seg_lengths.to(torch.float32)
-        s = dict(store=st, step=0, lens=lens, scalar=(st.seg_lengths == 1),
-                 has_scalar=any(n == 1 for n in st.lengths),
-                 delta=torch.zeros(st.numel, device=dev),
-                 exp_avg_sq=torch.zeros(st.numel, device=dev),
-                 scale_exp_avg_sq=torch.zeros(n, device=dev),
-                 scale_grads=torch.zeros(P, n, device=dev),
-                 model_norms=torch.zeros(group["clipping_update_period"], device=dev),
-                 threshold=None, num_clipped=torch.zeros((), device=dev))
-        p = st.p()
-        s["param_rms"] = (st.seg_sum(p * p) / lens).sqrt()
-        self._gstate[gi] = s
-        return s
+        self._delta = torch.zeros_like(st.flat_p)
+        self._eas = torch.zeros_like(st.flat_p)
+        tb = st.tables()
+        self._partial = torch.zeros(tb["nchunks"] * 3, device=dev)
+        self._segstat = torch.zeros(tb["nseg"] * 3, device=dev)
+        self._segc = None
+        self._gstate = []
+        for ps, group in zip(groups, self.param_groups):
+            lo, hi = st.range_of(ps)
+            n = hi - lo
+            P = group["size_update_period"]
+            lens = st.seg_lengths[lo:hi].to(torch.float32)
+            f_lo, f_hi = st.offsets[lo], (st.offsets[hi] if hi < len(st.offsets) else st.numel)
+            s = dict(lo=lo, hi=hi, f_lo=f_lo, f_hi=f_hi, step=0, lens=lens,
+                     scale_exp_avg_sq=torch.zeros(n, device=dev),
+                     scale_grads=torch.zeros(P, n, device=dev),
+                     model_norms=torch.zeros(group["clipping_update_period"], device=dev),
+                     fstate=torch.zeros(3, device=dev),
+                     istate=torch.zeros(3, dtype=torch.int32, device=dev))
+            # segment ids of the group's flat range (padding belongs to the tensor it follows)
+            padded = [(st.offsets[i + 1] if i + 1 < len(st.offsets) else st.numel) - st.offsets[i]
+                      for i in range(lo, hi)]
+            s["padded"] = torch.tensor(padded, device=dev)
+            s["seg"] = torch.repeat_interleave(torch.arange(n, device=dev), s["padded"])
+            p = st.flat_p[f_lo:f_hi]
+            s["param_rms"] = (self._seg_sum(s, p * p) / lens).sqrt()
+            self._gstate.append(s)
 
+    @staticmethod
+    def _seg_sum(s, x):
+        # segment_reduce is deterministic (index_add_ uses atomics on the GPU: replicas of a
+        # data-parallel job would drift apart in the last bit)
+        return torch.segment_reduce(x, "sum", lengths=s["padded"], unsafe=True)
+
+    # ------------------------------------------------------------------ step
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        for gi, group in enumerate(self.param_groups):
-            s = self._gstate[gi] or self._init_group(gi, group)
-            self._step_group(group, s)
+        if self._gstate is None:
+            self._init()
+        st = self.store
+        st.check_views()
+        if st.flat_p.is_cuda:
+            self._step_hip()
+        else:
+            self._step_torch()
         return loss
 
-    def _clip(self, group, s, g, gsq_seg):
-        cs = group["clipping_scale"]
+    def _host_scalars(self, group, s):
         k = s["step"]
-        if cs is None or k == 0:
-            return
-        period = group["clipping_update_period"]
-        slr = group["scalar_lr_scale"]
-        w = torch.where(s["scalar"], torch.full_like(s["param_rms"], slr * slr),
-                        s["param_rms"] * s["param_rms"])
-        tot_norm = (gsq_seg * w).sum().sqrt()
-        s["model_norms"][k % period] = tot_norm
-        irregular = [i for i in (10, 20, 40) if i < period]
-        if k % period == 0 or k in irregular:
-            sorted_norms = s["model_norms"].sort()[0]
-            if k in irregular:
-                sorted_norms = sorted_norms[-k:]
-            num = sorted_norms.numel()
-            median = sorted_norms[min(num - 1, (num // 4) * 2)]
-            if not bool(torch.isfinite(median)):          # rare, host sync only here
-                raise RuntimeError("Too many grads were not finite")
-            thr = cs * median
-            if k in irregular:
-                thr = thr * 2.0
-            s["threshold"] = thr
-            s["num_clipped"].zero_()
-        if s["threshold"] is None:
-            return
-        ans = torch.clamp(s["threshold"] / (tot_norm + 1.0e-20), max=1.0)
-        ans = torch.nan_to_num(ans, nan=0.0)
-        s["num_clipped"] += (ans < 1.0)
-        g.mul_(ans)
-        # reference zeroes the grads when the factor is 0 (inf/nan grads): 0 * inf = nan
-        torch.nan_to_num_(g, nan=0.0, posinf=0.0, neginf=0.0)
-
-    def _step_group(self, group, s):
-        st = s["store"]
-        st.check_views()
-        p, g = st.p(), st.g()
-        k = s["step"]
-        lr = group["lr"]
         beta1, beta2 = group["betas"]
-        eps = group["eps"]
         P = group["size_update_period"]
-        slr = group["scalar_lr_scale"]
-        seg = st.seg_ids
-        scalar = s["scalar"]
-        delta, eas = s["delta"], s["exp_avg_sq"]
-        gsq = g * g
-        self._clip(group, s, g, st.seg_sum(gsq))
-        if group["clipping_scale"] is not None and k > 0 and s["threshold"] is not None:
-            gsq = g * g
-        delta.mul_(beta1)
-        # ---- learned tensor scale (non-scalar tensors)
-        s["scale_grads"][k % P] = st.seg_sum(p * g)
-        if k % P == P - 1:
-            s["param_rms"] = (st.seg_sum(p * p) / s["lens"]).sqrt()
-            if k > 0:
-                rms = s["param_rms"]
-                beta2c = beta2 ** P
-                sg = s["scale_grads"]
-                s["scale_exp_avg_sq"].mul_(beta2c).add_((sg * sg).mean(dim=0), alpha=1 - beta2c)
-                size_step = (k + 1) // P
-                bc2 = 1 - beta2c ** size_step
-                denom = s["scale_exp_avg_sq"].sqrt() + eps
-                scale_step = -(lr * slr) * (bc2 ** 0.5) * sg.sum(dim=0) / denom
-                scale_step = scale_step.masked_fill(rms < group["param_min_rms"], 0.0)
-                scale_step = torch.minimum(scale_step, (group["param_max_rms"] - rms) / rms)
-                scale_step = scale_step.masked_fill(scalar, 0.0)
-                delta.add_(p * scale_step[seg], alpha=(1 - beta1))
-        # ---- Adam-like step, scaled by the tensor rms (or the scalar rule)
-        eas.mul_(beta2).add_(gsq, alpha=1 - beta2)
-        bc2 = 1 - beta2 ** (k + 1)
-        bc_vec = torch.where(scalar, torch.full_like(s["lens"], bc2),
-                             torch.full_like(s["lens"], bc2 if bc2 < 0.99 else 1.0))
-        coef = torch.where(scalar, torch.full_like(s["lens"], -lr * slr * (1 - beta1)),
-                           -lr * (1 - beta1) * s["param_rms"].clamp(min=group["param_min_rms"]))
-        denom = (eas / bc_vec[seg]).sqrt_().add_(eps)
-        delta.add_(g / denom * coef[seg])
-        # scalar parameters are clamped before the update, as in the reference
-        if s["has_scalar"]:
-            lim = torch.where(scalar, torch.full_like(s["lens"], group["scalar_max"]),
-                              torch.full_like(s["lens"], float("inf")))[seg]
-            torch.minimum(p, lim, out=p)
-            torch.maximum(p, -lim, out=p)
-        p.add_(delta)
-        s["step"] = k + 1
+        beta2c = beta2 ** P
+        return dict(k=k, beta1=beta1, beta2=beta2, P=P, beta2c=beta2c, bc2=1 - beta2 ** (k + 1),
+                    bc2_size=1 - beta2c ** ((k + 1) // P))
+
+    def _step_hip(self):
+        from speech2text_amd import _native as N
+        st = self.store
+        tb = st.tables()
+        L = N.lib()
+        stream = N.stream()
+        if self._segc is None:
+            self._segc = torch.zeros(tb["nseg"] * L.s2t_optim_segc_floats(), device=st.flat_p.device)
+            assert L.s2t_optim_chunk_elems() == 8192
+        nbytes = 4.0 * st.numel
+        N.profile_note("s2t_seg_stats", 2 * nbytes)
+        N.check(L.s2t_seg_stats(N.fp(st.flat_p), N.fp(st.flat_g), N.ip(tb["chunk_off"]),
+                                N.ip(tb["chunk_len"]), tb["nchunks"], N.fp(self._partial), stream),
+                "s2t_seg_stats")
+        rare = []
+        for group, s in zip(self.param_groups, self._gstate):
+            h = self._host_scalars(group, s)
+            k = h["k"]
+            cs = group["clipping_scale"]
+            period = group["clipping_update_period"]
+            N.check(L.s2t_scaled_adam_coef(
+                N.fp(self._partial), N.ip(tb["seg_chunk_begin"]), N.ip(tb["seg_len"]),
+                tb["nchunks"], s["lo"], s["hi"], float(group["lr"]), h["beta1"], h["beta2"],
+                float(group["eps"]), float(group["scalar_lr_scale"]), float(group["param_min_rms"]),
+                float(group["param_max_rms"]), float(group["scalar_max"]),
+                float(self.pre_clip or 0.0), float(cs or 0.0), k, h["P"], period, h["bc2"],
+                h["bc2_size"], h["beta2c"], N.fp(s["param_rms"]), N.fp(s["scale_exp_avg_sq"]),
+                N.fp(s["scale_grads"]), N.fp(s["model_norms"]), N.fp(s["fstate"]),
+                N.ip(s["istate"]), N.fp(self._segstat), N.fp(self._segc), stream),
+                "s2t_scaled_adam_coef")
+            if cs is not None and k > 0 and (k % period == 0 or (k in (10, 20, 40) and k < period)):
+                rare.append(s)
+            s["step"] = k + 1
+        N.profile_note("s2t_scaled_adam_apply", 8 * nbytes)
+        N.check(L.s2t_scaled_adam_apply(N.fp(st.flat_p), N.fp(st.flat_g), N.fp(self._delta),
+                                        N.fp(self._eas), N.ip(tb["chunk_off"]),
+                                        N.ip(tb["chunk_len"]), N.ip(tb["chunk_seg"]), tb["nchunks"],
+                                        N.fp(self._segc), int(self.zero_grad_in_step), stream),
+                "s2t_scaled_adam_apply")
+        for s in rare:                                   # the only host sync (every `period` steps)
+            if int(s["istate"][2]) != 0:
+                raise RuntimeError("Too many grads were not finite")
+
+    # ---- the same arithmetic as torch ops (CPU tensors: host-logic tests)
+    def _step_torch(self):
+        st = self.store
+        c = None
+        if self.pre_clip:
+            c = torch.clamp(self.pre_clip / (st.g().norm() + 1.0e-6), max=1.0)
+        for group, s in zip(self.param_groups, self._gstate):
+            h = self._host_scalars(group, s)
+            k, beta1, beta2, P = h["k"], h["beta1"], h["beta2"], h["P"]
+            p = st.flat_p[s["f_lo"]:s["f_hi"]]
+            g = st.flat_g[s["f_lo"]:s["f_hi"]]
+            delta = self._delta[s["f_lo"]:s["f_hi"]]
+            eas = self._eas[s["f_lo"]:s["f_hi"]]
+            seg, lens = s["seg"], s["lens"]
+            scalar = lens == 1
+            lr, slr, eps = group["lr"], group["scalar_lr_scale"], group["eps"]
+            if c is not None:
+                g.mul_(c)
+            cs, period = group["clipping_scale"], group["clipping_update_period"]
+            if cs is not None and k > 0:
+                gsq_seg = self._seg_sum(s, g * g)
+                w = torch.where(scalar, torch.full_like(lens, slr * slr),
+                                s["param_rms"] * s["param_rms"])
+                tot_norm = (gsq_seg * w).sum().sqrt()
+                s["model_norms"][k % period] = tot_norm
+                irregular = k in (10, 20, 40) and k < period
+                if k % period == 0 or irregular:
+                    sorted_norms = s["model_norms"].sort()[0]
+                    if irregular:
+                        sorted_norms = sorted_norms[-k:]
+                    num = sorted_norms.numel()
+                    median = sorted_norms[min(num - 1, (num // 4) * 2)]
+                    if not bool(torch.isfinite(median)):
+                        raise RuntimeError("Too many grads were not finite")
+                    s["fstate"][0] = cs * median * (2.0 if irregular else 1.0)
+                    s["istate"][0] = 1
+                    s["istate"][1] = 0
+                if int(s["istate"][0]):
+                    ans = torch.nan_to_num(torch.clamp(s["fstate"][0] / (tot_norm + 1.0e-20),
+                                                       max=1.0), nan=0.0)
+                    s["istate"][1] += int(ans < 1.0)
+                    g.mul_(ans)
+                    torch.nan_to_num_(g, nan=0.0, posinf=0.0, neginf=0.0)
+            delta.mul_(beta1)
+            s["scale_grads"][k % P] = self._seg_sum(s, p * g)
+            if k % P == P - 1:
+                s["param_rms"] = (self._seg_sum(s, p * p) / lens).sqrt()
+                if k > 0:
+                    rms = s["param_rms"]
+                    sg = s["scale_grads"]
+                    s["scale_exp_avg_sq"].mul_(h["beta2c"]).add_((sg * sg).mean(dim=0),
+                                                                 alpha=1 - h["beta2c"])
+                    denom = s["scale_exp_avg_sq"].sqrt() + eps
+                    scale_step = -(lr * slr) * (h["bc2_size"] ** 0.5) * sg.sum(dim=0) / denom
+                    scale_step = scale_step.masked_fill(rms < group["param_min_rms"], 0.0)
+                    scale_step = torch.minimum(scale_step, (group["param_max_rms"] - rms) / rms)
+                    scale_step = scale_step.masked_fill(scalar, 0.0)
+                    delta.add_(p * scale_step[seg], alpha=(1 - beta1))
+            eas.mul_(beta2).add_(g * g, alpha=1 - beta2)
+            bc2 = h["bc2"]
+            bc_vec = torch.where(scalar, torch.full_like(lens, bc2),
+                                 torch.full_like(lens, bc2 if bc2 < 0.99 else 1.0))
+            coef = torch.where(scalar, torch.full_like(lens, -lr * slr * (1 - beta1)),
+                               -lr * (1 - beta1) * s["param_rms"].clamp(min=group["param_min_rms"]))
+            denom = (eas / bc_vec[seg]).sqrt_().add_(eps)
+            delta.add_(g / denom * coef[seg])
+            if bool(scalar.any()):
+                lim = torch.where(scalar, torch.full_like(lens, group["scalar_max"]),
+                                  torch.full_like(lens, float("inf")))[seg]
+                torch.minimum(p, lim, out=p)
+                torch.maximum(p, -lim, out=p)
+            p.add_(delta)
+            s["step"] = k + 1
+        if self.zero_grad_in_step:
+            st.zero_grad()
 
     def zero_grad(self, set_to_none: bool = False):
-        done = False
-        for s in self._gstate:
-            if s is not None:
-                s["store"].zero_grad()
-                done = True
-        if not done:
+        if self.store is not None:
+            self.store.zero_grad()
+        else:
             super().zero_grad(set_to_none=False)

@@ -12,6 +12,15 @@ class CtcTask(TaskBase):
         self._decoder = Decoder(config["decoder"])
         self._loss = Loss(config["loss"])
 
+    def _optimizer_params(self):
+        """reference ctc_task.py:201-213: encoder / decoder groups under seperate_lr."""
+        sep = self._optim_config["seperate_lr"]
+        if sep["apply"]:
+            c = sep["config"]
+            return [{"params": self._encoder.parameters(), "name": "encoder_lr", "lr": c["encoder_lr"]},
+                    {"params": self._decoder.parameters(), "name": "decoder_lr", "lr": c["decoder_lr"]}]
+        return self.parameters()
+
     def training_step(self, batch, batch_idx):
         feat, feat_len = self.features(batch)
         enc, enc_len = self._encoder(feat, feat_len)

@@ -92,6 +92,15 @@ class PrunedRnntTask(BaseRnntTask):
             self._ctc_loss = Loss({"model": "CTC", "config": {**self._loss_config["ctc_config"]}})
             self._ctc_projector = Decoder(config["ctc_projector"])
 
+    def _optimizer_params(self):
+        """reference rnnt_task.py:596-630: the CTC head is a fifth group when enable_ctc."""
+        params = super()._optimizer_params()
+        sep = self._optim_config["seperate_lr"]
+        if sep["apply"] and self._enable_ctc:
+            params.append({"params": self._ctc_projector.parameters(), "name": "ctc_projector_lr",
+                           "lr": sep["config"]["ctc_projector_lr"]})
+        return params
+
     def training_step(self, batch, batch_idx):
         feat, feat_len = self.features(batch)
         enc, enc_len = self._encoder(feat, feat_len)

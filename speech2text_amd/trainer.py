@@ -49,9 +49,24 @@ class Trainer:
         opt = task.configure_optimizers()
         self.optimizer = opt["optimizer"]
         self.scheduler = opt["lr_scheduler"]["scheduler"]
-        params = [p for p in task.parameters() if p.requires_grad]
-        # parked-gradient mode is opt-in: measured slower than in-place accumulation so far
-        self.store = get_store(params, steal=os.environ.get("S2T_STEAL_GRADS", "0") == "1")
+        # ONE flat store per model, ordered by optimizer param group (so that each group is a
+        # contiguous tensor range), then whatever trainable parameter no group lists
+        seen, params = set(), []
+        for group in self.optimizer.param_groups:
+            for p in group["params"]:
+                if p.requires_grad and id(p) not in seen:
+                    seen.add(id(p))
+                    params.append(p)
+        for p in task.parameters():
+            if p.requires_grad and id(p) not in seen:
+                seen.add(id(p))
+                params.append(p)
+        self.store = get_store(params)
+        self.fused = bool(getattr(self.optimizer, "fused_clip", False))
+        if self.fused:
+            if self.clip_val and self.clip_algo != "value":
+                self.optimizer.pre_clip = float(self.clip_val)
+            self.optimizer.zero_grad_in_step = True
         broadcast_parameters(self.store)
         self.reducer = GradReducer(self.store, self.bucket_bytes)
         return self
@@ -63,6 +78,8 @@ class Trainer:
         if self.clip_algo == "value":
             g.clamp_(-self.clip_val, self.clip_val)
             return
+        if self.fused:
+            return                                      # applied inside the optimizer's kernels
         norm = g.norm()
         g.mul_(torch.clamp(self.clip_val / (norm + 1.0e-6), max=1.0))
 
@@ -79,7 +96,6 @@ class Trainer:
             with self.reducer.no_sync():
                 loss = task.training_step(batch, batch_idx)
                 (loss / self.accum).backward()
-            self.store.gather()
         self.micro += 1
         if last:
             logged = None
@@ -93,7 +109,8 @@ class Trainer:
             self._clip()
             self.optimizer.step()
             self.scheduler.step()
-            self.store.zero_grad()
+            if not self.fused:
+                self.store.zero_grad()
             task.global_step += 1
         return loss.detach()
 

@@ -10,6 +10,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _native as N
+from . import flat
 
 _SW = {True: (4.0, 0.035), False: (1.0, 0.313261687)}   # SwooshL / SwooshR (offset, constant)
 
@@ -70,14 +71,16 @@ def swoosh(x, is_l):
 
 
 class _SwooshLinear(torch.autograd.Function):
-    """y = linear(swoosh(x) [* mask], W, b); only x is saved (activation recomputed), GEMMs
-    are plain rocBLAS/hipBLASLt calls."""
+    """y = linear(swoosh(x) [* mask], W, b); only x is saved (reference scaling.py:1512-1583).
+    Backward: the weight / bias gradients come from the TN MFMA GEMM with the swoosh applied to
+    x while it is staged (no recomputed activation tensor) and are accumulated straight into
+    the flat gradient buffer."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, is_l, mask):
         ctx.save_for_backward(x, weight, mask)
         ctx.is_l = is_l
-        ctx.has_bias = bias is not None
+        ctx.params = (weight, bias)
         h = swoosh_forward(x, is_l)
         if mask is not None:
             h = h * mask
@@ -86,11 +89,16 @@ class _SwooshLinear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, weight, mask = ctx.saved_tensors
-        h = swoosh_forward(x, ctx.is_l)
-        if mask is not None:
-            h = h * mask
+        wp, bp = ctx.params
         g2 = g.reshape(-1, g.shape[-1])
-        dw, db = linear_wgrad(g2, h.reshape(-1, h.shape[-1]), ctx.has_bias)
+        x2 = x.reshape(-1, x.shape[-1])
+        if mask is None and wgrad_into(wp, bp, g2, x2, pro=1 if ctx.is_l else 2):
+            dw = db = None
+        else:
+            h = swoosh_forward(x, ctx.is_l)
+            if mask is not None:
+                h = h * mask
+            dw, db = linear_wgrad(g2, h.reshape(-1, h.shape[-1]), bp is not None)
         dh = g.matmul(weight)
         dx = swoosh_backward(x, dh, ctx.is_l, mask)
         return dx, dw, db, None, None
@@ -640,21 +648,63 @@ def linear_wgrad(g2, a2, want_bias):
 WGRAD_MAX_TILES = 64   # measured crossover against hipBLASLt (tools/bench_kernels.py wgrad)
 
 
+def _tn_ok(t):
+    return (t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 4 == 0
+            and t.shape[1] % 4 == 0 and t.shape[0] >= 4 and t.data_ptr() % 16 == 0)
+
+
+def gemm_tn(g2, a2, out, colsum=None, pro=0):
+    """out (N,M) += g2^T act(a2); colsum (N) += column sums of g2.   HIP: gemm.hip mode TN."""
+    R, Nf = g2.shape
+    Mf = a2.shape[1]
+    N.profile_note("s2t_gemm_f32", 4.0 * (g2.numel() + a2.numel() + out.numel()),
+                   2.0 * R * Nf * Mf)
+    N.check(N.lib().s2t_gemm_f32(2, N.raw(g2, torch.float32), g2.stride(0),
+                                 N.raw(a2, torch.float32), a2.stride(0), N.fp(out), out.stride(0),
+                                 Nf, Mf, R, None, None, 0, None, 0, 0, 0, int(pro),
+                                 N.fp(colsum), 0, N.stream()), "s2t_gemm_f32(TN)")
+
+
+def wgrad_into(wparam, bparam, g2, a2, pro=0):
+    """Accumulates dW = g2^T act(a2) (and db) DIRECTLY into wparam.grad / bparam.grad when those
+    are the flat-store views (speech2text_amd.flat): one launch, no temporary, no autograd
+    accumulate kernel.  Returns False when that is not possible (the caller then returns the
+    gradients as tensors)."""
+    wg = wparam.grad
+    if wg is None or not wg.is_contiguous() or wg.dim() != 2 or not (_tn_ok(g2) and _tn_ok(a2)):
+        return False
+    bg = None
+    if bparam is not None:
+        bg = bparam.grad
+        if bg is None or not bg.is_contiguous():
+            return False
+    gemm_tn(g2, a2, wg, bg, pro)
+    flat.grad_written(wparam)
+    if bparam is not None:
+        flat.grad_written(bparam)
+    return True
+
+
 class _Linear(torch.autograd.Function):
-    """F.linear whose weight and bias gradients come from one pass over (g, x)."""
+    """F.linear whose weight and bias gradients come from one pass over (g, x), accumulated
+    in place into the flat gradient buffer when the parameters live in one."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
-        ctx.has_bias = bias is not None
+        ctx.params = (weight, bias)
         return F.linear(x, weight, bias)
 
     @staticmethod
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
+        wp, bp = ctx.params
         g2 = g.reshape(-1, g.shape[-1])
+        x2 = x.reshape(-1, x.shape[-1])
         dx = g.matmul(weight) if ctx.needs_input_grad[0] else None
-        dw, db = linear_wgrad(g2, x.reshape(-1, x.shape[-1]), ctx.has_bias)
+        if wgrad_into(wp, bp, g2, x2):
+            return dx, None, None
+        dw, db = linear_wgrad(g2, x2, bp is not None)
         return dx, dw, db
 
 
@@ -679,26 +729,8 @@ def _wgrad_splitk(a, g, chunk=16384):
     return main
 
 
-class _LinearBigM(torch.autograd.Function):
-    """F.linear for (rows >> features) activations with a split-K weight gradient."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
-        ctx.has_bias = bias is not None
-        return F.linear(x, weight, bias)
-
-    @staticmethod
-    def backward(ctx, g):
-        x, weight = ctx.saved_tensors
-        g2 = g.reshape(-1, g.shape[-1])
-        dx = g.matmul(weight) if ctx.needs_input_grad[0] else None
-        dw, db = linear_wgrad(g2, x.reshape(-1, x.shape[-1]), ctx.has_bias)
-        return dx, dw, db
-
-
 def linear_big_m(x, weight, bias):
-    return _LinearBigM.apply(x, weight, bias)
+    return _Linear.apply(x, weight, bias)
 
 
 class _Conv3x3Nhwc(torch.autograd.Function):

@@ -16,7 +16,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q, steal):
+def _worker(rank, world, port, q, algo):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -27,9 +27,9 @@ def _worker(rank, world, port, q, steal):
                               torch.nn.Tanh(), torch.nn.Linear(16, 3))
     unused = torch.nn.Parameter(torch.ones(5))
     params = list(net.parameters()) + [unused]
-    store = FlatStore(params, steal=steal)
+    store = FlatStore(params)
     broadcast_parameters(store)                         # rank 0's weights everywhere
-    red = GradReducer(store, bucket_bytes=4 * 200)      # several small buckets
+    red = GradReducer(store, bucket_bytes=4 * 200, algo=algo)      # several small buckets
     g = torch.Generator().manual_seed(7)
     xs = torch.randn(4, 8, 6, generator=g)
     ys = torch.randn(4, 8, 3, generator=g)
@@ -39,28 +39,30 @@ def _worker(rank, world, port, q, steal):
         # accumulation micro-step without sync, then a synced one
         with red.no_sync():
             ((net(xs[rank]) - ys[rank]) ** 2).mean().backward()
-        store.gather()                                  # no-op unless steal mode
         red.prepare()
         ((net(xs[2 + rank]) - ys[2 + rank]) ** 2).mean().backward()
         red.finish()
-        outs.append(store.g().clone())
+        outs.append([p.grad.clone() for p in params])
     # single-process oracle: accumulate both micro-batches, average over the two ranks
     ref = []
-    for r in range(world):
-        for p in net.parameters():
-            p.grad = None
-        ((net(xs[r]) - ys[r]) ** 2).mean().backward()
-        first = [p.grad.clone() for p in net.parameters()]
-        for p in net.parameters():
-            p.grad = None
-        ((net(xs[2 + r]) - ys[2 + r]) ** 2).mean().backward()
-        ref.append((first, [p.grad.clone() for p in net.parameters()]))
+    with red.no_sync():                                 # the reducer's hooks stay registered
+        for r in range(world):
+            for p in net.parameters():
+                p.grad = None
+            ((net(xs[r]) - ys[r]) ** 2).mean().backward()
+            first = [p.grad.clone() for p in net.parameters()]
+            for p in net.parameters():
+                p.grad = None
+            ((net(xs[2 + r]) - ys[2 + r]) ** 2).mean().backward()
+            ref.append((first, [p.grad.clone() for p in net.parameters()]))
     # expected on rank: own first micro-batch grad (unsynced) is part of the buffer that gets
     # all-reduced, so result = mean over ranks of (first + second)
     exp = [sum(ref[r][0][i] + ref[r][1][i] for r in range(world)) / world
            for i in range(len(ref[0][0]))]
-    exp_flat = torch.cat([e.reshape(-1) for e in exp] + [torch.zeros(5)])
-    ok = all(torch.allclose(o, exp_flat, atol=1e-6) for o in outs)
+    exp.append(torch.zeros(5))
+    ok = all(all(torch.allclose(a, e, atol=1e-6) for a, e in zip(o, exp)) for o in outs)
+    # every tensor of the store starts on a 16-byte boundary; the padding stays zero
+    ok = ok and all(o % 4 == 0 for o in store.offsets) and float(store.flat_g.abs().sum()) > 0
     q.put((rank, ok, len(red.buckets), sorted(red._expected) == list(range(len(params) - 1))))
     dist.destroy_process_group()
 
@@ -68,17 +70,16 @@ def _worker(rank, world, port, q, steal):
 import pytest
 
 
-@pytest.mark.parametrize("steal", [False, True])
-def test_grad_reducer_world2_gloo(steal):
-    """steal=False: p.grad are views of the flat buffer; steal=True: gradients are parked on the
-    parameters by autograd and added into the flat buffer per bucket (FlatStore.gather)."""
+@pytest.mark.parametrize("algo", ["allreduce", "rs_ag"])
+def test_grad_reducer_world2_gloo(algo):
+    """Both exchange forms: in-place all-reduce, and reduce-scatter + shard divide + all-gather."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, steal)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, algo)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in procs]
+    res = [q.get(timeout=90) for _ in procs]
     for p in procs:
         p.join(timeout=60)
     for rank, ok, nb, learned in res:

@@ -1,0 +1,97 @@
+"""GPU: s2t_gemm_f32 (csrc/gemm.hip, fp32 MFMA) against fp64 torch: forward (NT) with staged
+Swoosh + bias + residual, dgrad (NN) with the activation derivative + residual + accumulate,
+wgrad (TN) with atomically accumulated output + bias gradient + staged Swoosh; ragged tile
+edges; and the refusal (-2) of layouts the float4 staging cannot read."""
+import numpy as np
+import pytest
+import torch
+
+from speech2text_amd import _native as N
+from speech2text_amd import zip_kernels as zk
+
+pytestmark = pytest.mark.gpu
+
+
+def _gemm(mode, A, B, C, M, Nn, K, bias=None, resid=None, act_src=None, act_kind=0, pro_a=0, pro_b=0,
+          colsum=None, accumulate=0):
+    return N.lib().s2t_gemm_f32(mode, N.raw(A), A.stride(0), N.raw(B), B.stride(0), N.fp(C), C.stride(0),
+                                M, Nn, K, N.fp(bias), N.fp(resid), 0 if resid is None else resid.stride(0),
+                                N.fp(act_src), 0 if act_src is None else act_src.stride(0), act_kind,
+                                pro_a, pro_b, N.fp(colsum), accumulate, N.stream())
+
+
+def _swoosh(x, kind):
+    off, c = (4.0, 0.035) if kind == 1 else (1.0, 0.313261687)
+    return torch.logaddexp(torch.zeros((), dtype=x.dtype, device=x.device), x - off) - 0.08 * x - c
+
+
+def _swd(x, kind):
+    return torch.sigmoid(x - (4.0 if kind == 1 else 1.0)) - 0.08
+
+
+def _close(got, ref, tol=2e-5):
+    ref = ref.float()
+    err = (got - ref).abs().max().item()
+    assert err <= tol * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("M,K,Nn", [(1000, 192, 384), (517, 64, 68), (4099, 256, 192), (130, 132, 500),
+                                    (9000, 768, 256)])
+def test_gemm_modes_vs_fp64(dev, M, K, Nn):
+    g = torch.Generator(device="cpu").manual_seed(M + K + Nn)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)   # noqa: E731
+    x, W, b, gr, res, r2 = rnd(M, K), rnd(Nn, K) * 0.2, rnd(Nn), rnd(M, Nn), rnd(M, Nn), rnd(M, K)
+    xd, Wd, grd = x.double(), W.double(), gr.double()
+    for kind in (0, 1, 2):                                   # ---- NT
+        y = torch.full((M, Nn), float("nan"), device=dev)
+        assert _gemm(0, x, W, y, M, Nn, K, bias=b, resid=res, pro_a=kind) == 0
+        a = xd if kind == 0 else _swoosh(xd, kind)
+        _close(y, a @ Wd.t() + b.double() + res.double())
+    dx = torch.full((M, K), float("nan"), device=dev)        # ---- NN
+    assert _gemm(1, gr, W, dx, M, K, Nn) == 0
+    _close(dx, grd @ Wd)
+    assert _gemm(1, gr, W, dx, M, K, Nn, act_src=x, act_kind=2, resid=r2) == 0
+    _close(dx, (grd @ Wd) * _swd(xd, 2) + r2.double())
+    base = dx.clone()
+    assert _gemm(1, gr, W, dx, M, K, Nn, accumulate=1) == 0
+    _close(dx, base.double() + grd @ Wd)
+    for kind in (0, 1):                                      # ---- TN (accumulates)
+        dW = torch.ones(Nn, K, device=dev)
+        db = torch.full((Nn,), 2.0, device=dev)
+        assert _gemm(2, gr, x, dW, Nn, K, M, colsum=db, pro_b=kind) == 0
+        a = xd if kind == 0 else _swoosh(xd, kind)
+        _close(dW, 1.0 + grd.t() @ a, tol=4e-5)
+        _close(db, 2.0 + grd.sum(0), tol=4e-5)
+
+
+def test_gemm_refuses_unaligned_layouts(dev):
+    x = torch.randn(64, 66, device=dev)
+    W = torch.randn(32, 66, device=dev)
+    y = torch.empty(64, 32, device=dev)
+    assert _gemm(0, x, W, y, 64, 32, 66) == -2               # K % 4 != 0
+    xs = torch.randn(64, 69, device=dev)[:, 1:]              # rows not 16-byte aligned
+    W2 = torch.randn(32, 68, device=dev)
+    assert _gemm(0, xs, W2, y, 64, 32, 68) == -2
+
+
+def test_linear_backward_accumulates_into_flat_grads(dev):
+    """zk.linear / zk.swoosh_linear: with FlatStore-owned parameters the weight and bias
+    gradients are accumulated in place by the TN kernel (autograd sees None) and equal torch's."""
+    from speech2text_amd.flat import FlatStore
+    torch.manual_seed(3)
+    lin = torch.nn.Linear(96, 160).to(dev)
+    ref = torch.nn.Linear(96, 160).to(dev)
+    ref.load_state_dict(lin.state_dict())
+    store = FlatStore(list(lin.parameters()))
+    x = torch.randn(50, 12, 96, device=dev, requires_grad=True)
+    xr = x.detach().clone().requires_grad_(True)
+    w = torch.randn(50, 12, 160, device=dev)
+    for rep in range(2):                                      # second pass accumulates
+        (zk.swoosh_linear(x, lin.weight, lin.bias, True) * w).sum().backward()
+        (torch.nn.functional.linear(_swoosh(xr, 1), ref.weight, ref.bias) * w).sum().backward()
+    np.testing.assert_allclose(lin.weight.grad.cpu().numpy(), ref.weight.grad.cpu().numpy(),
+                               rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(lin.bias.grad.cpu().numpy(), ref.bias.grad.cpu().numpy(),
+                               rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), xr.grad.cpu().numpy(), rtol=2e-4, atol=2e-5)
+    assert lin.weight.grad.data_ptr() == store.flat_g.data_ptr()

@@ -23,9 +23,30 @@ def main(src, tag, steps, ms_per_step):
         a[0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         a[1] += 1
     tot = sum(a[0] for a in agg.values())
+
+    def klass(k):
+        if k.startswith("Cijk_") or "rocblas" in k.lower() or "hipblaslt" in k.lower():
+            return "GEMM library (hipBLASLt/rocBLAS)"
+        if "at::native" in k or "at::cuda" in k or k.startswith("void at::"):
+            return "ATen elementwise/reduce"
+        if "rocclr" in k or "hipMemcpy" in k or "copyBuffer" in k or "fillBuffer" in k:
+            return "copy/fill"
+        if "miopen" in k.lower() or "Im2d2Col" in k or "Col2Im" in k:
+            return "MIOpen"
+        if "ccl" in k.lower():
+            return "RCCL"
+        return "hand-written HIP (libs2t_mi355)"
+
+    cls = collections.defaultdict(lambda: [0, 0])
+    for k, (d, n) in agg.items():
+        c = cls[klass(k)]
+        c[0] += d
+        c[1] += n
     with open(os.path.join(out, f"{tag}_timed_region.txt"), "w") as f:
         f.write(f"# kernels whose start lies in the last {steps} steps ({ms_per_step:.1f} ms each) of the trace\n")
         f.write(f"# GPU busy {tot/steps/1e6:.2f} ms/step, {len(sel)/steps:.0f} launches/step\n")
+        for c, (d, n) in sorted(cls.items(), key=lambda x: -x[1][0]):
+            f.write(f"# class {c:36s} {d/steps/1e6:8.3f} ms/step {100*d/tot:5.1f}% {n/steps:8.1f} launches/step\n")
         for k, (d, n) in sorted(agg.items(), key=lambda x: -x[1][0])[:70]:
             f.write(f"{d/steps/1e6:8.3f} ms/step {100*d/tot:5.1f}% {n/steps:8.1f} calls/step "
                     f"{d/n/1e3:9.1f} us avg  {k[:140]}\n")
