@@ -168,7 +168,10 @@ __global__ __launch_bounds__(256) void scaled_adam_coef_kernel(CoefArgs A) {
     const int q = s - A.seg_lo;
     const int len = A.seg_len[s];
     const bool scalar = len == 1;
-    A.scale_grads[(long)(k % P) * ng + q] = gm * A.segstat[3 * (long)s + 1];
+    // a zero factor under live clipping means the gradients were non-finite and are zeroed by
+    // apply (reference: nan_to_num after the scale): their p.g sum is 0, not 0 * inf
+    A.scale_grads[(long)(k % P) * ng + q] =
+        (sanitize && gm == 0.f) ? 0.f : gm * A.segstat[3 * (long)s + 1];
     float sstep = 0.f;
     if (k % P == P - 1) {
       const float rms = sqrtf(A.segstat[3 * (long)s + 2] / (float)len);

@@ -110,6 +110,11 @@ class FlatStore:
                 p.grad = g
 
 
+def owned(param) -> bool:
+    ent = _OWNER.get(id(param))
+    return ent is not None and ent[0].alive(param)
+
+
 def grad_written(param):
     """A kernel accumulated this parameter's gradient directly into its flat view (autograd's
     AccumulateGrad node will not run for it): tell the data-parallel reducer."""

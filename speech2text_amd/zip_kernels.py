@@ -670,11 +670,15 @@ def wgrad_into(wparam, bparam, g2, a2, pro=0):
     are the flat-store views (speech2text_amd.flat): one launch, no temporary, no autograd
     accumulate kernel.  Returns False when that is not possible (the caller then returns the
     gradients as tensors)."""
+    if not (wparam.is_leaf and flat.owned(wparam) and _tn_ok(g2) and _tn_ok(a2)):
+        return False
     wg = wparam.grad
-    if wg is None or not wg.is_contiguous() or wg.dim() != 2 or not (_tn_ok(g2) and _tn_ok(a2)):
+    if wg is None or not wg.is_contiguous() or wg.dim() != 2:
         return False
     bg = None
     if bparam is not None:
+        if not (bparam.is_leaf and flat.owned(bparam)):
+            return False
         bg = bparam.grad
         if bg is None or not bg.is_contiguous():
             return False
