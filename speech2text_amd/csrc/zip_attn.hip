@@ -16,6 +16,7 @@
 // single pass with the scores held in registers; longer sequences use two passes
 // (statistics, then recompute + write) so LDS use is independent of T.
 #include "common.h"
+#include <cstdint>
 #include <cstdlib>
 
 namespace {
@@ -255,6 +256,225 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a, float* __rest
       }
     }
   }
+}
+
+
+// ---------------------------------------------------------------- forward on the f32 MFMA
+// Workgroup = 128 query rows of one (b,h): 4 waves x one 32-row strip each.  The whole key
+// matrix of the (b,h) (T <= 512 keys x qd) is staged ONCE in LDS, k-contiguous with a 4-float
+// pad (conflict-free ds_read_b128 fragments); each wave keeps its strip of scores
+// (32 rows x T) in MFMA accumulators (NT tiles x 16 registers), adds the position term from an
+// LDS window of linear_pos rows (one ds_read_b128 = the 4 position dims of one offset), applies
+// the masks, does the softmax with half-wave shuffles and writes W once.  Lane = key column
+// (lane & 31), register r = query row (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the strip.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int MF_ROWS = 128;
+constexpr int MF_KLD = MAXQD;   // unpadded; 16-byte chunks are XOR-swizzled by (row & 7)
+
+// SPLIT = 2: two waves share a strip (each NT of the 2 NT key tiles) and combine their row
+// statistics through LDS -- keeps the accumulators of a 512-key strip within the register file.
+template <int NT, int SPLIT, bool HAS_POS, bool HAS_AM>
+__global__ __launch_bounds__(256 * SPLIT, (NT >= 8 && SPLIT == 1) ? 2 : 1)
+void attn_fwd_mfma_kernel(AttnArgs a, float* __restrict__ W) {
+  constexpr int KT = NT * SPLIT;                                // key tiles staged
+  constexpr int NTH = 256 * SPLIT;                              // SPLIT waves per 32-row strip
+  constexpr int WG_ROWS = MF_ROWS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* sK = reinterpret_cast<float*>(smem_raw);               // [KT*32][MF_KLD]
+  float4* sPos = reinterpret_cast<float4*>(sK + KT * 32 * MF_KLD);   // [KT*32 + MF_ROWS]
+  float4* sP = sPos + (KT * 32 + MF_ROWS);                      // [MF_ROWS]
+  float* sStat = reinterpret_cast<float*>(sP + MF_ROWS);        // [waves][32 rows]
+  const int T = a.T, qd = a.qd, pd = a.pd;
+  const int i0 = blockIdx.x * WG_ROWS, b = blockIdx.y, h = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lo = lane & 31, hi = lane >> 5;
+  const long rs = (long)a.B * (a.H * (2 * qd + pd));           // floats between frames
+  // ---- stage K (zero rows past T, zero dims past qd are never read), pos window, p rows
+  {
+    // all of a thread's global loads are issued before the first LDS store (the key rows of one
+    // (b,h) are 128-byte pieces B*Dp floats apart: latency-bound unless many are in flight)
+    const float* kb = k_row(a, 0, b, h);
+    const int v4 = qd >> 2;                                     // float4 per key row (<= 8)
+    const int jr = threadIdx.x >> 3, c = threadIdx.x & 7;
+    constexpr int JR = NTH / 8, KI = KT * 32 / JR;              // key rows per pass, passes
+    float4 kv[KI];
+#pragma unroll
+    for (int it = 0; it < KI; ++it) {
+      const int j = jr + JR * it;
+      kv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (j < T && c < v4) kv[it] = *reinterpret_cast<const float4*>(kb + (long)j * rs + 4 * c);
+    }
+    // window entry w <-> relative index rel = (T-1) - (i0 + MF_ROWS-1) + w  (w = 127 - il + j)
+    const int base = (T - 1) - (i0 + MF_ROWS - 1);
+    constexpr int NW = (KT * 32 + MF_ROWS + NTH - 1) / NTH;
+    float4 wv[NW];
+    const bool vec4 = pd == 4 && ((reinterpret_cast<uintptr_t>(a.pos) & 15) == 0);
+#pragma unroll
+    for (int it = 0; it < NW; ++it) {
+      const int w = threadIdx.x + NTH * it;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int r = base + w;
+      if (HAS_POS && w < KT * 32 + MF_ROWS && r >= 0 && r < 2 * T - 1) {
+        const float* pp = a.pos + (long)r * a.H * pd + h * pd;
+        if (vec4) {
+          v = *reinterpret_cast<const float4*>(pp);
+        } else {
+          v.x = pp[0];
+          if (pd > 1) v.y = pp[1];
+          if (pd > 2) v.z = pp[2];
+          if (pd > 3) v.w = pp[3];
+        }
+      }
+      wv[it] = v;
+    }
+    float4 pq = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (HAS_POS && threadIdx.x < MF_ROWS && i0 + (int)threadIdx.x < T) {
+      const float* pp = p_row(a, i0 + threadIdx.x, b, h);
+      pq.x = pp[0];
+      if (pd > 1) pq.y = pp[1];
+      if (pd > 2) pq.z = pp[2];
+      if (pd > 3) pq.w = pp[3];
+    }
+#pragma unroll
+    for (int it = 0; it < KI; ++it)
+      if (c < v4)
+        *reinterpret_cast<float4*>(sK + (jr + JR * it) * MF_KLD + 4 * (c ^ (jr & 7))) = kv[it];
+#pragma unroll
+    for (int it = 0; it < NW; ++it) {
+      const int w = threadIdx.x + NTH * it;
+      if (w < KT * 32 + MF_ROWS) sPos[w] = wv[it];
+    }
+    if (threadIdx.x < MF_ROWS) sP[threadIdx.x] = pq;
+  }
+  // ---- this lane's query fragments: row (strip row lo), dims 8 s + 4 hi .. + 3
+  const int strip = wave / SPLIT, half = wave % SPLIT;
+  const int iw = i0 + strip * 32;                               // first row of the strip
+  float4 qf[MAXQD / 8];
+  {
+    const int i = min(iw + lo, T - 1);
+    const float* qp = q_row(a, i, b, h);
+#pragma unroll
+    for (int s8 = 0; s8 < MAXQD / 8; ++s8)
+      qf[s8] = (8 * s8 < qd) ? *reinterpret_cast<const float4*>(qp + 8 * s8 + 4 * hi)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+  if (SPLIT == 1 && iw >= T) return;                            // strip entirely past the end
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+    for (int s8 = 0; s8 < MAXQD / 8; ++s8) {
+      if (8 * s8 < qd) {
+        const float4 kf = *reinterpret_cast<const float4*>(
+            sK + (32 * (half * NT + t) + lo) * MF_KLD + 4 * ((2 * s8 + hi) ^ (lo & 7)));
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[s8].x, kf.x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[s8].y, kf.y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[s8].z, kf.z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[s8].w, kf.w, acc[t], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);     // keep the next tile's fragment reads behind these MFMAs
+  }
+  // ---- position term + masks, row statistics
+  const unsigned char* kpm = a.kpm ? a.kpm + (long)b * T : nullptr;
+  unsigned pad_bits = 0;                                        // bit t: key 32 t + lo is padding
+  if (kpm) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int j = 32 * (half * NT + t) + lo;
+      if (j < T && kpm[j]) pad_bits |= 1u << t;
+    }
+  }
+  float* Wb = W + ((long)h * a.B + b) * T * T;
+  // row by row: the row's position vector is read once, stores walk one row pointer
+  const int ilb = strip * 32 + 4 * hi;                          // row of register 0
+  float rmax[16], rsum[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int il = ilb + (r & 3) + 8 * (r >> 2);
+    float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (HAS_POS) pv = sP[il];
+    const float4* prow = sPos + (MF_ROWS - 1) - il + 32 * half * NT + lo;
+    const unsigned char* am = HAS_AM ? a.amask + (long)min(i0 + il, T - 1) * T : nullptr;
+    float m = S2T_NEG_INF;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int j = 32 * (half * NT + t) + lo;
+      float x = acc[t][r];
+      if (HAS_POS) {
+        const float4 e = prow[32 * t];
+        x = fmaf(pv.x, e.x, x);
+        x = fmaf(pv.y, e.y, x);
+        x = fmaf(pv.z, e.z, x);
+        x = fmaf(pv.w, e.w, x);
+      }
+      bool masked = (pad_bits >> t) & 1u;
+      if (HAS_AM) masked = masked || am[min(j, T - 1)] != 0;
+      x = masked ? -1000.f : x;
+      x = (j >= T) ? S2T_NEG_INF : x;
+      acc[t][r] = x;
+      m = fmaxf(m, x);
+    }
+    rmax[r] = m;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) rmax[r] = fmaxf(rmax[r], __shfl_xor(rmax[r], o, 64));
+  }
+  if (SPLIT == 2) {                                             // combine with the partner wave
+    if (lo == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sStat[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi] = rmax[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      rmax[r] = fmaxf(rmax[r], sStat[(wave ^ 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi]);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float e = (32 * (half * NT + t) + lo >= T) ? 0.f : __expf(acc[t][r] - rmax[r]);
+      acc[t][r] = e;
+      sum += e;
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    rsum[r] = sum;
+  }
+  if (SPLIT == 2) {
+    if (lo == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sStat[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi] = rsum[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rsum[r] += sStat[(wave ^ 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi];
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = i0 + ilb + (r & 3) + 8 * (r >> 2);
+    if (i < T) {
+      const float inv = 1.f / rsum[r];
+      float* wr = Wb + (long)i * T + 32 * half * NT + lo;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        if (32 * (half * NT + t) + lo < T) wr[32 * t] = acc[t][r] * inv;
+    }
+  }
+}
+
+template <int KT>
+inline size_t attn_mfma_smem() {
+  return sizeof(float) * ((size_t)KT * 32 * MF_KLD + 4 * ((size_t)KT * 32 + MF_ROWS) + 4 * MF_ROWS +
+                          8 * 32);
 }
 
 // ---------------------------------------------------------------- backward
@@ -900,6 +1120,31 @@ extern "C" int s2t_attn_apply(const float* W, const float* v, int T, int B, int 
   return 0;
 }
 
+template <int NT, int SPLIT, bool HAS_POS, bool HAS_AM>
+int launch_fwd_mfma_v(const AttnArgs& a, float* W, hipStream_t st) {
+  auto kern = attn_fwd_mfma_kernel<NT, SPLIT, HAS_POS, HAS_AM>;
+  const size_t smem = attn_mfma_smem<NT * SPLIT>();
+  static bool attr = false;                       // per instantiation
+  if (!attr && smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  dim3 grid((a.T + MF_ROWS - 1) / MF_ROWS, a.B, a.H);
+  hipLaunchKernelGGL(kern, grid, dim3(256 * SPLIT), smem, st, a, W);
+  return (int)hipGetLastError();
+}
+template <int NT, int SPLIT>
+int launch_fwd_mfma(int variant, const AttnArgs& a, float* W, hipStream_t st) {
+  switch (variant) {
+    case 0: return launch_fwd_mfma_v<NT, SPLIT, false, false>(a, W, st);
+    case 1: return launch_fwd_mfma_v<NT, SPLIT, true, false>(a, W, st);
+    case 2: return launch_fwd_mfma_v<NT, SPLIT, false, true>(a, W, st);
+    default: return launch_fwd_mfma_v<NT, SPLIT, true, true>(a, W, st);
+  }
+}
+
 extern "C" int s2t_relpos_attn_fwd(const float* qkp, const float* pos, const unsigned char* kpm,
                                    const unsigned char* amask, int T, int B, int H, int qd, int pd,
                                    float* W, void* stream) {
@@ -907,14 +1152,28 @@ extern "C" int s2t_relpos_attn_fwd(const float* qkp, const float* pos, const uns
   if (qd <= 0 || qd > MAXQD || pd < 0 || pd > MAXPD) return -1;
   AttnArgs a{qkp, pos, kpm, amask, T, B, H, qd, pd, nullptr, nullptr, {nullptr, nullptr},
              {nullptr, nullptr}, {0, 0}};
-  dim3 grid((T + ROWS - 1) / ROWS, B, H);
+  hipStream_t st = (hipStream_t)stream;
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<8>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<8>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e1 != hipSuccess) return (int)e1;
     attr_done = true;
   }
-  hipStream_t st = (hipStream_t)stream;
+  // MFMA path: whole key matrix of a (b,h) in LDS, scores of a 32-row strip in accumulators
+  static const bool no_mfma = getenv("S2T_ATTN_FWD_OLD") != nullptr;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(qkp) & 15) == 0) && (qd % 8 == 0) &&
+                       ((H * (2 * qd + pd)) % 4 == 0) && ((H * qd) % 4 == 0);
+  if (!no_mfma && T <= 512 && pd <= 4 && aligned) {
+    const int v = (pos ? 1 : 0) + (amask ? 2 : 0);
+    int rc;
+    if (T > 256) rc = launch_fwd_mfma<8, 2>(v, a, W, st);
+    else if (T > 128) rc = launch_fwd_mfma<8, 1>(v, a, W, st);
+    else if (T > 64) rc = launch_fwd_mfma<4, 1>(v, a, W, st);
+    else rc = launch_fwd_mfma<2, 1>(v, a, W, st);
+    return rc;
+  }
+  dim3 grid((T + ROWS - 1) / ROWS, B, H);
   if (T <= 128)
     hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, dim3(256), attn_smem<2>(qd, pd), st, a, W);
   else if (T <= 256)

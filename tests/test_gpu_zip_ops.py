@@ -176,7 +176,11 @@ def test_relpos_attention_backward_factored(dev, T, B, H, qd, pd, dvs, use_dw0, 
 @pytest.mark.parametrize("T,B,H,qd,pd,use_pos,use_am", [
     (50, 2, 4, 8, 4, True, True), (130, 3, 8, 32, 4, True, False), (64, 2, 2, 16, 4, True, True),
     (530, 2, 2, 32, 4, True, False), (1, 2, 2, 8, 4, True, False), (77, 2, 4, 24, 4, False, True),
-    (200, 2, 4, 32, 8, True, True)])
+    (200, 2, 4, 32, 8, True, True),
+    # the MFMA forward: C3 stack shapes (T, H, qd of stacks 0..3), both strip layouts, edges
+    (495, 3, 4, 32, 4, True, False), (495, 2, 4, 32, 4, True, True), (248, 2, 4, 32, 4, True, False),
+    (124, 2, 4, 32, 4, True, True), (62, 3, 8, 32, 4, True, False), (257, 2, 2, 16, 3, True, True),
+    (512, 1, 2, 32, 4, False, False), (33, 2, 2, 8, 2, True, False), (256, 2, 2, 32, 4, True, False)])
 def test_relpos_attention_weights(dev, T, B, H, qd, pd, use_pos, use_am):
     from speech2text_amd import zip_kernels as zk
     torch.manual_seed(T)
