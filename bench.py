@@ -249,6 +249,12 @@ def cpu_baseline_c2(cfg, state_dict, seconds=10.0, batch=4, n_labels=40, vocab=1
 
 
 # ------------------------------------------------------------------ roofline bookkeeping
+def _bound(p):
+    """mfma when the call sites' algorithmic intensity exceeds the machine balance, else hbm."""
+    balance = MFMA_F32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+    return "mfma" if p["algo_flops"] > 0 and p["algo_flops"] > balance * p["algo_bytes"] else "hbm"
+
+
 def roofline_report(prof_timed, prof_all, want, step_flops, ms_per_step):
     """`prof_timed`: HIP-event timings of the chosen entry point taken INSIDE the timed region.
     `prof_all`: every hand-written entry point, timed over extra (untimed) steps."""
@@ -258,15 +264,24 @@ def roofline_report(prof_timed, prof_all, want, step_flops, ms_per_step):
                "ms_per_step": p["ms_per_step"], "avg_us": 1000.0 * p["avg_ms"]}
         if p["algo_bytes"] > 0 and p["total_ms"] > 0:
             gbs = p["algo_bytes"] / (p["total_ms"] * 1e-3) / 1e9
-            row.update(alg_GBps=gbs, frac_hbm=gbs / HBM_PEAK_GBS)
+            row.update(bound=_bound(p), alg_GBps=gbs, frac_hbm=gbs / HBM_PEAK_GBS)
+            if p["algo_flops"] > 0:
+                tf = p["algo_flops"] / (p["total_ms"] * 1e-3) / 1e12
+                row.update(alg_TFLOPs=tf, frac_mfma=tf / MFMA_F32_PEAK_TFLOPS)
         table.append(row)
     out = {"bound": "hbm", "kernel": want, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": None, "traffic": None}
     p = prof_timed.get(want) if prof_timed else None
     if p and p["launches"] and p["algo_bytes"] > 0:
-        ach = p["algo_bytes"] / (p["total_ms"] * 1e-3) / 1e9
-        out.update(achieved=ach, frac=ach / HBM_PEAK_GBS, launches=p["launches"],
-                   avg_launch_ms=p["avg_ms"],
+        if _bound(p) == "mfma":
+            ach = p["algo_flops"] / (p["total_ms"] * 1e-3) / 1e12
+            out.update(bound="mfma", achieved=ach, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
+                       frac=ach / MFMA_F32_PEAK_TFLOPS,
+                       algorithmic_flops_per_launch=p["algo_flops"] / p["launches"])
+        else:
+            ach = p["algo_bytes"] / (p["total_ms"] * 1e-3) / 1e9
+            out.update(achieved=ach, frac=ach / HBM_PEAK_GBS)
+        out.update(launches=p["launches"], avg_launch_ms=p["avg_ms"],
                    algorithmic_bytes_per_launch=p["algo_bytes"] / p["launches"])
     else:
         out["note"] = f"{want} was not launched in the timed region"

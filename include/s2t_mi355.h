@@ -230,6 +230,18 @@ int s2t_gemm_f32(int mode, const float* A, long lda, const float* B, long ldb, f
                  const float* act_src, long lds, int act_kind, int pro_a, int pro_b, float* colsum,
                  int accumulate, void* stream);
 
+/* ---- BEST-RQ SSL heads: fused log-softmax + smoothed-target loss (model/loss/kl_divergence.py:
+ * 36-76, model/loss/cross_entropy.py:38-69; call site task_factory/ssl_task.py:140-158).
+ * logits [rows][K]; labels [rows]; target t_c = t_other (c != label) / t_label; row_loss[r] =
+ * c0 - sum_c t_c log_softmax(scale x)_c and lse[r]; backward grad[r][c] = row_weight[r] * scale *
+ * (softmax_c - t_c)  (row_weight = upstream gradient * mask / mask.sum()). */
+int s2t_smoothed_nll_fwd(const float* logits, const long* labels, long rows, int K, float scale,
+                         float t_other, float t_label, float c0, float* row_loss, float* lse,
+                         void* stream);
+int s2t_smoothed_nll_bwd(const float* logits, const long* labels, const float* lse,
+                         const float* row_weight, long rows, int K, float scale, float t_other,
+                         float t_label, float* grad, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

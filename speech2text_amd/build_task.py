@@ -11,27 +11,33 @@ import yaml
 
 from speech2text_amd.task_factory.ctc_task import CtcTask
 from speech2text_amd.task_factory.rnnt_task import CtcHybridRnnt, PrunedRnntTask, RnntTask
+from speech2text_amd.task_factory.ssl_task import SslTask
 from speech2text_amd.trainer import Trainer
 
 
-def _ssl_task():
-    from speech2text_amd.task_factory.ssl_task import SslTask
-    return SslTask
+class CifTask:
+    def __init__(self, config):
+        raise NotImplementedError("task CIF is outside the accelerated path (SURVEY.md 2)")
+
+
+class NnlmTask:
+    def __init__(self, config):
+        raise NotImplementedError("task NNLM is outside the accelerated path (SURVEY.md 2)")
 
 
 @unique
 class TaskFactory(Enum):
+    """Same keys as the reference enum (build_task.py:36-45): TaskFactory[type].value(config)."""
     CTC = CtcTask
     Rnnt = RnntTask
     CTC_Hybrid_Rnnt = CtcHybridRnnt
     Pruned_Rnnt = PrunedRnntTask
+    SSL = SslTask
+    CIF = CifTask
+    NNLM = NnlmTask
 
     @classmethod
     def get(cls, name):
-        if name == "SSL":
-            return _ssl_task()
-        if name in ("CIF", "NNLM"):
-            raise NotImplementedError(f"task {name} is outside the accelerated path (SURVEY.md 2)")
         return cls[name].value
 
 

@@ -331,3 +331,40 @@ def make_boundary(target_lengths, frame_lengths, device):
     b[:, 2] = target_lengths.to(device)
     b[:, 3] = frame_lengths.to(device)
     return b
+
+
+# =============================================================== BEST-RQ SSL heads
+class _SmoothedNll(torch.autograd.Function):
+    """Per-row  C0 - sum_c t_c log_softmax(scale * logits)_c  (csrc/ssl_loss.hip)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, scale, t_other, t_label, c0):
+        _dev_check(logits)
+        logits = logits.contiguous().float()
+        rows, K = logits.shape
+        labels = labels.to(device=logits.device, dtype=torch.int64).contiguous()
+        row = torch.empty(rows, dtype=torch.float32, device=logits.device)
+        lse = torch.empty(rows, dtype=torch.float32, device=logits.device)
+        N.profile_note("s2t_smoothed_nll_fwd", 4.0 * logits.numel())
+        N.check(N.lib().s2t_smoothed_nll_fwd(N.fp(logits), N.lp(labels), rows, K, float(scale),
+                                             float(t_other), float(t_label), float(c0),
+                                             N.fp(row), N.fp(lse), N.stream()), "smoothed_nll_fwd")
+        ctx.save_for_backward(logits, labels, lse)
+        ctx.cfg = (float(scale), float(t_other), float(t_label))
+        return row
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, labels, lse = ctx.saved_tensors
+        scale, t_other, t_label = ctx.cfg
+        rows, K = logits.shape
+        grad = torch.empty_like(logits)
+        N.profile_note("s2t_smoothed_nll_bwd", 8.0 * logits.numel())
+        N.check(N.lib().s2t_smoothed_nll_bwd(N.fp(logits), N.lp(labels), N.fp(lse),
+                                             N.fp(g.contiguous().float()), rows, K, scale, t_other,
+                                             t_label, N.fp(grad), N.stream()), "smoothed_nll_bwd")
+        return grad, None, None, None, None, None
+
+
+def smoothed_nll_rows(logits2d, labels, scale, t_other, t_label, c0):
+    return _SmoothedNll.apply(logits2d, labels, scale, t_other, t_label, c0)

@@ -1,6 +1,7 @@
 """Loss factory + wrappers (reference model/loss/{loss,ctc_loss,rnnt_loss,pruned_rnnt_loss,
 cross_entropy,kl_divergence}.py).  CTC / RNN-T / pruned RNN-T run the HIP lattice kernels."""
 import dataclasses
+import math
 from typing import Dict
 
 import torch
@@ -98,23 +99,28 @@ class MaskedCELossConfig:
 
 
 class MaskedCELoss(nn.Module):
+    """Cross entropy with label smoothing and a frame mask (reference cross_entropy.py:38-69),
+    computed by the fused row kernel: target = eps/K everywhere + (1-eps) at the label."""
+
     def __init__(self, config: MaskedCELossConfig):
         super().__init__()
         self._num_classes = config.num_classes
         self._scale_factor = config.scale_factor
-        self._ce = nn.CrossEntropyLoss(reduction="none", label_smoothing=config.label_smoothing)
+        self._label_smoothing = config.label_smoothing
 
     def forward(self, logits, ori_labels, mask=None):
         max_len = logits.size(1)
-        logits = logits.contiguous().reshape(-1, self._num_classes)
-        logits = logits * self._scale_factor
-        loss = self._ce(logits, ori_labels.contiguous().reshape(-1))
+        nc = self._num_classes
+        eps = float(self._label_smoothing)
+        row = K.smoothed_nll_rows(logits.contiguous().reshape(-1, nc), ori_labels.reshape(-1),
+                                  self._scale_factor, eps / nc, 1.0 - eps + eps / nc, 0.0)
         if mask is not None:
             if mask.dim() == 1:
-                mask = make_non_pad_mask(mask).long()
-            mask = mask.contiguous().reshape(-1)
-            loss = (loss * mask).sum() / mask.sum()
-        return loss.mean()
+                assert int(mask.max()) == max_len
+                mask = make_non_pad_mask(mask)
+            mask = mask.contiguous().reshape(-1).to(row.dtype)
+            return (row * mask).sum() / mask.sum()
+        return row.mean()
 
     def predict(self, logits):
         logits = logits * self._scale_factor
@@ -136,29 +142,26 @@ class MaskedKLDivergence(nn.Module):
         self._label_smoothing = config.label_smoothing
 
     def forward(self, logits, ori_labels, mask=None):
+        """KL(smoothed one-hot || softmax) summed over classes, masked mean over frames
+        (reference kl_divergence.py:36-76).  The smoothed-label tensor, the log-softmax and the
+        element-wise KL are never materialised (fused row kernel).  The reference scales
+        `logits` IN PLACE by scale_factor on every call (:61), so its second call per codebook
+        sees scale_factor**2; that quirk is not reproduced (every shipped YAML uses 1.0)."""
+        nc = self._num_classes
         if mask is not None:
             if mask.dim() == 1:
+                assert int(mask.max()) == logits.size(1)
                 mask = make_non_pad_mask(mask)
             mask = mask.contiguous().reshape(-1)
         else:
             mask = torch.ones_like(ori_labels).reshape(-1)
-        logits = logits.contiguous().reshape(-1, self._num_classes)
-        logits = logits * self._scale_factor
-        lab = ori_labels.contiguous().reshape(-1)
-        # KL(smoothed one-hot || softmax) summed over classes, without materialising the
-        # smoothed-label tensor: sum_c t_c (log t_c - logp_c)
-        logp = logits.log_softmax(dim=-1)
-        eps = self._label_smoothing / (self._num_classes - 1)
-        conf = 1.0 - self._label_smoothing
-        lp_lab = logp.gather(1, lab.unsqueeze(1)).squeeze(1)
-        ent = conf * torch.log(torch.tensor(conf)) if conf > 0 else 0.0
-        if eps > 0:
-            ent = ent + (self._num_classes - 1) * eps * torch.log(torch.tensor(eps))
-            row = ent - (conf - eps) * lp_lab - eps * logp.sum(dim=-1)
-        else:
-            row = ent - conf * lp_lab
-        row = row.masked_fill(~mask.bool(), 0)
-        return row.sum() / mask.sum()
+        a = self._label_smoothing / (nc - 1)
+        b = 1.0 - self._label_smoothing
+        c0 = (nc - 1) * (a * math.log(a) if a > 0 else 0.0) + (b * math.log(b) if b > 0 else 0.0)
+        row = K.smoothed_nll_rows(logits.contiguous().reshape(-1, nc), ori_labels.reshape(-1),
+                                  self._scale_factor, a, b, c0)
+        m = mask.to(row.dtype)
+        return (row * m).sum() / m.sum()
 
     def predict(self, logits):
         logits = logits * self._scale_factor

@@ -1,0 +1,279 @@
+"""GPU: every BASELINE.json configuration at its FULL size.
+
+C3 (zipformer YAML dims, 500 BPE, prune_range 5): 2 x 10 s against the oracle (features,
+encoder activations, simple / pruned loss within the north-star 1e-3, prune ranges), then the
+per-rank batch of 64 through size-independent properties (finite, lengths, ranges monotone and
+in bounds, loss decreasing under the real optimizer).  C2 (conformer-CTC, 12 layers, d = 256),
+C4 (CTC_Hybrid_Rnnt, B = 16, U = 60) and C5 (BEST-RQ, 30 s, 8192 x 16 codebook, KL over 8193
+classes) likewise: a small-batch comparison with the oracle at full model size plus the full
+batch through properties.  The oracle for k2 / torchaudio / lhotse arithmetic is our restatement
+(PARITY UNPINNED for those parts, see oracle/*.py headers).
+"""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import bench
+from oracle import conformer as OC
+from oracle import fbank as ofb
+from oracle import heads as H
+from oracle import k2_rnnt as K2
+from oracle import zipformer as Z
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return abs(float(a) - float(b)) / max(1e-12, abs(float(b)))
+
+
+def _c2(layers=12):
+    cfg = bench.c2_config(128, layers=layers)
+    cfg["optim_setup"]["lr_scheduler"]["config"]["warmup_steps"] = 10      # reach a real lr quickly
+    return cfg
+
+
+def _cpu_sd(task):
+    return {k: v.detach().cpu().clone() for k, v in task.state_dict().items()}
+
+
+# ------------------------------------------------------------------------------------ C3
+def test_c3_yaml_dims_two_utterances_vs_oracle(dev):
+    from speech2text_amd.build_task import TaskFactory
+    cfg = bench.c3_config(500)
+    random.seed(1234)
+    torch.manual_seed(1234)
+    task = TaskFactory.get("Pruned_Rnnt")(cfg)
+    sd = _cpu_sd(task)
+    task.to(dev).eval()
+    batch = bench.make_batch(0, 2, 10.0, 50, 500, dev)
+    batch["pcm_length"][1] = 131000                         # ragged: 8.2 s
+    batch["label_length"][1] = 37
+    with torch.no_grad():
+        feat, feat_len = task.features(batch)
+        enc, enc_len = task._encoder(feat, feat_len)
+        pred, pred_len, _ = task._predictor(batch["label"], batch["label_length"],
+                                            task._predictor.init_state())
+        lattice, boundary, ranges, simple = task._joiner(enc, enc_len, pred, pred_len, batch["label"])
+        pruned = task._loss({"logits": lattice, "logits_length": enc_len, "targets": batch["label"],
+                             "targets_length": batch["label_length"], "boundary": boundary,
+                             "ranges": ranges})
+    # ---- oracle on the same parameters and PCM (lhotes_fbank: 16-bit scale, high_freq -400)
+    pcm = batch["pcm"].cpu().numpy()
+    n = batch["pcm_length"].cpu().numpy()
+    fo = [ofb.fbank(pcm[i, :n[i]] * 32768.0, 80, high_freq=-400.0) for i in range(2)]
+    assert [f.shape[0] for f in fo] == feat_len.cpu().tolist() == [998, 817]
+    for i in range(2):
+        np.testing.assert_allclose(feat[i, :fo[i].shape[0]].cpu().numpy(), fo[i], atol=5e-3)
+    x = torch.zeros(2, 998, 80)
+    for i in range(2):
+        x[i, :fo[i].shape[0]] = torch.from_numpy(fo[i])
+    enc_sd = {k[len("_encoder.encoder."):]: v for k, v in sd.items() if k.startswith("_encoder.encoder.")}
+    lab, lab_len = batch["label"].cpu(), batch["label_length"].cpu()
+    with torch.no_grad():
+        yo, ylo = Z.zipformer_forward(enc_sd, bench._zcfg(cfg["encoder"]["config"]), x,
+                                      feat_len.cpu(), Z.Ctl(False), -1, -1)
+        po = H.stateless_predictor(sd, "_predictor.predictor.", lab, 5)
+        am, lm = H.joiner_projections(sd, "_joiner.", yo, po)
+        lo, bo, ro, so = K2.joiner_pruned(am, lm, lab, lab_len, ylo, 5)
+        pro = K2.rnnt_loss_pruned(lo, lab, ro, 0, bo)
+    assert enc_len.cpu().tolist() == ylo.tolist() == [248, 203]
+    # encoder activations: stated fp32 tolerance (12 layers deep, features differ by ~1e-3)
+    err = (enc.cpu() - yo).abs().max().item()
+    assert err <= 2e-3 * max(1.0, yo.abs().max().item()), err
+    # north star: loss parity within 1e-3 relative
+    assert _rel(simple, so) <= 1e-3, (float(simple), float(so))
+    assert _rel(pruned, pro) <= 1e-3, (float(pruned), float(pro))
+    same = (ranges.cpu() == ro).float().mean().item()
+    assert same >= 0.98, same                               # argmax ties can move a window by one
+
+
+def test_c3_full_batch_properties(dev):
+    from speech2text_amd.build_task import TaskFactory
+    from speech2text_amd.trainer import Trainer
+    cfg = bench.c3_config(500)
+    random.seed(1234)
+    torch.manual_seed(1234)
+    task = TaskFactory.get("Pruned_Rnnt")(cfg)
+    tr = Trainer(**cfg["trainer"]).setup(task, dev)
+    task.train()
+    batch = bench.make_batch(0, 64, 10.0, 50, 500, dev)
+    batch["pcm_length"][5] = 99000
+    batch["label_length"][5] = 21
+    losses = [float(tr.training_step(batch, i)) for i in range(4)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    task.eval()
+    with torch.no_grad():
+        feat, feat_len = task.features(batch)
+        enc, enc_len = task._encoder(feat, feat_len)
+        pred, pred_len, _ = task._predictor(batch["label"], batch["label_length"],
+                                            task._predictor.init_state())
+        lattice, boundary, ranges, simple = task._joiner(enc, enc_len, pred, pred_len, batch["label"])
+    assert enc.shape == (64, 248, 256) and torch.isfinite(enc).all()
+    assert enc_len.cpu().tolist() == [((int(f) - 7) // 2 + 1) // 2 for f in feat_len.cpu()]
+    r = ranges.cpu()
+    assert r.shape == (64, 248, 5) and int(r.min()) >= 0
+    for b in range(64):                                      # k2 prune-range invariants
+        S, T = int(batch["label_length"][b]), int(enc_len[b])
+        rb = r[b, :T]
+        assert int(rb.max()) <= S and (rb[:, 1:] - rb[:, :-1] == 1).all()
+        assert (rb[1:, 0] >= rb[:-1, 0]).all() and (rb[1:, 0] - rb[:-1, 0] <= 4).all()
+        assert int(rb[0, 0]) == 0 and int(rb[T - 1, 4]) == S
+    assert lattice.shape == (64, 248, 5, 500)
+
+
+# ------------------------------------------------------------------------------------ C2
+def test_c2_conformer_ctc_full_size(dev):
+    from speech2text_amd.build_task import TaskFactory
+    from speech2text_amd.trainer import Trainer
+    cfg = _c2()
+    random.seed(1234)
+    torch.manual_seed(1234)
+    task = TaskFactory.get("CTC")(cfg)
+    sd = _cpu_sd(task)
+    task.to(dev).eval()
+    batch = bench.make_batch(0, 2, 10.0, 40, 128, dev)
+    batch["pcm_length"][1] = 120000
+    with torch.no_grad():
+        feat, feat_len = task.features(batch)
+        enc, enc_len = task._encoder(feat, feat_len)
+        dec, dec_len = task._decoder(enc, enc_len)
+        loss = task._loss({"logits": dec, "logits_length": dec_len, "targets": batch["label"],
+                           "targets_length": batch["label_length"]})
+    pcm, n = batch["pcm"].cpu().numpy(), batch["pcm_length"].cpu().numpy()
+    x = torch.zeros(2, 998, 80)
+    for i in range(2):
+        f = ofb.fbank(pcm[i, :n[i]], 80)
+        x[i, :f.shape[0]] = torch.from_numpy(f)
+    enc_sd = {k[len("_encoder.encoder."):]: v for k, v in sd.items() if k.startswith("_encoder.encoder.")}
+    with torch.no_grad():
+        yo, ylo = OC.conformer_forward(enc_sd, x, feat_len.cpu(), 12, 4, training=False)
+        lg = H.projector(sd, "_decoder.decoder.", yo)
+        ref = torch.nn.functional.ctc_loss(lg.log_softmax(-1).transpose(0, 1), batch["label"].cpu(),
+                                           ylo, batch["label_length"].cpu(), blank=0,
+                                           reduction="mean", zero_infinity=True)
+    assert enc.shape == (2, 248, 256) and enc_len.cpu().tolist() == ylo.tolist()
+    # frames past an utterance's length are unspecified in both; compare the valid ones
+    for i in range(2):
+        L = int(ylo[i])
+        err = (enc[i, :L].cpu() - yo[i, :L]).abs().max().item()
+        assert err <= 2e-3 * max(1.0, yo[i, :L].abs().max().item()), (i, err)
+    assert _rel(loss, ref) <= 1e-3, (float(loss), float(ref))
+    # ---- the full batch of 32 under the optimizer
+    random.seed(1234)
+    torch.manual_seed(1234)
+    task = TaskFactory.get("CTC")(cfg)
+    tr = Trainer(**cfg["trainer"]).setup(task, dev)
+    task.train()
+    big = bench.make_batch(0, 32, 10.0, 40, 128, dev)
+    losses = [float(tr.training_step(big, i)) for i in range(4)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+# ------------------------------------------------------------------------------------ C4
+def _c4_cfg():
+    cfg = _c2()
+    cfg["task"] = {"type": "CTC_Hybrid_Rnnt", "name": "c4", "export_path": "/tmp"}
+    cfg["predictor"] = {"model": "Lstm", "config": {"num_symbols": 128, "output_dim": 256,
+                                                    "symbol_embedding_dim": 256, "num_lstm_layers": 2,
+                                                    "lstm_hidden_dim": 256, "lstm_layer_norm": True,
+                                                    "lstm_layer_norm_epsilon": 1e-3,
+                                                    "lstm_dropout": 0.0}}
+    cfg["joiner"] = {"input_dim": 256, "output_dim": 128, "inner_dim": 256, "activation": "tanh",
+                     "prune_range": -1}
+    cfg["loss"] = {"rnnt_weight": 0.8, "ctc_weight": 0.2,
+                   "rnnt_loss": {"model": "Rnnt", "config": {"blank_label": 0, "reduction": "mean"}},
+                   "ctc_loss": {"model": "CTC", "config": {"blank_label": 0, "reduction": "mean"}}}
+    return cfg
+
+
+def test_c4_hybrid_full_size(dev):
+    from speech2text_amd.build_task import TaskFactory
+    from speech2text_amd.trainer import Trainer
+    cfg = _c4_cfg()
+    random.seed(1234)
+    torch.manual_seed(1234)
+    task = TaskFactory.get("CTC_Hybrid_Rnnt")(cfg)
+    task.to(dev).eval()
+    batch = bench.make_batch(0, 2, 10.0, 60, 128, dev)
+    batch["label_length"][1] = 44
+    with torch.no_grad():
+        feat, feat_len = task.features(batch)
+        enc, enc_len = task._encoder(feat, feat_len)
+        dec, dec_len = task._decoder(enc, enc_len)
+        pred, pred_len, _ = task._predictor(batch["label"], batch["label_length"],
+                                            task._predictor.init_state())
+        joint, _, _, _ = task._joiner(enc, enc_len, pred, pred_len)
+        l_rnnt = task._rnnt_loss({"logits": joint, "logits_length": enc_len,
+                                  "targets": batch["label"], "targets_length": batch["label_length"]})
+        l_ctc = task._ctc_loss({"logits": dec, "logits_length": dec_len, "targets": batch["label"],
+                                "targets_length": batch["label_length"]})
+    assert joint.shape == (2, 248, 61, 128)
+    # unpruned lattice loss against the oracle recursion on the product's own lattice
+    ref = K2.rnnt_loss_full(joint.cpu(), batch["label"].cpu(), enc_len.cpu(),
+                            batch["label_length"].cpu())
+    assert _rel(l_rnnt, ref) <= 1e-3, (float(l_rnnt), float(ref))
+    ref_ctc = torch.nn.functional.ctc_loss(dec.cpu().log_softmax(-1).transpose(0, 1),
+                                           batch["label"].cpu(), dec_len.cpu(),
+                                           batch["label_length"].cpu(), blank=0, reduction="mean",
+                                           zero_infinity=True)
+    assert _rel(l_ctc, ref_ctc) <= 1e-3
+    # ---- full batch: B = 16, U = 60 (lattice 16 x 248 x 61 x 128)
+    random.seed(1234)
+    torch.manual_seed(1234)
+    task = TaskFactory.get("CTC_Hybrid_Rnnt")(cfg)
+    tr = Trainer(**cfg["trainer"]).setup(task, dev)
+    task.train()
+    big = bench.make_batch(0, 16, 10.0, 60, 128, dev)
+    losses = [float(tr.training_step(big, i)) for i in range(3)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    lg = {k: float(v) for k, v in task.logged.items()}
+    assert abs(lg["train_loss"] - (0.8 * lg["train_loss/loss_rnnt"] + 0.2 * lg["train_loss/loss_ctc"])) \
+        <= 1e-4 * abs(lg["train_loss"])
+
+
+# ------------------------------------------------------------------------------------ C5
+def test_c5_bestrq_ssl_full_size(dev):
+    from speech2text_amd.build_task import TaskFactory
+    from speech2text_amd.trainer import Trainer
+    from oracle import best_rq as OB
+    cfg = _c2()
+    cfg["task"] = {"type": "SSL", "name": "c5", "export_path": "/tmp"}
+    cfg["ssl_layer"] = {"model": "Best-RQ",
+                        "layer_config": {"cnn_kernel_size": [3, 3], "cnn_stride": [2, 2], "feat_dim": 80,
+                                         "num_codebooks": 1, "codebook_dim": 16, "codebook_size": 8192,
+                                         "label_basis": "cosine"},
+                        "masking_config": {"mask_proportion": 0.5, "mean_span_length": 1,
+                                           "span_select_type": "static", "min_num_spans": 1,
+                                           "no_overlap": False, "min_space": 0, "seed": 1234}}
+    cfg["logits_layer"] = {"model": "Projector", "config": {"input_dim": 256, "output_dim": 8193,
+                                                           "dropout_p": 0.0}}
+    cfg["loss"] = {"loss_select": "mask_loss", "model": "MaskedKLDiv",
+                   "config": {"num_classes": 8193, "scale_factor": 1.0, "label_smoothing": 0.1}}
+    random.seed(1234)
+    np.random.seed(1234)
+    torch.manual_seed(1234)
+    task = TaskFactory.get("SSL")(cfg)
+    tr = Trainer(**cfg["trainer"]).setup(task, dev)
+    task.train()
+    batch = bench.make_batch(0, 8, 30.0, 1, 128, dev)       # 30 s clips -> 2998 frames -> 748 labels
+    batch["pcm_length"][3] = 400000
+    # labels of the quantizer are bit-exact against the oracle on the features the task computes
+    with torch.no_grad():
+        feat, feat_len = task.features(batch)
+        out = task._ssl_layer(feat, feat.clone(), feat_len)
+    assert feat.shape == (8, 2998, 80) and out["labels"].shape == (1, 8, 748)
+    proj = task._ssl_layer.state_dict()
+    pk = [k for k in proj if "project" in k.lower()][0]
+    ck = [k for k in proj if "codebook" in k.lower()][0]
+    ref = OB.make_labels(feat.cpu().numpy().astype(np.float64), proj[pk].cpu().numpy(),
+                         proj[ck].cpu().numpy().reshape(1, 8192, 16))
+    lens = OB.label_lengths(feat_len.cpu().numpy())
+    got = out["labels"].cpu().numpy()
+    for b in range(8):
+        assert (got[0, b, :lens[b]] == ref[0, b, :lens[b]]).all(), b     # bit-exact indices
+    losses = [float(tr.training_step(batch, i)) for i in range(3)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    assert 0.3 < float(task.logged["mask_rate"]) < 0.7
