@@ -59,9 +59,20 @@ class Subsampling(nn.Module):
         return length
 
     def forward(self, x: torch.Tensor, length: torch.Tensor):
-        x = self.conv(x.unsqueeze(1))
+        # channel-last all the way: MIOpen's implicit-GEMM kernels are NHWC natively (an NCHW
+        # call wraps them in two transposes of the 32 x 256 x 498 x 39 activation), and the
+        # Linear consumes the (t, f, c) order through a column-permuted view of its weight
+        x = x.unsqueeze(1).contiguous(memory_format=torch.channels_last)
+        for m in self.conv:
+            if isinstance(m, nn.Conv2d):
+                x = F.conv2d(x, m.weight.contiguous(memory_format=torch.channels_last), m.bias,
+                             m.stride)
+            else:
+                x = m(x)
         b, c, t, f = x.size()
-        out = self.linear(x.transpose(1, 2).contiguous().view(b, t, c * f))
+        lin = self.linear[0] if isinstance(self.linear, nn.Sequential) else self.linear
+        wperm = lin.weight.view(-1, c, f).transpose(1, 2).reshape(-1, f * c)
+        out = zk.linear(x.permute(0, 2, 3, 1).reshape(b, t, f * c), wperm, lin.bias)
         length = self.subsampled_length(length)
         mask = torch.arange(t, device=length.device).unsqueeze(0) >= length.unsqueeze(1)
         out = out.masked_fill(mask.unsqueeze(-1), 0.0)
@@ -76,7 +87,9 @@ class _FeedForwardModule(nn.Module):
                                         nn.Linear(hidden_dim, input_dim), nn.Dropout(dropout))
 
     def forward(self, x):
-        return self.sequential(x)
+        ln, l1, act, d1, l2, d2 = self.sequential
+        h = act(zk.linear(ln(x), l1.weight, l1.bias))
+        return d2(zk.linear(d1(h), l2.weight, l2.bias))
 
 
 class _ConvolutionModule(nn.Module):
@@ -100,7 +113,7 @@ class _ConvolutionModule(nn.Module):
         pw1, _, dw, norm, act, pw2, drop = self.sequential
         T, B, D = x.shape
         x = self.layer_norm(x)
-        u = F.linear(x, pw1.weight.squeeze(-1), pw1.bias)            # (T,B,2C): [a | gate]
+        u = zk.linear(x, pw1.weight, pw1.bias)                        # (T,B,2C): [a | gate]
         C = u.shape[-1] // 2
         y = zk.glu_chunk_causal_dwconv(u, C, None, dw, -1)            # GLU + depthwise, fused
         if isinstance(norm, nn.BatchNorm1d):
@@ -108,7 +121,7 @@ class _ConvolutionModule(nn.Module):
         else:
             y = norm(y.permute(1, 2, 0)).permute(2, 0, 1)
         y = act(y)
-        y = F.linear(y, pw2.weight.squeeze(-1), pw2.bias)
+        y = zk.linear(y, pw2.weight, pw2.bias)
         return drop(y)
 
 
@@ -126,13 +139,30 @@ class ConformerLayer(nn.Module):
         self.final_layer_norm = nn.LayerNorm(input_dim)
         self.convolution_first = convolution_first
 
+    def _mhsa(self, x, key_padding_mask):
+        """nn.MultiheadAttention (no positional term) on (T,B,D): the in/out projections are
+        zk.linear (weight gradients accumulated in place by the TN MFMA GEMM), the softmax(QK^T)V
+        core is torch's fused SDPA kernel.  `self.self_attn` only holds the parameters, under
+        torchaudio's names."""
+        mha = self.self_attn
+        T, B, D = x.shape
+        H = mha.num_heads
+        qkv = zk.linear(x, mha.in_proj_weight, mha.in_proj_bias).view(T, B, 3, H, D // H)
+        q, k, v = (qkv[:, :, i].permute(1, 2, 0, 3) for i in range(3))      # (B,H,T,dh) views
+        mask = None
+        if key_padding_mask is not None:
+            mask = (~key_padding_mask).view(B, 1, 1, T)
+        p = mha.dropout if self.training else 0.0
+        o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, dropout_p=p)
+        o = o.permute(2, 0, 1, 3).reshape(T, B, D)
+        return zk.linear(o, mha.out_proj.weight, mha.out_proj.bias)
+
     def forward(self, x, key_padding_mask):
         x = self.ffn1(x) * 0.5 + x
         if self.convolution_first:
             x = x + self.conv_module(x)
         res = x
-        x = self.self_attn_layer_norm(x)
-        x, _ = self.self_attn(x, x, x, key_padding_mask=key_padding_mask, need_weights=False)
+        x = self._mhsa(self.self_attn_layer_norm(x), key_padding_mask)
         x = self.self_attn_dropout(x) + res
         if not self.convolution_first:
             x = x + self.conv_module(x)
@@ -179,5 +209,5 @@ class Conformer(nn.Module):
             feats = self._batchnorm(feats.transpose(1, 2)).transpose(1, 2)
         x, lengths = self._subsampling_module(feats, lengths)
         x, lengths = self._conformer_module(x, lengths)
-        logits = F.linear(x, self._output_layer.weight.squeeze(-1), self._output_layer.bias)
+        logits = zk.linear(x, self._output_layer.weight, self._output_layer.bias)
         return logits, lengths

@@ -673,8 +673,10 @@ def wgrad_into(wparam, bparam, g2, a2, pro=0):
     if not (wparam.is_leaf and flat.owned(wparam) and _tn_ok(g2) and _tn_ok(a2)):
         return False
     wg = wparam.grad
-    if wg is None or not wg.is_contiguous() or wg.dim() != 2:
+    if wg is None or not wg.is_contiguous() or wg.dim() < 2:
         return False
+    if wg.dim() > 2:                                 # (N, M, 1) weight of a 1x1 convolution
+        wg = wg.view(wg.shape[0], -1)
     bg = None
     if bparam is not None:
         if not (bparam.is_leaf and flat.owned(bparam)):
@@ -697,19 +699,21 @@ class _Linear(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.params = (weight, bias)
-        return F.linear(x, weight, bias)
+        w2 = weight if weight.dim() == 2 else weight.reshape(weight.shape[0], -1)   # 1x1 conv
+        return F.linear(x, w2, bias)
 
     @staticmethod
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
         wp, bp = ctx.params
+        w2 = weight if weight.dim() == 2 else weight.reshape(weight.shape[0], -1)
         g2 = g.reshape(-1, g.shape[-1])
         x2 = x.reshape(-1, x.shape[-1])
-        dx = g.matmul(weight) if ctx.needs_input_grad[0] else None
+        dx = g.matmul(w2) if ctx.needs_input_grad[0] else None
         if wgrad_into(wp, bp, g2, x2):
             return dx, None, None
         dw, db = linear_wgrad(g2, x2, bp is not None)
-        return dx, dw, db
+        return dx, dw.view(weight.shape), db
 
 
 def linear(x, weight, bias=None):
