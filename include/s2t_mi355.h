@@ -242,6 +242,21 @@ int s2t_smoothed_nll_bwd(const float* logits, const long* labels, const float* l
                          const float* row_weight, long rows, int K, float scale, float t_other,
                          float t_label, float* grad, void* stream);
 
+/* ---- validation-time greedy decoders (model/decoding.py:51-82 CtcGreedyDecoding, :196-271
+ * RnntGreedyDecoding; batch_search :27-48 calls them per utterance).  One launch per batch.
+ * s2t_ctc_greedy: logits [B][T][V] -> tokens [B][T] (first out_len[b] valid), argmax ties take
+ * the first index.  s2t_rnnt_greedy_stateless: am [B][T][V] = joiner enc_proj(encoder_out);
+ * stateless predictor parameters (embedding [S][E], depthwise conv [E][ctx], linear [D][E]+[D]),
+ * joiner pre_proj [V][D]+[V]; act 0 relu / 1 tanh; at most max_token_step+1 symbols per frame
+ * as the reference loop; tokens [B][max_out]. */
+int s2t_ctc_greedy(const float* logits, const long* lengths, int B, int T, int V, int blank,
+                   long* tokens, long* out_len, void* stream);
+int s2t_rnnt_greedy_stateless(const float* am, const long* lengths, const float* emb,
+                              const float* conv_w, const float* lin_w, const float* lin_b,
+                              const float* pre_w, const float* pre_b, int B, int T, int V, int E,
+                              int D, int ctx, int act, int max_token_step, int max_out, int blank,
+                              long* tokens, long* out_len, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

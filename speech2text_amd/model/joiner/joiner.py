@@ -105,3 +105,11 @@ class Joiner(nn.Module):
             return lattice, boundary, ranges, simple_loss
         joint = am.unsqueeze(2).contiguous() + lm.unsqueeze(1).contiguous()
         return self._out_projection(self._activation(joint)), None, None, None
+
+    def streaming_step(self, encoder_out: torch.Tensor, predictor_out: torch.Tensor):
+        """(1,1,D) x (beam,1,D) -> (beam,V) log-probabilities (reference joiner.py:186-207)."""
+        assert encoder_out.shape[0] == 1 and encoder_out.shape[1] == 1
+        assert predictor_out.shape[1] == 1
+        joint = self._enc_proj(encoder_out).unsqueeze(2) + self._pre_proj(predictor_out).unsqueeze(1)
+        out = self._out_projection(self._activation(joint))
+        return out.log_softmax(dim=-1).squeeze(1).squeeze(1)

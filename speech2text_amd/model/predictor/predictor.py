@@ -56,8 +56,21 @@ class StatelessPredictor(nn.Module):
         out = self._conv(emb).transpose(1, 2)                       # (B, U+1, D)
         return self._output_linear(out), lengths, out_state
 
+    def streaming_step(self, input: torch.Tensor, state: torch.Tensor):
+        """One token in, one prediction out; state = the previous context-1 tokens
+        (reference stateless_predictor.py:109-125)."""
+        assert input.shape[1] == 1
+        ctxed = torch.cat([state.to(input.device), input.to(state.dtype)], dim=1)
+        out_state = ctxed[:, ctxed.shape[1] - self._context_size + 1:]
+        emb = self._embedding(ctxed).transpose(1, 2)
+        out = self._conv(emb).transpose(1, 2)
+        return self._output_linear(out), out_state
+
 
 class Predictor(nn.Module):
+    def streaming_step(self, input, state):
+        return self.predictor.streaming_step(input, state)
+
     def __init__(self, config) -> None:
         super().__init__()
         if config["model"] == "Stateless":

@@ -16,4 +16,4 @@ def test_header_symbols_exported():
 
 def test_ctc_workspace_size_is_pure_host_function():
     lib = _native.lib()
-    assert lib.s2t_ctc_workspace_floats(2, 10, 3) == 2 * 10 + 2 * 10 * 7 + 2
+    assert lib.s2t_ctc_workspace_floats(2, 10, 3) == 2 * 10 + 3 * 2 * 10 * 7 + 2   # lse + lp,alpha,beta + nll

@@ -1,0 +1,126 @@
+"""Greedy decoders + WER.  CPU: the oracle against the reference's own known-answer tests
+(model/decoding_test.py:19-116, model/utils_test.py:19-57).  GPU: the product (csrc/decode.hip)
+against the same known answers and against the oracle on random lattices."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import decoding as OD
+
+# the literal (T=8, V=6) matrix of the reference tests (char labels a,b,c -> ids 2,3,4)
+_LOGITS = np.array([[0.6, 0.0, 0.2, 0.1, 0.1, 0.0], [1.0, 0, 0, 0, 0, 0], [0, 0, 1.0, 0, 0, 0],
+                    [0, 0, 1.0, 0, 0, 0], [1.0, 0, 0, 0, 0, 0], [1.0, 0, 0, 0, 0, 0],
+                    [0, 0, 0, 1.0, 0, 0], [0, 0, 0, 0, 1.0, 0]], np.float32)
+_CHAR = {"type": "char", "config": {"labels": ["a", "b", "c"]}}
+
+
+def test_oracle_known_answers():
+    from speech2text_amd.dataset.utils import TokenizerSetup
+    tok = TokenizerSetup(_CHAR)
+    assert tok.labels == ["<blank_id>", "<unk>", "a", "b", "c", "<sos/eos>"]
+    dec = lambda n: tok.decode(torch.tensor(OD.ctc_greedy(_LOGITS, n)))   # noqa: E731
+    assert dec(8) == "abc" and dec(3) == "a"
+    # utils_test.py: ground truth ("aabb", "abc"); hypotheses ("abc","abc") -> 0.5, ("abc","a") -> 1.0
+    assert OD.word_error_rate(["abc", "abc"], ["aabb", "abc"]) == 0.5
+    assert OD.word_error_rate(["abc", "a"], ["aabb", "abc"]) == 1.0
+    assert OD.levenshtein("kitten", "sitting") == 3
+
+
+def test_product_wer_and_reference_decoder_host_logic():
+    from speech2text_amd.dataset.utils import TokenizerSetup
+    from speech2text_amd.model.decoding import reference_decoder
+    from speech2text_amd.model.utils import _levenshtein, word_error_rate
+    tok = TokenizerSetup(_CHAR)
+    assert reference_decoder(torch.tensor([[2, 2, 3, 3], [2, 3, 4, 0]]), tok) == ["aabb", "abc"]
+    assert word_error_rate(["abc", "abc"], ["aabb", "abc"]) == 0.5
+    assert word_error_rate(["abc", "a"], ["aabb", "abc"], show_on_screen=False) == 1.0
+    assert word_error_rate(["ab c"], ["a b c"], use_cer=True) == pytest.approx(1 / 5)
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        a, b = (rng.integers(0, 4, rng.integers(0, 9)).tolist() for _ in range(2))
+        assert _levenshtein(a, b) == OD.levenshtein(a, b)
+    with pytest.raises(ValueError):
+        word_error_rate(["a"], ["a", "b"])
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/sample_data/spm/tokenizer.model"),
+                    reason="reference sample_data not present")
+def test_subword_tokenizer_roundtrip_as_reference_test():
+    from speech2text_amd.dataset.utils import TokenizerSetup
+    tok = TokenizerSetup({"type": "subword", "config": {
+        "spm_model": "/root/reference/sample_data/spm/tokenizer.model",
+        "spm_vocab": "/root/reference/sample_data/spm/tokenizer.vocab"}})
+    assert len(tok.labels) == 128                      # decoding_test.py uses (.., 128) logits
+    for ref in ["abc", "aabc", "i love china", "bilibili is good"]:
+        assert tok.decode(tok.encode(ref)) == ref
+    # decoding_test.py:99-116: ids [0,0,24,30,30,0,2] collapse to "that is"
+    lg = np.zeros((7, 128), np.float32)
+    for t, i in enumerate([0, 0, 24, 30, 30, 0, 2]):
+        lg[t, i] = 1
+    assert tok.decode(torch.tensor(OD.ctc_greedy(lg, 7))) == "that is"
+
+
+@pytest.mark.gpu
+def test_ctc_greedy_kernel_known_answers_and_random(dev):
+    from speech2text_amd.dataset.utils import TokenizerSetup
+    from speech2text_amd.model.decoding import CtcGreedyDecoding, batch_search, ctc_greedy_tokens
+    from speech2text_amd.model.utils import AsrMetric, AsrMetricConfig
+    tok = TokenizerSetup(_CHAR)
+    sess = CtcGreedyDecoding(tokenizer=tok)
+    lg = torch.from_numpy(_LOGITS).unsqueeze(0).repeat(2, 1, 1).to(dev)
+    assert batch_search(lg, torch.tensor([8, 8]), sess) == ["abc", "abc"]
+    assert batch_search(lg, torch.tensor([8, 3]), sess) == ["abc", "a"]
+    assert sess.decode(lg[:1]) == "abc"
+    metric = AsrMetric(tok, AsrMetricConfig(decode_method="ctc_greedy_search"))
+    gt = torch.tensor([[2, 2, 3, 3], [2, 3, 4, 0]])
+    assert metric(lg, torch.tensor([8, 8]), gt) == 0.5       # utils_test.py:49-57
+    assert metric(lg, torch.tensor([8, 3]), gt) == 1.0
+    g = torch.Generator().manual_seed(1)
+    B, T, V = 9, 300, 128
+    x = torch.randn(B, T, V, generator=g)
+    x[:, :, 0] += 2.0                                         # plenty of blanks and repeats
+    x[:, 1::3] = x[:, 0::3][:, :x[:, 1::3].shape[1]]
+    lens = torch.randint(1, T + 1, (B,), generator=g)
+    lens[0] = T
+    tokens, n = ctc_greedy_tokens(x.to(dev), lens)
+    for b in range(B):
+        ref = OD.ctc_greedy(x[b].numpy(), int(lens[b]))
+        assert tokens[b, :int(n[b])].cpu().tolist() == ref
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("act,mts", [("relu", 5), ("tanh", 1)])
+def test_rnnt_greedy_kernel_vs_oracle(dev, act, mts):
+    from speech2text_amd.dataset.utils import TokenizerSetup
+    from speech2text_amd.model.decoding import RnntGreedyDecoding
+    from speech2text_amd.model.joiner.joiner import Joiner, JoinerConfig
+    from speech2text_amd.model.predictor.predictor import Predictor
+    torch.manual_seed(3)
+    V, D, E, ctx = 40, 48, 32, 5
+    pred = Predictor({"model": "Stateless", "config": {"num_symbols": V, "output_dim": D,
+                                                       "symbol_embedding_dim": E, "context_size": ctx}})
+    join = Joiner(JoinerConfig(input_dim=D, output_dim=V, activation=act, prune_range=5,
+                               use_out_project=False))
+    with torch.no_grad():
+        for p in list(pred.parameters()) + list(join.parameters()):
+            p.mul_(3.0 if act == "relu" else 0.6)               # separated argmax, tanh unsaturated
+    sd = {"p." + k: v.detach().clone() for k, v in pred.predictor.state_dict().items()}
+    sd.update({"j." + k: v.detach().clone() for k, v in join.state_dict().items()})
+    pred.to(dev)
+    join.to(dev)
+    tok = TokenizerSetup({"type": "char", "config": {"labels": [chr(97 + i) for i in range(V - 3)]}})
+    sess = RnntGreedyDecoding(tok, pred, join, max_token_step=mts)
+    enc = torch.randn(4, 37, D) * (1.5 if act == "relu" else 0.5)
+    lens = torch.tensor([37, 30, 11, 1])
+    tokens, n = sess.greedy_tokens(enc.to(dev), lens)
+    total = 0
+    for b in range(4):
+        ref = OD.rnnt_greedy_stateless(sd, "p.", "j.", enc[b], int(lens[b]), ctx, act, mts)
+        assert tokens[b, :int(n[b])].cpu().tolist() == ref, b
+        total += len(ref)
+    assert total > 10                                          # the walk really emits symbols
+    texts = sess.decode_batch(enc.to(dev), lens)
+    assert texts[0] == tok.decode(tokens[0, :int(n[0])].cpu())
+    assert sess.decode(enc[2:3, :11].to(dev)) == texts[2]
