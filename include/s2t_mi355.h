@@ -257,6 +257,26 @@ int s2t_rnnt_greedy_stateless(const float* am, const long* lengths, const float*
                               int D, int ctx, int act, int max_token_step, int max_out, int blank,
                               long* tokens, long* out_len, void* stream);
 
+/* ---- batched on-device augmentation + collate next to the fbank kernel
+ * (dataset/frontend/data_augmentation.py:13-56 AddNoise, :59-118 MixFeats, :150-196 SpecAugment;
+ * dataset/utils.py:182-202 batch()).  Random decisions are made on the host as the reference
+ * does; each op is one launch over the padded batch.
+ * s2t_row_energy: out[b] = sum over the len[b]*D valid elements of exp(x) (mode 0) or x^2 (mode 1).
+ * s2t_mix: mode 0 MixFeats on log-mel (T,D) rows, mode 1 AddNoise on PCM (D = 1); the noise is
+ *   indexed (start[b] + t) mod nlen[b] (= the reference's repeat + slice).
+ * s2t_specaug: zero the nt time spans and nf frequency spans (start, end) of each utterance.
+ * s2t_pad_rows: packed rows + element offsets [B+1] -> zero-padded (B, Lmax, D). */
+int s2t_row_energy(const float* x, long stride, const long* len, int B, int D, int mode, float* out,
+                   void* stream);
+int s2t_mix(const float* src, long sstride, const long* slen, const float* noise, long nstride,
+            const long* nlen, const long* start, const float* snr, const float* src_e,
+            const float* noise_e, int B, long rows_max, int D, int mode, float max_gain_db,
+            float* out, void* stream);
+int s2t_specaug(float* feats, int B, int T, int F, const int* tspan, int nt, const int* fspan,
+                int nf, void* stream);
+int s2t_pad_rows(const float* packed, const long* offsets, int B, long Lmax, int D, float* out,
+                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif

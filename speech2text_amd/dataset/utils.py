@@ -100,3 +100,42 @@ def TokenizerSetup(config) -> Tokenizer:
     if config["type"] == "subword":
         return SubwordTokenizer(config=SubwordTokenizerConfig(**config["config"]))
     raise ValueError("Only 'char' and 'subword' tokenizer supported currently.")
+
+
+def batch(batch, device=None):
+    """Pads the variable-length entries of a batch dict and stacks them (reference
+    dataset/utils.py:182-202 `batch`: pad_sequence per key on the CPU).  Here the rows are
+    packed once and scattered into the zero-padded (B, Lmax, D) device tensor by one kernel."""
+    from speech2text_amd import _native as N
+
+    def pad(rows, dtype):
+        dev = device or rows[0].device
+        if dtype == torch.int64:                       # labels: tiny, plain torch
+            return torch.nn.utils.rnn.pad_sequence([r.to(dev) for r in rows], batch_first=True,
+                                                   padding_value=0)
+        rows = [r.to(device=dev, dtype=torch.float32) for r in rows]
+        if not rows[0].is_cuda:
+            raise RuntimeError("speech2text_amd collate runs on the GPU only (no CPU fallback)")
+        D = 1 if rows[0].dim() == 1 else rows[0].shape[-1]
+        lens = [r.shape[0] for r in rows]
+        offs = [0]
+        for n in lens:
+            offs.append(offs[-1] + n * D)
+        packed = torch.cat([r.reshape(-1) for r in rows])
+        Lmax = max(lens)
+        out = torch.empty((len(rows), Lmax) + (() if rows[0].dim() == 1 else (D,)),
+                          dtype=torch.float32, device=dev)
+        N.check(N.lib().s2t_pad_rows(N.fp(packed), N.lp(torch.tensor(offs, device=dev)), len(rows),
+                                     Lmax, D, N.fp(out), N.stream()), "s2t_pad_rows")
+        return out
+
+    if "feat" in batch and "label" in batch:
+        batch["feat"] = pad(batch["feat"], torch.float32)
+        batch["feat_length"] = torch.tensor(batch["feat_length"]).long()
+        batch["label"] = pad([l.long() for l in batch["label"]], torch.int64)
+        batch["label_length"] = torch.tensor(batch["label_length"]).long()
+    elif "raw_feat" in batch and "auged_feat" in batch:
+        batch["raw_feat"] = pad(batch["raw_feat"], torch.float32)
+        batch["auged_feat"] = pad(batch["auged_feat"], torch.float32)
+        batch["feat_length"] = torch.tensor(batch["feat_length"]).long()
+    return batch

@@ -314,6 +314,93 @@ def gen_heads():
     print("heads:", len(out), "arrays")
 
 
+def gen_aug():
+    """SpecAugment / MixFeats / AddNoise / DynamicBucketBatchSampler run from the reference tree
+    (third-party torchaudio / pytorch_lightning stubbed; they are not touched by these classes)
+    with Python `random` seeded: inputs, the draws' seed and the outputs."""
+    import importlib.machinery
+    import random
+    import types
+    import torch
+    ref_import.install_stubs()
+    for name in ("torchaudio", "torchaudio.sox_effects", "sentencepiece"):
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                m = types.ModuleType(name)
+                m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+                sys.modules[name] = m
+    from dataset.frontend.data_augmentation import AddNoise, MixFeats, SpecAugment
+    rng = np.random.default_rng(99)
+    out = {}
+    # ---- SpecAugment: 3 utterances, sequential calls under one seed
+    feats = [torch.from_numpy(rng.standard_normal((T, 80)).astype(np.float32)) for T in (120, 57, 300)]
+    random.seed(4321)
+    sa = SpecAugment(num_t_mask=2, num_f_mask=2, max_t=50, max_f=10)
+    for i, f in enumerate(feats):
+        out[f"sa_in{i}"] = f.numpy()
+        out[f"sa_out{i}"] = sa.process(f).numpy()
+    # ---- MixFeats: noise shorter and longer than the source
+    random.seed(4322)
+    mf = MixFeats(snrs=(10, 20))
+    for i, (T, Tn) in enumerate([(100, 37), (64, 200), (150, 150)]):
+        src = torch.from_numpy((rng.standard_normal((T, 80)) * 2 - 3).astype(np.float32))
+        nz = torch.from_numpy((rng.standard_normal((Tn, 80)) * 2 - 5).astype(np.float32))
+        out[f"mf_src{i}"], out[f"mf_noise{i}"] = src.numpy(), nz.numpy()
+        out[f"mf_out{i}"] = mf.process(src, nz).numpy()
+    # ---- AddNoise (it scales its noise argument in place: pass a copy)
+    random.seed(4323)
+    an = AddNoise(min_snr_db=10, max_snr_db=50)
+    for i, (n, m) in enumerate([(4000, 1500), (2000, 6000), (3001, 3001)]):
+        pcm = torch.from_numpy((rng.standard_normal((1, n)) * 0.1).astype(np.float32))
+        nz = torch.from_numpy((rng.standard_normal((1, m)) * 0.05).astype(np.float32))
+        out[f"an_pcm{i}"], out[f"an_noise{i}"] = pcm.numpy(), nz.numpy()
+        out[f"an_out{i}"] = an.process(pcm.clone(), nz.clone()).numpy()
+    # ---- DynamicBucketBatchSampler on a synthetic duration table
+    try:
+        for _ in range(12):                                  # stub whatever third-party wheel is absent
+            try:
+                from dataset.sampler import DynamicBucketBatchSampler
+                break
+            except ModuleNotFoundError as e:
+                name = e.name
+                assert not os.path.exists(os.path.join("/root/reference", name.split(".")[0])), name
+                m = types.ModuleType(name)
+                m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+                m.__path__ = []
+                m.__getattr__ = lambda attr, _n=name: type(attr, (), {})
+                sys.modules[name] = m
+        durs = rng.uniform(1.0, 15.0, size=400)
+
+        class DS:
+            lower_bound, high_bound, total_data_amount = 1.0, 15.0, float(durs.sum())
+
+            def fetch_data_k_info(self, i, k="duration"):
+                return float(durs[i])
+
+        class SM:
+            rank, num_replicas = 0, 1
+
+            def __iter__(self):
+                return iter(range(400))
+
+            def __len__(self):
+                return 400
+
+        bs = DynamicBucketBatchSampler(SM(), DS(), num_bucket=6, min_batch_size=4, volume_threshold=60)
+        it = iter(bs)
+        batches = [next(it) for _ in range(25)]
+        out["bs_durs"] = durs
+        out["bs_len"] = np.array([len(bs)])
+        out["bs_sizes"] = np.array([len(b) for b in batches])
+        out["bs_flat"] = np.array([i for b in batches for i in b])
+    except Exception as e:                                  # dataset.dataset needs more wheels
+        print("sampler golden skipped:", type(e).__name__, e)
+    np.savez_compressed(os.path.join(OUT, "aug_ref.npz"), **out)
+    print("aug:", len(out), "arrays")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ["fbank", "ctc", "bestrq", "zipformer", "scaledadam"]
