@@ -1,0 +1,97 @@
+"""HBM traffic per launch of every hand-written entry point, from two rocprofv3 PMC passes
+(FETCH_SIZE and WRITE_SIZE collected in SEPARATE runs, as MI355X_MICROARCH.md prescribes) over
+the same bench command.  Units / gfx950 corrections per that guide's HBM section: both counters
+are in KiB; FETCH_SIZE counts a wide coalesced streaming read at exactly half its bytes, so the
+read side is reported raw and doubled (`hbm_bytes_per_launch` uses the doubled value);
+WRITE_SIZE is exact for 16-byte stores and float atomics.
+
+    python tools/pmc_traffic.py FETCH_DIR WRITE_DIR [out.json]
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+# kernel-name substring -> (C entry point, is_primary): the primary kernel counts the launches
+KERNELS = [
+    ("attn_fwd_mfma_kernel", "s2t_relpos_attn_fwd", True), ("attn_fwd_kernel", "s2t_relpos_attn_fwd", True),
+    ("attn_bwd_q", "s2t_relpos_attn_bwd", True), ("attn_bwd_k", "s2t_relpos_attn_bwd", False),
+    ("dpos_reduce", "s2t_relpos_attn_bwd", False),
+    ("attn_apply_kernel", "s2t_attn_apply", True),
+    ("gemm_kernel", "s2t_gemm_f32", True),
+    ("wgrad_kernel", "s2t_linear_wgrad", True), ("wgrad_reduce_kernel", "s2t_linear_wgrad", False),
+    ("zipconv_fwd_kernel", "s2t_zipconv_fwd", True),
+    ("zipconv_bwd_data_kernel", "s2t_zipconv_bwd", True), ("zipconv_bwd_w_kernel", "s2t_zipconv_bwd", False),
+    ("zipconv_reduce_w_kernel", "s2t_zipconv_bwd", False),
+    ("swoosh_fwd_kernel", "s2t_swoosh_fwd", True), ("swoosh_bwd_kernel", "s2t_swoosh_bwd", True),
+    ("biasnorm_fwd_kernel", "s2t_biasnorm_fwd", True), ("biasnorm_bwd_kernel", "s2t_biasnorm_bwd", True),
+    ("col_stats_kernel", "s2t_col_stats", True), ("balancer_apply_kernel", "s2t_balancer_apply", True),
+    ("whiten_apply_kernel", "s2t_whiten_apply", True), ("sumsq2_kernel", "s2t_whiten_apply", False),
+    ("mi_fwd_kernel", "s2t_mutual_info_fwd", True), ("mi_bwd_kernel", "s2t_mutual_info_bwd", True),
+    ("pruned_fwd", "s2t_rnnt_pruned_fwd", True), ("pruned_bwd", "s2t_rnnt_pruned_bwd", True),
+    ("simple_pxpy", "s2t_rnnt_simple_pxpy", True), ("simple_bwd", "s2t_rnnt_simple_bwd", True),
+    ("row_exp", "s2t_rnnt_row_exp", True),
+    ("ctc_alpha_beta_kernel", "s2t_ctc_loss_fwd_bwd", True), ("ctc_lse_gather_kernel", "s2t_ctc_loss_fwd_bwd", False),
+    ("ctc_grad_kernel", "s2t_ctc_loss_fwd_bwd", False),
+    ("fbank", "s2t_fbank_f32", True),
+    ("seg_stats_kernel", "s2t_seg_stats", True), ("scaled_adam_apply_kernel", "s2t_scaled_adam_apply", True),
+    ("dwconv2d_kernel", "s2t_dwconv2d_nhwc_fwd", True), ("dwconv2d_wgrad_kernel", "s2t_dwconv2d_nhwc_wgrad", True),
+    ("dwconv2d_wreduce_kernel", "s2t_dwconv2d_nhwc_wgrad", False),
+    ("smoothed_nll_fwd_kernel", "s2t_smoothed_nll_fwd", True), ("smoothed_nll_bwd_kernel", "s2t_smoothed_nll_bwd", True),
+    ("bestrq", "s2t_bestrq_labels", True),
+]
+
+
+def entry_of(kname):
+    best = None
+    for sub, entry, prim in KERNELS:
+        if sub in kname and (best is None or len(sub) > len(best[0])):
+            best = (sub, entry, prim)
+    return best
+
+
+def collect(d, counter):
+    files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    assert files, f"no counter_collection.csv under {d}"
+    tot = collections.defaultdict(float)
+    cnt = collections.defaultdict(int)
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            e = entry_of(r["Kernel_Name"])
+            if e is None:
+                continue
+            tot[e[1]] += float(r["Counter_Value"])
+            if e[2]:
+                cnt[e[1]] += 1
+    return tot, cnt
+
+
+def main(fetch_dir, write_dir, out):
+    ft, fc = collect(fetch_dir, "FETCH_SIZE")
+    wt, wc = collect(write_dir, "WRITE_SIZE")
+    res = {}
+    for e in sorted(set(ft) | set(wt)):
+        n = fc.get(e) or wc.get(e)
+        if not n:
+            continue
+        fetch_raw = 1024.0 * ft.get(e, 0.0) / n
+        write = 1024.0 * wt.get(e, 0.0) / max(1, wc.get(e, n))
+        res[e] = {"launches_sampled": n, "fetch_bytes_raw_per_launch": fetch_raw,
+                  "fetch_bytes_x2_per_launch": 2.0 * fetch_raw, "write_bytes_per_launch": write,
+                  "hbm_bytes_per_launch": 2.0 * fetch_raw + write,
+                  "note": "mean over the launches of the C3 bench steps; FETCH_SIZE raw and x2 "
+                          "(gfx950 half-count of wide streaming reads), WRITE_SIZE exact"}
+    json.dump(res, open(out, "w"), indent=1)
+    for e, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
+        print(f"{e:28s} n={v['launches_sampled']:5d} fetch(x2) {v['fetch_bytes_x2_per_launch']/1e6:9.2f} MB "
+              f"write {v['write_bytes_per_launch']/1e6:9.2f} MB")
+
+
+if __name__ == "__main__":
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    main(sys.argv[1], sys.argv[2],
+         sys.argv[3] if len(sys.argv) > 3 else os.path.join(root, "profiles", "roofline_traffic.json"))
