@@ -277,6 +277,16 @@ int s2t_specaug(float* feats, int B, int T, int F, const int* tspan, int nt, con
 int s2t_pad_rows(const float* packed, const long* offsets, int B, long Lmax, int D, float* out,
                  void* stream);
 
+/* ---- plain dense GEMMs of the Linear layers through hipBLASLt's C API (csrc/gemm_lib.hip), with
+ * bias and residual / accumulation in the epilogue (model/encoder/zipformer.py:1095-1221
+ * `src = src + module(src)`, and the data gradients under loss.backward()).
+ * mode 0: D[M,N] = X[M,K] W[N,K]^T (+ bias[N]) (+ beta C[M,N]);  mode 1: D[M,K] = X[M,N] W[N,K] (+ beta C).
+ * Row-major, leading dimensions in floats; C may be NULL (beta ignored) or alias D.  Returns -2 when
+ * the library offers no algorithm for the shape (the caller then uses torch.matmul). */
+int s2t_linear_lt(int mode, const float* X, long ldx, const float* W, long ldw, const float* bias,
+                  const float* C, long ldc, float beta, float* D, long ldd, int M, int N, int K,
+                  void* workspace, long ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,7 +66,8 @@ def build(force=False, verbose=True):
                 if verbose:
                     print(f"[s2t build] compiled {os.path.basename(s)}")
     if force or jobs or _stale(LIB, objs):
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs + \
+            ["-L/opt/rocm/lib", "-lhipblaslt"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stdout + r.stderr)

@@ -1,0 +1,107 @@
+// Thin host-side caller of hipBLASLt for the PLAIN dense GEMMs of the training path (forward
+// y = x W^T and data gradient dx = g W of every Linear).  "hipBLASLt only for plain library
+// GEMMs": no kernel here, just the C API driven directly (one heuristic query per distinct
+// shape, then cached) so that
+//   * bias AND residual ride in the GEMM epilogue (D = A B + bias + beta C): the reference's
+//     `src = src + linear(h)` (model/encoder/zipformer.py:1095-1221) is one launch, and a data
+//     gradient can be accumulated onto an existing gradient (beta = 1);
+//   * the host pays a ~µs table lookup per call instead of a framework dispatch.
+// hipBLASLt is column-major; a row-major (rows, cols, ld) matrix is passed as the column-major
+// (cols, rows, ld) one, i.e. the row-major product Y = X W^T is computed as Y^T = W X^T.
+#include <hip/hip_runtime.h>
+#include <hipblaslt/hipblaslt.h>
+
+#include <map>
+#include <mutex>
+#include <tuple>
+
+namespace {
+
+struct Plan {
+  hipblasLtMatmulDesc_t desc = nullptr;
+  hipblasLtMatrixLayout_t a = nullptr, b = nullptr, c = nullptr, d = nullptr;
+  hipblasLtMatmulAlgo_t algo;
+  size_t ws = 0;
+  bool ok = false;
+};
+
+using Key = std::tuple<int, int, int, int, long, long, long, long, int>;
+std::map<Key, Plan> g_plans;
+std::mutex g_mu;
+hipblasLtHandle_t g_handle = nullptr;
+
+#define LT_CHECK(x)                                   \
+  do {                                                \
+    hipblasStatus_t s__ = (x);                        \
+    if (s__ != HIPBLAS_STATUS_SUCCESS) return -100 - (int)s__; \
+  } while (0)
+
+int make_plan(Plan& p, int mode, int M, int N, int K, long ldx, long ldw, long ldc, long ldd,
+              bool has_bias, size_t ws_bytes) {
+  if (!g_handle) LT_CHECK(hipblasLtCreate(&g_handle));
+  LT_CHECK(hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F));
+  // mode 0: Yc (N x M) = op_T(Wc: K x N, ld ldw) . Xc (K x M, ld ldx)
+  // mode 1: dXc (K x M) = Wc (K x N, ld ldw) . Gc (N x M, ld ldx)      (x := g, output cols := K)
+  hipblasOperation_t opa = mode == 0 ? HIPBLAS_OP_T : HIPBLAS_OP_N, opb = HIPBLAS_OP_N;
+  LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &opa, sizeof(opa)));
+  LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &opb, sizeof(opb)));
+  if (has_bias) {
+    hipblasLtEpilogue_t epi = HIPBLASLT_EPILOGUE_BIAS;
+    LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof(epi)));
+  }
+  const int out_rows = mode == 0 ? N : K;     // column-major rows of the result = output features
+  const int inner = mode == 0 ? K : N;
+  LT_CHECK(hipblasLtMatrixLayoutCreate(&p.a, HIP_R_32F, K, N, ldw));
+  LT_CHECK(hipblasLtMatrixLayoutCreate(&p.b, HIP_R_32F, inner, M, ldx));
+  LT_CHECK(hipblasLtMatrixLayoutCreate(&p.c, HIP_R_32F, out_rows, M, ldc));
+  LT_CHECK(hipblasLtMatrixLayoutCreate(&p.d, HIP_R_32F, out_rows, M, ldd));
+  hipblasLtMatmulPreference_t pref;
+  LT_CHECK(hipblasLtMatmulPreferenceCreate(&pref));
+  LT_CHECK(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES,
+                                                 &ws_bytes, sizeof(ws_bytes)));
+  hipblasLtMatmulHeuristicResult_t res[1];
+  int n = 0;
+  hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(g_handle, p.desc, p.a, p.b, p.c, p.d, pref, 1,
+                                                       res, &n);
+  hipblasLtMatmulPreferenceDestroy(pref);
+  if (st != HIPBLAS_STATUS_SUCCESS || n < 1) return -2;      // caller falls back
+  p.algo = res[0].algo;
+  p.ws = res[0].workspaceSize;
+  p.ok = true;
+  return 0;
+}
+
+}  // namespace
+
+// mode 0: D[M,N] = X[M,K] W[N,K]^T (+ bias[N]) (+ beta C[M,N]);   mode 1: D[M,K] = X[M,N] W[N,K] (+ beta C[M,K]).
+// Row-major, leading dimensions in floats.  C may be NULL when beta == 0, and may alias D.
+// Returns 0, -2 when hipBLASLt has no algorithm for the shape (caller falls back), or < -100.
+extern "C" int s2t_linear_lt(int mode, const float* X, long ldx, const float* W, long ldw,
+                             const float* bias, const float* C, long ldc, float beta, float* D,
+                             long ldd, int M, int N, int K, void* workspace, long ws_bytes,
+                             void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || (mode != 0 && mode != 1)) return -1;
+  if (mode == 1 && bias) return -1;
+  std::lock_guard<std::mutex> lock(g_mu);
+  if (!C) {
+    C = D;
+    ldc = ldd;
+    beta = 0.f;
+  }
+  const Key key{mode, M, N, K, ldx, ldw, ldc, ldd, bias ? 1 : 0};
+  auto it = g_plans.find(key);
+  if (it == g_plans.end()) {
+    Plan p;
+    const int rc = make_plan(p, mode, M, N, K, ldx, ldw, ldc, ldd, bias != nullptr, (size_t)ws_bytes);
+    it = g_plans.emplace(key, p).first;
+    if (rc != 0 && rc != -2) return rc;
+  }
+  Plan& p = it->second;
+  if (!p.ok || p.ws > (size_t)ws_bytes) return -2;
+  if (bias)
+    LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)));
+  const float alpha = 1.f;
+  LT_CHECK(hipblasLtMatmul(g_handle, p.desc, &alpha, W, p.a, X, p.b, &beta, C, p.c, D, p.d, &p.algo,
+                           workspace, p.ws, (hipStream_t)stream));
+  return 0;
+}

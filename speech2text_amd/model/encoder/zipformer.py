@@ -429,10 +429,18 @@ class SelfAttention(nn.Module):
         self.whiten = Whiten(num_groups=1, whitening_limit=_whitening_schedule(7.5, ratio=3.0),
                              prob=(0.025, 0.25), grad_scale=0.01)
 
-    def forward(self, x: Tensor, attn_weights: Tensor) -> Tensor:
+    def forward(self, x: Tensor, attn_weights: Tensor, residual: Optional[Tensor] = None) -> Tensor:
+        """With `residual` the result is residual + module(x); when the output Whiten does not
+        fire this step the add rides in the out_proj GEMM's epilogue."""
         v = self.in_proj(x)
         x = zk.attention_apply(attn_weights, v, attn_weights.shape[0])
-        return self.whiten(self.out_proj(x))
+        fw = self.whiten.fires(x)
+        if residual is not None and not fw:
+            return zk.linear(x, self.out_proj.weight, self.out_proj.bias, residual=residual)
+        x = self.out_proj(x)
+        if fw:
+            x = self.whiten.shape_grad(x)
+        return x if residual is None else residual + x
 
 
 class FeedforwardModule(nn.Module):
@@ -448,9 +456,22 @@ class FeedforwardModule(nn.Module):
         self.out_whiten = Whiten(num_groups=1, whitening_limit=_whitening_schedule(7.5),
                                  prob=(0.025, 0.25), grad_scale=0.01)
 
-    def forward(self, x: Tensor):
+    def forward(self, x: Tensor, residual: Optional[Tensor] = None, post=None):
+        """`post`: the layer's Balancer applied to this module's output (its random draw is made
+        here, right after out_whiten's, i.e. in the reference's order).  With `residual` the
+        result is residual + post(module(x)); if neither gradient-shaping op fires this step the
+        add is fused into the out_proj GEMM."""
         x = self.hidden_balancer(self.in_proj(x))
-        return self.out_whiten(self.out_proj(x))
+        fw = self.out_whiten.fires(x)
+        fp = post.fires(x) if post is not None else False
+        if residual is not None and not fw and not fp:
+            return self.out_proj(x, residual=residual)
+        x = self.out_proj(x)
+        if fw:
+            x = self.out_whiten.shape_grad(x)
+        if fp:
+            x = post.shape_grad(x)
+        return x if residual is None else residual + x
 
 
 class NonlinAttention(nn.Module):
@@ -471,12 +492,23 @@ class NonlinAttention(nn.Module):
         self.whiten2 = Whiten(num_groups=1, whitening_limit=_whitening_schedule(5.0, ratio=3.0),
                               prob=(0.025, 0.25), grad_scale=0.01)
 
-    def forward(self, x: Tensor, attn_weights: Tensor) -> Tensor:
+    def forward(self, x: Tensor, attn_weights: Tensor, residual: Optional[Tensor] = None,
+                post=None) -> Tensor:
         s, x, y = self.in_proj(x).chunk(3, dim=2)
         s = self.tanh(self.balancer(s))
         x = self.whiten1(x) * s
         x = zk.attention_apply(attn_weights, x, attn_weights.shape[0])
-        return self.whiten2(self.out_proj(x * y))
+        x = x * y
+        fw = self.whiten2.fires(x)
+        fp = post.fires(x) if post is not None else False
+        if residual is not None and not fw and not fp:
+            return zk.linear(x, self.out_proj.weight, self.out_proj.bias, residual=residual)
+        x = self.out_proj(x)
+        if fw:
+            x = self.whiten2.shape_grad(x)
+        if fp:
+            x = post.shape_grad(x)
+        return x if residual is None else residual + x
 
 
 class ConvolutionModule(nn.Module):
@@ -510,7 +542,7 @@ class ConvolutionModule(nn.Module):
                                                    dropout_p=0.0, initial_scale=0.05)
 
     def forward(self, x: Tensor, src_key_padding_mask: Optional[Tensor] = None,
-                chunk_size: int = -1) -> Tensor:
+                chunk_size: int = -1, residual: Optional[Tensor] = None) -> Tensor:
         u = self.in_proj(x)                      # (T,B,2C): [x | gate pre-activation]
         C = u.shape[-1] // 2
         if self.balancer1.fires(u):
@@ -521,7 +553,7 @@ class ConvolutionModule(nn.Module):
         x = zk.glu_chunk_causal_dwconv(u, C, src_key_padding_mask, self.depthwise_conv,
                                        chunk_size)
         x = self.whiten(self.balancer2(x))
-        return self.out_proj(x)
+        return self.out_proj(x, residual=residual)     # out_proj is last: the add is always fused
 
 
 class Zipformer2EncoderLayer(nn.Module):
@@ -592,7 +624,7 @@ class Zipformer2EncoderLayer(nn.Module):
         attn_skip = float(self.attention_skip_rate) if train else 0.0
         w = self.self_attn_weights(src, pos_emb=pos_emb, attn_mask=attn_mask,
                                    key_padding_mask=src_key_padding_mask)
-        src = src + self.feed_forward1(src)
+        src = self.feed_forward1(src, residual=src)
         amask = self._seq_mask(src, attn_skip)
         const_attn = train and random.random() < float(self.const_attention_rate)
         if self.self_attn_weights.last_deferrable and not const_attn:
@@ -607,28 +639,46 @@ class Zipformer2EncoderLayer(nn.Module):
             if const_attn:
                 w0 = (w0 > 0.0).to(w0.dtype)
                 w0 = w0 * (1.0 / w0.sum(dim=-1, keepdim=True))
-        na = self.balancer_na(self.nonlin_attention(src, w0))
-        src = src + (na if amask is None else na * amask)
-        sa = self.self_attn1(src, w_a1)
-        src = src + (sa if amask is None else sa * amask)
+        # the residual adds ride in each module's last GEMM (sequence masks: defaults are None)
+        if amask is None:
+            src = self.nonlin_attention(src, w0, residual=src, post=self.balancer_na)
+            src = self.self_attn1(src, w_a1, residual=src)
+        else:
+            src = src + self.nonlin_attention(src, w0, post=self.balancer_na) * amask
+            src = src + self.self_attn1(src, w_a1) * amask
         conv_skip = float(self.conv_skip_rate) if train else 0.0
-        cv = self.conv_module1(src, chunk_size=chunk_size,
-                               src_key_padding_mask=src_key_padding_mask)
-        cm = self._seq_mask(src, conv_skip)
-        src = src + (cv if cm is None else cv * cm)
-        ff = self.balancer_ff2(self.feed_forward2(src))
-        fm = self._seq_mask(src, float(self.ff2_skip_rate) if train else 0.0)
-        src = src + (ff if fm is None else ff * fm)
+        cm = None if conv_skip == 0.0 else 0
+        if cm is None:
+            src = self.conv_module1(src, chunk_size=chunk_size,
+                                    src_key_padding_mask=src_key_padding_mask, residual=src)
+        else:
+            cv = self.conv_module1(src, chunk_size=chunk_size,
+                                   src_key_padding_mask=src_key_padding_mask)
+            src = src + cv * self._seq_mask(src, conv_skip)
+        ff2_skip = float(self.ff2_skip_rate) if train else 0.0
+        if ff2_skip == 0.0:
+            src = self.feed_forward2(src, residual=src, post=self.balancer_ff2)
+        else:
+            ff = self.feed_forward2(src, post=self.balancer_ff2)
+            src = src + ff * self._seq_mask(src, ff2_skip)
         src = self.bypass_mid(src_orig, src)
-        sa = self.self_attn2(src, w_a2)
-        src = src + (sa if amask is None else sa * amask)
-        cv = self.conv_module2(src, chunk_size=chunk_size,
-                               src_key_padding_mask=src_key_padding_mask)
-        cm = self._seq_mask(src, conv_skip)
-        src = src + (cv if cm is None else cv * cm)
-        ff = self.balancer_ff3(self.feed_forward3(src))
-        fm = self._seq_mask(src, float(self.ff3_skip_rate) if train else 0.0)
-        src = src + (ff if fm is None else ff * fm)
+        if amask is None:
+            src = self.self_attn2(src, w_a2, residual=src)
+        else:
+            src = src + self.self_attn2(src, w_a2) * amask
+        if cm is None:
+            src = self.conv_module2(src, chunk_size=chunk_size,
+                                    src_key_padding_mask=src_key_padding_mask, residual=src)
+        else:
+            cv = self.conv_module2(src, chunk_size=chunk_size,
+                                   src_key_padding_mask=src_key_padding_mask)
+            src = src + cv * self._seq_mask(src, conv_skip)
+        ff3_skip = float(self.ff3_skip_rate) if train else 0.0
+        if ff3_skip == 0.0:
+            src = self.feed_forward3(src, residual=src, post=self.balancer_ff3)
+        else:
+            ff = self.feed_forward3(src, post=self.balancer_ff3)
+            src = src + ff * self._seq_mask(src, ff3_skip)
         src = self.norm(self.balancer1(src))
         src = self.bypass(src_orig, src)
         return self.whiten(self.balancer2(src))

@@ -372,7 +372,7 @@ class ActivationDropoutAndLinear(nn.Module):
         self.dropout_p = dropout_p
         self.dropout_shared_dim = dropout_shared_dim
 
-    def forward(self, x: Tensor) -> Tensor:
+    def forward(self, x: Tensor, residual: Optional[Tensor] = None) -> Tensor:
         p = float(self.dropout_p) if self.training else 0.0
         mask = None
         if p != 0.0:
@@ -380,7 +380,8 @@ class ActivationDropoutAndLinear(nn.Module):
             if self.dropout_shared_dim is not None:
                 shape[self.dropout_shared_dim] = 1
             mask = (1.0 / (1.0 - p)) * (rng.rand(*shape, device=x.device, dtype=x.dtype) > p)
-        return zk.swoosh_linear(x, self.weight, self.bias, self.activation == "SwooshL", mask)
+        return zk.swoosh_linear(x, self.weight, self.bias, self.activation == "SwooshL", mask,
+                                residual)
 
 
 def convert_num_channels(x: Tensor, num_channels: int) -> Tensor:

@@ -77,20 +77,23 @@ class _SwooshLinear(torch.autograd.Function):
     the flat gradient buffer."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, is_l, mask):
+    def forward(ctx, x, weight, bias, is_l, mask, residual):
         ctx.save_for_backward(x, weight, mask)
         ctx.is_l = is_l
         ctx.params = (weight, bias)
+        ctx.has_res = residual is not None
         h = swoosh_forward(x, is_l)
         if mask is not None:
             h = h * mask
-        return F.linear(h, weight, bias)
+        r2 = None if residual is None else _rows(residual)
+        y = lt_matmul(0, _rows(h), weight, bias, r2)
+        return y.view(x.shape[:-1] + (weight.shape[0],))
 
     @staticmethod
     def backward(ctx, g):
         x, weight, mask = ctx.saved_tensors
         wp, bp = ctx.params
-        g2 = g.reshape(-1, g.shape[-1])
+        g2 = _rows(g)
         x2 = x.reshape(-1, x.shape[-1])
         if mask is None and wgrad_into(wp, bp, g2, x2, pro=1 if ctx.is_l else 2):
             dw = db = None
@@ -99,13 +102,13 @@ class _SwooshLinear(torch.autograd.Function):
             if mask is not None:
                 h = h * mask
             dw, db = linear_wgrad(g2, h.reshape(-1, h.shape[-1]), bp is not None)
-        dh = g.matmul(weight)
+        dh = lt_matmul(1, g2, weight).view(x.shape)
         dx = swoosh_backward(x, dh, ctx.is_l, mask)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, (g if ctx.has_res else None)
 
 
-def swoosh_linear(x, weight, bias, is_l, mask=None):
-    return _SwooshLinear.apply(x, weight, bias, is_l, mask)
+def swoosh_linear(x, weight, bias, is_l, mask=None, residual=None):
+    return _SwooshLinear.apply(x, weight, bias, is_l, mask, residual)
 
 
 # ------------------------------------------------------------------ BiasNorm
@@ -691,35 +694,86 @@ def wgrad_into(wparam, bparam, g2, a2, pro=0):
     return True
 
 
+_LT_WS = {}
+
+
+def _lt_workspace(dev):
+    ws = _LT_WS.get(dev)
+    if ws is None:
+        ws = torch.empty(32 << 20, dtype=torch.uint8, device=dev)
+        _LT_WS[dev] = ws
+    return ws
+
+
+def _rows(t):
+    """(..., K) -> (R, K) view with unit inner stride (copy only if the layout forces one)."""
+    t2 = t.reshape(-1, t.shape[-1])
+    if t2.stride(1) != 1 or t2.stride(0) < t2.shape[1] or t2.dtype != torch.float32:
+        t2 = t2.contiguous().float()
+    return t2
+
+
+def lt_matmul(mode, x2, w2, bias=None, resid2=None, out_shape=None):
+    """mode 0: x2 (R,K) w2 (N,K)^T (+bias) (+resid2) -> (R,N);  mode 1: x2 (R,N) w2 (N,K) (+resid2)
+    -> (R,K).  One hipBLASLt launch with the bias / residual in the epilogue (gemm_lib.hip);
+    torch.matmul when the library has no algorithm for the shape."""
+    R = x2.shape[0]
+    Nf, Kf = w2.shape
+    cols = Nf if mode == 0 else Kf
+    out = torch.empty((R, cols), dtype=torch.float32, device=x2.device)
+    if R == 0:
+        return out
+    w2 = w2 if (w2.stride(1) == 1 and w2.stride(0) >= w2.shape[1]) else w2.contiguous()
+    ws = _lt_workspace(x2.device)
+    rc = N.lib().s2t_linear_lt(mode, N.raw(x2, torch.float32), x2.stride(0),
+                               N.raw(w2, torch.float32), w2.stride(0), N.fp(bias),
+                               None if resid2 is None else N.raw(resid2, torch.float32),
+                               0 if resid2 is None else resid2.stride(0),
+                               1.0 if resid2 is not None else 0.0, N.fp(out), cols, R, Nf, Kf,
+                               ctypes.c_void_p(ws.data_ptr()), ws.numel(), N.stream())
+    if rc == -2:                                   # shape without a library algorithm
+        y = F.linear(x2, w2, bias) if mode == 0 else x2.matmul(w2)
+        return y if resid2 is None else y + resid2
+    N.check(rc, "s2t_linear_lt")
+    return out
+
+
 class _Linear(torch.autograd.Function):
-    """F.linear whose weight and bias gradients come from one pass over (g, x), accumulated
+    """y = x W^T + b (+ residual): one library GEMM with bias and residual in the epilogue; the
+    weight and bias gradients come from one pass of the TN MFMA GEMM over (g, x), accumulated
     in place into the flat gradient buffer when the parameters live in one."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
-        ctx.params = (weight, bias)
+    def forward(ctx, x, weight, bias, residual):
         w2 = weight if weight.dim() == 2 else weight.reshape(weight.shape[0], -1)   # 1x1 conv
-        return F.linear(x, w2, bias)
+        x2 = _rows(x)
+        r2 = None if residual is None else _rows(residual)
+        y = lt_matmul(0, x2, w2, bias, r2)
+        ctx.save_for_backward(x2, weight)
+        ctx.params = (weight, bias)
+        ctx.xshape = x.shape
+        ctx.has_res = residual is not None
+        return y.view(x.shape[:-1] + (w2.shape[0],))
 
     @staticmethod
     def backward(ctx, g):
-        x, weight = ctx.saved_tensors
+        x2, weight = ctx.saved_tensors
         wp, bp = ctx.params
         w2 = weight if weight.dim() == 2 else weight.reshape(weight.shape[0], -1)
-        g2 = g.reshape(-1, g.shape[-1])
-        x2 = x.reshape(-1, x.shape[-1])
-        dx = g.matmul(w2) if ctx.needs_input_grad[0] else None
+        g2 = _rows(g)
+        dx = lt_matmul(1, g2, w2).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dres = g if ctx.has_res else None
         if wgrad_into(wp, bp, g2, x2):
-            return dx, None, None
+            return dx, None, None, dres
         dw, db = linear_wgrad(g2, x2, bp is not None)
-        return dx, dw.view(weight.shape), db
+        return dx, dw.view(weight.shape), db, dres
 
 
-def linear(x, weight, bias=None):
+def linear(x, weight, bias=None, residual=None):
+    """F.linear(x, weight, bias) [+ residual] on the GPU."""
     if not x.is_cuda:
         raise RuntimeError("speech2text_amd.linear needs device tensors (HIP path only)")
-    return _Linear.apply(x, weight, bias)
+    return _Linear.apply(x, weight, bias, residual)
 
 
 # ------------------------------------------------------------------ channel-last frontend convs
@@ -738,7 +792,7 @@ def _wgrad_splitk(a, g, chunk=16384):
 
 
 def linear_big_m(x, weight, bias):
-    return _Linear.apply(x, weight, bias)
+    return _Linear.apply(x, weight, bias, None)
 
 
 class _Conv3x3Nhwc(torch.autograd.Function):

@@ -95,3 +95,39 @@ def test_linear_backward_accumulates_into_flat_grads(dev):
                                rtol=2e-4, atol=2e-4)
     np.testing.assert_allclose(x.grad.cpu().numpy(), xr.grad.cpu().numpy(), rtol=2e-4, atol=2e-5)
     assert lin.weight.grad.data_ptr() == store.flat_g.data_ptr()
+
+
+@pytest.mark.parametrize("M,K,Nn", [(31680, 192, 384), (1000, 256, 768), (517, 64, 68), (130, 132, 500)])
+def test_library_gemm_wrapper_bias_residual_accumulate(dev, M, K, Nn):
+    """zk.lt_matmul (hipBLASLt C API, bias + residual / accumulation in the epilogue) vs fp64."""
+    g = torch.Generator(device="cpu").manual_seed(M)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)   # noqa: E731
+    x, W, b, res, gr = rnd(M, K), rnd(Nn, K) * 0.2, rnd(Nn), rnd(M, Nn), rnd(M, Nn)
+    y = zk.lt_matmul(0, x, W, b, res)
+    _close(y, x.double() @ W.double().t() + b.double() + res.double())
+    _close(zk.lt_matmul(0, x, W), x.double() @ W.double().t())
+    wide = rnd(M, K + 12)
+    xs = wide[:, 4:4 + K]                                   # row-strided view: no copy needed
+    _close(zk.lt_matmul(0, xs, W, b), xs.double() @ W.double().t() + b.double())
+    r2 = rnd(M, K)
+    _close(zk.lt_matmul(1, gr, W, None, r2), gr.double() @ W.double() + r2.double())
+
+
+def test_linear_with_residual_autograd(dev):
+    torch.manual_seed(1)
+    lin = torch.nn.Linear(64, 96).to(dev)
+    x = torch.randn(7, 5, 64, device=dev, requires_grad=True)
+    r = torch.randn(7, 5, 96, device=dev, requires_grad=True)
+    w = torch.randn(7, 5, 96, device=dev)
+    y = zk.linear(x, lin.weight, lin.bias, residual=r)
+    (y * w).sum().backward()
+    xr, rr = x.detach().clone().requires_grad_(True), r.detach().clone().requires_grad_(True)
+    ref = torch.nn.Linear(64, 96).to(dev)
+    ref.load_state_dict(lin.state_dict())
+    yr = torch.nn.functional.linear(xr, ref.weight, ref.bias) + rr
+    (yr * w).sum().backward()
+    _close(y.detach(), yr.detach().double())
+    _close(x.grad, xr.grad.double())
+    _close(r.grad, rr.grad.double())
+    _close(lin.weight.grad, ref.weight.grad.double(), tol=1e-4)
+    _close(lin.bias.grad, ref.bias.grad.double(), tol=1e-4)
