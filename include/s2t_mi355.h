@@ -287,6 +287,24 @@ int s2t_linear_lt(int mode, const float* X, long ldx, const float* W, long ldw, 
                   const float* C, long ldc, float beta, float* D, long ldd, int M, int N, int K,
                   void* workspace, long ws_bytes, void* stream);
 
+/* ---- fused glue of the zipformer layer (csrc/zip_glue.hip), rows of C channels, time-major.
+ * bypass (model/encoder/zipformer.py:1523-1555): out = orig + (src - orig) * scale[c]; backward
+ * writes d_orig, d_src and ACCUMULATES d_scale[c] (caller zeroes it).
+ * nonlinear attention (zipformer.py:2438-2483): u (T,B,3C) = in_proj(x) = [s | x | y];
+ * gate_fwd: xs (B,T,C) = x * tanh(s) (batch-major for the head-0 weights @ x bmm);
+ * out_fwd: o (T,B,C) = z (B,T,C) * y;  out_bwd: dz (B,T,C) = g * y, du[..,2C:3C] = g * z;
+ * gate_bwd: du[..,0:C] = dxs * x * (1 - tanh(s)^2), du[..,C:2C] = dxs * tanh(s). */
+int s2t_bypass_fwd(const float* orig, const float* src, const float* scale, long rows, int C,
+                   float* out, void* stream);
+int s2t_bypass_bwd(const float* orig, const float* src, const float* scale, const float* g,
+                   long rows, int C, float* d_orig, float* d_src, float* d_scale, void* stream);
+int s2t_nonlin_gate_fwd(const float* u, int T, int B, int C, float* xs, void* stream);
+int s2t_nonlin_out_fwd(const float* z, const float* u, int T, int B, int C, float* o, void* stream);
+int s2t_nonlin_out_bwd(const float* g, const float* z, const float* u, int T, int B, int C, float* dz,
+                       float* du, void* stream);
+int s2t_nonlin_gate_bwd(const float* dxs, const float* u, int T, int B, int C, float* du,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,181 @@
+// Fused glue of the zipformer layer (the ops between the GEMMs that the reference runs as
+// chains of elementwise torch kernels), time-major (T,B,C) rows of C channels:
+//   bypass      out = orig + (src - orig) * scale[c]                     zipformer.py:1523-1555
+//   nonlin gate xs[b,t,c] = x[t,b,c] * tanh(s[t,b,c])   (batch-major for the W0 @ x bmm)
+//   nonlin out  o[t,b,c]  = z[b,t,c] * y[t,b,c]                          zipformer.py:2438-2483
+// and their backward passes; per-channel parameter gradients are block partial sums + one
+// atomic per channel per workgroup.  All HBM-bound single passes.
+#include "common.h"
+
+namespace {
+
+constexpr int RB = 64;   // rows per workgroup in the column-reducing kernels
+
+__global__ __launch_bounds__(256) void bypass_fwd_kernel(const float* __restrict__ orig,
+                                                         const float* __restrict__ src,
+                                                         const float* __restrict__ scale, long n4,
+                                                         int C4, float* __restrict__ out) {
+  const float4* o4 = reinterpret_cast<const float4*>(orig);
+  const float4* s4 = reinterpret_cast<const float4*>(src);
+  const float4* sc4 = reinterpret_cast<const float4*>(scale);
+  float4* y4 = reinterpret_cast<float4*>(out);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const float4 a = o4[i], b = s4[i], k = sc4[i % C4];
+    y4[i] = make_float4(fmaf(b.x - a.x, k.x, a.x), fmaf(b.y - a.y, k.y, a.y),
+                        fmaf(b.z - a.z, k.z, a.z), fmaf(b.w - a.w, k.w, a.w));
+  }
+}
+
+// d_src = g * scale, d_orig = g - d_src, d_scale[c] += sum_rows g * (src - orig)
+__global__ __launch_bounds__(256) void bypass_bwd_kernel(const float* __restrict__ orig,
+                                                         const float* __restrict__ src,
+                                                         const float* __restrict__ scale,
+                                                         const float* __restrict__ g, long rows,
+                                                         int C, float* __restrict__ d_orig,
+                                                         float* __restrict__ d_src,
+                                                         float* __restrict__ d_scale) {
+  const long r0 = (long)blockIdx.x * RB, r1 = min(rows, r0 + RB);
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float k = scale[c];
+    float acc = 0.f;
+    for (long r = r0; r < r1; ++r) {
+      const long i = r * C + c;
+      const float gv = g[i], ds = gv * k;
+      d_src[i] = ds;
+      d_orig[i] = gv - ds;
+      acc = fmaf(gv, src[i] - orig[i], acc);
+    }
+    atomicAdd(d_scale + c, acc);
+  }
+}
+
+// u (T,B,3C) = [s | x | y]  ->  xs (B,T,C) = x * tanh(s)
+__global__ __launch_bounds__(256) void nonlin_gate_fwd_kernel(const float* __restrict__ u, int T,
+                                                              int B, int C,
+                                                              float* __restrict__ xs) {
+  const long n = (long)T * B * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long tb = i / C;
+    const int b = (int)(tb % B);
+    const long t = tb / B;
+    const float* row = u + tb * 3 * C;
+    xs[((long)b * T + t) * C + c] = row[C + c] * tanhf(row[c]);
+  }
+}
+
+// z (B,T,C), u (T,B,3C) -> o (T,B,C) = z * y
+__global__ __launch_bounds__(256) void nonlin_out_fwd_kernel(const float* __restrict__ z,
+                                                             const float* __restrict__ u, int T,
+                                                             int B, int C, float* __restrict__ o) {
+  const long n = (long)T * B * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long tb = i / C;
+    const int b = (int)(tb % B);
+    const long t = tb / B;
+    o[i] = z[((long)b * T + t) * C + c] * u[tb * 3 * C + 2 * C + c];
+  }
+}
+
+// g (T,B,C) -> dz (B,T,C) = g * y ;  du[.., 2C:3C] = dy = g * z
+__global__ __launch_bounds__(256) void nonlin_out_bwd_kernel(const float* __restrict__ g,
+                                                             const float* __restrict__ z,
+                                                             const float* __restrict__ u, int T,
+                                                             int B, int C, float* __restrict__ dz,
+                                                             float* __restrict__ du) {
+  const long n = (long)T * B * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long tb = i / C;
+    const int b = (int)(tb % B);
+    const long t = tb / B;
+    const long zi = ((long)b * T + t) * C + c;
+    const float gv = g[i];
+    dz[zi] = gv * u[tb * 3 * C + 2 * C + c];
+    du[tb * 3 * C + 2 * C + c] = gv * z[zi];
+  }
+}
+
+// dxs (B,T,C) -> du[.., 0:C] = ds = dxs * x * (1 - tanh(s)^2) ; du[.., C:2C] = dx = dxs * tanh(s)
+__global__ __launch_bounds__(256) void nonlin_gate_bwd_kernel(const float* __restrict__ dxs,
+                                                              const float* __restrict__ u, int T,
+                                                              int B, int C,
+                                                              float* __restrict__ du) {
+  const long n = (long)T * B * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long tb = i / C;
+    const int b = (int)(tb % B);
+    const long t = tb / B;
+    const float d = dxs[((long)b * T + t) * C + c];
+    const float* row = u + tb * 3 * C;
+    const float th = tanhf(row[c]);
+    du[tb * 3 * C + c] = d * row[C + c] * (1.f - th * th);
+    du[tb * 3 * C + C + c] = d * th;
+  }
+}
+
+inline unsigned grid1(long n) {
+  long g = (n + 255) / 256;
+  return (unsigned)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" int s2t_bypass_fwd(const float* orig, const float* src, const float* scale, long rows,
+                              int C, float* out, void* stream) {
+  if (rows <= 0) return 0;
+  if (C <= 0 || (C & 3)) return -1;
+  const long n4 = rows * C / 4;
+  hipLaunchKernelGGL(bypass_fwd_kernel, dim3(grid1(n4)), dim3(256), 0, (hipStream_t)stream, orig,
+                     src, scale, n4, C / 4, out);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int s2t_bypass_bwd(const float* orig, const float* src, const float* scale,
+                              const float* g, long rows, int C, float* d_orig, float* d_src,
+                              float* d_scale, void* stream) {
+  if (rows <= 0) return 0;
+  if (C <= 0) return -1;
+  hipLaunchKernelGGL(bypass_bwd_kernel, dim3((unsigned)((rows + RB - 1) / RB)), dim3(256), 0,
+                     (hipStream_t)stream, orig, src, scale, g, rows, C, d_orig, d_src, d_scale);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int s2t_nonlin_gate_fwd(const float* u, int T, int B, int C, float* xs, void* stream) {
+  if (T <= 0 || B <= 0 || C <= 0) return 0;
+  hipLaunchKernelGGL(nonlin_gate_fwd_kernel, dim3(grid1((long)T * B * C)), dim3(256), 0,
+                     (hipStream_t)stream, u, T, B, C, xs);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int s2t_nonlin_out_fwd(const float* z, const float* u, int T, int B, int C, float* o,
+                                  void* stream) {
+  if (T <= 0 || B <= 0 || C <= 0) return 0;
+  hipLaunchKernelGGL(nonlin_out_fwd_kernel, dim3(grid1((long)T * B * C)), dim3(256), 0,
+                     (hipStream_t)stream, z, u, T, B, C, o);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int s2t_nonlin_out_bwd(const float* g, const float* z, const float* u, int T, int B,
+                                  int C, float* dz, float* du, void* stream) {
+  if (T <= 0 || B <= 0 || C <= 0) return 0;
+  hipLaunchKernelGGL(nonlin_out_bwd_kernel, dim3(grid1((long)T * B * C)), dim3(256), 0,
+                     (hipStream_t)stream, g, z, u, T, B, C, dz, du);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int s2t_nonlin_gate_bwd(const float* dxs, const float* u, int T, int B, int C,
+                                   float* du, void* stream) {
+  if (T <= 0 || B <= 0 || C <= 0) return 0;
+  hipLaunchKernelGGL(nonlin_gate_bwd_kernel, dim3(grid1((long)T * B * C)), dim3(256), 0,
+                     (hipStream_t)stream, dxs, u, T, B, C, du);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}

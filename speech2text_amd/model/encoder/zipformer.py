@@ -494,11 +494,19 @@ class NonlinAttention(nn.Module):
 
     def forward(self, x: Tensor, attn_weights: Tensor, residual: Optional[Tensor] = None,
                 post=None) -> Tensor:
-        s, x, y = self.in_proj(x).chunk(3, dim=2)
-        s = self.tanh(self.balancer(s))
-        x = self.whiten1(x) * s
-        x = zk.attention_apply(attn_weights, x, attn_weights.shape[0])
-        x = x * y
+        u = self.in_proj(x)                       # (T,B,3C) = [s | x | y]
+        if attn_weights.shape[0] == 1 and u.shape[-1] % 3 == 0:
+            # fused core; the random draws keep the reference's order (balancer, then whiten1)
+            fb = self.balancer.fires(u)
+            fw1 = self.whiten1.fires(u)
+            x = zk.nonlin_core(u, attn_weights, self.balancer.cfg(3) if fb else None,
+                               self.whiten1 if fw1 else None)
+        else:
+            s, x, y = u.chunk(3, dim=2)
+            s = self.tanh(self.balancer(s))
+            x = self.whiten1(x) * s
+            x = zk.attention_apply(attn_weights, x, attn_weights.shape[0])
+            x = x * y
         fw = self.whiten2.fires(x)
         fp = post.fires(x) if post is not None else False
         if residual is not None and not fw and not fp:

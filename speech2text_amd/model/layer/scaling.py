@@ -109,13 +109,16 @@ class Balancer(nn.Module):
         """Draws this call's random decision (one random.random(), as the reference)."""
         return x.requires_grad and random.random() < float(self.prob)
 
+    def cfg(self, ndim: int):
+        """(min_mean, max_mean, min_rms, max_rms, grad_scale, channel_dim) for the backward."""
+        return (_prop_pos_to_mean(float(self.min_positive)),
+                _prop_pos_to_mean(float(self.max_positive)),
+                1.25331413732 * float(self.min_abs), 1.25331413732 * float(self.max_abs),
+                float(self.grad_scale), self.channel_dim % ndim)
+
     def shape_grad(self, x: Tensor) -> Tensor:
         assert x.shape[self.channel_dim] == self.num_channels
-        cfg = (_prop_pos_to_mean(float(self.min_positive)),
-               _prop_pos_to_mean(float(self.max_positive)),
-               1.25331413732 * float(self.min_abs), 1.25331413732 * float(self.max_abs),
-               float(self.grad_scale), self.channel_dim % x.ndim)
-        return _BalancerFn.apply(x, cfg)
+        return _BalancerFn.apply(x, self.cfg(x.ndim))
 
     def forward(self, x: Tensor) -> Tensor:
         return self.shape_grad(x) if self.fires(x) else _no_op(x)

@@ -322,6 +322,7 @@ class _ZipConv(torch.autograd.Function):
                                         N.stream()), "s2t_zipconv_fwd")
         ctx.save_for_backward(u, m8, args["wc"], args["wk"], args["bk"], args["scale"])
         ctx.cfg = (gate_off, chunk, K, bc is not None)
+        ctx.params = (wc, bc, wk, bk, scale)
         return y
 
     @staticmethod
@@ -334,17 +335,29 @@ class _ZipConv(torch.autograd.Function):
         dev = u.device
         du = torch.empty((T, B, 2 * C if gate_off >= 0 else C), dtype=torch.float32, device=dev)
         Kh = (K + 1) // 2
-        # one zeroed buffer for all parameter gradients (they are accumulated with atomics)
-        sizes = [C * Kh if wc is not None else 0, C if wc is not None else 0, C * K,
-                 C if bk is not None else 0, 2 * C * K if scale is not None else 0]
-        buf = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
-        parts, o = [], 0
-        for n in sizes:
-            parts.append(buf[o:o + n] if n else None)
-            o += n
-        dwc, dbc, dwk, dbk, dsc = parts
+        # parameter gradients are ACCUMULATED by the kernels (reduce pass / atomics): when every
+        # parameter lives in the flat store they go straight into its gradient views, otherwise
+        # into one zeroed scratch buffer that is handed back to autograd
+        plist = [p for p in ctx.params if p is not None]
+        direct = all(p.is_leaf and flat.owned(p) and p.grad is not None and p.grad.is_contiguous()
+                     for p in plist)
         ws = torch.empty(N.lib().s2t_zipconv_bwd_workspace_floats(T, B, C, K), dtype=torch.float32,
                          device=dev)
+        if direct:
+            pw, pb, pk, pbk, ps = ctx.params
+            dwc = None if pw is None else pw.grad
+            dbc = None if pb is None else pb.grad
+            dwk, dbk = pk.grad, (None if pbk is None else pbk.grad)
+            dsc = None if ps is None else ps.grad
+        else:
+            sizes = [C * Kh if wc is not None else 0, C if wc is not None else 0, C * K,
+                     C if bk is not None else 0, 2 * C * K if scale is not None else 0]
+            buf = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+            parts, o = [], 0
+            for n in sizes:
+                parts.append(buf[o:o + n] if n else None)
+                o += n
+            dwc, dbc, dwk, dbk, dsc = parts
         N.profile_note("s2t_zipconv_bwd", 4.0 * (2 * u.numel() + 2 * dy.numel()))
         N.check(N.lib().s2t_zipconv_bwd(N.fp(u), ld, gate_off, N.ptr(m8), T, B, C, K, chunk,
                                         N.fp(wc), N.fp(wk), N.fp(bk), N.fp(scale), N.fp(dy),
@@ -353,6 +366,10 @@ class _ZipConv(torch.autograd.Function):
                                         N.raw(dbk) if dbk is not None else None,
                                         N.raw(dsc) if dsc is not None else None, N.fp(ws),
                                         N.stream()), "s2t_zipconv_bwd")
+        if direct:
+            for p in plist:
+                flat.grad_written(p)
+            return (du,) + (None,) * 9
         return (du, None, None, None, None,
                 None if dwc is None else dwc.view(C, 1, Kh),
                 dbc if has_bc else None, dwk.view(C, 1, K), dbk,
@@ -599,8 +616,102 @@ def attention_apply(weights, v, num_heads):
 
 
 # ------------------------------------------------------------------ misc streaming ops
+class _Bypass(torch.autograd.Function):
+    """orig + (src - orig) * scale[c] in one pass; backward = one pass + per-channel atomics."""
+
+    @staticmethod
+    def forward(ctx, orig, src, scale):
+        orig, src = orig.contiguous().float(), src.contiguous().float()
+        scale = scale.contiguous().float()
+        C = src.shape[-1]
+        out = torch.empty_like(src)
+        N.profile_note("s2t_bypass_fwd", 12.0 * src.numel())
+        N.check(N.lib().s2t_bypass_fwd(N.fp(orig), N.fp(src), N.fp(scale), src.numel() // C, C,
+                                       N.fp(out), N.stream()), "s2t_bypass_fwd")
+        ctx.save_for_backward(orig, src, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        orig, src, scale = ctx.saved_tensors
+        g = g.contiguous().float()
+        C = src.shape[-1]
+        d_orig, d_src = torch.empty_like(src), torch.empty_like(src)
+        d_scale = torch.zeros_like(scale)
+        N.profile_note("s2t_bypass_bwd", 20.0 * src.numel())
+        N.check(N.lib().s2t_bypass_bwd(N.fp(orig), N.fp(src), N.fp(scale), N.fp(g),
+                                       src.numel() // C, C, N.fp(d_orig), N.fp(d_src),
+                                       N.fp(d_scale), N.stream()), "s2t_bypass_bwd")
+        return d_orig, d_src, d_scale
+
+
 def bypass_combine(src_orig, src, scale):
-    return src_orig + (src - src_orig) * scale
+    """BypassModule core (reference zipformer.py:1523-1555).  HIP: zip_glue.hip."""
+    if scale.dim() == 1 and src.is_cuda and src.shape[-1] % 4 == 0 and src.shape == src_orig.shape \
+            and src.data_ptr() % 16 == 0 and src_orig.data_ptr() % 16 == 0:
+        return _Bypass.apply(src_orig, src, scale)
+    return src_orig + (src - src_orig) * scale          # per-utterance skip / straight-through masks
+
+
+class _NonlinCore(torch.autograd.Function):
+    """NonlinAttention between in_proj and out_proj (reference zipformer.py:2459-2478):
+    u = [s | x | y] -> (W0 @ (x * tanh(s))) * y, with the Balancer on s and the Whiten on x (both
+    identity in forward) applied to the slices of the gradient inside this backward.  Three
+    launches forward (gate -> batch-major, rocBLAS bmm, out), five backward; no chunk / cat /
+    permute copies."""
+
+    @staticmethod
+    def forward(ctx, u, w0, bal_cfg, whiten_mod):
+        _dev(u, w0)
+        u = u.contiguous().float()
+        T, B, C3 = u.shape
+        C = C3 // 3
+        L = N.lib()
+        st = N.stream()
+        xs = torch.empty((B, T, C), dtype=torch.float32, device=u.device)
+        N.check(L.s2t_nonlin_gate_fwd(N.fp(u), T, B, C, N.fp(xs), st), "nonlin_gate_fwd")
+        wm = w0.reshape(B, T, T)
+        z = torch.bmm(wm, xs)                                         # rocBLAS
+        o = torch.empty((T, B, C), dtype=torch.float32, device=u.device)
+        N.check(L.s2t_nonlin_out_fwd(N.fp(z), N.fp(u), T, B, C, N.fp(o), st), "nonlin_out_fwd")
+        ctx.save_for_backward(u, wm, xs, z)
+        ctx.bal_cfg, ctx.whiten_mod = bal_cfg, whiten_mod
+        ctx.wshape = w0.shape
+        ctx.stats = None
+        if whiten_mod is not None:
+            ctx.stats = WhitenStats(u[..., C:2 * C], whiten_mod.num_groups)
+        return o
+
+    @staticmethod
+    def backward(ctx, g):
+        u, wm, xs, z = ctx.saved_tensors
+        T, B, C3 = u.shape
+        C = C3 // 3
+        L = N.lib()
+        st = N.stream()
+        g = g.contiguous().float()
+        dz = torch.empty_like(z)
+        du = torch.empty_like(u)
+        N.check(L.s2t_nonlin_out_bwd(N.fp(g), N.fp(z), N.fp(u), T, B, C, N.fp(dz), N.fp(du), st),
+                "nonlin_out_bwd")
+        dxs = torch.bmm(wm.transpose(1, 2), dz)
+        dW0 = torch.bmm(dz, xs.transpose(1, 2)) if ctx.needs_input_grad[1] else None
+        N.check(L.s2t_nonlin_gate_bwd(N.fp(dxs), N.fp(u), T, B, C, N.fp(du), st), "nonlin_gate_bwd")
+        if ctx.bal_cfg is not None:
+            du[..., :C] = balancer_backward(u[..., :C], du[..., :C].contiguous(), *ctx.bal_cfg[:5],
+                                            2)
+        if ctx.whiten_mod is not None:
+            wmod = ctx.whiten_mod
+            out, active = whiten_backward(u[..., C:2 * C], du[..., C:2 * C].contiguous(), ctx.stats,
+                                          float(wmod.whitening_limit), float(wmod.grad_scale))
+            if active:
+                du[..., C:2 * C] = out
+            wmod.prob = wmod.max_prob if active else wmod.min_prob
+        return du, (None if dW0 is None else dW0.view(ctx.wshape)), None, None
+
+
+def nonlin_core(u, w0, bal_cfg=None, whiten_mod=None):
+    return _NonlinCore.apply(u, w0, bal_cfg, whiten_mod)
 
 
 def simple_downsample(src, bias, ds):
