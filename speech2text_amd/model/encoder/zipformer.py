@@ -432,7 +432,10 @@ class SelfAttention(nn.Module):
     def forward(self, x: Tensor, attn_weights: Tensor, residual: Optional[Tensor] = None) -> Tensor:
         """With `residual` the result is residual + module(x); when the output Whiten does not
         fire this step the add rides in the out_proj GEMM's epilogue."""
-        v = self.in_proj(x)
+        if residual is x:
+            v, residual = zk.linear_pass(x, self.in_proj.weight, self.in_proj.bias)
+        else:
+            v = self.in_proj(x)
         x = zk.attention_apply(attn_weights, v, attn_weights.shape[0])
         fw = self.whiten.fires(x)
         if residual is not None and not fw:
@@ -461,7 +464,11 @@ class FeedforwardModule(nn.Module):
         here, right after out_whiten's, i.e. in the reference's order).  With `residual` the
         result is residual + post(module(x)); if neither gradient-shaping op fires this step the
         add is fused into the out_proj GEMM."""
-        x = self.hidden_balancer(self.in_proj(x))
+        if residual is x:
+            h, residual = zk.linear_pass(x, self.in_proj.weight, self.in_proj.bias)
+        else:
+            h = self.in_proj(x)
+        x = self.hidden_balancer(h)
         fw = self.out_whiten.fires(x)
         fp = post.fires(x) if post is not None else False
         if residual is not None and not fw and not fp:
@@ -494,7 +501,10 @@ class NonlinAttention(nn.Module):
 
     def forward(self, x: Tensor, attn_weights: Tensor, residual: Optional[Tensor] = None,
                 post=None) -> Tensor:
-        u = self.in_proj(x)                       # (T,B,3C) = [s | x | y]
+        if residual is x:
+            u, residual = zk.linear_pass(x, self.in_proj.weight, self.in_proj.bias)
+        else:
+            u = self.in_proj(x)                   # (T,B,3C) = [s | x | y]
         if attn_weights.shape[0] == 1 and u.shape[-1] % 3 == 0:
             # fused core; the random draws keep the reference's order (balancer, then whiten1)
             fb = self.balancer.fires(u)
@@ -551,7 +561,10 @@ class ConvolutionModule(nn.Module):
 
     def forward(self, x: Tensor, src_key_padding_mask: Optional[Tensor] = None,
                 chunk_size: int = -1, residual: Optional[Tensor] = None) -> Tensor:
-        u = self.in_proj(x)                      # (T,B,2C): [x | gate pre-activation]
+        if residual is x:
+            u, residual = zk.linear_pass(x, self.in_proj.weight, self.in_proj.bias)
+        else:
+            u = self.in_proj(x)                  # (T,B,2C): [x | gate pre-activation]
         C = u.shape[-1] // 2
         if self.balancer1.fires(u):
             # gradient shaping of the gate half only (identity in forward)

@@ -880,6 +880,43 @@ class _Linear(torch.autograd.Function):
         return dx, dw.view(weight.shape), db, dres
 
 
+class _LinearPass(torch.autograd.Function):
+    """(linear(x), x) -- the second output is x itself, to be used as the residual branch of the
+    module that starts with this projection.  In backward the residual branch's gradient then
+    arrives here and rides in the data-gradient GEMM's epilogue (dx = g W + g_residual) instead
+    of costing autograd an extra add kernel per module."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        w2 = weight if weight.dim() == 2 else weight.reshape(weight.shape[0], -1)
+        x2 = _rows(x)
+        y = lt_matmul(0, x2, w2, bias)
+        ctx.save_for_backward(x2, weight)
+        ctx.params = (weight, bias)
+        ctx.xshape = x.shape
+        return y.view(x.shape[:-1] + (w2.shape[0],)), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g, g_pass):
+        x2, weight = ctx.saved_tensors
+        wp, bp = ctx.params
+        w2 = weight if weight.dim() == 2 else weight.reshape(weight.shape[0], -1)
+        g2 = _rows(g)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            r2 = None if g_pass is None else _rows(g_pass)
+            dx = lt_matmul(1, g2, w2, None, r2).view(ctx.xshape)
+        if wgrad_into(wp, bp, g2, x2):
+            return dx, None, None
+        dw, db = linear_wgrad(g2, x2, bp is not None)
+        return dx, dw.view(weight.shape), db
+
+
+def linear_pass(x, weight, bias=None):
+    """-> (F.linear(x, weight, bias), alias of x for the residual branch)."""
+    return _LinearPass.apply(x, weight, bias)
+
+
 def linear(x, weight, bias=None, residual=None):
     """F.linear(x, weight, bias) [+ residual] on the GPU."""
     if not x.is_cuda:
