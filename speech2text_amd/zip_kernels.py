@@ -242,7 +242,14 @@ class WhitenStats:
         n = xf.shape[0]
         G, cg = num_groups, C // num_groups
         dev = x.device
-        xtx, colsum = linear_wgrad(xf, xf, True)
+        if _tn_ok(xf):
+            # x^T x and the column sums in one pass of the TN MFMA GEMM (accumulating kernel:
+            # one zeroed (C+1, C) buffer holds both)
+            acc = torch.zeros((C + 1, C), dtype=torch.float32, device=dev)
+            xtx, colsum = acc[:C], acc[C]
+            gemm_tn(xf, xf, xtx, colsum)
+        else:
+            xtx, colsum = linear_wgrad(xf, xf, True)
         self.cov = torch.empty((G, cg, cg), dtype=torch.float32, device=dev)
         self.mean = torch.empty((C,), dtype=torch.float32, device=dev)
         self.scal = torch.empty((4,), dtype=torch.float32, device=dev)
