@@ -278,8 +278,9 @@ template <int MODE>
 int dispatch(GemmArgs& g, hipStream_t st) {
   int tn_sel = pick_tn(g.N);
   const int pro = MODE == MODE_NT ? g.pro_a : (MODE == MODE_TN ? g.pro_b : 0);
-  const long tiles_big = (long)((g.M + 127) / 128) * ((g.N + 64 * tn_sel - 1) / (64 * tn_sel));
+  long tiles_big = (long)((g.M + 127) / 128) * ((g.N + 64 * tn_sel - 1) / (64 * tn_sel));
   if (MODE == MODE_TN) {
+    if (g.M <= 64 && tn_sel == 3) tiles_big = (long)((g.N + 127) / 128);
     // output is small (features x features): split the long contraction over the chip; every
     // slice adds its tile with fp32 atomics, so keep slices x output bytes small
     int splits = (int)((tn_blocks_target() + tiles_big - 1) / tiles_big);
@@ -290,7 +291,7 @@ int dispatch(GemmArgs& g, hipStream_t st) {
     kper = ((kper + BK - 1) / BK) * BK;
     g.kper = kper;
     splits = (g.K + kper - 1) / kper;
-    return launch_t<MODE>(g, 2, tn_sel, pro, splits, st);
+    return launch_t<MODE>(g, g.M <= 64 ? 1 : 2, tn_sel == 3 && g.M <= 64 ? 2 : tn_sel, pro, splits, st);
   }
   if (tiles_big >= 384) return launch_t<MODE>(g, 2, tn_sel, pro, 1, st);
   if (tn_sel == 3) tn_sel = 2;

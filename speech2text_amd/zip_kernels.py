@@ -751,6 +751,13 @@ def linear_wgrad(g2, a2, want_bias):
     _dev(g2, a2)
     R, Nf = g2.shape
     Mf = a2.shape[1]
+    if _tn_ok(g2) and _tn_ok(a2) and R >= 2048:
+        # TN MFMA GEMM (accumulating): one zeroed (N+1, M) buffer receives dW and, in its last
+        # row's first N entries, nothing -- the bias gradient has its own zeroed vector
+        dW = torch.zeros((Nf, Mf), dtype=torch.float32, device=g2.device)
+        db = torch.zeros((Nf,), dtype=torch.float32, device=g2.device) if want_bias else None
+        gemm_tn(g2, a2, dW, db)
+        return dW, db
     tiles = ((Nf + 63) // 64) * ((Mf + 63) // 64)
     if R >= 3000 and tiles <= WGRAD_MAX_TILES and _wgrad_ok(g2, a2):
         dW = torch.empty((Nf, Mf), dtype=torch.float32, device=g2.device)
