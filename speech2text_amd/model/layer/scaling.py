@@ -55,7 +55,10 @@ FloatLike = Union[float, ScheduledFloat]
 
 
 def _no_op(x: Tensor) -> Tensor:
-    return x.chunk(1, dim=-1)[0]
+    """Identity.  (The reference returns `x.chunk(1, dim=-1)[0]`, scaling.py:1193-1199, to hand
+    TorchScript a distinct tensor; that costs an autograd node per non-firing Balancer / Whiten
+    -- ~200 per step -- and changes no value, so the tensor itself is returned.)"""
+    return x
 
 
 class Identity(nn.Module):
