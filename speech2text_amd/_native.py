@@ -45,22 +45,26 @@ class _Prof:
 
 
 class _LibProxy:
-    """Attribute access returns the ctypes function, wrapped so that launches of the entry
-    point(s) selected by profile_begin() are bracketed by HIP events on the current stream."""
+    """Attribute access returns the ctypes function.  While profile_begin() is active the
+    functions are wrapped so that launches of the selected entry point(s) are bracketed by HIP
+    events on the current stream; otherwise the raw ctypes function is cached on the instance
+    (no per-call indirection on the training path)."""
 
     def __init__(self, cdll):
         self._cdll = cdll
-        self._fns = {}
+
+    def _reset(self):
+        for k in [k for k in self.__dict__ if k.startswith("s2t_")]:
+            del self.__dict__[k]
 
     def __getattr__(self, name):
-        fn = self._fns.get(name)
-        if fn is None:
-            raw = getattr(self._cdll, name)
-            timed = not name.endswith("_floats")          # workspace-size queries launch nothing
-
-            def call(*args, _raw=raw, _name=name, _timed=timed):
+        raw = getattr(self._cdll, name)
+        if _Prof.target is None or name.endswith("_floats") or name.endswith("_elems"):
+            fn = raw
+        else:
+            def fn(*args, _raw=raw, _name=name):
                 tgt = _Prof.target
-                if tgt is None or not _timed or (tgt != "*" and tgt != _name):
+                if tgt is None or (tgt != "*" and tgt != _name):
                     return _raw(*args)
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
@@ -69,9 +73,7 @@ class _LibProxy:
                 e1.record()
                 _Prof.events.setdefault(_name, []).append((e0, e1))
                 return rc
-
-            fn = call
-            self._fns[name] = fn
+        self.__dict__[name] = fn
         return fn
 
 
@@ -99,12 +101,16 @@ def profile_begin(entry_point):
     _Prof.events = {}
     _Prof.algo_bytes = {}
     _Prof.algo_flops = {}
+    if _lib is not None:
+        _lib._reset()
 
 
 def profile_note(entry_point, nbytes=0.0, flops=0.0):
     """Call sites report the ALGORITHMIC bytes/flops of a launch (DESIGN.md formulas)."""
     tgt = _Prof.target
-    if tgt is not None and (tgt == "*" or tgt == entry_point):
+    if tgt is None:
+        return
+    if tgt == "*" or tgt == entry_point:
         _Prof.algo_bytes[entry_point] = _Prof.algo_bytes.get(entry_point, 0.0) + nbytes
         _Prof.algo_flops[entry_point] = _Prof.algo_flops.get(entry_point, 0.0) + flops
 
@@ -112,6 +118,8 @@ def profile_note(entry_point, nbytes=0.0, flops=0.0):
 def profile_end():
     """-> {entry: {launches, total_ms, avg_ms, algo_bytes, algo_flops}}"""
     _Prof.target = None
+    if _lib is not None:
+        _lib._reset()
     out = {}
     if _Prof.events:
         torch.cuda.synchronize()
@@ -126,7 +134,8 @@ def profile_end():
 
 
 def stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """hipStream_t torch considers current on the current device (raw handle, no Stream object)."""
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def ptr(t, dtype=None):
