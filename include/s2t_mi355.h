@@ -305,6 +305,12 @@ int s2t_nonlin_out_bwd(const float* g, const float* z, const float* u, int T, in
 int s2t_nonlin_gate_bwd(const float* dxs, const float* u, int T, int B, int C, float* du,
                         void* stream);
 
+/* ---- side stream for work off the critical path (csrc/streams.hip): the weight-gradient GEMMs
+ * of backward overlap the data-gradient chain.  s2t_side_stream returns the library-owned stream;
+ * s2t_stream_order(from, to) makes later work on `to` wait for the work enqueued so far on `from`. */
+void* s2t_side_stream(void);
+int s2t_stream_order(void* from, void* to);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,7 +14,8 @@ LIB_PATH = os.path.join(_HERE, "libs2t_mi355.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "s2t_mi355.h")
 _lib = None
 
-_CT = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float}
+_CT = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float,
+       "void*": ctypes.c_void_p}
 
 
 def parse_header(path=HEADER_PATH):
@@ -22,7 +23,7 @@ def parse_header(path=HEADER_PATH):
     txt = open(path).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     protos = {}
-    for m in re.finditer(r"\b(int|long)\s+(s2t_\w+)\s*\(([^)]*)\)\s*;", txt):
+    for m in re.finditer(r"\b(int|long|void\*)\s+(s2t_\w+)\s*\(([^)]*)\)\s*;", txt):
         ret, name, args = m.group(1), m.group(2), m.group(3)
         ats = []
         for a in args.split(","):

@@ -126,10 +126,22 @@ class GradReducer:
         self._next = b + 1
         if self._is_cuda:
             self._stream.wait_stream(torch.cuda.current_stream())
+            self._wait_wgrad_stream()
             with torch.cuda.stream(self._stream):
                 self._exchange(buf, b)
         else:
             self._exchange(buf, b)
+
+    def _wait_wgrad_stream(self):
+        """Weight gradients may still be in flight on the kernels' side stream (zip_kernels._Side):
+        the exchange stream must be ordered after it as well."""
+        from speech2text_amd import _native as N
+        from speech2text_amd import zip_kernels as zk
+        h = zk.side_stream_handle()
+        if h is not None:
+            import ctypes
+            N.check(N.lib().s2t_stream_order(h, ctypes.c_void_p(self._stream.cuda_stream)),
+                    "s2t_stream_order(reducer)")
 
     def prepare(self):
         """Call before backward of a micro-step whose gradients must be synchronised."""

@@ -5,6 +5,7 @@ torch-op compositions (rocBLAS GEMMs + elementwise) to hand-written gfx950 kerne
 time; see DESIGN.md for the status table of each.
 """
 import ctypes
+import os
 
 import torch
 import torch.nn.functional as F
@@ -781,7 +782,51 @@ def _tn_ok(t):
             and t.shape[1] % 4 == 0 and t.shape[0] >= 4 and t.data_ptr() % 16 == 0)
 
 
-def gemm_tn(g2, a2, out, colsum=None, pro=0):
+class _Side:
+    """Weight-gradient GEMMs of backward run on the library's side stream (streams.hip): they
+    only feed the optimizer, so they overlap the data-gradient chain.  Operands are kept alive
+    until the join, which autograd runs as an end-of-backward callback."""
+    enabled = os.environ.get("S2T_WGRAD_STREAM", "1") == "1"
+    handle = None
+    keep = []
+    queued = False
+
+
+def side_stream_handle():
+    """Raw handle of the side stream if weight-gradient work may be in flight on it."""
+    return _Side.handle
+
+
+def _side_join():
+    if _Side.handle is not None:
+        N.check(N.lib().s2t_stream_order(_Side.handle, N.stream()), "s2t_stream_order(join)")
+    _Side.keep.clear()
+    _Side.queued = False
+
+
+def _side_launch_stream(*tensors):
+    """Orders the side stream after the work enqueued so far on the current stream and returns
+    its handle; falls back to the current stream outside a backward pass."""
+    if not _Side.enabled:
+        return None
+    if _Side.handle is None:
+        h = N.lib().s2t_side_stream()
+        if not h:
+            _Side.enabled = False
+            return None
+        _Side.handle = ctypes.c_void_p(h)
+    if not _Side.queued:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_side_join)
+        except RuntimeError:                       # not inside a backward pass
+            return None
+        _Side.queued = True
+    N.check(N.lib().s2t_stream_order(N.stream(), _Side.handle), "s2t_stream_order(fork)")
+    _Side.keep.append(tensors)
+    return _Side.handle
+
+
+def gemm_tn(g2, a2, out, colsum=None, pro=0, stream=None):
     """out (N,M) += g2^T act(a2); colsum (N) += column sums of g2.   HIP: gemm.hip mode TN."""
     R, Nf = g2.shape
     Mf = a2.shape[1]
@@ -790,7 +835,8 @@ def gemm_tn(g2, a2, out, colsum=None, pro=0):
     N.check(N.lib().s2t_gemm_f32(2, N.raw(g2, torch.float32), g2.stride(0),
                                  N.raw(a2, torch.float32), a2.stride(0), N.fp(out), out.stride(0),
                                  Nf, Mf, R, None, None, 0, None, 0, 0, 0, int(pro),
-                                 N.fp(colsum), 0, N.stream()), "s2t_gemm_f32(TN)")
+                                 N.fp(colsum), 0, stream if stream is not None else N.stream()),
+            "s2t_gemm_f32(TN)")
 
 
 def wgrad_into(wparam, bparam, g2, a2, pro=0):
@@ -812,7 +858,7 @@ def wgrad_into(wparam, bparam, g2, a2, pro=0):
         bg = bparam.grad
         if bg is None or not bg.is_contiguous():
             return False
-    gemm_tn(g2, a2, wg, bg, pro)
+    gemm_tn(g2, a2, wg, bg, pro, stream=_side_launch_stream(g2, a2))
     flat.grad_written(wparam)
     if bparam is not None:
         flat.grad_written(bparam)
