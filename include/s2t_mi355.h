@@ -298,6 +298,19 @@ int s2t_bypass_fwd(const float* orig, const float* src, const float* scale, long
                    float* out, void* stream);
 int s2t_bypass_bwd(const float* orig, const float* src, const float* scale, const float* g,
                    long rows, int C, float* d_orig, float* d_src, float* d_scale, void* stream);
+/* layer-executor helpers (speech2text_amd/zip_layer.py): bypass backward whose d_orig also takes
+ * the gradient already collected for orig (acc_in); grad += d with limit_param_value's sign flip
+ * (model/layer/scaling.py:1153-1190) applied to d when `limit`; the softmax-backward row constants
+ * delta[h,b,i] of the attention weights from its deferred consumers (pairs (dO,O) of the two
+ * SelfAttention modules, dW0 (B,T,T) of the head-0 consumer), one launch. */
+int s2t_bypass_bwd_acc(const float* orig, const float* src, const float* scale, const float* g,
+                       const float* acc_in, long rows, int C, float* d_orig, float* d_src,
+                       float* d_scale, void* stream);
+int s2t_param_grad_commit(const float* x, const float* d, float lo, float hi, int limit, long n,
+                          float* grad, void* stream);
+int s2t_attn_delta_pairs(const float* W, const float* dW0, const float* dO1, const float* O1,
+                         int dv1, const float* dO2, const float* O2, int dv2, int T, int B, int H,
+                         float* delta, void* stream);
 int s2t_nonlin_gate_fwd(const float* u, int T, int B, int C, float* xs, void* stream);
 int s2t_nonlin_out_fwd(const float* z, const float* u, int T, int B, int C, float* o, void* stream);
 int s2t_nonlin_out_bwd(const float* g, const float* z, const float* u, int T, int B, int C, float* dz,

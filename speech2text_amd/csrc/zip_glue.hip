@@ -49,6 +49,77 @@ __global__ __launch_bounds__(256) void bypass_bwd_kernel(const float* __restrict
   }
 }
 
+// as bypass_bwd, d_orig additionally receives acc_in (the gradient already collected for orig)
+__global__ __launch_bounds__(256) void bypass_bwd_acc_kernel(const float* __restrict__ orig,
+                                                             const float* __restrict__ src,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ g,
+                                                             const float* __restrict__ acc_in,
+                                                             long rows, int C,
+                                                             float* __restrict__ d_orig,
+                                                             float* __restrict__ d_src,
+                                                             float* __restrict__ d_scale) {
+  const long r0 = (long)blockIdx.x * RB, r1 = min(rows, r0 + RB);
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float k = scale[c];
+    float acc = 0.f;
+    for (long r = r0; r < r1; ++r) {
+      const long i = r * C + c;
+      const float gv = g[i], ds = gv * k;
+      d_src[i] = ds;
+      d_orig[i] = gv - ds + acc_in[i];
+      acc = fmaf(gv, src[i] - orig[i], acc);
+    }
+    atomicAdd(d_scale + c, acc);
+  }
+}
+
+// grad[e] += d[e], with limit_param_value's sign flip applied to d first when `limit` is set
+__global__ __launch_bounds__(256) void param_grad_commit_kernel(const float* __restrict__ x,
+                                                                const float* __restrict__ d,
+                                                                float lo, float hi, int limit,
+                                                                long n, float* __restrict__ grad) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  float v = d[e];
+  if (limit) {
+    const float xv = x[e];
+    if (v > 0.f && xv < lo) v = -v;
+    if (v < 0.f && xv > hi) v = -v;
+  }
+  grad[e] += v;
+}
+
+// delta[h,b,i] = sum_d dO1 O1 + sum_d dO2 O2 (+ sum_j W[0,b,i,j] dW0[b,i,j] for h == 0):
+// the softmax-backward row constants from the deferred consumers; one wave per (h,b,i)
+__global__ __launch_bounds__(256) void attn_delta_pairs_kernel(
+    const float* __restrict__ W, const float* __restrict__ dW0, const float* __restrict__ dO1,
+    const float* __restrict__ O1, int dv1, const float* __restrict__ dO2,
+    const float* __restrict__ O2, int dv2, int T, int B, int H, float* __restrict__ delta) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= (long)H * B * T) return;
+  const int i = (int)(row % T);
+  const int b = (int)((row / T) % B);
+  const int h = (int)(row / ((long)T * B));
+  float acc = 0.f;
+  if (dO1 && lane < dv1) {
+    const long o = ((long)i * B + b) * H * dv1 + (long)h * dv1 + lane;
+    acc = dO1[o] * O1[o];
+  }
+  if (dO2 && lane < dv2) {
+    const long o = ((long)i * B + b) * H * dv2 + (long)h * dv2 + lane;
+    acc = fmaf(dO2[o], O2[o], acc);
+  }
+  if (h == 0 && dW0) {
+    const float* w = W + ((long)b * T + i) * T;
+    const float* d = dW0 + ((long)b * T + i) * T;
+    for (int j = lane; j < T; j += 64) acc = fmaf(w[j], d[j], acc);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) delta[row] = acc;
+}
+
 // u (T,B,3C) = [s | x | y]  ->  xs (B,T,C) = x * tanh(s)
 __global__ __launch_bounds__(256) void nonlin_gate_fwd_kernel(const float* __restrict__ u, int T,
                                                               int B, int C,
@@ -141,6 +212,39 @@ extern "C" int s2t_bypass_bwd(const float* orig, const float* src, const float* 
   if (C <= 0) return -1;
   hipLaunchKernelGGL(bypass_bwd_kernel, dim3((unsigned)((rows + RB - 1) / RB)), dim3(256), 0,
                      (hipStream_t)stream, orig, src, scale, g, rows, C, d_orig, d_src, d_scale);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int s2t_bypass_bwd_acc(const float* orig, const float* src, const float* scale,
+                                  const float* g, const float* acc_in, long rows, int C,
+                                  float* d_orig, float* d_src, float* d_scale, void* stream) {
+  if (rows <= 0) return 0;
+  if (C <= 0 || !acc_in) return -1;
+  hipLaunchKernelGGL(bypass_bwd_acc_kernel, dim3((unsigned)((rows + RB - 1) / RB)), dim3(256), 0,
+                     (hipStream_t)stream, orig, src, scale, g, acc_in, rows, C, d_orig, d_src,
+                     d_scale);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int s2t_param_grad_commit(const float* x, const float* d, float lo, float hi, int limit,
+                                     long n, float* grad, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(param_grad_commit_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, x, d, lo, hi, limit, n, grad);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int s2t_attn_delta_pairs(const float* W, const float* dW0, const float* dO1,
+                                    const float* O1, int dv1, const float* dO2, const float* O2,
+                                    int dv2, int T, int B, int H, float* delta, void* stream) {
+  if (T <= 0 || B <= 0 || H <= 0) return 0;
+  if (dv1 > 64 || dv2 > 64 || dv1 < 0 || dv2 < 0) return -1;
+  const long rows = (long)H * B * T;
+  hipLaunchKernelGGL(attn_delta_pairs_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                     (hipStream_t)stream, W, dW0, dO1, O1, dv1, dO2, O2, dv2, T, B, H, delta);
   S2T_CHECK_LAUNCH();
   return 0;
 }

@@ -80,9 +80,10 @@ class GradReducer:
         return lambda _p: self._grad_ready(q)
 
     def _grad_ready(self, q):
-        """One gradient contribution of parameter q is complete: called by autograd's
-        post-accumulate hook (once per backward), or once per use by kernels that accumulate
-        into the flat buffer themselves (FlatStore.on_grad).  The number of calls per parameter
+        """Parameter q's gradient of this backward is complete: called by autograd's
+        post-accumulate hook (once per backward; it also runs when a Function wrote the gradient
+        in place and returned None), or by the layer executor, whose parameters are not part of
+        the autograd graph (FlatStore.on_grad, once per use).  The number of calls per parameter
         and step is learned in the first synchronised step."""
         if not self.require_sync:
             return

@@ -116,8 +116,12 @@ def owned(param) -> bool:
 
 
 def grad_written(param):
-    """A kernel accumulated this parameter's gradient directly into its flat view (autograd's
-    AccumulateGrad node will not run for it): tell the data-parallel reducer."""
+    """A kernel accumulated this parameter's gradient directly into its flat view from OUTSIDE
+    autograd's graph of that parameter (the layer executor, zip_layer.py: the parameter is not an
+    input of its autograd node, so no AccumulateGrad / post-accumulate hook runs for it): tell the
+    data-parallel reducer.  Autograd Functions that write a parameter's gradient in place and
+    return None for it must NOT call this -- the engine still runs the parameter's
+    post-accumulate hook afterwards, and that hook is the reducer's signal."""
     ent = _OWNER.get(id(param))
     if ent is not None and ent[0].on_grad is not None:
         ent[0].on_grad(ent[1])

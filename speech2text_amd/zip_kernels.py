@@ -308,6 +308,69 @@ def limit_param_grad(x, g, lo, hi):
 
 
 # ------------------------------------------------------------------ conv module core
+def conv_params(conv, T, chunk_size):
+    """-> (chunk, K, wc, bc, wk, bk, scale): the parameters of a ChunkCausalDepthwiseConv1d-like
+    module (causal_conv / chunkwise_conv / chunkwise_conv_scale) or of a depthwise nn.Conv1d
+    (wc, bc, scale = None) and the chunk length the kernel works with."""
+    if isinstance(conv, torch.nn.Conv1d):
+        K = conv.kernel_size[0]
+        assert conv.groups == conv.in_channels and conv.padding[0] == K // 2
+        return max(T, 1), K, None, None, conv.weight, conv.bias, None
+    chunk = T if (chunk_size < 0 or chunk_size > T) else chunk_size
+    return (chunk, conv.kernel_size, conv.causal_conv.weight, conv.causal_conv.bias,
+            conv.chunkwise_conv.weight, conv.chunkwise_conv.bias, conv.chunkwise_conv_scale)
+
+
+def zipconv_forward(u, gate_off, m8, chunk, K, wc, bc, wk, bk, scale):
+    """u (T,B,ld) contiguous fp32 -> y (T,B,C).   HIP: zip_conv.hip."""
+    T, B, ld = u.shape
+    C = wk.shape[0]
+    y = torch.empty((T, B, C), dtype=torch.float32, device=u.device)
+    N.profile_note("s2t_zipconv_fwd", 4.0 * (u.numel() + y.numel()))
+    N.check(N.lib().s2t_zipconv_fwd(N.fp(u), ld, gate_off, N.ptr(m8), T, B, C, K, chunk,
+                                    N.fp(wc), N.fp(bc), N.fp(wk), N.fp(bk), N.fp(scale), N.fp(y),
+                                    N.stream()), "s2t_zipconv_fwd")
+    return y
+
+
+def zipconv_backward(u, gate_off, m8, chunk, K, wc, wk, bk, scale, dy, grads):
+    """-> du (T,B,2C | C).  grads = (dwc, dbc, dwk, dbk, dscale) tensors the kernels ACCUMULATE the
+    parameter gradients into (None where the parameter is absent)."""
+    T, B, ld = u.shape
+    C = wk.shape[0]
+    dev = u.device
+    du = torch.empty((T, B, 2 * C if gate_off >= 0 else C), dtype=torch.float32, device=dev)
+    ws = torch.empty(N.lib().s2t_zipconv_bwd_workspace_floats(T, B, C, K), dtype=torch.float32,
+                     device=dev)
+    dwc, dbc, dwk, dbk, dsc = grads
+    N.profile_note("s2t_zipconv_bwd", 4.0 * (2 * u.numel() + 2 * dy.numel()))
+    N.check(N.lib().s2t_zipconv_bwd(N.fp(u), ld, gate_off, N.ptr(m8), T, B, C, K, chunk,
+                                    N.fp(wc), N.fp(wk), N.fp(bk), N.fp(scale), N.fp(dy),
+                                    N.fp(du), N.raw(dwc) if dwc is not None else None,
+                                    N.raw(dbc) if dbc is not None else None, N.raw(dwk),
+                                    N.raw(dbk) if dbk is not None else None,
+                                    N.raw(dsc) if dsc is not None else None, N.fp(ws),
+                                    N.stream()), "s2t_zipconv_bwd")
+    return du
+
+
+def direct_grads(params):
+    """The flat-store gradient views of `params` (None entries stay None) when every one of them
+    is a leaf living in a FlatStore, else None."""
+    out = []
+    for p in params:
+        if p is None:
+            out.append(None)
+            continue
+        if not (p.is_leaf and flat.owned(p)):
+            return None
+        g = p.grad
+        if g is None or not g.is_contiguous():
+            return None
+        out.append(g)
+    return out
+
+
 class _ZipConv(torch.autograd.Function):
     """Fused gate + padding mask + (chunk-causal | plain) depthwise conv, time-major."""
 
@@ -315,20 +378,10 @@ class _ZipConv(torch.autograd.Function):
     def forward(ctx, u, gate_off, mask, chunk, K, wc, bc, wk, bk, scale):
         _dev(u, wk)
         u = u.contiguous().float()
-        T, B, ld = u.shape
-        C = wk.shape[0]
-        y = torch.empty((T, B, C), dtype=torch.float32, device=u.device)
         m8 = None if mask is None else mask.to(torch.uint8).contiguous()
-        args = dict(wc=None if wc is None else wc.contiguous(),
-                    bc=None if bc is None else bc.contiguous(), wk=wk.contiguous(),
-                    bk=None if bk is None else bk.contiguous(),
-                    scale=None if scale is None else scale.contiguous())
-        N.profile_note("s2t_zipconv_fwd", 4.0 * (u.numel() + y.numel()))
-        N.check(N.lib().s2t_zipconv_fwd(N.fp(u), ld, gate_off, N.ptr(m8), T, B, C, K, chunk,
-                                        N.fp(args["wc"]), N.fp(args["bc"]), N.fp(args["wk"]),
-                                        N.fp(args["bk"]), N.fp(args["scale"]), N.fp(y),
-                                        N.stream()), "s2t_zipconv_fwd")
-        ctx.save_for_backward(u, m8, args["wc"], args["wk"], args["bk"], args["scale"])
+        cont = [None if t is None else t.contiguous() for t in (wc, bc, wk, bk, scale)]
+        y = zipconv_forward(u, gate_off, m8, chunk, K, *cont)
+        ctx.save_for_backward(u, m8, cont[0], cont[2], cont[3], cont[4])
         ctx.cfg = (gate_off, chunk, K, bc is not None)
         ctx.params = (wc, bc, wk, bk, scale)
         return y
@@ -338,46 +391,24 @@ class _ZipConv(torch.autograd.Function):
         u, m8, wc, wk, bk, scale = ctx.saved_tensors
         gate_off, chunk, K, has_bc = ctx.cfg
         dy = dy.contiguous().float()
-        T, B, ld = u.shape
         C = wk.shape[0]
-        dev = u.device
-        du = torch.empty((T, B, 2 * C if gate_off >= 0 else C), dtype=torch.float32, device=dev)
         Kh = (K + 1) // 2
         # parameter gradients are ACCUMULATED by the kernels (reduce pass / atomics): when every
         # parameter lives in the flat store they go straight into its gradient views, otherwise
         # into one zeroed scratch buffer that is handed back to autograd
-        plist = [p for p in ctx.params if p is not None]
-        direct = all(p.is_leaf and flat.owned(p) and p.grad is not None and p.grad.is_contiguous()
-                     for p in plist)
-        ws = torch.empty(N.lib().s2t_zipconv_bwd_workspace_floats(T, B, C, K), dtype=torch.float32,
-                         device=dev)
-        if direct:
-            pw, pb, pk, pbk, ps = ctx.params
-            dwc = None if pw is None else pw.grad
-            dbc = None if pb is None else pb.grad
-            dwk, dbk = pk.grad, (None if pbk is None else pbk.grad)
-            dsc = None if ps is None else ps.grad
-        else:
-            sizes = [C * Kh if wc is not None else 0, C if wc is not None else 0, C * K,
-                     C if bk is not None else 0, 2 * C * K if scale is not None else 0]
-            buf = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
-            parts, o = [], 0
-            for n in sizes:
-                parts.append(buf[o:o + n] if n else None)
-                o += n
-            dwc, dbc, dwk, dbk, dsc = parts
-        N.profile_note("s2t_zipconv_bwd", 4.0 * (2 * u.numel() + 2 * dy.numel()))
-        N.check(N.lib().s2t_zipconv_bwd(N.fp(u), ld, gate_off, N.ptr(m8), T, B, C, K, chunk,
-                                        N.fp(wc), N.fp(wk), N.fp(bk), N.fp(scale), N.fp(dy),
-                                        N.fp(du), N.raw(dwc) if dwc is not None else None,
-                                        N.raw(dbc) if dbc is not None else None, N.raw(dwk),
-                                        N.raw(dbk) if dbk is not None else None,
-                                        N.raw(dsc) if dsc is not None else None, N.fp(ws),
-                                        N.stream()), "s2t_zipconv_bwd")
-        if direct:
-            for p in plist:
-                flat.grad_written(p)
+        grads = direct_grads(ctx.params)
+        if grads is not None:
+            du = zipconv_backward(u, gate_off, m8, chunk, K, wc, wk, bk, scale, dy, grads)
             return (du,) + (None,) * 9
+        sizes = [C * Kh if wc is not None else 0, C if wc is not None else 0, C * K,
+                 C if bk is not None else 0, 2 * C * K if scale is not None else 0]
+        buf = torch.zeros(sum(sizes), dtype=torch.float32, device=u.device)
+        parts, o = [], 0
+        for n in sizes:
+            parts.append(buf[o:o + n] if n else None)
+            o += n
+        dwc, dbc, dwk, dbk, dsc = parts
+        du = zipconv_backward(u, gate_off, m8, chunk, K, wc, wk, bk, scale, dy, parts)
         return (du, None, None, None, None,
                 None if dwc is None else dwc.view(C, 1, Kh),
                 dbc if has_bc else None, dwk.view(C, 1, K), dbk,
@@ -387,20 +418,10 @@ class _ZipConv(torch.autograd.Function):
 def glu_chunk_causal_dwconv(u, gate_off, key_padding_mask, conv, chunk_size):
     """u (T,B,ld): x = u[..., :C], gate pre-activation = u[..., gate_off:gate_off+C]
     (gate_off None: no gate) -> y (T,B,C) = dwconv((x * sigmoid(gate)) zeroed on padded frames).
-    conv: ChunkCausalDepthwiseConv1d-like module (causal_conv / chunkwise_conv /
-    chunkwise_conv_scale) or a depthwise nn.Conv1d.   HIP: zip_conv.hip."""
-    T = u.shape[0]
+    conv: ChunkCausalDepthwiseConv1d-like module or a depthwise nn.Conv1d.   HIP: zip_conv.hip."""
     go = -1 if gate_off is None else int(gate_off)
-    if isinstance(conv, torch.nn.Conv1d):
-        K = conv.kernel_size[0]
-        assert conv.groups == conv.in_channels and conv.padding[0] == K // 2
-        return _ZipConv.apply(u, go, key_padding_mask, max(T, 1), K, None, None, conv.weight,
-                              conv.bias, None)
-    K = conv.kernel_size
-    chunk = T if (chunk_size < 0 or chunk_size > T) else chunk_size
-    return _ZipConv.apply(u, go, key_padding_mask, chunk, K, conv.causal_conv.weight,
-                          conv.causal_conv.bias, conv.chunkwise_conv.weight,
-                          conv.chunkwise_conv.bias, conv.chunkwise_conv_scale)
+    chunk, K, wc, bc, wk, bk, scale = conv_params(conv, u.shape[0], chunk_size)
+    return _ZipConv.apply(u, go, key_padding_mask, chunk, K, wc, bc, wk, bk, scale)
 
 
 # ------------------------------------------------------------------ attention
@@ -839,11 +860,12 @@ def gemm_tn(g2, a2, out, colsum=None, pro=0, stream=None):
             "s2t_gemm_f32(TN)")
 
 
-def wgrad_into(wparam, bparam, g2, a2, pro=0):
+def wgrad_into(wparam, bparam, g2, a2, pro=0, notify=False):
     """Accumulates dW = g2^T act(a2) (and db) DIRECTLY into wparam.grad / bparam.grad when those
     are the flat-store views (speech2text_amd.flat): one launch, no temporary, no autograd
     accumulate kernel.  Returns False when that is not possible (the caller then returns the
-    gradients as tensors)."""
+    gradients as tensors).  notify: the caller is not an autograd node of these parameters (the
+    layer executor), so no post-accumulate hook will follow -- tell the gradient reducer here."""
     if not (wparam.is_leaf and flat.owned(wparam) and _tn_ok(g2) and _tn_ok(a2)):
         return False
     wg = wparam.grad
@@ -859,9 +881,10 @@ def wgrad_into(wparam, bparam, g2, a2, pro=0):
         if bg is None or not bg.is_contiguous():
             return False
     gemm_tn(g2, a2, wg, bg, pro, stream=_side_launch_stream(g2, a2))
-    flat.grad_written(wparam)
-    if bparam is not None:
-        flat.grad_written(bparam)
+    if notify:
+        flat.grad_written(wparam)
+        if bparam is not None:
+            flat.grad_written(bparam)
     return True
 
 

@@ -1,0 +1,96 @@
+"""GPU: the one-node-per-layer executor (speech2text_amd/zip_layer.py) against the
+module-by-module layer path on the same weights, inputs and random stream -- with every Balancer
+and Whiten forced to fire, with the default probabilities, full and chunk-causal attention.
+(The module path itself is pinned to the reference goldens / the oracle in test_gpu_zipformer.py,
+which also runs the executor against the oracle.)"""
+import random
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(feature_dim=80, downsampling_factor=(1, 2, 4), num_encoder_layers=(2, 1, 1),
+           feedforward_dim=(128, 192, 192), encoder_dim=(64, 96, 96), encoder_unmasked_dim=(48, 64, 64),
+           num_heads=(4, 4, 8), query_head_dim=(16,), value_head_dim=(8,), pos_head_dim=(4,),
+           pos_dim=24, cnn_module_kernel=(15, 7, 7), causal=True)
+
+
+def _build(dev, chunk, left):
+    from speech2text_amd import flat
+    from speech2text_amd.model.encoder.zipformer import Zipformer2, Zipformer2Config
+    torch.manual_seed(5)
+    m = Zipformer2(Zipformer2Config(**CFG, chunk_size=chunk, left_context_frames=left)).to(dev)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith("bypass_scale"):
+                p.uniform_(0.2, 1.1)                       # some outside [min, max]: limit flips
+            elif n.endswith("chunkwise_conv_scale"):
+                p.normal_(0, 0.3)
+            elif "out_proj" in n or "linear_pos" in n:
+                p.mul_(6.0)
+    for mod in m.modules():
+        if mod.__class__.__name__ == "CompactRelPositionalEncoding":
+            mod.dropout.p = 0.0
+    store = flat.FlatStore(list(m.parameters()))
+    m.train()
+    return m, store
+
+
+def _force(m, on):
+    from speech2text_amd.model.layer.scaling import Balancer, Whiten
+    for mod in m.modules():
+        if isinstance(mod, Balancer) and on:
+            mod._modules.pop("prob", None)             # a ScheduledFloat child by default
+            mod.prob = 1.0
+        if isinstance(mod, Whiten):
+            if on:
+                mod.min_prob = mod.max_prob = 1.0
+            mod.prob = mod.max_prob
+
+
+def _step(m, store, x, lens, wts, seed, executor):
+    from speech2text_amd import zip_layer
+    zip_layer.ENABLED = executor
+    store.flat_g.zero_()
+    random.seed(seed)
+    torch.manual_seed(seed)
+    xg = x.clone().requires_grad_(True)
+    y, _ = m(xg, lens)
+    (y * wts).sum().backward()
+    torch.cuda.synchronize()
+    zip_layer.ENABLED = True
+    return y.detach().clone(), xg.grad.clone(), store.flat_g.clone()
+
+
+@pytest.mark.parametrize("force", [True, False])
+@pytest.mark.parametrize("chunk,left", [((-1,), (-1,)), ((8,), (16,))])
+def test_executor_matches_module_path(dev, monkeypatch, force, chunk, left):
+    from speech2text_amd import rng, zip_layer
+    monkeypatch.setattr(rng, "rand", lambda *s, device=None, dtype=torch.float32:
+                        torch.rand(*s, dtype=dtype).to(device))
+    m, store = _build(dev, chunk, left)
+    _force(m, force)
+    g = torch.Generator().manual_seed(9)
+    B, T = 4, 211
+    x = (torch.randn(B, T, 80, generator=g) * 2).to(dev)
+    lens = torch.tensor([211, 190, 97, 64]).to(dev)
+    with torch.no_grad():
+        wts = torch.randn(m(x, lens)[0].shape, generator=g).to(dev)
+    served = 0
+    for seed in range(6):
+        _force(m, force)
+        c0 = zip_layer.CALLS[0]
+        y1, gx1, gp1 = _step(m, store, x, lens, wts, seed, True)
+        served += zip_layer.CALLS[0] - c0
+        _force(m, force)                      # Whiten.prob moves in backward: same start state
+        y0, gx0, gp0 = _step(m, store, x, lens, wts, seed, False)
+        torch.testing.assert_close(y1, y0, atol=2e-5, rtol=1e-4)
+        torch.testing.assert_close(gx1, gx0, atol=2e-5, rtol=2e-3)
+        scale = gp0.abs().max()
+        assert (gp1 - gp0).abs().max() / scale < 2e-4, (seed, (gp1 - gp0).abs().max(), scale)
+        # per parameter, so a small tensor's gradient cannot hide behind a large one's scale
+        for p, (o, n) in zip(store.params, zip(store.offsets, store.lengths)):
+            a, b = gp1[o:o + n], gp0[o:o + n]
+            assert (a - b).abs().max() <= 2e-3 * b.abs().max() + 1e-6, (seed, tuple(p.shape))
+    assert served >= 12                       # 4 layers x 6 steps minus the ~10 % penalty draws

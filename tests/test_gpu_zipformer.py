@@ -95,13 +95,22 @@ def test_tiny_vs_reference_goldens(golden_dir, dev, cpu_rng, tag, chunk, left):
         assert np.abs(got - ref).max() / denom < 5e-3, (n, np.abs(got - ref).max(), denom)
 
 
-@pytest.mark.parametrize("rv", [0.0, 0.5])
-def test_mid_ragged_vs_oracle(dev, cpu_rng, rv):
+@pytest.mark.parametrize("rv,store", [(0.0, False), (0.5, False), (0.5, True), (0.2, True),
+                                      (0.0, True)])
+def test_mid_ragged_vs_oracle(dev, cpu_rng, rv, store):
     """rv = value returned by random.random(): 0.0 -> all gradient shaping + the score penalty
     (materialised attention path); 0.5 -> no Balancer/Whiten/penalty, limit_param_value only,
-    which exercises the fused attention path with deferred (never materialised) dW."""
+    which exercises the fused attention path with deferred (never materialised) dW; 0.2 -> the
+    default-probability Balancers, every Whiten and limit_param_value, no penalty.
+    store: parameters in a FlatStore (as under the Trainer) -> the one-node-per-layer executor
+    (speech2text_amd/zip_layer.py) serves every layer call whose draws do not ask for the score
+    penalty; without a store the module-by-module path runs."""
+    from speech2text_amd import flat, zip_layer
     torch.manual_seed(11)
     m = _model(MID, (-1,), (-1,), dev)
+    if store:
+        flat.FlatStore(list(m.parameters()))
+    calls0 = zip_layer.CALLS[0]
     with torch.no_grad():
         for n, p in m.named_parameters():
             if n.endswith("bypass_scale"):
@@ -132,6 +141,8 @@ def test_mid_ragged_vs_oracle(dev, cpu_rng, rv):
     (yo * wts).sum().backward()
     xg = x.to(dev).requires_grad_(True)
     y, _ = _train_step(m, xg, lens.to(dev), wts.to(dev), rv)
+    n_layers = sum(MID["num_encoder_layers"])
+    assert zip_layer.CALLS[0] - calls0 == (n_layers if store and rv >= 0.1 else 0)
     np.testing.assert_allclose(y.detach().cpu().numpy(), yo.detach().numpy(), atol=1e-4, rtol=2e-3)
     np.testing.assert_allclose(xg.grad.cpu().numpy(), xc.grad.numpy(), atol=5e-5, rtol=1e-2)
     worst = 0.0
