@@ -45,10 +45,28 @@ class _Prof:
     algo_flops = {}
 
 
+_NO_LAUNCH = ("s2t_side_stream", "s2t_stream_order")   # stream plumbing, nothing to time
+_EXT = {}
+
+
+def _launch_stream(args):
+    """The torch stream object of the hipStream_t a launch was given (every launching entry point
+    takes it as its last argument): events must be recorded on THAT stream -- the weight-gradient
+    GEMMs run on the library's side stream, not on torch's current one."""
+    cur = torch.cuda.current_stream()
+    h = args[-1].value if args and isinstance(args[-1], ctypes.c_void_p) else None
+    if not h or h == cur.cuda_stream:
+        return cur
+    st = _EXT.get(h)
+    if st is None:
+        st = _EXT[h] = torch.cuda.ExternalStream(h)
+    return st
+
+
 class _LibProxy:
     """Attribute access returns the ctypes function.  While profile_begin() is active the
     functions are wrapped so that launches of the selected entry point(s) are bracketed by HIP
-    events on the current stream; otherwise the raw ctypes function is cached on the instance
+    events on the stream the launch is given; otherwise the raw ctypes function is cached on the instance
     (no per-call indirection on the training path)."""
 
     def __init__(self, cdll):
@@ -60,7 +78,8 @@ class _LibProxy:
 
     def __getattr__(self, name):
         raw = getattr(self._cdll, name)
-        if _Prof.target is None or name.endswith("_floats") or name.endswith("_elems"):
+        if _Prof.target is None or name.endswith("_floats") or name.endswith("_elems") \
+                or name in _NO_LAUNCH:
             fn = raw
         else:
             def fn(*args, _raw=raw, _name=name):
@@ -69,9 +88,10 @@ class _LibProxy:
                     return _raw(*args)
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
-                e0.record()
+                st = _launch_stream(args)
+                e0.record(st)
                 rc = _raw(*args)
-                e1.record()
+                e1.record(st)
                 _Prof.events.setdefault(_name, []).append((e0, e1))
                 return rc
         self.__dict__[name] = fn

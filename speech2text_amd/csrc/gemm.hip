@@ -24,7 +24,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 32;
+constexpr int BK0 = 32;   // contraction chunk of the big tiles; the 64x64 tile uses 64
 enum { MODE_NT = 0, MODE_NN = 1, MODE_TN = 2 };
 enum { ACT_NONE = 0, ACT_SWOOSH_L = 1, ACT_SWOOSH_R = 2 };
 
@@ -47,6 +47,7 @@ struct GemmArgs {
   int accumulate;         // NT / NN: C += result
   int kper;               // TN: contraction rows per z-slice (multiple of BK)
   int tiles_m, tiles_n;
+  int splits;
   int debug;
 };
 
@@ -65,7 +66,7 @@ __device__ __forceinline__ float swoosh_deriv(float x, int kind) {
 // KM: [BK][ROWS + 4] (k-major).  ROWS = 64 * T.  Loads are unconditional (clamped addresses) so
 // that all of a chunk's global loads are in flight together; validity and the activation are
 // applied one iteration later, when the registers are written to LDS.
-template <int ROWS, bool KC, int ACT>
+template <int ROWS, bool KC, int ACT, int BK>
 struct Tile {
   static constexpr int LD = KC ? (BK + 4) : (ROWS + 4);
   static constexpr int SIZE = KC ? ROWS * LD : BK * LD;
@@ -80,8 +81,8 @@ struct Tile {
       const int idx = threadIdx.x + 256 * i;
       int o, k;
       if (KC) {
-        o = out0 + (idx >> 3);                         // 8 float4 per row of 32 k
-        k = k0 + 4 * (idx & 7);
+        o = out0 + idx / (BK / 4);                     // BK / 4 float4 per row of BK k
+        k = k0 + 4 * (idx % (BK / 4));
       } else {
         constexpr int V = ROWS / 4;                    // float4 per k row
         k = k0 + idx / V;
@@ -105,7 +106,7 @@ struct Tile {
         x = make_float4(swoosh(x.x, ACT), swoosh(x.y, ACT), swoosh(x.z, ACT), swoosh(x.w, ACT));
       if (!((ok >> i) & 1u)) x = make_float4(0.f, 0.f, 0.f, 0.f);
       if (KC) {
-        *reinterpret_cast<float4*>(s + (idx >> 3) * LD + 4 * (idx & 7)) = x;
+        *reinterpret_cast<float4*>(s + (idx / (BK / 4)) * LD + 4 * (idx % (BK / 4))) = x;
       } else {
         constexpr int V = ROWS / 4;
         *reinterpret_cast<float4*>(s + (idx / V) * LD + 4 * (idx % V)) = x;
@@ -123,13 +124,18 @@ struct Tile {
   }
 };
 
+constexpr int bk_of(int tm, int tn, int mode) {
+  return BK0;   // (a 64-deep chunk for the 64x64 TN tile measured the same as 32)
+}
+
 template <int TM, int TN, int MODE, int PRO>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   constexpr bool A_KC = MODE != MODE_TN, B_KC = MODE == MODE_NT;
   constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int BK = bk_of(TM, TN, MODE);
   // the staged activation applies to A in NT (y = act(x) W^T) and to B in TN (dW = g^T act(x))
-  using TA = Tile<BM, A_KC, (MODE == MODE_NT ? PRO : ACT_NONE)>;
-  using TB = Tile<BN, B_KC, (MODE == MODE_TN ? PRO : ACT_NONE)>;
+  using TA = Tile<BM, A_KC, (MODE == MODE_NT ? PRO : ACT_NONE), BK>;
+  using TB = Tile<BN, B_KC, (MODE == MODE_TN ? PRO : ACT_NONE), BK>;
   __shared__ __attribute__((aligned(16))) float sA[TA::SIZE];
   __shared__ __attribute__((aligned(16))) float sB[TB::SIZE];
 
@@ -137,11 +143,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   // tiles, n fastest, so the n-tiles of one m-panel share that XCD's L2 copy of the A panel
   const int total = g.tiles_m * g.tiles_n;
   const int per_xcd = (total + 7) / 8;
-  // (TN grids are (tiles, 1, slices) with few tiles: taken in launch order, which already
-  // spreads consecutive blocks over the XCDs)
-  const int lin = MODE == MODE_TN ? (int)blockIdx.x
-                                  : (int)((blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3));
-  if (lin >= total) return;
+  // TN: 1-D grid of tiles x slices.  Workgroups are dealt to the XCDs round-robin, so XCD x gets
+  // blocks x, x + 8, ...: those walk the tiles of slice x, then of slice x + 8, ... -- all tiles
+  // of one contraction slice run on ONE XCD and share its L2 copy of that slice's operand rows.
+  int lin, zslice = 0;
+  if (MODE == MODE_TN) {
+    const int q = (int)(blockIdx.x >> 3);
+    zslice = (int)(blockIdx.x & 7) + 8 * (q / total);
+    lin = q % total;
+    if (zslice >= g.splits) return;
+  } else {
+    lin = (int)((blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3));
+    if (lin >= total) return;
+  }
   const int tm = lin / g.tiles_n, tn = lin % g.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -149,7 +163,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
   int kbeg = 0, kend = g.K;
   if (MODE == MODE_TN) {
-    kbeg = blockIdx.z * g.kper;
+    kbeg = zslice * g.kper;
     kend = min(g.K, kbeg + g.kper);
     if (kbeg >= kend) return;
   }
@@ -237,8 +251,9 @@ int launch(GemmArgs& g, int splits, hipStream_t st) {
   g.tiles_n = (g.N + BN - 1) / BN;
   { const char* e = getenv("S2T_GEMM_DEBUG"); g.debug = e ? atoi(e) : 0; }
   const int total = g.tiles_m * g.tiles_n;
-  const int grid = MODE == MODE_TN ? total : ((total + 7) / 8) * 8;
-  hipLaunchKernelGGL((gemm_kernel<TM, TN, MODE, PRO>), dim3(grid, 1, splits), dim3(256), 0, st, g);
+  g.splits = splits;
+  const int grid = MODE == MODE_TN ? 8 * total * ((splits + 7) / 8) : ((total + 7) / 8) * 8;
+  hipLaunchKernelGGL((gemm_kernel<TM, TN, MODE, PRO>), dim3(grid), dim3(256), 0, st, g);
   return (int)hipGetLastError();
 }
 
@@ -249,10 +264,11 @@ int launch_p(GemmArgs& g, int pro, int splits, hipStream_t st) {
   return launch<TM, TN, MODE, ACT_SWOOSH_R>(g, splits, st);
 }
 
-// tile shapes: (2,2) 128x128, (2,3) 128x192, (1,2) 64x128, (1,1) 64x64
+// tile shapes: (2,2) 128x128, (2,3) 128x192, (2,1) 128x64, (1,2) 64x128, (1,1) 64x64
 template <int MODE>
 int launch_t(GemmArgs& g, int tm, int tn, int pro, int splits, hipStream_t st) {
   if (tm == 2 && tn == 3) return launch_p<2, 3, MODE>(g, pro, splits, st);
+  if (tm == 2 && tn == 1) return launch_p<2, 1, MODE>(g, pro, splits, st);
   if (tm == 2) return launch_p<2, 2, MODE>(g, pro, splits, st);
   if (tn >= 2) return launch_p<1, 2, MODE>(g, pro, splits, st);
   return launch_p<1, 1, MODE>(g, pro, splits, st);
@@ -265,14 +281,7 @@ int pick_tn(int N) {
   return (w192 < w128) ? 3 : 2;
 }
 
-int tn_blocks_target() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("S2T_TN_BLOCKS");
-    v = e ? atoi(e) : 512;
-  }
-  return v;
-}
+constexpr int KR = 64;   // TN slices are multiples of the deepest chunk
 
 template <int MODE>
 int dispatch(GemmArgs& g, hipStream_t st) {
@@ -280,18 +289,28 @@ int dispatch(GemmArgs& g, hipStream_t st) {
   const int pro = MODE == MODE_NT ? g.pro_a : (MODE == MODE_TN ? g.pro_b : 0);
   long tiles_big = (long)((g.M + 127) / 128) * ((g.N + 64 * tn_sel - 1) / (64 * tn_sel));
   if (MODE == MODE_TN) {
-    if (g.M <= 64 && tn_sel == 3) tiles_big = (long)((g.N + 127) / 128);
-    // output is small (features x features): split the long contraction over the chip; every
-    // slice adds its tile with fp32 atomics, so keep slices x output bytes small
-    int splits = (int)((tn_blocks_target() + tiles_big - 1) / tiles_big);
-    const int maxs = (g.K + 4 * BK - 1) / (4 * BK);
+    // The output (features x features) is small and the contraction long: split it over the chip
+    // and add every slice's tile with fp32 atomics.  Atomic bytes = workgroups x tile bytes and
+    // the chip adds ~1.3 TB/s, so SMALL tiles win: 64x64 tiles at ~6 workgroups per CU moved the
+    // C3 shapes from ~50 to ~75 TFLOP/s against 128x192 tiles at 2 per CU (tools/bench_tn.py);
+    // 64x128 once the output is wide enough to give the slices enough tiles.
+    // S2T_TN_TILE ("11", "12", "21", "22", "23") / S2T_TN_BLOCKS override the choice for tuning.
+    static int force = -1, user_blocks = -2;
+    if (force < 0) { const char* e = getenv("S2T_TN_TILE"); force = e ? atoi(e) : 0; }
+    if (user_blocks == -2) { const char* e = getenv("S2T_TN_BLOCKS"); user_blocks = e ? atoi(e) : -1; }
+    const int ttm = force > 0 ? force / 10 : 1;
+    const int ttn = force > 0 ? force % 10 : (g.N >= 512 ? 2 : 1);
+    const long tiles = (long)((g.M + 64 * ttm - 1) / (64 * ttm)) * ((g.N + 64 * ttn - 1) / (64 * ttn));
+    const int target = user_blocks > 0 ? user_blocks : (ttm * ttn == 1 ? 1536 : 768);
+    int splits = (int)((target + tiles - 1) / tiles);
+    const int maxs = (g.K + 2 * KR - 1) / (2 * KR);
     if (splits > maxs) splits = maxs;
     if (splits < 1) splits = 1;
     int kper = (g.K + splits - 1) / splits;
-    kper = ((kper + BK - 1) / BK) * BK;
+    kper = ((kper + KR - 1) / KR) * KR;
     g.kper = kper;
     splits = (g.K + kper - 1) / kper;
-    return launch_t<MODE>(g, g.M <= 64 ? 1 : 2, tn_sel == 3 && g.M <= 64 ? 2 : tn_sel, pro, splits, st);
+    return launch_t<MODE>(g, ttm, ttn, pro, splits, st);
   }
   if (tiles_big >= 384) return launch_t<MODE>(g, 2, tn_sel, pro, 1, st);
   if (tn_sel == 3) tn_sel = 2;
@@ -317,7 +336,7 @@ extern "C" int s2t_gemm_f32(int mode, const float* A, long lda, const float* B, 
   if (act_kind < 0 || act_kind > 2 || pro_a < 0 || pro_a > 2 || pro_b < 0 || pro_b > 2) return -1;
   if (mode == MODE_TN && (resid || act_src || bias)) return -1;
   GemmArgs g{A, lda, B, ldb, C, ldc, M, N, K, bias, resid, ldr, act_src, lds, act_kind, pro_a,
-             pro_b, colsum, accumulate, 0, 0, 0, 0};
+             pro_b, colsum, accumulate, 0, 0, 0, 0, 0};
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (mode == MODE_NT) rc = dispatch<MODE_NT>(g, st);

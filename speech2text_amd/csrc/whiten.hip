@@ -201,7 +201,10 @@ extern "C" int s2t_whiten_apply(const float* g, const float* pg, long numel, flo
     return -1;
   const long n4 = numel >> 2;
   const unsigned blocks = (unsigned)std::min<long>(2048, std::max<long>(1, (n4 + 255) / 256));
-  hipLaunchKernelGGL(sumsq2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, pg, numel,
+  // every workgroup ends with two atomics on the SAME two words (serialised by the memory
+  // system): keep that tail short -- 512 workgroups stream the two tensors just as fast
+  const unsigned sblocks = std::min(blocks, 512u);
+  hipLaunchKernelGGL(sumsq2_kernel, dim3(sblocks), dim3(256), 0, (hipStream_t)stream, g, pg, numel,
                      sums);
   S2T_CHECK_LAUNCH();
   hipLaunchKernelGGL(whiten_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, pg,

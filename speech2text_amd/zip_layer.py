@@ -196,7 +196,9 @@ def _ff_fwd(m, dec, x_in):
     fb, fw, fp = dec
     sv = _Saved()
     sv.h = zk.lt_matmul(0, x_in, m.in_proj.weight, m.in_proj.bias)
-    a = zk.swoosh_forward(sv.h, True)
+    # the activation is KEPT for the weight gradient (the reference recomputes it to save memory,
+    # scaling.py:1512-1583; 288 GB of HBM make the ~1 GB per step the cheaper side of that trade)
+    a = sv.a = zk.swoosh_forward(sv.h, True)
     sv.y = sv.st = None
     if not (fw or fp):
         out = zk.lt_matmul(0, a, m.out_proj.weight, m.out_proj.bias, x_in)
@@ -216,7 +218,7 @@ def _ff_bwd(m, post, dec, sv, x_in, g):
     if fw:
         gy = _whiten_bwd(m.out_whiten, sv.y, gy, sv.st)
     W = m.out_proj.weight
-    _wgrad(W, m.out_proj.bias, gy, sv.h, pro=1)
+    _wgrad(W, m.out_proj.bias, gy, sv.a)
     dh = zk.swoosh_backward(sv.h, zk.lt_matmul(1, gy, W), True)
     if fb:
         dh = _balancer_bwd(m.hidden_balancer, sv.h, dh)
@@ -265,15 +267,15 @@ def _conv_fwd(m, dec, x_in, T, B, chunk_size, k8):
     sv.cp = zk.conv_params(m.depthwise_conv, T, chunk_size)
     sv.y = zk.zipconv_forward(sv.u.view(T, B, 2 * D), D, k8, *sv.cp).view(T * B, D)
     sv.st = zk.WhitenStats(sv.y, m.whiten.num_groups) if fw else None
-    a = zk.swoosh_forward(sv.y, False)
-    return zk.lt_matmul(0, a, m.out_proj.weight, m.out_proj.bias, x_in), sv
+    sv.a = zk.swoosh_forward(sv.y, False)
+    return zk.lt_matmul(0, sv.a, m.out_proj.weight, m.out_proj.bias, x_in), sv
 
 
 def _conv_bwd(m, dec, sv, x_in, g, T, B, k8):
     fb1, fb2, fw = dec
     D = x_in.shape[1]
     W = m.out_proj.weight
-    _wgrad(W, m.out_proj.bias, g, sv.y, pro=2)
+    _wgrad(W, m.out_proj.bias, g, sv.a)
     dy = zk.swoosh_backward(sv.y, zk.lt_matmul(1, g, W), False)
     if fw:
         dy = _whiten_bwd(m.whiten, sv.y, dy, sv.st)

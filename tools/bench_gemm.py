@@ -43,9 +43,13 @@ def swd(x, kind):
 
 def main():
     torch.manual_seed(0)
-    shapes = [(31680, 192, 384), (31680, 192, 576), (31680, 384, 192), (31680, 192, 272), (15872, 256, 768),
-              (15872, 768, 256), (15872, 256, 960), (7936, 256, 768), (3968, 256, 768), (3968, 768, 256),
-              (31680, 2432 // 4 * 0 + 192, 512), (12672, 500, 256), (1001, 132, 68)]
+    # (rows, K, N) of the C3 layer projections: stack 0 (D=192), stacks 1/5 (D=256), stack 3
+    shapes = [(31680, 192, 384), (31680, 192, 512), (31680, 192, 640), (31680, 512, 192),
+              (31680, 192, 272), (31680, 192, 432), (31680, 144, 192), (31680, 192, 48),
+              (31680, 48, 192), (15872, 256, 576), (15872, 256, 768), (15872, 256, 960),
+              (15872, 768, 256), (15872, 960, 256), (15872, 256, 512), (15872, 256, 272),
+              (7936, 256, 768), (7936, 768, 256), (3968, 256, 768), (3968, 768, 256),
+              (12672, 500, 256), (1001, 132, 68)]
     print(f"{'M':>6} {'K':>5} {'N':>5} | {'NT us':>8} {'torch':>8} {'TF/s':>6} | {'NN us':>8} {'torch':>8} | {'TN us':>8} {'torch':>8} {'TF/s':>6} | maxerr")
     for (M, K, Nn) in shapes:
         x = torch.randn(M, K, device=dev)

@@ -1,13 +1,29 @@
-import sys, os
+"""GPU: the TN (weight-gradient) mode of s2t_gemm_f32 on the C3 shapes; tile / slice count come
+from S2T_TN_TILE / S2T_TN_BLOCKS (read once per process), so sweep them from the shell."""
+import os
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
-from speech2text_amd import _native as N
-from tools.bench_gemm import gemm, timeit, dev
-for (M, K, Nn) in [(31680, 192, 384), (31680, 192, 576), (15872, 256, 768)]:
-    x = torch.randn(M, K, device=dev); g = torch.randn(M, Nn, device=dev)
-    dW = torch.zeros(Nn, K, device=dev); db = torch.zeros(Nn, device=dev)
-    t1 = timeit(lambda: gemm(2, g, x, dW, Nn, K, M, colsum=db))
-    t2 = timeit(lambda: gemm(2, g, x, dW, Nn, K, M))
-    dWt = torch.zeros(K, Nn, device=dev)
-    t3 = timeit(lambda: gemm(2, x, g, dWt, K, Nn, M))
-    print(M, K, Nn, f"with colsum {t1:.1f} us, without {t2:.1f}, transposed-out {t3:.1f}", flush=True)
+import torch  # noqa: E402
+
+from tools.bench_gemm import dev, gemm, timeit  # noqa: E402
+
+SHAPES = [(31680, 192, 384), (31680, 192, 640), (31680, 512, 192), (31680, 192, 272),
+          (31680, 192, 48), (15872, 256, 768), (15872, 960, 256), (15872, 256, 272),
+          (7936, 256, 768), (3968, 768, 256)]
+tag = f"tile={os.environ.get('S2T_TN_TILE', 'auto')} blocks={os.environ.get('S2T_TN_BLOCKS', '512')}"
+out = []
+tot = 0.0
+for (M, K, Nn) in SHAPES:
+    x = torch.randn(M, K, device=dev)
+    g = torch.randn(M, Nn, device=dev)
+    dW = torch.zeros(Nn, K, device=dev)
+    db = torch.zeros(Nn, device=dev)
+    gemm(2, g, x, dW, Nn, K, M, colsum=db)
+    ref = g.t() @ x
+    err = ((dW - ref).abs().max() / ref.abs().max()).item()
+    assert err < 1e-4, (M, K, Nn, err)
+    t = timeit(lambda: gemm(2, g, x, dW, Nn, K, M, colsum=db))
+    tot += t
+    out.append(f"{t:6.1f}({2.0 * M * K * Nn / t / 1e6:5.1f})")
+print(f"{tag:24s} " + " ".join(out) + f"  sum {tot:.0f} us", flush=True)
