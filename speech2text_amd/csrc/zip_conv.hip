@@ -13,6 +13,8 @@
 // taps, then back through the gate) and one weight kernel (per-thread tap partials, LDS
 // reduction over the 4 frame groups, one atomic per tap per block).
 #include "common.h"
+#include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -62,28 +64,46 @@ __device__ __forceinline__ void stage_weights(const ConvArgs& a, int c0, float* 
   }
 }
 
-// gated, masked input tile: rows r <-> frame t0 - halo + r
+// gated, masked input tile: rows r <-> frame t0 - halo + r.  Thread = (channel c, row group);
+// the loads of a batch of NB rows are issued back to back from clamped (always valid) addresses
+// -- padding mask byte, x and gate of every row in flight together -- and validity is applied
+// afterwards.  (Loads behind per-element `if (t in range && !mask[t])` branches serialise into
+// one global round trip per row, which is what bounded these kernels before.)
 template <int K>
 __device__ __forceinline__ void stage_xg(const ConvArgs& a, int b, int t0, int c0, float* s_x) {
   constexpr int halo = K / 2;
   constexpr int rows = TT + 2 * halo;
-  for (int i = threadIdx.x; i < rows * 64; i += 256) {
-    const int r = i >> 6, c = i & 63;
-    const int t = t0 - halo + r;
-    float v = 0.f;
-    if (t >= 0 && t < a.T && c0 + c < a.C && !(a.mask && a.mask[(long)b * a.T + t])) {
+  constexpr int NB = 8;
+  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const bool cok = c0 + c < a.C;
+  const int cc = cok ? c0 + c : 0;
+  const bool gated = a.gate_off >= 0;
+  for (int r0 = rg; r0 < rows; r0 += 4 * NB) {
+    float xv[NB], gv[NB];
+    unsigned char mk[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int t = min(max(t0 - halo + r0 + 4 * i, 0), a.T - 1);
       const float* row = a.u + ((long)t * a.B + b) * a.ld;
-      v = row[c0 + c];
-      if (a.gate_off >= 0) v *= sigmoidf_(row[a.gate_off + c0 + c]);
+      mk[i] = a.mask ? a.mask[(long)b * a.T + t] : (unsigned char)0;
+      xv[i] = row[cc];
+      gv[i] = gated ? row[a.gate_off + cc] : 0.f;
     }
-    s_x[i] = v;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int r = r0 + 4 * i, t = t0 - halo + r;
+      if (r < rows) {
+        const bool ok = cok && t >= 0 && t < a.T && !mk[i];
+        float v = xv[i];
+        if (gated) v *= sigmoidf_(gv[i]);
+        s_x[r * 64 + c] = ok ? v : 0.f;
+      }
+    }
   }
 }
 
-template <int K, int MODE, bool GEN>
-__global__ __launch_bounds__(256) void zipconv_fwd_kernel(ConvArgs a, float* __restrict__ y,
-                                                          const float* __restrict__ dy,
-                                                          float* __restrict__ dscale) {
+template <int K, bool GEN>
+__global__ __launch_bounds__(256) void zipconv_fwd_kernel(ConvArgs a, float* __restrict__ y) {
   constexpr int Kh = (K + 1) / 2, halo = K / 2, W = FPT + 2 * halo;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* s_x = reinterpret_cast<float*>(smem_raw);
@@ -91,14 +111,10 @@ __global__ __launch_bounds__(256) void zipconv_fwd_kernel(ConvArgs a, float* __r
   float* s_wk = s_wc + Kh * 64;
   float* s_le = s_wk + K * 64;
   float* s_re = s_le + K * 64;
-  const int t0 = blockIdx.x * TT, b = blockIdx.y, c0 = blockIdx.z * 64;
+  // channel tile fastest, then utterance, then frame tile: workgroups that are dispatched together
+  // read neighbouring pieces of the same (t, b) rows (rows of adjacent b are adjacent in memory)
+  const int c0 = blockIdx.x * 64, b = blockIdx.y, t0 = blockIdx.z * TT;
   const int c = threadIdx.x & 63, tg = threadIdx.x >> 6;
-  if (MODE == 1) {
-    // only tiles that contain a frame within K of a chunk edge contribute to d(edge scale)
-    const int p0 = t0 % a.chunk;
-    const bool has_edge = (p0 < K) || (p0 + TT - 1 >= a.chunk - K);
-    if (!has_edge) return;
-  }
   stage_weights<K>(a, c0, s_wc, s_wk, s_le, s_re);
   stage_xg<K>(a, b, t0, c0, s_x);
   __syncthreads();
@@ -116,7 +132,7 @@ __global__ __launch_bounds__(256) void zipconv_fwd_kernel(ConvArgs a, float* __r
     acck[i] = bk;
   }
   const int chunk = a.chunk;
-  if (a.wc && MODE == 0) {
+  if (a.wc) {
 #pragma unroll
     for (int j = 0; j < Kh; ++j) {
       const float w = s_wc[j * 64 + c];
@@ -150,18 +166,9 @@ __global__ __launch_bounds__(256) void zipconv_fwd_kernel(ConvArgs a, float* __r
   for (int i = 0; i < FPT; ++i) {
     const int t = tb + i;
     if (t < a.T) {
-      if (MODE == 0) {
-        float v = acck[i];
-        if (a.scale) v *= edge_scale(s_le, s_re, c, t % chunk, chunk, K);
-        y[((long)t * a.B + b) * a.C + c0 + c] = v + accc[i];
-      } else {
-        const int pos = t % chunk, idx = pos - chunk + K;
-        if (pos < K || (idx >= 0 && idx < K)) {
-          const float v = dy[((long)t * a.B + b) * a.C + c0 + c] * acck[i];
-          if (pos < K) atomicAdd(&dscale[(long)(c0 + c) * K + pos], v);
-          if (idx >= 0 && idx < K) atomicAdd(&dscale[((long)a.C + c0 + c) * K + idx], v);
-        }
-      }
+      float v = acck[i];
+      if (a.scale) v *= edge_scale(s_le, s_re, c, t % chunk, chunk, K);
+      y[((long)t * a.B + b) * a.C + c0 + c] = v + accc[i];
     }
   }
 }
@@ -179,22 +186,38 @@ __global__ __launch_bounds__(256) void zipconv_bwd_data_kernel(ConvArgs a,
   float* s_wk = s_wc + Kh * 64;
   float* s_le = s_wk + K * 64;
   float* s_re = s_le + K * 64;
-  const int t0 = blockIdx.x * TT, b = blockIdx.y, c0 = blockIdx.z * 64;
+  // channel tile fastest, then utterance, then frame tile: workgroups that are dispatched together
+  // read neighbouring pieces of the same (t, b) rows (rows of adjacent b are adjacent in memory)
+  const int c0 = blockIdx.x * 64, b = blockIdx.y, t0 = blockIdx.z * TT;
   const int c = threadIdx.x & 63, tg = threadIdx.x >> 6;
   stage_weights<K>(a, c0, s_wc, s_wk, s_le, s_re);
   __syncthreads();
   const int chunk = a.chunk;
-  // two tiles: raw dy (causal taps) and dy * edge_scale (chunkwise taps)
-  for (int i = threadIdx.x; i < (TT + 2 * halo) * 64; i += 256) {
-    const int r = i >> 6, cc = i & 63;
-    const int t = t0 - halo + r;
-    float v = 0.f, vs = 0.f;
-    if (t >= 0 && t < a.T && c0 + cc < a.C) {
-      v = dy[((long)t * a.B + b) * a.C + c0 + cc];
-      vs = a.scale ? v * edge_scale(s_le, s_re, cc, t % chunk, chunk, K) : v;
+  // two tiles: raw dy (causal taps) and dy * edge_scale (chunkwise taps); batched loads from
+  // clamped addresses as in stage_xg
+  {
+    constexpr int rows = TT + 2 * halo, NB = 8;
+    const bool cok = c0 + c < a.C;
+    const int cc = cok ? c0 + c : 0;
+    for (int r0 = tg; r0 < rows; r0 += 4 * NB) {
+      float gv[NB];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int t = min(max(t0 - halo + r0 + 4 * i, 0), a.T - 1);
+        gv[i] = dy[((long)t * a.B + b) * a.C + cc];
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int r = r0 + 4 * i, t = t0 - halo + r;
+        if (r < rows) {
+          const bool ok = cok && t >= 0 && t < a.T;
+          const float v = ok ? gv[i] : 0.f;
+          s_g[r * 64 + c] = v;
+          s_gs[r * 64 + c] =
+              (ok && a.scale) ? v * edge_scale(s_le, s_re, c, t % chunk, chunk, K) : v;
+        }
+      }
     }
-    s_g[i] = v;
-    s_gs[i] = vs;
   }
   __syncthreads();
   if (c0 + c >= a.C) return;
@@ -263,7 +286,8 @@ __global__ __launch_bounds__(256) void zipconv_bwd_data_kernel(ConvArgs a,
 template <int K, bool GEN>
 __global__ __launch_bounds__(256) void zipconv_bwd_w_kernel(ConvArgs a,
                                                             const float* __restrict__ dy, int BB,
-                                                            float* __restrict__ part) {
+                                                            float* __restrict__ part,
+                                                            float* __restrict__ dscale) {
   constexpr int Kh = (K + 1) / 2, halo = K / 2, W = FPT + 2 * halo, NV = Kh + K + 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* s_x = reinterpret_cast<float*>(smem_raw);
@@ -272,7 +296,7 @@ __global__ __launch_bounds__(256) void zipconv_bwd_w_kernel(ConvArgs a,
   float* s_le = s_wk + K * 64;
   float* s_re = s_le + K * 64;
   float* s_red = s_re + K * 64;  // [4][64] reduction scratch
-  const int t0 = blockIdx.x * TT, c0 = blockIdx.z * 64;
+  const int c0 = blockIdx.x * 64, t0 = blockIdx.z * TT;
   const int c = threadIdx.x & 63, tg = threadIdx.x >> 6;
   const int tb = t0 + tg * FPT;
   const int chunk = a.chunk;
@@ -297,6 +321,18 @@ __global__ __launch_bounds__(256) void zipconv_bwd_w_kernel(ConvArgs a,
     for (int i = 0; i < FPT; ++i)
       if (tb + i < a.T) sc[i] = edge_scale(s_le, s_re, c, tb + i - cs[i], chunk, K);
   }
+  // d(edge scale)[c, pos] = sum dy * (unscaled chunkwise conv output) over the frames within K of
+  // a chunk edge: only tiles that contain such a frame compute it (block-uniform), summed over
+  // this block's utterances in registers, one atomic per (frame, side) at the end
+  bool edge = false;
+  if (dscale != nullptr) {
+    const int p0 = t0 % chunk;
+    edge = (p0 < K) || (p0 + TT - 1 >= chunk - K) || (p0 + TT > chunk);
+  }
+  const float bkv = (a.bk && chan_ok) ? a.bk[c0 + c] : 0.f;
+  float ds[FPT];
+#pragma unroll
+  for (int i = 0; i < FPT; ++i) ds[i] = 0.f;
   const int b_end = min(a.B, (int)(blockIdx.y + 1) * BB);
   for (int b = blockIdx.y * BB; b < b_end; ++b) {
     __syncthreads();
@@ -306,6 +342,23 @@ __global__ __launch_bounds__(256) void zipconv_bwd_w_kernel(ConvArgs a,
     float win[W];
 #pragma unroll
     for (int w = 0; w < W; ++w) win[w] = s_x[(tg * FPT + w) * 64 + c];
+    if (edge) {
+      float ak[FPT];
+#pragma unroll
+      for (int i = 0; i < FPT; ++i) ak[i] = bkv;
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        const float w = s_wk[j * 64 + c];
+#pragma unroll
+        for (int i = 0; i < FPT; ++i) {
+          const int tt = tb + i - halo + j;
+          if (!GEN || (tt >= cs[i] && tt < cs[i] + chunk)) ak[i] = fmaf(w, win[i + j], ak[i]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < FPT; ++i)
+        if (tb + i < a.T) ds[i] = fmaf(dy[((long)(tb + i) * a.B + b) * a.C + c0 + c], ak[i], ds[i]);
+    }
 #pragma unroll
     for (int i = 0; i < FPT; ++i) {
       const int t = tb + i;
@@ -328,8 +381,18 @@ __global__ __launch_bounds__(256) void zipconv_bwd_w_kernel(ConvArgs a,
       }
     }
   }
+  if (edge && chan_ok) {
+#pragma unroll
+    for (int i = 0; i < FPT; ++i) {
+      const int t = tb + i;
+      if (t >= a.T) continue;
+      const int pos = t - cs[i], idx = pos - chunk + K;
+      if (pos < K) atomicAdd(&dscale[(long)(c0 + c) * K + pos], ds[i]);
+      if (idx >= 0 && idx < K) atomicAdd(&dscale[((long)a.C + c0 + c) * K + idx], ds[i]);
+    }
+  }
   // reduce the 4 frame groups of each channel through LDS, then one store per value
-  const long blk = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  const long blk = ((long)blockIdx.x * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z;
   float* dst = part + (blk * 64 + c) * NV;
   auto reduce_store = [&](float v, int slot) {
     __syncthreads();
@@ -404,16 +467,14 @@ extern "C" int s2t_zipconv_fwd(const float* u, long ld, int gate_off, const unsi
                                const float* scale, float* y, void* stream) {
   if (!conv_args_ok(T, B, C, K, chunk)) return -1;
   ConvArgs a{u, ld, gate_off, mask, T, B, C, chunk, wc, bc, wk, bk, scale};
-  dim3 grid((T + TT - 1) / TT, B, (C + 63) / 64);
+  dim3 grid((C + 63) / 64, B, (T + TT - 1) / TT);
   hipStream_t st = (hipStream_t)stream;
-  const float* nf = nullptr;
-  float* nfm = nullptr;
   if (chunk >= T) {
-    S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_fwd_kernel<KK, 0, false>), grid, dim3(256),
-                                            conv_smem<KK>(false), st, a, y, nf, nfm));
+    S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_fwd_kernel<KK, false>), grid, dim3(256),
+                                            conv_smem<KK>(false), st, a, y));
   } else {
-    S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_fwd_kernel<KK, 0, true>), grid, dim3(256),
-                                            conv_smem<KK>(false), st, a, y, nf, nfm));
+    S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_fwd_kernel<KK, true>), grid, dim3(256),
+                                            conv_smem<KK>(false), st, a, y));
   }
   S2T_CHECK_LAUNCH();
   return 0;
@@ -433,7 +494,7 @@ extern "C" int s2t_zipconv_bwd(const float* u, long ld, int gate_off, const unsi
   if (!conv_args_ok(T, B, C, K, chunk)) return -1;
   hipStream_t st = (hipStream_t)stream;
   ConvArgs a{u, ld, gate_off, mask, T, B, C, chunk, wc, nullptr, wk, bk, scale};
-  dim3 grid((T + TT - 1) / TT, B, (C + 63) / 64);
+  dim3 grid((C + 63) / 64, B, (T + TT - 1) / TT);
   const bool gen = chunk < T;
   if (!gen) {
     S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_data_kernel<KK, false>), grid, dim3(256),
@@ -445,33 +506,24 @@ extern "C" int s2t_zipconv_bwd(const float* u, long ld, int gate_off, const unsi
   S2T_CHECK_LAUNCH();
   // utterances per block: enough workgroups to hide the staging latency
   const long tiles = (long)grid.x * grid.z;
-  int BB = (int)((tiles * B) / 1536);
+  const char* env = getenv("S2T_CONV_BLOCKS");         // tuning / tests: workgroup-count target
+  int BB = (int)((tiles * B) / (env ? std::max(1, atoi(env)) : 1536));
   if (BB < 1) BB = 1;
   if (BB > 8) BB = 8;
-  dim3 gridw(grid.x, (B + BB - 1) / BB, grid.z);
+  dim3 gridw(grid.x, (B + BB - 1) / BB, grid.z);   // (c tiles, utterance groups, t tiles)
   if (!gen) {
     S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_w_kernel<KK, false>), gridw, dim3(256),
-                                            conv_smem<KK>(true), st, a, dy, BB, workspace));
+                                            conv_smem<KK>(true), st, a, dy, BB, workspace,
+                                            (scale && dscale) ? dscale : nullptr));
   } else {
     S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_w_kernel<KK, true>), gridw, dim3(256),
-                                            conv_smem<KK>(true), st, a, dy, BB, workspace));
+                                            conv_smem<KK>(true), st, a, dy, BB, workspace,
+                                            (scale && dscale) ? dscale : nullptr));
   }
   S2T_CHECK_LAUNCH();
   hipLaunchKernelGGL(zipconv_reduce_w_kernel, dim3(C), dim3(256), 0, st, workspace,
-                     (int)(gridw.x * gridw.y), C, (K + 1) / 2, K, wc ? dwc : nullptr,
+                     (int)(gridw.z * gridw.y), C, (K + 1) / 2, K, wc ? dwc : nullptr,
                      wc ? dbc : nullptr, dwk, dbk);
   S2T_CHECK_LAUNCH();
-  if (scale && dscale) {
-    ConvArgs af{u, ld, gate_off, mask, T, B, C, chunk, nullptr, nullptr, wk, bk, scale};
-    float* nfm = nullptr;
-    if (!gen) {
-      S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_fwd_kernel<KK, 1, false>), grid, dim3(256),
-                                              conv_smem<KK>(false), st, af, nfm, dy, dscale));
-    } else {
-      S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_fwd_kernel<KK, 1, true>), grid, dim3(256),
-                                              conv_smem<KK>(false), st, af, nfm, dy, dscale));
-    }
-    S2T_CHECK_LAUNCH();
-  }
   return 0;
 }

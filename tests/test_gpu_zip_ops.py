@@ -20,10 +20,13 @@ class _Conv(torch.nn.Module):
 
 @pytest.mark.parametrize("T,B,C,K,chunk", [(200, 3, 192, 31, -1), (130, 2, 96, 31, 32),
                                            (77, 4, 70, 15, 16), (50, 2, 64, 7, 8),
-                                           (20, 2, 33, 31, -1), (64, 1, 64, 15, 4)])
-def test_glu_chunk_causal_dwconv(dev, T, B, C, K, chunk):
+                                           (20, 2, 33, 31, -1), (64, 1, 64, 15, 4),
+                                           (150, 7, 96, 31, -1), (90, 6, 64, 15, 16)])
+def test_glu_chunk_causal_dwconv(dev, monkeypatch, T, B, C, K, chunk):
     from speech2text_amd import zip_kernels as zk
     torch.manual_seed(0)
+    if B >= 6:
+        monkeypatch.setenv("S2T_CONV_BLOCKS", "4")     # several utterances per workgroup
     conv = _Conv(C, K)
     u = torch.randn(T, B, 2 * C)
     lens = torch.randint(T // 2, T + 1, (B,)); lens[0] = T
