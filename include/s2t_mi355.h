@@ -230,6 +230,24 @@ int s2t_gemm_f32(int mode, const float* A, long lda, const float* B, long ldb, f
                  const float* act_src, long lds, int act_kind, int pro_a, int pro_b, float* colsum,
                  int accumulate, void* stream);
 
+/* The weight-gradient GEMMs of one layer in ONE launch (mode TN of s2t_gemm_f32, 64x64 tiles):
+ * for each problem  C[M,N] += A[K,M]^T . B[K,N]  and  colsum[m] += sum_k A[k][m]  (colsum may be
+ * NULL).  A = the gradient of a Linear's output (rows x out_features), B = its input
+ * (rows x in_features), C / colsum = the weight / bias gradient views of the flat gradient buffer
+ * (what loss.backward() leaves in .grad for every nn.Linear of
+ * model/encoder/zipformer.py:1095-1221).  `probs` is a HOST array of n entries. */
+typedef struct S2tTnProblem {
+  const float* A;
+  long lda;
+  const float* B;
+  long ldb;
+  float* C;
+  long ldc;
+  int M, N, K;
+  float* colsum;
+} S2tTnProblem;
+int s2t_gemm_tn_grouped(int n, const S2tTnProblem* probs, void* stream);
+
 /* ---- BEST-RQ SSL heads: fused log-softmax + smoothed-target loss (model/loss/kl_divergence.py:
  * 36-76, model/loss/cross_entropy.py:38-69; call site task_factory/ssl_task.py:140-158).
  * logits [rows][K]; labels [rows]; target t_c = t_other (c != label) / t_label; row_loss[r] =

@@ -17,6 +17,8 @@
 // TN splits the (long) contraction dimension over gridDim.z and accumulates with fp32 atomics
 // straight into the caller's gradient buffer: no partial-sum pass, no separate "+=" kernel.
 #include "common.h"
+#include "../../include/s2t_mi355.h"
+#include <algorithm>
 #include <cstdint>
 #include <cstdlib>
 
@@ -129,7 +131,7 @@ constexpr int bk_of(int tm, int tn, int mode) {
 }
 
 template <int TM, int TN, int MODE, int PRO>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& g, const unsigned bid) {
   constexpr bool A_KC = MODE != MODE_TN, B_KC = MODE == MODE_NT;
   constexpr int BM = 64 * TM, BN = 64 * TN;
   constexpr int BK = bk_of(TM, TN, MODE);
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float sA[TA::SIZE];
   __shared__ __attribute__((aligned(16))) float sB[TB::SIZE];
 
-  // XCD-aware tile order: blocks that land on one XCD (blockIdx % 8) walk a contiguous range of
+  // XCD-aware tile order: blocks that land on one XCD (block id % 8) walk a contiguous range of
   // tiles, n fastest, so the n-tiles of one m-panel share that XCD's L2 copy of the A panel
   const int total = g.tiles_m * g.tiles_n;
   const int per_xcd = (total + 7) / 8;
@@ -148,12 +150,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   // of one contraction slice run on ONE XCD and share its L2 copy of that slice's operand rows.
   int lin, zslice = 0;
   if (MODE == MODE_TN) {
-    const int q = (int)(blockIdx.x >> 3);
-    zslice = (int)(blockIdx.x & 7) + 8 * (q / total);
+    const int q = (int)(bid >> 3);
+    zslice = (int)(bid & 7) + 8 * (q / total);
     lin = q % total;
     if (zslice >= g.splits) return;
   } else {
-    lin = (int)((blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3));
+    lin = (int)((bid & 7) * per_xcd + (bid >> 3));
     if (lin >= total) return;
   }
   const int tm = lin / g.tiles_n, tn = lin % g.tiles_n;
@@ -242,6 +244,37 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         }
       }
     }
+}
+
+template <int TM, int TN, int MODE, int PRO>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  gemm_body<TM, TN, MODE, PRO>(g, blockIdx.x);
+}
+
+// ---- grouped TN: the weight-gradient GEMMs of one layer in ONE launch.  Each problem keeps its
+// own (tiles x slices) block range (a multiple of 8 blocks, so the slice -> XCD mapping of the
+// single-problem launch holds); a block finds its problem by a scan of the prefix table.
+constexpr int MAXG = 24;
+struct TnProb {
+  const float* A;
+  const float* B;
+  float* C;
+  float* colsum;
+  int lda, ldb, ldc, M, N, K, kper, tiles_m, tiles_n, splits;
+};
+struct TnGroup {
+  int n;
+  unsigned begin[MAXG + 1];
+  TnProb p[MAXG];
+};
+
+__global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(TnGroup grp) {
+  int i = 0;
+  while (i + 1 < grp.n && blockIdx.x >= grp.begin[i + 1]) ++i;
+  const TnProb& q = grp.p[i];
+  GemmArgs g{q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, nullptr, nullptr, 0, nullptr, 0,
+             0, 0, 0, q.colsum, 0, q.kper, q.tiles_m, q.tiles_n, q.splits, 0};
+  gemm_body<1, 1, MODE_TN, ACT_NONE>(g, blockIdx.x - grp.begin[i]);
 }
 
 template <int TM, int TN, int MODE, int PRO>
@@ -344,4 +377,39 @@ extern "C" int s2t_gemm_f32(int mode, const float* A, long lda, const float* B, 
   else if (mode == MODE_TN) rc = dispatch<MODE_TN>(g, st);
   else return -1;
   return rc;
+}
+
+extern "C" int s2t_gemm_tn_grouped(int n, const S2tTnProblem* probs, void* stream) {
+  if (n <= 0) return 0;
+  if (!probs) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  for (int base = 0; base < n; base += MAXG) {
+    TnGroup grp;
+    grp.n = std::min(MAXG, n - base);
+    unsigned blocks = 0;
+    for (int i = 0; i < grp.n; ++i) {
+      const S2tTnProblem& s = probs[base + i];
+      if (s.M < 4 || s.N < 4 || s.K < 4 || (s.M & 3) || (s.N & 3) || (s.lda & 3) || (s.ldb & 3) ||
+          (reinterpret_cast<uintptr_t>(s.A) & 15) || (reinterpret_cast<uintptr_t>(s.B) & 15) ||
+          s.lda > INT32_MAX || s.ldb > INT32_MAX || s.ldc > INT32_MAX)
+        return -2;
+      TnProb& q = grp.p[i];
+      q = TnProb{s.A, s.B, s.C, s.colsum, (int)s.lda, (int)s.ldb, (int)s.ldc, s.M, s.N, s.K,
+                 0, (s.M + 63) / 64, (s.N + 63) / 64, 0};
+      const long tiles = (long)q.tiles_m * q.tiles_n;
+      int splits = (int)((1536 + tiles - 1) / tiles);          // as the single-problem 64x64 rule
+      const int maxs = (s.K + 2 * KR - 1) / (2 * KR);
+      splits = std::max(1, std::min(splits, maxs));
+      int kper = (s.K + splits - 1) / splits;
+      kper = ((kper + KR - 1) / KR) * KR;
+      q.kper = kper;
+      q.splits = (s.K + kper - 1) / kper;
+      grp.begin[i] = blocks;
+      blocks += (unsigned)(8 * tiles * ((q.splits + 7) / 8));
+    }
+    grp.begin[grp.n] = blocks;
+    hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(blocks), dim3(256), 0, st, grp);
+    if (hipGetLastError() != hipSuccess) return -3;
+  }
+  return 0;
 }

@@ -888,6 +888,61 @@ def wgrad_into(wparam, bparam, g2, a2, pro=0, notify=False):
     return True
 
 
+class TnProblem(ctypes.Structure):
+    """Mirror of S2tTnProblem (include/s2t_mi355.h)."""
+    _fields_ = [("A", ctypes.c_void_p), ("lda", ctypes.c_long), ("B", ctypes.c_void_p),
+                ("ldb", ctypes.c_long), ("C", ctypes.c_void_p), ("ldc", ctypes.c_long),
+                ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int),
+                ("colsum", ctypes.c_void_p)]
+
+
+def wgrad_group(items):
+    """items: [(weight, bias | None, g2 (R,N), a2 (R,M))] -- the weight / bias gradients of a whole
+    layer, accumulated into the flat gradient views by ONE grouped TN launch on the side stream
+    (gemm.hip s2t_gemm_tn_grouped).  The caller is not an autograd node of these parameters (the
+    layer executor), so the gradient reducer is told here.  Operands that do not meet the
+    kernel's layout rules fall back to wgrad_into / a library GEMM one by one."""
+    ok = []
+    for it in items:
+        w, b, g2, a2 = it
+        wg = w.grad
+        if (_tn_ok(g2) and _tn_ok(a2) and flat.owned(w) and wg is not None and wg.is_contiguous()
+                and (b is None or (flat.owned(b) and b.grad is not None))):
+            ok.append(it)
+            continue
+        if not wgrad_into(w, b, g2, a2, 0, notify=True):
+            dw, db = linear_wgrad(g2, a2, b is not None)
+            w.grad.add_(dw.view(w.shape))
+            flat.grad_written(w)
+            if b is not None:
+                b.grad.add_(db)
+                flat.grad_written(b)
+    n = len(ok)
+    if n == 0:
+        return
+    arr = (TnProblem * n)()
+    nbytes = flops = 0.0
+    for q, (w, b, g2, a2) in zip(arr, ok):
+        R, Nf = g2.shape
+        Mf = a2.shape[1]
+        q.A, q.lda = g2.data_ptr(), g2.stride(0)
+        q.B, q.ldb = a2.data_ptr(), a2.stride(0)
+        q.C, q.ldc = w.grad.data_ptr(), Mf
+        q.M, q.N, q.K = Nf, Mf, R
+        q.colsum = None if b is None else b.grad.data_ptr()
+        nbytes += 4.0 * (g2.numel() + a2.numel() + Nf * Mf)
+        flops += 2.0 * R * Nf * Mf
+    N.profile_note("s2t_gemm_tn_grouped", nbytes, flops)
+    st = _side_launch_stream(ok)
+    N.check(N.lib().s2t_gemm_tn_grouped(n, ctypes.cast(arr, ctypes.c_void_p),
+                                        st if st is not None else N.stream()),
+            "s2t_gemm_tn_grouped")
+    for w, b, _, _ in ok:
+        flat.grad_written(w)
+        if b is not None:
+            flat.grad_written(b)
+
+
 _LT_WS = {}
 
 

@@ -152,18 +152,13 @@ def _e(rows, cols, dev):
     return torch.empty((rows, cols), dtype=_F32, device=dev)
 
 
-def _wgrad(w, b, g2, a2, pro=0):
-    """dW += g2^T act(a2), db += colsum(g2), into the flat gradient views (side stream)."""
-    if zk.wgrad_into(w, b, g2, a2, pro, notify=True):
-        return
-    if pro:
-        a2 = zk.swoosh_forward(a2, pro == 1)
-    dw, db = zk.linear_wgrad(g2, a2, b is not None)
-    w.grad.add_(dw.view(w.shape))
-    flat.grad_written(w)
-    if b is not None:
-        b.grad.add_(db)
-        flat.grad_written(b)
+_PEND = []
+
+
+def _wgrad(w, b, g2, a2):
+    """Queue dW += g2^T a2, db += colsum(g2): the layer's weight gradients go out as ONE grouped
+    launch at the end of its backward (zk.wgrad_group), on the side stream."""
+    _PEND.append((w, b, g2, a2))
 
 
 def _whiten_bwd(mod, x, g, stats):
@@ -411,6 +406,7 @@ class _LayerFn(torch.autograd.Function):
     def backward(ctx, g):
         s, layer = ctx.s, ctx.layer
         ctx.s = None
+        _PEND.clear()
         d = s.d
         T, B, D, H, qd, pd = s.dims
         R = T * B
@@ -494,4 +490,7 @@ class _LayerFn(torch.autograd.Function):
         _wgrad(sa.in_proj.weight, sa.in_proj.bias, dqkp, x0)
         gx = zk.lt_matmul(1, dqkp, sa.in_proj.weight, None, g0)
         gx.add_(d0m)
+        pend = list(_PEND)
+        _PEND.clear()
+        zk.wgrad_group(pend)
         return gx.view(T, B, D), None, None, None, None, None, None

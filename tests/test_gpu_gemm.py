@@ -131,3 +131,34 @@ def test_linear_with_residual_autograd(dev):
     _close(r.grad, rr.grad.double())
     _close(lin.weight.grad, ref.weight.grad.double(), tol=1e-4)
     _close(lin.bias.grad, ref.bias.grad.double(), tol=1e-4)
+
+
+def test_grouped_wgrad_launch(dev):
+    """s2t_gemm_tn_grouped: 27 problems of mixed shapes (two kernel launches: 24 + 3), with and
+    without bias, accumulated into the views of one FlatStore on top of what is already there."""
+    from speech2text_amd import flat
+    g = torch.Generator().manual_seed(4)
+    shapes = [(517, 64, 68), (1000, 192, 384), (130, 132, 500), (2051, 48, 192), (999, 256, 16)] * 5 + \
+             [(4099, 256, 192), (64, 8, 4)]
+    params, items, refs = [], [], []
+    for i, (R, K, Nn) in enumerate(shapes):
+        w = torch.nn.Parameter(torch.zeros(Nn, K, device=dev))
+        b = torch.nn.Parameter(torch.zeros(Nn, device=dev)) if i % 3 else None
+        params += [w] + ([b] if b is not None else [])
+        x = torch.randn(R, K, generator=g).to(dev)
+        gy = torch.randn(R, Nn, generator=g).to(dev)
+        items.append((w, b, gy, x))
+        refs.append((gy.double().t() @ x.double(), gy.double().sum(0)))
+    store = flat.FlatStore(params)
+    store.flat_g.fill_(0.5)
+    fired = []
+    store.on_grad = fired.append
+    zk.wgrad_group(items)
+    zk._side_join() if zk.side_stream_handle() is not None else None
+    torch.cuda.synchronize()
+    assert len(fired) == len(params)
+    for (w, b, _, _), (dw, db) in zip(items, refs):
+        err = (w.grad.double() - 0.5 - dw).abs().max() / dw.abs().max()
+        assert err < 2e-5, err
+        if b is not None:
+            assert ((b.grad.double() - 0.5 - db).abs().max() / db.abs().max()) < 2e-5
