@@ -97,6 +97,18 @@ int s2t_balancer_coef(const float* sum, const float* sumsq, float n, int C, floa
                       float* b, void* stream);
 int s2t_balancer_apply(const float* x, long ldx, const float* g, long ldg, const float* a,
                        const float* b, long rows, int C, float* out, long ldo, void* stream);
+/* The whole Balancer backward (model/layer/scaling.py:741-789) in two launches and no fills:
+ * out = g + |g| * (a'[c] + b'[c] x); the column statistics of x are accumulated by the first
+ * launch, every workgroup of the second derives the per-channel coefficients from them itself.
+ * x / g / out are row-strided (ldx / ldg / ldo floats; out == g allowed).  `workspace`:
+ * s2t_balancer_bwd_workspace_floats() floats holding two alternating accumulators, zeroed ONCE
+ * when allocated; the caller passes parity = 0, 1, 0, 1, ... on successive calls (each call
+ * clears the accumulator of the next) and keeps all calls on one stream.  C <= 1024. */
+long s2t_balancer_bwd_workspace_floats(void);
+int s2t_balancer_bwd(const float* x, long ldx, const float* g, long ldg, long rows, int C,
+                     float min_mean, float max_mean, float min_rms, float max_rms,
+                     float grad_scale, float* out, long ldo, float* workspace, int parity,
+                     void* stream);
 
 
 /* ---- zipformer convolution module core (model/encoder/zipformer.py:2672-2690 +
@@ -154,14 +166,17 @@ int s2t_linear_wgrad(const float* g, long ldg, const float* a, long lda, int R, 
                      float* dW, float* db, int accumulate, float* workspace, void* stream);
 
 /* ---- Whiten gradient shaping (model/layer/scaling.py:949-1095).  Forward, when the module
- * fires: xtx (C,C) = x^T x and colsum (C) (both from s2t_linear_wgrad(x, x)) -> per-group centred
- * covariance cov (G,cg,cg), mean (C), scal = [mean diag, sum cov^2 / C, denom, metric]; the
- * metric is also stored to host_metric (pinned host memory, may be NULL) so the host can read
- * it after an event without draining the stream.  Backward: dcov (C,C, block diagonal) =
+ * fires: xtx (C,C) = x^T x and colsum (C) (both accumulated by the TN mode of s2t_gemm_f32 over
+ * (x, x)) -> per-group centred covariance cov (G,cg,cg), mean (C), scal = [mean diag,
+ * sum cov^2 / C, denom, metric]; the metric is also stored to host_metric (pinned host memory,
+ * may be NULL) so the host can read it after an event without draining the stream.  xtx and
+ * colsum are CONSUMED: the kernel leaves them zeroed, ready for the next accumulating GEMM (no
+ * fill launch per call); `workspace` = 4 + 2*C floats, zeroed once when allocated (a
+ * self-resetting ticket + per-row partial sums).  Backward: dcov (C,C, block diagonal) =
  * d metric / d cov, bias (C) = -mean . dcov, sums[2] zeroed; the caller forms pg = x dcov + bias
  * with a plain GEMM; s2t_whiten_apply writes out = g + pg * grad_scale * |g| / (|pg| + 1e-20). */
-int s2t_whiten_metric(const float* xtx, const float* colsum, long n, int G, int cg, float* cov,
-                      float* mean, float* scal, float* host_metric, void* stream);
+int s2t_whiten_metric(float* xtx, float* colsum, long n, int G, int cg, float* cov, float* mean,
+                      float* scal, float* host_metric, float* workspace, void* stream);
 int s2t_whiten_dcov(const float* cov, const float* mean, const float* scal, int G, int cg,
                     float* dcov, float* bias, float* sums, void* stream);
 int s2t_whiten_apply(const float* g, const float* pg, long numel, float grad_scale, float* sums,

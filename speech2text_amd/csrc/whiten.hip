@@ -29,33 +29,73 @@ __device__ __forceinline__ float block_sum(float v, float* s_tmp) {
 }
 
 // xtx: (C,C) = x^T x over all groups' channels; cov: (G,cg,cg) per-group centred covariance
-// scal: [md, covsq, denom, metric]
-__global__ __launch_bounds__(NT) void whiten_metric_kernel(const float* __restrict__ xtx,
-                                                           const float* __restrict__ colsum,
-                                                           float n, int G, int cg,
-                                                           float* __restrict__ cov,
-                                                           float* __restrict__ mean,
-                                                           float* __restrict__ scal,
-                                                           float* host_metric) {
-  __shared__ float s_tmp[NT >> 6];
+// scal: [md, covsq, denom, metric].  One workgroup per row ci: its group's block of the centred
+// covariance, the row's partial sums, then the row of xtx is ZEROED (the accumulating TN GEMM that
+// fills it finds it clean next time -- no fill launch per call).  The last workgroup (ticket) adds
+// the partials up, writes scal / mean / the host-visible metric, zeroes colsum and the ticket.
+// ws: [ticket (unsigned)][pad to 4][2 floats per row]
+__global__ __launch_bounds__(256) void whiten_metric_kernel(float* __restrict__ xtx,
+                                                            float* __restrict__ colsum, float n,
+                                                            int G, int cg, float* __restrict__ cov,
+                                                            float* __restrict__ mean,
+                                                            float* __restrict__ scal,
+                                                            float* host_metric,
+                                                            float* __restrict__ ws) {
+  __shared__ float s_red[2][4];
+  __shared__ unsigned s_old;
   const int C = G * cg;
+  const int ci = blockIdx.x;
+  const int g = ci / cg, i = ci - g * cg;
   const float inv_n = 1.f / n;
+  const float mi = colsum[ci] * inv_n;
   float dsum = 0.f, sq = 0.f;
-  const long total = (long)G * cg * cg;
-  for (long e = threadIdx.x; e < total; e += NT) {
-    const int g = (int)(e / ((long)cg * cg));
-    const int r = (int)(e % ((long)cg * cg));
-    const int i = r / cg, j = r % cg;
-    const int ci = g * cg + i, cj = g * cg + j;
-    const float v = xtx[(long)ci * C + cj] - colsum[ci] * colsum[cj] * inv_n;
-    cov[e] = v;
+  float* xrow = xtx + (long)ci * C;
+  for (int j = threadIdx.x; j < cg; j += 256) {
+    const int cj = g * cg + j;
+    const float v = xrow[cj] - mi * colsum[cj];
+    cov[((long)g * cg + i) * cg + j] = v;
     sq = fmaf(v, v, sq);
-    if (i == j) dsum += v;
+    if (i == j) dsum = v;
   }
-  for (int c = threadIdx.x; c < C; c += NT) mean[c] = colsum[c] * inv_n;
-  const float dtot = block_sum(dsum, s_tmp);
-  const float sqtot = block_sum(sq, s_tmp);
+  __syncthreads();                                   // row fully read before it is cleared
+  for (int j = threadIdx.x; j < C; j += 256) xrow[j] = 0.f;
+  dsum = wave_sum(dsum);
+  sq = wave_sum(sq);
+  if ((threadIdx.x & 63) == 0) {
+    s_red[0][threadIdx.x >> 6] = dsum;
+    s_red[1][threadIdx.x >> 6] = sq;
+  }
+  __syncthreads();
+  unsigned* ticket = reinterpret_cast<unsigned*>(ws);
+  float* part = ws + 4;
   if (threadIdx.x == 0) {
+    part[2 * ci] = (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
+    part[2 * ci + 1] = (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
+    __threadfence();
+    s_old = atomicAdd(ticket, 1u);
+  }
+  __syncthreads();
+  if (s_old != gridDim.x - 1) return;
+  __threadfence();
+  dsum = 0.f;
+  sq = 0.f;
+  for (int r = threadIdx.x; r < C; r += 256) {
+    dsum += __builtin_nontemporal_load(part + 2 * r);
+    sq += __builtin_nontemporal_load(part + 2 * r + 1);
+    mean[r] = colsum[r] * inv_n;
+  }
+  dsum = wave_sum(dsum);
+  sq = wave_sum(sq);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+    s_red[0][threadIdx.x >> 6] = dsum;
+    s_red[1][threadIdx.x >> 6] = sq;
+  }
+  __syncthreads();
+  for (int r = threadIdx.x; r < C; r += 256) colsum[r] = 0.f;
+  if (threadIdx.x == 0) {
+    const float dtot = (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
+    const float sqtot = (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
     const float md = dtot / (float)C;
     const float covsq = sqtot / (float)C;
     const float denom = md * md + 1.0e-20f;
@@ -64,6 +104,7 @@ __global__ __launch_bounds__(NT) void whiten_metric_kernel(const float* __restri
     scal[1] = covsq;
     scal[2] = denom;
     scal[3] = metric;
+    *ticket = 0u;
     if (host_metric)
       __hip_atomic_store(host_metric, metric, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
@@ -174,12 +215,12 @@ __global__ __launch_bounds__(256) void limit_param_grad_kernel(const float* __re
 
 }  // namespace
 
-extern "C" int s2t_whiten_metric(const float* xtx, const float* colsum, long n, int G, int cg,
-                                 float* cov, float* mean, float* scal, float* host_metric,
+extern "C" int s2t_whiten_metric(float* xtx, float* colsum, long n, int G, int cg, float* cov,
+                                 float* mean, float* scal, float* host_metric, float* workspace,
                                  void* stream) {
-  if (G <= 0 || cg <= 0 || n <= 0) return -1;
-  hipLaunchKernelGGL(whiten_metric_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, xtx, colsum,
-                     (float)n, G, cg, cov, mean, scal, host_metric);
+  if (G <= 0 || cg <= 0 || n <= 0 || !workspace) return -1;
+  hipLaunchKernelGGL(whiten_metric_kernel, dim3(G * cg), dim3(256), 0, (hipStream_t)stream, xtx,
+                     colsum, (float)n, G, cg, cov, mean, scal, host_metric, workspace);
   S2T_CHECK_LAUNCH();
   return 0;
 }

@@ -170,6 +170,53 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict_
   }
 }
 
+// Balancer backward, second pass: out = g + |g| * (a'[c] + b'[c] x).  Every workgroup first turns
+// the column statistics (sum, sumsq over n rows, from col_stats_kernel) into the coefficients of
+// its own copy in LDS (balancer_coef's formulas; C <= 1024), so no coefficient kernel runs; block 0
+// also clears `stats_next`, the accumulator the NEXT call's statistics pass will add into (the two
+// accumulators alternate, so no fill launch is needed either).
+__global__ __launch_bounds__(256) void balancer_apply_fused_kernel(
+    const float* __restrict__ x, long ldx, const float* __restrict__ g, long ldg,
+    const float* __restrict__ stats, float* __restrict__ stats_next, float n, float min_mean,
+    float max_mean, float min_rms, float max_rms, float grad_scale, long rows, int C,
+    float* __restrict__ out, long ldo) {
+  __shared__ float s_a[1024], s_b[1024];
+  const float inv_n = 1.f / n;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float mean = stats[c] * inv_n, uvar = stats[1024 + c] * inv_n;
+    const float raw_var = uvar - mean * mean;
+    const bool live_v = raw_var > 1.0e-20f, live_r = uvar > 1.0e-20f;
+    const float var = fmaxf(raw_var, 1.0e-20f);
+    const float sd = sqrtf(var);
+    const float rms = sqrtf(fmaxf(uvar, 1.0e-20f));
+    const float m = mean / sd;
+    const float mc = fminf(fmaxf(m, min_mean), max_mean);
+    const float s_m = (m > mc) ? 1.f : ((m < mc) ? -1.f : 0.f);
+    const float rc = fminf(fmaxf(rms, min_rms), max_rms);
+    const float lq = logf(rc / rms);
+    const float s_r = (lq > 0.f) ? -1.f : ((lq < 0.f) ? 1.f : 0.f);
+    const float a = s_m * inv_n * (live_v ? (1.f / sd + mean * mean / (sd * var)) : 1.f / sd);
+    const float b = (live_v ? -s_m * inv_n * mean / (sd * var) : 0.f) +
+                    (live_r ? s_r * inv_n / (rms * rms) : 0.f);
+    const float lg_rms =
+        fmaxf(sqrtf(fmaxf(a * a + 2.f * a * b * mean + b * b * uvar, 0.f)), 1.0e-20f);
+    const float coef = grad_scale / lg_rms;
+    s_a[c] = a * coef;
+    s_b[c] = b * coef;
+  }
+  if (blockIdx.x == 0)          // the whole accumulator: the previous user may have had more channels
+    for (int c = threadIdx.x; c < 2 * 1024; c += 256) stats_next[c] = 0.f;
+  __syncthreads();
+  const long total = rows * C;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long r = i / C;
+    const int c = (int)(i - r * C);
+    const float gv = g[r * ldg + c];
+    out[r * ldo + c] = gv + fabsf(gv) * fmaf(s_b[c], x[r * ldx + c], s_a[c]);
+  }
+}
+
 // g_out[r][c] = g + |g| * (a[c] + b[c]*x)   (in-place allowed: g_out == g)
 __global__ __launch_bounds__(256) void balancer_apply_kernel(
     const float* __restrict__ x, long ldx, const float* __restrict__ g, long ldg,
@@ -299,6 +346,33 @@ extern "C" int s2t_balancer_apply(const float* x, long ldx, const float* g, long
   if (rows <= 0 || C <= 0) return 0;
   hipLaunchKernelGGL(balancer_apply_kernel, dim3(grid_for(rows * C, 1024)), dim3(256), 0,
                      (hipStream_t)stream, x, ldx, g, ldg, a, b, rows, C, out, ldo);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+// workspace: two alternating (sum[C], sumsq[C]) accumulators of 2 * BAL_MAXC floats each
+constexpr int BAL_MAXC = 1024;
+extern "C" long s2t_balancer_bwd_workspace_floats(void) { return 4L * BAL_MAXC; }
+
+extern "C" int s2t_balancer_bwd(const float* x, long ldx, const float* g, long ldg, long rows,
+                                int C, float min_mean, float max_mean, float min_rms,
+                                float max_rms, float grad_scale, float* out, long ldo,
+                                float* workspace, int parity, void* stream) {
+  if (rows <= 0 || C <= 0) return 0;
+  if (C > BAL_MAXC || !workspace) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  float* cur = workspace + (parity & 1) * 2 * BAL_MAXC;
+  float* nxt = workspace + ((parity + 1) & 1) * 2 * BAL_MAXC;
+  int gy = (C + 63) / 64;
+  if (gy > 16) gy = 16;
+  long gx = (rows + 4 * 16 - 1) / (4 * 16);
+  gx = gx > 1024 ? 1024 : (gx < 1 ? 1 : gx);
+  hipLaunchKernelGGL(col_stats_kernel, dim3((unsigned)gx, gy), dim3(64, 4), 0, st, x, rows, C, ldx,
+                     cur, cur + BAL_MAXC);
+  S2T_CHECK_LAUNCH();
+  hipLaunchKernelGGL(balancer_apply_fused_kernel, dim3(grid_for(rows * C, 1024)), dim3(256), 0, st,
+                     x, ldx, g, ldg, cur, nxt, (float)rows, min_mean, max_mean, min_rms, max_rms,
+                     grad_scale, rows, C, out, ldo);
   S2T_CHECK_LAUNCH();
   return 0;
 }

@@ -153,17 +153,33 @@ def bias_norm(x, bias, log_scale):
 
 
 # ------------------------------------------------------------------ Balancer / Whiten backward
-def balancer_backward(x, g, min_mean, max_mean, min_rms, max_rms, grad_scale, channel_dim):
+_BAL_WS = {}
+
+
+def _balancer_workspace(dev):
+    """[workspace, call parity]: two alternating statistics accumulators, zeroed once (each call
+    clears the one the next call adds into -- zip_elem.hip balancer_apply_fused_kernel)."""
+    ws = _BAL_WS.get(dev)
+    if ws is None:
+        ws = [torch.zeros(N.lib().s2t_balancer_bwd_workspace_floats(), dtype=torch.float32,
+                          device=dev), 0]
+        _BAL_WS[dev] = ws
+    return ws
+
+
+def balancer_backward(x, g, min_mean, max_mean, min_rms, max_rms, grad_scale, channel_dim,
+                      inplace=False):
     """Closed form of reference scaling.py:741-789: the autograd-inside-backward there reduces
     to per-channel statistics (mean, E[x^2]) and a per-element affine term
         g' = g + |g| * grad_scale * (a_c + b_c x) / rms_c(a + b x).
-    Channel-last tensors (the zipformer layers) run three HIP kernels: column statistics,
-    coefficient kernel, fused update.  Other layouts (NCHW frontend) use the same formulas as
-    torch reductions."""
+    Channel-last tensors (the zipformer layers) run two HIP launches (s2t_balancer_bwd): column
+    statistics + coefficients, fused update.  x and g may be row-strided slices of wider tensors;
+    inplace=True writes the result over g (a slice of a gradient being assembled).  Other layouts
+    (NCHW frontend) use the same formulas as torch reductions."""
     _dev(x, g)
     nd = x.ndim
     if channel_dim == nd - 1 and x.dim() >= 2 and x.stride(-1) == 1 and g.dtype == torch.float32 \
-            and x.dtype == torch.float32:
+            and x.dtype == torch.float32 and x.shape[-1] <= 1024:
         C = x.shape[-1]
         x2 = x.reshape(-1, C) if x.is_contiguous() else None
         if x2 is None:
@@ -172,22 +188,21 @@ def balancer_backward(x, g, min_mean, max_mean, min_rms, max_rms, grad_scale, ch
             if xs.stride(-1) != 1:
                 xs = x.contiguous().reshape(-1, C)
             x2 = xs
-        g2 = g.contiguous().reshape(-1, C)
         rows = x2.shape[0]
-        L = N.lib()
-        st = N.stream()
-        stats = torch.zeros(2, C, dtype=torch.float32, device=x.device)
-        coef = torch.empty(2, C, dtype=torch.float32, device=x.device)
-        out = torch.empty_like(g2)
-        N.check(L.s2t_col_stats(N.raw(x2, torch.float32), rows, C, x2.stride(0),
-                                N.fp(stats), ctypes_off(stats, C), st), "col_stats")
-        N.check(L.s2t_balancer_coef(N.fp(stats), ctypes_off(stats, C), float(rows), C, min_mean,
-                                    max_mean, min_rms, max_rms, grad_scale, N.fp(coef),
-                                    ctypes_off(coef, C), st), "balancer_coef")
-        N.check(L.s2t_balancer_apply(N.raw(x2, torch.float32), x2.stride(0), N.fp(g2), C,
-                                     N.fp(coef), ctypes_off(coef, C), rows, C, N.fp(out), C, st),
-                "balancer_apply")
-        return out.reshape(g.shape)
+        if inplace and g.dim() == 2 and g.stride(1) == 1:
+            g2 = out = g
+        else:
+            g2 = g.contiguous().reshape(-1, C)
+            out = torch.empty_like(g2)
+        ws = _balancer_workspace(x.device)
+        ws[1] ^= 1
+        N.check(N.lib().s2t_balancer_bwd(N.raw(x2, torch.float32), x2.stride(0),
+                                         N.raw(g2, torch.float32), g2.stride(0), rows, C, min_mean,
+                                         max_mean, min_rms, max_rms, grad_scale,
+                                         N.raw(out, torch.float32), out.stride(0), N.fp(ws[0]),
+                                         ws[1], N.stream()),
+                "s2t_balancer_bwd")
+        return out if out is g else out.reshape(g.shape)
     dims = [i for i in range(nd) if i != channel_dim]
     xf = x.float()
     n = xf.numel() // xf.shape[channel_dim]
@@ -226,6 +241,20 @@ def _pinned_slot():
     return _PINNED[0][i:i + 1]
 
 
+_WH_SCRATCH = {}
+
+
+def _whiten_scratch(dev, C):
+    """(accumulator (C+1, C), metric-kernel workspace) of the whitening statistics, per channel
+    count; both zeroed once -- the metric kernel leaves them clean (whiten.hip)."""
+    ent = _WH_SCRATCH.get((dev, C))
+    if ent is None:
+        ent = (torch.zeros((C + 1, C), dtype=torch.float32, device=dev),
+               torch.zeros(4 + 2 * C, dtype=torch.float32, device=dev))
+        _WH_SCRATCH[(dev, C)] = ent
+    return ent
+
+
 class WhitenStats:
     """Whitening statistics of x, computed when the module fires in FORWARD (they depend on x
     only) so that the scalar `metric` reaches the host through pinned memory long before the
@@ -243,21 +272,24 @@ class WhitenStats:
         n = xf.shape[0]
         G, cg = num_groups, C // num_groups
         dev = x.device
+        # x^T x and the column sums in one pass of the TN MFMA GEMM, accumulated into a
+        # persistent (C+1, C) buffer that the metric kernel hands back zeroed
+        acc, ws = _whiten_scratch(dev, C)
+        xtx, colsum = acc[:C], acc[C]
         if _tn_ok(xf):
-            # x^T x and the column sums in one pass of the TN MFMA GEMM (accumulating kernel:
-            # one zeroed (C+1, C) buffer holds both)
-            acc = torch.zeros((C + 1, C), dtype=torch.float32, device=dev)
-            xtx, colsum = acc[:C], acc[C]
             gemm_tn(xf, xf, xtx, colsum)
         else:
-            xtx, colsum = linear_wgrad(xf, xf, True)
+            a, b = linear_wgrad(xf, xf, True)
+            xtx.copy_(a)
+            colsum.copy_(b)
         self.cov = torch.empty((G, cg, cg), dtype=torch.float32, device=dev)
         self.mean = torch.empty((C,), dtype=torch.float32, device=dev)
         self.scal = torch.empty((4,), dtype=torch.float32, device=dev)
         self.host = _pinned_slot()
         N.check(N.lib().s2t_whiten_metric(N.fp(xtx), N.fp(colsum), n, G, cg, N.fp(self.cov),
                                           N.fp(self.mean), N.fp(self.scal),
-                                          ctypes.c_void_p(self.host.data_ptr()), N.stream()),
+                                          ctypes.c_void_p(self.host.data_ptr()), N.fp(ws),
+                                          N.stream()),
                 "s2t_whiten_metric")
         self.event = torch.cuda.Event()
         self.event.record()

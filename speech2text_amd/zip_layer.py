@@ -168,8 +168,8 @@ def _whiten_bwd(mod, x, g, stats):
     return out
 
 
-def _balancer_bwd(mod, x, g):
-    return zk.balancer_backward(x, g, *mod.cfg(2))
+def _balancer_bwd(mod, x, g, inplace=False):
+    return zk.balancer_backward(x, g, *mod.cfg(2), inplace=inplace)
 
 
 def _commit(p, d, lo, hi, limit):
@@ -287,7 +287,7 @@ def _conv_bwd(m, dec, sv, x_in, g, T, B, k8):
         if p is not None:
             flat.grad_written(p)
     if fb1:
-        du[:, D:] = _balancer_bwd(m.balancer1, sv.u[:, D:], du[:, D:].contiguous())
+        _balancer_bwd(m.balancer1, sv.u[:, D:], du[:, D:], inplace=True)
     _wgrad(m.in_proj.weight, m.in_proj.bias, du, x_in)
     return zk.lt_matmul(1, du, m.in_proj.weight, None, g)
 
@@ -338,7 +338,7 @@ def _na_bwd(m, post, dec, sv, x_in, g, T, B):
     dW0 = torch.bmm(dz, sv.xs.transpose(1, 2))
     N.check(L.s2t_nonlin_gate_bwd(N.fp(dxs), N.fp(sv.u), T, B, C, N.fp(du), st), "nonlin_gate_bwd")
     if fb:
-        du[:, :C] = _balancer_bwd(m.balancer, sv.u[:, :C], du[:, :C].contiguous())
+        _balancer_bwd(m.balancer, sv.u[:, :C], du[:, :C], inplace=True)
     if fw1:
         du[:, C:2 * C] = _whiten_bwd(m.whiten1, sv.u[:, C:2 * C], du[:, C:2 * C].contiguous(),
                                      sv.st1)

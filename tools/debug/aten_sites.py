@@ -1,0 +1,52 @@
+"""Which source lines of speech2text_amd issue the remaining ATen kernels of a C3 step."""
+import collections
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import bench  # noqa: E402
+from speech2text_amd.build_task import TaskFactory  # noqa: E402
+from speech2text_amd.trainer import Trainer  # noqa: E402
+
+dev = torch.device("cuda:0")
+cfg = bench.c3_config(500)
+random.seed(1234); np.random.seed(1234); torch.manual_seed(1234)
+task = TaskFactory.get("Pruned_Rnnt")(cfg)
+tr = Trainer(**cfg["trainer"]).setup(task, dev); task.train()
+batch = bench.make_batch(0, 64, 10.0, 50, 500, dev)
+for i in range(4):
+    tr.training_step(batch, i)
+torch.cuda.synchronize()
+import traceback  # noqa: E402
+from torch.utils._python_dispatch import TorchDispatchMode  # noqa: E402
+
+SKIP = {"empty", "empty_like", "empty_strided", "view", "as_strided", "reshape", "permute",
+        "transpose", "slice", "select", "unsqueeze", "squeeze", "expand", "detach", "alias", "t",
+        "_unsafe_view", "resize_", "item", "_local_scalar_dense", "narrow", "unbind", "lift_fresh",
+        "new_empty", "new_empty_strided", "record_stream", "is_pinned", "unsafe_chunk", "split",
+        "chunk", "unflatten", "flatten", "squeeze_", "unsqueeze_", "view_as", "expand_as", "stride",
+        "size", "sym_size", "sym_stride", "sym_numel", "is_contiguous", "dim"}
+sites = collections.Counter()
+
+
+class Rec(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = func.__name__.split(".")[0]
+        if name not in SKIP:
+            fr = [f for f in traceback.extract_stack()[:-1] if "speech2text_amd" in f.filename
+                  or f.filename.endswith("bench.py")]
+            where = "<autograd engine>" if not fr else \
+                f"{fr[-1].filename.split('speech2text_amd/')[-1]}:{fr[-1].lineno} {fr[-1].name}"
+            sites[(name, where)] += 1
+        return func(*args, **(kwargs or {}))
+
+
+with Rec():
+    tr.training_step(batch, 5)
+torch.cuda.synchronize()
+for (name, where), n in sites.most_common(90):
+    print(f"{n:5d}  {name:24s} {where}")
