@@ -193,6 +193,12 @@ int s2t_bestrq_labels(const float* feats, int B, int T, int F, const float* proj
                       const float* codebooks, int ncb, int K, int T2, long* labels, void* stream);
 
 
+/* col2im of the 3x3 convolutions of Conv2dSubsampling (model/layer/subsampling.py:184-229, the
+ * data gradient of nn.Conv2d under loss.backward()) on channel-last data, as one gather pass:
+ * dc (B,Ho,Wo,3,3,C) = dy . W^T per patch -> dx (B,H,W,C), Ho = (H-3)/sh+1, Wo = (W-3)/sw+1. */
+int s2t_col2im3x3_nhwc(const float* dc, int B, int H, int W, int C, int Ho, int Wo, int sh, int sw,
+                       float* dx, void* stream);
+
 /* ---- channel-last depthwise conv2d of the zipformer frontend (ConvNeXt 7x7,
  * model/layer/subsampling.py:47-53,121).  x,y (N,H,W,C); wgt (C,KH,KW); "same" zero padding.
  * flip=1 applies the flipped taps (= backward data).  wgrad writes dw (C,KH,KW) and db (C). */
@@ -344,6 +350,26 @@ int s2t_param_grad_commit(const float* x, const float* d, float lo, float hi, in
 int s2t_attn_delta_pairs(const float* W, const float* dW0, const float* dO1, const float* O1,
                          int dv1, const float* dO2, const float* O2, int dv2, int T, int B, int H,
                          float* delta, void* stream);
+/* bypass with the stack's per-utterance feature mask (zipformer.py:1095-1113, `output * feature_mask`
+ * after every layer) folded in: out = (orig + (src - orig) * scale[c]) * fm[b, c], rows ordered
+ * (t, b); the backward multiplies the incoming gradient by fm on the fly. */
+int s2t_bypass_fwd_mask(const float* orig, const float* src, const float* scale, const float* fm,
+                        int B, long rows, int C, float* out, void* stream);
+int s2t_bypass_bwd_mask(const float* orig, const float* src, const float* scale, const float* g,
+                        const float* fm, int B, long rows, int C, float* d_orig, float* d_src,
+                        float* d_scale, void* stream);
+/* Up to 8 small parameters in one launch: grad[e] += d[e] (limit_param_value's sign flip,
+ * scaling.py:1153-1190, applied to d first where `limit`), then d[e] = 0 -- the accumulators the
+ * layer's backward kernels add into are handed back clean.  `items` is a HOST array. */
+typedef struct S2tCommit {
+  const float* x;
+  float* d;
+  float* grad;
+  float lo, hi;
+  int limit;
+  long n;
+} S2tCommit;
+int s2t_param_grad_commit_n(int n, const S2tCommit* items, void* stream);
 int s2t_nonlin_gate_fwd(const float* u, int T, int B, int C, float* xs, void* stream);
 int s2t_nonlin_out_fwd(const float* z, const float* u, int T, int B, int C, float* o, void* stream);
 int s2t_nonlin_out_bwd(const float* g, const float* z, const float* u, int T, int B, int C, float* dz,

@@ -182,3 +182,54 @@ extern "C" int s2t_dwconv2d_nhwc_wgrad(const float* x, const float* dy, int N, i
   S2T_CHECK_LAUNCH();
   return 0;
 }
+
+namespace {
+
+// col2im of a 3x3 convolution on channel-last data, as a GATHER: every input position adds up the
+// (at most 9) patch entries that cover it -- no zero fill, no strided slice-add passes.
+// dc (B,Ho,Wo,3,3,C) -> dx (B,H,W,C)
+__global__ __launch_bounds__(256) void col2im3x3_kernel(const float* __restrict__ dc, int B, int H,
+                                                        int W, int C, int Ho, int Wo, int sh,
+                                                        int sw, float* __restrict__ dx) {
+  const long total = (long)B * H * W * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    long r = i / C;
+    const int w = (int)(r % W);
+    r /= W;
+    const int h = (int)(r % H);
+    const int b = (int)(r / H);
+    float acc = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int hh = h - kh;
+      if (hh < 0 || hh % sh) continue;
+      const int ho = hh / sh;
+      if (ho >= Ho) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ww = w - kw;
+        if (ww < 0 || ww % sw) continue;
+        const int wo = ww / sw;
+        if (wo >= Wo) continue;
+        acc += dc[((((long)b * Ho + ho) * Wo + wo) * 9 + kh * 3 + kw) * C + c];
+      }
+    }
+    dx[i] = acc;
+  }
+}
+
+}  // namespace
+
+extern "C" int s2t_col2im3x3_nhwc(const float* dc, int B, int H, int W, int C, int Ho, int Wo,
+                                  int sh, int sw, float* dx, void* stream) {
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
+  if (sh <= 0 || sw <= 0 || Ho != (H - 3) / sh + 1 || Wo != (W - 3) / sw + 1) return -1;
+  const long total = (long)B * H * W * C;
+  long blocks = (total + 1023) / 1024;
+  blocks = blocks > 8192 ? 8192 : (blocks < 1 ? 1 : blocks);
+  hipLaunchKernelGGL(col2im3x3_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     dc, B, H, W, C, Ho, Wo, sh, sw, dx);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}

@@ -6,6 +6,7 @@
 // and their backward passes; per-channel parameter gradients are block partial sums + one
 // atomic per channel per workgroup.  All HBM-bound single passes.
 #include "common.h"
+#include "../../include/s2t_mi355.h"
 
 namespace {
 
@@ -118,6 +119,77 @@ __global__ __launch_bounds__(256) void attn_delta_pairs_kernel(
   }
   acc = wave_sum(acc);
   if (lane == 0) delta[row] = acc;
+}
+
+// bypass with the encoder stack's per-utterance feature mask folded in (zipformer.py:1095-1113:
+// `output = mod(output, ...); output = output * feature_mask`): out = (orig + (src - orig) * scale)
+// * fm[b, c], rows ordered (t, b).
+__global__ __launch_bounds__(256) void bypass_fwd_mask_kernel(const float* __restrict__ orig,
+                                                              const float* __restrict__ src,
+                                                              const float* __restrict__ scale,
+                                                              const float* __restrict__ fm, int B,
+                                                              long n4, int C4,
+                                                              float* __restrict__ out) {
+  const float4* o4 = reinterpret_cast<const float4*>(orig);
+  const float4* s4 = reinterpret_cast<const float4*>(src);
+  const float4* sc4 = reinterpret_cast<const float4*>(scale);
+  const float4* m4 = reinterpret_cast<const float4*>(fm);
+  float4* y4 = reinterpret_cast<float4*>(out);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C4);
+    const int b = (int)((i / C4) % B);
+    const float4 a = o4[i], v = s4[i], k = sc4[c], m = m4[(long)b * C4 + c];
+    y4[i] = make_float4(fmaf(v.x - a.x, k.x, a.x) * m.x, fmaf(v.y - a.y, k.y, a.y) * m.y,
+                        fmaf(v.z - a.z, k.z, a.z) * m.z, fmaf(v.w - a.w, k.w, a.w) * m.w);
+  }
+}
+
+// backward of the above: the incoming gradient is multiplied by fm[b, c] on the fly
+__global__ __launch_bounds__(256) void bypass_bwd_mask_kernel(const float* __restrict__ orig,
+                                                              const float* __restrict__ src,
+                                                              const float* __restrict__ scale,
+                                                              const float* __restrict__ g,
+                                                              const float* __restrict__ fm, int B,
+                                                              long rows, int C,
+                                                              float* __restrict__ d_orig,
+                                                              float* __restrict__ d_src,
+                                                              float* __restrict__ d_scale) {
+  const long r0 = (long)blockIdx.x * RB, r1 = min(rows, r0 + RB);
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float k = scale[c];
+    float acc = 0.f;
+    for (long r = r0; r < r1; ++r) {
+      const long i = r * C + c;
+      const float gv = g[i] * fm[(r % B) * C + c], ds = gv * k;
+      d_src[i] = ds;
+      d_orig[i] = gv - ds;
+      acc = fmaf(gv, src[i] - orig[i], acc);
+    }
+    atomicAdd(d_scale + c, acc);
+  }
+}
+
+struct CommitGroup {
+  int n;
+  S2tCommit it[8];
+};
+
+// grad += d for up to 8 small parameters at once, limit_param_value's sign flip applied where
+// asked; d is CLEARED afterwards (the accumulators the layer's kernels add into stay clean)
+__global__ __launch_bounds__(256) void param_grad_commit_n_kernel(CommitGroup grp) {
+  for (int q = 0; q < grp.n; ++q) {
+    const S2tCommit& it = grp.it[q];
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < it.n; e += (long)gridDim.x * 256) {
+      float v = it.d[e];
+      it.d[e] = 0.f;
+      if (it.limit) {
+        const float xv = it.x[e];
+        if (v > 0.f && xv < it.lo) v = -v;
+        if (v < 0.f && xv > it.hi) v = -v;
+      }
+      it.grad[e] += v;
+    }
+  }
 }
 
 // u (T,B,3C) = [s | x | y]  ->  xs (B,T,C) = x * tanh(s)
@@ -245,6 +317,46 @@ extern "C" int s2t_attn_delta_pairs(const float* W, const float* dW0, const floa
   const long rows = (long)H * B * T;
   hipLaunchKernelGGL(attn_delta_pairs_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
                      (hipStream_t)stream, W, dW0, dO1, O1, dv1, dO2, O2, dv2, T, B, H, delta);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int s2t_bypass_fwd_mask(const float* orig, const float* src, const float* scale,
+                                   const float* fm, int B, long rows, int C, float* out,
+                                   void* stream) {
+  if (rows <= 0) return 0;
+  if (C <= 0 || (C & 3) || B <= 0 || !fm) return -1;
+  const long n4 = rows * C / 4;
+  hipLaunchKernelGGL(bypass_fwd_mask_kernel, dim3(grid1(n4)), dim3(256), 0, (hipStream_t)stream,
+                     orig, src, scale, fm, B, n4, C / 4, out);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int s2t_bypass_bwd_mask(const float* orig, const float* src, const float* scale,
+                                   const float* g, const float* fm, int B, long rows, int C,
+                                   float* d_orig, float* d_src, float* d_scale, void* stream) {
+  if (rows <= 0) return 0;
+  if (C <= 0 || B <= 0 || !fm) return -1;
+  hipLaunchKernelGGL(bypass_bwd_mask_kernel, dim3((unsigned)((rows + RB - 1) / RB)), dim3(256), 0,
+                     (hipStream_t)stream, orig, src, scale, g, fm, B, rows, C, d_orig, d_src,
+                     d_scale);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int s2t_param_grad_commit_n(int n, const S2tCommit* items, void* stream) {
+  if (n <= 0) return 0;
+  if (n > 8 || !items) return -1;
+  CommitGroup grp;
+  grp.n = n;
+  long longest = 1;
+  for (int i = 0; i < n; ++i) {
+    grp.it[i] = items[i];
+    longest = items[i].n > longest ? items[i].n : longest;
+  }
+  hipLaunchKernelGGL(param_grad_commit_n_kernel, dim3((unsigned)((longest + 255) / 256)), dim3(256),
+                     0, (hipStream_t)stream, grp);
   S2T_CHECK_LAUNCH();
   return 0;
 }

@@ -326,9 +326,8 @@ class Zipformer2Encoder(nn.Module):
         out = src * feature_mask if masked else src
         for layer in self.layers:
             out = layer(out, pos_emb, chunk_size=chunk_size, attn_mask=attn_mask,
-                        src_key_padding_mask=src_key_padding_mask)
-            if masked:
-                out = out * feature_mask
+                        src_key_padding_mask=src_key_padding_mask,
+                        feature_mask=feature_mask if masked else None)
         return out
 
 
@@ -640,12 +639,22 @@ class Zipformer2EncoderLayer(nn.Module):
 
     def forward(self, src: Tensor, pos_emb: Tensor, chunk_size: int = -1,
                 attn_mask: Optional[Tensor] = None,
-                src_key_padding_mask: Optional[Tensor] = None) -> Tensor:
+                src_key_padding_mask: Optional[Tensor] = None,
+                feature_mask: Optional[Tensor] = None) -> Tensor:
+        """feature_mask: the encoder stack's (1,B,C) mask, applied to the output (reference
+        Zipformer2Encoder.forward, zipformer.py:1095-1113, does it right after the layer call)."""
         if zl.eligible(self, src, attn_mask, src_key_padding_mask):
             # one autograd node for the whole layer (speech2text_amd/zip_layer.py)
-            out = zl.run(self, src, pos_emb, chunk_size, attn_mask, src_key_padding_mask)
+            out = zl.run(self, src, pos_emb, chunk_size, attn_mask, src_key_padding_mask,
+                         feature_mask)
             if out is not None:
                 return out
+        out = self._forward_modules(src, pos_emb, chunk_size, attn_mask, src_key_padding_mask)
+        return out if feature_mask is None else out * feature_mask
+
+    def _forward_modules(self, src: Tensor, pos_emb: Tensor, chunk_size: int,
+                         attn_mask: Optional[Tensor],
+                         src_key_padding_mask: Optional[Tensor]) -> Tensor:
         train = self.training
         src_orig = src
         attn_skip = float(self.attention_skip_rate) if train else 0.0

@@ -1116,7 +1116,7 @@ def linear_big_m(x, weight, bias):
 class _Conv3x3Nhwc(torch.autograd.Function):
     """3x3 conv on channel-last (N,H,W,Cin) as im2col (one strided copy; each patch row is 3
     contiguous runs of 3*Cin floats in NHWC) + one plain GEMM (hipBLASLt).  Backward: two
-    GEMMs + col2im as 9 strided slice-adds.  weight keeps nn.Conv2d's (Cout,Cin,3,3) layout."""
+    GEMMs + one col2im gather kernel (zip_front.hip).  weight keeps nn.Conv2d's (Cout,Cin,3,3) layout."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, sh, sw):
@@ -1144,12 +1144,10 @@ class _Conv3x3Nhwc(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             wmat = weight.permute(2, 3, 1, 0).reshape(9 * C, Cout)
-            dc = g.mm(wmat.t()).view(B, Ho, Wo, 3, 3, C)
-            dx = torch.zeros((B, H, W, C), dtype=dy.dtype, device=dy.device)
-            for kh in range(3):
-                for kw in range(3):
-                    dx[:, kh:kh + (Ho - 1) * sh + 1:sh, kw:kw + (Wo - 1) * sw + 1:sw, :] += \
-                        dc[:, :, :, kh, kw, :]
+            dc = g.mm(wmat.t())                                  # (B*Ho*Wo, 3*3*C)
+            dx = torch.empty((B, H, W, C), dtype=torch.float32, device=dy.device)
+            N.check(N.lib().s2t_col2im3x3_nhwc(N.fp(dc), B, H, W, C, Ho, Wo, sh, sw, N.fp(dx),
+                                               N.stream()), "s2t_col2im3x3_nhwc")
         return dx, dweight, db, None, None
 
 

@@ -107,8 +107,9 @@ def _mask8(m):
     return m8
 
 
-def run(layer, src, pos_emb, chunk_size, attn_mask=None, key_padding_mask=None):
-    """-> layer output, or None when this call's draws ask for the score penalty (module path)."""
+def run(layer, src, pos_emb, chunk_size, attn_mask=None, key_padding_mask=None, feature_mask=None):
+    """-> layer output (times the stack's feature mask (1,B,D) if one is given), or None when this
+    call's draws ask for the score penalty (module path)."""
     sa = layer.self_attn_weights
     d = _Plan()
     r0, r1, r2, r3 = S._rand(), S._rand(), S._rand(), S._rand()
@@ -143,8 +144,13 @@ def run(layer, src, pos_emb, chunk_size, attn_mask=None, key_padding_mask=None):
     d.bal2 = _bal(layer.balancer2)
     d.wh_out = _wh(layer.whiten)
     CALLS[0] += 1
+    fm = None
+    if feature_mask is not None:
+        fm = feature_mask.reshape(src.shape[1], src.shape[2])
+        if fm.dtype != _F32 or not fm.is_contiguous():
+            fm = fm.contiguous().float()
     return _LayerFn.apply(src, pos_emb, layer, chunk_size, d, _mask8(attn_mask),
-                          _mask8(key_padding_mask))
+                          _mask8(key_padding_mask), fm)
 
 
 # ----------------------------------------------------------------------------- raw helpers
@@ -172,14 +178,36 @@ def _balancer_bwd(mod, x, g, inplace=False):
     return zk.balancer_backward(x, g, *mod.cfg(2), inplace=inplace)
 
 
-def _commit(p, d, lo, hi, limit):
-    """p.grad += limit_param(d) -- one launch, then tell the gradient reducer."""
-    g = p.grad
-    N.check(N.lib().s2t_param_grad_commit(ctypes.c_void_p(p.data_ptr()),
-                                          ctypes.c_void_p(d.data_ptr()), float(lo), float(hi),
-                                          int(limit), d.numel(), ctypes.c_void_p(g.data_ptr()),
-                                          N.stream()), "s2t_param_grad_commit")
-    flat.grad_written(p)
+class _Commit(ctypes.Structure):
+    """Mirror of S2tCommit (include/s2t_mi355.h)."""
+    _fields_ = [("x", ctypes.c_void_p), ("d", ctypes.c_void_p), ("grad", ctypes.c_void_p),
+                ("lo", ctypes.c_float), ("hi", ctypes.c_float), ("limit", ctypes.c_int),
+                ("n", ctypes.c_long)]
+
+
+def _commit(items):
+    """items: [(param, d, lo, hi, limit)]: param.grad += limit_param(d), d cleared -- one launch
+    for all of them, then tell the gradient reducer."""
+    arr = (_Commit * len(items))()
+    for q, (p, d, lo, hi, limit) in zip(arr, items):
+        q.x, q.d, q.grad = p.data_ptr(), d.data_ptr(), p.grad.data_ptr()
+        q.lo, q.hi, q.limit, q.n = float(lo), float(hi), int(limit), d.numel()
+    N.check(N.lib().s2t_param_grad_commit_n(len(items), ctypes.cast(arr, ctypes.c_void_p),
+                                            N.stream()), "s2t_param_grad_commit_n")
+    for it in items:
+        flat.grad_written(it[0])
+
+
+_ACC = {}
+
+
+def _layer_acc(dev, D):
+    """Persistent accumulator of a layer's per-channel parameter gradients, [bypass scale |
+    bypass_mid scale | norm bias | norm log_scale]; zeroed once, the commit kernel clears it."""
+    acc = _ACC.get((dev, D))
+    if acc is None:
+        acc = _ACC[(dev, D)] = torch.zeros(3 * D + 4, dtype=_F32, device=dev)
+    return acc
 
 
 class _Saved:
@@ -349,7 +377,7 @@ def _na_bwd(m, post, dec, sv, x_in, g, T, B):
 # ----------------------------------------------------------------------------- the layer
 class _LayerFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, src, pos_emb, layer, chunk_size, d, a8, k8):
+    def forward(ctx, src, pos_emb, layer, chunk_size, d, a8, k8, fm):
         T, B, D = src.shape
         R = T * B
         dev = src.device
@@ -394,13 +422,21 @@ class _LayerFn(torch.autograd.Function):
                                    ctypes.c_void_p(norm.log_scale.data_ptr()), R, D, N.fp(x10),
                                    N.fp(s.nscales), st), "biasnorm_fwd")
         x11 = _e(R, D, dev)
+        # the stack's feature mask rides in the last bypass unless a gradient-shaping op of this
+        # call needs the unmasked output
+        s.fm, s.fm_fused = fm, fm is not None and not (d.wh_out or d.bal2)
         N.profile_note("s2t_bypass_fwd", 12.0 * R * D)
-        N.check(L.s2t_bypass_fwd(N.fp(x0), N.fp(x10), N.fp(layer.bypass.bypass_scale), R, D,
-                                 N.fp(x11), st), "s2t_bypass_fwd")
+        if s.fm_fused:
+            N.check(L.s2t_bypass_fwd_mask(N.fp(x0), N.fp(x10), N.fp(layer.bypass.bypass_scale),
+                                          N.fp(fm), B, R, D, N.fp(x11), st), "s2t_bypass_fwd_mask")
+        else:
+            N.check(L.s2t_bypass_fwd(N.fp(x0), N.fp(x10), N.fp(layer.bypass.bypass_scale), R, D,
+                                     N.fp(x11), st), "s2t_bypass_fwd")
         s.wst = zk.WhitenStats(x11, layer.whiten.num_groups) if d.wh_out else None
         s.x = (x1, x2, x3, x4, x5, x6, x7, x8, x9, x10, x11)
         ctx.s, ctx.layer = s, layer
-        return x11.view(T, B, D)
+        out = x11.view(T, B, D)
+        return out * fm if (fm is not None and not s.fm_fused) else out
 
     @staticmethod
     def backward(ctx, g):
@@ -419,29 +455,32 @@ class _LayerFn(torch.autograd.Function):
             g = g.float()
         if g.data_ptr() % 16:
             g = g.clone()
+        if s.fm is not None and not s.fm_fused:
+            g = (g.view(T, B, D) * s.fm).view(R, D)
         if d.wh_out:
             g = _whiten_bwd(layer.whiten, x11, g, s.wst)
         if d.bal2:
             g = _balancer_bwd(layer.balancer2, x11, g)
         # per-channel parameter gradients: [bypass scale | bypass_mid scale | norm bias | log_scale]
-        acc = torch.zeros(3 * D + 4, dtype=_F32, device=dev)
+        acc = _layer_acc(dev, D)
         off = lambda n: ctypes.c_void_p(acc.data_ptr() + 4 * n)      # noqa: E731
 
         byp = layer.bypass
         d0 = _e(R, D, dev)
         g10 = _e(R, D, dev)
         N.profile_note("s2t_bypass_bwd", 20.0 * R * D)
-        N.check(L.s2t_bypass_bwd(N.fp(x0), N.fp(x10), N.fp(byp.bypass_scale), N.fp(g), R, D,
-                                 N.fp(d0), N.fp(g10), off(0), st), "s2t_bypass_bwd")
-        _commit(byp.bypass_scale, acc[:D], float(byp.scale_min), float(byp.scale_max), d.byp_lim)
+        if s.fm_fused:
+            N.check(L.s2t_bypass_bwd_mask(N.fp(x0), N.fp(x10), N.fp(byp.bypass_scale), N.fp(g),
+                                          N.fp(s.fm), B, R, D, N.fp(d0), N.fp(g10), off(0), st),
+                    "s2t_bypass_bwd_mask")
+        else:
+            N.check(L.s2t_bypass_bwd(N.fp(x0), N.fp(x10), N.fp(byp.bypass_scale), N.fp(g), R, D,
+                                     N.fp(d0), N.fp(g10), off(0), st), "s2t_bypass_bwd")
 
         norm = layer.norm
         g9 = _e(R, D, dev)
         N.check(L.s2t_biasnorm_bwd(N.fp(x9), N.fp(norm.bias), N.fp(s.nscales), N.fp(g10), R, D,
                                    N.fp(g9), off(2 * D), off(3 * D), st), "biasnorm_bwd")
-        _commit(norm.bias, acc[2 * D:3 * D], 0.0, 0.0, False)
-        _commit(norm.log_scale, acc[3 * D:3 * D + 1], float(norm.log_scale_min),
-                float(norm.log_scale_max), d.norm_lim)
         if d.bal1:
             g9 = _balancer_bwd(layer.balancer1, x9, g9)
 
@@ -457,8 +496,11 @@ class _LayerFn(torch.autograd.Function):
         N.check(L.s2t_bypass_bwd_acc(N.fp(x0), N.fp(x5), N.fp(mid.bypass_scale), N.fp(g6),
                                      N.fp(d0), R, D, N.fp(d0m), N.fp(g5), off(D), st),
                 "s2t_bypass_bwd_acc")
-        _commit(mid.bypass_scale, acc[D:2 * D], float(mid.scale_min), float(mid.scale_max),
-                d.mid_lim)
+        _commit([(byp.bypass_scale, acc[:D], byp.scale_min, byp.scale_max, d.byp_lim),
+                 (mid.bypass_scale, acc[D:2 * D], mid.scale_min, mid.scale_max, d.mid_lim),
+                 (norm.bias, acc[2 * D:3 * D], 0.0, 0.0, False),
+                 (norm.log_scale, acc[3 * D:3 * D + 1], norm.log_scale_min, norm.log_scale_max,
+                  d.norm_lim)])
 
         g4 = _ff_bwd(layer.feed_forward2, layer.balancer_ff2, d.ff2, s.ff2, x4, g5)
         g3 = _conv_bwd(layer.conv_module1, d.cv1, s.cv1, x3, g4, T, B, s.k8)
@@ -493,4 +535,4 @@ class _LayerFn(torch.autograd.Function):
         pend = list(_PEND)
         _PEND.clear()
         zk.wgrad_group(pend)
-        return gx.view(T, B, D), None, None, None, None, None, None
+        return gx.view(T, B, D), None, None, None, None, None, None, None
