@@ -106,14 +106,15 @@ __global__ __launch_bounds__(256) void dwconv2d_wgrad_kernel(const float* __rest
       }
     }
   }
+  // part[c-tile][block][slot][64 channels]: lanes = channels, so every store is one 256-byte row
   const long blk = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-  float* dst = part + (blk * 64 + c) * NV;
+  float* dst = part + blk * NV * 64 + c;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     __syncthreads();
     s_red[r][c] = acc[k];
     __syncthreads();
-    if (r == 0) dst[k] = s_red[0][c] + s_red[1][c] + s_red[2][c] + s_red[3][c];
+    if (r == 0) dst[k * 64] = s_red[0][c] + s_red[1][c] + s_red[2][c] + s_red[3][c];
   }
 }
 
@@ -121,16 +122,17 @@ __global__ __launch_bounds__(256) void dwconv2d_wreduce_kernel(const float* __re
                                                                int nblk, int C, int NV,
                                                                float* __restrict__ dw,
                                                                float* __restrict__ db) {
+  // grid (c tiles, NV slots); thread = (channel, block group): coalesced reads of 64 channels
   __shared__ float s_red[4][64];
-  const int cg = blockIdx.x, ct = cg >> 6, c = cg & 63;
-  const int slot = threadIdx.x & 63, kg = threadIdx.x >> 6;
+  const int ct = blockIdx.x, slot = blockIdx.y;
+  const int c = threadIdx.x & 63, kg = threadIdx.x >> 6;
   float s = 0.f;
-  if (slot < NV)
-    for (int k = kg; k < nblk; k += 4) s += part[(((long)ct * nblk + k) * 64 + c) * NV + slot];
-  s_red[kg][slot] = s;
+  for (int k = kg; k < nblk; k += 4) s += part[(((long)ct * nblk + k) * NV + slot) * 64 + c];
+  s_red[kg][c] = s;
   __syncthreads();
-  if (kg == 0 && slot < NV) {
-    s = s_red[0][slot] + s_red[1][slot] + s_red[2][slot] + s_red[3][slot];
+  const int cg = ct * 64 + c;
+  if (kg == 0 && cg < C) {
+    s = s_red[0][c] + s_red[1][c] + s_red[2][c] + s_red[3][c];
     if (slot < NV - 1) dw[(long)cg * (NV - 1) + slot] = s;
     else if (db) db[cg] = s;
   }
@@ -167,7 +169,9 @@ extern "C" int s2t_dwconv2d_nhwc_wgrad(const float* x, const float* dy, int N, i
                                        int KH, int KW, float* workspace, float* dw, float* db,
                                        void* stream) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
-  const int rows_per_blk = 8;
+  // ~1000 workgroups: enough to fill the chip, few enough that the partial sums stay small
+  int rows_per_blk = (int)(((long)H * N * ((C + 63) / 64) + 1023) / 1024);
+  rows_per_blk = rows_per_blk < 8 ? 8 : ((rows_per_blk + 3) / 4) * 4;
   dim3 grid((H + rows_per_blk - 1) / rows_per_blk, N, (C + 63) / 64);
   hipStream_t st = (hipStream_t)stream;
   if (KH == 7 && KW == 7)
@@ -177,8 +181,8 @@ extern "C" int s2t_dwconv2d_nhwc_wgrad(const float* x, const float* dy, int N, i
   else
     return -1;
   S2T_CHECK_LAUNCH();
-  hipLaunchKernelGGL(dwconv2d_wreduce_kernel, dim3(C), dim3(256), 0, st, workspace,
-                     (int)(grid.x * grid.y), C, KH * KW + 1, dw, db);
+  hipLaunchKernelGGL(dwconv2d_wreduce_kernel, dim3((C + 63) / 64, KH * KW + 1), dim3(256), 0, st,
+                     workspace, (int)(grid.x * grid.y), C, KH * KW + 1, dw, db);
   S2T_CHECK_LAUNCH();
   return 0;
 }

@@ -253,3 +253,41 @@ def test_linear_wgrad(dev, R, Nf, Mf, bias, stride_pad):
     np.testing.assert_allclose(x.grad.cpu().numpy(), x2.grad.cpu().numpy(), atol=1e-4, rtol=1e-4)
     if bias:
         np.testing.assert_allclose(b.grad.cpu().numpy(), b2.grad.cpu().numpy(), atol=2 * tol, rtol=1e-4)
+
+
+@pytest.mark.parametrize("N_,H,W,C,K", [(3, 37, 19, 128, 7), (2, 9, 5, 70, 7), (5, 130, 19, 64, 3)])
+def test_dwconv2d_and_conv3x3_nhwc_vs_torch(dev, N_, H, W, C, K):
+    """Channel-last frontend convolutions (zip_front.hip: depthwise stencil, its two-stage weight
+    gradient, the col2im gather of the 3x3 conv) against torch's NCHW convolutions in fp64."""
+    from speech2text_amd import zip_kernels as zk
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(N_, H, W, C, generator=g)
+    w = torch.randn(C, 1, K, K, generator=g) * 0.2
+    b = torch.randn(C, generator=g)
+    wts = torch.randn(N_, H, W, C, generator=g)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    yr = torch.nn.functional.conv2d(xr.permute(0, 3, 1, 2), wr, br, padding=K // 2, groups=C)
+    (yr.permute(0, 2, 3, 1) * wts.double()).sum().backward()
+    xg, wg, bg = (t.to(dev).requires_grad_(True) for t in (x, w, b))
+    y = zk.dwconv2d_nhwc(xg, wg, bg)
+    (y * wts.to(dev)).sum().backward()
+    torch.testing.assert_close(y.detach().cpu().double(), yr.permute(0, 2, 3, 1).detach(), atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(xg.grad.cpu().double(), xr.grad, atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(wg.grad.cpu().double(), wr.grad, atol=2e-3, rtol=2e-4)
+    torch.testing.assert_close(bg.grad.cpu().double(), br.grad, atol=2e-3, rtol=2e-4)
+    # 3x3 conv, strides (1,1) and (2,2): im2col GEMM forward, col2im gather backward
+    Cin, Cout = 8, 16
+    for stride in ((1, 1), (2, 2), (1, 2)):
+        x3 = torch.randn(N_, H, W, Cin, generator=g)
+        w3 = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.2
+        b3 = torch.randn(Cout, generator=g)
+        xr, wr, br = (t.double().requires_grad_(True) for t in (x3, w3, b3))
+        yr = torch.nn.functional.conv2d(xr.permute(0, 3, 1, 2), wr, br, stride=stride)
+        wt3 = torch.randn(yr.shape, generator=g, dtype=torch.float64)
+        (yr * wt3).sum().backward()
+        xg, wg, bg = (t.to(dev).requires_grad_(True) for t in (x3, w3, b3))
+        y = zk.conv3x3_nhwc(xg, wg, bg, stride)
+        (y * wt3.permute(0, 2, 3, 1).float().to(dev)).sum().backward()
+        torch.testing.assert_close(y.detach().cpu().double(), yr.permute(0, 2, 3, 1).detach(), atol=1e-4, rtol=1e-4)
+        torch.testing.assert_close(xg.grad.cpu().double(), xr.grad, atol=1e-4, rtol=1e-4)
+        torch.testing.assert_close(wg.grad.cpu().double(), wr.grad, atol=2e-3, rtol=2e-4)
