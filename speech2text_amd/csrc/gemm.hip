@@ -53,16 +53,20 @@ struct GemmArgs {
   int debug;
 };
 
+__device__ __forceinline__ float log1p_fast(float e) {   // as zip_elem.hip
+  const float u = 1.f + e;
+  return u == 1.f ? e : __logf(u) * __fdividef(e, u - 1.f);
+}
 __device__ __forceinline__ float swoosh(float x, int kind) {
   // log(1 + exp(x - off)) - 0.08 x - c   (scaling.py:1340-1343, 1418-1423)
   const float off = kind == ACT_SWOOSH_L ? 4.f : 1.f;
   const float c = kind == ACT_SWOOSH_L ? 0.035f : 0.313261687f;
   const float z = x - off;
-  return fmaxf(z, 0.f) + log1pf(__expf(-fabsf(z))) - 0.08f * x - c;   // as zip_elem.hip swoosh_f
+  return fmaxf(z, 0.f) + log1p_fast(__expf(-fabsf(z))) - 0.08f * x - c;   // as zip_elem.hip swoosh_f
 }
 __device__ __forceinline__ float swoosh_deriv(float x, int kind) {
   const float off = kind == ACT_SWOOSH_L ? 4.f : 1.f;
-  return 1.f / (1.f + __expf(off - x)) - 0.08f;
+  return __fdividef(1.f, 1.f + __expf(off - x)) - 0.08f;
 }
 // One operand tile in LDS.  KC: [ROWS][BK + 4] (rows = output index, k contiguous);
 // KM: [BK][ROWS + 4] (k-major).  ROWS = 64 * T.  Loads are unconditional (clamped addresses) so

@@ -11,11 +11,14 @@
 #include <hip/hip_runtime.h>
 #include <hipblaslt/hipblaslt.h>
 
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <tuple>
 
 namespace {
+
+constexpr int MAX_CAND = 16;
 
 struct Plan {
   hipblasLtMatmulDesc_t desc = nullptr;
@@ -23,6 +26,10 @@ struct Plan {
   hipblasLtMatmulAlgo_t algo;
   size_t ws = 0;
   bool ok = false;
+  // the heuristic's candidates, timed on the real operands at the first call (tune())
+  hipblasLtMatmulHeuristicResult_t cand[MAX_CAND];
+  int ncand = 0;
+  bool tuned = false;
 };
 
 using Key = std::tuple<int, int, int, int, long, long, long, long, int>;
@@ -59,16 +66,68 @@ int make_plan(Plan& p, int mode, int M, int N, int K, long ldx, long ldw, long l
   LT_CHECK(hipblasLtMatmulPreferenceCreate(&pref));
   LT_CHECK(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES,
                                                  &ws_bytes, sizeof(ws_bytes)));
-  hipblasLtMatmulHeuristicResult_t res[1];
   int n = 0;
-  hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(g_handle, p.desc, p.a, p.b, p.c, p.d, pref, 1,
-                                                       res, &n);
+  hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(g_handle, p.desc, p.a, p.b, p.c, p.d, pref,
+                                                       MAX_CAND, p.cand, &n);
   hipblasLtMatmulPreferenceDestroy(pref);
   if (st != HIPBLAS_STATUS_SUCCESS || n < 1) return -2;      // caller falls back
-  p.algo = res[0].algo;
-  p.ws = res[0].workspaceSize;
+  p.ncand = n;
+  p.algo = p.cand[0].algo;
+  p.ws = p.cand[0].workspaceSize;
   p.ok = true;
   return 0;
+}
+
+bool tuning_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("S2T_LT_TUNE");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v == 1;
+}
+
+// Time every candidate the heuristic returned on the call's own operands (output into a scratch
+// buffer, so accumulating epilogues are not applied twice) and keep the fastest.  The library's
+// first choice is tuned for large square problems; on the tall, short-K shapes of this model
+// another of its kernels is often 10-30 % faster.  Runs once per distinct shape (during warm-up).
+void tune(Plan& p, const float* X, const float* W, const float* C, float beta, long d_elems,
+          void* workspace, size_t ws_bytes, hipStream_t st) {
+  p.tuned = true;
+  if (p.ncand < 2 || !tuning_enabled()) return;
+  float* scratch = nullptr;
+  if (hipMalloc(&scratch, (size_t)d_elems * sizeof(float)) != hipSuccess) return;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  const float alpha = 1.f;
+  float best = 1e30f;
+  int best_i = 0;
+  if (!C) C = scratch;                     // beta == 0: the C operand is only a placeholder
+  for (int i = 0; i < p.ncand; ++i) {
+    if (p.cand[i].workspaceSize > ws_bytes) continue;
+    bool ok = true;
+    float ms = 0.f;
+    for (int rep = 0; rep < 4 && ok; ++rep) {
+      if (rep == 1) hipEventRecord(e0, st);
+      ok = hipblasLtMatmul(g_handle, p.desc, &alpha, W, p.a, X, p.b, &beta, C, p.c, scratch, p.d,
+                           &p.cand[i].algo, workspace, p.cand[i].workspaceSize,
+                           st) == HIPBLAS_STATUS_SUCCESS;
+    }
+    if (!ok) continue;
+    hipEventRecord(e1, st);
+    hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best) {
+      best = ms;
+      best_i = i;
+    }
+  }
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  hipFree(scratch);
+  p.algo = p.cand[best_i].algo;
+  p.ws = p.cand[best_i].workspaceSize;
 }
 
 }  // namespace
@@ -100,6 +159,9 @@ extern "C" int s2t_linear_lt(int mode, const float* X, long ldx, const float* W,
   if (!p.ok || p.ws > (size_t)ws_bytes) return -2;
   if (bias)
     LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)));
+  if (!p.tuned)
+    tune(p, X, W, C == D ? nullptr : C, C == D ? 0.f : beta, (long)M * ldd, workspace,
+         (size_t)ws_bytes, (hipStream_t)stream);
   const float alpha = 1.f;
   LT_CHECK(hipblasLtMatmul(g_handle, p.desc, &alpha, W, p.a, X, p.b, &beta, C, p.c, D, p.d, &p.algo,
                            workspace, p.ws, (hipStream_t)stream));

@@ -9,13 +9,20 @@
 
 namespace {
 
+// log1p(e) for e in (0, 1]: hardware log of u = fl(1 + e), times e / (u - 1) to undo the rounding
+// of the sum (the classic compensation) -- a handful of instructions instead of libm's log1pf
+__device__ __forceinline__ float log1p_fast(float e) {
+  const float u = 1.f + e;
+  return u == 1.f ? e : __logf(u) * __fdividef(e, u - 1.f);
+}
+
 __device__ __forceinline__ float swoosh_f(float x, float off, float c) {
   const float z = x - off;
   // log(1+exp(z)) = max(z,0) + log1p(exp(-|z|))
-  return fmaxf(z, 0.f) + log1pf(__expf(-fabsf(z))) - 0.08f * x - c;
+  return fmaxf(z, 0.f) + log1p_fast(__expf(-fabsf(z))) - 0.08f * x - c;
 }
 __device__ __forceinline__ float swoosh_d(float x, float off) {
-  return 1.f / (1.f + __expf(off - x)) - 0.08f;
+  return __fdividef(1.f, 1.f + __expf(off - x)) - 0.08f;
 }
 
 __global__ __launch_bounds__(256) void swoosh_fwd_kernel(const float* __restrict__ x,
