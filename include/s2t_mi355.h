@@ -139,6 +139,14 @@ long s2t_zipconv_bwd_workspace_floats(int T, int B, int C, int K);
 int s2t_relpos_attn_fwd(const float* qkp, const float* pos, const unsigned char* kpm,
                         const unsigned char* amask, int T, int B, int H, int qd, int pd, float* W,
                         void* stream);
+/* As s2t_relpos_attn_fwd, and *pen_flag (device-visible, e.g. pinned host memory; the caller zeroes
+ * it) is set to 1.0f when any raw score -- q.k + p.pos, before masking -- exceeds pen_limit in
+ * absolute value: whether the reference's penalize_abs_values_gt(scores, limit=25, penalty=1e-4)
+ * (zipformer.py:2010-2026, scaling.py:905-935) contributes a gradient on this call.  Returns -3
+ * when the shape is outside the MFMA kernel's range (the only one that reports the limit). */
+int s2t_relpos_attn_fwd_flag(const float* qkp, const float* pos, const unsigned char* kpm,
+                             const unsigned char* amask, int T, int B, int H, int qd, int pd,
+                             float* W, float pen_limit, float* pen_flag, void* stream);
 int s2t_relpos_attn_bwd(const float* qkp, const float* pos, const unsigned char* kpm,
                         const unsigned char* amask, int T, int B, int H, int qd, int pd,
                         const float* W, const float* dW, const float* dW0, const float* dO1,

@@ -43,6 +43,10 @@ struct AttnArgs {
   const float* pdO[2]; // (T,B,H*dv_c) each, or null
   const float* pV[2];
   int pdv[2];
+  // forward only: *pen_flag = 1 when any raw score (before masking) exceeds pen_limit in absolute
+  // value -- tells the caller whether penalize_abs_values_gt has a non-zero gradient this call
+  float pen_limit;
+  float* pen_flag;
 };
 
 __device__ __forceinline__ const float* q_row(const AttnArgs& a, int t, int b, int h) {
@@ -392,6 +396,7 @@ void attn_fwd_mfma_kernel(AttnArgs a, float* __restrict__ W) {
   // row by row: the row's position vector is read once, stores walk one row pointer
   const int ilb = strip * 32 + 4 * hi;                          // row of register 0
   float rmax[16], rsum[16];
+  bool big = false;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int il = ilb + (r & 3) + 8 * (r >> 2);
@@ -411,6 +416,7 @@ void attn_fwd_mfma_kernel(AttnArgs a, float* __restrict__ W) {
         x = fmaf(pv.z, e.z, x);
         x = fmaf(pv.w, e.w, x);
       }
+      big |= (fabsf(x) > a.pen_limit) && j < T && (i0 + il) < T;
       bool masked = (pad_bits >> t) & 1u;
       if (HAS_AM) masked = masked || am[min(j, T - 1)] != 0;
       x = masked ? -1000.f : x;
@@ -420,6 +426,8 @@ void attn_fwd_mfma_kernel(AttnArgs a, float* __restrict__ W) {
     }
     rmax[r] = m;
   }
+  if (a.pen_flag != nullptr && big)
+    __hip_atomic_store(a.pen_flag, 1.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
 #pragma unroll
@@ -1145,13 +1153,25 @@ int launch_fwd_mfma(int variant, const AttnArgs& a, float* W, hipStream_t st) {
   }
 }
 
+extern "C" int s2t_relpos_attn_fwd_flag(const float* qkp, const float* pos,
+                                        const unsigned char* kpm, const unsigned char* amask,
+                                        int T, int B, int H, int qd, int pd, float* W,
+                                        float pen_limit, float* pen_flag, void* stream);
+
 extern "C" int s2t_relpos_attn_fwd(const float* qkp, const float* pos, const unsigned char* kpm,
                                    const unsigned char* amask, int T, int B, int H, int qd, int pd,
                                    float* W, void* stream) {
+  return s2t_relpos_attn_fwd_flag(qkp, pos, kpm, amask, T, B, H, qd, pd, W, 0.f, nullptr, stream);
+}
+
+extern "C" int s2t_relpos_attn_fwd_flag(const float* qkp, const float* pos,
+                                        const unsigned char* kpm, const unsigned char* amask,
+                                        int T, int B, int H, int qd, int pd, float* W,
+                                        float pen_limit, float* pen_flag, void* stream) {
   if (T <= 0 || B <= 0 || H <= 0) return 0;
   if (qd <= 0 || qd > MAXQD || pd < 0 || pd > MAXPD) return -1;
   AttnArgs a{qkp, pos, kpm, amask, T, B, H, qd, pd, nullptr, nullptr, {nullptr, nullptr},
-             {nullptr, nullptr}, {0, 0}};
+             {nullptr, nullptr}, {0, 0}, pen_limit, pen_flag};
   hipStream_t st = (hipStream_t)stream;
   static bool attr_done = false;
   if (!attr_done) {
@@ -1173,6 +1193,7 @@ extern "C" int s2t_relpos_attn_fwd(const float* qkp, const float* pos, const uns
     else rc = launch_fwd_mfma<2, 1>(v, a, W, st);
     return rc;
   }
+  if (pen_flag) return -3;                        // only the MFMA kernel reports the score limit
   dim3 grid((T + ROWS - 1) / ROWS, B, H);
   if (T <= 128)
     hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, dim3(256), attn_smem<2>(qd, pd), st, a, W);

@@ -33,11 +33,13 @@ from .model.layer import scaling as S
 _F32 = torch.float32
 ENABLED = os.environ.get("S2T_LAYER_EXEC", "1") == "1"
 CALLS = [0]          # layer calls served by the executor (tests assert the path really ran)
+STATS = {"penalize": 0, "penalty_active": 0}     # score-penalty draws / calls where it was non-zero
+PEN_LIMIT, PEN_VALUE = 25.0, 1.0e-4              # zipformer.py:2010-2026
 
 
 class _Plan:
     """Decisions of one layer call, in draw order."""
-    __slots__ = ("k_bal", "k_wh", "use_pos", "ff1", "na", "sa1", "cv1", "ff2", "mid_lim", "sa2",
+    __slots__ = ("k_bal", "k_wh", "use_pos", "penalize", "ff1", "na", "sa1", "cv1", "ff2", "mid_lim", "sa2",
                  "cv2", "ff3", "bal1", "norm_lim", "byp_lim", "bal2", "wh_out")
 
 
@@ -107,13 +109,21 @@ def _mask8(m):
     return m8
 
 
+def _pen_ok(sa, T):
+    """The score-limit flag comes from the MFMA attention kernel only (zip_attn.hip)."""
+    H, qd, pd = sa.num_heads, sa.query_head_dim, sa.pos_head_dim
+    return (T <= 512 and pd <= 4 and qd % 8 == 0 and (H * (2 * qd + pd)) % 4 == 0
+            and "S2T_ATTN_FWD_OLD" not in os.environ)
+
+
 def run(layer, src, pos_emb, chunk_size, attn_mask=None, key_padding_mask=None, feature_mask=None):
     """-> layer output (times the stack's feature mask (1,B,D) if one is given), or None when this
-    call's draws ask for the score penalty (module path)."""
+    call's draws ask for the score penalty on a shape the flagging kernel does not serve."""
     sa = layer.self_attn_weights
     d = _Plan()
     r0, r1, r2, r3 = S._rand(), S._rand(), S._rand(), S._rand()
-    if r3 < 0.1:                                     # penalize_abs_values_gt on the raw scores
+    d.penalize = r3 < 0.1                            # penalize_abs_values_gt on the raw scores
+    if d.penalize and not _pen_ok(sa, src.shape[0]):
         S._REPLAY.extend((r0, r1, r2, r3))
         return None
     d.k_bal = r0 < float(sa.balance_keys.prob)
@@ -374,6 +384,29 @@ def _na_bwd(m, post, dec, sv, x_in, g, T, B):
     return zk.lt_matmul(1, du, m.in_proj.weight, None, g), dW0
 
 
+def _attn_bwd_penalized(s, qkp3, pairs, dW0, H, qd, pd):
+    """Rare branch: some raw score exceeded the limit of penalize_abs_values_gt, so its gradient
+    term is non-zero.  The scores are rebuilt as an autograd graph (the materialised composition
+    of zip_kernels.relpos_attention_weights, penalty included) and differentiated against the
+    consumers' gradient w.r.t. W, materialised here from its factors."""
+    T, B, _ = qkp3.shape
+    dW = None
+    for dO, v, _, dv in pairs:
+        t = torch.matmul(dO.view(T, B, H, dv).permute(2, 1, 0, 3), v.view(T, B, H, dv).permute(2, 1, 3, 0))
+        dW = t if dW is None else dW.add_(t)
+    dW[0] += dW0
+    with torch.enable_grad():
+        q_ = qkp3.detach().requires_grad_(True)
+        p_ = None if s.posp is None else s.posp.detach().requires_grad_(True)
+        w = zk.relpos_attention_weights(
+            q_, p_, H, qd, pd, None if s.a8 is None else s.a8.bool(),
+            None if s.k8 is None else s.k8.bool(),
+            penalize=lambda sc: S.penalize_abs_values_gt(sc, limit=PEN_LIMIT, penalty=PEN_VALUE))
+        ins = [q_] if p_ is None else [q_, p_]
+        gs = torch.autograd.grad(w, ins, dW)
+    return gs[0].contiguous(), (None if p_ is None else gs[1].contiguous())
+
+
 # ----------------------------------------------------------------------------- the layer
 class _LayerFn(torch.autograd.Function):
     @staticmethod
@@ -399,8 +432,22 @@ class _LayerFn(torch.autograd.Function):
             s.posp = zk.lt_matmul(0, s.pos2, sa.linear_pos.weight, None)
         W = torch.empty((H, B, T, T), dtype=_F32, device=dev)
         N.profile_note("s2t_relpos_attn_fwd", 4.0 * (s.qkp.numel() + W.numel()))
-        N.check(L.s2t_relpos_attn_fwd(N.fp(s.qkp), N.fp(s.posp), N.ptr(k8), N.ptr(a8), T, B, H, qd,
-                                      pd, N.fp(W), st), "s2t_relpos_attn_fwd")
+        s.pen_slot = s.pen_event = None
+        if d.penalize:
+            # the penalty has a gradient only where |score| > 25: the kernel raises a host-visible
+            # flag if that happens at all, read (long after, no stall) when backward starts
+            STATS["penalize"] += 1
+            s.pen_slot = zk._pinned_slot()
+            s.pen_slot[0] = 0.0
+            N.check(L.s2t_relpos_attn_fwd_flag(N.fp(s.qkp), N.fp(s.posp), N.ptr(k8), N.ptr(a8), T,
+                                               B, H, qd, pd, N.fp(W), PEN_LIMIT,
+                                               ctypes.c_void_p(s.pen_slot.data_ptr()), st),
+                    "s2t_relpos_attn_fwd_flag")
+            s.pen_event = torch.cuda.Event()
+            s.pen_event.record()
+        else:
+            N.check(L.s2t_relpos_attn_fwd(N.fp(s.qkp), N.fp(s.posp), N.ptr(k8), N.ptr(a8), T, B, H,
+                                          qd, pd, N.fp(W), st), "s2t_relpos_attn_fwd")
         s.W = W
 
         x1, s.ff1 = _ff_fwd(layer.feed_forward1, d.ff1, x0)
@@ -516,8 +563,16 @@ class _LayerFn(torch.autograd.Function):
                                        N.fp(O2), dv2, T, B, H, N.fp(delta), st),
                 "s2t_attn_delta_pairs")
         qkp3 = s.qkp.view(T, B, -1)
-        dqkp, dpos = zk._attn_bwd_call(qkp3, s.posp, s.k8, s.a8, H, qd, pd, s.W, None, dW0, pairs,
-                                       delta)
+        pen_active = False
+        if d.penalize:
+            s.pen_event.synchronize()
+            pen_active = float(s.pen_slot[0]) != 0.0
+        if pen_active:
+            STATS["penalty_active"] += 1
+            dqkp, dpos = _attn_bwd_penalized(s, qkp3, pairs, dW0, H, qd, pd)
+        else:
+            dqkp, dpos = zk._attn_bwd_call(qkp3, s.posp, s.k8, s.a8, H, qd, pd, s.W, None, dW0,
+                                           pairs, delta)
         dqkp = dqkp.view(R, -1)
         if d.k_wh or d.k_bal:
             ks = slice(H * qd, 2 * H * qd)

@@ -16,7 +16,7 @@ CFG = dict(feature_dim=80, downsampling_factor=(1, 2, 4), num_encoder_layers=(2,
            pos_dim=24, cnn_module_kernel=(15, 7, 7), causal=True)
 
 
-def _build(dev, chunk, left):
+def _build(dev, chunk, left, big=False):
     from speech2text_amd import flat
     from speech2text_amd.model.encoder.zipformer import Zipformer2, Zipformer2Config
     torch.manual_seed(5)
@@ -29,6 +29,8 @@ def _build(dev, chunk, left):
                 p.normal_(0, 0.3)
             elif "out_proj" in n or "linear_pos" in n:
                 p.mul_(6.0)
+            elif big and "self_attn_weights.in_proj" in n:
+                p.mul_(5.0)                                # raw scores beyond the penalty limit
     for mod in m.modules():
         if mod.__class__.__name__ == "CompactRelPositionalEncoding":
             mod.dropout.p = 0.0
@@ -63,13 +65,16 @@ def _step(m, store, x, lens, wts, seed, executor):
     return y.detach().clone(), xg.grad.clone(), store.flat_g.clone()
 
 
-@pytest.mark.parametrize("force", [True, False])
+@pytest.mark.parametrize("force,big", [(True, False), (False, False), (False, True)])
 @pytest.mark.parametrize("chunk,left", [((-1,), (-1,)), ((8,), (16,))])
-def test_executor_matches_module_path(dev, monkeypatch, force, chunk, left):
+def test_executor_matches_module_path(dev, monkeypatch, force, big, chunk, left):
+    """big: attention projections scaled so raw scores exceed penalize_abs_values_gt's limit -- on
+    the ~10 % of calls that draw the penalty the executor must take its materialised branch."""
     from speech2text_amd import rng, zip_layer
     monkeypatch.setattr(rng, "rand", lambda *s, device=None, dtype=torch.float32:
                         torch.rand(*s, dtype=dtype).to(device))
-    m, store = _build(dev, chunk, left)
+    m, store = _build(dev, chunk, left, big)
+    active0 = zip_layer.STATS["penalty_active"]
     _force(m, force)
     g = torch.Generator().manual_seed(9)
     B, T = 4, 211
@@ -78,7 +83,7 @@ def test_executor_matches_module_path(dev, monkeypatch, force, chunk, left):
     with torch.no_grad():
         wts = torch.randn(m(x, lens)[0].shape, generator=g).to(dev)
     served = 0
-    for seed in range(6):
+    for seed in range(14 if big else 6):
         _force(m, force)
         c0 = zip_layer.CALLS[0]
         y1, gx1, gp1 = _step(m, store, x, lens, wts, seed, True)
@@ -93,4 +98,6 @@ def test_executor_matches_module_path(dev, monkeypatch, force, chunk, left):
         for p, (o, n) in zip(store.params, zip(store.offsets, store.lengths)):
             a, b = gp1[o:o + n], gp0[o:o + n]
             assert (a - b).abs().max() <= 2e-3 * b.abs().max() + 1e-6, (seed, tuple(p.shape))
-    assert served >= 12                       # 4 layers x 6 steps minus the ~10 % penalty draws
+    assert served == 4 * (14 if big else 6)   # every layer call, penalty draws included
+    if big:
+        assert zip_layer.STATS["penalty_active"] > active0
