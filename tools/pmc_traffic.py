@@ -20,14 +20,19 @@ KERNELS = [
     ("attn_bwd_q", "s2t_relpos_attn_bwd", True), ("attn_bwd_k", "s2t_relpos_attn_bwd", False),
     ("dpos_reduce", "s2t_relpos_attn_bwd", False),
     ("attn_apply_kernel", "s2t_attn_apply", True),
-    ("gemm_kernel", "s2t_gemm_f32", True),
+    ("gemm_kernel", "s2t_gemm_f32", True), ("gemm_tn_grouped_kernel", "s2t_gemm_tn_grouped", True),
     ("wgrad_kernel", "s2t_linear_wgrad", True), ("wgrad_reduce_kernel", "s2t_linear_wgrad", False),
     ("zipconv_fwd_kernel", "s2t_zipconv_fwd", True),
     ("zipconv_bwd_data_kernel", "s2t_zipconv_bwd", True), ("zipconv_bwd_w_kernel", "s2t_zipconv_bwd", False),
     ("zipconv_reduce_w_kernel", "s2t_zipconv_bwd", False),
     ("swoosh_fwd_kernel", "s2t_swoosh_fwd", True), ("swoosh_bwd_kernel", "s2t_swoosh_bwd", True),
     ("biasnorm_fwd_kernel", "s2t_biasnorm_fwd", True), ("biasnorm_bwd_kernel", "s2t_biasnorm_bwd", True),
-    ("col_stats_kernel", "s2t_col_stats", True), ("balancer_apply_kernel", "s2t_balancer_apply", True),
+    ("col_stats_kernel", "s2t_balancer_bwd", True), ("balancer_apply_kernel", "s2t_balancer_apply", True),
+    ("balancer_apply_fused_kernel", "s2t_balancer_bwd", False),
+    ("bypass_fwd", "s2t_bypass_fwd", True), ("bypass_bwd", "s2t_bypass_bwd", True),
+    ("nonlin_gate_fwd", "s2t_nonlin_gate_fwd", True), ("nonlin_out_bwd", "s2t_nonlin_out_bwd", True),
+    ("whiten_metric_kernel", "s2t_whiten_metric", True), ("col2im3x3_kernel", "s2t_col2im3x3_nhwc", True),
+    ("attn_delta_pairs_kernel", "s2t_attn_delta_pairs", True),
     ("whiten_apply_kernel", "s2t_whiten_apply", True), ("sumsq2_kernel", "s2t_whiten_apply", False),
     ("mi_fwd_kernel", "s2t_mutual_info_fwd", True), ("mi_bwd_kernel", "s2t_mutual_info_bwd", True),
     ("pruned_fwd", "s2t_rnnt_pruned_fwd", True), ("pruned_bwd", "s2t_rnnt_pruned_bwd", True),
