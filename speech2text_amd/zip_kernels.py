@@ -912,7 +912,9 @@ def wgrad_into(wparam, bparam, g2, a2, pro=0, notify=False):
         bg = bparam.grad
         if bg is None or not bg.is_contiguous():
             return False
-    gemm_tn(g2, a2, wg, bg, pro, stream=_side_launch_stream(g2, a2))
+    # (main stream: forking to the side stream per Linear costs the host more than the overlap
+    # gives back -- measured on the conformer step; the grouped per-layer launch below does fork)
+    gemm_tn(g2, a2, wg, bg, pro)
     if notify:
         flat.grad_written(wparam)
         if bparam is not None:
