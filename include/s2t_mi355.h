@@ -366,6 +366,21 @@ int s2t_bypass_fwd_mask(const float* orig, const float* src, const float* scale,
 int s2t_bypass_bwd_mask(const float* orig, const float* src, const float* scale, const float* g,
                         const float* fm, int B, long rows, int C, float* d_orig, float* d_src,
                         float* d_scale, void* stream);
+/* SimpleDownsample (zipformer.py:1653-1695): out (ceil(T/ds),B,C) = sum_k w[k] src[min(tt*ds+k, T-1)]
+ * with w = softmax(bias) supplied by the caller (ds <= 8); the backward writes d_src (T,B,C) and
+ * ACCUMULATES dw[ds] (caller zeroes it; the softmax backward stays with the caller).
+ * SimpleUpsample + the out_combiner BypassModule of a downsampled stack (zipformer.py:1253-1283,
+ * 1698-1719): out[t] = orig[t] + (src[t / up] - orig[t]) * scale[c] with src (ceil(T/up),B,C) --
+ * the upsampled tensor is never materialised; the backward writes d_orig, d_src and ACCUMULATES
+ * d_scale[C] (caller zeroes it). */
+int s2t_downsample_fwd(const float* src, const float* w, int ds, int T, int B, int C, float* out,
+                       void* stream);
+int s2t_downsample_bwd(const float* src, const float* w, const float* g, int ds, int T, int B, int C,
+                       float* d_src, float* dw, void* stream);
+int s2t_bypass_up_fwd(const float* orig, const float* src, const float* scale, int up, int T, int B,
+                      int C, float* out, void* stream);
+int s2t_bypass_up_bwd(const float* orig, const float* src, const float* scale, const float* g, int up,
+                      int T, int B, int C, float* d_orig, float* d_src, float* d_scale, void* stream);
 /* Up to 8 small parameters in one launch: grad[e] += d[e] (limit_param_value's sign flip,
  * scaling.py:1153-1190, applied to d first where `limit`), then d[e] = 0 -- the accumulators the
  * layer's backward kernels add into are handed back clean.  `items` is a HOST array. */

@@ -192,6 +192,117 @@ __global__ __launch_bounds__(256) void param_grad_commit_n_kernel(CommitGroup gr
   }
 }
 
+// SimpleDownsample (zipformer.py:1653-1695): out[tt,b,c] = sum_k w[k] src[min(tt*ds + k, T-1), b, c]
+// (the reference pads by repeating the last frame), w = softmax(bias) computed by the caller.
+// rowlen = B*C; one thread per output element, coalesced over (b,c).
+__global__ __launch_bounds__(256) void downsample_fwd_kernel(const float* __restrict__ src,
+                                                             const float* __restrict__ w, int ds,
+                                                             int T, long rowlen, long n_out,
+                                                             float* __restrict__ out) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_out; i += (long)gridDim.x * 256) {
+    const long tt = i / rowlen, e = i - tt * rowlen;
+    float acc = 0.f;
+    for (int k = 0; k < ds; ++k) {
+      const long t = min((long)tt * ds + k, (long)T - 1);
+      acc = fmaf(w[k], src[t * rowlen + e], acc);
+    }
+    out[i] = acc;
+  }
+}
+
+// backward: d_src[t] = sum over the (tt,k) that read frame t of w[k] g[tt]  (the last frame also
+// collects the padded taps); dw[k] += sum g[tt] * src[frame(tt,k)]  (block partials + atomics)
+__global__ __launch_bounds__(256) void downsample_bwd_kernel(const float* __restrict__ src,
+                                                             const float* __restrict__ w,
+                                                             const float* __restrict__ g, int ds,
+                                                             int T, int dT, long rowlen,
+                                                             float* __restrict__ d_src,
+                                                             float* __restrict__ dw) {
+  __shared__ float s_dw[8][4];
+  float pw[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) pw[k] = 0.f;
+  const long n = (long)dT * rowlen;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long tt = i / rowlen, e = i - tt * rowlen;
+    const float gv = g[i];
+    float last = 0.f;                                    // contributions landing on frame T-1
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (k < ds) {
+        const long t = (long)tt * ds + k;
+        const long tc = min(t, (long)T - 1);
+        pw[k] = fmaf(gv, src[tc * rowlen + e], pw[k]);
+        if (t < T - 1) d_src[t * rowlen + e] = w[k] * gv;
+        else last = fmaf(w[k], gv, last);
+      }
+    }
+    if ((long)tt * ds + ds - 1 >= T - 1) d_src[(long)(T - 1) * rowlen + e] = last;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float v = wave_sum(pw[k]);
+    if ((threadIdx.x & 63) == 0) s_dw[k][threadIdx.x >> 6] = v;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < ds)
+    atomicAdd(dw + threadIdx.x, (s_dw[threadIdx.x][0] + s_dw[threadIdx.x][1]) +
+                                    (s_dw[threadIdx.x][2] + s_dw[threadIdx.x][3]));
+}
+
+// SimpleUpsample + out_combiner bypass of a downsampled stack (zipformer.py:1253-1283,
+// 1698-1719, 1523-1555): out[t] = orig[t] + (src[t / up] - orig[t]) * scale[c] -- the upsampled
+// tensor is never materialised.  rows of C channels; Bn = rows per frame (batch).
+__global__ __launch_bounds__(256) void bypass_up_fwd_kernel(const float* __restrict__ orig,
+                                                            const float* __restrict__ src,
+                                                            const float* __restrict__ scale,
+                                                            int up, int Bn, long n4, int C4,
+                                                            float* __restrict__ out) {
+  const float4* o4 = reinterpret_cast<const float4*>(orig);
+  const float4* s4 = reinterpret_cast<const float4*>(src);
+  const float4* sc4 = reinterpret_cast<const float4*>(scale);
+  float4* y4 = reinterpret_cast<float4*>(out);
+  const long frame4 = (long)Bn * C4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const long t = i / frame4, e = i - t * frame4;
+    const float4 a = o4[i], v = s4[(t / up) * frame4 + e], k = sc4[e % C4];
+    y4[i] = make_float4(fmaf(v.x - a.x, k.x, a.x), fmaf(v.y - a.y, k.y, a.y),
+                        fmaf(v.z - a.z, k.z, a.z), fmaf(v.w - a.w, k.w, a.w));
+  }
+}
+
+// backward: block = one source frame tt x a slab of its (b) rows; thread = channel
+__global__ __launch_bounds__(256) void bypass_up_bwd_kernel(const float* __restrict__ orig,
+                                                            const float* __restrict__ src,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ g, int up,
+                                                            int T, int Bn, int C,
+                                                            float* __restrict__ d_orig,
+                                                            float* __restrict__ d_src,
+                                                            float* __restrict__ d_scale) {
+  const int tt = blockIdx.x;
+  const int b0 = blockIdx.y * 16, b1 = min(Bn, b0 + 16);
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float k = scale[c];
+    float acc = 0.f;
+    for (int b = b0; b < b1; ++b) {
+      const float sv = src[((long)tt * Bn + b) * C + c];
+      float ds_ = 0.f;
+      for (int u = 0; u < up; ++u) {
+        const long t = (long)tt * up + u;
+        if (t >= T) break;
+        const long i = (t * Bn + b) * C + c;
+        const float gv = g[i];
+        d_orig[i] = gv * (1.f - k);
+        ds_ = fmaf(gv, k, ds_);
+        acc = fmaf(gv, sv - orig[i], acc);
+      }
+      d_src[((long)tt * Bn + b) * C + c] = ds_;
+    }
+    atomicAdd(d_scale + c, acc);
+  }
+}
+
 // u (T,B,3C) = [s | x | y]  ->  xs (B,T,C) = x * tanh(s)
 __global__ __launch_bounds__(256) void nonlin_gate_fwd_kernel(const float* __restrict__ u, int T,
                                                               int B, int C,
@@ -357,6 +468,54 @@ extern "C" int s2t_param_grad_commit_n(int n, const S2tCommit* items, void* stre
   }
   hipLaunchKernelGGL(param_grad_commit_n_kernel, dim3((unsigned)((longest + 255) / 256)), dim3(256),
                      0, (hipStream_t)stream, grp);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int s2t_downsample_fwd(const float* src, const float* w, int ds, int T, int B, int C,
+                                  float* out, void* stream) {
+  if (T <= 0 || B <= 0 || C <= 0) return 0;
+  if (ds < 1 || ds > 8) return -1;
+  const long rowlen = (long)B * C, n_out = (long)((T + ds - 1) / ds) * rowlen;
+  hipLaunchKernelGGL(downsample_fwd_kernel, dim3(grid1(n_out)), dim3(256), 0, (hipStream_t)stream,
+                     src, w, ds, T, rowlen, n_out, out);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int s2t_downsample_bwd(const float* src, const float* w, const float* g, int ds, int T,
+                                  int B, int C, float* d_src, float* dw, void* stream) {
+  if (T <= 0 || B <= 0 || C <= 0) return 0;
+  if (ds < 1 || ds > 8) return -1;
+  const int dT = (T + ds - 1) / ds;
+  const long rowlen = (long)B * C;
+  long blocks = ((long)dT * rowlen + 1023) / 1024;
+  blocks = blocks > 1024 ? 1024 : (blocks < 1 ? 1 : blocks);
+  hipLaunchKernelGGL(downsample_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, src, w, g, ds, T, dT, rowlen, d_src, dw);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int s2t_bypass_up_fwd(const float* orig, const float* src, const float* scale, int up,
+                                 int T, int B, int C, float* out, void* stream) {
+  if (T <= 0 || B <= 0) return 0;
+  if (C <= 0 || (C & 3) || up < 1) return -1;
+  const long n4 = (long)T * B * C / 4;
+  hipLaunchKernelGGL(bypass_up_fwd_kernel, dim3(grid1(n4)), dim3(256), 0, (hipStream_t)stream,
+                     orig, src, scale, up, B, n4, C / 4, out);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int s2t_bypass_up_bwd(const float* orig, const float* src, const float* scale,
+                                 const float* g, int up, int T, int B, int C, float* d_orig,
+                                 float* d_src, float* d_scale, void* stream) {
+  if (T <= 0 || B <= 0) return 0;
+  if (C <= 0 || up < 1) return -1;
+  const int Ts = (T + up - 1) / up;
+  hipLaunchKernelGGL(bypass_up_bwd_kernel, dim3(Ts, (B + 15) / 16), dim3(256), 0,
+                     (hipStream_t)stream, orig, src, scale, g, up, T, B, C, d_orig, d_src, d_scale);
   S2T_CHECK_LAUNCH();
   return 0;
 }

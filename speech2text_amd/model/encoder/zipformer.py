@@ -351,8 +351,10 @@ class DownsampledZipformer2Encoder(nn.Module):
             attn_mask = attn_mask[::ds, ::ds]
         src = self.encoder(src, chunk_size=chunk_size // ds, feature_mask=feature_mask,
                            attn_mask=attn_mask, src_key_padding_mask=src_key_padding_mask)
-        src = self.upsample(src, orig.shape[0])
-        return self.out_combiner(orig, src)
+        # upsample + out_combiner in one pass (the upsampled tensor is never materialised); the
+        # combiner's limit_param_value draw happens here, as in its forward
+        scale = self.out_combiner._get_bypass_scale(src.shape[1])
+        return zk.bypass_upsampled(orig, src, scale, self.upsample.upsample)
 
 
 class RelPositionMultiheadAttentionWeights(nn.Module):

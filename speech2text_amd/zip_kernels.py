@@ -775,7 +775,38 @@ def nonlin_core(u, w0, bal_cfg=None, whiten_mod=None):
     return _NonlinCore.apply(u, w0, bal_cfg, whiten_mod)
 
 
+class _Downsample(torch.autograd.Function):
+    """sum_k w[k] * src[min(tt*ds + k, T-1)]: one pass forward, one pass backward (d_src and the
+    tap gradients; the softmax over the learnable bias stays in autograd)."""
+
+    @staticmethod
+    def forward(ctx, src, w, ds):
+        src = src.contiguous().float()
+        w = w.contiguous().float()
+        T, B, C = src.shape
+        out = torch.empty(((T + ds - 1) // ds, B, C), dtype=torch.float32, device=src.device)
+        N.check(N.lib().s2t_downsample_fwd(N.fp(src), N.fp(w), ds, T, B, C, N.fp(out), N.stream()),
+                "s2t_downsample_fwd")
+        ctx.save_for_backward(src, w)
+        ctx.ds = ds
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        src, w = ctx.saved_tensors
+        T, B, C = src.shape
+        g = g.contiguous().float()
+        d_src = torch.empty_like(src)
+        dw = torch.zeros_like(w)
+        N.check(N.lib().s2t_downsample_bwd(N.fp(src), N.fp(w), N.fp(g), ctx.ds, T, B, C,
+                                           N.fp(d_src), N.fp(dw), N.stream()), "s2t_downsample_bwd")
+        return d_src, dw, None
+
+
 def simple_downsample(src, bias, ds):
+    """SimpleDownsample (reference zipformer.py:1653-1695).  HIP: zip_glue.hip."""
+    if src.is_cuda and src.dim() == 3 and 1 <= ds <= 8:
+        return _Downsample.apply(src, bias.softmax(dim=0), ds)
     T, B, C = src.shape
     dT = (T + ds - 1) // ds
     pad = dT * ds - T
@@ -788,6 +819,48 @@ def simple_downsample(src, bias, ds):
 def simple_upsample(src, up, out_len):
     T, B, C = src.shape
     return src.unsqueeze(1).expand(T, up, B, C).reshape(T * up, B, C)[:out_len]
+
+
+class _BypassUp(torch.autograd.Function):
+    """out[t] = orig[t] + (src[t // up] - orig[t]) * scale: SimpleUpsample + the out_combiner
+    bypass of a downsampled stack without materialising the upsampled tensor."""
+
+    @staticmethod
+    def forward(ctx, orig, src, scale, up):
+        orig, src = orig.contiguous().float(), src.contiguous().float()
+        scale = scale.contiguous().float()
+        T, B, C = orig.shape
+        out = torch.empty_like(orig)
+        N.profile_note("s2t_bypass_up_fwd", 4.0 * (2 * orig.numel() + src.numel()))
+        N.check(N.lib().s2t_bypass_up_fwd(N.fp(orig), N.fp(src), N.fp(scale), up, T, B, C,
+                                          N.fp(out), N.stream()), "s2t_bypass_up_fwd")
+        ctx.save_for_backward(orig, src, scale)
+        ctx.up = up
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        orig, src, scale = ctx.saved_tensors
+        T, B, C = orig.shape
+        g = g.contiguous().float()
+        d_orig, d_src = torch.empty_like(orig), torch.empty_like(src)
+        d_scale = torch.zeros_like(scale)
+        N.profile_note("s2t_bypass_up_bwd", 4.0 * (3 * orig.numel() + 2 * src.numel()))
+        N.check(N.lib().s2t_bypass_up_bwd(N.fp(orig), N.fp(src), N.fp(scale), N.fp(g), ctx.up, T, B,
+                                          C, N.fp(d_orig), N.fp(d_src), N.fp(d_scale), N.stream()),
+                "s2t_bypass_up_bwd")
+        return d_orig, d_src, d_scale, None
+
+
+def bypass_upsampled(orig, src, scale, up):
+    """out_combiner(orig, upsample(src)[:T]) of DownsampledZipformer2Encoder.forward
+    (reference zipformer.py:1253-1283).  HIP: zip_glue.hip."""
+    T = orig.shape[0]
+    if (scale.dim() == 1 and orig.is_cuda and orig.shape[-1] % 4 == 0 and src.shape[1:] == orig.shape[1:]
+            and src.shape[0] == (T + up - 1) // up and orig.data_ptr() % 16 == 0
+            and src.data_ptr() % 16 == 0):
+        return _BypassUp.apply(orig, src, scale, up)
+    return bypass_combine(orig, simple_upsample(src, up, T), scale)
 
 
 # ------------------------------------------------------------------ linear layers

@@ -291,3 +291,42 @@ def test_dwconv2d_and_conv3x3_nhwc_vs_torch(dev, N_, H, W, C, K):
         torch.testing.assert_close(y.detach().cpu().double(), yr.permute(0, 2, 3, 1).detach(), atol=1e-4, rtol=1e-4)
         torch.testing.assert_close(xg.grad.cpu().double(), xr.grad, atol=1e-4, rtol=1e-4)
         torch.testing.assert_close(wg.grad.cpu().double(), wr.grad, atol=2e-3, rtol=2e-4)
+
+
+@pytest.mark.parametrize("T,B,C,ds", [(37, 3, 64, 2), (64, 2, 96, 4), (101, 4, 128, 8), (5, 1, 32, 4)])
+def test_downsample_and_upsampled_bypass_vs_torch(dev, T, B, C, ds):
+    """zip_glue.hip SimpleDownsample and the fused SimpleUpsample + out_combiner bypass against the
+    torch compositions of the reference's formulas (zipformer.py:1653-1719, 1523-1555), fp64."""
+    from speech2text_amd import zip_kernels as zk
+    g = torch.Generator().manual_seed(T)
+    src = torch.randn(T, B, C, generator=g)
+    bias = torch.randn(ds, generator=g)
+    dT = (T + ds - 1) // ds
+    wts = torch.randn(dT, B, C, generator=g)
+    sr, br = src.double().requires_grad_(True), bias.double().requires_grad_(True)
+    pad = dT * ds - T
+    sp = torch.cat((sr, sr[T - 1:].expand(pad, B, C)), dim=0) if pad else sr
+    yr = (sp.reshape(dT, ds, B, C) * br.softmax(0).reshape(1, ds, 1, 1)).sum(dim=1)
+    (yr * wts.double()).sum().backward()
+    sg, bg = src.to(dev).requires_grad_(True), bias.to(dev).requires_grad_(True)
+    y = zk.simple_downsample(sg, bg, ds)
+    (y * wts.to(dev)).sum().backward()
+    torch.testing.assert_close(y.detach().cpu().double(), yr.detach(), atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(sg.grad.cpu().double(), sr.grad, atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(bg.grad.cpu().double(), br.grad, atol=1e-3, rtol=1e-4)
+    # upsample + bypass: orig (T,B,C), low-rate src (dT,B,C)
+    orig = torch.randn(T, B, C, generator=g)
+    low = torch.randn(dT, B, C, generator=g)
+    scale = torch.rand(C, generator=g)
+    w2 = torch.randn(T, B, C, generator=g)
+    o_r, l_r, s_r = (t.double().requires_grad_(True) for t in (orig, low, scale))
+    upr = l_r.unsqueeze(1).expand(dT, ds, B, C).reshape(dT * ds, B, C)[:T]
+    zr = o_r + (upr - o_r) * s_r
+    (zr * w2.double()).sum().backward()
+    o_g, l_g, s_g = (t.to(dev).requires_grad_(True) for t in (orig, low, scale))
+    z = zk.bypass_upsampled(o_g, l_g, s_g, ds)
+    (z * w2.to(dev)).sum().backward()
+    torch.testing.assert_close(z.detach().cpu().double(), zr.detach(), atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(o_g.grad.cpu().double(), o_r.grad, atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(l_g.grad.cpu().double(), l_r.grad, atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(s_g.grad.cpu().double(), s_r.grad, atol=1e-3, rtol=1e-4)
