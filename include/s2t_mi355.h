@@ -90,13 +90,6 @@ int s2t_biasnorm_fwd(const float* x, const float* bias, const float* log_scale, 
                      float* y, float* scales, void* stream);
 int s2t_biasnorm_bwd(const float* x, const float* bias, const float* scales, const float* g,
                      long rows, int D, float* dx, float* dbias, float* dls, void* stream);
-int s2t_col_stats(const float* x, long rows, int C, long ld, float* sum, float* sumsq,
-                  void* stream);
-int s2t_balancer_coef(const float* sum, const float* sumsq, float n, int C, float min_mean,
-                      float max_mean, float min_rms, float max_rms, float grad_scale, float* a,
-                      float* b, void* stream);
-int s2t_balancer_apply(const float* x, long ldx, const float* g, long ldg, const float* a,
-                       const float* b, long rows, int C, float* out, long ldo, void* stream);
 /* The whole Balancer backward (model/layer/scaling.py:741-789) in two launches and no fills:
  * out = g + |g| * (a'[c] + b'[c] x); the column statistics of x are accumulated by the first
  * launch, every workgroup of the second derives the per-channel coefficients from them itself.
@@ -353,8 +346,6 @@ int s2t_bypass_bwd(const float* orig, const float* src, const float* scale, cons
 int s2t_bypass_bwd_acc(const float* orig, const float* src, const float* scale, const float* g,
                        const float* acc_in, long rows, int C, float* d_orig, float* d_src,
                        float* d_scale, void* stream);
-int s2t_param_grad_commit(const float* x, const float* d, float lo, float hi, int limit, long n,
-                          float* grad, void* stream);
 int s2t_attn_delta_pairs(const float* W, const float* dW0, const float* dO1, const float* O1,
                          int dv1, const float* dO2, const float* O2, int dv2, int T, int B, int H,
                          float* delta, void* stream);

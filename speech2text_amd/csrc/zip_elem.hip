@@ -224,52 +224,6 @@ __global__ __launch_bounds__(256) void balancer_apply_fused_kernel(
   }
 }
 
-// g_out[r][c] = g + |g| * (a[c] + b[c]*x)   (in-place allowed: g_out == g)
-__global__ __launch_bounds__(256) void balancer_apply_kernel(
-    const float* __restrict__ x, long ldx, const float* __restrict__ g, long ldg,
-    const float* __restrict__ a, const float* __restrict__ b, long rows, int C,
-    float* __restrict__ out, long ldo) {
-  const long total = rows * C;
-  const long stride = (long)gridDim.x * blockDim.x;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    const long r = i / C;
-    const int c = (int)(i - r * C);
-    const float gv = g[r * ldg + c];
-    out[r * ldo + c] = gv + fabsf(gv) * fmaf(b[c], x[r * ldx + c], a[c]);
-  }
-}
-
-
-// per-channel coefficients of the Balancer gradient term from (sum, sumsq) over n rows:
-//   a' = coef*a, b' = coef*b with loss_grad = a + b*x  (see zip_kernels.balancer_backward)
-__global__ void balancer_coef_kernel(const float* __restrict__ sum, const float* __restrict__ sumsq,
-                                     float n, int C, float min_mean, float max_mean, float min_rms,
-                                     float max_rms, float grad_scale, float* __restrict__ a_out,
-                                     float* __restrict__ b_out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const float inv_n = 1.f / n;
-  const float mean = sum[c] * inv_n, uvar = sumsq[c] * inv_n;
-  const float raw_var = uvar - mean * mean;
-  const bool live_v = raw_var > 1.0e-20f, live_r = uvar > 1.0e-20f;
-  const float var = fmaxf(raw_var, 1.0e-20f);
-  const float sd = sqrtf(var);
-  const float rms = sqrtf(fmaxf(uvar, 1.0e-20f));
-  const float m = mean / sd;
-  const float mc = fminf(fmaxf(m, min_mean), max_mean);
-  const float s_m = (m > mc) ? 1.f : ((m < mc) ? -1.f : 0.f);
-  const float rc = fminf(fmaxf(rms, min_rms), max_rms);
-  const float lq = logf(rc / rms);
-  const float s_r = (lq > 0.f) ? -1.f : ((lq < 0.f) ? 1.f : 0.f);
-  float a = s_m * inv_n * (live_v ? (1.f / sd + mean * mean / (sd * var)) : 1.f / sd);
-  float b = (live_v ? -s_m * inv_n * mean / (sd * var) : 0.f) +
-            (live_r ? s_r * inv_n / (rms * rms) : 0.f);
-  const float lg_rms = fmaxf(sqrtf(fmaxf(a * a + 2.f * a * b * mean + b * b * uvar, 0.f)), 1.0e-20f);
-  const float coef = grad_scale / lg_rms;
-  a_out[c] = a * coef;
-  b_out[c] = b * coef;
-}
-
 inline unsigned grid_for(long n, int per_block) {
   long b = (n + per_block - 1) / per_block;
   if (b > 256 * 16) b = 256 * 16;
@@ -333,30 +287,6 @@ extern "C" int s2t_biasnorm_bwd(const float* x, const float* bias, const float* 
   return 0;
 }
 
-extern "C" int s2t_col_stats(const float* x, long rows, int C, long ld, float* sum, float* sumsq,
-                             void* stream) {
-  if (rows <= 0 || C <= 0) return 0;
-  int gy = (C + 63) / 64;
-  if (gy > 16) gy = 16;
-  long gx = (rows + 4 * 16 - 1) / (4 * 16);
-  if (gx > 1024) gx = 1024;
-  if (gx < 1) gx = 1;
-  hipLaunchKernelGGL(col_stats_kernel, dim3((unsigned)gx, gy), dim3(64, 4), 0,
-                     (hipStream_t)stream, x, rows, C, ld, sum, sumsq);
-  S2T_CHECK_LAUNCH();
-  return 0;
-}
-
-extern "C" int s2t_balancer_apply(const float* x, long ldx, const float* g, long ldg,
-                                  const float* a, const float* b, long rows, int C, float* out,
-                                  long ldo, void* stream) {
-  if (rows <= 0 || C <= 0) return 0;
-  hipLaunchKernelGGL(balancer_apply_kernel, dim3(grid_for(rows * C, 1024)), dim3(256), 0,
-                     (hipStream_t)stream, x, ldx, g, ldg, a, b, rows, C, out, ldo);
-  S2T_CHECK_LAUNCH();
-  return 0;
-}
-
 // workspace: two alternating (sum[C], sumsq[C]) accumulators of 2 * BAL_MAXC floats each
 constexpr int BAL_MAXC = 1024;
 extern "C" long s2t_balancer_bwd_workspace_floats(void) { return 4L * BAL_MAXC; }
@@ -384,13 +314,3 @@ extern "C" int s2t_balancer_bwd(const float* x, long ldx, const float* g, long l
   return 0;
 }
 
-extern "C" int s2t_balancer_coef(const float* sum, const float* sumsq, float n, int C,
-                                 float min_mean, float max_mean, float min_rms, float max_rms,
-                                 float grad_scale, float* a, float* b, void* stream) {
-  if (C <= 0) return 0;
-  hipLaunchKernelGGL(balancer_coef_kernel, dim3((C + 255) / 256), dim3(256), 0,
-                     (hipStream_t)stream, sum, sumsq, n, C, min_mean, max_mean, min_rms, max_rms,
-                     grad_scale, a, b);
-  S2T_CHECK_LAUNCH();
-  return 0;
-}

@@ -75,22 +75,6 @@ __global__ __launch_bounds__(256) void bypass_bwd_acc_kernel(const float* __rest
   }
 }
 
-// grad[e] += d[e], with limit_param_value's sign flip applied to d first when `limit` is set
-__global__ __launch_bounds__(256) void param_grad_commit_kernel(const float* __restrict__ x,
-                                                                const float* __restrict__ d,
-                                                                float lo, float hi, int limit,
-                                                                long n, float* __restrict__ grad) {
-  const long e = (long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= n) return;
-  float v = d[e];
-  if (limit) {
-    const float xv = x[e];
-    if (v > 0.f && xv < lo) v = -v;
-    if (v < 0.f && xv > hi) v = -v;
-  }
-  grad[e] += v;
-}
-
 // delta[h,b,i] = sum_d dO1 O1 + sum_d dO2 O2 (+ sum_j W[0,b,i,j] dW0[b,i,j] for h == 0):
 // the softmax-backward row constants from the deferred consumers; one wave per (h,b,i)
 __global__ __launch_bounds__(256) void attn_delta_pairs_kernel(
@@ -407,15 +391,6 @@ extern "C" int s2t_bypass_bwd_acc(const float* orig, const float* src, const flo
   hipLaunchKernelGGL(bypass_bwd_acc_kernel, dim3((unsigned)((rows + RB - 1) / RB)), dim3(256), 0,
                      (hipStream_t)stream, orig, src, scale, g, acc_in, rows, C, d_orig, d_src,
                      d_scale);
-  S2T_CHECK_LAUNCH();
-  return 0;
-}
-
-extern "C" int s2t_param_grad_commit(const float* x, const float* d, float lo, float hi, int limit,
-                                     long n, float* grad, void* stream) {
-  if (n <= 0) return 0;
-  hipLaunchKernelGGL(param_grad_commit_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, x, d, lo, hi, limit, n, grad);
   S2T_CHECK_LAUNCH();
   return 0;
 }

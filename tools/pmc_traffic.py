@@ -27,7 +27,7 @@ KERNELS = [
     ("zipconv_reduce_w_kernel", "s2t_zipconv_bwd", False),
     ("swoosh_fwd_kernel", "s2t_swoosh_fwd", True), ("swoosh_bwd_kernel", "s2t_swoosh_bwd", True),
     ("biasnorm_fwd_kernel", "s2t_biasnorm_fwd", True), ("biasnorm_bwd_kernel", "s2t_biasnorm_bwd", True),
-    ("col_stats_kernel", "s2t_balancer_bwd", True), ("balancer_apply_kernel", "s2t_balancer_apply", True),
+    ("col_stats_kernel", "s2t_balancer_bwd", True),
     ("balancer_apply_fused_kernel", "s2t_balancer_bwd", False),
     ("bypass_fwd", "s2t_bypass_fwd", True), ("bypass_bwd", "s2t_bypass_bwd", True),
     ("nonlin_gate_fwd", "s2t_nonlin_gate_fwd", True), ("nonlin_out_bwd", "s2t_nonlin_out_bwd", True),
