@@ -6,6 +6,7 @@
 // backward data = the same stencil with the taps flipped; backward weight = per-block
 // partial sums [block][c][KH*KW+1] reduced by a second kernel (no contended atomics).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -118,6 +119,130 @@ __global__ __launch_bounds__(256) void dwconv2d_wgrad_kernel(const float* __rest
   }
 }
 
+// Rolling-window form of the stencil (the one the 7x7 ConvNeXt conv runs on): a thread owns one
+// channel, WO = 7 consecutive output columns and RT consecutive rows.  It keeps the KH x (WO+KW-1)
+// input window in REGISTERS (a ring of KH + RPD rows), and moving down one output row costs one
+// new input row (13 coalesced loads) instead of refetching KH rows through the cache; that row is
+// requested RPD steps before it is used, so ~4 rows of loads are in flight per wave -- with one
+// row in flight the kernel ran at the latency-bound 620 us of its predecessors (bytes in flight,
+// not FMAs or bandwidth, were the limit: 8 waves/CU x 13 x 256 B against ~2 us of latency).
+//   MODE 0: y = conv(x)   MODE 1: taps flipped (= backward data)
+//   MODE 2: weight / bias gradient partials of (x, dy), part[c-tile][block][tap | bias][64]
+__device__ float g_zero[256];   // zero-initialised: the padding taps of the stencil read it
+
+constexpr int RWO = 7;    // output columns per thread
+constexpr int RPD = 3;    // input rows requested ahead of use (memory latency / time per row step)
+constexpr int RRT = 30;   // output rows per thread (multiple of the ring length KH + RPD)
+constexpr int RCT = 128;  // channels per workgroup
+
+template <int KH, int KW, int MODE>
+__global__ __launch_bounds__(256) void dwconv2d_roll_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ wgt,
+                                                            const float* __restrict__ bias,
+                                                            const float* __restrict__ dy, int N,
+                                                            int H, int W, int C, int nparts,
+                                                            int nrr, float* __restrict__ out) {
+  constexpr int RING = KH + RPD;
+  static_assert(RRT % RING == 0, "row range must be a multiple of the ring length");
+  constexpr int PH = KH / 2, PW = KW / 2, WW = RWO + KW - 1, NV = KH * KW + 1;
+  // RCT channels per workgroup: sibling waves read the neighbouring 256-byte pieces of the same
+  // pixels at the same time
+  const int c0 = blockIdx.z * RCT, c = threadIdx.x % RCT, n = blockIdx.y;
+  const int q = blockIdx.x * (256 / RCT) + (threadIdx.x / RCT);
+  const int part = q % nparts, rr = q / nparts;
+  const bool live = c0 + c < C && rr < nrr;
+  const int cc = (c0 + c < C) ? c0 + c : 0;
+  const int w0 = part * RWO, hs = rr * RRT, he = min(H, hs + RRT);
+  float wv[KH * KW];          // MODE 0/1: taps; MODE 2: tap-gradient accumulators
+  float bacc = 0.f;
+#pragma unroll
+  for (int k = 0; k < KH * KW; ++k)
+    wv[k] = (MODE == 2) ? 0.f : wgt[(long)cc * KH * KW + (MODE == 1 ? KH * KW - 1 - k : k)];
+  const float bv = (MODE != 2 && bias) ? bias[cc] : 0.f;
+  const float* xn = x + (long)n * H * W * C;
+  float win[RING][WW];     // ring of input rows: slot (k + i) % RING holds row hs - PH + k + i
+  // Out-of-range taps read a zero word instead of being patched after the load: the address
+  // choice is wave-uniform (scalar), and nothing has to wait for the loaded value until the FMAs
+  // that use it, RPD steps later.
+  auto load_row = [&](float (&dst)[WW], int hin) {
+    const bool rv = hin >= 0 && hin < H;
+    const float* row = xn + (long)hin * W * C;
+#pragma unroll
+    for (int v = 0; v < WW; ++v) {
+      const int ww = w0 + v - PW;
+      const float* p = (rv && ww >= 0 && ww < W) ? row + (long)ww * C : g_zero;
+      dst[v] = p[cc];
+    }
+  };
+  if (live) {
+#pragma unroll
+    for (int s = 0; s < RING - 1; ++s) load_row(win[s], hs - PH + s);
+    for (int k0 = 0; hs + k0 < he; k0 += RING) {
+#pragma unroll
+      for (int u = 0; u < RING; ++u) {
+        const int h = hs + k0 + u;
+        if (h < he) {                                   // uniform per wave
+          // request the row that is needed RPD steps from now into the slot the oldest row left:
+          // RPD + 1 rows of loads are in flight while a step's FMAs run
+          load_row(win[(u + RING - 1) % RING], h + PH + RPD);
+          if (MODE != 2) {
+            float acc[RWO];
+#pragma unroll
+            for (int o = 0; o < RWO; ++o) acc[o] = bv;
+#pragma unroll
+            for (int i = 0; i < KH; ++i)
+#pragma unroll
+              for (int j = 0; j < KW; ++j)
+#pragma unroll
+                for (int o = 0; o < RWO; ++o)
+                  acc[o] = fmaf(wv[i * KW + j], win[(u + i) % RING][o + j], acc[o]);
+            float* yr = out + (((long)n * H + h) * W + w0) * C + cc;
+#pragma unroll
+            for (int o = 0; o < RWO; ++o)
+              if (w0 + o < W) yr[(long)o * C] = acc[o];
+          } else {
+            float g[RWO];
+            const float* gr = dy + (((long)n * H + h) * W + w0) * C + cc;
+#pragma unroll
+            for (int o = 0; o < RWO; ++o) {
+              g[o] = (w0 + o < W) ? gr[(long)min(o, W - 1 - w0) * C] : 0.f;
+              bacc += g[o];
+            }
+#pragma unroll
+            for (int i = 0; i < KH; ++i)
+#pragma unroll
+              for (int j = 0; j < KW; ++j)
+#pragma unroll
+                for (int o = 0; o < RWO; ++o)
+                  wv[i * KW + j] = fmaf(g[o], win[(u + i) % RING][o + j], wv[i * KW + j]);
+          }
+        }
+      }
+    }
+  }
+  if (MODE == 2) {
+    // partial layout [64-channel tile][block][slot][64]; a workgroup covers RCT / 64 tiles
+    __shared__ float s_red[256 / RCT][RCT];
+    const int r = threadIdx.x / RCT;
+    const long nblk = (long)gridDim.y * gridDim.x;
+    const long blk = (long)blockIdx.y * gridDim.x + blockIdx.x;
+    const long tile = (long)blockIdx.z * (RCT / 64) + c / 64;
+    float* dst = out + ((tile * nblk + blk) * NV) * 64 + (c & 63);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      __syncthreads();
+      s_red[r][c] = live ? (k < NV - 1 ? wv[k < NV - 1 ? k : 0] : bacc) : 0.f;
+      __syncthreads();
+      if (r == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int rr2 = 0; rr2 < 256 / RCT; ++rr2) t += s_red[rr2][c];
+        dst[k * 64] = t;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void dwconv2d_wreduce_kernel(const float* __restrict__ part,
                                                                int nblk, int C, int NV,
                                                                float* __restrict__ dw,
@@ -148,8 +273,12 @@ extern "C" int s2t_dwconv2d_nhwc_fwd(const float* x, const float* wgt, const flo
   dim3 grid((H + TH - 1) / TH, N, (C + 63) / 64);
   hipStream_t st = (hipStream_t)stream;
   if (KH == 7 && KW == 7) {
-    if (flip) hipLaunchKernelGGL((dwconv2d_kernel<7, 7, true>), grid, dim3(256), 0, st, x, wgt, bias, N, H, W, C, y);
-    else hipLaunchKernelGGL((dwconv2d_kernel<7, 7, false>), grid, dim3(256), 0, st, x, wgt, bias, N, H, W, C, y);
+    const int nparts = (W + RWO - 1) / RWO, nrr = (H + RRT - 1) / RRT;
+    constexpr int CPB = 256 / RCT;
+    dim3 gr((nparts * nrr + CPB - 1) / CPB, N, (C + RCT - 1) / RCT);
+    const float* nf = nullptr;
+    if (flip) hipLaunchKernelGGL((dwconv2d_roll_kernel<7, 7, 1>), gr, dim3(256), 0, st, x, wgt, bias, nf, N, H, W, C, nparts, nrr, y);
+    else hipLaunchKernelGGL((dwconv2d_roll_kernel<7, 7, 0>), gr, dim3(256), 0, st, x, wgt, bias, nf, N, H, W, C, nparts, nrr, y);
   } else if (KH == 3 && KW == 3) {
     if (flip) hipLaunchKernelGGL((dwconv2d_kernel<3, 3, true>), grid, dim3(256), 0, st, x, wgt, bias, N, H, W, C, y);
     else hipLaunchKernelGGL((dwconv2d_kernel<3, 3, false>), grid, dim3(256), 0, st, x, wgt, bias, N, H, W, C, y);
@@ -169,11 +298,25 @@ extern "C" int s2t_dwconv2d_nhwc_wgrad(const float* x, const float* dy, int N, i
                                        int KH, int KW, float* workspace, float* dw, float* db,
                                        void* stream) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int nparts = (W + RWO - 1) / RWO, nrr = (H + RRT - 1) / RRT;
+  // (the workspace is sized for (H + 7) / 8 partial blocks per (n, c-tile): holds for W <= 98)
+  constexpr int CPB = 256 / RCT;
+  if (KH == 7 && KW == 7 && (nparts * nrr + CPB - 1) / CPB <= (H + 7) / 8) {
+    dim3 gr((nparts * nrr + CPB - 1) / CPB, N, (C + RCT - 1) / RCT);
+    const float* nf = nullptr;
+    hipLaunchKernelGGL((dwconv2d_roll_kernel<7, 7, 2>), gr, dim3(256), 0, st, x, nf, nf, dy, N, H, W,
+                       C, nparts, nrr, workspace);
+    S2T_CHECK_LAUNCH();
+    hipLaunchKernelGGL(dwconv2d_wreduce_kernel, dim3((C + 63) / 64, KH * KW + 1), dim3(256), 0, st,
+                       workspace, (int)(gr.x * gr.y), C, KH * KW + 1, dw, db);
+    S2T_CHECK_LAUNCH();
+    return 0;
+  }
   // ~1000 workgroups: enough to fill the chip, few enough that the partial sums stay small
   int rows_per_blk = (int)(((long)H * N * ((C + 63) / 64) + 1023) / 1024);
   rows_per_blk = rows_per_blk < 8 ? 8 : ((rows_per_blk + 3) / 4) * 4;
   dim3 grid((H + rows_per_blk - 1) / rows_per_blk, N, (C + 63) / 64);
-  hipStream_t st = (hipStream_t)stream;
   if (KH == 7 && KW == 7)
     hipLaunchKernelGGL((dwconv2d_wgrad_kernel<7, 7>), grid, dim3(256), 0, st, x, dy, N, H, W, C, rows_per_blk, workspace);
   else if (KH == 3 && KW == 3)
