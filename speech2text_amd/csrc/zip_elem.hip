@@ -6,6 +6,7 @@
 // :347-399 (BiasNormFunction), :741-789 (BalancerFunction.backward, closed form
 // derived in DESIGN.md), :1559-1578 (activation derivative recomputed in backward).
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -106,26 +107,43 @@ __global__ __launch_bounds__(256) void biasnorm_bwd_kernel(
     db[j] = 0.f;
   }
   float dl = 0.f;
-  for (long row = wave; row < rows; row += nwaves) {
+  // two rows per trip: both rows' loads are issued before either reduction (a wave that walks one
+  // row at a time sits through a full memory round trip per row)
+  for (long row = wave; row < rows; row += 2 * nwaves) {
+    const long row2 = row + nwaves;
+    const bool has2 = row2 < rows;
     const float* xr = x + row * D;
     const float* gr = g + row * D;
-    float xv[CPL], gv[CPL];
-    float A = 0.f, ss = 0.f;
+    const float* xr2 = x + (has2 ? row2 : row) * D;
+    const float* gr2 = g + (has2 ? row2 : row) * D;
+    float xv[CPL], gv[CPL], xw[CPL], gw[CPL];
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
       const int c = lane + 64 * j;
       xv[j] = c < D ? xr[c] : 0.f;
       gv[j] = c < D ? gr[c] : 0.f;
+      xw[j] = c < D ? xr2[c] : 0.f;
+      gw[j] = c < D ? gr2[c] : 0.f;
+    }
+    float A = 0.f, ss = 0.f, A2 = 0.f, ss2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const int c = lane + 64 * j;
       A = fmaf(gv[j], xv[j], A);
-      const float d = c < D ? xv[j] - b[j] : 0.f;
+      A2 = fmaf(gw[j], xw[j], A2);
+      const float d = c < D ? xv[j] - b[j] : 0.f, d2 = c < D ? xw[j] - b[j] : 0.f;
       ss = fmaf(d, d, ss);
+      ss2 = fmaf(d2, d2, ss2);
     }
     A = wave_sum(A);
     ss = wave_sum(ss);
-    const float s = scales[row];
-    const float coef = s * A / ss;  // ss = D*ms
-    dl += A * s;
+    A2 = wave_sum(A2);
+    ss2 = wave_sum(ss2);
+    const float s = scales[row], s2 = has2 ? scales[row2] : 0.f;
+    const float coef = s * A / ss, coef2 = has2 ? s2 * A2 / ss2 : 0.f;   // ss = D*ms
+    dl += A * s + (has2 ? A2 * s2 : 0.f);
     float* dr = dx + row * D;
+    float* dr2 = dx + row2 * D;
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
       const int c = lane + 64 * j;
@@ -133,15 +151,33 @@ __global__ __launch_bounds__(256) void biasnorm_bwd_kernel(
         const float t = coef * (xv[j] - b[j]);
         dr[c] = s * gv[j] - t;
         db[j] += t;
+        if (has2) {
+          const float t2 = coef2 * (xw[j] - b[j]);
+          dr2[c] = s2 * gw[j] - t2;
+          db[j] += t2;
+        }
       }
     }
   }
+  // one atomic per column per WORKGROUP (the four waves add up through LDS first): every atomic
+  // of this pass lands on the same D addresses, so their count is what the tail costs
+  __shared__ float s_db[4][64 * CPL];
+  __shared__ float s_dl[4];
+  const int wv = threadIdx.x >> 6;
 #pragma unroll
-  for (int j = 0; j < CPL; ++j) {
-    const int c = lane + 64 * j;
-    if (c < D && db[j] != 0.f) atomicAdd(&dbias[c], db[j]);
+  for (int j = 0; j < CPL; ++j) s_db[wv][lane + 64 * j] = db[j];
+  if (lane == 0) s_dl[wv] = dl;              // dl is wave-uniform (built from wave sums)
+  __syncthreads();
+  if (wv == 0) {
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const int c = lane + 64 * j;
+      const float t = (s_db[0][c] + s_db[1][c]) + (s_db[2][c] + s_db[3][c]);
+      if (c < D && t != 0.f) atomicAdd(&dbias[c], t);
+    }
+    const float tl = (s_dl[0] + s_dl[1]) + (s_dl[2] + s_dl[3]);
+    if (lane == 0 && tl != 0.f) atomicAdd(dls, tl);
   }
-  if (lane == 0 && dl != 0.f) atomicAdd(dls, dl);
 }
 
 // ---------------------------------------------------------------- column statistics
@@ -155,7 +191,20 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict_
     const int c = c0 + threadIdx.x;
     float s = 0.f, q = 0.f;
     if (c < C) {
-      for (long r = (long)blockIdx.x * 4 + threadIdx.y; r < rows; r += (long)gridDim.x * 4) {
+      // 8 row loads in flight per thread: the pass is latency-bound otherwise
+      const long step = (long)gridDim.x * 4;
+      long r = (long)blockIdx.x * 4 + threadIdx.y;
+      for (; r + 7 * step < rows; r += 8 * step) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = x[(r + u * step) * ld + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          s += v[u];
+          q = fmaf(v[u], v[u], q);
+        }
+      }
+      for (; r < rows; r += step) {
         const float v = x[r * ld + c];
         s += v;
         q = fmaf(v, v, q);
@@ -265,7 +314,7 @@ extern "C" int s2t_biasnorm_bwd(const float* x, const float* bias, const float* 
                                 float* dls, void* stream) {
   if (rows <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  const unsigned nb = grid_for(rows, 4 * 8);
+  const unsigned nb = std::min(grid_for(rows, 4 * 8), 1024u);
   if (D <= 64)
     hipLaunchKernelGGL(biasnorm_bwd_kernel<1>, dim3(nb), dim3(256), 0, st, x, bias, scales, g,
                        rows, D, dx, dbias, dls);
@@ -303,7 +352,7 @@ extern "C" int s2t_balancer_bwd(const float* x, long ldx, const float* g, long l
   int gy = (C + 63) / 64;
   if (gy > 16) gy = 16;
   long gx = (rows + 4 * 16 - 1) / (4 * 16);
-  gx = gx > 1024 ? 1024 : (gx < 1 ? 1 : gx);
+  gx = gx > 256 ? 256 : (gx < 1 ? 1 : gx);
   hipLaunchKernelGGL(col_stats_kernel, dim3((unsigned)gx, gy), dim3(64, 4), 0, st, x, rows, C, ldx,
                      cur, cur + BAL_MAXC);
   S2T_CHECK_LAUNCH();

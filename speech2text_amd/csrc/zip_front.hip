@@ -338,31 +338,34 @@ namespace {
 __global__ __launch_bounds__(256) void col2im3x3_kernel(const float* __restrict__ dc, int B, int H,
                                                         int W, int C, int Ho, int Wo, int sh,
                                                         int sw, float* __restrict__ dx) {
-  const long total = (long)B * H * W * C;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int c = (int)(i % C);
-    long r = i / C;
-    const int w = (int)(r % W);
-    r /= W;
-    const int h = (int)(r % H);
-    const int b = (int)(r / H);
+  // one workgroup per (h, b) row of dx: the row part of the patch arithmetic is wave-uniform,
+  // the rest is 32-bit (64-bit divisions per element were what this pass spent its time on)
+  const int h = blockIdx.x, b = blockIdx.y;
+  int ho[3];
+  bool hv[3];
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const int hh = h - kh;
+    hv[kh] = hh >= 0 && hh % sh == 0 && hh / sh < Ho;
+    ho[kh] = hv[kh] ? hh / sh : 0;
+  }
+  float* row = dx + ((long)b * H + h) * W * C;
+  const int n = W * C;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int w = i / C, c = i - w * C;
     float acc = 0.f;
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-      const int hh = h - kh;
-      if (hh < 0 || hh % sh) continue;
-      const int ho = hh / sh;
-      if (ho >= Ho) continue;
+    for (int kw = 0; kw < 3; ++kw) {
+      const int ww = w - kw;
+      if (ww < 0 || ww % sw) continue;
+      const int wo = ww / sw;
+      if (wo >= Wo) continue;
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const int ww = w - kw;
-        if (ww < 0 || ww % sw) continue;
-        const int wo = ww / sw;
-        if (wo >= Wo) continue;
-        acc += dc[((((long)b * Ho + ho) * Wo + wo) * 9 + kh * 3 + kw) * C + c];
-      }
+      for (int kh = 0; kh < 3; ++kh)
+        if (hv[kh])
+          acc += dc[((((long)b * Ho + ho[kh]) * Wo + wo) * 9 + kh * 3 + kw) * C + c];
     }
-    dx[i] = acc;
+    row[i] = acc;
   }
 }
 
@@ -372,11 +375,8 @@ extern "C" int s2t_col2im3x3_nhwc(const float* dc, int B, int H, int W, int C, i
                                   int sh, int sw, float* dx, void* stream) {
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
   if (sh <= 0 || sw <= 0 || Ho != (H - 3) / sh + 1 || Wo != (W - 3) / sw + 1) return -1;
-  const long total = (long)B * H * W * C;
-  long blocks = (total + 1023) / 1024;
-  blocks = blocks > 8192 ? 8192 : (blocks < 1 ? 1 : blocks);
-  hipLaunchKernelGGL(col2im3x3_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                     dc, B, H, W, C, Ho, Wo, sh, sw, dx);
+  hipLaunchKernelGGL(col2im3x3_kernel, dim3(H, B), dim3(256), 0, (hipStream_t)stream, dc, B, H, W,
+                     C, Ho, Wo, sh, sw, dx);
   S2T_CHECK_LAUNCH();
   return 0;
 }

@@ -39,7 +39,26 @@ __global__ __launch_bounds__(256) void bypass_bwd_kernel(const float* __restrict
   for (int c = threadIdx.x; c < C; c += 256) {
     const float k = scale[c];
     float acc = 0.f;
-    for (long r = r0; r < r1; ++r) {
+    long r = r0;
+    for (; r + 3 < r1; r += 4) {                         // 12 loads in flight per thread
+      float gq[4], sq[4], oq[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long i = (r + u) * C + c;
+        gq[u] = g[i];
+        sq[u] = src[i];
+        oq[u] = orig[i];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long i = (r + u) * C + c;
+        const float ds = gq[u] * k;
+        d_src[i] = ds;
+        d_orig[i] = gq[u] - ds;
+        acc = fmaf(gq[u], sq[u] - oq[u], acc);
+      }
+    }
+    for (; r < r1; ++r) {
       const long i = r * C + c;
       const float gv = g[i], ds = gv * k;
       d_src[i] = ds;
@@ -64,7 +83,27 @@ __global__ __launch_bounds__(256) void bypass_bwd_acc_kernel(const float* __rest
   for (int c = threadIdx.x; c < C; c += 256) {
     const float k = scale[c];
     float acc = 0.f;
-    for (long r = r0; r < r1; ++r) {
+    long r = r0;
+    for (; r + 3 < r1; r += 4) {
+      float gq[4], sq[4], oq[4], aq[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long i = (r + u) * C + c;
+        gq[u] = g[i];
+        sq[u] = src[i];
+        oq[u] = orig[i];
+        aq[u] = acc_in[i];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long i = (r + u) * C + c;
+        const float ds = gq[u] * k;
+        d_src[i] = ds;
+        d_orig[i] = gq[u] - ds + aq[u];
+        acc = fmaf(gq[u], sq[u] - oq[u], acc);
+      }
+    }
+    for (; r < r1; ++r) {
       const long i = r * C + c;
       const float gv = g[i], ds = gv * k;
       d_src[i] = ds;
@@ -142,7 +181,26 @@ __global__ __launch_bounds__(256) void bypass_bwd_mask_kernel(const float* __res
   for (int c = threadIdx.x; c < C; c += 256) {
     const float k = scale[c];
     float acc = 0.f;
-    for (long r = r0; r < r1; ++r) {
+    long r = r0;
+    for (; r + 3 < r1; r += 4) {
+      float gq[4], sq[4], oq[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long i = (r + u) * C + c;
+        gq[u] = g[i] * fm[((r + u) % B) * C + c];
+        sq[u] = src[i];
+        oq[u] = orig[i];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long i = (r + u) * C + c;
+        const float ds = gq[u] * k;
+        d_src[i] = ds;
+        d_orig[i] = gq[u] - ds;
+        acc = fmaf(gq[u], sq[u] - oq[u], acc);
+      }
+    }
+    for (; r < r1; ++r) {
       const long i = r * C + c;
       const float gv = g[i] * fm[(r % B) * C + c], ds = gv * k;
       d_src[i] = ds;

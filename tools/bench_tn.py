@@ -8,7 +8,12 @@ import torch  # noqa: E402
 
 from tools.bench_gemm import dev, gemm, timeit  # noqa: E402
 
-SHAPES = [(31680, 192, 384), (31680, 192, 640), (31680, 512, 192), (31680, 192, 272),
+if os.environ.get("TN_SHAPES") == "sym":      # Whiten statistics: x^T x
+    SHAPES_ = [(31680, 192, 192), (31680, 144, 144), (31680, 128, 128), (15872, 256, 256), (15872, 192, 192),
+               (7936, 256, 256), (3968, 256, 256)]
+else:
+    SHAPES_ = None
+SHAPES = SHAPES_ or [(31680, 192, 384), (31680, 192, 640), (31680, 512, 192), (31680, 192, 272),
           (31680, 192, 48), (15872, 256, 768), (15872, 960, 256), (15872, 256, 272),
           (7936, 256, 768), (3968, 768, 256)]
 tag = f"tile={os.environ.get('S2T_TN_TILE', 'auto')} blocks={os.environ.get('S2T_TN_BLOCKS', '512')}"
