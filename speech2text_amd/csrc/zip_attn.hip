@@ -1068,19 +1068,24 @@ __global__ __launch_bounds__(256) void attn_apply_kernel(const float* __restrict
   float acc0[4] = {0.f, 0.f, 0.f, 0.f}, acc1[4] = {0.f, 0.f, 0.f, 0.f};
   for (int c0 = 0; c0 < T; c0 += CT) {
     __syncthreads();
-    if (!TRANS) {
-      // rows = outputs i (o0..), cols = contraction j (c0..)
-      for (int idx = tid; idx < RT * CT; idx += 256) {
-        const int r = idx / CT, cc = idx % CT;
-        const int i = o0 + r, j = c0 + cc;
-        s_W[r][cc] = (i < T && j < T) ? Wb[(long)i * T + j] : 0.f;
+    // W tile: 8 loads per thread in flight (clamped addresses, validity applied on the LDS store);
+    // one conditional load per trip serialises into a memory round trip each
+    constexpr int WROW = TRANS ? RT : CT;              // tile row length in LDS
+    for (int base = 0; base < RT * CT; base += 256 * 8) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + u * 256 + tid;
+        const int r = idx / WROW, cc = idx % WROW;
+        const int i = TRANS ? c0 + r : o0 + r, j = TRANS ? o0 + cc : c0 + cc;
+        t[u] = Wb[(long)min(i, T - 1) * T + min(j, T - 1)];
       }
-    } else {
-      // contraction over i (c0..) rows of W, outputs j (o0..) along the row
-      for (int idx = tid; idx < CT * RT; idx += 256) {
-        const int r = idx / RT, cc = idx % RT;
-        const int i = c0 + r, j = o0 + cc;
-        s_W[r][cc] = (i < T && j < T) ? Wb[(long)i * T + j] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + u * 256 + tid;
+        const int r = idx / WROW, cc = idx % WROW;
+        const int i = TRANS ? c0 + r : o0 + r, j = TRANS ? o0 + cc : c0 + cc;
+        s_W[r][cc] = (i < T && j < T) ? t[u] : 0.f;
       }
     }
     for (int idx = tid; idx < CT * dv; idx += 256) {
