@@ -50,17 +50,44 @@ struct ConvArgs {
 template <int K>
 __device__ __forceinline__ void stage_weights(const ConvArgs& a, int c0, float* s_wc, float* s_wk,
                                               float* s_le, float* s_re) {
+  // all of a thread's tap loads are issued back to back from clamped (always valid) addresses;
+  // validity is applied on the LDS store (loads behind per-lane conditions serialise)
   constexpr int Kh = (K + 1) / 2;
-  for (int i = threadIdx.x; i < 64 * K; i += 256) {
-    const int c = i / K, j = i % K;
-    const bool ok = c0 + c < a.C;
-    s_wk[j * 64 + c] = ok ? a.wk[(long)(c0 + c) * K + j] : 0.f;
-    s_le[j * 64 + c] = (ok && a.scale) ? a.scale[(long)(c0 + c) * K + j] : 0.f;
-    s_re[j * 64 + c] = (ok && a.scale) ? a.scale[((long)a.C + c0 + c) * K + j] : 0.f;
+  constexpr int NI = (64 * K + 255) / 256, NH = (64 * Kh + 255) / 256;
+  const bool sc = a.scale != nullptr;
+  float wk[NI], le[NI], re[NI], wc[NH];
+#pragma unroll
+  for (int q = 0; q < NI; ++q) {
+    const int i = min((int)threadIdx.x + 256 * q, 64 * K - 1);
+    const int c = min(c0 + i / K, a.C - 1), j = i % K;
+    wk[q] = a.wk[(long)c * K + j];
+    le[q] = sc ? a.scale[(long)c * K + j] : 0.f;
+    re[q] = sc ? a.scale[((long)a.C + c) * K + j] : 0.f;
   }
-  for (int i = threadIdx.x; i < 64 * Kh; i += 256) {
-    const int c = i / Kh, j = i % Kh;
-    s_wc[j * 64 + c] = (a.wc && c0 + c < a.C) ? a.wc[(long)(c0 + c) * Kh + j] : 0.f;
+#pragma unroll
+  for (int q = 0; q < NH; ++q) {
+    const int i = min((int)threadIdx.x + 256 * q, 64 * Kh - 1);
+    const int c = min(c0 + i / Kh, a.C - 1), j = i % Kh;
+    wc[q] = a.wc ? a.wc[(long)c * Kh + j] : 0.f;
+  }
+#pragma unroll
+  for (int q = 0; q < NI; ++q) {
+    const int i = threadIdx.x + 256 * q;
+    if (i < 64 * K) {
+      const int c = i / K, j = i % K;
+      const bool ok = c0 + c < a.C;
+      s_wk[j * 64 + c] = ok ? wk[q] : 0.f;
+      s_le[j * 64 + c] = ok ? le[q] : 0.f;
+      s_re[j * 64 + c] = ok ? re[q] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NH; ++q) {
+    const int i = threadIdx.x + 256 * q;
+    if (i < 64 * Kh) {
+      const int c = i / Kh, j = i % Kh;
+      s_wc[j * 64 + c] = (c0 + c < a.C) ? wc[q] : 0.f;
+    }
   }
 }
 
@@ -281,7 +308,7 @@ __global__ __launch_bounds__(256) void zipconv_bwd_data_kernel(ConvArgs a,
 }
 
 // weight / bias gradients; block = (t-tile, group of BB utterances, c-tile).  Each block
-// writes its partial sums to part[block][c][NV] (NV = Kh + 1 + K + 1); zipconv_reduce_w_kernel
+// writes its partial sums to part[block][NV][64 ch] (NV = Kh + 1 + K + 1); zipconv_reduce_w_kernel
 // sums over blocks -- no atomics (contended float atomics on a few KB run ~14x slower).
 template <int K, bool GEN>
 __global__ __launch_bounds__(256) void zipconv_bwd_w_kernel(ConvArgs a,
@@ -393,12 +420,12 @@ __global__ __launch_bounds__(256) void zipconv_bwd_w_kernel(ConvArgs a,
   }
   // reduce the 4 frame groups of each channel through LDS, then one store per value
   const long blk = ((long)blockIdx.x * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z;
-  float* dst = part + (blk * 64 + c) * NV;
+  float* dst = part + blk * NV * 64 + c;          // [block][slot][64 channels]: coalesced stores
   auto reduce_store = [&](float v, int slot) {
     __syncthreads();
     s_red[tg * 64 + c] = v;
     __syncthreads();
-    if (tg == 0) dst[slot] = s_red[c] + s_red[64 + c] + s_red[128 + c] + s_red[192 + c];
+    if (tg == 0) dst[slot * 64] = s_red[c] + s_red[64 + c] + s_red[128 + c] + s_red[192 + c];
   };
 #pragma unroll
   for (int j = 0; j < Kh; ++j) reduce_store(pwc[j], j);
@@ -408,24 +435,33 @@ __global__ __launch_bounds__(256) void zipconv_bwd_w_kernel(ConvArgs a,
   reduce_store(pbk, Kh + 1 + K);
 }
 
-// out[c][slot] = sum over the (t-tile, b-group) blocks of part.  One workgroup per channel:
-// thread = (slot = tid & 63, k-group = tid >> 6); rows of NV floats are read contiguously.
+// out[c][slot] = sum over the (t-tile, b-group) blocks of part.  Grid (c tiles, slots); thread =
+// (channel, block group): every read is a 256-byte row of 64 channels.
 __global__ __launch_bounds__(256) void zipconv_reduce_w_kernel(
     const float* __restrict__ part, int nblk_per_ctile, int C, int Kh, int K,
     float* __restrict__ dwc, float* __restrict__ dbc, float* __restrict__ dwk,
     float* __restrict__ dbk) {
   __shared__ float s_red[4][64];
   const int NV = Kh + K + 2;
-  const int cg = blockIdx.x, ct = cg >> 6, c = cg & 63;
-  const int slot = threadIdx.x & 63, kg = threadIdx.x >> 6;
+  const int ct = blockIdx.x, slot = blockIdx.y;
+  const int c = threadIdx.x & 63, kg = threadIdx.x >> 6;
   float s = 0.f;
-  if (slot < NV)
-    for (int k = kg; k < nblk_per_ctile; k += 4)
-      s += part[(((long)ct * nblk_per_ctile + k) * 64 + c) * NV + slot];
-  s_red[kg][slot] = s;
+  const float* base = part + ((long)ct * nblk_per_ctile * NV + slot) * 64 + c;
+  const long stride = (long)NV * 64;
+  int k = kg;
+  for (; k + 28 < nblk_per_ctile; k += 32) {           // 8 loads in flight per thread
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = base[(k + 4 * u) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += t[u];
+  }
+  for (; k < nblk_per_ctile; k += 4) s += base[k * stride];
+  s_red[kg][c] = s;
   __syncthreads();
-  if (kg == 0 && slot < NV) {
-    s = s_red[0][slot] + s_red[1][slot] + s_red[2][slot] + s_red[3][slot];
+  const int cg = ct * 64 + c;
+  if (kg == 0 && cg < C) {
+    s = s_red[0][c] + s_red[1][c] + s_red[2][c] + s_red[3][c];
     if (slot < Kh) {
       if (dwc) dwc[(long)cg * Kh + slot] += s;
     } else if (slot == Kh) {
@@ -521,8 +557,8 @@ extern "C" int s2t_zipconv_bwd(const float* u, long ld, int gate_off, const unsi
                                             (scale && dscale) ? dscale : nullptr));
   }
   S2T_CHECK_LAUNCH();
-  hipLaunchKernelGGL(zipconv_reduce_w_kernel, dim3(C), dim3(256), 0, st, workspace,
-                     (int)(gridw.z * gridw.y), C, (K + 1) / 2, K, wc ? dwc : nullptr,
+  hipLaunchKernelGGL(zipconv_reduce_w_kernel, dim3((C + 63) / 64, (K + 1) / 2 + K + 2), dim3(256), 0,
+                     st, workspace, (int)(gridw.z * gridw.y), C, (K + 1) / 2, K, wc ? dwc : nullptr,
                      wc ? dbc : nullptr, dwk, dbk);
   S2T_CHECK_LAUNCH();
   return 0;
