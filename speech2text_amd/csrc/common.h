@@ -43,6 +43,17 @@ __device__ __forceinline__ float log_add_precise(float a, float b) {
   return m + log1pf(expf(d));
 }
 
+// log(exp(a)+exp(b)) on the hardware exp / log with the rounding of 1 + e compensated
+// (log1p(e) = log(u) * e / (u - 1), u = fl(1 + e)): ~15 instructions instead of libm's ~70.  For the
+// lattice recursions, whose single wave per utterance pays every dependent instruction's latency.
+__device__ __forceinline__ float log_add_comp(float a, float b) {
+  const float m = fmaxf(a, b);
+  if (m == S2T_NEG_INF) return S2T_NEG_INF;
+  const float e = __expf(fminf(a, b) - m);      // in [0, 1]
+  const float u = 1.f + e;
+  return m + (u == 1.f ? e : __logf(u) * __fdividef(e, u - 1.f));
+}
+
 // block-wide sum via LDS scratch (>= blockDim/64 floats); all threads get it.
 __device__ __forceinline__ float block_sum(float v, float* scratch) {
   v = wave_sum(v);

@@ -98,8 +98,8 @@ void tune(Plan& p, const float* X, const float* W, const float* C, float beta, l
   float* scratch = nullptr;
   if (hipMalloc(&scratch, (size_t)d_elems * sizeof(float)) != hipSuccess) return;
   hipEvent_t e0, e1;
-  hipEventCreate(&e0);
-  hipEventCreate(&e1);
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
   const float alpha = 1.f;
   float best = 1e30f, first = 1e30f;
   int best_i = 0;
@@ -109,15 +109,15 @@ void tune(Plan& p, const float* X, const float* W, const float* C, float beta, l
     bool ok = true;
     float ms = 0.f;
     for (int rep = 0; rep < 9 && ok; ++rep) {
-      if (rep == 1) hipEventRecord(e0, st);
+      if (rep == 1) (void)hipEventRecord(e0, st);
       ok = hipblasLtMatmul(g_handle, p.desc, &alpha, W, p.a, X, p.b, &beta, C, p.c, scratch, p.d,
                            &p.cand[i].algo, workspace, p.cand[i].workspaceSize,
                            st) == HIPBLAS_STATUS_SUCCESS;
     }
     if (!ok) continue;
-    hipEventRecord(e1, st);
-    hipEventSynchronize(e1);
-    hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventRecord(e1, st);
+    (void)hipEventSynchronize(e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
     if (i == 0) first = ms;
     if (ms < best) {
       best = ms;
@@ -127,9 +127,9 @@ void tune(Plan& p, const float* X, const float* W, const float* C, float beta, l
   // back-to-back timing on warm caches is only a proxy for the kernel's speed inside the step:
   // leave the heuristic's own choice unless a candidate is clearly (> 8 %) faster
   if (best > 0.92f * first) best_i = 0;
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
-  hipFree(scratch);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(scratch);
   p.algo = p.cand[best_i].algo;
   p.ws = p.cand[best_i].workspaceSize;
 }

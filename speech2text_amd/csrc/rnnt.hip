@@ -158,6 +158,8 @@ __global__ __launch_bounds__(256) void simple_dlm_kernel(
 }
 
 // --------------------------------------------- mutual information recursion
+constexpr int MI_PD = 8;   // diagonals of operand look-ahead
+
 __global__ void mi_fwd_kernel(const float* __restrict__ px, const float* __restrict__ py,
                               const long* __restrict__ boundary, int S, int T,
                               float* __restrict__ p, float* __restrict__ ans) {
@@ -177,38 +179,47 @@ __global__ void mi_fwd_kernel(const float* __restrict__ px, const float* __restr
   }
   __syncthreads();
   const bool act = s <= Sb;
-  // prefetch operands of diagonal 0 (t = -s .. only s==0 valid, needs none)
-  float nx = S2T_NEG_INF, ny = S2T_NEG_INF;
+  // Operands of diagonal d (px[s-1][t], py[s][t-1], t = d - s) are requested MI_PD diagonals
+  // ahead: a step of the recursion is a few dozen cycles, a global round trip ~1 us, and with one
+  // diagonal of look-ahead every step waited for one (236 us for 298 diagonals).
+  float rx[MI_PD], ry[MI_PD];
+  auto fetch = [&](int dd, float& x, float& y) {
+    const int t1 = dd - s;
+    x = S2T_NEG_INF;
+    y = S2T_NEG_INF;
+    if (act && t1 >= 0 && t1 <= Tb) {
+      if (s > 0) x = pxb[(long)(s - 1) * (T + 1) + t1];
+      if (t1 > 0) y = pyb[(long)s * T + (t1 - 1)];
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < MI_PD; ++u) fetch(u, rx[u], ry[u]);
   int cur = 0;
   const int D = Sb + Tb;
-  for (int d = 0; d <= D; ++d) {
-    const int t = d - s;
-    const float vx = nx, vy = ny;
-    // prefetch for diagonal d+1: t' = t+1
-    {
-      const int t1 = t + 1;
-      nx = S2T_NEG_INF;
-      ny = S2T_NEG_INF;
-      if (act && t1 >= 0 && t1 <= Tb) {
-        if (s > 0) nx = pxb[(long)(s - 1) * (T + 1) + t1];
-        if (t1 > 0) ny = pyb[(long)s * T + (t1 - 1)];
+  for (int d0 = 0; d0 <= D; d0 += MI_PD) {
+#pragma unroll
+    for (int u = 0; u < MI_PD; ++u) {
+      const int d = d0 + u;
+      if (d > D) break;                                  // block-uniform
+      const int t = d - s;
+      const float vx = rx[u], vy = ry[u];
+      fetch(d + MI_PD, rx[u], ry[u]);
+      float val = S2T_NEG_INF;
+      if (act && t >= 0 && t <= Tb) {
+        if (d == 0) {
+          val = 0.f;
+        } else {
+          const float up = (s > 0) ? ex[(cur ^ 1) * (nt + 1) + s - 1] + vx : S2T_NEG_INF;
+          const float left = (t > 0) ? own + vy : S2T_NEG_INF;
+          val = log_add_comp(up, left);
+        }
+        pb[(long)s * (T + 1) + t] = val;
+        own = val;
       }
+      ex[cur * (nt + 1) + s] = val;
+      __syncthreads();
+      cur ^= 1;
     }
-    float val = S2T_NEG_INF;
-    if (act && t >= 0 && t <= Tb) {
-      if (d == 0) {
-        val = 0.f;
-      } else {
-        const float up = (s > 0) ? ex[(cur ^ 1) * (nt + 1) + s - 1] + vx : S2T_NEG_INF;
-        const float left = (t > 0) ? own + vy : S2T_NEG_INF;
-        val = log_add_precise(up, left);
-      }
-      pb[(long)s * (T + 1) + t] = val;
-      own = val;
-    }
-    ex[cur * (nt + 1) + s] = val;
-    __syncthreads();
-    cur ^= 1;
   }
   if (s == Sb) ans[b] = own;
 }
@@ -237,61 +248,61 @@ __global__ void mi_bwd_kernel(const float* __restrict__ px, const float* __restr
   float own_g = 0.f, own_p = S2T_NEG_INF;  // p_grad[s][t+1], p[s][t+1]
   int cur = 0;
   const int D = Sb + Tb;
-  // prefetch for diagonal D
-  float n_p = S2T_NEG_INF, n_x = S2T_NEG_INF, n_y = S2T_NEG_INF;
-  {
-    const int t = D - s;
-    if (act && t >= 0 && t <= Tb) {
-      n_p = pb[(long)s * (T + 1) + t];
-      if (s < Sb) n_x = pxb[(long)s * (T + 1) + t];
-      if (t < Tb) n_y = pyb[(long)s * T + t];
+  // operands of diagonal d (p, px, py at (s, t = d - s)) are requested MI_PD diagonals ahead
+  float rp[MI_PD], rx[MI_PD], ry[MI_PD];
+  auto fetch = [&](int dd, float& vp, float& vx, float& vy) {
+    const int t1 = dd - s;
+    vp = S2T_NEG_INF;
+    vx = S2T_NEG_INF;
+    vy = S2T_NEG_INF;
+    if (act && dd >= 0 && t1 >= 0 && t1 <= Tb) {
+      vp = pb[(long)s * (T + 1) + t1];
+      if (s < Sb) vx = pxb[(long)s * (T + 1) + t1];
+      if (t1 < Tb) vy = pyb[(long)s * T + t1];
     }
-  }
-  for (int d = D; d >= 0; --d) {
-    const int t = d - s;
-    const float vp = n_p, vx = n_x, vy = n_y;
-    {
-      const int t1 = t - 1;
-      n_p = S2T_NEG_INF;
-      n_x = S2T_NEG_INF;
-      n_y = S2T_NEG_INF;
-      if (act && t1 >= 0 && t1 <= Tb) {
-        n_p = pb[(long)s * (T + 1) + t1];
-        if (s < Sb) n_x = pxb[(long)s * (T + 1) + t1];
-        if (t1 < Tb) n_y = pyb[(long)s * T + t1];
-      }
-    }
-    float g = 0.f;
-    if (act && t >= 0 && t <= Tb) {
-      if (d == D) {
-        g = ag;
-      } else {
-        float xg = 0.f, yg = 0.f;
-        if (s < Sb) {
-          const float pd = exp_[(cur ^ 1) * (nt + 1) + s + 1];  // p[s+1][t]
-          const float gd = exg[(cur ^ 1) * (nt + 1) + s + 1];   // p_grad[s+1][t]
-          if (pd != S2T_NEG_INF && gd != 0.f) {
-            const float e = expf(vp + vx - pd);
-            xg = (e == e) ? gd * e : 0.f;
+  };
+#pragma unroll
+  for (int u = 0; u < MI_PD; ++u) fetch(D - u, rp[u], rx[u], ry[u]);
+  for (int d0 = D; d0 >= 0; d0 -= MI_PD) {
+#pragma unroll
+    for (int u = 0; u < MI_PD; ++u) {
+      const int d = d0 - u;
+      if (d < 0) break;                                  // block-uniform
+      const int t = d - s;
+      const float vp = rp[u], vx = rx[u], vy = ry[u];
+      fetch(d - MI_PD, rp[u], rx[u], ry[u]);
+      float g = 0.f;
+      if (act && t >= 0 && t <= Tb) {
+        if (d == D) {
+          g = ag;
+        } else {
+          float xg = 0.f, yg = 0.f;
+          if (s < Sb) {
+            const float pd = exp_[(cur ^ 1) * (nt + 1) + s + 1];  // p[s+1][t]
+            const float gd = exg[(cur ^ 1) * (nt + 1) + s + 1];   // p_grad[s+1][t]
+            if (pd != S2T_NEG_INF && gd != 0.f) {
+              const float e = __expf(vp + vx - pd);
+              xg = (e == e) ? gd * e : 0.f;
+            }
           }
-        }
-        if (t < Tb) {
-          if (own_p != S2T_NEG_INF && own_g != 0.f) {
-            const float e = expf(vp + vy - own_p);
-            yg = (e == e) ? own_g * e : 0.f;
+          if (t < Tb) {
+            if (own_p != S2T_NEG_INF && own_g != 0.f) {
+              const float e = __expf(vp + vy - own_p);
+              yg = (e == e) ? own_g * e : 0.f;
+            }
           }
+          if (s < Sb) gx[(long)s * (T + 1) + t] = xg;
+          if (t < Tb) gy[(long)s * T + t] = yg;
+          g = xg + yg;
         }
-        if (s < Sb) gx[(long)s * (T + 1) + t] = xg;
-        if (t < Tb) gy[(long)s * T + t] = yg;
-        g = xg + yg;
+        own_g = g;
+        own_p = vp;
       }
-      own_g = g;
-      own_p = vp;
+      exg[cur * (nt + 1) + s] = g;
+      exp_[cur * (nt + 1) + s] = (act && t >= 0 && t <= Tb) ? vp : S2T_NEG_INF;
+      __syncthreads();
+      cur ^= 1;
     }
-    exg[cur * (nt + 1) + s] = g;
-    exp_[cur * (nt + 1) + s] = (act && t >= 0 && t <= Tb) ? vp : S2T_NEG_INF;
-    __syncthreads();
-    cur ^= 1;
   }
 }
 
