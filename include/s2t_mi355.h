@@ -200,6 +200,15 @@ int s2t_bestrq_labels(const float* feats, int B, int T, int F, const float* proj
 int s2t_col2im3x3_nhwc(const float* dc, int B, int H, int W, int C, int Ho, int Wo, int sh, int sw,
                        float* dx, void* stream);
 
+/* First subsampling convolution as a direct stencil: Conv2d(1, CO, 3, padding=(0, pw)) of
+ * Conv2dSubsampling (model/layer/subsampling.py:184-229) on x (B,H,W) -> y (B,H-2,W+2pw-2,CO),
+ * weights in nn.Conv2d's (CO,1,3,3) layout.  mode 0: y = conv(x) + bias; mode 1: dw (CO*9) and
+ * db (CO) ACCUMULATED from (x, g) (caller zeroes them); mode 2: dx (B,H,W) from (g, w).  Returns -2
+ * for channel counts other than the reference's 8 (the caller then uses im2col + GEMM). */
+int s2t_conv3x3_c1(int mode, const float* x, const float* w, const float* bias, const float* g, int B,
+                   int H, int W, int pw, int CO, float* y, float* dw, float* db, float* dx,
+                   void* stream);
+
 /* ---- channel-last depthwise conv2d of the zipformer frontend (ConvNeXt 7x7,
  * model/layer/subsampling.py:47-53,121).  x,y (N,H,W,C); wgt (C,KH,KW); "same" zero padding.
  * flip=1 applies the flipped taps (= backward data).  wgrad writes dw (C,KH,KW) and db (C). */

@@ -380,3 +380,184 @@ extern "C" int s2t_col2im3x3_nhwc(const float* dc, int B, int H, int W, int C, i
   S2T_CHECK_LAUNCH();
   return 0;
 }
+
+namespace {
+
+// ---------------------------------------------------------------- first subsampling conv, direct
+// Conv2d(1, CO, 3, padding=(0, pw)) on channel-last data (model/layer/subsampling.py:184-229): with
+// one input channel the im2col GEMM is a 12-wide, 8-tall "matrix product" that the GEMM library
+// runs at ~0.1 of HBM; as a stencil it is 9 loads, 9*CO FMAs and one CO-float row per output.
+// x (B,H,W), y / g (B,Ho,Wo,CO) with Ho = H - 2, Wo = W + 2 pw - 2; w (CO,1,3,3), bias (CO).
+template <int CO>
+__global__ __launch_bounds__(256) void conv3x3_c1_fwd_kernel(const float* __restrict__ x,
+                                                             const float* __restrict__ w,
+                                                             const float* __restrict__ bias, int B,
+                                                             int H, int W, int pw, int Ho, int Wo,
+                                                             float* __restrict__ y) {
+  float wv[CO * 9], bv[CO];
+#pragma unroll
+  for (int k = 0; k < CO * 9; ++k) wv[k] = w[k];
+#pragma unroll
+  for (int c = 0; c < CO; ++c) bv[c] = bias ? bias[c] : 0.f;
+  const long n = (long)B * Ho * Wo;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int wo = (int)(i % Wo);
+    const long r = i / Wo;
+    const int ho = (int)(r % Ho), b = (int)(r / Ho);
+    float xv[9];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ww = wo + kw - pw;
+        const float t = x[((long)b * H + ho + kh) * W + min(max(ww, 0), W - 1)];
+        xv[kh * 3 + kw] = (ww >= 0 && ww < W) ? t : 0.f;
+      }
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) {
+      acc[c] = bv[c];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) acc[c] = fmaf(wv[c * 9 + k], xv[k], acc[c]);
+    }
+    float4* o = reinterpret_cast<float4*>(y + i * CO);
+#pragma unroll
+    for (int c = 0; c < CO; c += 4) o[c / 4] = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
+  }
+}
+
+// dw[co][k] += sum g[.., co] * x[tap k], db[co] += sum g: per-thread accumulators over a
+// grid-stride range of output positions, wave + workgroup reduction, one atomic per value per
+// workgroup (caller zeroes dw / db)
+template <int CO>
+__global__ __launch_bounds__(256) void conv3x3_c1_wgrad_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ g, int B,
+                                                               int H, int W, int pw, int Ho, int Wo,
+                                                               float* __restrict__ dw,
+                                                               float* __restrict__ db) {
+  __shared__ float s_red[4][CO * 10];
+  float acc[CO * 9], bacc[CO];
+#pragma unroll
+  for (int k = 0; k < CO * 9; ++k) acc[k] = 0.f;
+#pragma unroll
+  for (int c = 0; c < CO; ++c) bacc[c] = 0.f;
+  const long n = (long)B * Ho * Wo;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int wo = (int)(i % Wo);
+    const long r = i / Wo;
+    const int ho = (int)(r % Ho), b = (int)(r / Ho);
+    float xv[9], gv[CO];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ww = wo + kw - pw;
+        const float t = x[((long)b * H + ho + kh) * W + min(max(ww, 0), W - 1)];
+        xv[kh * 3 + kw] = (ww >= 0 && ww < W) ? t : 0.f;
+      }
+    const float4* gp = reinterpret_cast<const float4*>(g + i * CO);
+#pragma unroll
+    for (int c = 0; c < CO; c += 4) {
+      const float4 t = gp[c / 4];
+      gv[c] = t.x;
+      gv[c + 1] = t.y;
+      gv[c + 2] = t.z;
+      gv[c + 3] = t.w;
+    }
+#pragma unroll
+    for (int c = 0; c < CO; ++c) {
+      bacc[c] += gv[c];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) acc[c * 9 + k] = fmaf(gv[c], xv[k], acc[c * 9 + k]);
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < CO * 9; ++k) {
+    const float v = wave_sum(acc[k]);
+    if (lane == 0) s_red[wave][k] = v;
+  }
+#pragma unroll
+  for (int c = 0; c < CO; ++c) {
+    const float v = wave_sum(bacc[c]);
+    if (lane == 0) s_red[wave][CO * 9 + c] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < CO * 10) {
+    const float v = (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) +
+                    (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
+    if (threadIdx.x < CO * 9) atomicAdd(dw + threadIdx.x, v);
+    else if (db) atomicAdd(db + (threadIdx.x - CO * 9), v);
+  }
+}
+
+// dx[b,h,w] = sum_{co,kh,kw} g[b, h-kh, w-kw+pw, co] * w[co][kh][kw]   (gather)
+template <int CO>
+__global__ __launch_bounds__(256) void conv3x3_c1_dgrad_kernel(const float* __restrict__ g,
+                                                               const float* __restrict__ w, int B,
+                                                               int H, int W, int pw, int Ho, int Wo,
+                                                               float* __restrict__ dx) {
+  float wv[CO * 9];
+#pragma unroll
+  for (int k = 0; k < CO * 9; ++k) wv[k] = w[k];
+  const long n = (long)B * H * W;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int ww = (int)(i % W);
+    const long r = i / W;
+    const int h = (int)(r % H), b = (int)(r / H);
+    float acc = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int ho = h - kh;
+      if (ho < 0 || ho >= Ho) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int wo = ww - kw + pw;
+        if (wo < 0 || wo >= Wo) continue;
+        const float4* gp = reinterpret_cast<const float4*>(g + (((long)b * Ho + ho) * Wo + wo) * CO);
+#pragma unroll
+        for (int c = 0; c < CO; c += 4) {
+          const float4 t = gp[c / 4];
+          acc = fmaf(t.x, wv[c * 9 + kh * 3 + kw], acc);
+          acc = fmaf(t.y, wv[(c + 1) * 9 + kh * 3 + kw], acc);
+          acc = fmaf(t.z, wv[(c + 2) * 9 + kh * 3 + kw], acc);
+          acc = fmaf(t.w, wv[(c + 3) * 9 + kh * 3 + kw], acc);
+        }
+      }
+    }
+    dx[i] = acc;
+  }
+}
+
+inline unsigned grid_c1(long n) {
+  long b = (n + 255) / 256;
+  return (unsigned)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+// mode 0: y = conv(x) + bias;  1: dw / db += (accumulated; caller zeroes);  2: dx.
+// Only CO == 8 (the reference's layer1_channels) is instantiated; -2 asks the caller to use the
+// im2col path.
+extern "C" int s2t_conv3x3_c1(int mode, const float* x, const float* w, const float* bias,
+                              const float* g, int B, int H, int W, int pw, int CO, float* y,
+                              float* dw, float* db, float* dx, void* stream) {
+  if (B <= 0 || H < 3 || W <= 0) return -1;
+  if (CO != 8 || pw < 0 || pw > 1) return -2;
+  const int Ho = H - 2, Wo = W + 2 * pw - 2;
+  if (Wo <= 0) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  if (mode == 0)
+    hipLaunchKernelGGL(conv3x3_c1_fwd_kernel<8>, dim3(grid_c1((long)B * Ho * Wo)), dim3(256), 0, st,
+                       x, w, bias, B, H, W, pw, Ho, Wo, y);
+  else if (mode == 1)
+    hipLaunchKernelGGL(conv3x3_c1_wgrad_kernel<8>, dim3(1024), dim3(256), 0, st, x, g, B, H, W, pw,
+                       Ho, Wo, dw, db);
+  else if (mode == 2)
+    hipLaunchKernelGGL(conv3x3_c1_dgrad_kernel<8>, dim3(grid_c1((long)B * H * W)), dim3(256), 0, st,
+                       g, w, B, H, W, pw, Ho, Wo, dx);
+  else
+    return -1;
+  S2T_CHECK_LAUNCH();
+  return 0;
+}

@@ -98,9 +98,7 @@ class Conv2dSubsampling(nn.Module):
         x = x.unsqueeze(-1)                                     # (N,T,F,1) channel-last
         for m in self.conv:
             if isinstance(m, nn.Conv2d):
-                if m.padding[1]:
-                    x = F.pad(x, (0, 0, m.padding[1], m.padding[1]))   # freq axis only
-                x = zk.conv3x3_nhwc(x, m.weight, m.bias, m.stride)
+                x = zk.conv3x3_nhwc(x, m.weight, m.bias, m.stride, pad_w=m.padding[1])  # freq axis
             else:
                 x = m(x)
         x = self.convnext(x)                                    # (N,T',F',C)

@@ -1226,7 +1226,52 @@ class _Conv3x3Nhwc(torch.autograd.Function):
         return dx, dweight, db, None, None
 
 
-def conv3x3_nhwc(x, weight, bias, stride=(1, 1)):
+class _Conv3x3C1(torch.autograd.Function):
+    """Conv2d(1, 8, 3, padding=(0, pw)) on (N,H,W,1) as a direct stencil (zip_front.hip): no
+    padded copy, no im2col matrix, no 12-wide GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, pw):
+        _dev(x, weight)
+        x3 = x.reshape(x.shape[0], x.shape[1], x.shape[2]).contiguous().float()
+        B, H, W = x3.shape
+        CO = weight.shape[0]
+        y = torch.empty((B, H - 2, W + 2 * pw - 2, CO), dtype=torch.float32, device=x.device)
+        w = weight.contiguous().float()
+        N.check(N.lib().s2t_conv3x3_c1(0, N.fp(x3), N.fp(w), N.fp(bias), None, B, H, W, pw, CO,
+                                       N.fp(y), None, None, None, N.stream()), "s2t_conv3x3_c1")
+        ctx.save_for_backward(x3, w)
+        ctx.cfg = (pw, bias is not None, x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x3, w = ctx.saved_tensors
+        pw, has_bias, xshape = ctx.cfg
+        B, H, W = x3.shape
+        CO = w.shape[0]
+        g = g.contiguous().float()
+        acc = torch.zeros(CO * 10, dtype=torch.float32, device=g.device)
+        L = N.lib()
+        N.check(L.s2t_conv3x3_c1(1, N.fp(x3), None, None, N.fp(g), B, H, W, pw, CO, None, N.fp(acc),
+                                 ctypes_off(acc, CO * 9), None, N.stream()), "s2t_conv3x3_c1(wgrad)")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x3)
+            N.check(L.s2t_conv3x3_c1(2, None, N.fp(w), None, N.fp(g), B, H, W, pw, CO, None, None,
+                                     None, N.fp(dx), N.stream()), "s2t_conv3x3_c1(dgrad)")
+            dx = dx.view(xshape)
+        return dx, acc[:CO * 9].view(w.shape), (acc[CO * 9:] if has_bias else None), None
+
+
+def conv3x3_nhwc(x, weight, bias, stride=(1, 1), pad_w=0):
+    """3x3 convolution on channel-last (N,H,W,Cin); pad_w = zero padding of the W axis (the
+    reference's padding=(0, 1) of the first subsampling conv)."""
+    if (x.shape[-1] == 1 and weight.shape[0] == 8 and tuple(stride) == (1, 1) and pad_w in (0, 1)
+            and x.is_cuda):
+        return _Conv3x3C1.apply(x, weight, bias, int(pad_w))
+    if pad_w:
+        x = F.pad(x, (0, 0, pad_w, pad_w))
     return _Conv3x3Nhwc.apply(x, weight, bias, int(stride[0]), int(stride[1]))
 
 

@@ -275,6 +275,21 @@ def test_dwconv2d_and_conv3x3_nhwc_vs_torch(dev, N_, H, W, C, K):
     torch.testing.assert_close(xg.grad.cpu().double(), xr.grad, atol=1e-4, rtol=1e-4)
     torch.testing.assert_close(wg.grad.cpu().double(), wr.grad, atol=2e-3, rtol=2e-4)
     torch.testing.assert_close(bg.grad.cpu().double(), br.grad, atol=2e-3, rtol=2e-4)
+    # first subsampling conv: 1 -> 8 channels, padding (0, 1), direct stencil kernels
+    x1 = torch.randn(N_, H, W, 1, generator=g)
+    w1 = torch.randn(8, 1, 3, 3, generator=g) * 0.3
+    b1 = torch.randn(8, generator=g)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x1, w1, b1))
+    yr = torch.nn.functional.conv2d(xr.permute(0, 3, 1, 2), wr, br, padding=(0, 1))
+    wt1 = torch.randn(yr.shape, generator=g, dtype=torch.float64)
+    (yr * wt1).sum().backward()
+    xg, wg, bg = (t.to(dev).requires_grad_(True) for t in (x1, w1, b1))
+    y = zk.conv3x3_nhwc(xg, wg, bg, (1, 1), pad_w=1)
+    (y * wt1.permute(0, 2, 3, 1).float().to(dev)).sum().backward()
+    torch.testing.assert_close(y.detach().cpu().double(), yr.permute(0, 2, 3, 1).detach(), atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(xg.grad.cpu().double(), xr.grad, atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(wg.grad.cpu().double(), wr.grad, atol=2e-3, rtol=2e-4)
+    torch.testing.assert_close(bg.grad.cpu().double(), br.grad, atol=2e-3, rtol=2e-4)
     # 3x3 conv, strides (1,1) and (2,2): im2col GEMM forward, col2im gather backward
     Cin, Cout = 8, 16
     for stride in ((1, 1), (2, 2), (1, 2)):
