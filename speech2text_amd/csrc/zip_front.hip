@@ -353,18 +353,24 @@ __global__ __launch_bounds__(256) void col2im3x3_kernel(const float* __restrict_
   const int n = W * C;
   for (int i = threadIdx.x; i < n; i += 256) {
     const int w = i / C, c = i - w * C;
-    float acc = 0.f;
+    // all nine taps are loaded from clamped (valid) addresses before any is used; taps that do
+    // not exist for this position are masked out afterwards (loads behind `continue`s serialise)
+    float t[9];
+    bool ok[9];
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
       const int ww = w - kw;
-      if (ww < 0 || ww % sw) continue;
-      const int wo = ww / sw;
-      if (wo >= Wo) continue;
+      const bool okw = ww >= 0 && ww % sw == 0 && ww / sw < Wo;
+      const int wo = okw ? ww / sw : 0;
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh)
-        if (hv[kh])
-          acc += dc[((((long)b * Ho + ho[kh]) * Wo + wo) * 9 + kh * 3 + kw) * C + c];
+      for (int kh = 0; kh < 3; ++kh) {
+        ok[kh * 3 + kw] = okw && hv[kh];
+        t[kh * 3 + kw] = dc[((((long)b * Ho + ho[kh]) * Wo + wo) * 9 + kh * 3 + kw) * C + c];
+      }
     }
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc += ok[k] ? t[k] : 0.f;
     row[i] = acc;
   }
 }
