@@ -209,6 +209,14 @@ int s2t_conv3x3_c1(int mode, const float* x, const float* w, const float* bias, 
                    int H, int W, int pw, int CO, float* y, float* dw, float* db, float* dx,
                    void* stream);
 
+/* Second subsampling convolution as direct kernels: Conv2d(8, 32, 3, stride 2) of
+ * Conv2dSubsampling (model/layer/subsampling.py:184-229) on x (B,H,W,8) -> y (B,(H-3)/2+1,
+ * (W-3)/2+1,32), weights in nn.Conv2d's (CO,CI,3,3) layout.  mode 0: y = conv(x) + bias; mode 2:
+ * dx (B,H,W,8) from (g, w) (the weight gradient stays a TN GEMM over the patch matrix).  Returns -2
+ * for other channel counts (the caller then uses im2col + GEMM). */
+int s2t_conv3x3_s2(int mode, const float* x, const float* w, const float* bias, const float* g, int B,
+                   int H, int W, int CI, int CO, float* y, float* dx, void* stream);
+
 /* ---- channel-last depthwise conv2d of the zipformer frontend (ConvNeXt 7x7,
  * model/layer/subsampling.py:47-53,121).  x,y (N,H,W,C); wgt (C,KH,KW); "same" zero padding.
  * flip=1 applies the flipped taps (= backward data).  wgrad writes dw (C,KH,KW) and db (C). */

@@ -6,6 +6,7 @@
 // backward data = the same stencil with the taps flipped; backward weight = per-block
 // partial sums [block][c][KH*KW+1] reduced by a second kernel (no contended atomics).
 #include "common.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace {
@@ -564,6 +565,144 @@ extern "C" int s2t_conv3x3_c1(int mode, const float* x, const float* w, const fl
                        g, w, B, H, W, pw, Ho, Wo, dx);
   else
     return -1;
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+namespace {
+
+// ---------------------------------------------------------------- second subsampling conv, direct
+// Conv2d(CI = 8, CO = 32, 3, stride 2) on channel-last data (model/layer/subsampling.py:184-229).
+// As im2col + GEMM it is a 72-deep, 32-wide product over 1.2 M rows: the 357 MB patch matrix is
+// written and read back and the library GEMM runs far below its rate.  Direct form: a thread owns
+// one output position, keeps its 72 inputs and 32 accumulators in registers and takes the weights
+// through wave-uniform (scalar) loads.  x (B,H,W,CI) -> y (B,Ho,Wo,CO), Ho = (H-3)/2+1.
+template <int CI, int CO>
+__global__ __launch_bounds__(256) void conv3x3_s2_fwd_kernel(const float* __restrict__ x,
+                                                             const float* __restrict__ w,
+                                                             const float* __restrict__ bias, int B,
+                                                             int H, int W, int Ho, int Wo,
+                                                             float* __restrict__ y) {
+  static_assert(CI % 4 == 0 && CO % 4 == 0, "float4 rows");
+  // (measured alternatives: two positions per thread 271 us, lane = output channel with the taps
+  // in registers 887 us; this form 213 us against 360 us for im2col + library GEMM)
+  const long n = (long)B * Ho * Wo;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int wo = (int)(i % Wo);
+  const long r = i / Wo;
+  const int ho = (int)(r % Ho), b = (int)(r / Ho);
+  float xv[9 * CI];
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const float4* p = reinterpret_cast<const float4*>(
+          x + (((long)b * H + 2 * ho + kh) * W + 2 * wo + kw) * CI);
+#pragma unroll
+      for (int q = 0; q < CI / 4; ++q) {
+        const float4 t = p[q];
+        xv[(kh * 3 + kw) * CI + 4 * q] = t.x;
+        xv[(kh * 3 + kw) * CI + 4 * q + 1] = t.y;
+        xv[(kh * 3 + kw) * CI + 4 * q + 2] = t.z;
+        xv[(kh * 3 + kw) * CI + 4 * q + 3] = t.w;
+      }
+    }
+  float4* o = reinterpret_cast<float4*>(y + i * CO);
+#pragma unroll
+  for (int c0 = 0; c0 < CO; c0 += 4) {
+    float acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      acc[c] = bias ? bias[c0 + c] : 0.f;
+      // nn.Conv2d weight (CO, CI, 3, 3): element (co, ci, kh, kw) at ((co*CI + ci)*3 + kh)*3 + kw
+#pragma unroll
+      for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+          acc[c] = fmaf(w[((c0 + c) * CI + ci) * 9 + k], xv[k * CI + ci], acc[c]);
+    }
+    o[c0 / 4] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  }
+}
+
+// dx[b,h,w,ci] = sum_{kh,kw,co} g[b,(h-kh)/2,(w-kw)/2,co] w[co,ci,kh,kw] over the taps whose
+// (h-kh, w-kw) are even and in range.  A thread owns the input pair (h, 2p) / (h, 2p+1): the
+// even column takes kw = 0 (wo = p) and kw = 2 (wo = p-1), the odd one kw = 1 (wo = p); the row
+// parity (kh in {0,2} or {1}) is uniform per workgroup row, so every weight index is wave-uniform.
+template <int CI, int CO>
+__global__ __launch_bounds__(256) void conv3x3_s2_dgrad_kernel(const float* __restrict__ g,
+                                                               const float* __restrict__ w, int B,
+                                                               int H, int W, int Ho, int Wo,
+                                                               float* __restrict__ dx) {
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const int npair = (W + 1) / 2;
+  if (p >= npair) return;
+  float ae[CI], ao[CI];                      // gradients of columns 2p and 2p+1
+#pragma unroll
+  for (int c = 0; c < CI; ++c) ae[c] = ao[c] = 0.f;
+  for (int kh = (h & 1); kh < 3; kh += 2) {  // uniform: h even -> 0, 2; h odd -> 1
+    const int hh = h - kh;
+    if (hh < 0 || hh / 2 >= Ho) continue;
+    const float* grow = g + ((long)b * Ho + hh / 2) * Wo * CO;
+    // g pixels wo = p (taps kw 0 and 1) and wo = p - 1 (tap kw 2), from clamped addresses
+    const bool v0 = p < Wo, v1 = p - 1 >= 0 && p - 1 < Wo;
+    const float4* g0 = reinterpret_cast<const float4*>(grow + (long)min(p, Wo - 1) * CO);
+    const float4* g1 = reinterpret_cast<const float4*>(grow + (long)min(max(p - 1, 0), Wo - 1) * CO);
+#pragma unroll
+    for (int q = 0; q < CO / 4; ++q) {
+      float4 t0 = g0[q], t1 = g1[q];
+      if (!v0) t0 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!v1) t1 = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float a0[4] = {t0.x, t0.y, t0.z, t0.w}, a1[4] = {t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int co = 4 * q + c;
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) {
+          const float* wp = w + ((co * CI + ci) * 3 + kh) * 3;
+          ae[ci] = fmaf(a0[c], wp[0], ae[ci]);          // even column, kw = 0, wo = p
+          ao[ci] = fmaf(a0[c], wp[1], ao[ci]);          // odd column,  kw = 1, wo = p
+          ae[ci] = fmaf(a1[c], wp[2], ae[ci]);          // even column, kw = 2, wo = p - 1
+        }
+      }
+    }
+  }
+  float* o = dx + (((long)b * H + h) * W + 2 * p) * CI;
+#pragma unroll
+  for (int q = 0; q < CI / 4; ++q)
+    reinterpret_cast<float4*>(o)[q] = make_float4(ae[4 * q], ae[4 * q + 1], ae[4 * q + 2], ae[4 * q + 3]);
+  if (2 * p + 1 < W) {
+#pragma unroll
+    for (int q = 0; q < CI / 4; ++q)
+      reinterpret_cast<float4*>(o + CI)[q] =
+          make_float4(ao[4 * q], ao[4 * q + 1], ao[4 * q + 2], ao[4 * q + 3]);
+  }
+}
+
+}  // namespace
+
+// mode 0: y = conv(x) + bias;  mode 2: dx from (g, w).  Only (CI, CO) = (8, 32), stride 2, no
+// padding (the reference's second subsampling conv) is instantiated; -2 = use im2col + GEMM.
+extern "C" int s2t_conv3x3_s2(int mode, const float* x, const float* w, const float* bias,
+                              const float* g, int B, int H, int W, int CI, int CO, float* y,
+                              float* dx, void* stream) {
+  if (B <= 0 || H < 3 || W < 3) return -1;
+  if (CI != 8 || CO != 32) return -2;
+  const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1;
+  hipStream_t st = (hipStream_t)stream;
+  if (mode == 0) {
+    const long n = (long)B * Ho * Wo;
+    hipLaunchKernelGGL((conv3x3_s2_fwd_kernel<8, 32>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       st, x, w, bias, B, H, W, Ho, Wo, y);
+  } else if (mode == 2) {
+    if (B > 65535 || H > 65535) return -2;
+    hipLaunchKernelGGL((conv3x3_s2_dgrad_kernel<8, 32>), dim3(((W + 1) / 2 + 255) / 256, H, B),
+                       dim3(256), 0, st, g, w, B, H, W, Ho, Wo, dx);
+  } else {
+    return -1;
+  }
   S2T_CHECK_LAUNCH();
   return 0;
 }

@@ -1264,12 +1264,55 @@ class _Conv3x3C1(torch.autograd.Function):
         return dx, acc[:CO * 9].view(w.shape), (acc[CO * 9:] if has_bias else None), None
 
 
+class _Conv3x3S2(torch.autograd.Function):
+    """Conv2d(8, 32, 3, stride 2) on (N,H,W,8) as direct kernels for the forward and the input
+    gradient (zip_front.hip); the weight gradient is the TN GEMM over the patch matrix, which is
+    built in backward only."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _dev(x, weight)
+        x = x.contiguous().float()
+        B, H, W, C = x.shape
+        CO = weight.shape[0]
+        w = weight.contiguous().float()
+        y = torch.empty((B, (H - 3) // 2 + 1, (W - 3) // 2 + 1, CO), dtype=torch.float32,
+                        device=x.device)
+        N.check(N.lib().s2t_conv3x3_s2(0, N.fp(x), N.fp(w), N.fp(bias), None, B, H, W, C, CO,
+                                       N.fp(y), None, N.stream()), "s2t_conv3x3_s2")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        B, H, W, C = x.shape
+        CO = w.shape[0]
+        Ho, Wo = dy.shape[1], dy.shape[2]
+        g = dy.contiguous().float()
+        s = x.stride()
+        cols = x.as_strided((B, Ho, Wo, 3, 3 * C), (s[0], s[1] * 2, s[2] * 2, s[1], 1)) \
+            .reshape(B * Ho * Wo, 9 * C)
+        dwmat, db = linear_wgrad(g.view(B * Ho * Wo, CO), cols, ctx.has_bias)       # (CO, 9C)
+        dweight = dwmat.view(CO, 3, 3, C).permute(0, 3, 1, 2)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            N.check(N.lib().s2t_conv3x3_s2(2, None, N.fp(w), None, N.fp(g), B, H, W, C, CO, None,
+                                           N.fp(dx), N.stream()), "s2t_conv3x3_s2(dgrad)")
+        return dx, dweight, db
+
+
 def conv3x3_nhwc(x, weight, bias, stride=(1, 1), pad_w=0):
     """3x3 convolution on channel-last (N,H,W,Cin); pad_w = zero padding of the W axis (the
     reference's padding=(0, 1) of the first subsampling conv)."""
     if (x.shape[-1] == 1 and weight.shape[0] == 8 and tuple(stride) == (1, 1) and pad_w in (0, 1)
             and x.is_cuda):
         return _Conv3x3C1.apply(x, weight, bias, int(pad_w))
+    if (x.shape[-1] == 8 and weight.shape[0] == 32 and tuple(stride) == (2, 2) and not pad_w
+            and x.is_cuda and x.shape[0] <= 65535 and x.shape[1] <= 65535):
+        return _Conv3x3S2.apply(x, weight, bias)
     if pad_w:
         x = F.pad(x, (0, 0, pad_w, pad_w))
     return _Conv3x3Nhwc.apply(x, weight, bias, int(stride[0]), int(stride[1]))

@@ -290,6 +290,22 @@ def test_dwconv2d_and_conv3x3_nhwc_vs_torch(dev, N_, H, W, C, K):
     torch.testing.assert_close(xg.grad.cpu().double(), xr.grad, atol=1e-4, rtol=1e-4)
     torch.testing.assert_close(wg.grad.cpu().double(), wr.grad, atol=2e-3, rtol=2e-4)
     torch.testing.assert_close(bg.grad.cpu().double(), br.grad, atol=2e-3, rtol=2e-4)
+    # second subsampling conv: 8 -> 32 channels, stride 2, direct forward / input-gradient kernels
+    if H >= 9 and W >= 5:
+        x2 = torch.randn(N_, H, W, 8, generator=g)
+        w2 = torch.randn(32, 8, 3, 3, generator=g) * 0.2
+        b2 = torch.randn(32, generator=g)
+        xr, wr, br = (t.double().requires_grad_(True) for t in (x2, w2, b2))
+        yr = torch.nn.functional.conv2d(xr.permute(0, 3, 1, 2), wr, br, stride=2)
+        wt2 = torch.randn(yr.shape, generator=g, dtype=torch.float64)
+        (yr * wt2).sum().backward()
+        xg, wg, bg = (t.to(dev).requires_grad_(True) for t in (x2, w2, b2))
+        y = zk.conv3x3_nhwc(xg, wg, bg, (2, 2))
+        (y * wt2.permute(0, 2, 3, 1).float().to(dev)).sum().backward()
+        torch.testing.assert_close(y.detach().cpu().double(), yr.permute(0, 2, 3, 1).detach(), atol=1e-4, rtol=1e-4)
+        torch.testing.assert_close(xg.grad.cpu().double(), xr.grad.permute(0, 1, 2, 3), atol=1e-4, rtol=1e-4)
+        torch.testing.assert_close(wg.grad.cpu().double(), wr.grad, atol=2e-3, rtol=2e-4)
+        torch.testing.assert_close(bg.grad.cpu().double(), br.grad, atol=2e-3, rtol=2e-4)
     # 3x3 conv, strides (1,1) and (2,2): im2col GEMM forward, col2im gather backward
     Cin, Cout = 8, 16
     for stride in ((1, 1), (2, 2), (1, 2)):
