@@ -263,13 +263,30 @@ __global__ __launch_bounds__(256) void balancer_apply_fused_kernel(
   if (blockIdx.x == 0)          // the whole accumulator: the previous user may have had more channels
     for (int c = threadIdx.x; c < 2 * 1024; c += 256) stats_next[c] = 0.f;
   __syncthreads();
-  const long total = rows * C;
-  const long stride = (long)gridDim.x * blockDim.x;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    const long r = i / C;
-    const int c = (int)(i - r * C);
-    const float gv = g[r * ldg + c];
-    out[r * ldo + c] = gv + fabsf(gv) * fmaf(s_b[c], x[r * ldx + c], s_a[c]);
+  // thread = (column within a 64-wide group, row lane): no per-element division, four rows of
+  // loads in flight; a workgroup walks all column groups of its rows
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const long step = (long)gridDim.x * 4;
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    const int c = c0 + tx;
+    if (c >= C) continue;
+    const float a = s_a[c], b = s_b[c];
+    long r = (long)blockIdx.x * 4 + ty;
+    for (; r + 3 * step < rows; r += 4 * step) {
+      float gv[4], xv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        gv[u] = g[(r + u * step) * ldg + c];
+        xv[u] = x[(r + u * step) * ldx + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        out[(r + u * step) * ldo + c] = gv[u] + fabsf(gv[u]) * fmaf(b, xv[u], a);
+    }
+    for (; r < rows; r += step) {
+      const float gv = g[r * ldg + c];
+      out[r * ldo + c] = gv + fabsf(gv) * fmaf(b, x[r * ldx + c], a);
+    }
   }
 }
 
@@ -356,7 +373,7 @@ extern "C" int s2t_balancer_bwd(const float* x, long ldx, const float* g, long l
   hipLaunchKernelGGL(col_stats_kernel, dim3((unsigned)gx, gy), dim3(64, 4), 0, st, x, rows, C, ldx,
                      cur, cur + BAL_MAXC);
   S2T_CHECK_LAUNCH();
-  hipLaunchKernelGGL(balancer_apply_fused_kernel, dim3(grid_for(rows * C, 1024)), dim3(256), 0, st,
+  hipLaunchKernelGGL(balancer_apply_fused_kernel, dim3((unsigned)std::min<long>((rows + 15) / 16, 2048)), dim3(256), 0, st,
                      x, ldx, g, ldg, cur, nxt, (float)rows, min_mean, max_mean, min_rms, max_rms,
                      grad_scale, rows, C, out, ldo);
   S2T_CHECK_LAUNCH();
