@@ -96,12 +96,15 @@ int s2t_biasnorm_bwd(const float* x, const float* bias, const float* scales, con
  * x / g / out are row-strided (ldx / ldg / ldo floats; out == g allowed).  `workspace`:
  * s2t_balancer_bwd_workspace_floats() floats holding two alternating accumulators, zeroed ONCE
  * when allocated; the caller passes parity = 0, 1, 0, 1, ... on successive calls (each call
- * clears the accumulator of the next) and keeps all calls on one stream.  C <= 1024. */
+ * clears the accumulator of the next) and keeps all calls on one stream.  C <= 1024.
+ * act_off >= 0: g is the gradient w.r.t. Swoosh(x) (offset act_off: 4 = SwooshL, 1 = SwooshR) and
+ * is taken through the activation first -- the hidden Balancer of FeedforwardModule
+ * (zipformer.py:1573-1593) and the Swoosh backward in one pass; act_off < 0: plain Balancer. */
 long s2t_balancer_bwd_workspace_floats(void);
 int s2t_balancer_bwd(const float* x, long ldx, const float* g, long ldg, long rows, int C,
                      float min_mean, float max_mean, float min_rms, float max_rms,
                      float grad_scale, float* out, long ldo, float* workspace, int parity,
-                     void* stream);
+                     float act_off, void* stream);
 
 
 /* ---- zipformer convolution module core (model/encoder/zipformer.py:2672-2690 +

@@ -235,7 +235,9 @@ __global__ __launch_bounds__(256) void balancer_apply_fused_kernel(
     const float* __restrict__ x, long ldx, const float* __restrict__ g, long ldg,
     const float* __restrict__ stats, float* __restrict__ stats_next, float n, float min_mean,
     float max_mean, float min_rms, float max_rms, float grad_scale, long rows, int C,
-    float* __restrict__ out, long ldo) {
+    float* __restrict__ out, long ldo, float act_off) {
+  // act_off >= 0: g is the gradient w.r.t. swoosh(x) and is first taken through the activation
+  // (g *= sigmoid(x - act_off) - 0.08): Swoosh backward and the Balancer update in one pass
   __shared__ float s_a[1024], s_b[1024];
   const float inv_n = 1.f / n;
   for (int c = threadIdx.x; c < C; c += 256) {
@@ -280,12 +282,16 @@ __global__ __launch_bounds__(256) void balancer_apply_fused_kernel(
         xv[u] = x[(r + u * step) * ldx + c];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < 4; ++u) {
+        if (act_off >= 0.f) gv[u] *= swoosh_d(xv[u], act_off);
         out[(r + u * step) * ldo + c] = gv[u] + fabsf(gv[u]) * fmaf(b, xv[u], a);
+      }
     }
     for (; r < rows; r += step) {
-      const float gv = g[r * ldg + c];
-      out[r * ldo + c] = gv + fabsf(gv) * fmaf(b, x[r * ldx + c], a);
+      const float xs = x[r * ldx + c];
+      float gv = g[r * ldg + c];
+      if (act_off >= 0.f) gv *= swoosh_d(xs, act_off);
+      out[r * ldo + c] = gv + fabsf(gv) * fmaf(b, xs, a);
     }
   }
 }
@@ -360,7 +366,7 @@ extern "C" long s2t_balancer_bwd_workspace_floats(void) { return 4L * BAL_MAXC; 
 extern "C" int s2t_balancer_bwd(const float* x, long ldx, const float* g, long ldg, long rows,
                                 int C, float min_mean, float max_mean, float min_rms,
                                 float max_rms, float grad_scale, float* out, long ldo,
-                                float* workspace, int parity, void* stream) {
+                                float* workspace, int parity, float act_off, void* stream) {
   if (rows <= 0 || C <= 0) return 0;
   if (C > BAL_MAXC || !workspace) return -1;
   hipStream_t st = (hipStream_t)stream;
@@ -375,7 +381,7 @@ extern "C" int s2t_balancer_bwd(const float* x, long ldx, const float* g, long l
   S2T_CHECK_LAUNCH();
   hipLaunchKernelGGL(balancer_apply_fused_kernel, dim3((unsigned)std::min<long>((rows + 15) / 16, 2048)), dim3(256), 0, st,
                      x, ldx, g, ldg, cur, nxt, (float)rows, min_mean, max_mean, min_rms, max_rms,
-                     grad_scale, rows, C, out, ldo);
+                     grad_scale, rows, C, out, ldo, act_off);
   S2T_CHECK_LAUNCH();
   return 0;
 }

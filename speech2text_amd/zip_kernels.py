@@ -168,14 +168,16 @@ def _balancer_workspace(dev):
 
 
 def balancer_backward(x, g, min_mean, max_mean, min_rms, max_rms, grad_scale, channel_dim,
-                      inplace=False):
+                      inplace=False, swoosh_l=None):
     """Closed form of reference scaling.py:741-789: the autograd-inside-backward there reduces
     to per-channel statistics (mean, E[x^2]) and a per-element affine term
         g' = g + |g| * grad_scale * (a_c + b_c x) / rms_c(a + b x).
     Channel-last tensors (the zipformer layers) run two HIP launches (s2t_balancer_bwd): column
     statistics + coefficients, fused update.  x and g may be row-strided slices of wider tensors;
-    inplace=True writes the result over g (a slice of a gradient being assembled).  Other layouts
-    (NCHW frontend) use the same formulas as torch reductions."""
+    inplace=True writes the result over g (a slice of a gradient being assembled).  swoosh_l
+    (True / False): g is the gradient w.r.t. SwooshL / SwooshR of x and goes through the
+    activation's derivative first, in the same pass.  Other layouts (NCHW frontend) use the same
+    formulas as torch reductions."""
     _dev(x, g)
     nd = x.ndim
     if channel_dim == nd - 1 and x.dim() >= 2 and x.stride(-1) == 1 and g.dtype == torch.float32 \
@@ -200,9 +202,12 @@ def balancer_backward(x, g, min_mean, max_mean, min_rms, max_rms, grad_scale, ch
                                          N.raw(g2, torch.float32), g2.stride(0), rows, C, min_mean,
                                          max_mean, min_rms, max_rms, grad_scale,
                                          N.raw(out, torch.float32), out.stride(0), N.fp(ws[0]),
-                                         ws[1], N.stream()),
+                                         ws[1], -1.0 if swoosh_l is None else _SW[swoosh_l][0],
+                                         N.stream()),
                 "s2t_balancer_bwd")
         return out if out is g else out.reshape(g.shape)
+    if swoosh_l is not None:
+        g = swoosh_backward(x, g, swoosh_l)
     dims = [i for i in range(nd) if i != channel_dim]
     xf = x.float()
     n = xf.numel() // xf.shape[channel_dim]

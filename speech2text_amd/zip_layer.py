@@ -184,8 +184,8 @@ def _whiten_bwd(mod, x, g, stats):
     return out
 
 
-def _balancer_bwd(mod, x, g, inplace=False):
-    return zk.balancer_backward(x, g, *mod.cfg(2), inplace=inplace)
+def _balancer_bwd(mod, x, g, inplace=False, swoosh_l=None):
+    return zk.balancer_backward(x, g, *mod.cfg(2), inplace=inplace, swoosh_l=swoosh_l)
 
 
 class _Commit(ctypes.Structure):
@@ -252,9 +252,11 @@ def _ff_bwd(m, post, dec, sv, x_in, g):
         gy = _whiten_bwd(m.out_whiten, sv.y, gy, sv.st)
     W = m.out_proj.weight
     _wgrad(W, m.out_proj.bias, gy, sv.a)
-    dh = zk.swoosh_backward(sv.h, zk.lt_matmul(1, gy, W), True)
-    if fb:
-        dh = _balancer_bwd(m.hidden_balancer, sv.h, dh)
+    dh = zk.lt_matmul(1, gy, W)
+    if fb:                                   # Swoosh backward rides in the Balancer's update pass
+        dh = _balancer_bwd(m.hidden_balancer, sv.h, dh, swoosh_l=True)
+    else:
+        dh = zk.swoosh_backward(sv.h, dh, True)
     _wgrad(m.in_proj.weight, m.in_proj.bias, dh, x_in)
     return zk.lt_matmul(1, dh, m.in_proj.weight, None, g)
 
