@@ -91,6 +91,31 @@ class _BalancerFn(torch.autograd.Function):
         return zk.balancer_backward(x, g, *ctx.cfg), None
 
 
+class _BalancerSwooshFn(torch.autograd.Function):
+    """swoosh(balancer(x)): the Balancer is the identity in forward, so this is the activation;
+    backward takes the gradient through the activation and the Balancer's update in ONE pass
+    (s2t_balancer_bwd with act_off) when the Balancer fired, else through the activation only."""
+
+    @staticmethod
+    def forward(ctx, x, cfg, is_l):
+        ctx.save_for_backward(x)
+        ctx.cfg, ctx.is_l = cfg, is_l
+        return zk.swoosh_forward(x, is_l)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        if ctx.cfg is None:
+            return zk.swoosh_backward(x, g, ctx.is_l), None, None
+        return zk.balancer_backward(x, g.contiguous(), *ctx.cfg, swoosh_l=ctx.is_l), None, None
+
+
+def balancer_swoosh(balancer: "Balancer", x: Tensor, is_l: bool) -> Tensor:
+    """SwooshL/R(balancer(x)) with the Balancer's random draw made here (as its forward would)."""
+    fires = balancer.fires(x)
+    return _BalancerSwooshFn.apply(x, balancer.cfg(x.ndim) if fires else None, is_l)
+
+
 def _prop_pos_to_mean(x: float) -> float:
     x = -1 + 2 * x
     eps = 1.0e-10

@@ -11,7 +11,7 @@ from speech2text_amd import zip_kernels as zk
 
 from speech2text_amd.model.layer.scaling import (Linear, Balancer, BiasNorm, Dropout3, FloatLike,
                                                  ScaledConv2d, ScaleGrad, ScheduledFloat, SwooshL,
-                                                 SwooshR, Whiten)
+                                                 SwooshR, Whiten, balancer_swoosh)
 
 
 class ConvNeXt(nn.Module):
@@ -96,11 +96,20 @@ class Conv2dSubsampling(nn.Module):
 
     def forward(self, x: Tensor, x_lens: Tensor) -> Tuple[Tensor, Tensor]:
         x = x.unsqueeze(-1)                                     # (N,T,F,1) channel-last
-        for m in self.conv:
+        mods = list(self.conv)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
             if isinstance(m, nn.Conv2d):
                 x = zk.conv3x3_nhwc(x, m.weight, m.bias, m.stride, pad_w=m.padding[1])  # freq axis
+            elif (isinstance(m, Balancer) and i + 1 < len(mods) and isinstance(mods[i + 1], SwooshR)
+                  and x.is_cuda and m.channel_dim in (-1, x.ndim - 1)):
+                # Balancer + SwooshR: one autograd node, one backward pass over these (large) maps
+                x = balancer_swoosh(m, x, False)
+                i += 1
             else:
                 x = m(x)
+            i += 1
         x = self.convnext(x)                                    # (N,T',F',C)
         b, t, f, c = x.shape
         # reference flattens (c,f) c-major: out.weight columns are indexed c*F' + f

@@ -311,11 +311,15 @@ def _conv_bwd(m, dec, sv, x_in, g, T, B, k8):
     D = x_in.shape[1]
     W = m.out_proj.weight
     _wgrad(W, m.out_proj.bias, g, sv.a)
-    dy = zk.swoosh_backward(sv.y, zk.lt_matmul(1, g, W), False)
-    if fw:
-        dy = _whiten_bwd(m.whiten, sv.y, dy, sv.st)
-    if fb2:
-        dy = _balancer_bwd(m.balancer2, sv.y, dy)
+    dy = zk.lt_matmul(1, g, W)
+    if fb2 and not fw:                       # Swoosh backward rides in the Balancer's update pass
+        dy = _balancer_bwd(m.balancer2, sv.y, dy, swoosh_l=False)
+    else:
+        dy = zk.swoosh_backward(sv.y, dy, False)
+        if fw:
+            dy = _whiten_bwd(m.whiten, sv.y, dy, sv.st)
+        if fb2:
+            dy = _balancer_bwd(m.balancer2, sv.y, dy)
     chunk, K, wc, bc, wk, bk, scale = sv.cp
     plist = (wc, bc, wk, bk, scale)
     grads = zk.direct_grads(plist)
