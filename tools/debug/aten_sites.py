@@ -13,11 +13,12 @@ from speech2text_amd.build_task import TaskFactory  # noqa: E402
 from speech2text_amd.trainer import Trainer  # noqa: E402
 
 dev = torch.device("cuda:0")
-cfg = bench.c3_config(500)
+C2 = len(sys.argv) > 1 and sys.argv[1] == "C2"
+cfg = bench.c2_config(128) if C2 else bench.c3_config(500)
 random.seed(1234); np.random.seed(1234); torch.manual_seed(1234)
-task = TaskFactory.get("Pruned_Rnnt")(cfg)
+task = TaskFactory.get("CTC" if C2 else "Pruned_Rnnt")(cfg)
 tr = Trainer(**cfg["trainer"]).setup(task, dev); task.train()
-batch = bench.make_batch(0, 64, 10.0, 50, 500, dev)
+batch = bench.make_batch(0, 32, 10.0, 40, 128, dev) if C2 else bench.make_batch(0, 64, 10.0, 50, 500, dev)
 for i in range(4):
     tr.training_step(batch, i)
 torch.cuda.synchronize()
