@@ -445,6 +445,11 @@ def main(argv=None):
         note(f"warmup step {i}: {time.perf_counter() - tw:.3f} s, loss {float(loss):.4f}")
     if want == "auto":
         want = "s2t_relpos_attn_fwd"
+    if world > 1:                                           # every rank brackets the SAME entry
+        names = sorted(_native.parse_header())
+        t = torch.tensor([names.index(want)], device=device, dtype=torch.int64)
+        dist.broadcast(t, src=0)
+        want = names[int(t.item())]
     sync()
     _native.profile_begin(want)
     t0 = time.perf_counter()
@@ -491,7 +496,10 @@ def main(argv=None):
                        "utterance_seconds": args.seconds, "labels_per_utt": args.labels,
                        "parallelism": f"dp{world}", "final_loss": final_loss},
             "roofline": roofline_report(prof_timed, prof_all, want, step_flops, ms),
-            "cpu_baseline": cpu,
+            "cpu_baseline": cpu if cpu is not None else {
+                "value": None, "unit": "audio-seconds/sec", "cores": host_threads(), "kind": "port",
+                "sample": "not timed in this run (multi-rank or --no-cpu-baseline): the oracle "
+                          "step is timed on rank 0 of the N=1 run, see that line"},
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -33,7 +33,10 @@ int s2t_fbank_f32(const float* pcm, long pcm_stride, const long* num_samples, in
 /* ---- CTC: model/loss/ctc_loss.py:35-41 (log_softmax + nn.CTCLoss).
  * logits [B][T][V] batch-major; targets [B][tgt_stride]; loss_per_utt [B] (nll,
  * or 0 where infinite and zero_infinity); grad_logits [B][T][V] =
- * grad_scale[b] * d nll_b / d logits (NULL to skip). */
+ * grad_scale[b] * d nll_b / d logits (NULL to skip).  Umax (padded label width) may be at most
+ * S2T_CTC_MAX_LABELS: the 2U+1 lattice states of an utterance live in one workgroup's LDS
+ * (128 threads x up to 16 states each); a wider batch returns -4. */
+#define S2T_CTC_MAX_LABELS 1023
 long s2t_ctc_workspace_floats(int B, int T, int Umax);
 int s2t_ctc_loss_fwd_bwd(const float* logits, const long* targets, long tgt_stride,
                          const long* in_len, const long* tgt_len, int B, int T, int V, int Umax,
@@ -231,7 +234,7 @@ int s2t_dwconv2d_nhwc_wgrad(const float* x, const float* dy, int N, int H, int W
 
 /* ---- fused multi-tensor ScaledAdam + grad-norm clip + zero_grad over one flat fp32 buffer
  * (optimizer/scaled_adam.py:408-527 _get_clipping_scale, :563-736 _step_one_batch / _size_update
- * / _step / _step_scalar; the trainer's gradient_clip_val of config/training/*.yaml `trainer:`).
+ * / _step / _step_scalar; the trainer's gradient_clip_val of config/training/<task>.yaml `trainer:`).
  * The flat buffer holds every tensor padded to 16 bytes; a host-built chunk table cuts each
  * tensor into chunks of s2t_optim_chunk_elems() elements: chunk_off/len/seg [nchunks],
  * seg_chunk_begin [nseg+1], seg_len [nseg].  s2t_seg_stats writes partial [nchunks][3] =

@@ -12,6 +12,7 @@
 //      CTCLoss' gradient and the log_softmax backward)
 // Logits stay batch-major (B,T,V); no transposed copy is ever made.
 #include "common.h"
+#include "../../include/s2t_mi355.h"
 
 namespace {
 
@@ -52,6 +53,8 @@ __global__ __launch_bounds__(64) void ctc_lse_gather_kernel(
 // threads 128..255 run the beta recursion backwards, one barrier per time step for both.  The
 // emission row of the NEXT step is prefetched into registers before the barrier.  alpha and
 // beta (log domain) go to the workspace; the gradient kernel forms the occupancies.
+// MAXR = lattice states per thread: 128 * MAXR >= 2U+1 (4 serves U <= 255, 16 serves U <= 1023).
+template <int MAXR>
 __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(
     const float* __restrict__ lp, const long* __restrict__ targets, long tgt_stride,
     const long* __restrict__ in_len, const long* __restrict__ tgt_len, int T, int Smax, int blank,
@@ -93,7 +96,6 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(
   const float* lpb = lp + (long)b * T * Smax;
   float* aw = alpha_ws + (long)b * T * Smax;
   float* bw = beta_ws + (long)b * T * Smax;
-  constexpr int MAXR = 4;                                // up to 512 lattice states (U <= 255)
   float nxt[MAXR];
   // step 0
   {
@@ -233,7 +235,8 @@ extern "C" int s2t_ctc_loss_fwd_bwd(const float* logits, const long* targets, lo
                                     float* workspace, float* loss_per_utt, float* grad_logits,
                                     void* stream) {
   if (B <= 0) return 0;
-  if (T <= 0 || V <= 0 || Umax < 0 || Umax > 255 || blank < 0 || blank >= V) return -1;
+  if (T <= 0 || V <= 0 || Umax < 0 || blank < 0 || blank >= V) return -1;
+  if (Umax > S2T_CTC_MAX_LABELS) return -4;   // 2U+1 lattice states must fit 128 x 16 per workgroup
   hipStream_t st = (hipStream_t)stream;
   const int Smax = 2 * Umax + 1;
   const long lat = (long)B * T * Smax;
@@ -246,9 +249,15 @@ extern "C" int s2t_ctc_loss_fwd_bwd(const float* logits, const long* targets, lo
                      tgt_stride, in_len, tgt_len, T, V, Smax, blank, lse, lp);
   S2T_CHECK_LAUNCH();
   const size_t smem1 = sizeof(float) * 4 * (Smax + 2) + Smax + 16;
-  hipLaunchKernelGGL(ctc_alpha_beta_kernel, dim3(B), dim3(256), smem1, st, lp, targets,
-                     tgt_stride, in_len, tgt_len, T, Smax, blank, zero_infinity, alpha, beta, nll,
-                     loss_per_utt);
+#define S2T_CTC_AB(R)                                                                          \
+  hipLaunchKernelGGL(ctc_alpha_beta_kernel<R>, dim3(B), dim3(256), smem1, st, lp, targets,       \
+                     tgt_stride, in_len, tgt_len, T, Smax, blank, zero_infinity, alpha, beta, nll, \
+                     loss_per_utt)
+  if (Smax <= 128 * 2) S2T_CTC_AB(2);
+  else if (Smax <= 128 * 4) S2T_CTC_AB(4);
+  else if (Smax <= 128 * 8) S2T_CTC_AB(8);
+  else S2T_CTC_AB(16);
+#undef S2T_CTC_AB
   S2T_CHECK_LAUNCH();
   if (grad_logits && grad_scale) {
     hipLaunchKernelGGL(ctc_grad_kernel, dim3(T, B), dim3(256), sizeof(float) * V, st, logits, lse,

@@ -217,7 +217,15 @@ __global__ __launch_bounds__(256) void scaled_adam_apply_kernel(
   const long off = chunk_off[b];
   const int len = chunk_len[b];
   const float* o = segc + (long)chunk_seg[b] * kSegC;
-  if (o[9] == 0.f) return;
+  if (o[9] == 0.f) {
+    // trainable tensor that no optimizer group lists: it is never updated, but its gradient must
+    // not pile up across steps (it would keep growing the global clip norm)
+    if (zero_grad) {
+      float4* z4 = reinterpret_cast<float4*>(g + off);
+      for (int i = threadIdx.x; i < (len >> 2); i += 256) z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return;
+  }
   const float gm = o[0], sstep = o[1], coef = o[2], bc = o[3], lim = o[4], beta1 = o[5],
               beta2 = o[6], eps = o[7];
   const bool sanitize = o[8] != 0.f;

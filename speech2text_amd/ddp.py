@@ -9,6 +9,12 @@ launched strictly in bucket order so every rank issues the same sequence of coll
 Parameters that never receive a gradient (e.g. Zipformer2EncoderLayer.bypass_scale, reference
 zipformer.py:1011-1012) keep their pre-zeroed gradient and are learned as "static unused"
 after the first step, which is what find_unused_parameters achieves by graph traversal.
+The learned set only GROWS (per-parameter maximum of the calls seen in any step): a parameter
+that skips a step defers its bucket (and the later ones) to finish(); a parameter that fires
+for the first time AFTER its bucket went out cannot be merged into a collective that is already
+in flight, so that step's gradient is zeroed on EVERY rank (the ranks agree through a flag that
+rides in the step's scalar all-reduce -- no rank raises, none is left waiting in a collective),
+`dropped_steps` counts it, and from the next step on the parameter is waited for.
 
 Two forms of the exchange (`algo`):
   "allreduce"  one in-place all-reduce(SUM) per bucket, then a divide over the whole bucket;
@@ -64,9 +70,12 @@ class GradReducer:
         self.bucket_members = [[q for q in range(n) if self.param_bucket[q] == b]
                                for b in range(len(self.buckets))]
         self._shards = {}
-        self._expected = None                        # params that produce grads (learned)
+        self._expected = None                        # param -> max #calls per step (learned, monotone)
         self._pending = None
         self._fired = {}
+        self._late = set()                           # fired after their bucket was launched
+        self.dropped_steps = 0                       # steps whose gradient was zeroed (see above)
+        self._drop_flags = []                        # device flags of recent steps (read lazily)
         self._next = 0                               # next bucket to launch (fixed order)
         self._hooks = []
         if self.world > 1:
@@ -92,11 +101,12 @@ class GradReducer:
             return
         b = self.param_bucket[q]
         if b < self._next:
-            raise RuntimeError(
-                f"parameter #{q} produced a gradient after its bucket {b} was reduced (the "
-                "set of parameters that receive gradients changed between steps); use "
-                "GradReducer(overlap=False) / S2T_DDP_OVERLAP=0 for such models")
-        if q in self._expected:
+            # the bucket is already with the exchange stream: this contribution cannot join it.
+            # Never raise on one rank (the others would hang in the collective): finish() makes
+            # all ranks agree to zero this step's gradient; the parameter joins the expected set.
+            self._late.add(q)
+            return
+        if self._fired[q] <= self._expected.get(q, 0):
             self._pending[b] -= 1
             while self._next < len(self.buckets) and self._pending[self._next] == 0:
                 self._launch(self._next)
@@ -147,6 +157,7 @@ class GradReducer:
     def prepare(self):
         """Call before backward of a micro-step whose gradients must be synchronised."""
         self._fired = {}
+        self._late = set()
         self._next = 0
         if self._expected is not None and self.overlap:
             self._pending = [sum(self._expected.get(q, 0) for q in m)
@@ -161,20 +172,44 @@ class GradReducer:
             return extra
         while self._next < len(self.buckets):
             self._launch(self._next)
+        # one small all-reduce per step: [logged scalars ..., "some rank fired late" flag]
+        fg = self.store.flat_g
+        flag = torch.full((1,), 1.0 if self._late else 0.0, dtype=fg.dtype, device=fg.device)
+        n_extra = 0 if extra is None else extra.numel()
+        pack = flag if extra is None else torch.cat([extra.reshape(-1).to(fg.dtype), flag])
         if self._is_cuda:
             main = torch.cuda.current_stream()
             with torch.cuda.stream(self._stream):
-                if extra is not None:
-                    self._stream.wait_stream(main)      # `extra` was produced on the main stream
-                    dist.all_reduce(extra, op=dist.ReduceOp.SUM, group=self.pg)
-                    extra.div_(self.world)
+                self._stream.wait_stream(main)          # `pack` was produced on the main stream
+                dist.all_reduce(pack, op=dist.ReduceOp.SUM, group=self.pg)
             main.wait_stream(self._stream)
-        elif extra is not None:
-            dist.all_reduce(extra, op=dist.ReduceOp.SUM, group=self.pg)
-            extra.div_(self.world)
-        if self._expected is None or self._fired != self._expected:
+        else:
+            dist.all_reduce(pack, op=dist.ReduceOp.SUM, group=self.pg)
+        if self.overlap and self._pending is not None:
+            # zero the step on every rank if any rank fired late (device-side: no host sync)
+            keep = (pack[n_extra:] == 0).to(fg.dtype)
+            fg.mul_(keep)
+            self._drop_flags.append(pack[n_extra:])
+            if len(self._drop_flags) > 64:
+                self.poll_dropped()
+        if extra is not None:
+            extra = (pack[:n_extra] / self.world).reshape(extra.shape).to(extra.dtype)
+        # the expected set only grows: per-parameter maximum of the calls seen in a step
+        if self._expected is None:
             self._expected = dict(self._fired)
+        else:
+            for q, c in self._fired.items():
+                if c > self._expected.get(q, 0):
+                    self._expected[q] = c
         return extra
+
+    def poll_dropped(self):
+        """Folds the recorded device flags into `dropped_steps` (a host read: call it off the
+        hot path, e.g. when logging)."""
+        if self._drop_flags:
+            self.dropped_steps += int((torch.cat(self._drop_flags) > 0).sum().item())
+            self._drop_flags = []
+        return self.dropped_steps
 
     @contextlib.contextmanager
     def no_sync(self):

@@ -11,6 +11,7 @@ import torch
 from . import _native as N
 
 _NEG_INF = float("-inf")
+CTC_MAX_LABELS = 1023     # == S2T_CTC_MAX_LABELS (include/s2t_mi355.h)
 
 
 def _dev_check(*ts):
@@ -107,6 +108,10 @@ class _CtcLoss(torch.autograd.Function):
         else:
             scale = torch.ones(B, device=dev)
         scale = scale.contiguous()
+        if U > CTC_MAX_LABELS:
+            raise ValueError(f"CTC: padded label width {U} exceeds the kernel's limit of "
+                             f"{CTC_MAX_LABELS} labels per utterance (2U+1 lattice states are "
+                             "held in one workgroup's LDS, csrc/ctc.hip)")
         ws = torch.empty(N.lib().s2t_ctc_workspace_floats(B, T, U), dtype=torch.float32,
                          device=dev)
         per = torch.empty(B, dtype=torch.float32, device=dev)

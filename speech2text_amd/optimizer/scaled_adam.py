@@ -147,15 +147,17 @@ class ScaledAdam(Optimizer):
             if cs is not None and k > 0 and (k % period == 0 or (k in (10, 20, 40) and k < period)):
                 rare.append(s)
             s["step"] = k + 1
+        for s in rare:                                   # the only host sync (every `period` steps),
+            if int(s["istate"][2]) != 0:                 # BEFORE the update touches the parameters
+                for s2 in self._gstate:
+                    s2["step"] -= 1
+                raise RuntimeError("Too many grads were not finite")
         N.profile_note("s2t_scaled_adam_apply", 8 * nbytes)
         N.check(L.s2t_scaled_adam_apply(N.fp(st.flat_p), N.fp(st.flat_g), N.fp(self._delta),
                                         N.fp(self._eas), N.ip(tb["chunk_off"]),
                                         N.ip(tb["chunk_len"]), N.ip(tb["chunk_seg"]), tb["nchunks"],
                                         N.fp(self._segc), int(self.zero_grad_in_step), stream),
                 "s2t_scaled_adam_apply")
-        for s in rare:                                   # the only host sync (every `period` steps)
-            if int(s["istate"][2]) != 0:
-                raise RuntimeError("Too many grads were not finite")
 
     # ---- the same arithmetic as torch ops (CPU tensors: host-logic tests)
     def _step_torch(self):
@@ -232,6 +234,98 @@ class ScaledAdam(Optimizer):
             s["step"] = k + 1
         if self.zero_grad_in_step:
             st.zero_grad()
+
+    # ------------------------------------------------------------------ checkpoint interchange
+    def _shape_batches(self, group, s):
+        """The reference keeps its state per BATCH of same-shaped tensors, in the state of the
+        batch's first parameter, batches ordered by (dtype, *shape) (optimizer/scaled_adam.py:
+        63-101): -> [[(param, store index)]] in that order."""
+        trainable = [p for p in group["params"] if p.requires_grad]
+        by_key = {}
+        for j, p in enumerate(trainable):
+            by_key.setdefault((str(p.dtype), *p.shape), []).append((p, s["lo"] + j))
+        return [by_key[k] for k in sorted(by_key)]
+
+    def state_dict(self):
+        """torch's optimizer state_dict layout with the reference's per-batch entries (`step`,
+        `delta`, `exp_avg_sq`, `param_rms`, `scale_exp_avg_sq`, `scale_grads`; `model_norms`,
+        `model_norm_threshold`, `num_clipped` on the group's first batch), gathered from the
+        flat buffers: a reference checkpoint's optimizer state loads here and vice versa."""
+        if self._gstate is None:
+            self._init()
+        st = self.store
+        state, groups, start = {}, [], 0
+
+        def rows(buf, batch):
+            return torch.stack([buf[st.offsets[i]:st.offsets[i] + st.lengths[i]].view(p.shape)
+                                for p, i in batch]).clone()
+
+        for group, s in zip(self.param_groups, self._gstate):
+            ps = group["params"]
+            index = {id(p): start + j for j, p in enumerate(ps)}
+            packed = {k: v for k, v in group.items() if k != "params"}
+            packed["params"] = list(range(start, start + len(ps)))
+            groups.append(packed)
+            P = group["size_update_period"]
+            for bi, batch in enumerate(self._shape_batches(group, s)):
+                p0 = batch[0][0]
+                e = {"step": s["step"], "delta": rows(self._delta, batch),
+                     "exp_avg_sq": rows(self._eas, batch)}
+                if p0.numel() > 1:
+                    loc = torch.tensor([i - s["lo"] for _, i in batch], device=st.flat_p.device)
+                    shp = (len(batch),) + (1,) * p0.dim()
+                    e["param_rms"] = s["param_rms"][loc].view(shp).clone()
+                    e["scale_exp_avg_sq"] = s["scale_exp_avg_sq"][loc].view(shp).clone()
+                    e["scale_grads"] = s["scale_grads"][:, loc].reshape((P,) + shp).clone()
+                if bi == 0 and group["clipping_scale"] is not None and s["step"] > 1:
+                    e["model_norms"] = s["model_norms"].clone()
+                    if int(s["istate"][0]):
+                        e["model_norm_threshold"] = float(s["fstate"][0])
+                        e["num_clipped"] = int(s["istate"][1])
+                state[index[id(p0)]] = e
+            start += len(ps)
+        return {"state": state, "param_groups": groups}
+
+    @torch.no_grad()
+    def load_state_dict(self, sd):
+        if self._gstate is None:
+            self._init()
+        st = self.store
+        if len(sd["param_groups"]) != len(self.param_groups):
+            raise ValueError("loaded state dict has a different number of parameter groups")
+        start = 0
+        for group, saved, s in zip(self.param_groups, sd["param_groups"], self._gstate):
+            if len(saved["params"]) != len(group["params"]):
+                raise ValueError("loaded state dict contains a parameter group that doesn't match "
+                                 "the size of optimizer's group")
+            for k, v in saved.items():
+                if k != "params":
+                    group[k] = v
+            ps = group["params"]
+            index = {id(p): start + j for j, p in enumerate(ps)}
+            for bi, batch in enumerate(self._shape_batches(group, s)):
+                e = sd["state"].get(index[id(batch[0][0])])
+                if e is None:
+                    e = sd["state"].get(str(index[id(batch[0][0])]))
+                if e is None:
+                    continue
+                s["step"] = int(e["step"])
+                for b, (p, i) in enumerate(batch):
+                    o, n = st.offsets[i], st.lengths[i]
+                    self._delta[o:o + n].copy_(e["delta"][b].reshape(-1))
+                    self._eas[o:o + n].copy_(e["exp_avg_sq"][b].reshape(-1))
+                    if "param_rms" in e:
+                        j = i - s["lo"]
+                        s["param_rms"][j] = e["param_rms"][b].reshape(())
+                        s["scale_exp_avg_sq"][j] = e["scale_exp_avg_sq"][b].reshape(())
+                        s["scale_grads"][:, j] = e["scale_grads"][:, b].reshape(-1)
+                if bi == 0 and "model_norms" in e:
+                    s["model_norms"].copy_(e["model_norms"])
+                    if "model_norm_threshold" in e:
+                        s["fstate"][0] = float(e["model_norm_threshold"])
+                        s["istate"][0] = 1
+                        s["istate"][1] = int(e.get("num_clipped", 0))
+            start += len(ps)
 
     def zero_grad(self, set_to_none: bool = False):
         if self.store is not None:

@@ -9,6 +9,7 @@ import torch
 import torch.distributed as dist
 
 from speech2text_amd.ddp import GradReducer, broadcast_parameters
+from speech2text_amd import zip_kernels as zk
 from speech2text_amd.flat import get_store
 
 
@@ -88,6 +89,9 @@ class Trainer:
         micro-batch of an accumulation window), then clip / optimizer / scheduler."""
         task = self.task
         last = (self.micro + 1) % self.accum == 0
+        on_gpu = self.device.type == "cuda"
+        if on_gpu:
+            zk.side_sync()            # a backward that raised leaves the side stream un-joined
         if last:
             self.reducer.prepare()
             loss = task.training_step(batch, batch_idx)
@@ -106,6 +110,8 @@ class Trainer:
             logged = self.reducer.finish(logged)
             if logged is not None:
                 task.logged = dict(zip(task.logged.keys(), logged.unbind(0)))
+            if on_gpu:
+                zk.side_sync()        # weight gradients of this step are complete before we read
             self._clip()
             self.optimizer.step()
             self.scheduler.step()

@@ -51,6 +51,7 @@ def swoosh_forward(x, is_l):
     off, c = _SW[is_l]
     x = _c16(x.float())
     y = torch.empty_like(x)
+    N.profile_note("s2t_swoosh_fwd", 8.0 * x.numel())
     N.check(N.lib().s2t_swoosh_fwd(N.fp(x), N.fp(y), x.numel(), off, c, N.stream()), "swoosh")
     return y
 
@@ -62,6 +63,7 @@ def swoosh_backward(x, g, is_l, mask=None):
     x = _c16(x.float())
     g = _c16(g.float())
     d = torch.empty_like(x)
+    N.profile_note("s2t_swoosh_bwd", 12.0 * x.numel())
     N.check(N.lib().s2t_swoosh_bwd(N.fp(x), N.fp(g), N.fp(d), x.numel(), off, N.stream()),
             "swoosh_bwd")
     return d if mask is None else d * mask
@@ -123,6 +125,7 @@ class _BiasNorm(torch.autograd.Function):
         y = torch.empty_like(x)
         scales = torch.empty(rows, dtype=torch.float32, device=x.device)
         bias = bias.contiguous().float()
+        N.profile_note("s2t_biasnorm_fwd", 8.0 * x.numel())
         N.check(N.lib().s2t_biasnorm_fwd(N.fp(x), N.fp(bias),
                                          N.fp(log_scale.reshape(1).contiguous().float()), rows, D,
                                          N.fp(y), N.fp(scales), N.stream()), "biasnorm_fwd")
@@ -137,6 +140,7 @@ class _BiasNorm(torch.autograd.Function):
         rows = x.numel() // D
         dx = torch.empty_like(x)
         acc = torch.zeros(D + 1, dtype=torch.float32, device=x.device)
+        N.profile_note("s2t_biasnorm_bwd", 12.0 * x.numel())
         N.check(N.lib().s2t_biasnorm_bwd(N.fp(x), N.fp(bias), N.fp(scales), N.fp(g), rows, D,
                                          N.fp(dx), N.fp(acc), ctypes_off(acc, D), N.stream()),
                 "biasnorm_bwd")
@@ -198,6 +202,7 @@ def balancer_backward(x, g, min_mean, max_mean, min_rms, max_rms, grad_scale, ch
             out = torch.empty_like(g2)
         ws = _balancer_workspace(x.device)
         ws[1] ^= 1
+        N.profile_note("s2t_balancer_bwd", 4.0 * rows * C * 4)     # x twice (stats, update), g, out
         N.check(N.lib().s2t_balancer_bwd(N.raw(x2, torch.float32), x2.stride(0),
                                          N.raw(g2, torch.float32), g2.stride(0), rows, C, min_mean,
                                          max_mean, min_rms, max_rms, grad_scale,
@@ -330,6 +335,7 @@ def whiten_backward(x, g, stats, limit, grad_scale):
     if g2.data_ptr() % 16:
         g2 = g2.clone()
     out = torch.empty_like(g2)
+    N.profile_note("s2t_whiten_apply", 12.0 * g2.numel())
     N.check(N.lib().s2t_whiten_apply(N.fp(g2), N.fp(pg), g2.numel(), float(grad_scale), N.fp(sums),
                                      N.fp(out), N.stream()), "s2t_whiten_apply")
     return out.view(shp), True
@@ -935,6 +941,18 @@ def _side_join():
     _Side.queued = False
 
 
+def side_sync():
+    """Orders the current stream after whatever the side stream holds and drops the operand
+    references.  The trainer calls it at the start of every step and again before the optimizer:
+    autograd skips its end-of-backward callbacks when backward raises (e.g. a batch skipped after
+    an out-of-memory error), which would otherwise leave `queued` set -- later backwards would
+    then never join the side stream and the optimizer could read gradients still being written."""
+    if _Side.handle is not None:
+        N.check(N.lib().s2t_stream_order(_Side.handle, N.stream()), "s2t_stream_order(sync)")
+    _Side.keep.clear()
+    _Side.queued = False
+
+
 def _side_launch_stream(*tensors):
     """Orders the side stream after the work enqueued so far on the current stream and returns
     its handle; falls back to the current stream outside a backward pass."""
@@ -1086,6 +1104,8 @@ def lt_matmul(mode, x2, w2, bias=None, resid2=None, out_shape=None):
         return out
     w2 = w2 if (w2.stride(1) == 1 and w2.stride(0) >= w2.shape[1]) else w2.contiguous()
     ws = _lt_workspace(x2.device)
+    N.profile_note("s2t_linear_lt", 4.0 * (R * (Nf + Kf) + Nf * Kf + (R * cols if resid2 is not None else 0)),
+                   2.0 * R * Nf * Kf)
     rc = N.lib().s2t_linear_lt(mode, N.raw(x2, torch.float32), x2.stride(0),
                                N.raw(w2, torch.float32), w2.stride(0), N.fp(bias),
                                None if resid2 is None else N.raw(resid2, torch.float32),

@@ -471,6 +471,7 @@ class _LayerFn(torch.autograd.Function):
         norm = layer.norm
         x10 = _e(R, D, dev)
         s.nscales = torch.empty(R, dtype=_F32, device=dev)
+        N.profile_note("s2t_biasnorm_fwd", 8.0 * R * D)
         N.check(L.s2t_biasnorm_fwd(N.fp(x9), N.fp(norm.bias),
                                    ctypes.c_void_p(norm.log_scale.data_ptr()), R, D, N.fp(x10),
                                    N.fp(s.nscales), st), "biasnorm_fwd")
@@ -478,7 +479,7 @@ class _LayerFn(torch.autograd.Function):
         # the stack's feature mask rides in the last bypass unless a gradient-shaping op of this
         # call needs the unmasked output
         s.fm, s.fm_fused = fm, fm is not None and not (d.wh_out or d.bal2)
-        N.profile_note("s2t_bypass_fwd", 12.0 * R * D)
+        N.profile_note("s2t_bypass_fwd_mask" if s.fm_fused else "s2t_bypass_fwd", 12.0 * R * D)
         if s.fm_fused:
             N.check(L.s2t_bypass_fwd_mask(N.fp(x0), N.fp(x10), N.fp(layer.bypass.bypass_scale),
                                           N.fp(fm), B, R, D, N.fp(x11), st), "s2t_bypass_fwd_mask")
@@ -521,7 +522,7 @@ class _LayerFn(torch.autograd.Function):
         byp = layer.bypass
         d0 = _e(R, D, dev)
         g10 = _e(R, D, dev)
-        N.profile_note("s2t_bypass_bwd", 20.0 * R * D)
+        N.profile_note("s2t_bypass_bwd_mask" if s.fm_fused else "s2t_bypass_bwd", 20.0 * R * D)
         if s.fm_fused:
             N.check(L.s2t_bypass_bwd_mask(N.fp(x0), N.fp(x10), N.fp(byp.bypass_scale), N.fp(g),
                                           N.fp(s.fm), B, R, D, N.fp(d0), N.fp(g10), off(0), st),
@@ -532,6 +533,7 @@ class _LayerFn(torch.autograd.Function):
 
         norm = layer.norm
         g9 = _e(R, D, dev)
+        N.profile_note("s2t_biasnorm_bwd", 12.0 * R * D)
         N.check(L.s2t_biasnorm_bwd(N.fp(x9), N.fp(norm.bias), N.fp(s.nscales), N.fp(g10), R, D,
                                    N.fp(g9), off(2 * D), off(3 * D), st), "biasnorm_bwd")
         if d.bal1:
@@ -545,7 +547,7 @@ class _LayerFn(torch.autograd.Function):
         mid = layer.bypass_mid
         d0m = _e(R, D, dev)
         g5 = _e(R, D, dev)
-        N.profile_note("s2t_bypass_bwd", 24.0 * R * D)
+        N.profile_note("s2t_bypass_bwd_acc", 24.0 * R * D)
         N.check(L.s2t_bypass_bwd_acc(N.fp(x0), N.fp(x5), N.fp(mid.bypass_scale), N.fp(g6),
                                      N.fp(d0), R, D, N.fp(d0m), N.fp(g5), off(D), st),
                 "s2t_bypass_bwd_acc")

@@ -86,3 +86,78 @@ def test_grad_reducer_world2_gloo(algo):
         assert ok, f"rank {rank}: gradients differ from the 2-replica average"
         assert nb >= 3
         assert learned, "unused parameter should be excluded from the expected set"
+
+
+def _late_worker(rank, world, port, q):
+    """A parameter that starts to receive gradients at step 2, on rank 0 only, and whose
+    gradient arrives after its bucket was launched."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from speech2text_amd.ddp import GradReducer, broadcast_parameters
+    from speech2text_amd.flat import FlatStore
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16),
+                              torch.nn.Tanh(), torch.nn.Linear(16, 3))
+    gate = torch.nn.Parameter(torch.ones(6))            # last in the store -> first bucket
+    params = list(net.parameters()) + [gate]
+    store = FlatStore(params)
+    broadcast_parameters(store)
+    red = GradReducer(store, bucket_bytes=4 * 120)
+    g = torch.Generator().manual_seed(11)
+    xs = torch.randn(2, 8, 6, generator=g)
+    ys = torch.randn(2, 8, 3, generator=g)
+
+    def loss_fn(r, use_gate):
+        x = xs[r] * gate if use_gate else xs[r]         # used FIRST in forward: gradient comes last
+        return ((net(x) - ys[r]) ** 2).mean()
+
+    norms, gate_grads = [], []
+    for step in range(5):
+        store.zero_grad()
+        red.prepare()
+        loss_fn(rank, step >= 2 and rank == 0).backward()
+        red.finish()
+        norms.append(float(store.flat_g.abs().sum()))
+        gate_grads.append(gate.grad.clone())
+    dropped = red.poll_dropped()
+    # oracle for the steps after the drop: plain average of the two ranks' gradients
+    with red.no_sync():
+        ref = []
+        for r in range(world):
+            store.zero_grad()
+            loss_fn(r, r == 0).backward()
+            ref.append(store.flat_g.clone())
+        store.zero_grad()
+        red.prepare()
+        loss_fn(rank, rank == 0).backward()
+    exp = (ref[0] + ref[1]) / world
+    # redo the last step synchronised and compare with the oracle
+    store.zero_grad()
+    red.prepare()
+    loss_fn(rank, rank == 0).backward()
+    red.finish()
+    ok_last = torch.allclose(store.flat_g, exp, atol=1e-6)
+    q.put((rank, norms, dropped, ok_last, float(gate_grads[4].abs().sum())))
+    dist.destroy_process_group()
+
+
+def test_late_parameter_does_not_hang_or_raise():
+    """a parameter that begins to fire late must neither raise on one rank (hang) nor
+    corrupt the step: all ranks zero that step's gradient, then wait for it from then on."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_late_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=90) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, norms, dropped, ok_last, gate_abs in res:
+        assert norms[0] > 0 and norms[1] > 0
+        assert norms[2] == 0.0, f"rank {rank}: the step with the late gradient must be zeroed"
+        assert norms[3] > 0 and norms[4] > 0
+        assert dropped == 1, (rank, dropped)
+        assert ok_last, f"rank {rank}: gradients after the drop differ from the 2-rank average"
+        assert gate_abs > 0, "the late parameter's gradient is averaged from then on (rank 1 too)"

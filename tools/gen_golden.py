@@ -205,6 +205,38 @@ def gen_scaledadam():
     print("scaledadam lrs", lrs[:3], lrs[-1])
 
 
+def gen_scaledadam_state():
+    """The reference ScaledAdam's state_dict after 15 of the 30 steps of gen_scaledadam (same
+    seeds), flattened to arrays, plus the parameters at that point: the checkpoint-interchange
+    fixture (optimizer/scaled_adam.py:30-109 keeps the state per batch of same-shaped tensors)."""
+    import torch
+    ref_import.install_stubs()
+    from optimizer.scaled_adam import ScaledAdam
+    from optimizer.optim_setup import Eden
+    torch.manual_seed(0)
+    shapes = [(5, 7), (3,), (), (5, 7), (4, 2, 3)]
+    ps = [torch.nn.Parameter(torch.randn(s) * (0.1 if i == 3 else 1.0)) for i, s in enumerate(shapes)]
+    opt = ScaledAdam(ps, lr=0.045, clipping_scale=2.0, clipping_update_period=6)
+    sched = Eden(opt, lr_batches=10, warmup_batches=4)
+    g = torch.Generator().manual_seed(1)
+    for it in range(15):
+        for i, p in enumerate(ps):
+            p.grad = (torch.randn(p.shape, generator=g) * (5.0 if it % 7 == 3 else 1.0)).clone()
+        opt.step()
+        sched.step()
+    sd = opt.state_dict()
+    out = {f"p14_{i}": p.detach().numpy().copy() for i, p in enumerate(ps)}
+    keys = []
+    for idx, e in sd["state"].items():
+        for k, v in e.items():
+            out[f"state{idx}_{k}"] = v.numpy() if torch.is_tensor(v) else np.asarray(v)
+            keys.append(f"{idx}:{k}")
+    out["keys"] = np.array(keys)
+    out["lr"] = np.asarray(sd["param_groups"][0]["lr"])
+    np.savez_compressed(os.path.join(OUT, "scaledadam_state_ref.npz"), **out)
+    print("scaledadam state keys", keys)
+
+
 def gen_subsampling():
     """Reference conformer Subsampling (rates 4/6/8); torchaudio is stubbed (third-party)."""
     import sys, types, importlib.machinery
