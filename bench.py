@@ -97,6 +97,45 @@ def c2_config(vocab=128, layers=12):
     }
 
 
+def c4_config(vocab=128, layers=12):
+    """CTC_Hybrid_Rnnt (config/training/conformer_hybrid_rnnt.yaml dims): shared conformer encoder
+    + CTC head + LSTM predictor + unpruned joiner with the 2-Linear out-projection, 0.8 * rnnt +
+    0.2 * ctc (task_factory/rnnt_task.py:304-363)."""
+    cfg = c2_config(vocab, layers)
+    cfg["task"] = {"type": "CTC_Hybrid_Rnnt", "name": "bench-c4", "export_path": "/tmp"}
+    cfg["predictor"] = {"model": "Lstm", "config": {
+        "num_symbols": vocab, "output_dim": 256, "symbol_embedding_dim": 256, "num_lstm_layers": 2,
+        "lstm_hidden_dim": 256, "lstm_layer_norm": True, "lstm_layer_norm_epsilon": 1e-3,
+        "lstm_dropout": 0.0}}
+    cfg["joiner"] = {"input_dim": 256, "output_dim": vocab, "inner_dim": 256, "activation": "tanh",
+                     "prune_range": -1}
+    cfg["loss"] = {"rnnt_weight": 0.8, "ctc_weight": 0.2,
+                   "rnnt_loss": {"model": "Rnnt", "config": {"blank_label": 0, "reduction": "mean"}},
+                   "ctc_loss": {"model": "CTC", "config": {"blank_label": 0, "reduction": "mean"}}}
+    return cfg
+
+
+def c5_config(layers=12):
+    """BEST-RQ SSL pre-training (config/training/conformer_ssl.yaml:45-97): random-projection
+    quantizer (720 -> 16, 8192 codes, cosine) + masked conformer + Projector to 8193 classes +
+    masked KL loss (task_factory/ssl_task.py:114-180)."""
+    cfg = c2_config(128, layers)
+    cfg["task"] = {"type": "SSL", "name": "bench-c5", "export_path": "/tmp"}
+    cfg["ssl_layer"] = {"model": "Best-RQ",
+                        "layer_config": {"cnn_kernel_size": [3, 3], "cnn_stride": [2, 2],
+                                         "feat_dim": 80, "num_codebooks": 1, "codebook_dim": 16,
+                                         "codebook_size": 8192, "label_basis": "cosine"},
+                        "masking_config": {"mask_proportion": 0.5, "mean_span_length": 1,
+                                           "span_select_type": "static", "min_num_spans": 1,
+                                           "no_overlap": False, "min_space": 0, "seed": 1234}}
+    cfg["logits_layer"] = {"model": "Projector", "config": {"input_dim": 256, "output_dim": 8193,
+                                                           "dropout_p": 0.0}}
+    cfg["loss"] = {"loss_select": "mask_loss", "model": "MaskedKLDiv",
+                   "config": {"num_classes": 8193, "scale_factor": 1.0, "label_smoothing": 0.1}}
+    cfg.pop("decoder", None)
+    return cfg
+
+
 def synth_pcm(rng, batch, seconds):
     """Band-limited noise + 3 sinusoids, clipped to [-1,1]."""
     n = int(seconds * SR)
@@ -248,6 +287,113 @@ def cpu_baseline_c2(cfg, state_dict, seconds=10.0, batch=4, n_labels=40, vocab=1
                       f"loss={float(loss.detach()):.4f}"}
 
 
+def _cpu_time(step, batch, seconds, steps, warmup, what):
+    times, loss = [], None
+    for it in range(steps + warmup):
+        t0 = time.perf_counter()
+        loss = step()
+        dt = time.perf_counter() - t0
+        if it >= warmup:
+            times.append(dt)
+    med = float(np.median(times))
+    return {"value": batch * seconds / med, "unit": "audio-seconds/sec", "cores": host_threads(),
+            "kind": "port",
+            "sample": f"{batch} x {seconds:g}s utterances, {warmup} warm-up + {steps} timed steps "
+                      f"(median {med:.2f} s) of the oracle {what} train step, loss={loss:.4f}"}
+
+
+def _oracle_sd(state_dict):
+    import torch
+    sd = {k: v.detach().to("cpu").clone() for k, v in state_dict.items()}
+    for k, v in sd.items():                                 # buffers (BatchNorm running stats) stay plain
+        if v.dtype.is_floating_point and "running_" not in k and "_ssl_layer" not in k:
+            v.requires_grad_(True)
+    return sd
+
+
+def cpu_baseline_c4(cfg, state_dict, seconds=10.0, batch=2, n_labels=60, vocab=128, steps=3,
+                    warmup=1):
+    """Oracle CTC_Hybrid_Rnnt step: numpy fbank, oracle conformer, LSTM predictor, unpruned joiner
+    with out-projection (oracle/heads.py), full-lattice RNN-T loss (oracle/k2_rnnt.py) + CTC."""
+    import torch
+    from oracle import conformer as OC
+    from oracle import fbank as ofb
+    from oracle import heads as H
+    from oracle import k2_rnnt as K2
+    torch.set_num_threads(host_threads())
+    sd = _oracle_sd(state_dict)
+    enc = {k[len("_encoder.encoder."):]: v for k, v in sd.items() if k.startswith("_encoder.encoder.")}
+    ec, pc = cfg["encoder"]["config"], cfg["predictor"]["config"]
+    rng = np.random.default_rng(20241218)
+    pcm = synth_pcm(rng, batch, seconds)
+    lab = torch.from_numpy(rng.integers(1, vocab - 1, size=(batch, n_labels)))
+    lab_len = torch.full((batch,), n_labels, dtype=torch.int64)
+
+    def step():
+        feats = np.stack([ofb.fbank(p, 80) for p in pcm])
+        x = torch.from_numpy(feats)
+        lens = torch.full((batch,), feats.shape[1], dtype=torch.int64)
+        y, ylen = OC.conformer_forward(enc, x, lens, ec["num_layers"], ec["num_heads"], training=True)
+        logits = H.projector(sd, "_decoder.decoder.", y)
+        l_ctc = torch.nn.functional.ctc_loss(logits.log_softmax(-1).transpose(0, 1), lab, ylen,
+                                             lab_len, blank=0, reduction="mean", zero_infinity=True)
+        po = H.lstm_predictor(sd, "_predictor.predictor._predictor.", lab, pc["num_lstm_layers"],
+                              pc["lstm_layer_norm"], pc["lstm_layer_norm_epsilon"])
+        joint = H.joiner_full(sd, "_joiner.", y, po, cfg["joiner"]["activation"])
+        l_rnnt = K2.rnnt_loss_full(joint, lab, ylen, lab_len)
+        loss = H.hybrid_task_loss(l_rnnt, l_ctc, cfg["loss"]["rnnt_weight"], cfg["loss"]["ctc_weight"])
+        loss.backward()
+        for v in sd.values():
+            v.grad = None
+        return float(loss.detach())
+
+    return _cpu_time(step, batch, seconds, steps, warmup, "C4 hybrid CTC + RNN-T")
+
+
+def cpu_baseline_c5(cfg, state_dict, seconds=30.0, batch=2, steps=3, warmup=1):
+    """Oracle BEST-RQ step: numpy fbank, quantizer labels (oracle/best_rq.py, fp64), half of the
+    label frames masked with N(0, 0.1) noise, oracle conformer, Projector, masked KL."""
+    import torch
+    from oracle import best_rq as OB
+    from oracle import conformer as OC
+    from oracle import fbank as ofb
+    from oracle import heads as H
+    torch.set_num_threads(host_threads())
+    sd = _oracle_sd(state_dict)
+    enc = {k[len("_encoder.encoder."):]: v for k, v in sd.items() if k.startswith("_encoder.encoder.")}
+    ec = cfg["encoder"]["config"]
+    pk = [k for k in sd if k.startswith("_ssl_layer") and "project" in k.lower()][0]
+    cbk = [k for k in sd if k.startswith("_ssl_layer") and "codebook" in k.lower()][0]
+    K = cfg["ssl_layer"]["layer_config"]["codebook_size"]
+    rng = np.random.default_rng(20241218)
+    pcm = synth_pcm(rng, batch, seconds)
+
+    def step():
+        feats = np.stack([ofb.fbank(p, 80) for p in pcm])
+        lens = np.full((batch,), feats.shape[1], dtype=np.int64)
+        labels = OB.make_labels(feats.astype(np.float64), sd[pk].numpy(), sd[cbk].numpy().reshape(1, K, 16))
+        nl = OB.label_lengths(lens)
+        T2 = labels.shape[2]
+        mask = np.zeros((batch, T2), np.float32)
+        x = feats.copy()
+        for b in range(batch):
+            idx = rng.choice(nl[b], nl[b] // 2, replace=False)
+            mask[b, idx] = 1.0
+            for t2 in idx:
+                x[b, 4 * t2:4 * t2 + 7] = rng.normal(0.0, 0.1, size=(min(7, x.shape[1] - 4 * t2), 80))
+        y, ylen = OC.conformer_forward(enc, torch.from_numpy(x), torch.from_numpy(lens),
+                                       ec["num_layers"], ec["num_heads"], training=True)
+        logits = H.projector(sd, "_logits_layer.decoder.", y)
+        loss = H.masked_kl_div(logits, torch.from_numpy(labels[0][:, :logits.shape[1]]),
+                               torch.from_numpy(mask[:, :logits.shape[1]]), K + 1, 1.0, 0.1)
+        loss.backward()
+        for v in sd.values():
+            v.grad = None
+        return float(loss.detach())
+
+    return _cpu_time(step, batch, seconds, steps, warmup, "C5 BEST-RQ SSL")
+
+
 # ------------------------------------------------------------------ roofline bookkeeping
 def _bound(p):
     """mfma when the call sites' algorithmic intensity exceeds the machine balance, else hbm."""
@@ -348,9 +494,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="C3", choices=["C3", "C2"])
+    ap.add_argument("--config", default="C3", choices=["C3", "C2", "C4", "C5"])
     ap.add_argument("--batch", type=int, default=None, help="per-rank batch (utterances)")
-    ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--seconds", type=float, default=None)
     ap.add_argument("--labels", type=int, default=None)
     ap.add_argument("--vocab", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -361,10 +507,13 @@ def parse_args(argv=None):
                     help="extra untimed steps with every entry point bracketed by HIP events")
     ap.add_argument("--launcher-selftest", action="store_true")
     args = ap.parse_args(argv)
-    d = {"C3": (64, 50, 500), "C2": (32, 40, 128)}[args.config]
+    # per-rank batch, labels per utterance, vocabulary, utterance seconds
+    d = {"C3": (64, 50, 500, 10.0), "C2": (32, 40, 128, 10.0), "C4": (16, 60, 128, 10.0),
+         "C5": (8, 1, 128, 30.0)}[args.config]
     args.batch = args.batch or d[0]
     args.labels = args.labels or d[1]
     args.vocab = args.vocab or d[2]
+    args.seconds = args.seconds or d[3]
     return args
 
 
@@ -401,7 +550,8 @@ def main(argv=None):
     from speech2text_amd.trainer import Trainer
 
     c3 = args.config == "C3"
-    cfg = c3_config(args.vocab) if c3 else c2_config(args.vocab)
+    cfg = {"C3": lambda: c3_config(args.vocab), "C2": lambda: c2_config(args.vocab),
+           "C4": lambda: c4_config(args.vocab), "C5": c5_config}[args.config]()
     random.seed(1234 + rank)
     np.random.seed(1234 + rank)
     torch.manual_seed(1234)                                 # same init on every rank
@@ -410,9 +560,17 @@ def main(argv=None):
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         note("timing the CPU baseline (oracle) ...")
         try:
-            fn = cpu_baseline if c3 else cpu_baseline_c2
-            cpu = fn(cfg, task.state_dict(), args.seconds, args.cpu_batch if c3 else 4,
-                     args.labels, args.vocab, steps=args.cpu_steps)
+            if args.config == "C3":
+                cpu = cpu_baseline(cfg, task.state_dict(), args.seconds, args.cpu_batch,
+                                   args.labels, args.vocab, steps=args.cpu_steps)
+            elif args.config == "C2":
+                cpu = cpu_baseline_c2(cfg, task.state_dict(), args.seconds, 4, args.labels,
+                                      args.vocab, steps=args.cpu_steps)
+            elif args.config == "C4":
+                cpu = cpu_baseline_c4(cfg, task.state_dict(), args.seconds, 2, args.labels,
+                                      args.vocab, steps=args.cpu_steps)
+            else:
+                cpu = cpu_baseline_c5(cfg, task.state_dict(), args.seconds, 2, steps=args.cpu_steps)
             note(f"cpu baseline: {cpu['value']:.2f} audio-s/s on {cpu['cores']} threads")
         except Exception as e:                              # a baseline failure must not abort
             note(f"cpu baseline FAILED: {type(e).__name__}: {e}")
@@ -480,18 +638,23 @@ def main(argv=None):
     if rank == 0:
         # zipformer fwd+bwd ~3.6 GFLOP per audio-second; conformer ~6.7
         step_flops = (3.6e9 if c3 else 6.7e9) * args.batch * args.seconds
-        name = ("zipformer pruned-RNN-T" if c3 else "conformer-CTC")
+        name = {"C3": "zipformer pruned-RNN-T", "C2": "conformer-CTC",
+                "C4": "conformer CTC_Hybrid_Rnnt", "C5": "conformer BEST-RQ SSL"}[args.config]
+        workload = {
+            "C3": "C3 zipformer-stateless pruned-RNN-T train step (fbank+fwd+bwd+allreduce+ScaledAdam),"
+                  " 500 BPE, prune_range 5, chunk_size -1",
+            "C2": "C2 conformer-CTC train step (fbank+fwd+bwd+allreduce+AdamW), 12 layers d=256, V=128",
+            "C4": "C4 CTC_Hybrid_Rnnt train step (fbank+conformer 12x256+CTC head+LSTM predictor+"
+                  "unpruned joiner w/ out-projection+RNN-T lattice loss, 0.8/0.2), V=128",
+            "C5": "C5 BEST-RQ SSL train step (fbank+quantizer 8192x16+masked conformer 12x256+"
+                  "Projector 8193+masked KL), 30 s clips"}[args.config]
         out = {
             "metric": f"audio-seconds/sec (train step, {name})",
             "value": audio_s / dt, "unit": "audio-seconds/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": ("C3 zipformer-stateless pruned-RNN-T train step (fbank+fwd+bwd"
-                                    "+allreduce+ScaledAdam), 500 BPE, prune_range 5, chunk_size -1"
-                                    if c3 else
-                                    "C2 conformer-CTC train step (fbank+fwd+bwd+allreduce+AdamW), "
-                                    "12 layers d=256, V=128"),
+            "config": {"workload": workload,
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "utterance_seconds": args.seconds, "labels_per_utt": args.labels,
                        "parallelism": f"dp{world}", "final_loss": final_loss},

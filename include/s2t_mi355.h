@@ -277,7 +277,8 @@ int s2t_gemm_f32(int mode, const float* A, long lda, const float* B, long ldb, f
 
 /* The weight-gradient GEMMs of one layer in ONE launch (mode TN of s2t_gemm_f32, 64x64 tiles):
  * for each problem  C[M,N] += A[K,M]^T . B[K,N]  and  colsum[m] += sum_k A[k][m]  (colsum may be
- * NULL).  A = the gradient of a Linear's output (rows x out_features), B = its input
+ * NULL), both scaled by `alpha` (the conformer's 0.5 feed-forward residual weight rides here
+ * instead of in a scaling pass over the gradient).  A = the gradient of a Linear's output (rows x out_features), B = its input
  * (rows x in_features), C / colsum = the weight / bias gradient views of the flat gradient buffer
  * (what loss.backward() leaves in .grad for every nn.Linear of
  * model/encoder/zipformer.py:1095-1221).  `probs` is a HOST array of n entries. */
@@ -290,6 +291,7 @@ typedef struct S2tTnProblem {
   long ldc;
   int M, N, K;
   float* colsum;
+  float alpha;
 } S2tTnProblem;
 int s2t_gemm_tn_grouped(int n, const S2tTnProblem* probs, void* stream);
 
@@ -413,6 +415,56 @@ int s2t_nonlin_out_bwd(const float* g, const float* z, const float* u, int T, in
                        float* du, void* stream);
 int s2t_nonlin_gate_bwd(const float* dxs, const float* u, int T, int B, int C, float* du,
                         void* stream);
+
+/* ---- conformer block (torchaudio.models.Conformer as called at model/encoder/conformer.py:
+ * 170-178,193; block structure in csrc/conf_elem.hip).  All (rows, C) tensors row-major fp32,
+ * rows ordered (t, b), C % 4 == 0, C <= 1024, 16-byte aligned.
+ * s2t_layernorm_fwd: nn.LayerNorm.  y != NULL: the input is x + alpha * y (the layer's residual
+ * sums "0.5 * ffn(x) + x" / "x + module(x)"), written to xsum as well.  stats [rows][2] = (mean,
+ * rstd) for the backward.
+ * s2t_layernorm_bwd: dx = LayerNorm'(dy) (+ resid, the residual branch's gradient); dgamma[C] and
+ * dbeta[C] are ACCUMULATED (they are the parameters' views of the flat gradient buffer). */
+int s2t_layernorm_fwd(const float* x, const float* y, float alpha, const float* gamma,
+                      const float* beta, long rows, int C, float eps, float* xsum, float* out,
+                      float* stats, void* stream);
+int s2t_layernorm_bwd(const float* x, const float* stats, const float* gamma, const float* dy,
+                      const float* resid, long rows, int C, float* dx, float* dgamma, float* dbeta,
+                      void* stream);
+/* nn.SiLU of the feed-forward modules: a = h * sigmoid(h); dh = scale * da * silu'(h) (dh may
+ * alias da; scale carries the layer's 0.5 feed-forward residual weight). */
+int s2t_silu_fwd(const float* h, long n, float* a, void* stream);
+int s2t_silu_bwd(const float* h, const float* da, long n, float scale, float* dh, void* stream);
+/* nn.BatchNorm1d (training mode: statistics over all rows, biased variance for the normalisation,
+ * running_mean / running_var (unbiased) / num_batches_tracked updated; running_* may be NULL)
+ * followed by nn.SiLU, conv module of the conformer block.  save_mean / save_rstd [C] feed the
+ * backward, which ACCUMULATES dgamma / dbeta.  workspace: s2t_bn_workspace_floats(C) floats. */
+#define S2T_BN_PARTIALS 128
+long s2t_bn_workspace_floats(int C);
+int s2t_bn_silu_fwd(const float* x, const float* gamma, const float* beta, float eps,
+                    float momentum, float* running_mean, float* running_var, long* num_batches,
+                    long rows, int C, float* y, float* save_mean, float* save_rstd,
+                    float* workspace, void* stream);
+/* evaluation mode (running statistics): y = silu((x - mean) * rstd * gamma + beta) */
+int s2t_bn_silu_apply(const float* x, const float* mean, const float* rstd, const float* gamma,
+                      const float* beta, long rows, int C, float* y, void* stream);
+int s2t_bn_silu_bwd(const float* x, const float* ds, const float* save_mean,
+                    const float* save_rstd, const float* gamma, const float* beta, long rows, int C,
+                    float* dx, float* dgamma, float* dbeta, float* workspace, void* stream);
+/* nn.MultiheadAttention core (no positional term): o = softmax(q k^T * scale, keys >= lens[b]
+ * masked) v per (b, head).  q / k / v are the column blocks [qoff | koff | voff] + h * dh of the
+ * in-projection output qkv (T*B rows (t, b), row stride ld); o (T*B, ldo) column h * dh;
+ * lse [B][H][T] row log-sum-exp kept for the backward.  dh in {16, 32, 64}.
+ * dropout_p > 0: dropout on the attention probabilities (nn.MultiheadAttention(dropout=p),
+ * training); the mask is a hash of (seed, b, h, q, k) that the backward regenerates from the
+ * same seed -- it is never stored.
+ * s2t_mhsa_bwd: dqkv (same layout as qkv) from d_o; delta [B][H][T] is scratch. */
+int s2t_mhsa_fwd(const float* qkv, long ld, int qoff, int koff, int voff, const long* lens, int T,
+                 int B, int H, int dh, float scale, float dropout_p, unsigned long seed, float* o,
+                 long ldo, float* lse, void* stream);
+int s2t_mhsa_bwd(const float* qkv, long ld, int qoff, int koff, int voff, const long* lens, int T,
+                 int B, int H, int dh, float scale, float dropout_p, unsigned long seed,
+                 const float* o, const float* d_o, long ldo, const float* lse, float* delta,
+                 float* dqkv, void* stream);
 
 /* ---- side stream for work off the critical path (csrc/streams.hip): the weight-gradient GEMMs
  * of backward overlap the data-gradient chain.  s2t_side_stream returns the library-owned stream;

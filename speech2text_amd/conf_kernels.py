@@ -1,0 +1,270 @@
+"""Conformer-block entry points (the seam between model/encoder/conformer.py and the HIP ABI).
+
+Raw helpers (`ln_fwd`, `ln_bwd`, `silu_fwd`, ...) launch one kernel each on plain (rows, C)
+tensors and are what the layer executor (conf_layer.py) schedules by hand; the
+`torch.autograd.Function`s wrap the same launches for the module-by-module path (evaluation,
+dropout > 0, parameters outside a FlatStore).  Reference: torchaudio.models.Conformer as called
+at model/encoder/conformer.py:170-178,193 (block structure restated in csrc/conf_elem.hip).
+There is no CPU path: CPU tensors raise.
+"""
+import math
+
+import torch
+
+from . import _native as N
+from . import flat
+
+_F32 = torch.float32
+
+
+def _rows(x):
+    C = x.shape[-1]
+    x2 = x.reshape(-1, C)
+    if x2.dtype != _F32 or not x2.is_contiguous() or x2.data_ptr() % 16:
+        x2 = x2.contiguous().float()
+        if x2.data_ptr() % 16:
+            x2 = x2.clone()
+    return x2
+
+
+# ------------------------------------------------------------------ raw launches
+def ln_fwd(x2, y2, alpha, weight, bias, eps):
+    """-> (xsum | None, out, stats).  y2 given: the input is x2 + alpha * y2 (also returned)."""
+    if not x2.is_cuda:
+        raise RuntimeError("speech2text_amd conformer kernels run on the GPU only (no CPU fallback)")
+    R, C = x2.shape
+    out = torch.empty_like(x2)
+    stats = torch.empty((R, 2), dtype=_F32, device=x2.device)
+    xsum = torch.empty_like(x2) if y2 is not None else None
+    N.profile_note("s2t_layernorm_fwd", 4.0 * R * C * (2 if y2 is None else 4))
+    N.check(N.lib().s2t_layernorm_fwd(N.fp(x2), N.fp(y2), float(alpha), N.fp(weight), N.fp(bias),
+                                      R, C, float(eps), N.fp(xsum), N.fp(out), N.fp(stats),
+                                      N.stream()), "s2t_layernorm_fwd")
+    return xsum, out, stats
+
+
+def ln_bwd(x2, stats, weight, dy2, resid2, dgamma, dbeta):
+    """-> dx (+ resid2); dgamma / dbeta (C,) are accumulated in place."""
+    R, C = x2.shape
+    dx = torch.empty_like(x2)
+    N.profile_note("s2t_layernorm_bwd", 4.0 * R * C * (3 if resid2 is None else 4))
+    N.check(N.lib().s2t_layernorm_bwd(N.fp(x2), N.fp(stats), N.fp(weight), N.fp(dy2),
+                                      N.fp(resid2), R, C, N.fp(dx), N.fp(dgamma), N.fp(dbeta),
+                                      N.stream()), "s2t_layernorm_bwd")
+    return dx
+
+
+def silu_fwd(h2):
+    a = torch.empty_like(h2)
+    N.profile_note("s2t_silu_fwd", 8.0 * h2.numel())
+    N.check(N.lib().s2t_silu_fwd(N.fp(h2), h2.numel(), N.fp(a), N.stream()), "s2t_silu_fwd")
+    return a
+
+
+def silu_bwd(h2, da2, scale=1.0, inplace=True):
+    """scale * da * silu'(h); written over da2 when `inplace`."""
+    dh = da2 if inplace else torch.empty_like(da2)
+    N.profile_note("s2t_silu_bwd", 12.0 * h2.numel())
+    N.check(N.lib().s2t_silu_bwd(N.fp(h2), N.fp(da2), h2.numel(), float(scale), N.fp(dh),
+                                 N.stream()), "s2t_silu_bwd")
+    return dh
+
+
+_BN_WS = {}
+
+
+def _bn_ws(dev, C):
+    ws = _BN_WS.get((dev, C))
+    if ws is None:
+        ws = _BN_WS[(dev, C)] = torch.empty(N.lib().s2t_bn_workspace_floats(C), dtype=_F32,
+                                            device=dev)
+    return ws
+
+
+def bn_silu_fwd(x2, bn):
+    """training-mode nn.BatchNorm1d + SiLU on (rows, C) -> (y, save_mean, save_rstd); updates the
+    module's running statistics like torch does."""
+    R, C = x2.shape
+    y = torch.empty_like(x2)
+    mean = torch.empty(C, dtype=_F32, device=x2.device)
+    rstd = torch.empty(C, dtype=_F32, device=x2.device)
+    track = bn.track_running_stats and bn.running_mean is not None
+    mom = 0.1 if bn.momentum is None else float(bn.momentum)
+    N.profile_note("s2t_bn_silu_fwd", 12.0 * R * C)
+    N.check(N.lib().s2t_bn_silu_fwd(N.fp(x2), N.fp(bn.weight), N.fp(bn.bias), float(bn.eps), mom,
+                                    N.fp(bn.running_mean) if track else None,
+                                    N.fp(bn.running_var) if track else None,
+                                    N.lp(bn.num_batches_tracked) if track else None, R, C,
+                                    N.fp(y), N.fp(mean), N.fp(rstd), N.fp(_bn_ws(x2.device, C)),
+                                    N.stream()), "s2t_bn_silu_fwd")
+    return y, mean, rstd
+
+
+def bn_silu_eval(x2, bn):
+    R, C = x2.shape
+    y = torch.empty_like(x2)
+    rstd = torch.rsqrt(bn.running_var + bn.eps)
+    N.check(N.lib().s2t_bn_silu_apply(N.fp(x2), N.fp(bn.running_mean), N.fp(rstd), N.fp(bn.weight),
+                                      N.fp(bn.bias), R, C, N.fp(y), N.stream()),
+            "s2t_bn_silu_apply")
+    return y
+
+
+def bn_silu_bwd(x2, ds2, mean, rstd, weight, bias, dgamma, dbeta):
+    R, C = x2.shape
+    dx = torch.empty_like(x2)
+    N.profile_note("s2t_bn_silu_bwd", 20.0 * R * C)
+    N.check(N.lib().s2t_bn_silu_bwd(N.fp(x2), N.fp(ds2), N.fp(mean), N.fp(rstd), N.fp(weight),
+                                    N.fp(bias), R, C, N.fp(dx), N.fp(dgamma), N.fp(dbeta),
+                                    N.fp(_bn_ws(x2.device, C)), N.stream()), "s2t_bn_silu_bwd")
+    return dx
+
+
+def mhsa_fwd(qkv2, lens, T, B, H, dropout_p=0.0, seed=0):
+    """qkv2 (T*B, 3D) rows (t, b) -> (o (T*B, D), lse (B,H,T))."""
+    D = qkv2.shape[1] // 3
+    dh = D // H
+    o = torch.empty((T * B, D), dtype=_F32, device=qkv2.device)
+    lse = torch.empty((B, H, T), dtype=_F32, device=qkv2.device)
+    N.profile_note("s2t_mhsa_fwd", 4.0 * (qkv2.numel() + o.numel()), 4.0 * B * H * T * T * dh)
+    N.check(N.lib().s2t_mhsa_fwd(N.fp(qkv2), 3 * D, 0, D, 2 * D, N.lp(lens), T, B, H, dh,
+                                 1.0 / math.sqrt(dh), float(dropout_p), int(seed), N.fp(o), D,
+                                 N.fp(lse), N.stream()), "s2t_mhsa_fwd")
+    return o, lse
+
+
+def mhsa_bwd(qkv2, lens, T, B, H, o2, do2, lse, dropout_p=0.0, seed=0):
+    D = qkv2.shape[1] // 3
+    dh = D // H
+    dqkv = torch.empty_like(qkv2)
+    delta = torch.empty((B, H, T), dtype=_F32, device=qkv2.device)
+    N.profile_note("s2t_mhsa_bwd", 4.0 * (2 * qkv2.numel() + 2 * o2.numel()),
+                   14.0 * B * H * T * T * dh)
+    N.check(N.lib().s2t_mhsa_bwd(N.fp(qkv2), 3 * D, 0, D, 2 * D, N.lp(lens), T, B, H, dh,
+                                 1.0 / math.sqrt(dh), float(dropout_p), int(seed), N.fp(o2),
+                                 N.fp(do2), D, N.fp(lse), N.fp(delta), N.fp(dqkv), N.stream()),
+            "s2t_mhsa_bwd")
+    return dqkv
+
+
+def _grad_slots(params):
+    """Flat-store gradient views of `params` if all of them live in one, else None."""
+    out = []
+    for p in params:
+        if not (p.is_leaf and flat.owned(p) and p.grad is not None and p.grad.is_contiguous()):
+            return None
+        out.append(p.grad)
+    return out
+
+
+# ------------------------------------------------------------------ autograd wrappers
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        x2 = _rows(x)
+        _, out, stats = ln_fwd(x2, None, 0.0, weight.contiguous(), bias.contiguous(), eps)
+        ctx.save_for_backward(x2, stats, weight)
+        ctx.params = (weight, bias)
+        return out.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, stats, weight = ctx.saved_tensors
+        g2 = _rows(g)
+        slots = _grad_slots(ctx.params)
+        if slots is not None:
+            dx = ln_bwd(x2, stats, weight, g2, None, slots[0], slots[1])
+            return dx.view(g.shape), None, None, None
+        acc = torch.zeros((2, x2.shape[1]), dtype=_F32, device=x2.device)
+        dx = ln_bwd(x2, stats, weight.contiguous(), g2, None, acc[0], acc[1])
+        return dx.view(g.shape), acc[0], acc[1], None
+
+
+def layer_norm(x, ln):
+    if not x.is_cuda:
+        raise RuntimeError("speech2text_amd.layer_norm needs device tensors (HIP path only)")
+    return _LayerNorm.apply(x, ln.weight, ln.bias, ln.eps)
+
+
+class _SiLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h):
+        h2 = _rows(h)
+        ctx.save_for_backward(h2)
+        return silu_fwd(h2).view(h.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        (h2,) = ctx.saved_tensors
+        return silu_bwd(h2, _rows(g), 1.0, inplace=False).view(g.shape)
+
+
+def silu(x):
+    if not x.is_cuda:
+        raise RuntimeError("speech2text_amd.silu needs device tensors (HIP path only)")
+    return _SiLU.apply(x)
+
+
+class _BnSilu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, bn):
+        x2 = _rows(x)
+        y, mean, rstd = bn_silu_fwd(x2, bn)
+        ctx.save_for_backward(x2, mean, rstd, weight, bias)
+        ctx.params = (weight, bias)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, mean, rstd, weight, bias = ctx.saved_tensors
+        g2 = _rows(g)
+        slots = _grad_slots(ctx.params)
+        if slots is not None:
+            dx = bn_silu_bwd(x2, g2, mean, rstd, weight, bias, slots[0], slots[1])
+            return dx.view(g.shape), None, None, None
+        acc = torch.zeros((2, x2.shape[1]), dtype=_F32, device=x2.device)
+        dx = bn_silu_bwd(x2, g2, mean, rstd, weight, bias, acc[0], acc[1])
+        return dx.view(g.shape), acc[0], acc[1], None
+
+
+def batchnorm_silu(x, bn):
+    """SiLU(BatchNorm1d(x)) on channel-last (..., C): batch statistics over every leading index."""
+    if not x.is_cuda:
+        raise RuntimeError("speech2text_amd.batchnorm_silu needs device tensors (HIP path only)")
+    if bn.training or not bn.track_running_stats:
+        return _BnSilu.apply(x, bn.weight, bn.bias, bn)
+    return bn_silu_eval(_rows(x), bn).view(x.shape)
+
+
+class _Mhsa(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, lens, H, p, seed):
+        T, B, D3 = qkv.shape
+        q2 = _rows(qkv)
+        o, lse = mhsa_fwd(q2, lens, T, B, H, p, seed)
+        ctx.save_for_backward(q2, o, lse, lens)
+        ctx.cfg = (T, B, H, p, seed)
+        return o.view(T, B, D3 // 3)
+
+    @staticmethod
+    def backward(ctx, g):
+        q2, o, lse, lens = ctx.saved_tensors
+        T, B, H, p, seed = ctx.cfg
+        dqkv = mhsa_bwd(q2, lens, T, B, H, o, _rows(g), lse, p, seed)
+        return dqkv.view(T, B, -1), None, None, None, None
+
+
+def draw_seed():
+    """Host-side 62-bit seed for the in-kernel dropout hash (torch's CPU generator: follows
+    torch.manual_seed, never touches the device)."""
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
+def mhsa(qkv, lengths, num_heads, dropout_p=0.0):
+    """qkv (T,B,3D) = in_proj(x) -> (T,B,D): softmax(q k^T / sqrt(dh), keys >= lengths[b] masked) v
+    per head; dropout_p: dropout on the attention probabilities (training)."""
+    if not qkv.is_cuda:
+        raise RuntimeError("speech2text_amd.mhsa needs device tensors (HIP path only)")
+    lens = None if lengths is None else lengths.to(device=qkv.device, dtype=torch.int64).contiguous()
+    seed = draw_seed() if dropout_p > 0.0 else 0
+    return _Mhsa.apply(qkv, lens, num_heads, float(dropout_p), seed)

@@ -51,6 +51,7 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   int splits;
   int debug;
+  float alpha;            // TN: scale of the accumulated product / column sums
 };
 
 __device__ __forceinline__ float log1p_fast(float e) {   // as zip_elem.hip
@@ -219,7 +220,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const unsigned bid)
   }
   if (MODE == MODE_TN && g.colsum != nullptr && tn == 0 && threadIdx.x < BM &&
       m0 + (int)threadIdx.x < g.M)
-    atomicAdd(g.colsum + m0 + threadIdx.x, csum);
+    atomicAdd(g.colsum + m0 + threadIdx.x, csum * g.alpha);
 
   // ---- epilogue: lane holds column (lane & 31), rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
   const int hi = lane >> 5, lo = lane & 31;
@@ -238,7 +239,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const unsigned bid)
         float* cp = g.C + (long)row * g.ldc + col;
         if (g.debug & 1) continue;
         if (MODE == MODE_TN) {
-          atomicAdd(cp, v);
+          atomicAdd(cp, v * g.alpha);
         } else {
           v += bv;
           if (g.act_src) v *= swoosh_deriv(g.act_src[(long)row * g.lds + col], g.act_kind);
@@ -265,6 +266,7 @@ struct TnProb {
   float* C;
   float* colsum;
   int lda, ldb, ldc, M, N, K, kper, tiles_m, tiles_n, splits;
+  float alpha;
 };
 struct TnGroup {
   int n;
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(TnGroup grp) {
   while (i + 1 < grp.n && blockIdx.x >= grp.begin[i + 1]) ++i;
   const TnProb& q = grp.p[i];
   GemmArgs g{q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, nullptr, nullptr, 0, nullptr, 0,
-             0, 0, 0, q.colsum, 0, q.kper, q.tiles_m, q.tiles_n, q.splits, 0};
+             0, 0, 0, q.colsum, 0, q.kper, q.tiles_m, q.tiles_n, q.splits, 0, q.alpha};
   gemm_body<1, 1, MODE_TN, ACT_NONE>(g, blockIdx.x - grp.begin[i]);
 }
 
@@ -373,7 +375,7 @@ extern "C" int s2t_gemm_f32(int mode, const float* A, long lda, const float* B, 
   if (act_kind < 0 || act_kind > 2 || pro_a < 0 || pro_a > 2 || pro_b < 0 || pro_b > 2) return -1;
   if (mode == MODE_TN && (resid || act_src || bias)) return -1;
   GemmArgs g{A, lda, B, ldb, C, ldc, M, N, K, bias, resid, ldr, act_src, lds, act_kind, pro_a,
-             pro_b, colsum, accumulate, 0, 0, 0, 0, 0};
+             pro_b, colsum, accumulate, 0, 0, 0, 0, 0, 1.f};
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (mode == MODE_NT) rc = dispatch<MODE_NT>(g, st);
@@ -399,7 +401,7 @@ extern "C" int s2t_gemm_tn_grouped(int n, const S2tTnProblem* probs, void* strea
         return -2;
       TnProb& q = grp.p[i];
       q = TnProb{s.A, s.B, s.C, s.colsum, (int)s.lda, (int)s.ldb, (int)s.ldc, s.M, s.N, s.K,
-                 0, (s.M + 63) / 64, (s.N + 63) / 64, 0};
+                 0, (s.M + 63) / 64, (s.N + 63) / 64, 0, s.alpha};
       const long tiles = (long)q.tiles_m * q.tiles_n;
       int splits = (int)((1536 + tiles - 1) / tiles);          // as the single-problem 64x64 rule
       const int maxs = (s.K + 2 * KR - 1) / (2 * KR);

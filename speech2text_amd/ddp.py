@@ -33,10 +33,16 @@ import torch.distributed as dist
 
 class GradReducer:
     def __init__(self, store, bucket_bytes: int = 32 << 20, process_group=None,
-                 algo: Optional[str] = None, overlap: Optional[bool] = None):
+                 algo: Optional[str] = None, overlap: Optional[bool] = None,
+                 force_active: Optional[bool] = None):
         self.store = store
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # force_active: run the whole machinery (hooks, buckets, side stream, collectives) on a
+        # 1-rank group too -- a numerical no-op used to exercise RCCL on a single GPU
+        if force_active is None:
+            force_active = os.environ.get("S2T_DDP_FORCE", "0") == "1"
+        self.active = self.world > 1 or (bool(force_active) and dist.is_initialized())
         self.algo = algo or os.environ.get("S2T_DDP_ALGO", "allreduce")
         if self.algo not in ("allreduce", "rs_ag"):
             raise ValueError(f"unknown gradient-exchange algo {self.algo!r}")
@@ -78,7 +84,7 @@ class GradReducer:
         self._drop_flags = []                        # device flags of recent steps (read lazily)
         self._next = 0                               # next bucket to launch (fixed order)
         self._hooks = []
-        if self.world > 1:
+        if self.active:
             store.on_grad = self._grad_ready
             for q, p in enumerate(store.params):
                 if p.requires_grad:
@@ -168,7 +174,7 @@ class GradReducer:
     def finish(self, extra: Optional[torch.Tensor] = None):
         """After backward: reduce whatever was not launched by the hooks, wait, average.
         `extra` (1-D tensor of logged scalars) is mean-reduced along with the gradients."""
-        if self.world == 1:
+        if not self.active:
             return extra
         while self._next < len(self.buckets):
             self._launch(self._next)

@@ -5,8 +5,12 @@ torchaudio.models.Conformer (torchaudio 0.13.1, not vendored: the block structur
 is the published one -- FFN(0.5) -> MHSA -> conv module -> FFN(0.5) -> LayerNorm, conv module =
 LayerNorm -> pointwise(D->2D) -> GLU -> depthwise(k, pad k//2) -> BatchNorm1d|GroupNorm ->
 SiLU -> pointwise -> dropout; PARITY UNPINNED).  Parameter names follow torchaudio's so
-checkpoints interchange.  Everything runs time-major (T,B,D); GLU + depthwise conv is the
-fused HIP kernel (zip_conv.hip), GEMMs are hipBLASLt.
+checkpoints interchange.  Everything runs time-major (T,B,D) on hand-written HIP kernels:
+LayerNorm / SiLU / BatchNorm+SiLU (conf_elem.hip), the flash-style MFMA attention core
+(conf_attn.hip), GLU + depthwise conv (zip_conv.hip); dense GEMMs are hipBLASLt (forward, data
+gradient) and the TN MFMA kernel (weight gradient).  In training a layer is ONE autograd node
+(speech2text_amd/conf_layer.py); the module-by-module form below serves evaluation, dropout > 0
+and models whose parameters are not in a FlatStore, with the same kernels one op at a time.
 """
 import dataclasses
 from typing import Tuple
@@ -15,6 +19,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from speech2text_amd import conf_kernels as ck
+from speech2text_amd import conf_layer
 from speech2text_amd import zip_kernels as zk
 
 
@@ -88,7 +94,7 @@ class _FeedForwardModule(nn.Module):
 
     def forward(self, x):
         ln, l1, act, d1, l2, d2 = self.sequential
-        h = act(zk.linear(ln(x), l1.weight, l1.bias))
+        h = ck.silu(zk.linear(ck.layer_norm(x, ln), l1.weight, l1.bias))
         return d2(zk.linear(d1(h), l2.weight, l2.bias))
 
 
@@ -112,15 +118,14 @@ class _ConvolutionModule(nn.Module):
         """x (T,B,D) time-major -> (T,B,D)."""
         pw1, _, dw, norm, act, pw2, drop = self.sequential
         T, B, D = x.shape
-        x = self.layer_norm(x)
+        x = ck.layer_norm(x, self.layer_norm)
         u = zk.linear(x, pw1.weight, pw1.bias)                        # (T,B,2C): [a | gate]
         C = u.shape[-1] // 2
         y = zk.glu_chunk_causal_dwconv(u, C, None, dw, -1)            # GLU + depthwise, fused
         if isinstance(norm, nn.BatchNorm1d):
-            y = norm(y.reshape(T * B, C)).reshape(T, B, C)            # batch statistics over B*T
+            y = ck.batchnorm_silu(y, norm)                            # batch statistics over B*T
         else:
-            y = norm(y.permute(1, 2, 0)).permute(2, 0, 1)
-        y = act(y)
+            y = ck.silu(norm(y.permute(1, 2, 0)).permute(2, 0, 1).contiguous())
         y = zk.linear(y, pw2.weight, pw2.bias)
         return drop(y)
 
@@ -139,35 +144,32 @@ class ConformerLayer(nn.Module):
         self.final_layer_norm = nn.LayerNorm(input_dim)
         self.convolution_first = convolution_first
 
-    def _mhsa(self, x, key_padding_mask):
+    def _mhsa(self, x, lengths):
         """nn.MultiheadAttention (no positional term) on (T,B,D): the in/out projections are
-        zk.linear (weight gradients accumulated in place by the TN MFMA GEMM), the softmax(QK^T)V
-        core is torch's fused SDPA kernel.  `self.self_attn` only holds the parameters, under
-        torchaudio's names."""
+        zk.linear (weight gradients accumulated in place by the TN MFMA GEMM), the
+        softmax(QK^T / sqrt(dh))V core is the flash-style MFMA kernel (csrc/conf_attn.hip), which
+        reads q / k / v as column blocks of the in-projection's output and masks the keys at
+        t >= lengths[b].  `self.self_attn` only holds the parameters, under torchaudio's names."""
         mha = self.self_attn
-        T, B, D = x.shape
-        H = mha.num_heads
-        qkv = zk.linear(x, mha.in_proj_weight, mha.in_proj_bias).view(T, B, 3, H, D // H)
-        q, k, v = (qkv[:, :, i].permute(1, 2, 0, 3) for i in range(3))      # (B,H,T,dh) views
-        mask = None
-        if key_padding_mask is not None:
-            mask = (~key_padding_mask).view(B, 1, 1, T)
-        p = mha.dropout if self.training else 0.0
-        o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, dropout_p=p)
-        o = o.permute(2, 0, 1, 3).reshape(T, B, D)
+        qkv = zk.linear(x, mha.in_proj_weight, mha.in_proj_bias)
+        p = float(mha.dropout) if self.training else 0.0
+        o = ck.mhsa(qkv, lengths, mha.num_heads, p)
         return zk.linear(o, mha.out_proj.weight, mha.out_proj.bias)
 
-    def forward(self, x, key_padding_mask):
+    def forward(self, x, lengths):
+        """x (T,B,D) time-major; lengths (B,) valid frames (the key padding mask is t >= length)."""
+        if conf_layer.eligible(self, x):
+            return conf_layer.run(self, x, lengths)
         x = self.ffn1(x) * 0.5 + x
         if self.convolution_first:
             x = x + self.conv_module(x)
         res = x
-        x = self._mhsa(self.self_attn_layer_norm(x), key_padding_mask)
+        x = self._mhsa(ck.layer_norm(x, self.self_attn_layer_norm), lengths)
         x = self.self_attn_dropout(x) + res
         if not self.convolution_first:
             x = x + self.conv_module(x)
         x = self.ffn2(x) * 0.5 + x
-        return self.final_layer_norm(x)
+        return ck.layer_norm(x, self.final_layer_norm)
 
 
 class _ConformerStack(nn.Module):
@@ -181,11 +183,9 @@ class _ConformerStack(nn.Module):
                            use_group_norm, convolution_first) for _ in range(num_layers)])
 
     def forward(self, x, lengths):
-        T = x.shape[1]
-        mask = torch.arange(T, device=lengths.device).unsqueeze(0) >= lengths.unsqueeze(1)
-        x = x.transpose(0, 1)
+        x = x.transpose(0, 1).contiguous()
         for layer in self.conformer_layers:
-            x = layer(x, mask)
+            x = layer(x, lengths)
         return x.transpose(0, 1), lengths
 
 

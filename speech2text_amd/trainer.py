@@ -103,7 +103,7 @@ class Trainer:
         self.micro += 1
         if last:
             logged = None
-            if dist.is_initialized() and dist.get_world_size() > 1 and task.logged:
+            if self.reducer.active and task.logged:
                 vals = [v.detach().float().reshape(()) if torch.is_tensor(v)
                         else torch.tensor(float(v), device=loss.device) for v in task.logged.values()]
                 logged = torch.stack(vals)

@@ -1023,36 +1023,38 @@ class TnProblem(ctypes.Structure):
     _fields_ = [("A", ctypes.c_void_p), ("lda", ctypes.c_long), ("B", ctypes.c_void_p),
                 ("ldb", ctypes.c_long), ("C", ctypes.c_void_p), ("ldc", ctypes.c_long),
                 ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int),
-                ("colsum", ctypes.c_void_p)]
+                ("colsum", ctypes.c_void_p), ("alpha", ctypes.c_float)]
 
 
 def wgrad_group(items):
-    """items: [(weight, bias | None, g2 (R,N), a2 (R,M))] -- the weight / bias gradients of a whole
+    """items: [(weight, bias | None, g2 (R,N), a2 (R,M)[, alpha])] -- the weight / bias gradients of a whole
     layer, accumulated into the flat gradient views by ONE grouped TN launch on the side stream
     (gemm.hip s2t_gemm_tn_grouped).  The caller is not an autograd node of these parameters (the
     layer executor), so the gradient reducer is told here.  Operands that do not meet the
     kernel's layout rules fall back to wgrad_into / a library GEMM one by one."""
     ok = []
     for it in items:
-        w, b, g2, a2 = it
+        w, b, g2, a2 = it[:4]
+        alpha = it[4] if len(it) > 4 else 1.0
         wg = w.grad
         if (_tn_ok(g2) and _tn_ok(a2) and flat.owned(w) and wg is not None and wg.is_contiguous()
                 and (b is None or (flat.owned(b) and b.grad is not None))):
-            ok.append(it)
+            ok.append((w, b, g2, a2, alpha))
             continue
-        if not wgrad_into(w, b, g2, a2, 0, notify=True):
+        if alpha != 1.0 or not wgrad_into(w, b, g2, a2, 0, notify=True):
             dw, db = linear_wgrad(g2, a2, b is not None)
-            w.grad.add_(dw.view(w.shape))
+            w.grad.add_(dw.view(w.shape), alpha=alpha)
             flat.grad_written(w)
             if b is not None:
-                b.grad.add_(db)
+                b.grad.add_(db, alpha=alpha)
                 flat.grad_written(b)
     n = len(ok)
     if n == 0:
         return
     arr = (TnProblem * n)()
     nbytes = flops = 0.0
-    for q, (w, b, g2, a2) in zip(arr, ok):
+    for q, (w, b, g2, a2, alpha) in zip(arr, ok):
+        q.alpha = alpha
         R, Nf = g2.shape
         Mf = a2.shape[1]
         q.A, q.lda = g2.data_ptr(), g2.stride(0)
@@ -1067,7 +1069,7 @@ def wgrad_group(items):
     N.check(N.lib().s2t_gemm_tn_grouped(n, ctypes.cast(arr, ctypes.c_void_p),
                                         st if st is not None else N.stream()),
             "s2t_gemm_tn_grouped")
-    for w, b, _, _ in ok:
+    for w, b, _, _, _ in ok:
         flat.grad_written(w)
         if b is not None:
             flat.grad_written(b)

@@ -80,3 +80,73 @@ def test_two_ranks_stay_identical(dev):
     assert lg0.keys() == lg1.keys()
     for k in lg0:                                             # synced scalars are the rank mean
         assert abs(lg0[k] - lg1[k]) < 1e-5 * max(1.0, abs(lg0[k])), k
+
+
+def _nccl_worker(port, q, algo, force):
+    """One rank on cuda:0.  force=True: backend "nccl" (= RCCL) with world_size 1 and the reducer
+    forced active -- hooks, reverse-order buckets, exchange stream ordered after the
+    weight-gradient side stream, reduce-scatter / all-gather or all-reduce on device buffers, the
+    packed scalar + late-flag all-reduce -- all of it a numerical no-op on one rank."""
+    import random
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    if force:
+        os.environ["S2T_DDP_FORCE"] = "1"
+        os.environ["S2T_DDP_ALGO"] = algo
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    import bench
+    from speech2text_amd.build_task import TaskFactory
+    from speech2text_amd.trainer import Trainer
+    cfg = bench.c3_config(64)
+    cfg["encoder"]["config"].update({"downsampling_factor": [1, 2], "num_encoder_layers": [1, 1],
+                                     "feedforward_dim": [96, 128], "encoder_dim": [48, 64],
+                                     "encoder_unmasked_dim": [32, 48], "num_heads": [4, 4],
+                                     "query_head_dim": 8, "value_head_dim": 4, "pos_dim": 16,
+                                     "cnn_module_kernel": [15, 7]})
+    cfg["predictor"]["config"].update({"output_dim": 64, "symbol_embedding_dim": 32})
+    cfg["joiner"].update({"input_dim": 64})
+    random.seed(5)
+    torch.manual_seed(1234)
+    task = TaskFactory.get("Pruned_Rnnt")(cfg)
+    tr = Trainer(bucket_mb=0.05, **cfg["trainer"]).setup(task, dev)
+    task.train()
+    losses = []
+    for i in range(4):
+        batch = bench.make_batch(i, 2, 2.0, 5, 64, dev)
+        random.seed(100 + i)
+        torch.manual_seed(200 + i)
+        losses.append(float(tr.training_step(batch, i)))
+    torch.cuda.synchronize()
+    info = (tr.reducer.active, len(tr.reducer.buckets), tr.reducer.poll_dropped(),
+            len(tr.reducer._expected or {}), {k: float(v) for k, v in task.logged.items()})
+    q.put((losses, tr.store.p().detach().cpu().numpy().tobytes(), info))
+    if force:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("algo", ["allreduce", "rs_ag"])
+def test_rccl_world1_reducer_is_a_noop(dev, algo):
+    """RCCL really runs (backend nccl, device buffers, side streams) and changes nothing."""
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    out = []
+    for force in (False, True):
+        q = ctx.Queue()
+        p = ctx.Process(target=_nccl_worker, args=(_free_port(), q, algo, force))
+        p.start()
+        out.append(q.get(timeout=300))
+        p.join(timeout=60)
+    (l0, f0, i0), (l1, f1, i1) = out
+    assert i0[0] is False and i1[0] is True
+    assert i1[1] >= 3 and i1[2] == 0 and i1[3] > 10, i1    # buckets, no dropped step, hooks fired
+    a, b = np.frombuffer(f0, np.float32), np.frombuffer(f1, np.float32)
+    # (not bitwise: the weight-gradient atomics sum in a run-dependent order)
+    np.testing.assert_allclose(b, a, rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(l1, l0, rtol=1e-4)
+    assert i0[4].keys() == i1[4].keys()
