@@ -401,7 +401,7 @@ def _bound(p):
     return "mfma" if p["algo_flops"] > 0 and p["algo_flops"] > balance * p["algo_bytes"] else "hbm"
 
 
-def roofline_report(prof_timed, prof_all, want, step_flops, ms_per_step):
+def roofline_report(prof_timed, prof_all, want, step_flops, ms_per_step, sampled_every=1):
     """`prof_timed`: HIP-event timings of the chosen entry point taken INSIDE the timed region.
     `prof_all`: every hand-written entry point, timed over extra (untimed) steps."""
     table = []
@@ -427,7 +427,8 @@ def roofline_report(prof_timed, prof_all, want, step_flops, ms_per_step):
         else:
             ach = p["algo_bytes"] / (p["total_ms"] * 1e-3) / 1e9
             out.update(achieved=ach, frac=ach / HBM_PEAK_GBS)
-        out.update(launches=p["launches"], avg_launch_ms=p["avg_ms"],
+        out.update(launches=p["launches"], sampled_every=sampled_every,
+                   avg_launch_ms=p["avg_ms"],
                    algorithmic_bytes_per_launch=p["algo_bytes"] / p["launches"])
     else:
         out["note"] = f"{want} was not launched in the timed region"
@@ -589,6 +590,7 @@ def main(argv=None):
     note("model + synthetic batch ready; warmup ...")
     loss = None
     want = args.roofline_kernel
+    want_launches = 0
     for i in range(args.warmup):
         tw = time.perf_counter()
         last = i == args.warmup - 1
@@ -600,6 +602,7 @@ def main(argv=None):
             pw = _native.profile_end()
             cand = {k: v for k, v in pw.items() if v["algo_bytes"] > 0}
             want = max(cand, key=lambda k: cand[k]["total_ms"]) if cand else "s2t_relpos_attn_fwd"
+            want_launches = cand[want]["launches"] if cand else 0
         note(f"warmup step {i}: {time.perf_counter() - tw:.3f} s, loss {float(loss):.4f}")
     if want == "auto":
         want = "s2t_relpos_attn_fwd"
@@ -608,8 +611,16 @@ def main(argv=None):
         t = torch.tensor([names.index(want)], device=device, dtype=torch.int64)
         dist.broadcast(t, src=0)
         want = names[int(t.item())]
+    # an entry launched hundreds of times per step is SAMPLED inside the timed region (every n-th
+    # launch, n coprime to the launches per step): two event records per launch would cost the
+    # timed step several per cent
+    every = 1
+    if want_launches > 48:
+        every = max(2, want_launches // 32)
+        while want_launches % every == 0 or (every > 2 and every % 2 == 0):
+            every += 1
     sync()
-    _native.profile_begin(want)
+    _native.profile_begin(want, every)
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = trainer.training_step(batch, args.warmup + i)
@@ -658,7 +669,7 @@ def main(argv=None):
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "utterance_seconds": args.seconds, "labels_per_utt": args.labels,
                        "parallelism": f"dp{world}", "final_loss": final_loss},
-            "roofline": roofline_report(prof_timed, prof_all, want, step_flops, ms),
+            "roofline": roofline_report(prof_timed, prof_all, want, step_flops, ms, every),
             "cpu_baseline": cpu if cpu is not None else {
                 "value": None, "unit": "audio-seconds/sec", "cores": host_threads(), "kind": "port",
                 "sample": "not timed in this run (multi-rank or --no-cpu-baseline): the oracle "

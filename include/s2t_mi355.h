@@ -422,14 +422,25 @@ int s2t_nonlin_gate_bwd(const float* dxs, const float* u, int T, int B, int C, f
  * s2t_layernorm_fwd: nn.LayerNorm.  y != NULL: the input is x + alpha * y (the layer's residual
  * sums "0.5 * ffn(x) + x" / "x + module(x)"), written to xsum as well.  stats [rows][2] = (mean,
  * rstd) for the backward.
- * s2t_layernorm_bwd: dx = LayerNorm'(dy) (+ resid, the residual branch's gradient); dgamma[C] and
- * dbeta[C] are ACCUMULATED (they are the parameters' views of the flat gradient buffer). */
+ * s2t_layernorm_bwd: dx = LayerNorm'(dy) (+ resid, the residual branch's gradient); the
+ * per-workgroup sums of d gamma / d beta go to `partial` (s2t_layernorm_bwd_partial_floats(rows, C)
+ * floats).  s2t_layernorm_param_grad folds the partials of n LayerNorms of width C in one launch:
+ * dgamma[C] += ..., dbeta[C] += ... (the parameters' views of the flat gradient buffer); `items`
+ * is a HOST array. */
 int s2t_layernorm_fwd(const float* x, const float* y, float alpha, const float* gamma,
                       const float* beta, long rows, int C, float eps, float* xsum, float* out,
                       float* stats, void* stream);
+typedef struct S2tLnFold {
+  const float* partial;
+  long rows;
+  float* dgamma;
+  float* dbeta;
+} S2tLnFold;
+long s2t_layernorm_bwd_partial_floats(long rows, int C);
 int s2t_layernorm_bwd(const float* x, const float* stats, const float* gamma, const float* dy,
-                      const float* resid, long rows, int C, float* dx, float* dgamma, float* dbeta,
+                      const float* resid, long rows, int C, float* dx, float* partial,
                       void* stream);
+int s2t_layernorm_param_grad(int n, const S2tLnFold* items, int C, void* stream);
 /* nn.SiLU of the feed-forward modules: a = h * sigmoid(h); dh = scale * da * silu'(h) (dh may
  * alias da; scale carries the layer's 0.5 feed-forward residual weight). */
 int s2t_silu_fwd(const float* h, long n, float* a, void* stream);

@@ -43,6 +43,8 @@ class _Prof:
     events = {}          # entry -> [(start, stop)] HIP events on the launch stream
     algo_bytes = {}      # entry -> algorithmic bytes reported by the call sites
     algo_flops = {}
+    every = 1            # bracket every n-th launch of the target only (an entry launched hundreds
+    count = {}           # of times per step would otherwise pay two event records per launch)
 
 
 _NO_LAUNCH = ("s2t_side_stream", "s2t_stream_order")   # stream plumbing, nothing to time
@@ -86,6 +88,10 @@ class _LibProxy:
                 tgt = _Prof.target
                 if tgt is None or (tgt != "*" and tgt != _name):
                     return _raw(*args)
+                c = _Prof.count.get(_name, 0)
+                _Prof.count[_name] = c + 1
+                if c % _Prof.every:
+                    return _raw(*args)
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
                 st = _launch_stream(args)
@@ -114,14 +120,19 @@ def lib():
     return _lib
 
 
-def profile_begin(entry_point):
-    """entry_point: a C entry-point name declared in include/s2t_mi355.h, or "*" for all."""
+def profile_begin(entry_point, every=1):
+    """entry_point: a C entry-point name declared in include/s2t_mi355.h, or "*" for all.
+    every = n: only every n-th launch of it is bracketed by events (and only those launches'
+    algorithmic bytes / flops are counted): pick n coprime to the launches per step so that the
+    sample walks over all call sites."""
     if entry_point != "*" and entry_point not in parse_header():
         raise ValueError(f"{entry_point!r} is not an entry point of include/s2t_mi355.h")
     _Prof.target = entry_point
     _Prof.events = {}
     _Prof.algo_bytes = {}
     _Prof.algo_flops = {}
+    _Prof.every = max(1, int(every))
+    _Prof.count = {}
     if _lib is not None:
         _lib._reset()
 
@@ -131,7 +142,7 @@ def profile_note(entry_point, nbytes=0.0, flops=0.0):
     tgt = _Prof.target
     if tgt is None:
         return
-    if tgt == "*" or tgt == entry_point:
+    if (tgt == "*" or tgt == entry_point) and _Prof.count.get(entry_point, 0) % _Prof.every == 0:
         _Prof.algo_bytes[entry_point] = _Prof.algo_bytes.get(entry_point, 0.0) + nbytes
         _Prof.algo_flops[entry_point] = _Prof.algo_flops.get(entry_point, 0.0) + flops
 

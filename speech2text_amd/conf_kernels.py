@@ -7,6 +7,7 @@ dropout > 0, parameters outside a FlatStore).  Reference: torchaudio.models.Conf
 at model/encoder/conformer.py:170-178,193 (block structure restated in csrc/conf_elem.hip).
 There is no CPU path: CPU tensors raise.
 """
+import ctypes
 import math
 
 import torch
@@ -43,15 +44,36 @@ def ln_fwd(x2, y2, alpha, weight, bias, eps):
     return xsum, out, stats
 
 
-def ln_bwd(x2, stats, weight, dy2, resid2, dgamma, dbeta):
-    """-> dx (+ resid2); dgamma / dbeta (C,) are accumulated in place."""
+class LnFold(ctypes.Structure):
+    """Mirror of S2tLnFold (include/s2t_mi355.h)."""
+    _fields_ = [("partial", ctypes.c_void_p), ("rows", ctypes.c_long),
+                ("dgamma", ctypes.c_void_p), ("dbeta", ctypes.c_void_p)]
+
+
+def ln_bwd(x2, stats, weight, dy2, resid2, pend):
+    """-> dx (+ resid2).  The per-workgroup sums of d gamma / d beta are parked in a scratch
+    buffer and (partial, rows) is appended to `pend`; ln_param_grad(pend items) folds them."""
     R, C = x2.shape
     dx = torch.empty_like(x2)
+    partial = torch.empty(N.lib().s2t_layernorm_bwd_partial_floats(R, C), dtype=_F32,
+                          device=x2.device)
     N.profile_note("s2t_layernorm_bwd", 4.0 * R * C * (3 if resid2 is None else 4))
     N.check(N.lib().s2t_layernorm_bwd(N.fp(x2), N.fp(stats), N.fp(weight), N.fp(dy2),
-                                      N.fp(resid2), R, C, N.fp(dx), N.fp(dgamma), N.fp(dbeta),
-                                      N.stream()), "s2t_layernorm_bwd")
+                                      N.fp(resid2), R, C, N.fp(dx), N.fp(partial), N.stream()),
+            "s2t_layernorm_bwd")
+    pend.append((partial, R))
     return dx
+
+
+def ln_param_grad(items, C):
+    """items: [(partial, rows, dgamma (C,), dbeta (C,))] -- dgamma / dbeta += the folded partial
+    sums of up to any number of LayerNorms of width C, one launch per 8."""
+    arr = (LnFold * len(items))()
+    for q, (partial, rows, dg, db) in zip(arr, items):
+        q.partial, q.rows = partial.data_ptr(), rows
+        q.dgamma, q.dbeta = dg.data_ptr(), db.data_ptr()
+    N.check(N.lib().s2t_layernorm_param_grad(len(items), ctypes.cast(arr, ctypes.c_void_p), C,
+                                             N.stream()), "s2t_layernorm_param_grad")
 
 
 def silu_fwd(h2):
@@ -172,11 +194,14 @@ class _LayerNorm(torch.autograd.Function):
         x2, stats, weight = ctx.saved_tensors
         g2 = _rows(g)
         slots = _grad_slots(ctx.params)
+        pend = []
+        dx = ln_bwd(x2, stats, weight.contiguous(), g2, None, pend)
+        C = x2.shape[1]
         if slots is not None:
-            dx = ln_bwd(x2, stats, weight, g2, None, slots[0], slots[1])
+            ln_param_grad([pend[0] + (slots[0], slots[1])], C)
             return dx.view(g.shape), None, None, None
-        acc = torch.zeros((2, x2.shape[1]), dtype=_F32, device=x2.device)
-        dx = ln_bwd(x2, stats, weight.contiguous(), g2, None, acc[0], acc[1])
+        acc = torch.zeros((2, C), dtype=_F32, device=x2.device)
+        ln_param_grad([pend[0] + (acc[0], acc[1])], C)
         return dx.view(g.shape), acc[0], acc[1], None
 
 

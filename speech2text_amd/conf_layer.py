@@ -86,17 +86,30 @@ def _ffn_fwd(ffn, n):
     return h, a, y
 
 
-def _ffn_bwd(ffn, pend, n, h, a, g, ln, x_in, stats):
+def _ln_bwd(ln, lnp, x_in, stats, dn, resid):
+    """LayerNorm backward (+ the residual branch's gradient); the parameter gradients are folded
+    at the end of the layer's backward (one launch for its five LayerNorms)."""
+    part = []
+    dx = ck.ln_bwd(x_in, stats, ln.weight, dn, resid, part)
+    lnp.append(part[0] + (ln.weight.grad, ln.bias.grad))
+    lnp.params.extend((ln.weight, ln.bias))
+    return dx
+
+
+class _LnPend(list):
+    def __init__(self):
+        super().__init__()
+        self.params = []
+
+
+def _ffn_bwd(ffn, pend, lnp, n, h, a, g, ln, x_in, stats):
     """g = gradient w.r.t. the sum x_in + 0.5 * ffn(LN(x_in)) -> gradient w.r.t. x_in."""
     l1, l2 = ffn.sequential[1], ffn.sequential[4]
     pend.append((l2.weight, l2.bias, g, a, 0.5))
     dh = ck.silu_bwd(h, zk.lt_matmul(1, g, l2.weight), 0.5)
     pend.append((l1.weight, l1.bias, dh, n))
     dn = zk.lt_matmul(1, dh, l1.weight)
-    dx = ck.ln_bwd(x_in, stats, ln.weight, dn, g, ln.weight.grad, ln.bias.grad)
-    flat.grad_written(ln.weight)
-    flat.grad_written(ln.bias)
-    return dx
+    return _ln_bwd(ln, lnp, x_in, stats, dn, g)
 
 
 class _LayerFn(torch.autograd.Function):
@@ -160,12 +173,11 @@ class _LayerFn(torch.autograd.Function):
         if g.data_ptr() % 16:
             g = g.clone()
         pend = []
+        lnp = _LnPend()
 
-        lnf = layer.final_layer_norm
-        g4 = ck.ln_bwd(s.x4, s.st5, lnf.weight, g, None, lnf.weight.grad, lnf.bias.grad)
-        flat.grad_written(lnf.weight)
-        flat.grad_written(lnf.bias)
-        g3 = _ffn_bwd(layer.ffn2, pend, s.n4, s.h2, s.a2, g4, layer.ffn2.sequential[0], s.x3, s.st4)
+        g4 = _ln_bwd(layer.final_layer_norm, lnp, s.x4, s.st5, g, None)
+        g3 = _ffn_bwd(layer.ffn2, pend, lnp, s.n4, s.h2, s.a2, g4, layer.ffn2.sequential[0], s.x3,
+                      s.st4)
 
         # conv module
         pend.append((pw2.weight, pw2.bias, g3, s.sb))
@@ -182,10 +194,7 @@ class _LayerFn(torch.autograd.Function):
         du = du.view(R, 2 * D)
         pend.append((pw1.weight, pw1.bias, du, s.n3))
         dn3 = zk.lt_matmul(1, du, pw1.weight.view(2 * D, D))
-        lnc = cm.layer_norm
-        g2 = ck.ln_bwd(s.x2, s.st3, lnc.weight, dn3, g3, lnc.weight.grad, lnc.bias.grad)
-        flat.grad_written(lnc.weight)
-        flat.grad_written(lnc.bias)
+        g2 = _ln_bwd(cm.layer_norm, lnp, s.x2, s.st3, dn3, g3)
 
         # MHSA
         pend.append((mha.out_proj.weight, mha.out_proj.bias, g2, s.o))
@@ -193,11 +202,12 @@ class _LayerFn(torch.autograd.Function):
         dqkv = ck.mhsa_bwd(s.qkv, s.lens, T, B, H, s.o, do, s.lse)
         pend.append((mha.in_proj_weight, mha.in_proj_bias, dqkv, s.n2))
         dn2 = zk.lt_matmul(1, dqkv, mha.in_proj_weight)
-        lna = layer.self_attn_layer_norm
-        g1 = ck.ln_bwd(s.x1, s.st2, lna.weight, dn2, g2, lna.weight.grad, lna.bias.grad)
-        flat.grad_written(lna.weight)
-        flat.grad_written(lna.bias)
+        g1 = _ln_bwd(layer.self_attn_layer_norm, lnp, s.x1, s.st2, dn2, g2)
 
-        g0 = _ffn_bwd(layer.ffn1, pend, s.n1, s.h1, s.a1, g1, layer.ffn1.sequential[0], s.x0, s.st1)
+        g0 = _ffn_bwd(layer.ffn1, pend, lnp, s.n1, s.h1, s.a1, g1, layer.ffn1.sequential[0], s.x0,
+                      s.st1)
+        ck.ln_param_grad(lnp, D)
+        for p in lnp.params:
+            flat.grad_written(p)
         zk.wgrad_group(pend)
         return g0.view(T, B, D), None, None

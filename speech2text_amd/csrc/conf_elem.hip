@@ -86,34 +86,40 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(
 
 // dx = rstd (gamma dy - mean_C(gamma dy) - xhat mean_C(gamma dy xhat)) [+ resid];
 // dgamma += sum_rows dy xhat, dbeta += sum_rows dy.  A wave walks rows wave_id, wave_id + W, ...
-// and keeps its lanes' channel sums in registers; one LDS reduction + one atomic per channel
-// and workgroup at the end (<= 256 workgroups: one per CU).
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(
+// and keeps its lanes' channel sums in registers; after one LDS reduction the workgroup stores
+// its 2C partial sums (plain stores), and ln_fold_kernel adds the partials of up to 8
+// LayerNorms into their gradient words in a fixed order.  (Atomics straight into the 2C gradient
+// words cost ~25 us per call: 256 workgroups adding to the same 512 addresses at once.)
+// The pass is latency-bound (one row = 3 loads + two wave reductions), so a workgroup carries
+// NW waves (16 for C <= 256): many rows in flight per CU.
+template <int NV, int NW>
+__global__ __launch_bounds__(64 * NW) void layernorm_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
     const float* __restrict__ dy, const float* __restrict__ resid, long rows, int C,
-    float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  __shared__ float red[3][2 * 256 * MAXV];   // waves 1..3 park their channel sums here
+    float* __restrict__ dx, float* __restrict__ partial) {
+  __shared__ float red[NW - 1][2 * 256 * NV];   // waves 1.. park their channel sums here
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = C >> 2;
-  float4 g[MAXV], ag[MAXV], ab[MAXV];
+  float4 g[NV], ag[NV], ab[NV];
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c4 = lane + 64 * i;
     g[i] = c4 < nv ? reinterpret_cast<const float4*>(gamma)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
     ag[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  const long stride = (long)gridDim.x * 4;
-  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += stride) {
+  const long stride = (long)gridDim.x * NW;
+  for (long row = (long)blockIdx.x * NW + wave; row < rows; row += stride) {
     const float mean = stats[2 * row], rstd = stats[2 * row + 1];
-    float4 xh[MAXV], d[MAXV];
+    float4 xh[NV], d[NV], rr[NV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c4 = lane + 64 * i;
       if (c4 < nv) {
         const float4 xv = reinterpret_cast<const float4*>(x + row * C)[c4];
         d[i] = reinterpret_cast<const float4*>(dy + row * C)[c4];
+        if (resid) rr[i] = reinterpret_cast<const float4*>(resid + row * C)[c4];
         xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd,
                             (xv.w - mean) * rstd);
         ag[i].x += d[i].x * xh[i].x; ag[i].y += d[i].y * xh[i].y;
@@ -127,7 +133,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     s1 = wave_sum(s1) / (float)C;
     s2 = wave_sum(s2) / (float)C;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c4 = lane + 64 * i;
       if (c4 < nv) {
         float4 o;
@@ -135,17 +141,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
         o.y = rstd * (d[i].y - s1 - xh[i].y * s2);
         o.z = rstd * (d[i].z - s1 - xh[i].z * s2);
         o.w = rstd * (d[i].w - s1 - xh[i].w * s2);
-        if (resid) {
-          const float4 r = reinterpret_cast<const float4*>(resid + row * C)[c4];
-          o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-        }
+        if (resid) { o.x += rr[i].x; o.y += rr[i].y; o.z += rr[i].z; o.w += rr[i].w; }
         reinterpret_cast<float4*>(dx + row * C)[c4] = o;
       }
     }
   }
   if (wave > 0) {
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       float* p = red[wave - 1] + 8 * (lane + 64 * i);
       *reinterpret_cast<float4*>(p) = ag[i];
       *reinterpret_cast<float4*>(p + 4) = ab[i];
@@ -154,23 +157,55 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
   __syncthreads();
   if (wave == 0) {
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c4 = lane + 64 * i;
       if (c4 >= nv) continue;
       float4 a = ag[i], b = ab[i];
-      for (int w = 0; w < 3; ++w) {
+      for (int w = 0; w < NW - 1; ++w) {
         const float* p = red[w] + 8 * c4;
         const float4 a2 = *reinterpret_cast<const float4*>(p);
         const float4 b2 = *reinterpret_cast<const float4*>(p + 4);
         a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
         b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
       }
-      atomicAdd(dgamma + 4 * c4, a.x); atomicAdd(dgamma + 4 * c4 + 1, a.y);
-      atomicAdd(dgamma + 4 * c4 + 2, a.z); atomicAdd(dgamma + 4 * c4 + 3, a.w);
-      atomicAdd(dbeta + 4 * c4, b.x); atomicAdd(dbeta + 4 * c4 + 1, b.y);
-      atomicAdd(dbeta + 4 * c4 + 2, b.z); atomicAdd(dbeta + 4 * c4 + 3, b.w);
+      float* p = partial + (long)blockIdx.x * 2 * C;
+      reinterpret_cast<float4*>(p)[c4] = a;
+      reinterpret_cast<float4*>(p + C)[c4] = b;
     }
   }
+}
+
+constexpr int LN_MAX_FOLD = 8;
+struct LnFoldArgs {
+  int n, C;
+  const float* partial[LN_MAX_FOLD];
+  int nwg[LN_MAX_FOLD];
+  float* dgamma[LN_MAX_FOLD];
+  float* dbeta[LN_MAX_FOLD];
+};
+// grid (ceil(C / 64), n): thread (channel, stat, half) sums the partial rows of its parity
+__global__ __launch_bounds__(256) void ln_fold_kernel(LnFoldArgs a) {
+  __shared__ float red[4][64];
+  const int t = threadIdx.x, chl = t & 63, grp = t >> 6, stat = grp & 1, half = grp >> 1;
+  const int c = blockIdx.x * 64 + chl, it = blockIdx.y, C = a.C;
+  float acc = 0.f;
+  if (c < C) {
+    const float* p = a.partial[it] + stat * C + c;
+    for (int b = half; b < a.nwg[it]; b += 2) acc += p[(long)b * 2 * C];
+  }
+  red[grp][chl] = acc;
+  __syncthreads();
+  if (grp == 0 && c < C) {
+    a.dgamma[it][c] += red[0][chl] + red[2][chl];
+    a.dbeta[it][c] += red[1][chl] + red[3][chl];
+  }
+}
+
+inline int ln_bwd_waves(int C) { return C <= 256 ? 16 : (C <= 512 ? 8 : 4); }
+inline int ln_bwd_wgs(long rows, int C) {
+  const int nw = ln_bwd_waves(C);
+  const long wgs = (rows + nw - 1) / nw;
+  return (int)(wgs > 256 ? 256 : (wgs < 1 ? 1 : wgs));
 }
 
 // ------------------------------------------------------------------ SiLU
@@ -247,56 +282,76 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(
   }
 }
 
-// every workgroup folds the NB partials of all channels (fixed order, double) into LDS
-__device__ __forceinline__ void bn_fold(const float* __restrict__ partial, int nb, int C,
-                                        double* __restrict__ s0, double* __restrict__ s1) {
-  for (int c = threadIdx.x; c < 2 * C; c += 256) {
-    double acc = 0.0;
-    for (int b = 0; b < nb; ++b) acc += (double)partial[(long)b * 2 * C + c];
-    if (c < C) s0[c] = acc; else s1[c - C] = acc;
-  }
-  __syncthreads();
-}
-
-__global__ __launch_bounds__(256) void bn_silu_fwd_kernel(
-    const float* __restrict__ x, const float* __restrict__ partial, int nb,
-    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+// Fold of the partials: one workgroup per 64 channels, thread (ch, stat, half) adds the partial
+// rows of its parity in a fixed order (double), then the four pieces meet in LDS.
+// KIND 0 -> save_mean / save_rstd (+ running statistics);  KIND 1 -> m[0][c] = mean(dz),
+// m[1][c] = mean(dz xhat) for the apply pass, dgamma / dbeta accumulated.
+template <int KIND>
+__global__ __launch_bounds__(256) void bn_finalize_kernel(
+    const float* __restrict__ partial, int nb, long rows, int C, float eps, float momentum,
     float* __restrict__ running_mean, float* __restrict__ running_var,
-    long* __restrict__ num_batches, long rows, int C, float* __restrict__ y,
-    float* __restrict__ save_mean, float* __restrict__ save_rstd) {
-  __shared__ double s0[1024], s1[1024];
-  __shared__ float smu[1024], srs[1024];
-  bn_fold(partial, nb, C, s0, s1);
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const double m = s0[c] / (double)rows;
-    double var = s1[c] / (double)rows - m * m;           // biased (normalisation)
-    if (var < 0.0) var = 0.0;
-    const float rs = (float)(1.0 / sqrt(var + (double)eps));
-    smu[c] = (float)m;
-    srs[c] = rs;
-    if (blockIdx.x == 0) {
-      save_mean[c] = (float)m;
-      save_rstd[c] = rs;
+    long* __restrict__ num_batches, float* __restrict__ out0, float* __restrict__ out1,
+    float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ double red[4][64];
+  const int t = threadIdx.x, chl = t & 63, grp = t >> 6, stat = grp & 1, half = grp >> 1;
+  const int c = blockIdx.x * 64 + chl;
+  double acc = 0.0;
+  if (c < C)
+    for (int b = half; b < nb; b += 2) acc += (double)partial[(long)b * 2 * C + stat * C + c];
+  red[grp][chl] = acc;
+  __syncthreads();
+  if (grp == 0 && c < C) {
+    const double s0 = red[0][chl] + red[2][chl], s1 = red[1][chl] + red[3][chl];
+    if (KIND == 0) {
+      const double m = s0 / (double)rows;
+      double var = s1 / (double)rows - m * m;           // biased (normalisation)
+      if (var < 0.0) var = 0.0;
+      out0[c] = (float)m;
+      out1[c] = (float)(1.0 / sqrt(var + (double)eps));
       if (running_mean) {
         const double unb = rows > 1 ? var * (double)rows / (double)(rows - 1) : var;
         running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
       }
+    } else {
+      out0[c] = (float)(s0 / (double)rows);
+      out1[c] = (float)(s1 / (double)rows);
+      dbeta[c] += (float)s0;                            // gradients are accumulated (flat buffer)
+      dgamma[c] += (float)s1;
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches) *num_batches += 1;
-  __syncthreads();
+  if (KIND == 0 && blockIdx.x == 0 && t == 0 && num_batches) *num_batches += 1;
+}
+
+__global__ __launch_bounds__(256) void bn_silu_bwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ ds, const float* __restrict__ m1,
+    const float* __restrict__ m2, const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, long rows, int C,
+    float* __restrict__ dx) {
   const long n4 = rows * (long)(C >> 2);
   const int cg = C >> 2;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-    const int c = 4 * (int)(i % cg);
+    const int c4 = (int)(i % cg);
     const float4 v = reinterpret_cast<const float4*>(x)[i];
-    float4 o;
-    o.x = silu_f((v.x - smu[c]) * srs[c] * gamma[c] + beta[c]);
-    o.y = silu_f((v.y - smu[c + 1]) * srs[c + 1] * gamma[c + 1] + beta[c + 1]);
-    o.z = silu_f((v.z - smu[c + 2]) * srs[c + 2] * gamma[c + 2] + beta[c + 2]);
-    o.w = silu_f((v.w - smu[c + 3]) * srs[c + 3] * gamma[c + 3] + beta[c + 3]);
-    reinterpret_cast<float4*>(y)[i] = o;
+    const float4 g = reinterpret_cast<const float4*>(ds)[i];
+    const float4 mu = reinterpret_cast<const float4*>(mean)[c4];
+    const float4 rs = reinterpret_cast<const float4*>(rstd)[c4];
+    const float4 ga = reinterpret_cast<const float4*>(gamma)[c4];
+    const float4 be = reinterpret_cast<const float4*>(beta)[c4];
+    const float4 a1 = reinterpret_cast<const float4*>(m1)[c4];
+    const float4 a2 = reinterpret_cast<const float4*>(m2)[c4];
+    const float vv[4] = {v.x, v.y, v.z, v.w}, gg[4] = {g.x, g.y, g.z, g.w};
+    const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, rsv[4] = {rs.x, rs.y, rs.z, rs.w};
+    const float gav[4] = {ga.x, ga.y, ga.z, ga.w}, bev[4] = {be.x, be.y, be.z, be.w};
+    const float a1v[4] = {a1.x, a1.y, a1.z, a1.w}, a2v[4] = {a2.x, a2.y, a2.z, a2.w};
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float xh = (vv[j] - muv[j]) * rsv[j];
+      const float dz = gg[j] * silu_deriv(gav[j] * xh + bev[j]);
+      o[j] = gav[j] * rsv[j] * (dz - a1v[j] - xh * a2v[j]);
+    }
+    reinterpret_cast<float4*>(dx)[i] = make_float4(o[0], o[1], o[2], o[3]);
   }
 }
 
@@ -317,41 +372,6 @@ __global__ __launch_bounds__(256) void bn_silu_apply_kernel(
     reinterpret_cast<float4*>(y)[i] =
         make_float4(silu_f((v.x - mu.x) * rs.x * ga.x + be.x), silu_f((v.y - mu.y) * rs.y * ga.y + be.y),
                     silu_f((v.z - mu.z) * rs.z * ga.z + be.z), silu_f((v.w - mu.w) * rs.w * ga.w + be.w));
-  }
-}
-
-__global__ __launch_bounds__(256) void bn_silu_bwd_kernel(
-    const float* __restrict__ x, const float* __restrict__ ds, const float* __restrict__ partial,
-    int nb, const float* __restrict__ mean, const float* __restrict__ rstd,
-    const float* __restrict__ gamma, const float* __restrict__ beta, long rows, int C,
-    float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  __shared__ double s0[1024], s1[1024];
-  __shared__ float m1[1024], m2[1024];
-  bn_fold(partial, nb, C, s0, s1);
-  for (int c = threadIdx.x; c < C; c += 256) {
-    m1[c] = (float)(s0[c] / (double)rows);             // mean of dz
-    m2[c] = (float)(s1[c] / (double)rows);             // mean of dz * xhat
-    if (blockIdx.x == 0) {                             // gradients are accumulated (flat buffer)
-      dbeta[c] += (float)s0[c];
-      dgamma[c] += (float)s1[c];
-    }
-  }
-  __syncthreads();
-  const long n4 = rows * (long)(C >> 2);
-  const int cg = C >> 2;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-    const int c = 4 * (int)(i % cg);
-    const float4 v = reinterpret_cast<const float4*>(x)[i];
-    const float4 g = reinterpret_cast<const float4*>(ds)[i];
-    const float vv[4] = {v.x, v.y, v.z, v.w}, gg[4] = {g.x, g.y, g.z, g.w};
-    float o[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float xh = (vv[j] - mean[c + j]) * rstd[c + j];
-      const float dz = gg[j] * silu_deriv(gamma[c + j] * xh + beta[c + j]);
-      o[j] = gamma[c + j] * rstd[c + j] * (dz - m1[c + j] - xh * m2[c + j]);
-    }
-    reinterpret_cast<float4*>(dx)[i] = make_float4(o[0], o[1], o[2], o[3]);
   }
 }
 
@@ -383,17 +403,46 @@ int s2t_layernorm_fwd(const float* x, const float* y, float alpha, const float* 
   return 0;
 }
 
+long s2t_layernorm_bwd_partial_floats(long rows, int C) {
+  return (long)ln_bwd_wgs(rows, C) * 2 * C;
+}
+
 int s2t_layernorm_bwd(const float* x, const float* stats, const float* gamma, const float* dy,
-                      const float* resid, long rows, int C, float* dx, float* dgamma, float* dbeta,
+                      const float* resid, long rows, int C, float* dx, float* partial,
                       void* stream) {
   if (rows <= 0) return 0;
   if (bad_rows(x, C) || bad_rows(dy, C) || bad_rows(dx, C) || (resid && bad_rows(resid, C)))
     return -2;
-  long wgs = (rows + 3) / 4;
-  if (wgs > 256) wgs = 256;
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream,
-                     x, stats, gamma, dy, resid, rows, C, dx, dgamma, dbeta);
+  const int wgs = ln_bwd_wgs(rows, C);
+#define S2T_LN_BWD(NV, NW)                                                                       \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<NV, NW>), dim3((unsigned)wgs), dim3(64 * NW), 0,      \
+                     (hipStream_t)stream, x, stats, gamma, dy, resid, rows, C, dx, partial);
+  if (C <= 256) S2T_LN_BWD(1, 16)
+  else if (C <= 512) S2T_LN_BWD(2, 8)
+  else if (C <= 768) S2T_LN_BWD(3, 4)
+  else S2T_LN_BWD(4, 4)
+#undef S2T_LN_BWD
   S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+int s2t_layernorm_param_grad(int n, const S2tLnFold* items, int C, void* stream) {
+  if (n <= 0) return 0;
+  if (!items || C < 4 || (C & 3) || C > 1024) return -1;
+  for (int base = 0; base < n; base += LN_MAX_FOLD) {
+    LnFoldArgs a;
+    a.n = n - base < LN_MAX_FOLD ? n - base : LN_MAX_FOLD;
+    a.C = C;
+    for (int i = 0; i < a.n; ++i) {
+      const S2tLnFold& it = items[base + i];
+      a.partial[i] = it.partial;
+      a.nwg[i] = ln_bwd_wgs(it.rows, C);
+      a.dgamma[i] = it.dgamma;
+      a.dbeta[i] = it.dbeta;
+    }
+    hipLaunchKernelGGL(ln_fold_kernel, dim3((C + 63) / 64, a.n), dim3(256), 0, (hipStream_t)stream, a);
+    S2T_CHECK_LAUNCH();
+  }
   return 0;
 }
 
@@ -419,8 +468,8 @@ int s2t_silu_bwd(const float* h, const float* da, long n, float scale, float* dh
   return 0;
 }
 
-// workspace: S2T_BN_PARTIALS x 2 x C floats
-long s2t_bn_workspace_floats(int C) { return (long)S2T_BN_PARTIALS * 2 * C; }
+// workspace: S2T_BN_PARTIALS x 2 x C floats of partial sums + 2 x C folded means (backward)
+long s2t_bn_workspace_floats(int C) { return (long)(S2T_BN_PARTIALS + 1) * 2 * C; }
 
 int s2t_bn_silu_fwd(const float* x, const float* gamma, const float* beta, float eps,
                     float momentum, float* running_mean, float* running_var, long* num_batches,
@@ -434,9 +483,12 @@ int s2t_bn_silu_fwd(const float* x, const float* gamma, const float* beta, float
   hipLaunchKernelGGL(bn_stats_kernel<0>, dim3(nb), dim3(256), 0, st, x, nullptr, nullptr, nullptr,
                      nullptr, nullptr, rows, C, per, workspace);
   S2T_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bn_silu_fwd_kernel, dim3(stream_grid(rows * (C / 4))), dim3(256), 0, st, x,
-                     workspace, nb, gamma, beta, eps, momentum, running_mean, running_var,
-                     num_batches, rows, C, y, save_mean, save_rstd);
+  hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3((C + 63) / 64), dim3(256), 0, st, workspace, nb,
+                     rows, C, eps, momentum, running_mean, running_var, num_batches, save_mean,
+                     save_rstd, nullptr, nullptr);
+  S2T_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn_silu_apply_kernel, dim3(stream_grid(rows * (C / 4))), dim3(256), 0, st, x,
+                     save_mean, save_rstd, gamma, beta, rows, C, y);
   S2T_CHECK_LAUNCH();
   return 0;
 }
@@ -464,8 +516,12 @@ int s2t_bn_silu_bwd(const float* x, const float* ds, const float* save_mean,
   hipLaunchKernelGGL(bn_stats_kernel<1>, dim3(nb), dim3(256), 0, st, x, ds, save_mean, save_rstd,
                      gamma, beta, rows, C, per, workspace);
   S2T_CHECK_LAUNCH();
+  float* m1 = workspace + (long)S2T_BN_PARTIALS * 2 * C;
+  hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3((C + 63) / 64), dim3(256), 0, st, workspace, nb,
+                     rows, C, 0.f, 0.f, nullptr, nullptr, nullptr, m1, m1 + C, dgamma, dbeta);
+  S2T_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_silu_bwd_kernel, dim3(stream_grid(rows * (C / 4))), dim3(256), 0, st, x, ds,
-                     workspace, nb, save_mean, save_rstd, gamma, beta, rows, C, dx, dgamma, dbeta);
+                     m1, m1 + C, save_mean, save_rstd, gamma, beta, rows, C, dx);
   S2T_CHECK_LAUNCH();
   return 0;
 }

@@ -389,23 +389,41 @@ extern "C" int s2t_gemm_tn_grouped(int n, const S2tTnProblem* probs, void* strea
   if (n <= 0) return 0;
   if (!probs) return -1;
   hipStream_t st = (hipStream_t)stream;
+  // Contraction slices per problem.  Every slice's tile is ADDED to the output with fp32 atomics,
+  // so the atomic traffic is (slices x output bytes); a slice count chosen per problem to fill
+  // the chip on its own (the single-problem rule: ~1536 blocks each) made a 17-problem layer
+  // launch write 22x its output.  The problems of a group run concurrently, so the GROUP has to
+  // fill the chip: slices = the multiple of 8 (one residue per XCD, see gemm_body) that brings
+  // the group's total to ~S2T_TN_GROUP_BLOCKS blocks (default 6144 = 4 rounds of 6 per CU).
+  static long target = -1;
+  if (target < 0) {
+    const char* e = getenv("S2T_TN_GROUP_BLOCKS");
+    target = e ? atol(e) : 6144;
+    if (target < 8) target = 8;
+  }
   for (int base = 0; base < n; base += MAXG) {
     TnGroup grp;
     grp.n = std::min(MAXG, n - base);
-    unsigned blocks = 0;
+    long total_tiles = 0;
     for (int i = 0; i < grp.n; ++i) {
       const S2tTnProblem& s = probs[base + i];
       if (s.M < 4 || s.N < 4 || s.K < 4 || (s.M & 3) || (s.N & 3) || (s.lda & 3) || (s.ldb & 3) ||
           (reinterpret_cast<uintptr_t>(s.A) & 15) || (reinterpret_cast<uintptr_t>(s.B) & 15) ||
           s.lda > INT32_MAX || s.ldb > INT32_MAX || s.ldc > INT32_MAX)
         return -2;
+      total_tiles += (long)((s.M + 63) / 64) * ((s.N + 63) / 64);
+    }
+    int want = (int)((target + total_tiles - 1) / total_tiles);
+    want = std::max(8, ((want + 4) / 8) * 8);
+    unsigned blocks = 0;
+    for (int i = 0; i < grp.n; ++i) {
+      const S2tTnProblem& s = probs[base + i];
       TnProb& q = grp.p[i];
       q = TnProb{s.A, s.B, s.C, s.colsum, (int)s.lda, (int)s.ldb, (int)s.ldc, s.M, s.N, s.K,
                  0, (s.M + 63) / 64, (s.N + 63) / 64, 0, s.alpha};
       const long tiles = (long)q.tiles_m * q.tiles_n;
-      int splits = (int)((1536 + tiles - 1) / tiles);          // as the single-problem 64x64 rule
       const int maxs = (s.K + 2 * KR - 1) / (2 * KR);
-      splits = std::max(1, std::min(splits, maxs));
+      int splits = std::max(1, std::min(want, maxs));
       int kper = (s.K + splits - 1) / splits;
       kper = ((kper + KR - 1) / KR) * KR;
       q.kper = kper;

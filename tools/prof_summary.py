@@ -31,8 +31,11 @@ def main(src, tag, steps, ms_per_step):
             return "ATen elementwise/reduce"
         if "rocclr" in k or "hipMemcpy" in k or "copyBuffer" in k or "fillBuffer" in k:
             return "copy/fill"
-        if "miopen" in k.lower() or "Im2d2Col" in k or "Col2Im" in k:
+        if ("miopen" in k.lower() or "Im2d2Col" in k or "Col2Im" in k or k.startswith("igemm_")
+                or k.startswith("batched_transpose") or k.startswith("SubTensorOp")):
             return "MIOpen"
+        if k in ("attn_fwd", "bwd_kernel_dk_dv", "bwd_kernel_dq", "bwd_preprocess"):
+            return "AOTriton (torch SDPA)"
         if "ccl" in k.lower():
             return "RCCL"
         return "hand-written HIP (libs2t_mi355)"
