@@ -477,6 +477,25 @@ int s2t_mhsa_bwd(const float* qkv, long ld, int qoff, int koff, int voff, const 
                  const float* o, const float* d_o, long ldo, const float* lse, float* delta,
                  float* dqkv, void* stream);
 
+/* ---- layer-norm LSTM layer of the RNN-T predictor (model/predictor/lstm_predictor.py:28-109 ->
+ * torchaudio 0.13.1 _Predictor / _CustomLSTM), whole sequence per launch, one workgroup per
+ * utterance (csrc/lstm.hip).  gx (T,B,4H) = x2g(x); wp_t = p2g.weight transposed (H,4H) for the
+ * forward, wp = p2g.weight (4H,H) for the backward; g_* / c_* = g_norm / c_norm weight and bias
+ * (all four NULL: no layer norm); h0 / c0 (B,H) or NULL = zeros.  The forward writes hs (T,B,H),
+ * the final state hT / cT (B,H) and keeps ghat (T,B,4H), chat (T,B,H), rstd (T,B,2) for the
+ * backward, which writes dgx (T,B,4H) (gradient w.r.t. the raw gates: the weight gradients of
+ * x2g / p2g are TN GEMMs over its rows) and ACCUMULATES the four LayerNorm parameter gradients.
+ * H <= 1024. */
+int s2t_lnlstm_fwd(const float* gx, const float* wp_t, const float* g_gamma, const float* g_beta,
+                   const float* c_gamma, const float* c_beta, const float* h0, const float* c0,
+                   int T, int B, int H, float eps, float* hs, float* ghat, float* chat,
+                   float* rstd, float* hT, float* cT, void* stream);
+int s2t_lnlstm_bwd(const float* wp, const float* g_gamma, const float* g_beta,
+                   const float* c_gamma, const float* c_beta, const float* c0, int T, int B, int H,
+                   const float* ghat, const float* chat, const float* rstd, const float* dhs,
+                   float* dgx, float* d_g_gamma, float* d_g_beta, float* d_c_gamma,
+                   float* d_c_beta, void* stream);
+
 /* ---- side stream for work off the critical path (csrc/streams.hip): the weight-gradient GEMMs
  * of backward overlap the data-gradient chain.  s2t_side_stream returns the library-owned stream;
  * s2t_stream_order(from, to) makes later work on `to` wait for the work enqueued so far on `from`. */

@@ -293,3 +293,84 @@ def mhsa(qkv, lengths, num_heads, dropout_p=0.0):
     lens = None if lengths is None else lengths.to(device=qkv.device, dtype=torch.int64).contiguous()
     seed = draw_seed() if dropout_p > 0.0 else 0
     return _Mhsa.apply(qkv, lens, num_heads, float(dropout_p), seed)
+
+
+# ------------------------------------------------------------------ layer-norm LSTM layer
+class _LnLstm(torch.autograd.Function):
+    """hs, hT, cT = LSTM(gx; p2g, g_norm, c_norm) for a whole sequence (csrc/lstm.hip): gx (T,B,4H)
+    = x2g(x).  Backward: one reverse-time kernel gives the gradient w.r.t. the raw gates; the
+    recurrent weight's gradient is a TN GEMM of it against the shifted hidden states."""
+
+    @staticmethod
+    def forward(ctx, gx, wp, gg, gb, cg, cb, eps, h0, c0):
+        T, B, G = gx.shape
+        H = G // 4
+        dev = gx.device
+        gx = gx.contiguous().float()
+        wp_t = wp.detach().t().contiguous()
+        hs = torch.empty((T, B, H), dtype=_F32, device=dev)
+        ghat = torch.empty((T, B, G), dtype=_F32, device=dev)
+        chat = torch.empty((T, B, H), dtype=_F32, device=dev)
+        rstd = torch.empty((T, B, 2), dtype=_F32, device=dev)
+        hT = torch.empty((B, H), dtype=_F32, device=dev)
+        cT = torch.empty((B, H), dtype=_F32, device=dev)
+        h0c = None if h0 is None else h0.contiguous().float()
+        c0c = None if c0 is None else c0.contiguous().float()
+        N.check(N.lib().s2t_lnlstm_fwd(N.fp(gx), N.fp(wp_t), N.fp(gg), N.fp(gb), N.fp(cg), N.fp(cb),
+                                       N.fp(h0c), N.fp(c0c), T, B, H, float(eps), N.fp(hs),
+                                       N.fp(ghat), N.fp(chat), N.fp(rstd), N.fp(hT), N.fp(cT),
+                                       N.stream()), "s2t_lnlstm_fwd")
+        ctx.save_for_backward(wp, gg, gb, cg, cb, ghat, chat, rstd, hs, h0c, c0c)
+        ctx.params = (wp, gg, gb, cg, cb)
+        ctx.mark_non_differentiable(hT, cT)
+        return hs, hT, cT
+
+    @staticmethod
+    def backward(ctx, dhs, _dh, _dc):
+        from . import zip_kernels as zk
+        wp, gg, gb, cg, cb, ghat, chat, rstd, hs, h0c, c0c = ctx.saved_tensors
+        wparam, ggp, gbp, cgp, cbp = ctx.params
+        T, B, G = ghat.shape
+        H = G // 4
+        dev = ghat.device
+        dhs = dhs.contiguous().float()
+        dgx = torch.empty_like(ghat)
+        ln = gg is not None
+        slots = _grad_slots([ggp, gbp, cgp, cbp]) if ln else None
+        if ln and slots is None:
+            acc = torch.zeros(2 * G + 2 * H, dtype=_F32, device=dev)
+            slots = [acc[:G], acc[G:2 * G], acc[2 * G:2 * G + H], acc[2 * G + H:]]
+            ret_ln = tuple(slots)
+        else:
+            ret_ln = (None, None, None, None)
+        wc = wp.contiguous()
+        N.check(N.lib().s2t_lnlstm_bwd(N.fp(wc), N.fp(gg), N.fp(gb), N.fp(cg), N.fp(cb),
+                                       N.fp(c0c), T, B, H, N.fp(ghat), N.fp(chat), N.fp(rstd),
+                                       N.fp(dhs), N.fp(dgx), N.fp(slots[0]) if ln else None,
+                                       N.fp(slots[1]) if ln else None,
+                                       N.fp(slots[2]) if ln else None,
+                                       N.fp(slots[3]) if ln else None, N.stream()),
+                "s2t_lnlstm_bwd")
+        # d p2g.weight = sum_t dg_t^T h_{t-1}
+        hprev = torch.empty_like(hs)
+        hprev[1:] = hs[:-1]
+        if h0c is None:
+            hprev[0].zero_()
+        else:
+            hprev[0] = h0c
+        g2, a2 = dgx.view(T * B, G), hprev.view(T * B, H)
+        dwp = None
+        if not zk.wgrad_into(wparam, None, g2, a2):
+            dwp, _ = zk.linear_wgrad(g2, a2, False)
+        return (dgx, dwp) + ret_ln + (None, None, None)
+
+
+def lnlstm(gx, p2g_weight, g_norm, c_norm, h0=None, c0=None):
+    """gx (T,B,4H) -> (hs (T,B,H), h_T, c_T).  g_norm / c_norm: nn.LayerNorm modules, or
+    nn.Identity (no layer norm)."""
+    if not gx.is_cuda:
+        raise RuntimeError("speech2text_amd.lnlstm needs device tensors (HIP path only)")
+    if isinstance(g_norm, torch.nn.LayerNorm):
+        return _LnLstm.apply(gx, p2g_weight, g_norm.weight, g_norm.bias, c_norm.weight,
+                             c_norm.bias, g_norm.eps, h0, c0)
+    return _LnLstm.apply(gx, p2g_weight, None, None, None, None, 0.0, h0, c0)

@@ -183,21 +183,27 @@ struct LnFoldArgs {
   float* dgamma[LN_MAX_FOLD];
   float* dbeta[LN_MAX_FOLD];
 };
-// grid (ceil(C / 64), n): thread (channel, stat, half) sums the partial rows of its parity
-__global__ __launch_bounds__(256) void ln_fold_kernel(LnFoldArgs a) {
-  __shared__ float red[4][64];
-  const int t = threadIdx.x, chl = t & 63, grp = t >> 6, stat = grp & 1, half = grp >> 1;
+// grid (ceil(C / 64), n, 2 stats): thread (channel, row group of 16) sums every 16th partial row
+// (short dependent chains, many loads in flight), then the 16 pieces meet in LDS
+__global__ __launch_bounds__(1024) void ln_fold_kernel(LnFoldArgs a) {
+  __shared__ float red[16][64];
+  const int t = threadIdx.x, chl = t & 63, grp = t >> 6, stat = blockIdx.z;
   const int c = blockIdx.x * 64 + chl, it = blockIdx.y, C = a.C;
   float acc = 0.f;
   if (c < C) {
     const float* p = a.partial[it] + stat * C + c;
-    for (int b = half; b < a.nwg[it]; b += 2) acc += p[(long)b * 2 * C];
+    const int nwg = a.nwg[it];
+#pragma unroll 4
+    for (int b = grp; b < nwg; b += 16) acc += p[(long)b * 2 * C];
   }
   red[grp][chl] = acc;
   __syncthreads();
   if (grp == 0 && c < C) {
-    a.dgamma[it][c] += red[0][chl] + red[2][chl];
-    a.dbeta[it][c] += red[1][chl] + red[3][chl];
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) s += red[g][chl];
+    float* dst = stat == 0 ? a.dgamma[it] : a.dbeta[it];
+    dst[c] += s;
   }
 }
 
@@ -282,26 +288,34 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(
   }
 }
 
-// Fold of the partials: one workgroup per 64 channels, thread (ch, stat, half) adds the partial
-// rows of its parity in a fixed order (double), then the four pieces meet in LDS.
+// Fold of the partials: one workgroup per 64 channels, thread (ch, stat, row group of 8) adds every
+// 8th partial row in a fixed order (double), then the pieces meet in LDS.
 // KIND 0 -> save_mean / save_rstd (+ running statistics);  KIND 1 -> m[0][c] = mean(dz),
 // m[1][c] = mean(dz xhat) for the apply pass, dgamma / dbeta accumulated.
 template <int KIND>
-__global__ __launch_bounds__(256) void bn_finalize_kernel(
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(
     const float* __restrict__ partial, int nb, long rows, int C, float eps, float momentum,
     float* __restrict__ running_mean, float* __restrict__ running_var,
     long* __restrict__ num_batches, float* __restrict__ out0, float* __restrict__ out1,
     float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  __shared__ double red[4][64];
-  const int t = threadIdx.x, chl = t & 63, grp = t >> 6, stat = grp & 1, half = grp >> 1;
+  __shared__ double red[16][64];
+  const int t = threadIdx.x, chl = t & 63, grp = t >> 6, stat = grp & 1, piece = grp >> 1;
   const int c = blockIdx.x * 64 + chl;
   double acc = 0.0;
-  if (c < C)
-    for (int b = half; b < nb; b += 2) acc += (double)partial[(long)b * 2 * C + stat * C + c];
+  if (c < C) {
+    const float* p = partial + stat * C + c;
+#pragma unroll 4
+    for (int b = piece; b < nb; b += 8) acc += (double)p[(long)b * 2 * C];
+  }
   red[grp][chl] = acc;
   __syncthreads();
   if (grp == 0 && c < C) {
-    const double s0 = red[0][chl] + red[2][chl], s1 = red[1][chl] + red[3][chl];
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      s0 += red[2 * g][chl];
+      s1 += red[2 * g + 1][chl];
+    }
     if (KIND == 0) {
       const double m = s0 / (double)rows;
       double var = s1 / (double)rows - m * m;           // biased (normalisation)
@@ -440,7 +454,8 @@ int s2t_layernorm_param_grad(int n, const S2tLnFold* items, int C, void* stream)
       a.dgamma[i] = it.dgamma;
       a.dbeta[i] = it.dbeta;
     }
-    hipLaunchKernelGGL(ln_fold_kernel, dim3((C + 63) / 64, a.n), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(ln_fold_kernel, dim3((C + 63) / 64, a.n, 2), dim3(1024), 0,
+                       (hipStream_t)stream, a);
     S2T_CHECK_LAUNCH();
   }
   return 0;
@@ -483,7 +498,7 @@ int s2t_bn_silu_fwd(const float* x, const float* gamma, const float* beta, float
   hipLaunchKernelGGL(bn_stats_kernel<0>, dim3(nb), dim3(256), 0, st, x, nullptr, nullptr, nullptr,
                      nullptr, nullptr, rows, C, per, workspace);
   S2T_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3((C + 63) / 64), dim3(256), 0, st, workspace, nb,
+  hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3((C + 63) / 64), dim3(1024), 0, st, workspace, nb,
                      rows, C, eps, momentum, running_mean, running_var, num_batches, save_mean,
                      save_rstd, nullptr, nullptr);
   S2T_CHECK_LAUNCH();
@@ -517,7 +532,7 @@ int s2t_bn_silu_bwd(const float* x, const float* ds, const float* save_mean,
                      gamma, beta, rows, C, per, workspace);
   S2T_CHECK_LAUNCH();
   float* m1 = workspace + (long)S2T_BN_PARTIALS * 2 * C;
-  hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3((C + 63) / 64), dim3(256), 0, st, workspace, nb,
+  hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3((C + 63) / 64), dim3(1024), 0, st, workspace, nb,
                      rows, C, 0.f, 0.f, nullptr, nullptr, nullptr, m1, m1 + C, dgamma, dbeta);
   S2T_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_silu_bwd_kernel, dim3(stream_grid(rows * (C / 4))), dim3(256), 0, st, x, ds,
