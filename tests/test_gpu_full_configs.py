@@ -90,6 +90,72 @@ def test_c3_yaml_dims_two_utterances_vs_oracle(dev):
     assert same >= 0.98, same                               # argmax ties can move a window by one
 
 
+@pytest.mark.parametrize("rv", [0.0, 0.2])
+def test_c3_yaml_dims_training_step_gradients_vs_oracle(dev, monkeypatch, rv):
+    """The code the bench times -- the layer executor's backward at D = 192 / 256, H = 4 / 8,
+    K = 31 / 15, T = 495 ... 62, the stateless predictor, the joiner with the simple loss, prune
+    ranges and the fused pruned lattice -- in TRAINING mode at the YAML dims: 2 x 10 s (ragged),
+    Python `random` pinned (0.0: every Balancer / Whiten / limit_param_value and the attention
+    score penalty fire; 0.2: the default-probability Balancers and every Whiten), positional
+    dropout off, feature masks from the same CPU generator.  Loss (0.5 simple + 0.5 pruned,
+    task_factory/rnnt_task.py:496-499) and EVERY parameter gradient against oracle/zipformer.py
+    + oracle/heads.py + oracle/k2_rnnt.py (k2 part parity unpinned)."""
+    from speech2text_amd import flat, rng, zip_layer
+    from speech2text_amd.build_task import TaskFactory
+    monkeypatch.setattr(rng, "rand", lambda *s, device=None, dtype=torch.float32:
+                        torch.rand(*s, dtype=dtype).to(device))
+    cfg = bench.c3_config(500)
+    random.seed(1234)
+    torch.manual_seed(1234)
+    task = TaskFactory.get("Pruned_Rnnt")(cfg)
+    pnames = {n for n, _ in task.named_parameters()}
+    sd = {k: v.detach().cpu().clone().requires_grad_(k in pnames and v.dtype.is_floating_point)
+          for k, v in task.state_dict().items()}
+    task.to(dev)
+    flat.get_store([p for p in task.parameters() if p.requires_grad])
+    batch = bench.make_batch(0, 2, 10.0, 50, 500, dev)
+    batch["pcm_length"][1] = 131000
+    batch["label_length"][1] = 37
+    task.eval()
+    with torch.no_grad():
+        feat, feat_len = task.features(batch)
+    task.train()
+    for mod in task.modules():
+        if mod.__class__.__name__ == "CompactRelPositionalEncoding":
+            mod.dropout.p = 0.0
+    fb = {"feat": feat, "feat_length": feat_len, "label": batch["label"],
+          "label_length": batch["label_length"]}
+    calls0 = zip_layer.CALLS[0]
+    monkeypatch.setattr(random, "random", lambda: rv)
+    torch.manual_seed(7)
+    loss = task.training_step(fb, 0)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert zip_layer.CALLS[0] - calls0 == 12, "the layer executor did not serve every layer"
+    # ---- oracle, same parameters / features / decisions
+    enc_sd = {k[len("_encoder.encoder."):]: v for k, v in sd.items() if k.startswith("_encoder.encoder.")}
+    lab, lab_len = batch["label"].cpu(), batch["label_length"].cpu()
+    torch.manual_seed(7)
+    yo, ylo = Z.zipformer_forward(enc_sd, bench._zcfg(cfg["encoder"]["config"]), feat.cpu(),
+                                  feat_len.cpu(), Z.Ctl(True, lambda: rv, pos_dropout=0.0), -1, -1)
+    po = H.stateless_predictor(sd, "_predictor.predictor.", lab, 5)
+    am, lm = H.joiner_projections(sd, "_joiner.", yo, po)
+    lo, bo, ro, so = K2.joiner_pruned(am, lm, lab, lab_len, ylo, 5)
+    pro = K2.rnnt_loss_pruned(lo, lab, ro, 0, bo)
+    ref = H.pruned_rnnt_task_loss(so, pro, 0.5, 0.5)
+    ref.backward()
+    assert _rel(loss, ref) <= 1e-3, (float(loss), float(ref))
+    worst, worst_name = 0.0, None
+    for n, p in task.named_parameters():
+        r = sd[n].grad
+        r = torch.zeros_like(sd[n]) if r is None else r
+        g = torch.zeros_like(r) if p.grad is None else p.grad.detach().cpu()
+        e = (g - r).abs().max().item() / (r.abs().max().item() + 1e-6)
+        if e > worst:
+            worst, worst_name = e, n
+    assert worst <= 5e-3, (worst_name, worst)
+
+
 def test_c3_full_batch_properties(dev):
     from speech2text_amd.build_task import TaskFactory
     from speech2text_amd.trainer import Trainer
@@ -211,9 +277,14 @@ def test_c4_hybrid_full_size(dev):
         l_ctc = task._ctc_loss({"logits": dec, "logits_length": dec_len, "targets": batch["label"],
                                 "targets_length": batch["label_length"]})
     assert joint.shape == (2, 248, 61, 128)
-    # unpruned lattice loss against the oracle recursion on the product's own lattice
-    ref = K2.rnnt_loss_full(joint.cpu(), batch["label"].cpu(), enc_len.cpu(),
-                            batch["label_length"].cpu())
+    # the joiner (projections, broadcast add, tanh, 2-Linear out-projection) against the oracle
+    # joiner on the product's encoder / predictor outputs, then the lattice loss on the ORACLE's
+    # lattice
+    sd = _cpu_sd(task)
+    with torch.no_grad():
+        jo = H.joiner_full(sd, "_joiner.", enc.cpu(), pred.cpu(), "tanh")
+    assert (joint.cpu() - jo).abs().max().item() <= 2e-4 * max(1.0, jo.abs().max().item())
+    ref = K2.rnnt_loss_full(jo, batch["label"].cpu(), enc_len.cpu(), batch["label_length"].cpu())
     assert _rel(l_rnnt, ref) <= 1e-3, (float(l_rnnt), float(ref))
     ref_ctc = torch.nn.functional.ctc_loss(dec.cpu().log_softmax(-1).transpose(0, 1),
                                            batch["label"].cpu(), dec_len.cpu(),
