@@ -351,6 +351,9 @@ int s2t_pad_rows(const float* packed, const long* offsets, int B, long Lmax, int
 int s2t_linear_lt(int mode, const float* X, long ldx, const float* W, long ldw, const float* bias,
                   const float* C, long ldc, float beta, float* D, long ldd, int M, int N, int K,
                   void* workspace, long ws_bytes, void* stream);
+/* plans made (one per exact shape, table capped) and buckets {mode, half-octave of M, N, K,
+ * bias} whose candidates were timed (capped by S2T_LT_TUNE_MAX, default 192) so far. */
+int s2t_linear_lt_stats(int* plans, int* timed);
 
 /* ---- fused glue of the zipformer layer (csrc/zip_glue.hip), rows of C channels, time-major.
  * bypass (model/encoder/zipformer.py:1523-1555): out = orig + (src - orig) * scale[c]; backward

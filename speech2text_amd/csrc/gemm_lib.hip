@@ -6,12 +6,19 @@
 //     `src = src + linear(h)` (model/encoder/zipformer.py:1095-1221) is one launch, and a data
 //     gradient can be accumulated onto an existing gradient (beta = 1);
 //   * the host pays a ~µs table lookup per call instead of a framework dispatch.
+// Shapes change almost every step under the reference's duration-bucketed batching
+// (dataset/sampler.py:71-96: M = T*B).  A plan (descriptors + the heuristic's candidates) is made
+// per exact shape (cheap), but candidates are TIMED only once per bucket {mode, half-octave
+// of M, N, K, bias}: later shapes of a bucket take the bucket's winning kernel if the heuristic
+// offers it for them too.  The number of timed buckets per process and the plan table are capped.
 // hipBLASLt is column-major; a row-major (rows, cols, ld) matrix is passed as the column-major
 // (cols, rows, ld) one, i.e. the row-major product Y = X W^T is computed as Y^T = W X^T.
 #include <hip/hip_runtime.h>
 #include <hipblaslt/hipblaslt.h>
 
+#include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -34,6 +41,29 @@ struct Plan {
 
 using Key = std::tuple<int, int, int, int, long, long, long, long, int>;
 std::map<Key, Plan> g_plans;
+using BKey = std::tuple<int, int, int, int, int>;          // mode, half-octave of M, N, K, bias
+std::map<BKey, hipblasLtMatmulAlgo_t> g_winner;            // the timed choice of a bucket
+int g_tunings = 0;
+constexpr size_t MAX_PLANS = 8192;
+
+int tune_budget() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("S2T_LT_TUNE_MAX");
+    v = e ? atoi(e) : 192;
+  }
+  return v;
+}
+
+int half_octave(int m) { return (int)std::floor(2.0 * std::log2((double)(m < 1 ? 1 : m))); }
+
+void destroy_plan(Plan& p) {
+  if (p.a) hipblasLtMatrixLayoutDestroy(p.a);
+  if (p.b) hipblasLtMatrixLayoutDestroy(p.b);
+  if (p.c) hipblasLtMatrixLayoutDestroy(p.c);
+  if (p.d) hipblasLtMatrixLayoutDestroy(p.d);
+  if (p.desc) hipblasLtMatmulDescDestroy(p.desc);
+}
 std::mutex g_mu;
 hipblasLtHandle_t g_handle = nullptr;
 
@@ -102,10 +132,10 @@ void tune(Plan& p, const float* X, const float* W, const float* C, float beta, l
   (void)hipEventCreate(&e1);
   const float alpha = 1.f;
   if (!C) C = scratch;                     // beta == 0: the C operand is only a placeholder
-  // 8 back-to-back runs of candidate i, timed after one untimed run; -1 if the library rejects it
+  // 4 back-to-back runs of candidate i, timed after one untimed run; -1 if the library rejects it
   auto time_cand = [&](int i) -> float {
     if (p.cand[i].workspaceSize > ws_bytes) return -1.f;
-    for (int rep = 0; rep < 9; ++rep) {
+    for (int rep = 0; rep < 5; ++rep) {
       if (rep == 1) (void)hipEventRecord(e0, st);
       if (hipblasLtMatmul(g_handle, p.desc, &alpha, W, p.a, X, p.b, &beta, C, p.c, scratch, p.d,
                           &p.cand[i].algo, workspace, p.cand[i].workspaceSize,
@@ -121,7 +151,8 @@ void tune(Plan& p, const float* X, const float* W, const float* C, float beta, l
   (void)time_cand(0);                      // clocks and caches up before anything is compared
   float best = 1e30f;
   int best_i = 0;
-  for (int i = 0; i < p.ncand; ++i) {
+  const int ntry = p.ncand < 8 ? p.ncand : 8;
+  for (int i = 0; i < ntry; ++i) {
     const float ms = time_cand(i);
     if (ms > 0.f && ms < best) {
       best = ms;
@@ -147,6 +178,14 @@ void tune(Plan& p, const float* X, const float* W, const float* C, float beta, l
 
 }  // namespace
 
+// (plans made, buckets timed) so far: tests / diagnostics
+extern "C" int s2t_linear_lt_stats(int* plans, int* timed) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  if (plans) *plans = (int)g_plans.size();
+  if (timed) *timed = g_tunings;
+  return 0;
+}
+
 // mode 0: D[M,N] = X[M,K] W[N,K]^T (+ bias[N]) (+ beta C[M,N]);   mode 1: D[M,K] = X[M,N] W[N,K] (+ beta C[M,K]).
 // Row-major, leading dimensions in floats.  C may be NULL when beta == 0, and may alias D.
 // Returns 0, -2 when hipBLASLt has no algorithm for the shape (caller falls back), or < -100.
@@ -165,6 +204,10 @@ extern "C" int s2t_linear_lt(int mode, const float* X, long ldx, const float* W,
   const Key key{mode, M, N, K, ldx, ldw, ldc, ldd, bias ? 1 : 0};
   auto it = g_plans.find(key);
   if (it == g_plans.end()) {
+    if (g_plans.size() >= MAX_PLANS) {       // bounded: start over (bucket winners are kept)
+      for (auto& kv : g_plans) destroy_plan(kv.second);
+      g_plans.clear();
+    }
     Plan p;
     const int rc = make_plan(p, mode, M, N, K, ldx, ldw, ldc, ldd, bias != nullptr, (size_t)ws_bytes);
     it = g_plans.emplace(key, p).first;
@@ -174,9 +217,28 @@ extern "C" int s2t_linear_lt(int mode, const float* X, long ldx, const float* W,
   if (!p.ok || p.ws > (size_t)ws_bytes) return -2;
   if (bias)
     LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)));
-  if (!p.tuned)
-    tune(p, X, W, C == D ? nullptr : C, C == D ? 0.f : beta, (long)M * ldd, workspace,
-         (size_t)ws_bytes, (hipStream_t)stream);
+  if (!p.tuned) {
+    const BKey bkey{mode, half_octave(M), N, K, bias ? 1 : 0};
+    auto w = g_winner.find(bkey);
+    if (w != g_winner.end()) {
+      // the bucket was timed on another M: take its kernel if the heuristic offers it here too
+      p.tuned = true;
+      for (int i = 0; i < p.ncand; ++i)
+        if (p.cand[i].workspaceSize <= (size_t)ws_bytes &&
+            memcmp(&p.cand[i].algo, &w->second, sizeof(hipblasLtMatmulAlgo_t)) == 0) {
+          p.algo = p.cand[i].algo;
+          p.ws = p.cand[i].workspaceSize;
+          break;
+        }
+    } else if (g_tunings < tune_budget()) {
+      tune(p, X, W, C == D ? nullptr : C, C == D ? 0.f : beta, (long)M * ldd, workspace,
+           (size_t)ws_bytes, (hipStream_t)stream);
+      g_winner.emplace(bkey, p.algo);
+      ++g_tunings;
+    } else {
+      p.tuned = true;                      // budget spent: the heuristic's first choice
+    }
+  }
   const float alpha = 1.f;
   LT_CHECK(hipblasLtMatmul(g_handle, p.desc, &alpha, W, p.a, X, p.b, &beta, C, p.c, D, p.d, &p.algo,
                            workspace, p.ws, (hipStream_t)stream));

@@ -162,3 +162,51 @@ def test_grouped_wgrad_launch(dev):
         assert err < 2e-5, err
         if b is not None:
             assert ((b.grad.double() - 0.5 - db).abs().max() / db.abs().max()) < 2e-5
+
+
+def test_lt_plan_cache_survives_dynamic_batching(dev):
+    """The reference batches by duration (dataset/sampler.py:71-96), so M = T*B changes almost
+    every step.  50 distinct (T, B) shapes over the C3 layer's projections must cost well under a
+    second of extra host time in total: plans are per exact shape, but candidates are timed once
+    per {mode, half-octave of M, N, K} bucket and the number of timed buckets is capped."""
+    import ctypes
+    import time
+    from speech2text_amd import _native as N
+    from speech2text_amd import zip_kernels as zk
+    g = torch.Generator().manual_seed(0)
+    nk = [(576, 256), (768, 256), (960, 256), (256, 576), (256, 768), (256, 960), (272, 256),
+          (512, 256), (256, 256), (48, 256)]
+    Ws = [torch.randn(n, k, generator=g).to(dev) * 0.05 for n, k in nk]
+    bs = [torch.randn(n, generator=g).to(dev) for n, _ in nk]
+    shapes = [(t, b) for t in (150, 173, 199, 214, 248) for b in (20, 27, 33, 41, 48, 52, 57, 60, 64, 70)]
+    assert len(set(t * b for t, b in shapes)) == 50
+    xs = {k: torch.randn(max(t * b for t, b in shapes), k, generator=g).to(dev) for k in (256, 576, 768, 960)}
+    zk.lt_matmul(0, xs[256][:4096], Ws[0], bs[0])                # library handle, first tuning
+    torch.cuda.synchronize()
+
+    def sweep():
+        t0 = time.perf_counter()
+        for t, b in shapes:
+            R = t * b
+            for W, bias in zip(Ws, bs):
+                y = zk.lt_matmul(0, xs[W.shape[1]][:R], W, bias)
+                zk.lt_matmul(1, y, W)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    plans0, timed0 = ctypes.c_int(), ctypes.c_int()
+    N.lib().s2t_linear_lt_stats(ctypes.byref(plans0), ctypes.byref(timed0))
+    first = sweep()
+    plans1, timed1 = ctypes.c_int(), ctypes.c_int()
+    N.lib().s2t_linear_lt_stats(ctypes.byref(plans1), ctypes.byref(timed1))
+    second = sweep()                                             # every shape cached now
+    assert plans1.value - plans0.value >= 900                    # 50 shapes x 10 projections x 2 modes
+    print(f"plans {plans1.value - plans0.value}, timed buckets {timed1.value - timed0.value}, "
+          f"first sweep {first:.3f} s, cached sweep {second:.3f} s")
+    assert timed1.value - timed0.value <= 130, timed1.value      # ~6 half-octave buckets x 20
+    assert first - second < 1.0, (first, second)
+    # and the bucket's choice is still a correct GEMM
+    R = 173 * 41
+    y = zk.lt_matmul(0, xs[256][:R], Ws[1], bs[1])
+    ref = torch.nn.functional.linear(xs[256][:R].double(), Ws[1].double(), bs[1].double())
+    assert (y.double() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
