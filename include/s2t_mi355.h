@@ -480,6 +480,37 @@ int s2t_mhsa_bwd(const float* qkv, long ld, int qoff, int koff, int voff, const 
                  const float* o, const float* d_o, long ldo, const float* lse, float* delta,
                  float* dqkv, void* stream);
 
+/* ---- first convolution of the conformer Subsampling (model/encoder/conformer.py:47-60,114-126):
+ * Conv2d(1, C, 3, stride 2) + ReLU on x (B, T, F) -> out (B, T1, F1, C) channel-last, T1 =
+ * (T-3)/2+1, F1 = (F-3)/2+1; w (C, 9), bias (C).  s2t_conv1_relu_wgrad: dw (C, 9) and db (C) are
+ * ACCUMULATED from d_out (gradient w.r.t. out, same layout); the ReLU mask is recomputed from x.
+ * C % 4 == 0, 256 % (C/4) == 0.  workspace: s2t_conv1_relu_workspace_floats(C) floats. */
+long s2t_conv1_relu_workspace_floats(int C);
+int s2t_conv1_relu_fwd(const float* x, const float* w, const float* bias, int B, int T, int F,
+                       int C, float* out, void* stream);
+int s2t_conv1_relu_wgrad(const float* x, const float* w, const float* bias, const float* d_out,
+                         int B, int T, int F, int C, float* dw, float* db, float* workspace,
+                         void* stream);
+
+/* ---- Adam / AdamW on the flat parameter / gradient buffers (torch.optim.Adam / AdamW, amsgrad
+ * off: the conformer YAMLs' `optimizer: type: "AdamW"`, optimizer/optim_setup.py:364-385) with the
+ * trainer's grad-norm clip and zero_grad folded in: s2t_seg_stats -> s2t_clip_coef (out[0] =
+ * min(1, clip / (||g|| + 1e-6)), out[1] = ||g||; clip <= 0: 1) -> s2t_adam_apply.  Chunk tables as
+ * for ScaledAdam; group q owns the chunks below groups[q].chunk_hi that no earlier group owns;
+ * chunks past the last group are only zeroed.  `groups` is a HOST array. */
+#define S2T_ADAM_MAX_GROUPS 8
+typedef struct S2tAdamGroup {
+  int chunk_hi;
+  float lr, beta1, beta2, eps, weight_decay;
+  float bias_correction1;         /* 1 - beta1^step */
+  float sqrt_bias_correction2;    /* sqrt(1 - beta2^step) */
+  int decoupled;                  /* 1: AdamW, 0: Adam (L2 added to the gradient) */
+} S2tAdamGroup;
+int s2t_clip_coef(const float* partial, int nchunks, float clip_val, float* out, void* stream);
+int s2t_adam_apply(float* p, float* g, float* exp_avg, float* exp_avg_sq, const int* chunk_off,
+                   const int* chunk_len, int nchunks, int ngroups, const S2tAdamGroup* groups,
+                   const float* coef, int zero_grad, void* stream);
+
 /* ---- layer-norm LSTM layer of the RNN-T predictor (model/predictor/lstm_predictor.py:28-109 ->
  * torchaudio 0.13.1 _Predictor / _CustomLSTM), whole sequence per launch, one workgroup per
  * utterance (csrc/lstm.hip).  gx (T,B,4H) = x2g(x); wp_t = p2g.weight transposed (H,4H) for the

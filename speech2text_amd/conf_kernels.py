@@ -374,3 +374,69 @@ def lnlstm(gx, p2g_weight, g_norm, c_norm, h0=None, c0=None):
         return _LnLstm.apply(gx, p2g_weight, g_norm.weight, g_norm.bias, c_norm.weight,
                              c_norm.bias, g_norm.eps, h0, c0)
     return _LnLstm.apply(gx, p2g_weight, None, None, None, None, 0.0, h0, c0)
+
+
+# ------------------------------------------------------------------ Subsampling: first conv + ReLU
+def conv1_relu_ok(conv, x):
+    C = conv.out_channels
+    return (x.is_cuda and conv.in_channels == 1 and conv.kernel_size == (3, 3)
+            and conv.stride == (2, 2) and conv.padding == (0, 0) and conv.bias is not None
+            and C % 4 == 0 and C <= 1024 and 256 % (C // 4) == 0 and x.shape[-1] >= 3
+            and x.shape[-2] >= 3)
+
+
+class _Conv1Relu(torch.autograd.Function):
+    """relu(Conv2d(1, C, 3, stride 2)(x)) for x (B,T,F) -> (B,C,T1,F1) in channels_last memory
+    (csrc/conf_front.hip).  Backward: weight / bias gradients from one pass over the incoming
+    gradient (ReLU mask recomputed); the input gradient (features never need one in training) is
+    formed with torch ops when a test asks for it."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x3 = x.contiguous().float()
+        B, T, F_ = x3.shape
+        C = weight.shape[0]
+        T1, F1 = (T - 3) // 2 + 1, (F_ - 3) // 2 + 1
+        out = torch.empty((B, T1, F1, C), dtype=_F32, device=x.device)
+        w2 = weight.detach().reshape(C, 9).contiguous()
+        b1 = bias.detach().contiguous()
+        N.profile_note("s2t_conv1_relu_fwd", 4.0 * (x3.numel() + out.numel()))
+        N.check(N.lib().s2t_conv1_relu_fwd(N.fp(x3), N.fp(w2), N.fp(b1), B, T, F_, C, N.fp(out),
+                                           N.stream()), "s2t_conv1_relu_fwd")
+        ctx.save_for_backward(x3, w2, b1)
+        ctx.params = (weight, bias)
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        x3, w2, b1 = ctx.saved_tensors
+        weight, bias = ctx.params
+        B, T, F_ = x3.shape
+        C = w2.shape[0]
+        d = g.permute(0, 2, 3, 1)
+        if not d.is_contiguous() or d.dtype != _F32:
+            d = d.contiguous().float()
+        slots = _grad_slots([weight, bias])
+        if slots is None:
+            acc = torch.zeros(10 * C, dtype=_F32, device=x3.device)
+            dw, db = acc[:9 * C], acc[9 * C:]
+        else:
+            dw, db = slots
+        ws = torch.empty(N.lib().s2t_conv1_relu_workspace_floats(C), dtype=_F32, device=x3.device)
+        N.profile_note("s2t_conv1_relu_wgrad", 4.0 * (x3.numel() + d.numel()))
+        N.check(N.lib().s2t_conv1_relu_wgrad(N.fp(x3), N.fp(w2), N.fp(b1), N.fp(d), B, T, F_, C,
+                                             N.raw(dw), N.raw(db), N.fp(ws), N.stream()),
+                "s2t_conv1_relu_wgrad")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            z = torch.nn.functional.conv2d(x3.unsqueeze(1), w2.view(C, 1, 3, 3), b1, stride=2)
+            dx = torch.nn.grad.conv2d_input((B, 1, T, F_), w2.view(C, 1, 3, 3), g * (z > 0),
+                                            stride=2).view(B, T, F_)
+        if slots is None:
+            return dx, dw.view(weight.shape), db
+        return dx, None, None
+
+
+def conv1_relu(x, conv):
+    """x (B,T,F) -> relu(conv(x.unsqueeze(1))) as (B,C,T1,F1) channels_last."""
+    return _Conv1Relu.apply(x, conv.weight, conv.bias)

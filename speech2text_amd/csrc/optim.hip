@@ -10,6 +10,7 @@
 //   3. apply          one workgroup per chunk: g *= clip, delta/exp_avg_sq/param update, g = 0
 // HBM-bound: 2 + 8 fp32 streams over the parameter count (C3: 22.9 M params -> 0.92 GB/step).
 #include "common.h"
+#include "../../include/s2t_mi355.h"
 
 namespace {
 
@@ -261,9 +262,116 @@ __global__ __launch_bounds__(256) void scaled_adam_apply_kernel(
   }
 }
 
+// ---- Adam / AdamW on the flat buffers (torch.optim.Adam / AdamW semantics, amsgrad off):
+// the conformer configs (config/training/conformer_*.yaml `optimizer: type: "AdamW"`).
+// clip_coef: ONE workgroup folds the per-chunk sums of g^2 (seg_stats) in a fixed order and
+// writes min(1, clip / (norm + 1e-6)); adam_apply: one workgroup per chunk.
+__global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict__ partial,
+                                                        int nchunks, float clip_val,
+                                                        float* __restrict__ out) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nchunks; i += 256) s += (double)partial[3 * (long)i];
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double norm = sqrt((red[0] + red[1]) + (red[2] + red[3]));
+    out[0] = clip_val > 0.f ? (float)fmin(1.0, (double)clip_val / (norm + 1.0e-6)) : 1.f;
+    out[1] = (float)norm;
+  }
+}
+
+struct AdamGroups {
+  int n;
+  int chunk_hi[S2T_ADAM_MAX_GROUPS];      // group q owns chunks [chunk_hi[q-1], chunk_hi[q])
+  float lr[S2T_ADAM_MAX_GROUPS], beta1[S2T_ADAM_MAX_GROUPS], beta2[S2T_ADAM_MAX_GROUPS],
+      eps[S2T_ADAM_MAX_GROUPS], wd[S2T_ADAM_MAX_GROUPS], bc1[S2T_ADAM_MAX_GROUPS],
+      bc2s[S2T_ADAM_MAX_GROUPS];          // bc2s = sqrt(1 - beta2^step)
+  int decoupled[S2T_ADAM_MAX_GROUPS];     // 1: AdamW (p *= 1 - lr wd), 0: Adam (g += wd p)
+};
+
+__global__ __launch_bounds__(256) void adam_apply_kernel(
+    float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+    const int* __restrict__ chunk_off, const int* __restrict__ chunk_len, AdamGroups G,
+    const float* __restrict__ coef, int zero_grad) {
+  const int b = blockIdx.x;
+  int q = 0;
+  while (q < G.n && b >= G.chunk_hi[q]) ++q;
+  const long off = chunk_off[b];
+  const int len = chunk_len[b];
+  float4* g4 = reinterpret_cast<float4*>(g + off);
+  if (q >= G.n) {                              // trainable tensor outside every group
+    if (zero_grad)
+      for (int i = threadIdx.x; i < (len >> 2); i += 256) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
+  const float lr = G.lr[q], b1 = G.beta1[q], b2 = G.beta2[q], eps = G.eps[q], wd = G.wd[q];
+  const float step_size = lr / G.bc1[q], inv_bc2s = 1.f / G.bc2s[q];
+  const bool dec = G.decoupled[q] != 0;
+  const float shrink = dec ? 1.f - lr * wd : 1.f;
+  const float c = coef[0];
+  float4* p4 = reinterpret_cast<float4*>(p + off);
+  float4* m4 = reinterpret_cast<float4*>(m + off);
+  float4* v4 = reinterpret_cast<float4*>(v + off);
+  for (int i = threadIdx.x; i < (len >> 2); i += 256) {
+    float4 pv = p4[i], gv = g4[i], mv = m4[i], vv = v4[i];
+    float* pp = &pv.x;
+    float* gg = &gv.x;
+    float* mm = &mv.x;
+    float* ww = &vv.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float gj = gg[j] * c;
+      float pj = pp[j] * shrink;
+      if (!dec) gj += wd * pp[j];
+      mm[j] += (1.f - b1) * (gj - mm[j]);                   // lerp
+      ww[j] = ww[j] * b2 + (1.f - b2) * gj * gj;
+      const float denom = sqrtf(ww[j]) * inv_bc2s + eps;
+      pp[j] = pj - step_size * mm[j] / denom;
+      gg[j] = zero_grad ? 0.f : gj;
+    }
+    p4[i] = pv;
+    m4[i] = mv;
+    v4[i] = vv;
+    g4[i] = gv;
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int s2t_clip_coef(const float* partial, int nchunks, float clip_val, float* out, void* stream) {
+  if (nchunks <= 0) return -1;
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, nchunks,
+                     clip_val, out);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+int s2t_adam_apply(float* p, float* g, float* exp_avg, float* exp_avg_sq, const int* chunk_off,
+                   const int* chunk_len, int nchunks, int ngroups, const S2tAdamGroup* groups,
+                   const float* coef, int zero_grad, void* stream) {
+  if (nchunks <= 0 || ngroups < 0 || ngroups > S2T_ADAM_MAX_GROUPS) return -1;
+  AdamGroups G;
+  G.n = ngroups;
+  for (int q = 0; q < ngroups; ++q) {
+    G.chunk_hi[q] = groups[q].chunk_hi;
+    G.lr[q] = groups[q].lr;
+    G.beta1[q] = groups[q].beta1;
+    G.beta2[q] = groups[q].beta2;
+    G.eps[q] = groups[q].eps;
+    G.wd[q] = groups[q].weight_decay;
+    G.bc1[q] = groups[q].bias_correction1;
+    G.bc2s[q] = groups[q].sqrt_bias_correction2;
+    G.decoupled[q] = groups[q].decoupled;
+  }
+  hipLaunchKernelGGL(adam_apply_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, p, g,
+                     exp_avg, exp_avg_sq, chunk_off, chunk_len, G, coef, zero_grad);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
 
 int s2t_optim_chunk_elems(void) { return kChunk; }
 int s2t_optim_segc_floats(void) { return kSegC; }

@@ -68,8 +68,15 @@ class Subsampling(nn.Module):
         # channel-last all the way: MIOpen's implicit-GEMM kernels are NHWC natively (an NCHW
         # call wraps them in two transposes of the 32 x 256 x 498 x 39 activation), and the
         # Linear consumes the (t, f, c) order through a column-permuted view of its weight
-        x = x.unsqueeze(1).contiguous(memory_format=torch.channels_last)
-        for m in self.conv:
+        convs = list(self.conv)
+        if ck.conv1_relu_ok(convs[0], x):
+            # Conv2d(1, D, 3, 2) + ReLU as one direct stencil kernel (csrc/conf_front.hip): its
+            # (B, D, T/2, 39) output is the largest tensor of the step
+            x = ck.conv1_relu(x, convs[0])
+            convs = convs[2:]
+        else:
+            x = x.unsqueeze(1).contiguous(memory_format=torch.channels_last)
+        for m in convs:
             if isinstance(m, nn.Conv2d):
                 x = F.conv2d(x, m.weight.contiguous(memory_format=torch.channels_last), m.bias,
                              m.stride)

@@ -5,9 +5,9 @@ from enum import Enum, unique
 from typing import Union
 
 import torch
-from torch.optim import Adam, AdamW
 from torch.optim.lr_scheduler import CosineAnnealingLR, _LRScheduler
 
+from speech2text_amd.optimizer.flat_adam import FlatAdam, FlatAdamW
 from speech2text_amd.optimizer.scaled_adam import ScaledAdam
 
 
@@ -112,8 +112,8 @@ class NoamHoldAnnealing(_LRScheduler):
 
 @unique
 class OptimizerPool(Enum):
-    Adam = Adam
-    AdamW = AdamW
+    Adam = FlatAdam       # torch.optim.Adam / AdamW semantics, fused over the flat buffers on the GPU
+    AdamW = FlatAdamW
     ScaledAdam = ScaledAdam
 
 

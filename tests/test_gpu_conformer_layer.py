@@ -220,7 +220,11 @@ def _stack_vs_oracle(dev, cfg, B, T, lens, tol_out, tol_grad, seed=0):
         ref = sd[n].grad
         got = p.grad.detach().cpu()
         err = (got - ref).abs().max().item()
-        # (a bias in front of BatchNorm has zero true gradient: pure rounding noise)
+        if n.endswith("conv_module.sequential.2.bias"):
+            # the depthwise conv's bias sits in front of BatchNorm: its true gradient is exactly
+            # zero and both sides hold rounding noise of the (large) per-channel sums
+            assert err <= 1e-4 * p.shape[0] ** 0.5 * max(1.0, float(w.abs().max())), (n, err)
+            continue
         assert err <= tol_grad * ref.abs().max().item() + 3e-4, (n, err, ref.abs().max().item())
     # running statistics were updated like torch's BatchNorm1d does
     for k, v in m.state_dict().items():

@@ -74,3 +74,45 @@ def test_fused_scaled_adam_matches_torch_form(dev, period, clip):
         np.testing.assert_allclose(sg["param_rms"].cpu().numpy(), sc["param_rms"].numpy(), rtol=1e-5)
         assert int(sg["istate"][0]) == int(sc["istate"][0])
         np.testing.assert_allclose(float(sg["fstate"][0]), float(sc["fstate"][0]), rtol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["AdamW", "Adam"])
+def test_flat_adam_follows_torch(dev, name):
+    """The fused flat Adam / AdamW (3 launches: chunk sums, clip factor, update + zero_grad)
+    against torch.optim's own step + clip_grad_norm_ on the same gradients, two param groups,
+    and a state_dict round trip in torch's layout."""
+    from speech2text_amd.flat import FlatStore
+    from speech2text_amd.optimizer.optim_setup import OptimSetup
+    torch.manual_seed(0)
+    shapes = [(300, 17), (33,), (64, 8, 3), (5,), (1000, 9)]
+    ps = [torch.nn.Parameter(torch.randn(s, device=dev)) for s in shapes]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    Opt, _ = OptimSetup({"optimizer": {"type": name}, "lr_scheduler": {"type": "Warmup"}})
+    groups = lambda q: [{"params": q[:2], "lr": 3e-3, "weight_decay": 0.01},     # noqa: E731
+                        {"params": q[2:], "lr": 1e-3, "weight_decay": 0.1}]
+    FlatStore(ps)
+    opt = Opt(groups(ps), betas=(0.9, 0.98), eps=1e-8)
+    opt.pre_clip = 2.0
+    opt.zero_grad_in_step = True
+    topt = getattr(torch.optim, name)(groups(ref), betas=(0.9, 0.98), eps=1e-8)
+    g = torch.Generator().manual_seed(1)
+    for it in range(12):
+        grads = [torch.randn(s, generator=g) * (4.0 if it % 5 == 2 else 0.3) for s in shapes]
+        for p, r, gr in zip(ps, ref, grads):
+            p.grad.copy_(gr.to(dev))
+            r.grad = gr.to(dev).clone()
+        torch.nn.utils.clip_grad_norm_(ref, 2.0)
+        topt.step()
+        opt.step()
+        assert opt._flat not in (None, False), "the fused path did not run"
+        if it == 5:                                       # checkpoint round trip mid-way
+            sd = opt.state_dict()
+            assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+            opt2 = Opt(groups(ps), betas=(0.9, 0.98), eps=1e-8)
+            opt2.pre_clip, opt2.zero_grad_in_step = 2.0, True
+            opt2.load_state_dict(sd)
+            opt = opt2
+    for p, r in zip(ps, ref):
+        assert float(p.grad.abs().sum()) == 0.0            # zeroed inside the step
+        np.testing.assert_allclose(p.detach().cpu().numpy(), r.detach().cpu().numpy(), atol=2e-6,
+                                   rtol=2e-5)
