@@ -530,6 +530,22 @@ int s2t_lnlstm_bwd(const float* wp, const float* g_gamma, const float* g_beta,
                    float* dgx, float* d_g_gamma, float* d_g_beta, float* d_c_gamma,
                    float* d_c_beta, void* stream);
 
+/* ---- fp32 GEMM on the bf16 matrix cores (csrc/gemm_x3.hip): every fp32 value is split exactly
+ * into three bf16 pieces and the product evaluated as the six piece products of weight <= 2 with
+ * fp32 accumulation -- fp32-level error at 6/16 of the f32-MFMA cost.  Serves the forward
+ * (y = x W^T) and data-gradient (dx = g W = g (W^T)^T) products of every nn.Linear.
+ * s2t_split_planes: src[n] fp32 -> planes[p * plane + i], p = 0..2 (bf16 bits), n % 4 == 0.
+ * s2t_split_planes_t: the planes of the TRANSPOSES of ntab row-major matrices of one flat buffer
+ *   (tab: DEVICE array of {long off; int R, C, tile_begin}).
+ * s2t_gemm_x3_nt: C[M,N] = A[M,K] . W[N,K]^T (+ bias[N]) (+ beta R[M,N]); A fp32 (split while
+ *   staged), W = planes (row n of piece p at W + p * plane + n * ldw); K % 8 == 0. */
+int s2t_split_planes(const float* src, long n, unsigned short* planes, long plane, void* stream);
+int s2t_split_planes_t(const float* src, const void* tab, int ntab, int total_tiles,
+                       unsigned short* planes_t, long plane, void* stream);
+int s2t_gemm_x3_nt(const float* A, long lda, const unsigned short* W, long ldw, long plane,
+                   float* C, long ldc, int M, int N, int K, const float* bias, const float* resid,
+                   long ldr, float beta, void* stream);
+
 /* ---- side stream for work off the critical path (csrc/streams.hip): the weight-gradient GEMMs
  * of backward overlap the data-gradient chain.  s2t_side_stream returns the library-owned stream;
  * s2t_stream_order(from, to) makes later work on `to` wait for the work enqueued so far on `from`. */

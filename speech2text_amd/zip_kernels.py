@@ -265,6 +265,23 @@ def _whiten_scratch(dev, C):
     return ent
 
 
+_STATS_SIDE = os.environ.get("S2T_WHITEN_STREAM", "1") == "1"
+
+
+def _stats_stream():
+    """Side-stream handle for forward-pass statistics, ordered after the work enqueued so far on
+    the current stream; None when disabled (then the statistics run on the current stream)."""
+    if not (_STATS_SIDE and _Side.enabled):
+        return None
+    if _Side.handle is None:
+        h = N.lib().s2t_side_stream()
+        if not h:
+            return None
+        _Side.handle = ctypes.c_void_p(h)
+    N.check(N.lib().s2t_stream_order(N.stream(), _Side.handle), "s2t_stream_order(stats)")
+    return _Side.handle
+
+
 class WhitenStats:
     """Whitening statistics of x, computed when the module fires in FORWARD (they depend on x
     only) so that the scalar `metric` reaches the host through pinned memory long before the
@@ -286,8 +303,13 @@ class WhitenStats:
         # persistent (C+1, C) buffer that the metric kernel hands back zeroed
         acc, ws = _whiten_scratch(dev, C)
         xtx, colsum = acc[:C], acc[C]
+        # The statistics depend on x only and nothing in the forward pass reads them: they run on
+        # the library's side stream (ordered after the kernel that produced x), filling the CUs
+        # the main chain's small kernels leave idle.  All statistics share one accumulator per
+        # channel count; the side stream serialises them in issue order.
+        side = _stats_stream() if _tn_ok(xf) else None
         if _tn_ok(xf):
-            gemm_tn(xf, xf, xtx, colsum)
+            gemm_tn(xf, xf, xtx, colsum, stream=side)
         else:
             a, b = linear_wgrad(xf, xf, True)
             xtx.copy_(a)
@@ -299,10 +321,13 @@ class WhitenStats:
         N.check(N.lib().s2t_whiten_metric(N.fp(xtx), N.fp(colsum), n, G, cg, N.fp(self.cov),
                                           N.fp(self.mean), N.fp(self.scal),
                                           ctypes.c_void_p(self.host.data_ptr()), N.fp(ws),
-                                          N.stream()),
+                                          side if side is not None else N.stream()),
                 "s2t_whiten_metric")
         self.event = torch.cuda.Event()
-        self.event.record()
+        if side is not None:
+            self.event.record(N._launch_stream((side,)))
+        else:
+            self.event.record()
         self.num_groups, self.cg = G, cg
 
     def metric(self):

@@ -210,3 +210,44 @@ def test_lt_plan_cache_survives_dynamic_batching(dev):
     y = zk.lt_matmul(0, xs[256][:R], Ws[1], bs[1])
     ref = torch.nn.functional.linear(xs[256][:R].double(), Ws[1].double(), bs[1].double())
     assert (y.double() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("M,K,N", [(4097, 256, 768), (1001, 136, 72), (15872, 960, 256), (300, 8, 40)])
+def test_bf16x3_split_gemm_has_fp32_accuracy(dev, M, K, N):
+    """s2t_gemm_x3_nt: fp32 operands split exactly into three bf16 pieces, six bf16 MFMA products
+    with fp32 accumulation (csrc/gemm_x3.hip; verified, not on the step's path).  Its error
+    against fp64 must not exceed the fp32 library GEMM's; bias + residual epilogue included; the
+    planes reproduce the weights to the last bit."""
+    from speech2text_amd import _native as Nt
+    from speech2text_amd import zip_kernels as zk
+    L = Nt.lib()
+    g = torch.Generator().manual_seed(M + K)
+    x = (torch.randn(M, K, generator=g) * torch.logspace(-3, 3, K)).to(dev)     # wide dynamic range
+    W = (torch.randn(N, K, generator=g) * 0.1).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    n = W.numel()
+    pl = torch.empty(3 * n, dtype=torch.int16, device=dev)
+    Nt.check(L.s2t_split_planes(Nt.fp(W), n, Nt.raw(pl), n, Nt.stream()), "split")
+    pieces = pl.view(3, n).view(torch.bfloat16).float()
+    assert torch.equal((pieces[0].double() + pieces[1].double() + pieces[2].double()).float(),
+                       W.reshape(-1)), "the three bf16 pieces must add up to the fp32 value exactly"
+    y = torch.empty(M, N, device=dev)
+    Nt.check(L.s2t_gemm_x3_nt(Nt.fp(x), K, Nt.raw(pl), K, n, Nt.fp(y), N, M, N, K, Nt.fp(b), Nt.fp(res), N,
+                              0.5, Nt.stream()), "x3")
+    ref = torch.nn.functional.linear(x.double(), W.double(), b.double()) + 0.5 * res.double()
+    lib = zk.lt_matmul(0, x, W, b).double() + 0.5 * res.double()
+    scale = ref.abs().max().item()
+    e_x3 = (y.double() - ref).abs().max().item() / scale
+    e_lib = (lib - ref).abs().max().item() / scale
+    assert e_x3 <= max(1.5 * e_lib, 2e-7), (e_x3, e_lib)
+    # transposed planes of a table of matrices (the data-gradient operand)
+    import numpy as np
+    rec = np.zeros(1, dtype=[("off", "<i8"), ("R", "<i4"), ("C", "<i4"), ("tb", "<i4"), ("pad", "<i4")])
+    rec["off"], rec["R"], rec["C"], rec["tb"] = 0, N, K, 0
+    dt = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
+    plt_ = torch.empty(3 * n, dtype=torch.int16, device=dev)
+    tiles = ((N + 31) // 32) * ((K + 31) // 32)
+    Nt.check(L.s2t_split_planes_t(Nt.fp(W), Nt.raw(dt), 1, tiles, Nt.raw(plt_), n, Nt.stream()), "split_t")
+    pt = plt_.view(3, K, N).view(torch.bfloat16).double().sum(0).float()
+    assert torch.equal(pt, W.t().contiguous())
