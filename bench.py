@@ -506,6 +506,9 @@ def parse_args(argv=None):
     ap.add_argument("--roofline-kernel", default=DEFAULT_ROOFLINE_KERNEL)
     ap.add_argument("--profile-steps", type=int, default=2,
                     help="extra untimed steps with every entry point bracketed by HIP events")
+    ap.add_argument("--random-chunk", action="store_true",
+                    help="C3 only: the shipped YAML's chunk_size [16, 32, 64, -1] / "
+                         "left_context_frames [64, 128, 256, -1] (one draw per step) instead of -1")
     ap.add_argument("--launcher-selftest", action="store_true")
     args = ap.parse_args(argv)
     # per-rank batch, labels per utterance, vocabulary, utterance seconds
@@ -553,6 +556,12 @@ def main(argv=None):
     c3 = args.config == "C3"
     cfg = {"C3": lambda: c3_config(args.vocab), "C2": lambda: c2_config(args.vocab),
            "C4": lambda: c4_config(args.vocab), "C5": c5_config}[args.config]()
+    if args.random_chunk:
+        if args.config != "C3":
+            raise SystemExit("--random-chunk applies to the zipformer config (C3)")
+        # config/training/zipformer_stateless_pruned_rnnt.yaml:65-66
+        cfg["encoder"]["config"].update({"chunk_size": [16, 32, 64, -1],
+                                         "left_context_frames": [64, 128, 256, -1]})
     random.seed(1234 + rank)
     np.random.seed(1234 + rank)
     torch.manual_seed(1234)                                 # same init on every rank
@@ -665,7 +674,8 @@ def main(argv=None):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": workload,
+            "config": {"workload": workload + (" [random chunk_size 16/32/64/-1 per step]"
+                                               if args.random_chunk else ""),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "utterance_seconds": args.seconds, "labels_per_utt": args.labels,
                        "parallelism": f"dp{world}", "final_loss": final_loss},

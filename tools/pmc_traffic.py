@@ -46,6 +46,16 @@ KERNELS = [
     ("dwconv2d_wreduce_kernel", "s2t_dwconv2d_nhwc_wgrad", False),
     ("smoothed_nll_fwd_kernel", "s2t_smoothed_nll_fwd", True), ("smoothed_nll_bwd_kernel", "s2t_smoothed_nll_bwd", True),
     ("bestrq", "s2t_bestrq_labels", True),
+    ("Cijk_", "s2t_linear_lt", True),                       # hipBLASLt kernels (forward / dgrad GEMMs)
+    ("layernorm_fwd_kernel", "s2t_layernorm_fwd", True), ("layernorm_bwd_kernel", "s2t_layernorm_bwd", True),
+    ("silu_fwd_kernel", "s2t_silu_fwd", True), ("silu_bwd_kernel", "s2t_silu_bwd", True),
+    ("mhsa_fwd_kernel", "s2t_mhsa_fwd", True), ("mhsa_bwd_q_kernel", "s2t_mhsa_bwd", True),
+    ("mhsa_bwd_kv_kernel", "s2t_mhsa_bwd", False),
+    ("bn_silu_apply_kernel", "s2t_bn_silu_fwd", True), ("bn_stats_kernel<0>", "s2t_bn_silu_fwd", False),
+    ("bn_silu_bwd_kernel", "s2t_bn_silu_bwd", True), ("bn_stats_kernel<1>", "s2t_bn_silu_bwd", False),
+    ("conv1_relu_fwd_kernel", "s2t_conv1_relu_fwd", True), ("conv1_relu_wgrad_kernel", "s2t_conv1_relu_wgrad", True),
+    ("lnlstm_fwd_kernel", "s2t_lnlstm_fwd", True), ("lnlstm_bwd_kernel", "s2t_lnlstm_bwd", True),
+    ("adam_apply_kernel", "s2t_adam_apply", True),
 ]
 
 
@@ -88,8 +98,10 @@ def main(fetch_dir, write_dir, out):
         res[e] = {"launches_sampled": n, "fetch_bytes_raw_per_launch": fetch_raw,
                   "fetch_bytes_x2_per_launch": 2.0 * fetch_raw, "write_bytes_per_launch": write,
                   "hbm_bytes_per_launch": 2.0 * fetch_raw + write,
-                  "note": "mean over the launches of the C3 bench steps; FETCH_SIZE raw and x2 "
-                          "(gfx950 half-count of wide streaming reads), WRITE_SIZE exact"}
+                  "note": "mean over the launches of the bench steps; FETCH_SIZE raw and x2 "
+                          "(gfx950 counts 128-byte requests at 64 bytes: calibrated per access "
+                          "width with tools/probes/fetch_probe.hip, profiles/r03_fetch_calibration.txt"
+                          "), WRITE_SIZE exact"}
     json.dump(res, open(out, "w"), indent=1)
     for e, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
         print(f"{e:28s} n={v['launches_sampled']:5d} fetch(x2) {v['fetch_bytes_x2_per_launch']/1e6:9.2f} MB "
