@@ -455,3 +455,216 @@ def zipformer_forward(sd, cfg, x, x_lens, ctl, chunk_size=-1, left_context_chunk
     x = torch.cat(pieces, dim=-1)
     x = simple_downsample(x, sd["downsample_output.bias"], 2)
     return x.transpose(0, 1), (lens + 1) // 2
+
+
+# ------------------------------------------------------------------ streaming (inference only)
+def streaming_init_states(cfg, B, left):
+    """Zipformer2.get_init_states (zipformer.py:529-600): per layer (cached_key (L,B,H*qd),
+    cached_nonlin_attn (1,B,L,3D/4), cached_val1, cached_val2 (L,B,H*vd), cached_conv1,
+    cached_conv2 (B,D,K//2)), then the ConvNeXt left pad (B,128,3,F') and processed_lens (B,)."""
+    states = []
+    for i, ds in enumerate(cfg["downsampling_factor"]):
+        D, H = cfg["encoder_dim"][i], cfg["num_heads"][i]
+        L = left // ds
+        for _ in range(cfg["num_encoder_layers"][i]):
+            states += [torch.zeros(L, B, H * cfg["query_head_dim"][i]),
+                       torch.zeros(1, B, L, 3 * D // 4),
+                       torch.zeros(L, B, H * cfg["value_head_dim"][i]),
+                       torch.zeros(L, B, H * cfg["value_head_dim"][i]),
+                       torch.zeros(B, D, cfg["cnn_module_kernel"][i] // 2),
+                       torch.zeros(B, D, cfg["cnn_module_kernel"][i] // 2)]
+    fw = (((cfg.get("feature_dim", 80) - 1) // 2) - 1) // 2
+    states.append(torch.zeros(B, 128, 3, fw))
+    states.append(torch.zeros(B, dtype=torch.int64))
+    return states
+
+
+def _stream_attn_weights(sd, pfx, x, pos_emb, cached_key, L, H, qd, pd, kpm):
+    """RelPositionMultiheadAttentionWeights.streaming_forward (zipformer.py:2079-2190)."""
+    T, B, _ = x.shape
+    x = F.linear(x, sd[pfx + "in_proj.weight"], sd[pfx + "in_proj.bias"])
+    q, k, p = x[..., :H * qd], x[..., H * qd:2 * H * qd], x[..., 2 * H * qd:]
+    k = torch.cat([cached_key, k], dim=0)
+    cached_key = k[-L:]
+    S = k.shape[0]
+    q = q.reshape(T, B, H, qd).permute(2, 1, 0, 3)
+    p = p.reshape(T, B, H, pd).permute(2, 1, 0, 3)
+    k = k.reshape(S, B, H, qd).permute(2, 1, 3, 0)
+    scores = torch.matmul(q, k)
+    pe = F.linear(pos_emb, sd[pfx + "linear_pos.weight"])              # (1, L+2T-1, H*pd)
+    pe = pe.reshape(-1, 2 * T - 1 + L, H, pd).permute(2, 0, 3, 1)
+    ps = torch.matmul(p, pe)                                           # (H,B,T,L+2T-1)
+    idx = (T - 1) - torch.arange(T).unsqueeze(1) + torch.arange(S).unsqueeze(0)
+    ps = ps[:, :, torch.arange(T).unsqueeze(1), idx]                   # rel -> abs, (H,B,T,S)
+    scores = scores + ps
+    scores = scores.masked_fill(kpm.unsqueeze(1), -1000)
+    return scores.softmax(dim=-1), cached_key
+
+
+def _stream_self_attn(sd, pfx, x, w, cached_val, L):
+    """SelfAttention.streaming_forward (zipformer.py:2282-2333)."""
+    T, B, _ = x.shape
+    H = w.shape[0]
+    x = F.linear(x, sd[pfx + "in_proj.weight"], sd[pfx + "in_proj.bias"])
+    x = torch.cat([cached_val, x], dim=0)
+    cached_val = x[-L:]
+    x = x.reshape(T + L, B, H, -1).permute(2, 1, 0, 3)
+    x = torch.matmul(w, x).permute(2, 1, 0, 3).reshape(T, B, -1)
+    return F.linear(x, sd[pfx + "out_proj.weight"], sd[pfx + "out_proj.bias"]), cached_val
+
+
+def _stream_nonlin_attention(sd, pfx, x, w, cached_x, L):
+    """NonlinAttention.streaming_forward (zipformer.py:2485-2541)."""
+    T, B, _ = x.shape
+    x = F.linear(x, sd[pfx + "in_proj.weight"], sd[pfx + "in_proj.bias"])
+    s, x, y = x.chunk(3, dim=2)
+    x = x * torch.tanh(s)
+    Hh = w.shape[0]
+    x = x.reshape(T, B, Hh, -1).permute(2, 1, 0, 3)
+    xp = torch.cat([cached_x, x], dim=2)
+    cached_x = xp[:, :, -L:]
+    x = torch.matmul(w, xp).permute(2, 1, 0, 3).reshape(T, B, -1)
+    x = x * y
+    return F.linear(x, sd[pfx + "out_proj.weight"], sd[pfx + "out_proj.bias"]), cached_x
+
+
+def _stream_conv_module(sd, pfx, x, cache, kpm, K):
+    """ConvolutionModule.streaming_forward (zipformer.py:2697-2741) with
+    ChunkCausalDepthwiseConv1d.streaming_forward (scaling.py:683-716)."""
+    x = F.linear(x, sd[pfx + "in_proj.weight"], sd[pfx + "in_proj.bias"])
+    x, s = x.chunk(2, dim=2)
+    x = (x * torch.sigmoid(s)).permute(1, 2, 0)                        # (B,C,T)
+    x = x.masked_fill(kpm.unsqueeze(1).expand_as(x), 0.0)
+    B, C, T = x.shape
+    d = pfx + "depthwise_conv."
+    left = K // 2
+    x = torch.cat([cache, x], dim=2)
+    cache = x[..., -left:]
+    x_causal = F.conv1d(x, sd[d + "causal_conv.weight"], sd[d + "causal_conv.bias"], groups=C)
+    xc = F.conv1d(x[..., left:], sd[d + "chunkwise_conv.weight"], sd[d + "chunkwise_conv.bias"],
+                  padding=K // 2, groups=C)
+    le, re = sd[d + "chunkwise_conv_scale"][0], sd[d + "chunkwise_conv_scale"][1]
+    if T < K:
+        le, re = le[:, :T], re[:, -T:]
+    else:
+        z = torch.zeros(C, T - K)
+        le, re = torch.cat((le, z), -1), torch.cat((z, re), -1)
+    x = (xc * (1.0 + (le + re)) + x_causal).permute(2, 0, 1)
+    return F.linear(swoosh_r(x), sd[pfx + "out_proj.weight"], sd[pfx + "out_proj.bias"]), cache
+
+
+def _stream_layer(sd, pfx, src, pos_emb, st, L, cfg_i, kpm, ctl):
+    """Zipformer2EncoderLayer.streaming_forward (zipformer.py:1223-1338)."""
+    H, qd, pd, K = cfg_i["H"], cfg_i["qd"], cfg_i["pd"], cfg_i["K"]
+    ck, cna, cv1, cv2, cc1, cc2 = st
+    orig = src
+    w, ck = _stream_attn_weights(sd, pfx + "self_attn_weights.", src, pos_emb, ck, L, H, qd, pd, kpm)
+    src = src + feed_forward(sd, pfx + "feed_forward1.", src, ctl)
+    na, cna = _stream_nonlin_attention(sd, pfx + "nonlin_attention.", src, w[0:1], cna, L)
+    src = src + na
+    sa, cv1 = _stream_self_attn(sd, pfx + "self_attn1.", src, w, cv1, L)
+    src = src + sa
+    cv, cc1 = _stream_conv_module(sd, pfx + "conv_module1.", src, cc1, kpm[:, L:], K)
+    src = src + cv
+    src = src + feed_forward(sd, pfx + "feed_forward2.", src, ctl)
+    src = bypass(sd, pfx + "bypass_mid.", orig, src, ctl)
+    sa, cv2 = _stream_self_attn(sd, pfx + "self_attn2.", src, w, cv2, L)
+    src = src + sa
+    cv, cc2 = _stream_conv_module(sd, pfx + "conv_module2.", src, cc2, kpm[:, L:], K)
+    src = src + cv
+    src = src + feed_forward(sd, pfx + "feed_forward3.", src, ctl)
+    src = bias_norm(src, sd[pfx + "norm.bias"], sd[pfx + "norm.log_scale"], ctl)
+    src = bypass(sd, pfx + "bypass.", orig, src, ctl)
+    return src, [ck, cna, cv1, cv2, cc1, cc2]
+
+
+def _stream_stack(sd, pfx, src, states, n_layers, cfg_i, pos_dim, L, kpm, ctl):
+    """Zipformer2Encoder.streaming_forward (zipformer.py:1432-1496); pos_emb covers offsets
+    -(T+L-1) .. T-1 (CompactRelPositionalEncoding.forward :1815-1833)."""
+    T = src.shape[0]
+    pe = rel_pos_encoding(T + L, pos_dim)
+    c = pe.shape[0] // 2
+    pos_emb = pe[c - (T + L) + 1:c + T].unsqueeze(0)
+    new = []
+    for l in range(n_layers):
+        src, st = _stream_layer(sd, f"{pfx}layers.{l}.", src, pos_emb, states[6 * l:6 * l + 6], L,
+                                cfg_i, kpm, ctl)
+        new += st
+    return src, new
+
+
+def _stream_subsampling(sd, pfx, x, cached_left_pad, ctl):
+    """Conv2dSubsampling.streaming_forward (subsampling.py:321-375) with ConvNeXt.streaming_forward
+    (:134-178): T input frames -> (T-7)//2 - 3 output frames."""
+    x = x.unsqueeze(1)
+    x = swoosh_r(F.conv2d(x, sd[pfx + "conv.0.weight"], sd[pfx + "conv.0.bias"], padding=(0, 1)))
+    x = swoosh_r(F.conv2d(x, sd[pfx + "conv.4.weight"], sd[pfx + "conv.4.bias"], stride=2))
+    x = swoosh_r(F.conv2d(x, sd[pfx + "conv.7.weight"], sd[pfx + "conv.7.bias"], stride=(1, 2)))
+    T = x.shape[2] - 3
+    byp = x[:, :, :T]
+    x = torch.cat([cached_left_pad, x], dim=2)
+    cached_left_pad = x[:, :, T:T + 3]
+    c = x.shape[1]
+    x = F.conv2d(x, sd[pfx + "convnext.depthwise_conv.weight"],
+                 sd[pfx + "convnext.depthwise_conv.bias"], padding=(0, 3), groups=c)
+    x = F.conv2d(x, sd[pfx + "convnext.pointwise_conv1.weight"],
+                 sd[pfx + "convnext.pointwise_conv1.bias"])
+    x = F.conv2d(swoosh_l(x), sd[pfx + "convnext.pointwise_conv2.weight"],
+                 sd[pfx + "convnext.pointwise_conv2.bias"])
+    x = byp + x
+    b, c, t, f = x.shape
+    x = x.transpose(1, 2).reshape(b, t, c * f)
+    x = F.linear(x, sd[pfx + "out.weight"], sd[pfx + "out.bias"])
+    x = bias_norm(x, sd[pfx + "out_norm.bias"], sd[pfx + "out_norm.log_scale"], ctl)
+    return x, cached_left_pad
+
+
+def streaming_step(sd, cfg, x, states, chunk, left, for_ctc=False):
+    """Zipformer2.streaming_step (zipformer.py:601-663) + _encoder_layer_streaming_forward
+    (:465-527).  x (B, 2*chunk+13, F); states as streaming_init_states.  Returns
+    (out (B, chunk//2, max_dim) or log-softmax CTC scores, new_states)."""
+    ctl = Ctl(training=False)
+    ds_f, dims = cfg["downsampling_factor"], cfg["encoder_dim"]
+    B = x.shape[0]
+    assert x.shape[1] == 2 * chunk + 13
+    x, new_pad = _stream_subsampling(sd, "_encoder_embed.", x, states[-2], ctl)
+    assert x.shape[1] == chunk
+    processed = states[-1]
+    pm = (processed.unsqueeze(1) <= torch.arange(left).expand(B, left)).flip(1)
+    kpm = torch.cat([pm, torch.zeros(B, chunk, dtype=torch.bool)], dim=1)
+    new_processed = processed + chunk
+    x = x.permute(1, 0, 2)
+    outs, new_states, off = [], [], 0
+    for i, ds in enumerate(ds_f):
+        d, nl = dims[i], cfg["num_encoder_layers"][i]
+        x = x[..., :d] if d <= x.shape[-1] else torch.cat(
+            (x, torch.zeros(*x.shape[:-1], d - x.shape[-1])), dim=-1)
+        cfg_i = dict(H=cfg["num_heads"][i], qd=cfg["query_head_dim"][i], pd=cfg["pos_head_dim"][i],
+                     K=cfg["cnn_module_kernel"][i])
+        st = states[6 * off:6 * (off + nl)]
+        off += nl
+        k_i = kpm[..., ::ds]
+        if ds == 1:
+            x, st = _stream_stack(sd, f"encoders.{i}.", x, st, nl, cfg_i, cfg["pos_dim"], left // ds,
+                                  k_i, ctl)
+        else:
+            orig = x
+            y = simple_downsample(x, sd[f"encoders.{i}.downsample.bias"], ds)
+            y, st = _stream_stack(sd, f"encoders.{i}.encoder.", y, st, nl, cfg_i, cfg["pos_dim"],
+                                  left // ds, k_i, ctl)
+            y = simple_upsample(y, ds)[:orig.shape[0]]
+            x = bypass(sd, f"encoders.{i}.out_combiner.", orig, y, ctl)
+        outs.append(x)
+        new_states += st
+    pieces = [outs[-1]]
+    cur = dims[-1]
+    for i in range(len(ds_f) - 2, -1, -1):
+        if dims[i] > cur:
+            pieces.append(outs[i][..., cur:dims[i]])
+            cur = dims[i]
+    x = torch.cat(pieces, dim=-1)
+    x = simple_downsample(x, sd["downsample_output.bias"], 2).permute(1, 0, 2)
+    if for_ctc:
+        x = F.log_softmax(F.linear(x, sd["_ctc_projection.weight"], sd["_ctc_projection.bias"]),
+                          dim=-1)
+    return x, new_states + [new_pad, new_processed]

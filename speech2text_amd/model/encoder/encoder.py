@@ -21,3 +21,11 @@ class Encoder(nn.Module):
 
     def forward(self, x: torch.Tensor, lengths: torch.Tensor):
         return self.encoder(x, lengths)
+
+    @torch.no_grad()
+    def streaming_forward(self, x: torch.Tensor, length: torch.Tensor, **config):
+        """Simulated-streaming inference interface (reference encoder.py:39-49)."""
+        if hasattr(self.encoder, "streaming_forward"):
+            return self.encoder.streaming_forward(x, length, **config)
+        raise NotImplementedError("{} encoder does not support streaming_forward".format(
+            self.encoder.__class__.__name__))

@@ -193,6 +193,21 @@ class Zipformer2(nn.Module):
             x = self._ctc_projection(x)
         return x, lengths
 
+    # -- streaming inference (reference :391-406, :529-663); speech2text_amd/model/encoder/
+    #    zipformer_streaming.py
+    def get_init_states(self, batch_size: int = 1, device=torch.device("cpu")) -> List[Tensor]:
+        from speech2text_amd.model.encoder import zipformer_streaming as zs
+        return zs.get_init_states(self, batch_size, device)
+
+    def streaming_step(self, x: Tensor, states: List[Tensor]) -> Tuple[Tensor, List[Tensor]]:
+        from speech2text_amd.model.encoder import zipformer_streaming as zs
+        return zs.streaming_step(self, x, states)
+
+    def streaming_forward(self, x: Tensor, x_lens: Tensor, chunk_size=(32,),
+                          left_context_frames=(128,)) -> Tuple[Tensor, Tensor]:
+        from speech2text_amd.model.encoder import zipformer_streaming as zs
+        return zs.simulated_streaming_forward(self, x, x_lens, chunk_size, left_context_frames)
+
     def _get_full_dim_output(self, outputs: List[Tensor]):
         pieces = [outputs[-1]]
         cur = self.encoder_dim[-1]
@@ -297,8 +312,12 @@ class CompactRelPositionalEncoding(nn.Module):
         return pe
 
     def forward(self, x: Tensor, left_context_len: int = 0) -> Tensor:
-        assert left_context_len == 0, "streaming is out of scope of the training path"
-        return self.dropout(self.table(x.size(0), x.device).unsqueeze(0))
+        """(1, left_context_len + 2T-1, D): offsets -(T+left-1) .. T-1 (reference :1815-1833)."""
+        T = x.size(0)
+        pe = self.table(T + left_context_len, x.device)
+        if left_context_len:
+            pe = pe[:left_context_len + 2 * T - 1]
+        return self.dropout(pe.unsqueeze(0))
 
 
 class Zipformer2Encoder(nn.Module):

@@ -151,3 +151,87 @@ def test_mid_ragged_vs_oracle(dev, cpu_rng, rv, store):
         got = p.grad.cpu().numpy() if p.grad is not None else np.zeros_like(ref)
         worst = max(worst, np.abs(got - ref).max() / (np.abs(ref).max() + 1e-6))
     assert worst < 1e-2, worst
+
+
+# ------------------------------------------------------------------ streaming
+def _stream_model(golden_dir, dev):
+    g = np.load(os.path.join(golden_dir, "zipformer_tiny_stream.npz"))
+    chunk, left = int(g["chunk"]), int(g["left"])
+    from speech2text_amd.model.encoder.zipformer import Zipformer2, Zipformer2Config
+    m = Zipformer2(Zipformer2Config(**TINY, chunk_size=(chunk,), left_context_frames=(left,),
+                                    for_ctc=True, num_tokens=13))
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")}
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and not missing, (missing, unexpected)
+    return g, m.to(dev).eval(), chunk, left
+
+
+def test_streaming_step_vs_reference_goldens(golden_dir, dev):
+    """Zipformer2.get_init_states / streaming_step (HIP kernels) against the reference's own
+    streaming_step: 6 consecutive chunks, encoder output, CTC scores and every carried state."""
+    g, m, chunk, left = _stream_model(golden_dir, dev)
+    feats = torch.from_numpy(g["feats"]).to(dev)
+    B, T = feats.shape[0], 2 * chunk + 13
+    st = m.get_init_states(B, dev)
+    assert len(st) == int(g["n_states"])
+    for i, s in enumerate(st):
+        assert tuple(s.shape) == tuple(g[f"init_shape.{i}"]), i
+    for c in range(6):
+        x = feats[:, 2 * chunk * c:2 * chunk * c + T]
+        m._for_ctc = False
+        raw, _ = m.streaming_step(x, st)
+        m._for_ctc = True
+        y, st = m.streaming_step(x, st)
+        np.testing.assert_allclose(raw.cpu().numpy(), g[f"raw.{c}"], atol=5e-5, rtol=2e-4)
+        np.testing.assert_allclose(y.cpu().numpy(), g[f"out.{c}"], atol=5e-5, rtol=2e-4)
+        if c in (0, 2):
+            for i, s in enumerate(st):
+                assert tuple(s.shape) == tuple(g[f"state{c}.{i}"].shape), i
+                np.testing.assert_allclose(s.cpu().numpy(), g[f"state{c}.{i}"], atol=5e-5,
+                                           rtol=2e-4, err_msg=f"state {i} after chunk {c}")
+    for i, s in enumerate(st):
+        np.testing.assert_allclose(s.cpu().numpy(), g[f"final_state.{i}"], atol=5e-5, rtol=2e-4)
+    assert (st[-1].cpu().numpy() == 6 * chunk).all()
+
+
+def test_streaming_step_vs_oracle_mid(dev):
+    """A wider causal model (MID dims, chunk 16 / left 32, batch 3) against the oracle's
+    streaming restatement, including the steady state where every cache is full."""
+    torch.manual_seed(11)
+    chunk, left, B = 16, 32, 3
+    m = _model(MID, (chunk,), (left,), "cpu")
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith("bypass_scale"):
+                p.uniform_(0.2, 0.9)
+            elif n.endswith("chunkwise_conv_scale"):
+                p.normal_(0, 0.3)
+            elif "out_proj" in n or "pointwise_conv2" in n or "linear_pos" in n:
+                p.mul_(6.0)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    zc = dict(_zcfg(MID), value_head_dim=(8, 8, 8))
+    m = m.to(dev).eval()
+    T = 2 * chunk + 13
+    feats = torch.randn(B, 2 * chunk * 4 + T, 80) * 2.0
+    st_o = Z.streaming_init_states(zc, B, left)
+    st = m.get_init_states(B, dev)
+    for c in range(5):
+        x = feats[:, 2 * chunk * c:2 * chunk * c + T]
+        with torch.no_grad():
+            yo, st_o = Z.streaming_step(sd, zc, x, st_o, chunk, left)
+        y, st = m.streaming_step(x.to(dev), st)
+        np.testing.assert_allclose(y.cpu().numpy(), yo.numpy(), atol=1e-4, rtol=5e-4)
+    for a, b in zip(st, st_o):
+        np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), atol=1e-4, rtol=5e-4)
+
+
+def test_streaming_rejects_cpu_and_training(golden_dir, dev):
+    g, m, chunk, left = _stream_model(golden_dir, dev)
+    x = torch.zeros(1, 2 * chunk + 13, 80)
+    with pytest.raises(RuntimeError):
+        m.streaming_step(x, m.get_init_states(1))            # CPU tensors: no fallback
+    with pytest.raises(ValueError):
+        m.streaming_step(x[:, :-1].to(dev), m.get_init_states(1, dev))
+    m.train()
+    with pytest.raises(RuntimeError):
+        m.streaming_step(x.to(dev), m.get_init_states(1, dev))

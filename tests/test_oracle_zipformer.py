@@ -50,3 +50,29 @@ def test_deterministic_train_step_grads(golden_dir, tag, chunk, lcc):
         worst = max(worst, np.abs(got - ref).max() / denom)
         np.testing.assert_allclose(got, ref, atol=2e-3 * denom, rtol=0, err_msg=k)
     assert worst < 2e-3
+
+
+def test_streaming_step_vs_reference(golden_dir):
+    """oracle streaming_step against the reference's Zipformer2.streaming_step over 6 chunks from
+    get_init_states: per-chunk encoder output, CTC log-softmax output and the carried states."""
+    g, sd = load(golden_dir, "stream")
+    chunk, left = int(g["chunk"]), int(g["left"])
+    feats = torch.from_numpy(g["feats"])
+    B, T = feats.shape[0], 2 * chunk + 13
+    st = Z.streaming_init_states(TINY, B, left)
+    assert len(st) == int(g["n_states"])
+    for i, s in enumerate(st):
+        assert tuple(s.shape) == tuple(g[f"init_shape.{i}"]), i
+    with torch.no_grad():
+        for c in range(6):
+            x = feats[:, 2 * chunk * c:2 * chunk * c + T]
+            raw, _ = Z.streaming_step(sd, TINY, x, st, chunk, left)
+            y, st = Z.streaming_step(sd, TINY, x, st, chunk, left, for_ctc=True)
+            np.testing.assert_allclose(raw.numpy(), g[f"raw.{c}"], atol=2e-5, rtol=1e-4)
+            np.testing.assert_allclose(y.numpy(), g[f"out.{c}"], atol=2e-5, rtol=1e-4)
+            if c in (0, 2):
+                for i, s in enumerate(st):
+                    np.testing.assert_allclose(s.numpy(), g[f"state{c}.{i}"], atol=2e-5, rtol=1e-4)
+    for i, s in enumerate(st):
+        np.testing.assert_allclose(s.numpy(), g[f"final_state.{i}"], atol=2e-5, rtol=1e-4)
+    assert (st[-1].numpy() == 6 * chunk).all()

@@ -117,6 +117,70 @@ ZIP_TINY = dict(feature_dim=80, downsampling_factor=(1, 2, 4), num_encoder_layer
                 causal=True)
 
 
+def _tiny_zipformer(chunk, left, **extra):
+    import torch
+    from model.encoder.zipformer import Zipformer2, Zipformer2Config
+    torch.manual_seed(1234)
+    cfg = Zipformer2Config(**ZIP_TINY, chunk_size=chunk, left_context_frames=left, **extra)
+    m = Zipformer2(cfg)
+    # move parameters away from their special initial values so every term matters
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith("bypass_scale"):
+                p.uniform_(0.2, 0.9)
+            elif n.endswith("chunkwise_conv_scale"):
+                p.normal_(0, 0.3)
+            elif n.endswith("downsample.bias") or n.endswith("downsample_output.bias"):
+                p.normal_(0, 0.5)
+            elif n.endswith("log_scale"):
+                p.fill_(0.7)
+            elif "out_proj" in n or "pointwise_conv2" in n or "linear_pos" in n:
+                p.mul_(8.0)
+    return m
+
+
+def gen_zipformer_stream():
+    """Tiny causal Zipformer2 (chunk 8, left context 16, CTC projection on): `streaming_step`
+    over 6 consecutive chunks from `get_init_states`; per chunk the encoder output before the
+    projection, the log-softmax output, and the final states.  Also the chunked non-streaming
+    forward of the whole utterance for the streaming-vs-chunked property."""
+    import torch
+    ref_import.install_stubs()
+    chunk, left, nchunks, B = 8, 16, 6, 2
+    m = _tiny_zipformer((chunk,), (left,), for_ctc=True, num_tokens=13)
+    m.eval()
+    T = 2 * chunk + 13
+    g = torch.Generator().manual_seed(321)
+    feats = torch.randn(B, 2 * chunk * (nchunks - 1) + T, 80, generator=g) * 2.0
+    out = {"feats": feats.numpy(), "chunk": np.int64(chunk), "left": np.int64(left)}
+    for k, v in m.state_dict().items():
+        out["sd." + k] = v.numpy()
+    states = m.get_init_states(B)
+    out["n_states"] = np.int64(len(states))
+    for i, s in enumerate(states):
+        out[f"init_shape.{i}"] = np.array(s.shape, dtype=np.int64)
+    for c in range(nchunks):
+        x = feats[:, 2 * chunk * c:2 * chunk * c + T]
+        m._for_ctc = False
+        raw, _ = m.streaming_step(x, [s.clone() for s in states])
+        m._for_ctc = True
+        y, states = m.streaming_step(x, states)
+        out[f"raw.{c}"] = raw.numpy()
+        out[f"out.{c}"] = y.numpy()
+        if c in (0, 2):                       # warm-up (cache partly empty) and steady state
+            for i, s in enumerate(states):
+                out[f"state{c}.{i}"] = s.numpy()
+    for i, s in enumerate(states):
+        out[f"final_state.{i}"] = s.numpy()
+    with torch.no_grad():
+        lens = torch.full((B,), feats.shape[1], dtype=torch.int64)
+        yf, yl = m(feats, lens)
+    out["chunked_out"] = yf.numpy()
+    out["chunked_lens"] = yl.numpy()
+    np.savez_compressed(os.path.join(OUT, "zipformer_tiny_stream.npz"), **out)
+    print("zipformer_stream:", out["raw.0"].shape, out["out.0"].shape, len(states), "states")
+
+
 def gen_zipformer():
     """Tiny Zipformer2: eval forward, and a deterministic training step (random.random == 0:
     every Balancer / Whiten / limit_param_value / attention-score penalty fires) with grads."""
@@ -125,22 +189,7 @@ def gen_zipformer():
     ref_import.install_stubs()
     from model.encoder.zipformer import Zipformer2, Zipformer2Config
     for tag, chunk, left in [("full", (-1,), (-1,)), ("chunk8", (8,), (16,))]:
-        torch.manual_seed(1234)
-        cfg = Zipformer2Config(**ZIP_TINY, chunk_size=chunk, left_context_frames=left)
-        m = Zipformer2(cfg)
-        # move parameters away from their special initial values so every term matters
-        with torch.no_grad():
-            for n, p in m.named_parameters():
-                if n.endswith("bypass_scale"):
-                    p.uniform_(0.2, 0.9)
-                elif n.endswith("chunkwise_conv_scale"):
-                    p.normal_(0, 0.3)
-                elif n.endswith("downsample.bias") or n.endswith("downsample_output.bias"):
-                    p.normal_(0, 0.5)
-                elif n.endswith("log_scale"):
-                    p.fill_(0.7)
-                elif "out_proj" in n or "pointwise_conv2" in n or "linear_pos" in n:
-                    p.mul_(8.0)
+        m = _tiny_zipformer(chunk, left)
         g = torch.Generator().manual_seed(99)
         x = torch.randn(3, 77, 80, generator=g) * 2.0
         lens = torch.tensor([77, 60, 41])
