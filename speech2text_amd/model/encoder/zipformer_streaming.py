@@ -226,3 +226,53 @@ def simulated_streaming_forward(model, x: Tensor, x_lens: Tensor, chunk_size=(32
     pad_len = 30
     x = F.pad(x, pad=(0, 0, 0, pad_len), value=math.log(1e-10))
     return model.forward(x, x_lens + pad_len)
+
+
+class StreamingSession:
+    """A stream of fixed-shape `streaming_step` calls replayed as ONE hipGraph.
+
+    A chunk step is a few hundred small launches (every tensor is chunk-sized), so eager
+    execution is bound by launch latency, not by the GPU.  All shapes are static from one call
+    to the next, so the step is captured once -- input, states and output live in fixed buffers,
+    the state update is part of the graph -- and each `step()` is a copy-in plus one graph launch.
+    The first two steps of a session run eagerly on the capture stream (GEMM plan selection and
+    position tables happen there); states then restart from `get_init_states`."""
+
+    def __init__(self, model, batch_size: int = 1, device=None, warmup: int = 2):
+        if model.training:
+            raise RuntimeError("StreamingSession is an inference path: call model.eval() first")
+        device = torch.device("cuda") if device is None else torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("StreamingSession runs on the HIP kernels: device must be cuda")
+        self.model = model
+        chunk = model.chunk_size[0]
+        self.frames = 2 * chunk + 13
+        self.x = torch.zeros(batch_size, self.frames, model._feature_dim, device=device)
+        self.states = get_init_states(model, batch_size, device)
+        side = torch.cuda.Stream(device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            st = [s.clone() for s in self.states]
+            for _ in range(warmup):
+                _, st = streaming_step(model, self.x, st)
+        torch.cuda.current_stream(device).wait_stream(side)
+        torch.cuda.synchronize(device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=side):
+            self.out, new = streaming_step(model, self.x, self.states)
+            for dst, src in zip(self.states, new):
+                dst.copy_(src)
+
+    def reset(self):
+        for s in self.states:
+            s.zero_()
+
+    @torch.no_grad()
+    def step(self, x: Tensor) -> Tensor:
+        """x (B, 2*chunk+13, F) -> out (B, chunk//2, D) (a view of the session's output buffer:
+        consume or clone it before the next step)."""
+        if tuple(x.shape) != tuple(self.x.shape):
+            raise ValueError(f"expected input of shape {tuple(self.x.shape)}, got {tuple(x.shape)}")
+        self.x.copy_(x)
+        self.graph.replay()
+        return self.out

@@ -235,3 +235,25 @@ def test_streaming_rejects_cpu_and_training(golden_dir, dev):
     m.train()
     with pytest.raises(RuntimeError):
         m.streaming_step(x.to(dev), m.get_init_states(1, dev))
+
+
+def test_streaming_session_graph_matches_eager(golden_dir, dev):
+    """StreamingSession (one hipGraph per chunk step, states updated inside the graph) is
+    bit-identical to eager streaming_step, across reset()."""
+    from speech2text_amd.model.encoder.zipformer_streaming import StreamingSession
+    g, m, chunk, left = _stream_model(golden_dir, dev)
+    feats = torch.from_numpy(g["feats"]).to(dev)
+    B, T = feats.shape[0], 2 * chunk + 13
+    sess = StreamingSession(m, B, dev)
+    for rep in range(2):
+        st = m.get_init_states(B, dev)
+        sess.reset()
+        for c in range(6):
+            x = feats[:, 2 * chunk * c:2 * chunk * c + T]
+            y, st = m.streaming_step(x, st)
+            assert torch.equal(sess.step(x), y), (rep, c)
+        for a, b in zip(sess.states, st):
+            assert torch.equal(a, b)
+    np.testing.assert_allclose(sess.out.cpu().numpy(), g["out.5"], atol=5e-5, rtol=2e-4)
+    with pytest.raises(ValueError):
+        sess.step(feats[:, :T - 1])
