@@ -546,6 +546,19 @@ int s2t_gemm_x3_nt(const float* A, long lda, const unsigned short* W, long ldw, 
                    float* C, long ldc, int M, int N, int K, const float* bias, const float* resid,
                    long ldr, float beta, void* stream);
 
+/* Pipelined form (csrc/gemm_x3f.hip).  s2t_split_planes_frag writes the three bf16 pieces of the
+ * logical matrix Bm[n][k] (= src[n*ld + k], or src[k*ld + n] when transposed) in FRAGMENT-MAJOR order
+ * [N/32][K/16][3][64 lanes][8]: the 1 KB one v_mfma_f32_32x32x16_bf16 B operand needs is one
+ * contiguous piece (N % 32 == 0, K % 16 == 0, else -2; dst holds s2t_split_planes_frag_elems(N,K)
+ * bf16 = 3 N K).  s2t_gemm_x3f_nt: C[M,N] = A[M,K] . Bm^T (+ bias[N]) (+ beta R[M,N]); tnw = column
+ * tiles per wave (block tile 128 x 64 tnw), 0 = chosen from the shape. */
+long s2t_split_planes_frag_elems(int N, int K);
+int s2t_split_planes_frag(const float* src, long ld, int N, int K, int transposed,
+                          unsigned short* dst, void* stream);
+int s2t_gemm_x3f_nt(const float* A, long lda, const unsigned short* Bf, float* C, long ldc, int M,
+                    int N, int K, const float* bias, const float* resid, long ldr, float beta,
+                    int tnw, void* stream);
+
 /* ---- side stream for work off the critical path (csrc/streams.hip): the weight-gradient GEMMs
  * of backward overlap the data-gradient chain.  s2t_side_stream returns the library-owned stream;
  * s2t_stream_order(from, to) makes later work on `to` wait for the work enqueued so far on `from`. */

@@ -251,3 +251,42 @@ def test_bf16x3_split_gemm_has_fp32_accuracy(dev, M, K, N):
     Nt.check(L.s2t_split_planes_t(Nt.fp(W), Nt.raw(dt), 1, tiles, Nt.raw(plt_), n, Nt.stream()), "split_t")
     pt = plt_.view(3, K, N).view(torch.bfloat16).double().sum(0).float()
     assert torch.equal(pt, W.t().contiguous())
+
+
+@pytest.mark.parametrize("M,K,N", [(4097, 256, 768), (1000, 192, 96), (15872, 960, 256), (130, 16, 32)])
+def test_bf16x3_pipelined_gemm_has_fp32_accuracy(dev, M, K, N):
+    """s2t_gemm_x3f_nt (csrc/gemm_x3f.hip: fragment-major bf16 pieces, LDS-DMA rings; verified, not
+    on the step's path): error against fp64 within the fp32 library's, for every tile width, with
+    the bias + residual epilogue, a ragged last row tile and a column tile that overhangs N; the
+    transposed-source pieces (data-gradient operand) give the same product."""
+    from speech2text_amd import _native as Nt
+    from speech2text_amd import zip_kernels as zk
+    L = Nt.lib()
+    g = torch.Generator().manual_seed(M + 3 * K)
+    x = (torch.randn(M, K, generator=g) * torch.logspace(-2, 2, K)).to(dev)
+    W = (torch.randn(N, K, generator=g) * 0.1).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    assert L.s2t_split_planes_frag_elems(N, K) == 3 * N * K
+    pf = torch.empty(3 * N * K, dtype=torch.int16, device=dev)
+    Nt.check(L.s2t_split_planes_frag(Nt.fp(W), K, N, K, 0, Nt.raw(pf), Nt.stream()), "split_frag")
+    Wt = W.t().contiguous()                                   # (K,N) storage of the same matrix
+    pft = torch.empty_like(pf)
+    Nt.check(L.s2t_split_planes_frag(Nt.fp(Wt), N, N, K, 1, Nt.raw(pft), Nt.stream()), "split_frag(T)")
+    assert torch.equal(pf, pft)
+    # the pieces of element (n, k) add up to it exactly
+    v = pf.view(N // 32, K // 16, 3, 2, 32, 8).view(torch.bfloat16).double().sum(dim=2)   # nt,kb,hi,lo,e
+    back = v.permute(0, 3, 1, 2, 4).reshape(N, K).float()
+    assert torch.equal(back, W)
+    ref = torch.nn.functional.linear(x.double(), W.double(), b.double()) + 0.5 * res.double()
+    lib = zk.lt_matmul(0, x, W, b).double() + 0.5 * res.double()
+    scale = ref.abs().max().item()
+    e_lib = (lib - ref).abs().max().item() / scale
+    for tnw in (0, 1, 2, 3, 4):
+        y = torch.full((M, N), float("nan"), device=dev)
+        Nt.check(L.s2t_gemm_x3f_nt(Nt.fp(x), K, Nt.raw(pf), Nt.fp(y), N, M, N, K, Nt.fp(b), Nt.fp(res), N,
+                                   0.5, tnw, Nt.stream()), "x3f")
+        e = (y.double() - ref).abs().max().item() / scale
+        assert e <= max(1.5 * e_lib, 2e-7), (tnw, e, e_lib)
+    assert L.s2t_gemm_x3f_nt(Nt.fp(x), K, Nt.raw(pf), Nt.fp(y), N, M, N, 24, None, None, 0, 0.0, 0,
+                             Nt.stream()) == -2               # K % 16 != 0: caller uses the library

@@ -25,6 +25,51 @@ def x3(A, pl, Nn, K, C, bias=None, resid=None):
                              N.stream()), "x3")
 
 
+def frag_of(W, transposed=False):
+    """W (N,K) [or the (K,N) storage of its transpose] -> fragment-major bf16 pieces."""
+    Nn, K = (W.shape[1], W.shape[0]) if transposed else W.shape
+    pl = torch.empty(3 * Nn * K, dtype=torch.int16, device=dev)
+    N.check(L.s2t_split_planes_frag(N.fp(W), W.stride(0), Nn, K, int(transposed), N.raw(pl), N.stream()),
+            "split_frag")
+    return pl
+
+
+def x3f(A, pf, Nn, K, C, bias=None, resid=None, tnw=0):
+    M = A.shape[0]
+    N.check(L.s2t_gemm_x3f_nt(N.fp(A), A.stride(0), N.raw(pf), N.fp(C), C.stride(0), M, Nn, K,
+                              N.fp(bias), N.fp(resid), 0 if resid is None else resid.stride(0), 1.0,
+                              tnw, N.stream()), "x3f")
+
+
+def main_f():
+    torch.manual_seed(0)
+    shapes = [(31744, 192, 384), (31744, 192, 512), (31744, 192, 640), (31744, 512, 192), (31744, 192, 272),
+              (15872, 256, 576), (15872, 256, 768), (15872, 256, 960), (15872, 768, 256), (15872, 960, 256),
+              (7936, 256, 768), (7936, 768, 256), (3968, 256, 768), (3968, 768, 256), (7936, 256, 512)]
+    print(f"{'M':>7} {'K':>5} {'N':>5} | lt us  TF/s | x3f auto us TF/s | tnw=1..4 us | err x3f / lt (vs fp64)")
+    for (M, K, Nn) in shapes:
+        if Nn % 32 or K % 16:
+            continue
+        x = torch.randn(M, K, device=dev)
+        W = torch.randn(Nn, K, device=dev) * 0.1
+        b = torch.randn(Nn, device=dev)
+        res = torch.randn(M, Nn, device=dev)
+        pf = frag_of(W)
+        y = torch.empty(M, Nn, device=dev)
+        x3f(x, pf, Nn, K, y, b, res)
+        rows = slice(max(0, M - 4096), M)
+        ref = torch.nn.functional.linear(x[rows].double(), W.double(), b.double()) + res[rows].double()
+        e1 = ((y[rows].double() - ref).abs().max() / ref.abs().max()).item()
+        yl = zk.lt_matmul(0, x, W, b, res)
+        e2 = ((yl[rows].double() - ref).abs().max() / ref.abs().max()).item()
+        t2 = timeit(lambda: zk.lt_matmul(0, x, W, b, res))
+        t1 = timeit(lambda: x3f(x, pf, Nn, K, y, b, res))
+        ts = [timeit(lambda: x3f(x, pf, Nn, K, y, b, res, t)) for t in (1, 2, 3, 4)]
+        fl = 2.0 * M * K * Nn
+        print(f"{M:7d} {K:5d} {Nn:5d} | {t2:6.1f} {fl / t2 / 1e6:5.0f} | {t1:6.1f} {fl / t1 / 1e6:5.0f} | "
+              + " ".join(f"{t:6.1f}" for t in ts) + f" | {e1:.2e} {e2:.2e}", flush=True)
+
+
 def main():
     torch.manual_seed(0)
     shapes = [(31680, 192, 384), (31680, 192, 512), (31680, 512, 192), (31680, 192, 272), (15872, 256, 576),
@@ -59,4 +104,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main_f() if "f" in sys.argv[1:] else main()
