@@ -275,6 +275,13 @@ int s2t_gemm_f32(int mode, const float* A, long lda, const float* B, long ldb, f
                  const float* act_src, long lds, int act_kind, int pro_a, int pro_b, float* colsum,
                  int accumulate, void* stream);
 
+/* x^T x for the Whiten statistics (model/layer/scaling.py:949-1012): xtx (C,C, ldc) += x^T x and
+ * colsum (C) += column sums of x (R,C, ldx), restricted to what the per-group covariance needs:
+ * the 64x64 tiles on or above the diagonal that contain a pair of channels of the same group of
+ * cg channels.  Tiles below the diagonal are NOT written (s2t_whiten_metric mirrors them). */
+int s2t_gemm_xtx(const float* x, long ldx, int R, int C, int cg, float* xtx, long ldc,
+                 float* colsum, void* stream);
+
 /* The weight-gradient GEMMs of one layer in ONE launch (mode TN of s2t_gemm_f32, 64x64 tiles):
  * for each problem  C[M,N] += A[K,M]^T . B[K,N]  and  colsum[m] += sum_k A[k][m]  (colsum may be
  * NULL), both scaled by `alpha` (the conformer's 0.5 feed-forward residual weight rides here

@@ -52,6 +52,8 @@ struct GemmArgs {
   int splits;
   int debug;
   float alpha;            // TN: scale of the accumulated product / column sums
+  int sym_cg;             // TN with A == B (x^T x): > 0 = only the 64x64 tiles on / above the
+                          // diagonal that hold same-group pairs (groups of sym_cg channels)
 };
 
 __device__ __forceinline__ float log1p_fast(float e) {   // as zip_elem.hip
@@ -165,6 +167,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const unsigned bid)
   }
   const int tm = lin / g.tiles_n, tn = lin % g.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
+  if (MODE == MODE_TN && g.sym_cg > 0) {
+    // symmetric product: the tile below the diagonal is the transpose of one above it, and a tile
+    // whose first column group lies beyond its last row group holds no pair the caller reads
+    if (tn < tm || n0 / g.sym_cg > (m0 + BM - 1) / g.sym_cg) return;
+  }
+  const int csum_tn = (MODE == MODE_TN && g.sym_cg > 0) ? tm : 0;   // the tile that owns colsum
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
 
@@ -196,7 +204,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const unsigned bid)
       oka = TA::load(ra, g.A, g.lda, m0, g.M, k0 + BK, kend);
       okb = TB::load(rb, g.B, g.ldb, n0, g.N, k0 + BK, kend);
     }
-    if (MODE == MODE_TN && g.colsum != nullptr && tn == 0 && threadIdx.x < BM) {
+    if (MODE == MODE_TN && g.colsum != nullptr && tn == csum_tn && threadIdx.x < BM) {
 #pragma unroll 8
       for (int r = 0; r < BK; ++r) csum += sA[r * TA::LD + threadIdx.x];
     }
@@ -218,7 +226,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const unsigned bid)
         }
     }
   }
-  if (MODE == MODE_TN && g.colsum != nullptr && tn == 0 && threadIdx.x < BM &&
+  if (MODE == MODE_TN && g.colsum != nullptr && tn == csum_tn && threadIdx.x < BM &&
       m0 + (int)threadIdx.x < g.M)
     atomicAdd(g.colsum + m0 + threadIdx.x, csum * g.alpha);
 
@@ -337,8 +345,8 @@ int dispatch(GemmArgs& g, hipStream_t st) {
     static int force = -1, user_blocks = -2;
     if (force < 0) { const char* e = getenv("S2T_TN_TILE"); force = e ? atoi(e) : 0; }
     if (user_blocks == -2) { const char* e = getenv("S2T_TN_BLOCKS"); user_blocks = e ? atoi(e) : -1; }
-    const int ttm = force > 0 ? force / 10 : 1;
-    const int ttn = force > 0 ? force % 10 : (g.N >= 512 ? 2 : 1);
+    const int ttm = (force > 0 && !g.sym_cg) ? force / 10 : 1;
+    const int ttn = g.sym_cg ? 1 : (force > 0 ? force % 10 : (g.N >= 512 ? 2 : 1));
     const long tiles = (long)((g.M + 64 * ttm - 1) / (64 * ttm)) * ((g.N + 64 * ttn - 1) / (64 * ttn));
     const int target = user_blocks > 0 ? user_blocks : (ttm * ttn == 1 ? 1536 : 768);
     int splits = (int)((target + tiles - 1) / tiles);
@@ -375,7 +383,7 @@ extern "C" int s2t_gemm_f32(int mode, const float* A, long lda, const float* B, 
   if (act_kind < 0 || act_kind > 2 || pro_a < 0 || pro_a > 2 || pro_b < 0 || pro_b > 2) return -1;
   if (mode == MODE_TN && (resid || act_src || bias)) return -1;
   GemmArgs g{A, lda, B, ldb, C, ldc, M, N, K, bias, resid, ldr, act_src, lds, act_kind, pro_a,
-             pro_b, colsum, accumulate, 0, 0, 0, 0, 0, 1.f};
+             pro_b, colsum, accumulate, 0, 0, 0, 0, 0, 1.f, 0};
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (mode == MODE_NT) rc = dispatch<MODE_NT>(g, st);
@@ -383,6 +391,15 @@ extern "C" int s2t_gemm_f32(int mode, const float* A, long lda, const float* B, 
   else if (mode == MODE_TN) rc = dispatch<MODE_TN>(g, st);
   else return -1;
   return rc;
+}
+
+extern "C" int s2t_gemm_xtx(const float* x, long ldx, int R, int C, int cg, float* xtx, long ldc,
+                            float* colsum, void* stream) {
+  if (R <= 0 || C <= 0 || cg <= 0 || C % cg) return -1;
+  if ((reinterpret_cast<uintptr_t>(x) & 15) || (ldx & 3) || (C & 3) || C < 4 || R < 4) return -2;
+  GemmArgs g{x, ldx, x, ldx, xtx, ldc, C, C, R, nullptr, nullptr, 0, nullptr, 0, 0, 0,
+             0, colsum, 0, 0, 0, 0, 0, 0, 1.f, cg};
+  return dispatch<MODE_TN>(g, (hipStream_t)stream);
 }
 
 extern "C" int s2t_gemm_tn_grouped(int n, const S2tTnProblem* probs, void* stream) {

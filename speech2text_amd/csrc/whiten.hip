@@ -28,7 +28,7 @@ __device__ __forceinline__ float block_sum(float v, float* s_tmp) {
   return s_tmp[0];
 }
 
-// xtx: (C,C) = x^T x over all groups' channels; cov: (G,cg,cg) per-group centred covariance
+// xtx: (C,C) = x^T x over all groups' channels (upper 64x64 tiles; a full matrix works too); cov: (G,cg,cg) per-group centred covariance
 // scal: [md, covsq, denom, metric].  One workgroup per row ci: its group's block of the centred
 // covariance, the row's partial sums, then the row of xtx is ZEROED (the accumulating TN GEMM that
 // fills it finds it clean next time -- no fill launch per call).  The last workgroup (ticket) adds
@@ -50,12 +50,20 @@ __global__ __launch_bounds__(256) void whiten_metric_kernel(float* __restrict__ 
   const float mi = colsum[ci] * inv_n;
   float dsum = 0.f, sq = 0.f;
   float* xrow = xtx + (long)ci * C;
+  // xtx holds the 64x64 tiles on and above the diagonal (s2t_gemm_xtx): a row takes the pairs
+  // whose column tile is not left of its own, and mirrors those of tiles strictly to the right
+  // (the row that owns the mirror image has no valid copy of it)
   for (int j = threadIdx.x; j < cg; j += 256) {
     const int cj = g * cg + j;
+    if ((cj >> 6) < (ci >> 6)) continue;
     const float v = xrow[cj] - mi * colsum[cj];
     cov[((long)g * cg + i) * cg + j] = v;
     sq = fmaf(v, v, sq);
     if (i == j) dsum = v;
+    if ((cj >> 6) > (ci >> 6)) {
+      cov[((long)g * cg + j) * cg + i] = v;
+      sq = fmaf(v, v, sq);
+    }
   }
   __syncthreads();                                   // row fully read before it is cleared
   for (int j = threadIdx.x; j < C; j += 256) xrow[j] = 0.f;

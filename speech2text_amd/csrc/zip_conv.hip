@@ -49,12 +49,14 @@ struct ConvArgs {
 
 template <int K>
 __device__ __forceinline__ void stage_weights(const ConvArgs& a, int c0, float* s_wc, float* s_wk,
-                                              float* s_le, float* s_re) {
+                                              float* s_le, float* s_re, bool need_scale) {
   // all of a thread's tap loads are issued back to back from clamped (always valid) addresses;
   // validity is applied on the LDS store (loads behind per-lane conditions serialise)
   constexpr int Kh = (K + 1) / 2;
   constexpr int NI = (64 * K + 255) / 256, NH = (64 * Kh + 255) / 256;
-  const bool sc = a.scale != nullptr;
+  // need_scale (block-uniform): some frame this workgroup touches lies within K of a chunk edge;
+  // elsewhere the edge arrays are never read and their 2 K x 64 loads + LDS stores are skipped
+  const bool sc = a.scale != nullptr && need_scale;
   float wk[NI], le[NI], re[NI], wc[NH];
 #pragma unroll
   for (int q = 0; q < NI; ++q) {
@@ -77,8 +79,10 @@ __device__ __forceinline__ void stage_weights(const ConvArgs& a, int c0, float* 
       const int c = i / K, j = i % K;
       const bool ok = c0 + c < a.C;
       s_wk[j * 64 + c] = ok ? wk[q] : 0.f;
-      s_le[j * 64 + c] = ok ? le[q] : 0.f;
-      s_re[j * 64 + c] = ok ? re[q] : 0.f;
+      if (need_scale) {
+        s_le[j * 64 + c] = ok ? le[q] : 0.f;
+        s_re[j * 64 + c] = ok ? re[q] : 0.f;
+      }
     }
   }
 #pragma unroll
@@ -142,7 +146,8 @@ __global__ __launch_bounds__(256) void zipconv_fwd_kernel(ConvArgs a, float* __r
   // read neighbouring pieces of the same (t, b) rows (rows of adjacent b are adjacent in memory)
   const int c0 = blockIdx.x * 64, b = blockIdx.y, t0 = blockIdx.z * TT;
   const int c = threadIdx.x & 63, tg = threadIdx.x >> 6;
-  stage_weights<K>(a, c0, s_wc, s_wk, s_le, s_re);
+  stage_weights<K>(a, c0, s_wc, s_wk, s_le, s_re,
+                   GEN || t0 - K / 2 < K || t0 + TT + K / 2 > a.T - K);
   stage_xg<K>(a, b, t0, c0, s_x);
   __syncthreads();
   if (c0 + c >= a.C) return;
@@ -217,7 +222,8 @@ __global__ __launch_bounds__(256) void zipconv_bwd_data_kernel(ConvArgs a,
   // read neighbouring pieces of the same (t, b) rows (rows of adjacent b are adjacent in memory)
   const int c0 = blockIdx.x * 64, b = blockIdx.y, t0 = blockIdx.z * TT;
   const int c = threadIdx.x & 63, tg = threadIdx.x >> 6;
-  stage_weights<K>(a, c0, s_wc, s_wk, s_le, s_re);
+  stage_weights<K>(a, c0, s_wc, s_wk, s_le, s_re,
+                   GEN || t0 - K / 2 < K || t0 + TT + K / 2 > a.T - K);
   __syncthreads();
   const int chunk = a.chunk;
   // two tiles: raw dy (causal taps) and dy * edge_scale (chunkwise taps); batched loads from
@@ -327,7 +333,8 @@ __global__ __launch_bounds__(256) void zipconv_bwd_w_kernel(ConvArgs a,
   const int c = threadIdx.x & 63, tg = threadIdx.x >> 6;
   const int tb = t0 + tg * FPT;
   const int chunk = a.chunk;
-  stage_weights<K>(a, c0, s_wc, s_wk, s_le, s_re);
+  stage_weights<K>(a, c0, s_wc, s_wk, s_le, s_re,
+                   GEN || t0 - K / 2 < K || t0 + TT + K / 2 > a.T - K);
   float pwc[Kh], pwk[K];
 #pragma unroll
   for (int j = 0; j < Kh; ++j) pwc[j] = 0.f;

@@ -309,7 +309,12 @@ class WhitenStats:
         # channel count; the side stream serialises them in issue order.
         side = _stats_stream() if _tn_ok(xf) else None
         if _tn_ok(xf):
-            gemm_tn(xf, xf, xtx, colsum, stream=side)
+            # symmetric product: only the 64x64 tiles on / above the diagonal that hold same-group
+            # pairs are computed (6 of 9 at C = 192, 10 of 16 at 256, the diagonal for the keys)
+            N.profile_note("s2t_gemm_f32", 4.0 * (xf.numel() + C * C), 2.0 * n * C * cg)
+            N.check(N.lib().s2t_gemm_xtx(N.raw(xf, torch.float32), xf.stride(0), n, C, cg,
+                                         N.fp(xtx), xtx.stride(0), N.fp(colsum),
+                                         side if side is not None else N.stream()), "s2t_gemm_xtx")
         else:
             a, b = linear_wgrad(xf, xf, True)
             xtx.copy_(a)

@@ -361,3 +361,31 @@ def test_downsample_and_upsampled_bypass_vs_torch(dev, T, B, C, ds):
     torch.testing.assert_close(o_g.grad.cpu().double(), o_r.grad, atol=1e-5, rtol=1e-5)
     torch.testing.assert_close(l_g.grad.cpu().double(), l_r.grad, atol=1e-5, rtol=1e-5)
     torch.testing.assert_close(s_g.grad.cpu().double(), s_r.grad, atol=1e-3, rtol=1e-4)
+
+
+@pytest.mark.parametrize("R,C,G", [(700, 192, 1), (1000, 128, 4), (333, 96, 2), (2000, 512, 1),
+                                   (500, 256, 8), (260, 64, 1)])
+def test_whiten_backward_vs_oracle(dev, monkeypatch, R, C, G):
+    """Whiten (scaling.py:949-1095): x^T x comes from the symmetric TN GEMM (only the 64x64 tiles on /
+    above the diagonal with same-group pairs; cg = 48 straddles tiles), the metric kernel mirrors
+    them; the backward term against the oracle's autograd-in-backward statement."""
+    import random
+    from speech2text_amd.model.layer.scaling import Whiten
+    torch.manual_seed(R + C)
+    x = torch.randn(R, C) @ (torch.eye(C) + 0.3 * torch.randn(C, C))      # correlated channels
+    x = x + 0.5 * torch.randn(C)
+    w = torch.randn(R, C)
+    monkeypatch.setattr(random, "random", lambda: 0.0)                     # the module fires
+    ctl = Z.Ctl(training=True, rand=lambda: 0.0)
+    xc = x.clone().requires_grad_(True)
+    (Z.whiten(xc, ctl, G, 1.02, 0.05) * w).sum().backward()
+    m = Whiten(num_groups=G, whitening_limit=1.02, prob=(0.025, 0.25), grad_scale=0.05).to(dev).train()
+    for _ in range(2):                       # twice: the shared accumulator must come back clean
+        xg = x.to(dev).requires_grad_(True)
+        y = m(xg)
+        (y * w.to(dev)).sum().backward()
+        assert torch.equal(y.detach().cpu(), x)
+        d = (xg.grad.cpu() - w).numpy()                                    # the shaping term only
+        r = (xc.grad - w).numpy()
+        assert np.abs(r).max() > 0, "metric below the limit: the test would be vacuous"
+        np.testing.assert_allclose(d, r, atol=2e-3 * np.abs(r).max(), rtol=2e-3)

@@ -101,7 +101,10 @@ if __name__ == "__main__":
         wgrad()
         sys.exit(0)
     if only == "conv":
-        conv(495, B, 192, 31)
+        conv(496, B, 192, 31)
+        conv(248, B, 256, 31)
+        conv(124, B, 256, 15)
+        conv(62, B, 256, 15)
         sys.exit(0)
     if only == "attn":
         attn(495, B, 4)
