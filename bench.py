@@ -82,10 +82,10 @@ def c2_config(vocab=128, layers=12):
         "encoder": {"model": "Conformer", "config": {
             "bn_cmvn": False, "feats_dim": 80, "subsampling_rate": 4, "input_dim": 256,
             "num_heads": 4, "ffn_dim": 2048, "num_layers": layers,
-            "depthwise_conv_kernel_size": 31, "dropout": 0.0, "use_group_norm": False,
+            "depthwise_conv_kernel_size": 31, "dropout": 0.1, "use_group_norm": False,
             "convolution_first": False, "output_dim": 256}},
         "decoder": {"model": "Projector", "config": {"input_dim": 256, "output_dim": vocab,
-                                                     "dropout_p": 0.0}},
+                                                     "dropout_p": 0.1}},
         "loss": {"model": "CTC", "config": {"blank_label": 0, "reduction": "mean"}},
         "optim_setup": {"seperate_lr": {"apply": False},
                         "optimizer": {"type": "AdamW", "config": {"lr": 1.0e-3}},
@@ -106,7 +106,7 @@ def c4_config(vocab=128, layers=12):
     cfg["predictor"] = {"model": "Lstm", "config": {
         "num_symbols": vocab, "output_dim": 256, "symbol_embedding_dim": 256, "num_lstm_layers": 2,
         "lstm_hidden_dim": 256, "lstm_layer_norm": True, "lstm_layer_norm_epsilon": 1e-3,
-        "lstm_dropout": 0.0}}
+        "lstm_dropout": 0.3}}
     cfg["joiner"] = {"input_dim": 256, "output_dim": vocab, "inner_dim": 256, "activation": "tanh",
                      "prune_range": -1}
     cfg["loss"] = {"rnnt_weight": 0.8, "ctc_weight": 0.2,
@@ -268,7 +268,8 @@ def cpu_baseline_c2(cfg, state_dict, seconds=10.0, batch=4, n_labels=40, vocab=1
         feats = np.stack([ofb.fbank(p, 80) for p in pcm])
         x = torch.from_numpy(feats)
         lens = torch.full((batch,), feats.shape[1], dtype=torch.int64)
-        y, ylen = OC.conformer_forward(enc, x, lens, ec["num_layers"], ec["num_heads"], training=True)
+        y, ylen = OC.conformer_forward(enc, x, lens, ec["num_layers"], ec["num_heads"], training=True,
+                                       dropout=ec.get("dropout", 0.0), seeds="torch")
         logits = H.projector(sd, "_decoder.decoder.", y)
         lp = logits.log_softmax(-1).transpose(0, 1)
         loss = torch.nn.functional.ctc_loss(lp, lab, ylen, lab_len, blank=0, reduction="mean",
@@ -333,7 +334,8 @@ def cpu_baseline_c4(cfg, state_dict, seconds=10.0, batch=2, n_labels=60, vocab=1
         feats = np.stack([ofb.fbank(p, 80) for p in pcm])
         x = torch.from_numpy(feats)
         lens = torch.full((batch,), feats.shape[1], dtype=torch.int64)
-        y, ylen = OC.conformer_forward(enc, x, lens, ec["num_layers"], ec["num_heads"], training=True)
+        y, ylen = OC.conformer_forward(enc, x, lens, ec["num_layers"], ec["num_heads"], training=True,
+                                       dropout=ec.get("dropout", 0.0), seeds="torch")
         logits = H.projector(sd, "_decoder.decoder.", y)
         l_ctc = torch.nn.functional.ctc_loss(logits.log_softmax(-1).transpose(0, 1), lab, ylen,
                                              lab_len, blank=0, reduction="mean", zero_infinity=True)
@@ -382,7 +384,8 @@ def cpu_baseline_c5(cfg, state_dict, seconds=30.0, batch=2, steps=3, warmup=1):
             for t2 in idx:
                 x[b, 4 * t2:4 * t2 + 7] = rng.normal(0.0, 0.1, size=(min(7, x.shape[1] - 4 * t2), 80))
         y, ylen = OC.conformer_forward(enc, torch.from_numpy(x), torch.from_numpy(lens),
-                                       ec["num_layers"], ec["num_heads"], training=True)
+                                       ec["num_layers"], ec["num_heads"], training=True,
+                                       dropout=ec.get("dropout", 0.0), seeds="torch")
         logits = H.projector(sd, "_logits_layer.decoder.", y)
         loss = H.masked_kl_div(logits, torch.from_numpy(labels[0][:, :logits.shape[1]]),
                                torch.from_numpy(mask[:, :logits.shape[1]]), K + 1, 1.0, 0.1)

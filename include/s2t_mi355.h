@@ -455,6 +455,18 @@ int s2t_layernorm_param_grad(int n, const S2tLnFold* items, int C, void* stream)
  * alias da; scale carries the layer's 0.5 feed-forward residual weight). */
 int s2t_silu_fwd(const float* h, long n, float* a, void* stream);
 int s2t_silu_bwd(const float* h, const float* da, long n, float scale, float* dh, void* stream);
+/* nn.Dropout sites of the conformer block (torchaudio.models.Conformer: after the feed-forward
+ * SiLU, after each module's last Linear / pointwise conv, model/encoder/conformer.py:170-178).  The
+ * keep decision of element i is a stateless hash of (seed, i) -- the one s2t_mhsa_* uses for the
+ * attention probabilities -- so backward regenerates the forward's mask; kept values are scaled by
+ * 1 / (1 - p).  s2t_dropout_add: out = x + alpha * drop(y) (x may be NULL: the masked gradient);
+ * s2t_silu_drop_fwd: a = drop(silu(h)); s2t_silu_drop_bwd: dh = scale * da * mask * silu'(h). */
+int s2t_dropout_add(const float* x, const float* y, long n, float alpha, float p,
+                    unsigned long long seed, float* out, void* stream);
+int s2t_silu_drop_fwd(const float* h, long n, float p, unsigned long long seed, float* a,
+                      void* stream);
+int s2t_silu_drop_bwd(const float* h, const float* da, long n, float scale, float p,
+                      unsigned long long seed, float* dh, void* stream);
 /* nn.BatchNorm1d (training mode: statistics over all rows, biased variance for the normalisation,
  * running_mean / running_var (unbiased) / num_batches_tracked updated; running_* may be NULL)
  * followed by nn.SiLU, conv module of the conformer block.  save_mean / save_rstd [C] feed the

@@ -76,20 +76,39 @@ def ln_param_grad(items, C):
                                              N.stream()), "s2t_layernorm_param_grad")
 
 
-def silu_fwd(h2):
+def silu_fwd(h2, p=0.0, seed=0):
+    """silu(h), or drop(silu(h)) with the hashed mask of (seed, p) (nn.Dropout after the SiLU)."""
     a = torch.empty_like(h2)
     N.profile_note("s2t_silu_fwd", 8.0 * h2.numel())
-    N.check(N.lib().s2t_silu_fwd(N.fp(h2), h2.numel(), N.fp(a), N.stream()), "s2t_silu_fwd")
+    if p > 0.0:
+        N.check(N.lib().s2t_silu_drop_fwd(N.fp(h2), h2.numel(), float(p), int(seed), N.fp(a),
+                                          N.stream()), "s2t_silu_drop_fwd")
+    else:
+        N.check(N.lib().s2t_silu_fwd(N.fp(h2), h2.numel(), N.fp(a), N.stream()), "s2t_silu_fwd")
     return a
 
 
-def silu_bwd(h2, da2, scale=1.0, inplace=True):
-    """scale * da * silu'(h); written over da2 when `inplace`."""
+def silu_bwd(h2, da2, scale=1.0, inplace=True, p=0.0, seed=0):
+    """scale * da * silu'(h) (* the dropout mask of (seed, p)); written over da2 when `inplace`."""
     dh = da2 if inplace else torch.empty_like(da2)
     N.profile_note("s2t_silu_bwd", 12.0 * h2.numel())
-    N.check(N.lib().s2t_silu_bwd(N.fp(h2), N.fp(da2), h2.numel(), float(scale), N.fp(dh),
-                                 N.stream()), "s2t_silu_bwd")
+    if p > 0.0:
+        N.check(N.lib().s2t_silu_drop_bwd(N.fp(h2), N.fp(da2), h2.numel(), float(scale), float(p),
+                                          int(seed), N.fp(dh), N.stream()), "s2t_silu_drop_bwd")
+    else:
+        N.check(N.lib().s2t_silu_bwd(N.fp(h2), N.fp(da2), h2.numel(), float(scale), N.fp(dh),
+                                     N.stream()), "s2t_silu_bwd")
     return dh
+
+
+def dropout_add(x2, y2, alpha, p, seed):
+    """x + alpha * drop(y) in one pass (x2 None: alpha * drop(y), the gradient through the site);
+    mask = the stateless hash of (seed, element index), kept values scaled by 1 / (1 - p)."""
+    out = torch.empty_like(y2)
+    N.profile_note("s2t_dropout_add", 4.0 * y2.numel() * (3 if x2 is not None else 2))
+    N.check(N.lib().s2t_dropout_add(N.fp(x2), N.fp(y2), y2.numel(), float(alpha), float(p),
+                                    int(seed), N.fp(out), N.stream()), "s2t_dropout_add")
+    return out
 
 
 _BN_WS = {}
@@ -277,6 +296,32 @@ class _Mhsa(torch.autograd.Function):
         T, B, H, p, seed = ctx.cfg
         dqkv = mhsa_bwd(q2, lens, T, B, H, o, _rows(g), lse, p, seed)
         return dqkv.view(T, B, -1), None, None, None, None
+
+
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        ctx.cfg = (p, seed)
+        x2 = x.contiguous()
+        return dropout_add(None, x2.view(-1), 1.0, p, seed).view(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        p, seed = ctx.cfg
+        g2 = g.contiguous().float()
+        return dropout_add(None, g2.view(-1), 1.0, p, seed).view(g.shape), None, None
+
+
+class Dropout(torch.nn.Dropout):
+    """nn.Dropout whose training pass on the GPU is the hashed-mask kernel (one pass each way, no
+    mask tensor, no device RNG state); same `p`, same module type for isinstance checks."""
+
+    def forward(self, x):
+        p = float(self.p)
+        if (not self.training or p == 0.0 or not x.is_cuda or x.dtype != _F32 or x.numel() % 4
+                or p >= 1.0):
+            return super().forward(x)
+        return _Dropout.apply(x, p, draw_seed())
 
 
 def draw_seed():

@@ -232,6 +232,63 @@ __global__ __launch_bounds__(256) void silu_bwd_kernel(const float4* __restrict_
   }
 }
 
+// ------------------------------------------------------------------ dropout (nn.Dropout sites)
+// The keep decision of element i is the stateless hash the attention kernels use (splitmix64
+// finaliser of seed + i * golden): forward and backward regenerate the same mask from (seed, p),
+// no mask tensor is stored.  thr = p * 2^32, kept elements are scaled by 1 / (1 - p).
+__device__ __forceinline__ float keep_scale(unsigned long long seed, long idx, unsigned thr,
+                                            float inv_keep) {
+  unsigned long long z = seed + (unsigned long long)idx * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (unsigned)(z >> 32) >= thr ? inv_keep : 0.f;
+}
+
+// out = x + alpha * drop(y)   (x may be null: the masked, scaled gradient of a dropout site)
+__global__ __launch_bounds__(256) void dropout_add_kernel(const float4* __restrict__ x,
+                                                          const float4* __restrict__ y, long n4,
+                                                          float alpha, unsigned thr, float inv_keep,
+                                                          unsigned long long seed,
+                                                          float4* __restrict__ out) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const float4 v = y[i];
+    float4 o = x ? x[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    o.x = fmaf(alpha * keep_scale(seed, 4 * i, thr, inv_keep), v.x, o.x);
+    o.y = fmaf(alpha * keep_scale(seed, 4 * i + 1, thr, inv_keep), v.y, o.y);
+    o.z = fmaf(alpha * keep_scale(seed, 4 * i + 2, thr, inv_keep), v.z, o.z);
+    o.w = fmaf(alpha * keep_scale(seed, 4 * i + 3, thr, inv_keep), v.w, o.w);
+    out[i] = o;
+  }
+}
+
+// a = drop(silu(h));  dh = scale * da * drop-mask * silu'(h)
+__global__ __launch_bounds__(256) void silu_drop_fwd_kernel(const float4* __restrict__ h, long n4,
+                                                            unsigned thr, float inv_keep,
+                                                            unsigned long long seed,
+                                                            float4* __restrict__ a) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const float4 v = h[i];
+    a[i] = make_float4(silu_f(v.x) * keep_scale(seed, 4 * i, thr, inv_keep),
+                       silu_f(v.y) * keep_scale(seed, 4 * i + 1, thr, inv_keep),
+                       silu_f(v.z) * keep_scale(seed, 4 * i + 2, thr, inv_keep),
+                       silu_f(v.w) * keep_scale(seed, 4 * i + 3, thr, inv_keep));
+  }
+}
+__global__ __launch_bounds__(256) void silu_drop_bwd_kernel(const float4* __restrict__ h,
+                                                            const float4* __restrict__ da, long n4,
+                                                            float scale, unsigned thr,
+                                                            float inv_keep, unsigned long long seed,
+                                                            float4* __restrict__ dh) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const float4 v = h[i], g = da[i];
+    dh[i] = make_float4(scale * g.x * silu_deriv(v.x) * keep_scale(seed, 4 * i, thr, inv_keep),
+                        scale * g.y * silu_deriv(v.y) * keep_scale(seed, 4 * i + 1, thr, inv_keep),
+                        scale * g.z * silu_deriv(v.z) * keep_scale(seed, 4 * i + 2, thr, inv_keep),
+                        scale * g.w * silu_deriv(v.w) * keep_scale(seed, 4 * i + 3, thr, inv_keep));
+  }
+}
+
 // ------------------------------------------------------------------ BatchNorm1d + SiLU
 // Statistics: workgroup b sums its slab of rows per channel -> partial[b][2][C] (plain stores).
 // kind 0: (sum x, sum x^2);  kind 1: (sum dz, sum dz xhat) with dz = ds * silu'(gamma xhat + beta).
@@ -479,6 +536,62 @@ int s2t_silu_bwd(const float* h, const float* da, long n, float scale, float* dh
   hipLaunchKernelGGL(silu_bwd_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, (hipStream_t)stream,
                      reinterpret_cast<const float4*>(h), reinterpret_cast<const float4*>(da), n / 4,
                      scale, reinterpret_cast<float4*>(dh));
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+static bool drop_params(float p, unsigned* thr, float* inv_keep) {
+  if (!(p >= 0.f) || p >= 1.f) return false;
+  *thr = p > 0.f ? (unsigned)((double)p * 4294967296.0) : 0u;
+  if (p > 0.f && *thr == 0u) *thr = 1u;
+  *inv_keep = 1.f / (1.f - p);
+  return true;
+}
+
+int s2t_dropout_add(const float* x, const float* y, long n, float alpha, float p,
+                    unsigned long long seed, float* out, void* stream) {
+  if (n <= 0) return 0;
+  unsigned thr;
+  float inv_keep;
+  if (!drop_params(p, &thr, &inv_keep)) return -1;
+  if ((n & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15) ||
+      (reinterpret_cast<uintptr_t>(out) & 15))
+    return -2;
+  hipLaunchKernelGGL(dropout_add_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(y), n / 4,
+                     alpha, thr, inv_keep, seed, reinterpret_cast<float4*>(out));
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+int s2t_silu_drop_fwd(const float* h, long n, float p, unsigned long long seed, float* a,
+                      void* stream) {
+  if (n <= 0) return 0;
+  unsigned thr;
+  float inv_keep;
+  if (!drop_params(p, &thr, &inv_keep)) return -1;
+  if ((n & 3) || (reinterpret_cast<uintptr_t>(h) & 15) || (reinterpret_cast<uintptr_t>(a) & 15))
+    return -2;
+  hipLaunchKernelGGL(silu_drop_fwd_kernel, dim3(stream_grid(n / 4)), dim3(256), 0,
+                     (hipStream_t)stream, reinterpret_cast<const float4*>(h), n / 4, thr, inv_keep,
+                     seed, reinterpret_cast<float4*>(a));
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+int s2t_silu_drop_bwd(const float* h, const float* da, long n, float scale, float p,
+                      unsigned long long seed, float* dh, void* stream) {
+  if (n <= 0) return 0;
+  unsigned thr;
+  float inv_keep;
+  if (!drop_params(p, &thr, &inv_keep)) return -1;
+  if ((n & 3) || (reinterpret_cast<uintptr_t>(h) & 15) || (reinterpret_cast<uintptr_t>(da) & 15) ||
+      (reinterpret_cast<uintptr_t>(dh) & 15))
+    return -2;
+  hipLaunchKernelGGL(silu_drop_bwd_kernel, dim3(stream_grid(n / 4)), dim3(256), 0,
+                     (hipStream_t)stream, reinterpret_cast<const float4*>(h),
+                     reinterpret_cast<const float4*>(da), n / 4, scale, thr, inv_keep, seed,
+                     reinterpret_cast<float4*>(dh));
   S2T_CHECK_LAUNCH();
   return 0;
 }

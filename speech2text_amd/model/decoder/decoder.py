@@ -4,6 +4,7 @@ from typing import Tuple
 
 import torch
 import torch.nn as nn
+from speech2text_amd import conf_kernels as ck
 from speech2text_amd.model.layer.scaling import Linear
 
 
@@ -31,7 +32,7 @@ class Projector(nn.Module):
     def __init__(self, config: ProjectorConfig) -> None:
         super().__init__()
         self._fc = Linear(config.input_dim, config.output_dim)
-        self._dropout = nn.Dropout(p=config.dropout_p)
+        self._dropout = ck.Dropout(p=config.dropout_p)
 
     def forward(self, x: torch.Tensor, length: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         return self._dropout(self._fc(x)), length

@@ -96,8 +96,8 @@ class _FeedForwardModule(nn.Module):
     def __init__(self, input_dim, hidden_dim, dropout):
         super().__init__()
         self.sequential = nn.Sequential(nn.LayerNorm(input_dim), nn.Linear(input_dim, hidden_dim),
-                                        nn.SiLU(), nn.Dropout(dropout),
-                                        nn.Linear(hidden_dim, input_dim), nn.Dropout(dropout))
+                                        nn.SiLU(), ck.Dropout(dropout),
+                                        nn.Linear(hidden_dim, input_dim), ck.Dropout(dropout))
 
     def forward(self, x):
         ln, l1, act, d1, l2, d2 = self.sequential
@@ -119,7 +119,7 @@ class _ConvolutionModule(nn.Module):
             nn.GroupNorm(1, num_channels) if use_group_norm else nn.BatchNorm1d(num_channels),
             nn.SiLU(),
             nn.Conv1d(num_channels, input_dim, 1, bias=bias),
-            nn.Dropout(dropout))
+            ck.Dropout(dropout))
 
     def forward(self, x):
         """x (T,B,D) time-major -> (T,B,D)."""
@@ -144,7 +144,7 @@ class ConformerLayer(nn.Module):
         self.ffn1 = _FeedForwardModule(input_dim, ffn_dim, dropout)
         self.self_attn_layer_norm = nn.LayerNorm(input_dim)
         self.self_attn = nn.MultiheadAttention(input_dim, num_attention_heads, dropout=dropout)
-        self.self_attn_dropout = nn.Dropout(dropout)
+        self.self_attn_dropout = ck.Dropout(dropout)
         self.conv_module = _ConvolutionModule(input_dim, input_dim, depthwise_conv_kernel_size,
                                               dropout, bias=True, use_group_norm=use_group_norm)
         self.ffn2 = _FeedForwardModule(input_dim, ffn_dim, dropout)

@@ -58,7 +58,7 @@ class _Predictor(nn.Module):
         self.lstm_layers = nn.ModuleList([
             _CustomLSTM(symbol_embedding_dim if i == 0 else lstm_hidden_dim, lstm_hidden_dim,
                         lstm_layer_norm, lstm_layer_norm_epsilon) for i in range(num_lstm_layers)])
-        self.dropout = nn.Dropout(p=lstm_dropout)
+        self.dropout = ck.Dropout(p=lstm_dropout)
         self.linear = Linear(lstm_hidden_dim, output_dim)
         self.output_layer_norm = nn.LayerNorm(output_dim)
 
