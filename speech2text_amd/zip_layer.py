@@ -285,6 +285,7 @@ def _sa_bwd(m, fw, sv, x_in, g, W, T, B, H, pairs):
     dO = zk.lt_matmul(1, gy, m.out_proj.weight)
     dv = sv.v.shape[1] // H
     dV = torch.empty_like(sv.v)
+    N.profile_note("s2t_attn_apply", 4.0 * (W.numel() + 2 * sv.v.numel()))
     N.check(N.lib().s2t_attn_apply(N.fp(W), N.fp(dO), T, B, H, dv, 1, N.fp(dV), N.stream()),
             "s2t_attn_apply(T)")
     pairs.append((dO, sv.v, sv.o, dv))

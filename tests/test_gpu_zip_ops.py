@@ -389,3 +389,22 @@ def test_whiten_backward_vs_oracle(dev, monkeypatch, R, C, G):
         r = (xc.grad - w).numpy()
         assert np.abs(r).max() > 0, "metric below the limit: the test would be vacuous"
         np.testing.assert_allclose(d, r, atol=2e-3 * np.abs(r).max(), rtol=2e-3)
+
+
+@pytest.mark.parametrize("T,B,H,dv", [(496, 3, 4, 12), (248, 2, 4, 12), (124, 2, 8, 12), (62, 3, 4, 12),
+                                      (200, 2, 2, 16), (130, 2, 3, 4), (77, 2, 4, 12), (64, 1, 1, 8)])
+def test_attn_apply_both_ways(dev, T, B, H, dv):
+    """s2t_attn_apply: out = W v per head (zipformer.py:2269) and its transpose (the value
+    gradient), float4 path (T % 4 == 0) and the general one, against fp64 matmuls."""
+    from speech2text_amd import _native as Nt
+    torch.manual_seed(T + dv)
+    W = torch.rand(H, B, T, T).softmax(-1).to(dev).contiguous()
+    v = torch.randn(T, B, H * dv).to(dev)
+    out = torch.full_like(v, float("nan"))
+    for tr in (0, 1):
+        Nt.check(Nt.lib().s2t_attn_apply(Nt.fp(W), Nt.fp(v), T, B, H, dv, tr, Nt.fp(out), Nt.stream()),
+                 "s2t_attn_apply")
+        Wd = W.double().transpose(-1, -2) if tr else W.double()
+        ref = torch.matmul(Wd, v.double().reshape(T, B, H, dv).permute(2, 1, 0, 3))
+        ref = ref.permute(2, 1, 0, 3).reshape(T, B, H * dv)
+        np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), atol=2e-5, rtol=1e-4)
