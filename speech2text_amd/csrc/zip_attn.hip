@@ -1116,7 +1116,7 @@ __global__ __launch_bounds__(256) void attn_apply_kernel(const float* __restrict
   }
 }
 
-// The same product for T % 4 == 0 and dv % 4 == 0 (every shipped configuration), restructured
+// The same product for dv % 4 == 0 (every shipped configuration), restructured
 // around what bounded the kernel above (rocprof: 1.1 TB/s algorithmic): the W tile arrives as ONE
 // batch of float4 row loads per thread (one HBM round trip per tile instead of four dependent
 // ones), the next tile's loads are in flight in registers while the current one is multiplied, and
@@ -1134,6 +1134,9 @@ __global__ __launch_bounds__(256) void attn_apply4_kernel(const float* __restric
   const int o0 = blockIdx.x * RT, b = blockIdx.y, h = blockIdx.z;
   const int tid = threadIdx.x, row = tid >> 2, dg = tid & 3;
   const float* Wb = W + ((long)h * B + b) * T * T;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wb), 0, T * T * 4, 0x00020000);
   const long ld = (long)H * dv;
   const int ndg = dv >> 2;
   float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
@@ -1144,7 +1147,11 @@ __global__ __launch_bounds__(256) void attn_apply4_kernel(const float* __restric
       const int idx = u * 256 + tid;
       const int r = idx / (WROW / 4), c4 = idx % (WROW / 4);
       const int i = TRANS ? c0 + r : o0 + r, j = (TRANS ? o0 : c0) + 4 * c4;
-      tw[u] = *reinterpret_cast<const float4*>(Wb + (long)min(i, T - 1) * T + min(j, T - 4));
+      // buffer load: 16 bytes from a dword-aligned offset (rows start on 4-byte boundaries when
+      // T % 4 != 0 -- T = 495 at C3), dwords beyond the (b, h) slab come back as 0
+      const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (i * T + j) * 4, 0, 0);
+      tw[u] = make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z),
+                          __uint_as_float(q.w));
     }
     const int r = tid >> 2, t = c0 + r;               // 64 value rows x 4 groups of 4 channels
     tv = (dg < ndg) ? *reinterpret_cast<const float4*>(v + ((long)min(t, T - 1) * B + b) * ld +
@@ -1157,8 +1164,12 @@ __global__ __launch_bounds__(256) void attn_apply4_kernel(const float* __restric
       const int idx = u * 256 + tid;
       const int r = idx / (WROW / 4), c4 = idx % (WROW / 4);
       const int i = TRANS ? c0 + r : o0 + r, j = (TRANS ? o0 : c0) + 4 * c4;
-      *reinterpret_cast<float4*>(&s_W[r * WP + 4 * c4]) =
-          (i < T && j < T) ? tw[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 q = tw[u];
+      if (i >= T || j >= T) q.x = 0.f;
+      if (i >= T || j + 1 >= T) q.y = 0.f;
+      if (i >= T || j + 2 >= T) q.z = 0.f;
+      if (i >= T || j + 3 >= T) q.w = 0.f;
+      *reinterpret_cast<float4*>(&s_W[r * WP + 4 * c4]) = q;
     }
     const int r = tid >> 2;
     *reinterpret_cast<float4*>(&s_v[r * 16 + 4 * dg]) =
@@ -1214,9 +1225,9 @@ extern "C" int s2t_attn_apply(const float* W, const float* v, int T, int B, int 
   dim3 grid((T + 127) / 128, B, H);
   static int old = -1;
   if (old < 0) { const char* e = getenv("S2T_ATTN_APPLY_OLD"); old = e ? atoi(e) : 0; }
-  const bool wide = !old && T >= 4 && (T & 3) == 0 && (dv & 3) == 0 && (((long)H * dv) & 3) == 0 &&
-                    ((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(v) |
-                      reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  const bool wide = !old && T >= 4 && T <= 16384 && (dv & 3) == 0 &&
+                    ((reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(out)) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(W) & 3) == 0;
   if (wide) {
     if (transpose)
       hipLaunchKernelGGL(attn_apply4_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, W, v, T,

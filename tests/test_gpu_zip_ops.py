@@ -391,11 +391,12 @@ def test_whiten_backward_vs_oracle(dev, monkeypatch, R, C, G):
         np.testing.assert_allclose(d, r, atol=2e-3 * np.abs(r).max(), rtol=2e-3)
 
 
-@pytest.mark.parametrize("T,B,H,dv", [(496, 3, 4, 12), (248, 2, 4, 12), (124, 2, 8, 12), (62, 3, 4, 12),
+@pytest.mark.parametrize("T,B,H,dv", [(495, 3, 4, 12), (496, 3, 4, 12), (248, 2, 4, 12), (5, 1, 2, 4), (3, 2, 1, 4), (124, 2, 8, 12), (62, 3, 4, 12),
                                       (200, 2, 2, 16), (130, 2, 3, 4), (77, 2, 4, 12), (64, 1, 1, 8)])
 def test_attn_apply_both_ways(dev, T, B, H, dv):
     """s2t_attn_apply: out = W v per head (zipformer.py:2269) and its transpose (the value
-    gradient), float4 path (T % 4 == 0) and the general one, against fp64 matmuls."""
+    gradient), float4 path (dv % 4 == 0; rows unaligned when T % 4 != 0) and the general one,
+    against fp64 matmuls."""
     from speech2text_amd import _native as Nt
     torch.manual_seed(T + dv)
     W = torch.rand(H, B, T, T).softmax(-1).to(dev).contiguous()

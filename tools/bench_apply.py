@@ -5,7 +5,7 @@ import torch
 from speech2text_amd import _native as N
 from tools.bench_gemm import timeit
 dev = torch.device("cuda")
-for T, H in [(496, 4), (248, 4), (124, 4), (62, 8)]:
+for T, H in [(495, 4), (496, 4), (248, 4), (124, 4), (62, 8)]:
     B, dv = 64, 12
     W = torch.rand(H, B, T, T, device=dev)
     v = torch.randn(T, B, H * dv, device=dev)
