@@ -133,6 +133,55 @@ __device__ __forceinline__ void stage_xg(const ConvArgs& a, int b, int t0, int c
   }
 }
 
+// The same tile through BUFFER loads (the recipe that took s2t_attn_apply from 3.2 to 4.0 TB/s):
+// lane = 4 channels of one row, so a wave-instruction moves 4 whole rows (16-byte pieces, any dword
+// alignment), all of a thread's loads -- x and gate of its 6 rows -- are issued as ONE batch, and
+// frames outside [0, T) need no clamping: their offsets fall outside the buffer and read as 0.
+// One 32-bit offset register per load instead of a 64-bit address pair.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bool buf_ok(const ConvArgs& a) {
+  return (long)a.T * a.B * a.ld * 4 < (1L << 31);
+}
+
+template <int K>
+__device__ __forceinline__ void stage_xg_buf(const ConvArgs& a, int b, int t0, int c0, float* s_x) {
+  constexpr int halo = K / 2, rows = TT + 2 * halo, NP = (rows + 15) / 16;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.u), 0, (int)((long)a.T * a.B * a.ld * 4), 0x00020000);
+  const int rig = threadIdx.x >> 4, c4 = threadIdx.x & 15, ch = c0 + 4 * c4;
+  const bool gated = a.gate_off >= 0;
+  u32x4 xv[NP], gv[NP];
+  unsigned char mk[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int t = t0 - halo + 16 * p + rig;
+    // rows beyond the tile's last one (p = NP - 1 only) are not stored; their loads are harmless
+    const int off = (((t * a.B + b) * (int)a.ld) + ch) * 4;
+    const bool tin = t >= 0 && t < a.T;
+    xv[p] = __builtin_amdgcn_raw_buffer_load_b128(rs, tin ? off : 0x7FFFFFF0, 0, 0);
+    gv[p] = gated ? __builtin_amdgcn_raw_buffer_load_b128(rs, tin ? off + a.gate_off * 4 : 0x7FFFFFF0, 0, 0)
+                  : (u32x4){0u, 0u, 0u, 0u};
+    mk[p] = a.mask ? a.mask[(long)b * a.T + min(max(t, 0), a.T - 1)] : (unsigned char)0;
+  }
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int r = 16 * p + rig;
+    if (r < rows) {
+      float v[4] = {__uint_as_float(xv[p].x), __uint_as_float(xv[p].y), __uint_as_float(xv[p].z),
+                    __uint_as_float(xv[p].w)};
+      const float g[4] = {__uint_as_float(gv[p].x), __uint_as_float(gv[p].y),
+                          __uint_as_float(gv[p].z), __uint_as_float(gv[p].w)};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (gated) v[e] *= sigmoidf_(g[e]);
+        if (mk[p] || ch + e >= a.C) v[e] = 0.f;       // (frames outside [0,T) were read as 0)
+      }
+      *reinterpret_cast<float4*>(&s_x[r * 64 + 4 * c4]) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
 template <int K, bool GEN>
 __global__ __launch_bounds__(256) void zipconv_fwd_kernel(ConvArgs a, float* __restrict__ y) {
   constexpr int Kh = (K + 1) / 2, halo = K / 2, W = FPT + 2 * halo;
@@ -148,7 +197,8 @@ __global__ __launch_bounds__(256) void zipconv_fwd_kernel(ConvArgs a, float* __r
   const int c = threadIdx.x & 63, tg = threadIdx.x >> 6;
   stage_weights<K>(a, c0, s_wc, s_wk, s_le, s_re,
                    GEN || t0 - K / 2 < K || t0 + TT + K / 2 > a.T - K);
-  stage_xg<K>(a, b, t0, c0, s_x);
+  if (buf_ok(a)) stage_xg_buf<K>(a, b, t0, c0, s_x);
+  else stage_xg<K>(a, b, t0, c0, s_x);
   __syncthreads();
   if (c0 + c >= a.C) return;
   float win[W];
@@ -226,9 +276,40 @@ __global__ __launch_bounds__(256) void zipconv_bwd_data_kernel(ConvArgs a,
                    GEN || t0 - K / 2 < K || t0 + TT + K / 2 > a.T - K);
   __syncthreads();
   const int chunk = a.chunk;
-  // two tiles: raw dy (causal taps) and dy * edge_scale (chunkwise taps); batched loads from
-  // clamped addresses as in stage_xg
-  {
+  // two tiles: raw dy (causal taps) and dy * edge_scale (chunkwise taps)
+  const bool dy_buf = (long)a.T * a.B * a.C * 4 < (1L << 31);
+  if (dy_buf) {
+    // one batch of 16-byte buffer loads (lane = 4 channels of a row; frames outside [0,T) read 0)
+    constexpr int rows = TT + 2 * halo, NP = (rows + 15) / 16;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(dy), 0, (int)((long)a.T * a.B * a.C * 4), 0x00020000);
+    const int rig = threadIdx.x >> 4, c4 = threadIdx.x & 15, ch = c0 + 4 * c4;
+    u32x4 gq[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int t = t0 - halo + 16 * p + rig;
+      const int off = ((t * a.B + b) * a.C + ch) * 4;
+      gq[p] = __builtin_amdgcn_raw_buffer_load_b128(rs, (t >= 0 && t < a.T) ? off : 0x7FFFFFF0, 0, 0);
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int r = 16 * p + rig, t = t0 - halo + r;
+      if (r < rows) {
+        float v[4] = {__uint_as_float(gq[p].x), __uint_as_float(gq[p].y), __uint_as_float(gq[p].z),
+                      __uint_as_float(gq[p].w)};
+        float vs[4];
+        const bool tin = t >= 0 && t < a.T;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (ch + e >= a.C) v[e] = 0.f;
+          vs[e] = (tin && a.scale && ch + e < a.C)
+                      ? v[e] * edge_scale(s_le, s_re, 4 * c4 + e, t % chunk, chunk, K) : v[e];
+        }
+        *reinterpret_cast<float4*>(&s_g[r * 64 + 4 * c4]) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(&s_gs[r * 64 + 4 * c4]) = make_float4(vs[0], vs[1], vs[2], vs[3]);
+      }
+    }
+  } else {
     constexpr int rows = TT + 2 * halo, NB = 8;
     const bool cok = c0 + c < a.C;
     const int cc = cok ? c0 + c : 0;
@@ -255,6 +336,17 @@ __global__ __launch_bounds__(256) void zipconv_bwd_data_kernel(ConvArgs a,
   __syncthreads();
   if (c0 + c >= a.C) return;
   const int tb = t0 + tg * FPT;
+  // the projection values the gate's backward needs, issued now and consumed after the tap loops
+  float oxv[FPT], osv[FPT];
+  unsigned char opad[FPT];
+#pragma unroll
+  for (int i = 0; i < FPT; ++i) {
+    const int t = min(tb + i, a.T - 1);
+    const float* row = a.u + ((long)t * a.B + b) * a.ld;
+    opad[i] = a.mask ? a.mask[(long)b * a.T + t] : (unsigned char)0;
+    oxv[i] = a.gate_off >= 0 ? row[c0 + c] : 0.f;
+    osv[i] = a.gate_off >= 0 ? row[a.gate_off + c0 + c] : 0.f;
+  }
   float win[W];   // frames tb-halo .. tb+FPT-1+halo
   float acc[FPT];
 #pragma unroll
@@ -299,11 +391,10 @@ __global__ __launch_bounds__(256) void zipconv_bwd_data_kernel(ConvArgs a,
   for (int i = 0; i < FPT; ++i) {
     const int t = tb + i;
     if (t < a.T) {
-      const bool pad = a.mask && a.mask[(long)b * a.T + t];
+      const bool pad = opad[i] != 0;
       float* o = du + ((long)t * a.B + b) * nout;
       if (a.gate_off >= 0) {
-        const float* row = a.u + ((long)t * a.B + b) * a.ld;
-        const float xv = row[c0 + c], sg = sigmoidf_(row[a.gate_off + c0 + c]);
+        const float xv = oxv[i], sg = sigmoidf_(osv[i]);
         o[c0 + c] = pad ? 0.f : acc[i] * sg;
         o[a.C + c0 + c] = pad ? 0.f : acc[i] * xv * sg * (1.f - sg);
       } else {
@@ -370,7 +461,8 @@ __global__ __launch_bounds__(256) void zipconv_bwd_w_kernel(ConvArgs a,
   const int b_end = min(a.B, (int)(blockIdx.y + 1) * BB);
   for (int b = blockIdx.y * BB; b < b_end; ++b) {
     __syncthreads();
-    stage_xg<K>(a, b, t0, c0, s_x);
+    if (buf_ok(a)) stage_xg_buf<K>(a, b, t0, c0, s_x);
+  else stage_xg<K>(a, b, t0, c0, s_x);
     __syncthreads();
     if (!chan_ok) continue;
     float win[W];
