@@ -461,8 +461,13 @@ __global__ __launch_bounds__(256) void zipconv_bwd_w_kernel(ConvArgs a,
   const int b_end = min(a.B, (int)(blockIdx.y + 1) * BB);
   for (int b = blockIdx.y * BB; b < b_end; ++b) {
     __syncthreads();
+    // this thread's 16 gradient values travel with the tile's loads (one round trip, not two)
+    float gpre[FPT];
+#pragma unroll
+    for (int i = 0; i < FPT; ++i)
+      gpre[i] = dy[((long)min(tb + i, a.T - 1) * a.B + b) * a.C + (chan_ok ? c0 + c : 0)];
     if (buf_ok(a)) stage_xg_buf<K>(a, b, t0, c0, s_x);
-  else stage_xg<K>(a, b, t0, c0, s_x);
+    else stage_xg<K>(a, b, t0, c0, s_x);
     __syncthreads();
     if (!chan_ok) continue;
     float win[W];
@@ -483,12 +488,12 @@ __global__ __launch_bounds__(256) void zipconv_bwd_w_kernel(ConvArgs a,
       }
 #pragma unroll
       for (int i = 0; i < FPT; ++i)
-        if (tb + i < a.T) ds[i] = fmaf(dy[((long)(tb + i) * a.B + b) * a.C + c0 + c], ak[i], ds[i]);
+        if (tb + i < a.T) ds[i] = fmaf(gpre[i], ak[i], ds[i]);
     }
 #pragma unroll
     for (int i = 0; i < FPT; ++i) {
       const int t = tb + i;
-      const float g = (t < a.T) ? dy[((long)t * a.B + b) * a.C + c0 + c] : 0.f;
+      const float g = (t < a.T) ? gpre[i] : 0.f;
       const float gs = g * sc[i];
       pbc += g;
       pbk += gs;
@@ -639,13 +644,14 @@ extern "C" int s2t_zipconv_bwd(const float* u, long ld, int gate_off, const unsi
                                             conv_smem<KK>(false, 2), st, a, dy, du));
   }
   S2T_CHECK_LAUNCH();
-  // utterances per block: a few, so the tap staging and the 49-slot reduction epilogue are
-  // amortised, while ~400 workgroups still cover the chip
+  // utterances per block: many -- a workgroup's fixed costs (tap staging, the 49-slot reduction
+  // epilogue) are what this kernel's time is made of: at the C3 shapes 768 / 384 / 192 / 128
+  // workgroups take 92 / 66 / 56 / 62 us (K = 31) and 46 / 46 / 33 / 27 us (K = 15)
   const long tiles = (long)grid.x * grid.z;
   const char* env = getenv("S2T_CONV_BLOCKS");         // tuning / tests: workgroup-count target
-  int BB = (int)((tiles * B) / (env ? std::max(1, atoi(env)) : 384));   // measured: 123 -> 87 us
+  int BB = (int)((tiles * B) / (env ? std::max(1, atoi(env)) : (K >= 31 ? 192 : 128)));
   if (BB < 1) BB = 1;
-  if (BB > 8) BB = 8;
+  if (BB > 16) BB = 16;
   dim3 gridw(grid.x, (B + BB - 1) / BB, grid.z);   // (c tiles, utterance groups, t tiles)
   if (!gen) {
     S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_w_kernel<KK, false>), gridw, dim3(256),
