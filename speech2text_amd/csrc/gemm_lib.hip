@@ -125,6 +125,11 @@ void tune(Plan& p, const float* X, const float* W, const float* C, float beta, l
           void* workspace, size_t ws_bytes, hipStream_t st) {
   p.tuned = true;
   if (p.ncand < 2 || !tuning_enabled()) return;
+  // The candidates must be compared on an otherwise idle chip: the step's side streams (the
+  // grouped weight-gradient GEMM, the Whiten statistics) run 400 us kernels beside the main
+  // stream, and whichever candidate was timed under one of them lost -- at the conformer's
+  // 7936 x 2048 -> 256 product that left a 31-tile kernel in the plan (239 us against 67 us).
+  (void)hipDeviceSynchronize();
   float* scratch = nullptr;
   if (hipMalloc(&scratch, (size_t)d_elems * sizeof(float)) != hipSuccess) return;
   hipEvent_t e0, e1;
