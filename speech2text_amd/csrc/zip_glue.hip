@@ -254,7 +254,8 @@ __global__ __launch_bounds__(256) void downsample_fwd_kernel(const float* __rest
 
 // backward: d_src[t] = sum over the (tt,k) that read frame t of w[k] g[tt]  (the last frame also
 // collects the padded taps); dw[k] += sum g[tt] * src[frame(tt,k)]  (block partials + atomics)
-__global__ __launch_bounds__(256) void downsample_bwd_kernel(const float* __restrict__ src,
+// any row length / alignment (one element per thread and trip)
+__global__ __launch_bounds__(256) void downsample_bwd_any_kernel(const float* __restrict__ src,
                                                              const float* __restrict__ w,
                                                              const float* __restrict__ g, int ds,
                                                              int T, int dT, long rowlen,
@@ -280,6 +281,61 @@ __global__ __launch_bounds__(256) void downsample_bwd_kernel(const float* __rest
       }
     }
     if ((long)tt * ds + ds - 1 >= T - 1) d_src[(long)(T - 1) * rowlen + e] = last;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float v = wave_sum(pw[k]);
+    if ((threadIdx.x & 63) == 0) s_dw[k][threadIdx.x >> 6] = v;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < ds)
+    atomicAdd(dw + threadIdx.x, (s_dw[threadIdx.x][0] + s_dw[threadIdx.x][1]) +
+                                    (s_dw[threadIdx.x][2] + s_dw[threadIdx.x][3]));
+}
+
+__global__ __launch_bounds__(256) void downsample_bwd_kernel(const float* __restrict__ src,
+                                                             const float* __restrict__ w,
+                                                             const float* __restrict__ g, int ds,
+                                                             int T, int dT, long rowlen,
+                                                             float* __restrict__ d_src,
+                                                             float* __restrict__ dw) {
+  // workgroup = (output frame tt, slice of the row): float4 everywhere, no index division, the
+  // ds source rows of a frame are loaded as one batch
+  __shared__ float s_dw[8][4];
+  float pw[8], wk[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    pw[k] = 0.f;
+    wk[k] = k < ds ? w[k] : 0.f;
+  }
+  const long n4 = rowlen >> 2;
+  for (int tt = blockIdx.x; tt < dT; tt += gridDim.x) {
+    const float4* g4 = reinterpret_cast<const float4*>(g + (long)tt * rowlen);
+    for (long e = (long)blockIdx.y * 256 + threadIdx.x; e < n4; e += (long)gridDim.y * 256) {
+      const float4 gv = g4[e];
+      float4 sv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (k < ds) {
+          const long tc = min((long)tt * ds + k, (long)T - 1);
+          sv[k] = reinterpret_cast<const float4*>(src + tc * rowlen)[e];
+        }
+      float4 last = make_float4(0.f, 0.f, 0.f, 0.f);     // contributions landing on frame T-1
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (k < ds) {
+          const long t = (long)tt * ds + k;
+          pw[k] += gv.x * sv[k].x + gv.y * sv[k].y + gv.z * sv[k].z + gv.w * sv[k].w;
+          const float4 o = make_float4(wk[k] * gv.x, wk[k] * gv.y, wk[k] * gv.z, wk[k] * gv.w);
+          if (t < T - 1) {
+            reinterpret_cast<float4*>(d_src + t * rowlen)[e] = o;
+          } else {
+            last.x += o.x; last.y += o.y; last.z += o.z; last.w += o.w;
+          }
+        }
+      if ((long)tt * ds + ds - 1 >= T - 1)
+        reinterpret_cast<float4*>(d_src + (long)(T - 1) * rowlen)[e] = last;
+    }
   }
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
@@ -522,9 +578,20 @@ extern "C" int s2t_downsample_bwd(const float* src, const float* w, const float*
   if (ds < 1 || ds > 8) return -1;
   const int dT = (T + ds - 1) / ds;
   const long rowlen = (long)B * C;
-  long blocks = ((long)dT * rowlen + 1023) / 1024;
-  blocks = blocks > 1024 ? 1024 : (blocks < 1 ? 1 : blocks);
-  hipLaunchKernelGGL(downsample_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0,
+  if ((rowlen & 3) || ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(g) |
+                        reinterpret_cast<uintptr_t>(d_src)) & 15)) {
+    long blocks = ((long)dT * rowlen + 1023) / 1024;
+    blocks = blocks > 1024 ? 1024 : (blocks < 1 ? 1 : blocks);
+    hipLaunchKernelGGL(downsample_bwd_any_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                       (hipStream_t)stream, src, w, g, ds, T, dT, rowlen, d_src, dw);
+    S2T_CHECK_LAUNCH();
+    return 0;
+  }
+  // (frames, row slices): ~1024 workgroups, each finishing with ds atomics on the same words
+  int gy = (int)std::min<long>((rowlen / 4 + 255) / 256, std::max<long>(1, 1024 / dT));
+  if (gy < 1) gy = 1;
+  const int gx = dT < 1024 ? dT : 1024;
+  hipLaunchKernelGGL(downsample_bwd_kernel, dim3(gx, gy), dim3(256), 0,
                      (hipStream_t)stream, src, w, g, ds, T, dT, rowlen, d_src, dw);
   S2T_CHECK_LAUNCH();
   return 0;

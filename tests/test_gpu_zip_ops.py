@@ -324,7 +324,8 @@ def test_dwconv2d_and_conv3x3_nhwc_vs_torch(dev, N_, H, W, C, K):
         torch.testing.assert_close(wg.grad.cpu().double(), wr.grad, atol=2e-3, rtol=2e-4)
 
 
-@pytest.mark.parametrize("T,B,C,ds", [(37, 3, 64, 2), (64, 2, 96, 4), (101, 4, 128, 8), (5, 1, 32, 4)])
+@pytest.mark.parametrize("T,B,C,ds", [(37, 3, 64, 2), (64, 2, 96, 4), (101, 4, 128, 8), (5, 1, 32, 4),
+                                      (9, 3, 33, 2), (495, 2, 256, 2)])
 def test_downsample_and_upsampled_bypass_vs_torch(dev, T, B, C, ds):
     """zip_glue.hip SimpleDownsample and the fused SimpleUpsample + out_combiner bypass against the
     torch compositions of the reference's formulas (zipformer.py:1653-1719, 1523-1555), fp64."""
