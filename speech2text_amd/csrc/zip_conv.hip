@@ -141,7 +141,7 @@ __device__ __forceinline__ void stage_xg(const ConvArgs& a, int b, int t0, int c
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ bool buf_ok(const ConvArgs& a) {
-  return (long)a.T * a.B * a.ld * 4 < (1L << 31);
+  return (long)a.T * a.B * a.ld * 4 < 0x7FFFFF00L;
 }
 
 template <int K>
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void zipconv_bwd_data_kernel(ConvArgs a,
   __syncthreads();
   const int chunk = a.chunk;
   // two tiles: raw dy (causal taps) and dy * edge_scale (chunkwise taps)
-  const bool dy_buf = (long)a.T * a.B * a.C * 4 < (1L << 31);
+  const bool dy_buf = (long)a.T * a.B * a.C * 4 < 0x7FFFFF00L;
   if (dy_buf) {
     // one batch of 16-byte buffer loads (lane = 4 channels of a row; frames outside [0,T) read 0)
     constexpr int rows = TT + 2 * halo, NP = (rows + 15) / 16;
