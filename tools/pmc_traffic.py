@@ -19,7 +19,10 @@ KERNELS = [
     ("attn_fwd_mfma_kernel", "s2t_relpos_attn_fwd", True), ("attn_fwd_kernel", "s2t_relpos_attn_fwd", True),
     ("attn_bwd_q", "s2t_relpos_attn_bwd", True), ("attn_bwd_k", "s2t_relpos_attn_bwd", False),
     ("dpos_reduce", "s2t_relpos_attn_bwd", False),
-    ("attn_apply_kernel", "s2t_attn_apply", True),
+    ("attn_apply_kernel", "s2t_attn_apply", True), ("attn_apply4_kernel", "s2t_attn_apply", True),
+    ("downsample_bwd", "s2t_downsample_bwd", True), ("bypass_up_bwd", "s2t_bypass_up_bwd", True),
+    ("dropout_add_kernel", "s2t_dropout_add", True), ("silu_drop_fwd_kernel", "s2t_silu_fwd", True),
+    ("silu_drop_bwd_kernel", "s2t_silu_bwd", True),
     ("gemm_kernel", "s2t_gemm_f32", True), ("gemm_tn_grouped_kernel", "s2t_gemm_tn_grouped", True),
     ("wgrad_kernel", "s2t_linear_wgrad", True), ("wgrad_reduce_kernel", "s2t_linear_wgrad", False),
     ("zipconv_fwd_kernel", "s2t_zipconv_fwd", True),
