@@ -712,6 +712,20 @@ __device__ __forceinline__ float pair_elem(const AttnArgs& a, const float* const
   return 0.f;
 }
 
+// XCD-aware block order for the kernels that walk one (b, h) slab of W tile by tile: workgroups are
+// dealt to the 8 XCDs round-robin by linear id, so id -> (tile, slab) is chosen such that ALL tiles
+// of a slab run on one XCD (slab % 8 = id % 8).  W rows are T floats apart -- not a multiple of a
+// 128-byte line -- so a tile row straddles two lines and neighbouring tiles share one of them: on
+// one XCD the shared line comes out of its L2, across XCDs each fetches it from HBM (PMC: 3.2x the
+// algorithmic bytes for the backward pair before this mapping).  Returns false for padding ids.
+__device__ __forceinline__ bool slab_tile(int ntile, int nslab, int& tile, int& slab) {
+  const int lin = blockIdx.x, q = lin >> 3;
+  tile = q % ntile;
+  slab = (q / ntile) * 8 + (lin & 7);
+  return slab < nslab;
+}
+static inline unsigned slab_grid(int ntile, int nslab) { return (unsigned)(((nslab + 7) / 8) * 8 * ntile); }
+
 // 32x32 tile of a (T,T) matrix in accumulator layout, indices clamped (validity is in tile_ok)
 __device__ __forceinline__ void load_tile16(const float* __restrict__ base, int T, int i0, int j0,
                                             int lo, int hi, float (&w)[16]) {
@@ -782,7 +796,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_k_mfma_kernel(AttnArgs a,
                                                               float* __restrict__ dqkp) {
   constexpr int NSA = NS > 0 ? NS : 1;
   __shared__ float s_red[4][32][33];   // first the per-wave dO_cat staging, then the dk partials
-  const int j0 = blockIdx.x * 32, b = blockIdx.y, h = blockIdx.z;
+  int tile_, slab_;
+  if (!slab_tile((a.T + 31) / 32, a.B * a.H, tile_, slab_)) return;
+  const int j0 = tile_ * 32, b = slab_ % a.B, h = slab_ / a.B;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
   const float* Wb = W + ((long)h * a.B + b) * a.T * a.T;
   const float* dWb = a.dW ? a.dW + ((long)h * a.B + b) * a.T * a.T : nullptr;
@@ -861,7 +877,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_mfma_kernel(AttnArgs a,
   __shared__ __attribute__((aligned(16))) float s_pos[160][PD];        // pos window
   __shared__ float s_t[4][32][33];                                     // per-wave dS tile [i][j]
   __shared__ __attribute__((aligned(16))) float s_P[4][32][PD];        // per-wave p rows
-  const int ib0 = blockIdx.x * 128, b = blockIdx.y, h = blockIdx.z;
+  int tile_, slab_;
+  if (!slab_tile((a.T + 127) / 128, a.B * a.H, tile_, slab_)) return;
+  const int ib0 = tile_ * 128, b = slab_ % a.B, h = slab_ / a.B;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
   const int i0 = ib0 + wave * 32;
   const bool live = i0 < a.T;
@@ -1030,7 +1048,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict
 template <int NS>
 int launch_attn_bwd_mfma(const AttnArgs& a, const float* W, const float* delta, float* dqkp,
                          float* dpos, float* ws, hipStream_t st) {
-  const dim3 gq((a.T + 127) / 128, a.B, a.H), gk((a.T + 31) / 32, a.B, a.H);
+  const dim3 gq(slab_grid((a.T + 127) / 128, a.B * a.H)), gk(slab_grid((a.T + 31) / 32, a.B * a.H));
   if (a.pd <= 4)
     hipLaunchKernelGGL((attn_bwd_q_mfma_kernel<NS, 4>), gq, dim3(256), 0, st, a, W, delta, dqkp,
                        a.pos ? ws : nullptr);
