@@ -156,7 +156,9 @@ void tune(Plan& p, const float* X, const float* W, const float* C, float beta, l
   (void)time_cand(0);                      // clocks and caches up before anything is compared
   float best = 1e30f;
   int best_i = 0;
-  const int ntry = p.ncand < 8 ? p.ncand : 8;
+  static int max_try = -1;
+  if (max_try < 0) { const char* e = getenv("S2T_LT_CANDIDATES"); max_try = e ? atoi(e) : 8; }
+  const int ntry = p.ncand < max_try ? p.ncand : max_try;
   for (int i = 0; i < ntry; ++i) {
     const float ms = time_cand(i);
     if (ms > 0.f && ms < best) {
