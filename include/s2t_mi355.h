@@ -275,6 +275,12 @@ int s2t_gemm_f32(int mode, const float* A, long lda, const float* B, long ldb, f
                  const float* act_src, long lds, int act_kind, int pro_a, int pro_b, float* colsum,
                  int accumulate, void* stream);
 
+/* Arithmetic of the TN (weight-gradient) products, s2t_gemm_f32 mode 2 / s2t_gemm_tn_grouped /
+ * s2t_gemm_xtx: 1 (default, or S2T_TN_X3=1) = both fp32 operands split exactly into three bf16
+ * pieces, six v_mfma_f32_32x32x16_bf16 products per 16-deep step, fp32 accumulation (fp32-level
+ * error); 0 = v_mfma_f32_32x32x2_f32.  set >= 0 selects, set < 0 queries; returns the mode. */
+int s2t_tn_x3(int set);
+
 /* x^T x for the Whiten statistics (model/layer/scaling.py:949-1012): xtx (C,C, ldc) += x^T x and
  * colsum (C) += column sums of x (R,C, ldx), restricted to what the per-group covariance needs:
  * the 64x64 tiles on or above the diagonal that contain a pair of channels of the same group of

@@ -25,6 +25,22 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// (x0, x1) -> three packed bf16 pairs, exact: x = p0 + p1 + p2 to 24 bits (gemm_x3.hip)
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& p0, unsigned& p1,
+                                           unsigned& p2) {
+  f32x2 x = {x0, x1};
+  p0 = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+  f32x2 h = {__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xFFFF0000u)};
+  x = x - h;
+  p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+  f32x2 h1 = {__uint_as_float(p1 << 16), __uint_as_float(p1 & 0xFFFF0000u)};
+  x = x - h1;
+  p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+}
 
 constexpr int BK0 = 32;   // contraction chunk of the big tiles; the 64x64 tile uses 64
 enum { MODE_NT = 0, MODE_NN = 1, MODE_TN = 2 };
@@ -137,7 +153,11 @@ constexpr int bk_of(int tm, int tn, int mode) {
   return BK0;   // (a 64-deep chunk for the 64x64 TN tile measured the same as 32)
 }
 
-template <int TM, int TN, int MODE, int PRO>
+// X3 (TN only): the contraction runs on the bf16 matrix cores -- both operand fragments are split
+// exactly into three bf16 pieces when a wave reads them from LDS (8 k-strided reads per
+// fragment: the tiles are k-major) and every 16-deep step is six v_mfma_f32_32x32x16_bf16 products
+// (gemm_x3.hip: fp32-level error); 6 x 8 passes instead of 8 x 16 passes of the f32 MFMA.
+template <int TM, int TN, int MODE, int PRO, bool X3 = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, const unsigned bid) {
   constexpr bool A_KC = MODE != MODE_TN, B_KC = MODE == MODE_NT;
   constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -208,6 +228,38 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const unsigned bid)
 #pragma unroll 8
       for (int r = 0; r < BK; ++r) csum += sA[r * TA::LD + threadIdx.x];
     }
+    if (X3 && MODE == MODE_TN) {
+      const int lo3 = lane & 31, hi3 = lane >> 5;
+#pragma unroll
+      for (int s = 0; s < BK / 16; ++s) {
+        bf16x8 pa[TM][3], pb[TN][3];
+        auto gather = [&](const float* __restrict__ t, int ldt, int col, bf16x8 (&out)[3]) {
+          const float* q = t + (16 * s + 8 * hi3) * ldt + col;
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = q[e * ldt];
+          uint4 q0, q1, q2;
+          split_pair(v[0], v[1], q0.x, q1.x, q2.x);
+          split_pair(v[2], v[3], q0.y, q1.y, q2.y);
+          split_pair(v[4], v[5], q0.z, q1.z, q2.z);
+          split_pair(v[6], v[7], q0.w, q1.w, q2.w);
+          out[0] = __builtin_bit_cast(bf16x8, q0);
+          out[1] = __builtin_bit_cast(bf16x8, q1);
+          out[2] = __builtin_bit_cast(bf16x8, q2);
+        };
+#pragma unroll
+        for (int i = 0; i < TM; ++i) gather(sA, TA::LD, wm + 32 * i + lo3, pa[i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) gather(sB, TB::LD, wn + 32 * j + lo3, pb[j]);
+#define S2T_X3_TERM(PA, PB)                                                                     \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i][PA], pb[j][PB], acc[i][j], 0, 0, 0);
+        S2T_X3_TERM(2, 0) S2T_X3_TERM(1, 1) S2T_X3_TERM(0, 2) S2T_X3_TERM(1, 0) S2T_X3_TERM(0, 1)
+        S2T_X3_TERM(0, 0)
+#undef S2T_X3_TERM
+      }
+      continue;
+    }
 #pragma unroll
     for (int s = 0; s < BK / 8; ++s) {
       float4 fa[TM], fb[TN];
@@ -259,9 +311,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const unsigned bid)
     }
 }
 
-template <int TM, int TN, int MODE, int PRO>
+template <int TM, int TN, int MODE, int PRO, bool X3 = false>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-  gemm_body<TM, TN, MODE, PRO>(g, blockIdx.x);
+  gemm_body<TM, TN, MODE, PRO, X3>(g, blockIdx.x);
 }
 
 // ---- grouped TN: the weight-gradient GEMMs of one layer in ONE launch.  Each problem keeps its
@@ -282,13 +334,25 @@ struct TnGroup {
   TnProb p[MAXG];
 };
 
+template <bool X3>
 __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(TnGroup grp) {
   int i = 0;
   while (i + 1 < grp.n && blockIdx.x >= grp.begin[i + 1]) ++i;
   const TnProb& q = grp.p[i];
   GemmArgs g{q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, nullptr, nullptr, 0, nullptr, 0,
              0, 0, 0, q.colsum, 0, q.kper, q.tiles_m, q.tiles_n, q.splits, 0, q.alpha};
-  gemm_body<1, 1, MODE_TN, ACT_NONE>(g, blockIdx.x - grp.begin[i]);
+  gemm_body<1, 1, MODE_TN, ACT_NONE, X3>(g, blockIdx.x - grp.begin[i]);
+}
+
+// Weight-gradient contractions on the bf16 matrix cores (three-way exact split, six products:
+// fp32-level error, tests/test_gpu_gemm.py) -- on by default: in the training step the TN GEMMs
+// share the CUs with the main stream's library GEMMs, and 2.3x fewer matrix-pipe cycles for the
+// same product took the C3 step from 47.8 to 46.6 ms (same box, 3 x 3 runs).  S2T_TN_X3=0: the
+// f32 MFMA form.
+static int g_tn_x3 = -1;
+static bool tn_x3() {
+  if (g_tn_x3 < 0) { const char* e = getenv("S2T_TN_X3"); g_tn_x3 = e ? atoi(e) : 1; }
+  return g_tn_x3 == 1;
 }
 
 template <int TM, int TN, int MODE, int PRO>
@@ -300,7 +364,10 @@ int launch(GemmArgs& g, int splits, hipStream_t st) {
   const int total = g.tiles_m * g.tiles_n;
   g.splits = splits;
   const int grid = MODE == MODE_TN ? 8 * total * ((splits + 7) / 8) : ((total + 7) / 8) * 8;
-  hipLaunchKernelGGL((gemm_kernel<TM, TN, MODE, PRO>), dim3(grid), dim3(256), 0, st, g);
+  if (MODE == MODE_TN && PRO == ACT_NONE && tn_x3())
+    hipLaunchKernelGGL((gemm_kernel<TM, TN, MODE, PRO, true>), dim3(grid), dim3(256), 0, st, g);
+  else
+    hipLaunchKernelGGL((gemm_kernel<TM, TN, MODE, PRO>), dim3(grid), dim3(256), 0, st, g);
   return (int)hipGetLastError();
 }
 
@@ -393,6 +460,11 @@ extern "C" int s2t_gemm_f32(int mode, const float* A, long lda, const float* B, 
   return rc;
 }
 
+extern "C" int s2t_tn_x3(int set) {
+  if (set >= 0) g_tn_x3 = set ? 1 : 0;
+  return tn_x3() ? 1 : 0;
+}
+
 extern "C" int s2t_gemm_xtx(const float* x, long ldx, int R, int C, int cg, float* xtx, long ldc,
                             float* colsum, void* stream) {
   if (R <= 0 || C <= 0 || cg <= 0 || C % cg) return -1;
@@ -449,7 +521,10 @@ extern "C" int s2t_gemm_tn_grouped(int n, const S2tTnProblem* probs, void* strea
       blocks += (unsigned)(8 * tiles * ((q.splits + 7) / 8));
     }
     grp.begin[grp.n] = blocks;
-    hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(blocks), dim3(256), 0, st, grp);
+    if (tn_x3())
+      hipLaunchKernelGGL(gemm_tn_grouped_kernel<true>, dim3(blocks), dim3(256), 0, st, grp);
+    else
+      hipLaunchKernelGGL(gemm_tn_grouped_kernel<false>, dim3(blocks), dim3(256), 0, st, grp);
     if (hipGetLastError() != hipSuccess) return -3;
   }
   return 0;

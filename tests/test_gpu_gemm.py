@@ -290,3 +290,33 @@ def test_bf16x3_pipelined_gemm_has_fp32_accuracy(dev, M, K, N):
         assert e <= max(1.5 * e_lib, 2e-7), (tnw, e, e_lib)
     assert L.s2t_gemm_x3f_nt(Nt.fp(x), K, Nt.raw(pf), Nt.fp(y), N, M, N, 24, None, None, 0, 0.0, 0,
                              Nt.stream()) == -2               # K % 16 != 0: caller uses the library
+
+
+@pytest.mark.parametrize("R,Nf,Mf", [(31680, 384, 192), (5000, 768, 256), (1234, 68, 500), (257, 8, 12)])
+def test_tn_on_bf16_matrix_cores_has_fp32_accuracy(dev, R, Nf, Mf):
+    """The weight-gradient contraction dW = g^T x (+ column sums) in its two arithmetic forms
+    (s2t_tn_x3): three-way exact bf16 split with six MFMA products, and the f32 MFMA.  Operands with
+    6 decades of dynamic range; the split form's error against fp64 stays within 2x of the f32
+    form's (and far below bf16's 4e-3)."""
+    from speech2text_amd import _native as Nt
+    L = Nt.lib()
+    gen = torch.Generator().manual_seed(R)
+    g = (torch.randn(R, Nf, generator=gen) * torch.logspace(-3, 3, Nf)).to(dev)
+    x = (torch.randn(R, Mf, generator=gen) * torch.logspace(-2, 2, Mf)).to(dev)
+    ref = g.double().t() @ x.double()
+    refc = g.double().sum(0)
+    scale = ref.abs().max().item()
+    was = L.s2t_tn_x3(-1)
+    err = {}
+    try:
+        for mode in (1, 0):
+            assert L.s2t_tn_x3(mode) == mode
+            dW = torch.zeros(Nf, Mf, device=dev)
+            db = torch.zeros(Nf, device=dev)
+            zk.gemm_tn(g, x, dW, db)
+            err[mode] = (dW.double() - ref).abs().max().item() / scale
+            assert (db.double() - refc).abs().max().item() <= 1e-5 * refc.abs().max().item()
+    finally:
+        L.s2t_tn_x3(was)
+    assert err[1] <= max(2.0 * err[0], 3e-7), err
+    assert err[1] < 1e-5
