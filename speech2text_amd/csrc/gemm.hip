@@ -228,16 +228,25 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const unsigned bid)
 #pragma unroll 8
       for (int r = 0; r < BK; ++r) csum += sA[r * TA::LD + threadIdx.x];
     }
-    if (X3 && MODE == MODE_TN) {
+    if (X3) {
       const int lo3 = lane & 31, hi3 = lane >> 5;
 #pragma unroll
       for (int s = 0; s < BK / 16; ++s) {
         bf16x8 pa[TM][3], pb[TN][3];
-        auto gather = [&](const float* __restrict__ t, int ldt, int col, bf16x8 (&out)[3]) {
-          const float* q = t + (16 * s + 8 * hi3) * ldt + col;
+        // the lane's 8 contraction values k = 16 s + 8 hi .. + 7 of output index `col`:
+        // kc tiles ([out][k], k contiguous): two 16-byte reads; k-major tiles: 8 strided reads
+        auto gather = [&](const float* __restrict__ t, int ldt, int col, bool kc, bf16x8 (&out)[3]) {
           float v[8];
+          if (kc) {
+            const float4 u0 = *reinterpret_cast<const float4*>(t + col * ldt + 16 * s + 8 * hi3);
+            const float4 u1 = *reinterpret_cast<const float4*>(t + col * ldt + 16 * s + 8 * hi3 + 4);
+            v[0] = u0.x; v[1] = u0.y; v[2] = u0.z; v[3] = u0.w;
+            v[4] = u1.x; v[5] = u1.y; v[6] = u1.z; v[7] = u1.w;
+          } else {
+            const float* q = t + (16 * s + 8 * hi3) * ldt + col;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = q[e * ldt];
+            for (int e = 0; e < 8; ++e) v[e] = q[e * ldt];
+          }
           uint4 q0, q1, q2;
           split_pair(v[0], v[1], q0.x, q1.x, q2.x);
           split_pair(v[2], v[3], q0.y, q1.y, q2.y);
@@ -248,9 +257,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const unsigned bid)
           out[2] = __builtin_bit_cast(bf16x8, q2);
         };
 #pragma unroll
-        for (int i = 0; i < TM; ++i) gather(sA, TA::LD, wm + 32 * i + lo3, pa[i]);
+        for (int i = 0; i < TM; ++i) gather(sA, TA::LD, wm + 32 * i + lo3, A_KC, pa[i]);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) gather(sB, TB::LD, wn + 32 * j + lo3, pb[j]);
+        for (int j = 0; j < TN; ++j) gather(sB, TB::LD, wn + 32 * j + lo3, B_KC, pb[j]);
 #define S2T_X3_TERM(PA, PB)                                                                     \
   _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i][PA], pb[j][PB], acc[i][j], 0, 0, 0);
@@ -349,6 +358,12 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(TnGroup grp) {
 // share the CUs with the main stream's library GEMMs, and 2.3x fewer matrix-pipe cycles for the
 // same product took the C3 step from 47.8 to 46.6 ms (same box, 3 x 3 runs).  S2T_TN_X3=0: the
 // f32 MFMA form.
+// the same arithmetic for the NT / NN products of s2t_gemm_f32 (S2T_NN_X3=1; experiments)
+static bool nn_x3() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("S2T_NN_X3"); v = e ? atoi(e) : 0; }
+  return v == 1;
+}
 static int g_tn_x3 = -1;
 static bool tn_x3() {
   if (g_tn_x3 < 0) { const char* e = getenv("S2T_TN_X3"); g_tn_x3 = e ? atoi(e) : 1; }
@@ -364,7 +379,7 @@ int launch(GemmArgs& g, int splits, hipStream_t st) {
   const int total = g.tiles_m * g.tiles_n;
   g.splits = splits;
   const int grid = MODE == MODE_TN ? 8 * total * ((splits + 7) / 8) : ((total + 7) / 8) * 8;
-  if (MODE == MODE_TN && PRO == ACT_NONE && tn_x3())
+  if (MODE == MODE_TN ? tn_x3() : nn_x3())
     hipLaunchKernelGGL((gemm_kernel<TM, TN, MODE, PRO, true>), dim3(grid), dim3(256), 0, st, g);
   else
     hipLaunchKernelGGL((gemm_kernel<TM, TN, MODE, PRO>), dim3(grid), dim3(256), 0, st, g);
