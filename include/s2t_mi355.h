@@ -280,6 +280,8 @@ int s2t_gemm_f32(int mode, const float* A, long lda, const float* B, long ldb, f
  * pieces, six v_mfma_f32_32x32x16_bf16 products per 16-deep step, fp32 accumulation (fp32-level
  * error); 0 = v_mfma_f32_32x32x2_f32.  set >= 0 selects, set < 0 queries; returns the mode. */
 int s2t_tn_x3(int set);
+/* the same switch for the NT / NN products of s2t_gemm_f32 (default 1) */
+int s2t_nn_x3(int set);
 
 /* x^T x for the Whiten statistics (model/layer/scaling.py:949-1012): xtx (C,C, ldc) += x^T x and
  * colsum (C) += column sums of x (R,C, ldx), restricted to what the per-group covariance needs:
@@ -367,6 +369,10 @@ int s2t_linear_lt(int mode, const float* X, long ldx, const float* W, long ldw, 
 /* plans made (one per exact shape, table capped) and buckets {mode, half-octave of M, N, K,
  * bias} whose candidates were timed (capped by S2T_LT_TUNE_MAX, default 192) so far. */
 int s2t_linear_lt_stats(int* plans, int* timed);
+/* s2t_linear_lt times OUR NT / NN kernel (s2t_gemm_f32, bf16x3 form, bias + residual epilogue) as one
+ * more candidate of a bucket and keeps it where it beats the library's best by > 8 % twice
+ * (S2T_LT_OWN=0 disables); launches it has served so far: */
+long s2t_linear_lt_own_calls(void);
 
 /* ---- fused glue of the zipformer layer (csrc/zip_glue.hip), rows of C channels, time-major.
  * bypass (model/encoder/zipformer.py:1523-1555): out = orig + (src - orig) * scale[c]; backward

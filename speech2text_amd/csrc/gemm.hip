@@ -358,11 +358,15 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(TnGroup grp) {
 // share the CUs with the main stream's library GEMMs, and 2.3x fewer matrix-pipe cycles for the
 // same product took the C3 step from 47.8 to 46.6 ms (same box, 3 x 3 runs).  S2T_TN_X3=0: the
 // f32 MFMA form.
-// the same arithmetic for the NT / NN products of s2t_gemm_f32 (S2T_NN_X3=1; experiments)
+// the same arithmetic for the NT / NN products of s2t_gemm_f32 (default on; S2T_NN_X3=0: f32 MFMA)
+static int g_nn_x3 = -1;
 static bool nn_x3() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("S2T_NN_X3"); v = e ? atoi(e) : 0; }
-  return v == 1;
+  if (g_nn_x3 < 0) { const char* e = getenv("S2T_NN_X3"); g_nn_x3 = e ? atoi(e) : 1; }
+  return g_nn_x3 == 1;
+}
+extern "C" int s2t_nn_x3(int set) {
+  if (set >= 0) g_nn_x3 = set ? 1 : 0;
+  return nn_x3() ? 1 : 0;
 }
 static int g_tn_x3 = -1;
 static bool tn_x3() {

@@ -23,9 +23,34 @@
 #include <mutex>
 #include <tuple>
 
+extern "C" int s2t_gemm_f32(int mode, const float* A, long lda, const float* B, long ldb, float* C,
+                            long ldc, int M, int N, int K, const float* bias, const float* resid,
+                            long ldr, const float* act_src, long lds, int act_kind, int pro_a,
+                            int pro_b, float* colsum, int accumulate, void* stream);
+extern "C" int s2t_nn_x3(int set);
+
 namespace {
 
 constexpr int MAX_CAND = 16;
+
+// Our own NT / NN MFMA kernel (gemm.hip, bf16x3 form) as one more candidate of the plan: same
+// product, bias and residual in its epilogue.  Usable when the residual weight is 0 or 1.
+bool own_enabled() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("S2T_LT_OWN"); v = e ? atoi(e) : 1; }
+  return v == 1;
+}
+int run_own(int mode, const float* X, long ldx, const float* W, long ldw, const float* bias,
+            const float* C, long ldc, float beta, float* D, long ldd, int M, int N, int K,
+            hipStream_t st) {
+  const float* resid = (beta == 1.f && C && C != D) ? C : nullptr;
+  if (beta != 0.f && !resid) return -2;
+  if (mode == 0)
+    return s2t_gemm_f32(0, X, ldx, W, ldw, D, ldd, M, N, K, bias, resid, ldc, nullptr, 0, 0, 0, 0,
+                        nullptr, 0, st);
+  return s2t_gemm_f32(1, X, ldx, W, ldw, D, ldd, M, K, N, nullptr, resid, ldc, nullptr, 0, 0, 0, 0,
+                      nullptr, 0, st);
+}
 
 struct Plan {
   hipblasLtMatmulDesc_t desc = nullptr;
@@ -37,13 +62,19 @@ struct Plan {
   hipblasLtMatmulHeuristicResult_t cand[MAX_CAND];
   int ncand = 0;
   bool tuned = false;
+  bool own = false;      // the timed choice is OUR MFMA kernel (s2t_gemm_f32, bf16x3 form), not a library one
 };
 
 using Key = std::tuple<int, int, int, int, long, long, long, long, int>;
 std::map<Key, Plan> g_plans;
 using BKey = std::tuple<int, int, int, int, int>;          // mode, half-octave of M, N, K, bias
-std::map<BKey, hipblasLtMatmulAlgo_t> g_winner;            // the timed choice of a bucket
+struct Winner {
+  hipblasLtMatmulAlgo_t algo;
+  bool own;
+};
+std::map<BKey, Winner> g_winner;                           // the timed choice of a bucket
 int g_tunings = 0;
+long g_own_calls = 0;
 constexpr size_t MAX_PLANS = 8192;
 
 int tune_budget() {
@@ -122,7 +153,8 @@ bool tuning_enabled() {
 // first choice is tuned for large square problems; on the tall, short-K shapes of this model
 // another of its kernels is often 10-30 % faster.  Runs once per distinct shape (during warm-up).
 void tune(Plan& p, const float* X, const float* W, const float* C, float beta, long d_elems,
-          void* workspace, size_t ws_bytes, hipStream_t st) {
+          void* workspace, size_t ws_bytes, hipStream_t st, int mode, long ldx, long ldw,
+          const float* bias, long ldc, long ldd, int M, int N, int K) {
   p.tuned = true;
   if (p.ncand < 2 || !tuning_enabled()) return;
   // The candidates must be compared on an otherwise idle chip: the step's side streams (the
@@ -176,11 +208,33 @@ void tune(Plan& p, const float* X, const float* W, const float* C, float beta, l
       if (!(t0 > 0.f && tb > 0.f && tb < 0.92f * t0)) best_i = 0;
     }
   }
+  p.algo = p.cand[best_i].algo;
+  p.ws = p.cand[best_i].workspaceSize;
+  // our kernel against the library's best: same operands, same epilogue, output into the scratch
+  if (own_enabled() && (beta == 0.f || beta == 1.f)) {
+    auto time_own = [&]() -> float {
+      for (int rep = 0; rep < 5; ++rep) {
+        if (rep == 1) (void)hipEventRecord(e0, st);
+        if (run_own(mode, X, ldx, W, ldw, bias, beta == 1.f ? C : nullptr, ldc, beta, scratch, ldd, M,
+                    N, K, st) != 0)
+          return -1.f;
+      }
+      float ms = 0.f;
+      (void)hipEventRecord(e1, st);
+      (void)hipEventSynchronize(e1);
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      return ms;
+    };
+    bool win = true;
+    for (int round = 0; round < 2 && win; ++round) {
+      const float tl = time_cand(best_i), to = time_own();
+      win = to > 0.f && tl > 0.f && to < 0.92f * tl;
+    }
+    p.own = win;
+  }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   (void)hipFree(scratch);
-  p.algo = p.cand[best_i].algo;
-  p.ws = p.cand[best_i].workspaceSize;
 }
 
 }  // namespace
@@ -230,24 +284,33 @@ extern "C" int s2t_linear_lt(int mode, const float* X, long ldx, const float* W,
     if (w != g_winner.end()) {
       // the bucket was timed on another M: take its kernel if the heuristic offers it here too
       p.tuned = true;
+      p.own = w->second.own;
       for (int i = 0; i < p.ncand; ++i)
         if (p.cand[i].workspaceSize <= (size_t)ws_bytes &&
-            memcmp(&p.cand[i].algo, &w->second, sizeof(hipblasLtMatmulAlgo_t)) == 0) {
+            memcmp(&p.cand[i].algo, &w->second.algo, sizeof(hipblasLtMatmulAlgo_t)) == 0) {
           p.algo = p.cand[i].algo;
           p.ws = p.cand[i].workspaceSize;
           break;
         }
     } else if (g_tunings < tune_budget()) {
       tune(p, X, W, C == D ? nullptr : C, C == D ? 0.f : beta, (long)M * ldd, workspace,
-           (size_t)ws_bytes, (hipStream_t)stream);
-      g_winner.emplace(bkey, p.algo);
+           (size_t)ws_bytes, (hipStream_t)stream, mode, ldx, ldw, bias, ldc, ldd, M, N, K);
+      g_winner.emplace(bkey, Winner{p.algo, p.own});
       ++g_tunings;
     } else {
       p.tuned = true;                      // budget spent: the heuristic's first choice
     }
+  }
+  if (p.own && (beta == 0.f || (beta == 1.f && C != D)) &&
+      run_own(mode, X, ldx, W, ldw, bias, C, ldc, beta, D, ldd, M, N, K, (hipStream_t)stream) == 0) {
+    ++g_own_calls;
+    return 0;
   }
   const float alpha = 1.f;
   LT_CHECK(hipblasLtMatmul(g_handle, p.desc, &alpha, W, p.a, X, p.b, &beta, C, p.c, D, p.d, &p.algo,
                            workspace, p.ws, (hipStream_t)stream));
   return 0;
 }
+
+// launches served by our own kernel so far (diagnostics / tests)
+extern "C" long s2t_linear_lt_own_calls(void) { return g_own_calls; }
