@@ -146,7 +146,8 @@ def test_rccl_world1_reducer_is_a_noop(dev, algo):
     assert i0[0] is False and i1[0] is True
     assert i1[1] >= 3 and i1[2] == 0 and i1[3] > 10, i1    # buckets, no dropped step, hooks fired
     a, b = np.frombuffer(f0, np.float32), np.frombuffer(f1, np.float32)
-    # (not bitwise: the weight-gradient atomics sum in a run-dependent order)
-    np.testing.assert_allclose(b, a, rtol=2e-4, atol=2e-6)
+    # (not bitwise: the weight-gradient atomics sum in a run-dependent order, and the two
+    # processes time their GEMM plans independently -- library kernel or ours per bucket)
+    np.testing.assert_allclose(b, a, rtol=5e-4, atol=2e-5)
     np.testing.assert_allclose(l1, l0, rtol=1e-4)
     assert i0[4].keys() == i1[4].keys()
