@@ -343,14 +343,14 @@ struct TnGroup {
   TnProb p[MAXG];
 };
 
-template <bool X3>
+template <bool X3, int TNW = 1>
 __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(TnGroup grp) {
   int i = 0;
   while (i + 1 < grp.n && blockIdx.x >= grp.begin[i + 1]) ++i;
   const TnProb& q = grp.p[i];
   GemmArgs g{q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, nullptr, nullptr, 0, nullptr, 0,
              0, 0, 0, q.colsum, 0, q.kper, q.tiles_m, q.tiles_n, q.splits, 0, q.alpha};
-  gemm_body<1, 1, MODE_TN, ACT_NONE, X3>(g, blockIdx.x - grp.begin[i]);
+  gemm_body<1, TNW, MODE_TN, ACT_NONE, X3>(g, blockIdx.x - grp.begin[i]);
 }
 
 // Weight-gradient contractions on the bf16 matrix cores (three-way exact split, six products:
@@ -509,6 +509,8 @@ extern "C" int s2t_gemm_tn_grouped(int n, const S2tTnProblem* probs, void* strea
     target = e ? atol(e) : 6144;
     if (target < 8) target = 8;
   }
+  static int tnw = -1;      // output tile 64 x (64 tnw): S2T_TN_GROUP_TILE = 11 | 12
+  if (tnw < 0) { const char* e = getenv("S2T_TN_GROUP_TILE"); tnw = (e && atoi(e) == 12) ? 2 : 1; }
   for (int base = 0; base < n; base += MAXG) {
     TnGroup grp;
     grp.n = std::min(MAXG, n - base);
@@ -519,7 +521,7 @@ extern "C" int s2t_gemm_tn_grouped(int n, const S2tTnProblem* probs, void* strea
           (reinterpret_cast<uintptr_t>(s.A) & 15) || (reinterpret_cast<uintptr_t>(s.B) & 15) ||
           s.lda > INT32_MAX || s.ldb > INT32_MAX || s.ldc > INT32_MAX)
         return -2;
-      total_tiles += (long)((s.M + 63) / 64) * ((s.N + 63) / 64);
+      total_tiles += (long)((s.M + 63) / 64) * ((s.N + 64 * tnw - 1) / (64 * tnw));
     }
     int want = (int)((target + total_tiles - 1) / total_tiles);
     want = std::max(8, ((want + 4) / 8) * 8);
@@ -528,7 +530,7 @@ extern "C" int s2t_gemm_tn_grouped(int n, const S2tTnProblem* probs, void* strea
       const S2tTnProblem& s = probs[base + i];
       TnProb& q = grp.p[i];
       q = TnProb{s.A, s.B, s.C, s.colsum, (int)s.lda, (int)s.ldb, (int)s.ldc, s.M, s.N, s.K,
-                 0, (s.M + 63) / 64, (s.N + 63) / 64, 0, s.alpha};
+                 0, (s.M + 63) / 64, (s.N + 64 * tnw - 1) / (64 * tnw), 0, s.alpha};
       const long tiles = (long)q.tiles_m * q.tiles_n;
       const int maxs = (s.K + 2 * KR - 1) / (2 * KR);
       int splits = std::max(1, std::min(want, maxs));
@@ -540,10 +542,12 @@ extern "C" int s2t_gemm_tn_grouped(int n, const S2tTnProblem* probs, void* strea
       blocks += (unsigned)(8 * tiles * ((q.splits + 7) / 8));
     }
     grp.begin[grp.n] = blocks;
-    if (tn_x3())
-      hipLaunchKernelGGL(gemm_tn_grouped_kernel<true>, dim3(blocks), dim3(256), 0, st, grp);
+    if (tn_x3() && tnw == 2)
+      hipLaunchKernelGGL((gemm_tn_grouped_kernel<true, 2>), dim3(blocks), dim3(256), 0, st, grp);
+    else if (tn_x3())
+      hipLaunchKernelGGL((gemm_tn_grouped_kernel<true, 1>), dim3(blocks), dim3(256), 0, st, grp);
     else
-      hipLaunchKernelGGL(gemm_tn_grouped_kernel<false>, dim3(blocks), dim3(256), 0, st, grp);
+      hipLaunchKernelGGL((gemm_tn_grouped_kernel<false, 1>), dim3(blocks), dim3(256), 0, st, grp);
     if (hipGetLastError() != hipSuccess) return -3;
   }
   return 0;
