@@ -4,6 +4,7 @@
 // latency-bound kernels of the main chain leave idle.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -29,7 +30,17 @@ hipEvent_t next_event() {
 // The library-owned side stream of the current device (created on first use).
 extern "C" void* s2t_side_stream(void) {
   std::lock_guard<std::mutex> lock(g_mu);
-  if (!g_side && hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  if (!g_side) {
+    // lowest priority: the side stream's work only feeds the optimizer, the main stream is the
+    // step's critical path (S2T_SIDE_PRIORITY=0: default priority)
+    int lo = 0, hi = 0;
+    const char* e = getenv("S2T_SIDE_PRIORITY");
+    const bool low = !(e && e[0] == '0');
+    if (low && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi) {
+      if (hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, lo) != hipSuccess) g_side = nullptr;
+    }
+    if (!g_side && hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  }
   return (void*)g_side;
 }
 
