@@ -40,6 +40,11 @@ bool own_enabled() {
   if (v < 0) { const char* e = getenv("S2T_LT_OWN"); v = e ? atoi(e) : 1; }
   return v == 1;
 }
+float own_margin() {
+  static float v = -1.f;
+  if (v < 0.f) { const char* e = getenv("S2T_LT_OWN_MARGIN"); v = e ? (float)atof(e) : 0.92f; }
+  return v;
+}
 int run_own(int mode, const float* X, long ldx, const float* W, long ldw, const float* bias,
             const float* C, long ldc, float beta, float* D, long ldd, int M, int N, int K,
             hipStream_t st) {
@@ -228,7 +233,7 @@ void tune(Plan& p, const float* X, const float* W, const float* C, float beta, l
     bool win = true;
     for (int round = 0; round < 2 && win; ++round) {
       const float tl = time_cand(best_i), to = time_own();
-      win = to > 0.f && tl > 0.f && to < 0.92f * tl;
+      win = to > 0.f && tl > 0.f && to < own_margin() * tl;
     }
     p.own = win;
   }
