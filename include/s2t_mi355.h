@@ -275,6 +275,12 @@ int s2t_gemm_f32(int mode, const float* A, long lda, const float* B, long ldb, f
                  const float* act_src, long lds, int act_kind, int pro_a, int pro_b, float* colsum,
                  int accumulate, void* stream);
 
+/* s2t_gemm_f32 modes 0 (NT) / 1 (NN) with the block tile chosen by the caller: tile = "tm tn"
+ * digits for a (64 tm) x (64 tn) tile, one of 11 12 21 22 23; 0 = the dispatcher's choice. */
+int s2t_gemm_f32_tiled(int mode, const float* A, long lda, const float* B, long ldb, float* C,
+                       long ldc, int M, int N, int K, const float* bias, const float* resid,
+                       long ldr, int tile, void* stream);
+
 /* Arithmetic of the TN (weight-gradient) products, s2t_gemm_f32 mode 2 / s2t_gemm_tn_grouped /
  * s2t_gemm_xtx: 1 (default, or S2T_TN_X3=1) = both fp32 operands split exactly into three bf16
  * pieces, six v_mfma_f32_32x32x16_bf16 products per 16-deep step, fp32 accumulation (fp32-level

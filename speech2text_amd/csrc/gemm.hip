@@ -70,6 +70,7 @@ struct GemmArgs {
   float alpha;            // TN: scale of the accumulated product / column sums
   int sym_cg;             // TN with A == B (x^T x): > 0 = only the 64x64 tiles on / above the
                           // diagonal that hold same-group pairs (groups of sym_cg channels)
+  int tile_force;         // NT / NN: 0 = dispatch's choice, else "tm tn" digits (11 12 21 22 23)
 };
 
 __device__ __forceinline__ float log1p_fast(float e) {   // as zip_elem.hip
@@ -445,6 +446,10 @@ int dispatch(GemmArgs& g, hipStream_t st) {
     splits = (g.K + kper - 1) / kper;
     return launch_t<MODE>(g, ttm, ttn, pro, splits, st);
   }
+  static int nt_force = -1;     // S2T_NT_TILE = "tm tn" digits (11, 12, 21, 22, 23): tuning
+  if (nt_force < 0) { const char* e = getenv("S2T_NT_TILE"); nt_force = e ? atoi(e) : 0; }
+  if (g.tile_force > 0) return launch_t<MODE>(g, g.tile_force / 10, g.tile_force % 10, pro, 1, st);
+  if (nt_force > 0) return launch_t<MODE>(g, nt_force / 10, nt_force % 10, pro, 1, st);
   if (tiles_big >= 384) return launch_t<MODE>(g, 2, tn_sel, pro, 1, st);
   if (tn_sel == 3) tn_sel = 2;
   return launch_t<MODE>(g, 1, tn_sel, pro, 1, st);
@@ -477,6 +482,24 @@ extern "C" int s2t_gemm_f32(int mode, const float* A, long lda, const float* B, 
   else if (mode == MODE_TN) rc = dispatch<MODE_TN>(g, st);
   else return -1;
   return rc;
+}
+
+// s2t_gemm_f32 (modes 0 / 1) with the block tile chosen by the caller: tile = "tm tn" digits, block
+// tile (64 tm) x (64 tn), one of 11 12 21 22 23; 0 = the dispatcher's choice.  The plan cache of
+// s2t_linear_lt times these against the library's kernels.
+extern "C" int s2t_gemm_f32_tiled(int mode, const float* A, long lda, const float* B, long ldb,
+                                  float* C, long ldc, int M, int N, int K, const float* bias,
+                                  const float* resid, long ldr, int tile, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || (mode != MODE_NT && mode != MODE_NN)) return -1;
+  if (tile != 0 && tile != 11 && tile != 12 && tile != 21 && tile != 22 && tile != 23) return -1;
+  const bool b_kc = mode == MODE_NT;
+  if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15) || (lda & 3) ||
+      (ldb & 3) || (K & 3) || (!b_kc && (N & 3)) || M < 4 || N < 4 || K < 4)
+    return -2;
+  GemmArgs g{A, lda, B, ldb, C, ldc, M, N, K, bias, resid, ldr, nullptr, 0, 0, 0,
+             0, nullptr, 0, 0, 0, 0, 0, 0, 1.f, 0, tile};
+  hipStream_t st = (hipStream_t)stream;
+  return mode == MODE_NT ? dispatch<MODE_NT>(g, st) : dispatch<MODE_NN>(g, st);
 }
 
 extern "C" int s2t_tn_x3(int set) {

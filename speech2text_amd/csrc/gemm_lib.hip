@@ -28,6 +28,9 @@ extern "C" int s2t_gemm_f32(int mode, const float* A, long lda, const float* B, 
                             long ldr, const float* act_src, long lds, int act_kind, int pro_a,
                             int pro_b, float* colsum, int accumulate, void* stream);
 extern "C" int s2t_nn_x3(int set);
+extern "C" int s2t_gemm_f32_tiled(int mode, const float* A, long lda, const float* B, long ldb,
+                                  float* C, long ldc, int M, int N, int K, const float* bias,
+                                  const float* resid, long ldr, int tile, void* stream);
 
 namespace {
 
@@ -46,15 +49,13 @@ float own_margin() {
   return v;
 }
 int run_own(int mode, const float* X, long ldx, const float* W, long ldw, const float* bias,
-            const float* C, long ldc, float beta, float* D, long ldd, int M, int N, int K,
+            const float* C, long ldc, float beta, float* D, long ldd, int M, int N, int K, int tile,
             hipStream_t st) {
   const float* resid = (beta == 1.f && C && C != D) ? C : nullptr;
   if (beta != 0.f && !resid) return -2;
   if (mode == 0)
-    return s2t_gemm_f32(0, X, ldx, W, ldw, D, ldd, M, N, K, bias, resid, ldc, nullptr, 0, 0, 0, 0,
-                        nullptr, 0, st);
-  return s2t_gemm_f32(1, X, ldx, W, ldw, D, ldd, M, K, N, nullptr, resid, ldc, nullptr, 0, 0, 0, 0,
-                      nullptr, 0, st);
+    return s2t_gemm_f32_tiled(0, X, ldx, W, ldw, D, ldd, M, N, K, bias, resid, ldc, tile, st);
+  return s2t_gemm_f32_tiled(1, X, ldx, W, ldw, D, ldd, M, K, N, nullptr, resid, ldc, tile, st);
 }
 
 struct Plan {
@@ -68,6 +69,7 @@ struct Plan {
   int ncand = 0;
   bool tuned = false;
   bool own = false;      // the timed choice is OUR MFMA kernel (s2t_gemm_f32, bf16x3 form), not a library one
+  int own_tile = 0;      // ... with this block tile
 };
 
 using Key = std::tuple<int, int, int, int, long, long, long, long, int>;
@@ -76,6 +78,7 @@ using BKey = std::tuple<int, int, int, int, int>;          // mode, half-octave 
 struct Winner {
   hipblasLtMatmulAlgo_t algo;
   bool own;
+  int own_tile;
 };
 std::map<BKey, Winner> g_winner;                           // the timed choice of a bucket
 int g_tunings = 0;
@@ -223,11 +226,11 @@ void tune(Plan& p, const float* X, const float* W, const float* C, float beta, l
   p.ws = p.cand[best_i].workspaceSize;
   // our kernel against the library's best: same operands, same epilogue, output into the scratch
   if (own_enabled() && (beta == 0.f || beta == 1.f)) {
-    auto time_own = [&]() -> float {
+    auto time_own = [&](int tile) -> float {
       for (int rep = 0; rep < 5; ++rep) {
         if (rep == 1) (void)hipEventRecord(e0, st);
         if (run_own(mode, X, ldx, W, ldw, bias, beta == 1.f ? C : nullptr, ldc, beta, scratch, ldd, M,
-                    N, K, st) != 0)
+                    N, K, tile, st) != 0)
           return -1.f;
       }
       float ms = 0.f;
@@ -236,12 +239,25 @@ void tune(Plan& p, const float* X, const float* W, const float* C, float beta, l
       (void)hipEventElapsedTime(&ms, e0, e1);
       return ms;
     };
-    bool win = true;
+    // our kernel's block tiles: small tiles have the lower fixed cost (more rounds of workgroups,
+    // their store phases overlap other workgroups' main loops), large ones the better rate per k
+    static const int tiles[] = {21, 12, 22, 23, 11};
+    float best_o = 1e30f;
+    int best_t = 0;
+    for (int t : tiles) {
+      const float ms = time_own(t);
+      if (ms > 0.f && ms < best_o) {
+        best_o = ms;
+        best_t = t;
+      }
+    }
+    bool win = best_t != 0;
     for (int round = 0; round < 2 && win; ++round) {
-      const float tl = time_cand(best_i), to = time_own();
+      const float tl = time_cand(best_i), to = time_own(best_t);
       win = to > 0.f && tl > 0.f && to < own_margin() * tl;
     }
     p.own = win;
+    p.own_tile = win ? best_t : 0;
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
@@ -296,6 +312,7 @@ extern "C" int s2t_linear_lt(int mode, const float* X, long ldx, const float* W,
       // the bucket was timed on another M: take its kernel if the heuristic offers it here too
       p.tuned = true;
       p.own = w->second.own;
+      p.own_tile = w->second.own_tile;
       for (int i = 0; i < p.ncand; ++i)
         if (p.cand[i].workspaceSize <= (size_t)ws_bytes &&
             memcmp(&p.cand[i].algo, &w->second.algo, sizeof(hipblasLtMatmulAlgo_t)) == 0) {
@@ -306,14 +323,15 @@ extern "C" int s2t_linear_lt(int mode, const float* X, long ldx, const float* W,
     } else if (g_tunings < tune_budget()) {
       tune(p, X, W, C == D ? nullptr : C, C == D ? 0.f : beta, (long)M * ldd, workspace,
            (size_t)ws_bytes, (hipStream_t)stream, mode, ldx, ldw, bias, ldc, ldd, M, N, K);
-      g_winner.emplace(bkey, Winner{p.algo, p.own});
+      g_winner.emplace(bkey, Winner{p.algo, p.own, p.own_tile});
       ++g_tunings;
     } else {
       p.tuned = true;                      // budget spent: the heuristic's first choice
     }
   }
   if (p.own && (beta == 0.f || (beta == 1.f && C != D)) &&
-      run_own(mode, X, ldx, W, ldw, bias, C, ldc, beta, D, ldd, M, N, K, (hipStream_t)stream) == 0) {
+      run_own(mode, X, ldx, W, ldw, bias, C, ldc, beta, D, ldd, M, N, K, p.own_tile,
+              (hipStream_t)stream) == 0) {
     ++g_own_calls;
     return 0;
   }
