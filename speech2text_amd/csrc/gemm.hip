@@ -71,6 +71,7 @@ struct GemmArgs {
   int sym_cg;             // TN with A == B (x^T x): > 0 = only the 64x64 tiles on / above the
                           // diagonal that hold same-group pairs (groups of sym_cg channels)
   int tile_force;         // NT / NN: 0 = dispatch's choice, else "tm tn" digits (11 12 21 22 23)
+  int wide_ep;            // NT / NN: rows of C / residual / bias 16-byte aligned -> float4 epilogue
 };
 
 __device__ __forceinline__ float log1p_fast(float e) {   // as zip_elem.hip
@@ -294,6 +295,50 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const unsigned bid)
 
   // ---- epilogue: lane holds column (lane & 31), rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
   const int hi = lane >> 5, lo = lane & 31;
+  if (MODE != MODE_TN && g.wide_ep) {
+    // NT / NN with 16-byte-aligned rows: every 32 x 32 tile goes through a per-wave LDS scratch
+    // (the operand tiles are dead; 16 rows at a time) and leaves as 16-byte stores -- 4 store
+    // instructions per tile and lane instead of 16, bias and residual read as float4 too
+    __syncthreads();                                   // all waves finished reading sA / sB
+    float* scr = sA + wave * (16 * 36);                // 16 rows at a time: 4 x 2.3 KB fit in sA
+    const int er = lane >> 3, ec = (lane & 7) * 4;     // this lane's row (of 8) and column quad
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn + 32 * j + ec;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g.bias && col < g.N) bv = *reinterpret_cast<const float4*>(g.bias + col);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {                  // rows 16 h .. 16 h + 15 of the tile
+          float4 rv[2];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int row = min(m0 + wm + 32 * i + 16 * h + er + 8 * q, g.M - 1);
+            rv[q] = (g.resid && col < g.N)
+                        ? *reinterpret_cast<const float4*>(g.resid + (long)row * g.ldr + col)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+#pragma unroll
+          for (int r = 0; r < 8; ++r)
+            scr[((r & 3) + 8 * (r >> 2) + 4 * hi) * 36 + lo] = acc[i][j][8 * h + r];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int row = m0 + wm + 32 * i + 16 * h + er + 8 * q;
+            const float4 v = *reinterpret_cast<const float4*>(scr + (er + 8 * q) * 36 + ec);
+            if (row < g.M && col < g.N)
+              *reinterpret_cast<float4*>(g.C + (long)row * g.ldc + col) =
+                  make_float4(v.x + bv.x + rv[q].x, v.y + bv.y + rv[q].y, v.z + bv.z + rv[q].z,
+                              v.w + bv.w + rv[q].w);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -445,6 +490,14 @@ int dispatch(GemmArgs& g, hipStream_t st) {
     g.kper = kper;
     splits = (g.K + kper - 1) / kper;
     return launch_t<MODE>(g, ttm, ttn, pro, splits, st);
+  }
+  {
+    static int wide = -1;       // S2T_GEMM_WIDE_EP=0: the scalar epilogue
+    if (wide < 0) { const char* e = getenv("S2T_GEMM_WIDE_EP"); wide = e ? atoi(e) : 1; }
+    g.wide_ep = wide && !g.act_src && !g.accumulate && (g.N & 3) == 0 && (g.ldc & 3) == 0 &&
+                (reinterpret_cast<uintptr_t>(g.C) & 15) == 0 &&
+                (!g.bias || (reinterpret_cast<uintptr_t>(g.bias) & 15) == 0) &&
+                (!g.resid || ((g.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(g.resid) & 15) == 0));
   }
   static int nt_force = -1;     // S2T_NT_TILE = "tm tn" digits (11, 12, 21, 22, 23): tuning
   if (nt_force < 0) { const char* e = getenv("S2T_NT_TILE"); nt_force = e ? atoi(e) : 0; }
