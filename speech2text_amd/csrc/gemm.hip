@@ -480,7 +480,10 @@ int dispatch(GemmArgs& g, hipStream_t st) {
     const int ttm = (force > 0 && !g.sym_cg) ? force / 10 : 1;
     const int ttn = g.sym_cg ? 1 : (force > 0 ? force % 10 : (g.N >= 512 ? 2 : 1));
     const long tiles = (long)((g.M + 64 * ttm - 1) / (64 * ttm)) * ((g.N + 64 * ttn - 1) / (64 * ttn));
-    const int target = user_blocks > 0 ? user_blocks : (ttm * ttn == 1 ? 1536 : 768);
+    static int xtx_blocks = -2;   // S2T_XTX_BLOCKS: workgroup target of the symmetric x^T x
+    if (xtx_blocks == -2) { const char* e = getenv("S2T_XTX_BLOCKS"); xtx_blocks = e ? atoi(e) : -1; }
+    const int target = (g.sym_cg && xtx_blocks > 0) ? xtx_blocks
+                       : user_blocks > 0 ? user_blocks : (ttm * ttn == 1 ? 1536 : 768);
     int splits = (int)((target + tiles - 1) / tiles);
     const int maxs = (g.K + 2 * KR - 1) / (2 * KR);
     if (splits > maxs) splits = maxs;

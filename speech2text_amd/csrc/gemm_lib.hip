@@ -45,7 +45,7 @@ bool own_enabled() {
 }
 float own_margin() {
   static float v = -1.f;
-  if (v < 0.f) { const char* e = getenv("S2T_LT_OWN_MARGIN"); v = e ? (float)atof(e) : 0.92f; }
+  if (v < 0.f) { const char* e = getenv("S2T_LT_OWN_MARGIN"); v = e ? (float)atof(e) : 0.97f; }
   return v;
 }
 int run_own(int mode, const float* X, long ldx, const float* W, long ldw, const float* bias,

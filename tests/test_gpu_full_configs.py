@@ -348,3 +348,66 @@ def test_c5_bestrq_ssl_full_size(dev):
     losses = [float(tr.training_step(batch, i)) for i in range(3)]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
     assert 0.3 < float(task.logged["mask_rate"]) < 0.7
+
+
+def test_checkpoint_save_resume_continues_the_trajectory(dev, tmp_path):
+    """f4 checkpoint interchange: train 2 steps, save (Lightning layout), train 2 more; a fresh
+    task + trainer resumed from the file repeats those 2 steps (same losses, same parameters)."""
+    import random
+    import bench
+    from speech2text_amd import checkpoint as ck
+    from speech2text_amd.build_task import TaskFactory
+    from speech2text_amd.trainer import Trainer
+
+    def make(seed):
+        cfg = bench.c3_config(64)
+        cfg["encoder"]["config"].update({"downsampling_factor": [1, 2], "num_encoder_layers": [1, 1],
+                                         "feedforward_dim": [96, 128], "encoder_dim": [48, 64],
+                                         "encoder_unmasked_dim": [32, 48], "num_heads": [4, 4],
+                                         "query_head_dim": 8, "value_head_dim": 4, "pos_dim": 16,
+                                         "cnn_module_kernel": [15, 7]})
+        cfg["predictor"]["config"].update({"output_dim": 64, "symbol_embedding_dim": 32})
+        cfg["joiner"].update({"input_dim": 64})
+        random.seed(5)
+        torch.manual_seed(seed)
+        task = TaskFactory.get("Pruned_Rnnt")(cfg)
+        tr = Trainer(**cfg["trainer"]).setup(task, dev)
+        task.train()
+        return task, tr
+
+    def steps(tr, lo, hi):
+        out = []
+        for i in range(lo, hi):
+            batch = bench.make_batch(i, 2, 2.0, 5, 64, dev)
+            random.seed(100 + i)
+            torch.manual_seed(200 + i)
+            out.append(float(tr.training_step(batch, i)))
+        return out
+
+    task, tr = make(1234)
+    steps(tr, 0, 2)
+    path = str(tmp_path / "epoch0.ckpt")
+    tracker = ck.BestK(monitor="wer", save_top_k=2, mode="min")
+    assert ck.save_checkpoint(tr, path, score=0.5, tracker=tracker)
+    lr_at_save = tr.optimizer.param_groups[0]["lr"]
+    la = steps(tr, 2, 4)
+    torch.cuda.synchronize()
+    pa = tr.store.p().detach().cpu().clone()
+
+    saved = torch.load(path, weights_only=False)
+    assert saved["global_step"] == 2 and list(saved["callbacks"])[0].startswith("ModelCheckpoint")
+    assert all(not v.is_cuda for v in saved["state_dict"].values())
+
+    task2, tr2 = make(999)                                   # different init: the file must win
+    ck.resume(tr2, path)
+    assert task2.global_step == 2
+    assert tr2.optimizer.param_groups[0]["lr"] == pytest.approx(lr_at_save, rel=1e-6)
+    lb = steps(tr2, 2, 4)
+    torch.cuda.synchronize()
+    pb = tr2.store.p().detach().cpu()
+    np.testing.assert_allclose(lb, la, rtol=1e-4)
+    np.testing.assert_allclose(pb.numpy(), pa.numpy(), rtol=5e-4, atol=2e-5)
+    # finetune start: parameters only, by name
+    task3, _ = make(7)
+    res = ck.load_from_checkpoint(task3, path, strict=False)
+    assert not res.missing_keys and not res.unexpected_keys

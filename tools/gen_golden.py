@@ -482,6 +482,40 @@ def gen_aug():
     print("aug:", len(out), "arrays")
 
 
+def gen_state_keys():
+    """Checkpoint interchange fixture: parameter / buffer names and shapes of the reference
+    modules the Pruned_Rnnt task holds, built from the shipped zipformer YAML
+    (task_factory/rnnt_task.py:56-64,444-445 attribute names -> Lightning `state_dict` prefixes)."""
+    import json, sys, types, importlib.machinery
+    import torch, yaml
+    ref_import.install_stubs()
+    if "torchaudio" not in sys.modules:
+        ta = types.ModuleType("torchaudio")
+        ta.__spec__ = importlib.machinery.ModuleSpec("torchaudio", None)
+        ta.models = types.SimpleNamespace(Conformer=None, Emformer=None)
+        ta.functional = types.SimpleNamespace(rnnt_loss=None)
+        sys.modules["torchaudio"] = ta
+    cfg = yaml.safe_load(open("/root/reference/config/training/zipformer_stateless_pruned_rnnt.yaml"))
+    from model.encoder.zipformer import Zipformer2, Zipformer2Config
+    from model.predictor.stateless_predictor import StatelessPredictor, StatelessPredictorConfig
+    from model.joiner.joiner import Joiner, JoinerConfig
+    from model.decoder.decoder import Decoder
+    mods = {"_encoder.encoder": Zipformer2(Zipformer2Config(**cfg["encoder"]["config"])),
+            # model/predictor/predictor.py:27 holds it as `.predictor` (the factory module itself
+            # imports the torchaudio-based LSTM predictor, a third-party wheel absent here)
+            "_predictor.predictor": StatelessPredictor(StatelessPredictorConfig(**cfg["predictor"]["config"])),
+            "_joiner": Joiner(config=JoinerConfig(**cfg["joiner"])),
+            "_decoder": Decoder(cfg["decoder"])}
+    if "ctc_projector" in cfg:
+        mods["_ctc_projector"] = Decoder(cfg["ctc_projector"])
+    out = {}
+    for pre, m in mods.items():
+        for k, v in m.state_dict().items():
+            out[f"{pre}.{k}"] = list(v.shape)
+    json.dump(out, open(os.path.join(OUT, "state_keys_c3.json"), "w"), indent=0, sort_keys=True)
+    print("state_keys", len(out))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ["fbank", "ctc", "bestrq", "zipformer", "scaledadam"]
