@@ -228,6 +228,11 @@ int s2t_conv3x3_s2(int mode, const float* x, const float* w, const float* bias, 
  * flip=1 applies the flipped taps (= backward data).  wgrad writes dw (C,KH,KW) and db (C). */
 int s2t_dwconv2d_nhwc_fwd(const float* x, const float* wgt, const float* bias, int N, int H, int W,
                           int C, int KH, int KW, int flip, float* y, void* stream);
+/* same with y = conv(x) + add (add has y's layout; 7x7 only, -2 otherwise): ConvNeXt's residual
+ * gradient (subsampling.py:57 `bypass + x`) added inside the backward-data pass. */
+int s2t_dwconv2d_nhwc_fwd_add(const float* x, const float* wgt, const float* bias, const float* add,
+                              int N, int H, int W, int C, int KH, int KW, int flip, float* y,
+                              void* stream);
 long s2t_dwconv2d_wgrad_workspace_floats(int N, int H, int C, int KH, int KW);
 int s2t_dwconv2d_nhwc_wgrad(const float* x, const float* dy, int N, int H, int W, int C, int KH,
                             int KW, float* workspace, float* dw, float* db, void* stream);

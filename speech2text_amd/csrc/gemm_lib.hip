@@ -17,6 +17,7 @@
 #include <hipblaslt/hipblaslt.h>
 
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -258,6 +259,12 @@ void tune(Plan& p, const float* X, const float* W, const float* C, float beta, l
     }
     p.own = win;
     p.own_tile = win ? best_t : 0;
+    static int dump = -1;      // S2T_LT_DUMP=1: one line per timed bucket (diagnostics)
+    if (dump < 0) { const char* e = getenv("S2T_LT_DUMP"); dump = e ? atoi(e) : 0; }
+    if (dump)
+      fprintf(stderr, "[s2t lt] mode %d M %d N %d K %d bias %d beta %g: library %.1f us, ours %.1f us (tile %d)%s\n",
+              mode, M, N, K, bias ? 1 : 0, (double)beta, 1e3 * time_cand(best_i) / 4.0, 1e3 * best_o / 4.0,
+              best_t, win ? " <- ours" : "");
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);

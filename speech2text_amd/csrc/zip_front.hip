@@ -188,8 +188,15 @@ __global__ __launch_bounds__(256) void dwconv2d_roll_kernel(const float* __restr
           load_row(win[(u + RING - 1) % RING], h + PH + RPD);
           if (MODE != 2) {
             float acc[RWO];
+            if (dy) {          // MODE 0/1: dy is an optional addend with the output's layout
+              const float* ar = dy + (((long)n * H + h) * W + w0) * C + cc;
 #pragma unroll
-            for (int o = 0; o < RWO; ++o) acc[o] = bv;
+              for (int o = 0; o < RWO; ++o)
+                acc[o] = bv + ((w0 + o < W) ? ar[(long)min(o, W - 1 - w0) * C] : 0.f);
+            } else {
+#pragma unroll
+              for (int o = 0; o < RWO; ++o) acc[o] = bv;
+            }
 #pragma unroll
             for (int i = 0; i < KH; ++i)
 #pragma unroll
@@ -266,20 +273,22 @@ __global__ __launch_bounds__(256) void dwconv2d_wreduce_kernel(const float* __re
 
 }  // namespace
 
-// x,y (N,H,W,C) channel-last; wgt (C,KH,KW); only 7x7 (ConvNeXt) and 3x3 are instantiated
-extern "C" int s2t_dwconv2d_nhwc_fwd(const float* x, const float* wgt, const float* bias, int N,
-                                     int H, int W, int C, int KH, int KW, int flip, float* y,
-                                     void* stream) {
+// x,y (N,H,W,C) channel-last; wgt (C,KH,KW); only 7x7 (ConvNeXt) and 3x3 are instantiated.
+// add (optional, 7x7 only): y = conv(x) + add -- the residual branch's gradient riding in the
+// backward-data pass.
+extern "C" int s2t_dwconv2d_nhwc_fwd_add(const float* x, const float* wgt, const float* bias,
+                                         const float* add, int N, int H, int W, int C, int KH,
+                                         int KW, int flip, float* y, void* stream) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
+  if (add && !(KH == 7 && KW == 7)) return -2;
   dim3 grid((H + TH - 1) / TH, N, (C + 63) / 64);
   hipStream_t st = (hipStream_t)stream;
   if (KH == 7 && KW == 7) {
     const int nparts = (W + RWO - 1) / RWO, nrr = (H + RRT - 1) / RRT;
     constexpr int CPB = 256 / RCT;
     dim3 gr((nparts * nrr + CPB - 1) / CPB, N, (C + RCT - 1) / RCT);
-    const float* nf = nullptr;
-    if (flip) hipLaunchKernelGGL((dwconv2d_roll_kernel<7, 7, 1>), gr, dim3(256), 0, st, x, wgt, bias, nf, N, H, W, C, nparts, nrr, y);
-    else hipLaunchKernelGGL((dwconv2d_roll_kernel<7, 7, 0>), gr, dim3(256), 0, st, x, wgt, bias, nf, N, H, W, C, nparts, nrr, y);
+    if (flip) hipLaunchKernelGGL((dwconv2d_roll_kernel<7, 7, 1>), gr, dim3(256), 0, st, x, wgt, bias, add, N, H, W, C, nparts, nrr, y);
+    else hipLaunchKernelGGL((dwconv2d_roll_kernel<7, 7, 0>), gr, dim3(256), 0, st, x, wgt, bias, add, N, H, W, C, nparts, nrr, y);
   } else if (KH == 3 && KW == 3) {
     if (flip) hipLaunchKernelGGL((dwconv2d_kernel<3, 3, true>), grid, dim3(256), 0, st, x, wgt, bias, N, H, W, C, y);
     else hipLaunchKernelGGL((dwconv2d_kernel<3, 3, false>), grid, dim3(256), 0, st, x, wgt, bias, N, H, W, C, y);
@@ -288,6 +297,12 @@ extern "C" int s2t_dwconv2d_nhwc_fwd(const float* x, const float* wgt, const flo
   }
   S2T_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int s2t_dwconv2d_nhwc_fwd(const float* x, const float* wgt, const float* bias, int N,
+                                     int H, int W, int C, int KH, int KW, int flip, float* y,
+                                     void* stream) {
+  return s2t_dwconv2d_nhwc_fwd_add(x, wgt, bias, nullptr, N, H, W, C, KH, KW, flip, y, stream);
 }
 
 extern "C" long s2t_dwconv2d_wgrad_workspace_floats(int N, int H, int C, int KH, int KW) {

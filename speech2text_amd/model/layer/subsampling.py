@@ -46,15 +46,25 @@ class ConvNeXt(nn.Module):
             rate = float(self.layerdrop_rate)
             if rate != 0.0:
                 mask = rng.rand(x.shape[0], 1, 1, 1, dtype=x.dtype, device=x.device) > rate
-        bypass = x
-        x = zk.dwconv2d_nhwc(x, self.depthwise_conv.weight, self.depthwise_conv.bias)
-        x = zk.linear_big_m(x, self.pointwise_conv1.weight.flatten(1), self.pointwise_conv1.bias)
-        x = self.hidden_balancer(x)
-        x = self.activation(x)
-        x = zk.linear_big_m(x, self.pointwise_conv2.weight.flatten(1), self.pointwise_conv2.bias)
-        if mask is not None:
-            x = x * mask
-        x = bypass + x
+        if mask is None and x.is_cuda and tuple(self.depthwise_conv.kernel_size) == (7, 7):
+            # the residual add rides in the second pointwise GEMM's epilogue, its gradient in the
+            # depthwise backward-data pass: no add pass over the (N,T,F,C) map in either direction
+            x, bypass = zk.dwconv2d_nhwc_tap(x, self.depthwise_conv.weight, self.depthwise_conv.bias)
+            x = zk.linear_big_m(x, self.pointwise_conv1.weight.flatten(1), self.pointwise_conv1.bias)
+            x = self.hidden_balancer(x)
+            x = self.activation(x)
+            x = zk.linear(x, self.pointwise_conv2.weight.flatten(1), self.pointwise_conv2.bias,
+                          residual=bypass)
+        else:
+            bypass = x
+            x = zk.dwconv2d_nhwc(x, self.depthwise_conv.weight, self.depthwise_conv.bias)
+            x = zk.linear_big_m(x, self.pointwise_conv1.weight.flatten(1), self.pointwise_conv1.bias)
+            x = self.hidden_balancer(x)
+            x = self.activation(x)
+            x = zk.linear_big_m(x, self.pointwise_conv2.weight.flatten(1), self.pointwise_conv2.bias)
+            if mask is not None:
+                x = x * mask
+            x = bypass + x
         x = self.out_balancer(x)
         if x.requires_grad:
             x = self.out_whiten(x)
@@ -101,7 +111,13 @@ class Conv2dSubsampling(nn.Module):
         while i < len(mods):
             m = mods[i]
             if isinstance(m, nn.Conv2d):
-                x = zk.conv3x3_nhwc(x, m.weight, m.bias, m.stride, pad_w=m.padding[1])  # freq axis
+                gs = None
+                if (i + 1 < len(mods) and isinstance(mods[i + 1], ScaleGrad)
+                        and zk.conv3x3_direct_c1(x, m.weight, m.stride, m.padding[1])):
+                    gs = mods[i + 1].alpha if self.training else None   # ScaleGrad is identity forward
+                    i += 1
+                x = zk.conv3x3_nhwc(x, m.weight, m.bias, m.stride, pad_w=m.padding[1],  # freq axis
+                                    grad_scale=gs)
             elif (isinstance(m, Balancer) and i + 1 < len(mods) and isinstance(mods[i + 1], SwooshR)
                   and x.is_cuda and m.channel_dim in (-1, x.ndim - 1)):
                 # Balancer + SwooshR: one autograd node, one backward pass over these (large) maps

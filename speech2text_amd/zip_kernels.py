@@ -1259,8 +1259,8 @@ class _Conv3x3Nhwc(torch.autograd.Function):
         s = x.stride()
         cols = x.as_strided((B, Ho, Wo, 3, 3 * C), (s[0], s[1] * sh, s[2] * sw, s[1], 1)) \
             .reshape(B * Ho * Wo, 9 * C)
-        wmat = weight.permute(2, 3, 1, 0).reshape(9 * C, weight.shape[0])       # (kh,kw,cin) x cout
-        y = torch.addmm(bias, cols, wmat) if bias is not None else cols.mm(wmat)
+        w2 = weight.permute(0, 2, 3, 1).reshape(weight.shape[0], 9 * C)         # cout x (kh,kw,cin)
+        y = lt_matmul(0, cols, w2, bias)
         ctx.save_for_backward(cols, weight)
         ctx.cfg = (B, H, W, C, Ho, Wo, sh, sw, bias is not None)
         return y.view(B, Ho, Wo, weight.shape[0])
@@ -1275,8 +1275,8 @@ class _Conv3x3Nhwc(torch.autograd.Function):
         dweight = dwmat.view(Cout, 3, 3, C).permute(0, 3, 1, 2)
         dx = None
         if ctx.needs_input_grad[0]:
-            wmat = weight.permute(2, 3, 1, 0).reshape(9 * C, Cout)
-            dc = g.mm(wmat.t())                                  # (B*Ho*Wo, 3*3*C)
+            w2 = weight.permute(0, 2, 3, 1).reshape(Cout, 9 * C)
+            dc = lt_matmul(1, g if g.is_contiguous() else g.contiguous(), w2)   # (B*Ho*Wo, 3*3*C)
             dx = torch.empty((B, H, W, C), dtype=torch.float32, device=dy.device)
             N.check(N.lib().s2t_col2im3x3_nhwc(N.fp(dc), B, H, W, C, Ho, Wo, sh, sw, N.fp(dx),
                                                N.stream()), "s2t_col2im3x3_nhwc")
@@ -1288,8 +1288,9 @@ class _Conv3x3C1(torch.autograd.Function):
     padded copy, no im2col matrix, no 12-wide GEMM."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, pw):
+    def forward(ctx, x, weight, bias, pw, grad_scale=None):
         _dev(x, weight)
+        ctx.grad_scale = grad_scale
         x3 = x.reshape(x.shape[0], x.shape[1], x.shape[2]).contiguous().float()
         B, H, W = x3.shape
         CO = weight.shape[0]
@@ -1318,7 +1319,12 @@ class _Conv3x3C1(torch.autograd.Function):
             N.check(L.s2t_conv3x3_c1(2, None, N.fp(w), None, N.fp(g), B, H, W, pw, CO, None, None,
                                      None, N.fp(dx), N.stream()), "s2t_conv3x3_c1(dgrad)")
             dx = dx.view(xshape)
-        return dx, acc[:CO * 9].view(w.shape), (acc[CO * 9:] if has_bias else None), None
+        if ctx.grad_scale is not None:
+            # ScaleGrad(alpha) behind this conv (reference subsampling.py:217-218): the conv's
+            # backward is linear in g, so alpha scales its (tiny) results, not the big map
+            acc = acc * float(ctx.grad_scale)
+            dx = None if dx is None else dx * float(ctx.grad_scale)
+        return dx, acc[:CO * 9].view(w.shape), (acc[CO * 9:] if has_bias else None), None, None
 
 
 class _Conv3x3S2(torch.autograd.Function):
@@ -1361,12 +1367,21 @@ class _Conv3x3S2(torch.autograd.Function):
         return dx, dweight, db
 
 
-def conv3x3_nhwc(x, weight, bias, stride=(1, 1), pad_w=0):
+def conv3x3_direct_c1(x, weight, stride, pad_w):
+    """True when conv3x3_nhwc runs the direct 1 -> 8 channel kernel (which can absorb a following
+    ScaleGrad through `grad_scale`)."""
+    return (x.shape[-1] == 1 and weight.shape[0] == 8 and tuple(stride) == (1, 1) and pad_w in (0, 1)
+            and x.is_cuda)
+
+
+def conv3x3_nhwc(x, weight, bias, stride=(1, 1), pad_w=0, grad_scale=None):
     """3x3 convolution on channel-last (N,H,W,Cin); pad_w = zero padding of the W axis (the
-    reference's padding=(0, 1) of the first subsampling conv)."""
-    if (x.shape[-1] == 1 and weight.shape[0] == 8 and tuple(stride) == (1, 1) and pad_w in (0, 1)
-            and x.is_cuda):
-        return _Conv3x3C1.apply(x, weight, bias, int(pad_w))
+    reference's padding=(0, 1) of the first subsampling conv).  grad_scale: the gradients of this
+    conv are multiplied by it (only with conv3x3_direct_c1)."""
+    if conv3x3_direct_c1(x, weight, stride, pad_w):
+        return _Conv3x3C1.apply(x, weight, bias, int(pad_w), grad_scale)
+    if grad_scale is not None:
+        raise ValueError("grad_scale needs the direct 1->8 channel kernel")
     if (x.shape[-1] == 8 and weight.shape[0] == 32 and tuple(stride) == (2, 2) and not pad_w
             and x.is_cuda and x.shape[0] <= 65535 and x.shape[1] <= 65535):
         return _Conv3x3S2.apply(x, weight, bias)
@@ -1416,3 +1431,45 @@ class _DwConv2dNhwc(torch.autograd.Function):
 
 def dwconv2d_nhwc(x, weight, bias):
     return _DwConv2dNhwc.apply(x, weight, bias)
+
+
+class _DwConv2dTap(torch.autograd.Function):
+    """(depthwise conv(x), x) -- the second output is x itself for the block's residual branch;
+    that branch's gradient comes back here and is added inside the backward-data pass instead
+    of by an autograd add over the (N,H,W,C) map."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        y = _DwConv2dNhwc.forward(ctx, x, weight, bias)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, g_pass):
+        x, w = ctx.saved_tensors
+        Nn, H, W, C = x.shape
+        KH, KW = w.shape[1], w.shape[2]
+        if g_pass is None or dy is None or (KH, KW) != (7, 7):
+            dx, dw, db = _DwConv2dNhwc.backward(ctx, dy if dy is not None else torch.zeros_like(x))
+            if g_pass is not None and dx is not None:
+                dx = dx + g_pass
+            return dx, dw, db
+        dy = dy.contiguous().float()
+        gp = g_pass.contiguous().float()
+        L = N.lib()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            N.check(L.s2t_dwconv2d_nhwc_fwd_add(N.fp(dy), N.fp(w), None, N.fp(gp), Nn, H, W, C, KH, KW,
+                                                1, N.fp(dx), N.stream()), "s2t_dwconv2d_nhwc_bwd_data")
+        ws = torch.empty(L.s2t_dwconv2d_wgrad_workspace_floats(Nn, H, C, KH, KW),
+                         dtype=torch.float32, device=x.device)
+        dw = torch.empty_like(w)
+        db = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        N.check(L.s2t_dwconv2d_nhwc_wgrad(N.fp(x), N.fp(dy), Nn, H, W, C, KH, KW, N.fp(ws),
+                                          N.fp(dw), N.fp(db), N.stream()), "s2t_dwconv2d_nhwc_wgrad")
+        return dx, dw.view(ctx.wshape), db
+
+
+def dwconv2d_nhwc_tap(x, weight, bias):
+    """-> (depthwise conv(x), alias of x for the residual branch)."""
+    return _DwConv2dTap.apply(x, weight, bias)
