@@ -223,6 +223,17 @@ int s2t_conv3x3_c1(int mode, const float* x, const float* w, const float* bias, 
 int s2t_conv3x3_s2(int mode, const float* x, const float* w, const float* bias, const float* g, int B,
                    int H, int W, int CI, int CO, float* y, float* dx, void* stream);
 
+/* ---- 3x3 convolution products with the patch matrix read in place (no im2col copy in HBM):
+ * the third subsampling conv and the weight gradients of the second and third
+ * (model/layer/subsampling.py:226-243 nn.Conv2d(8,32,3,stride=2), nn.Conv2d(32,128,3,stride=(1,2))).
+ * x (B,H,W,C) channel-last, R = B*Ho*Wo output positions, C % 4 == 0 and CO % 4 == 0 (-2 otherwise).
+ *   mode 0: out[R,CO] = patches(x)[R,9C] . w2[CO,9C]^T (+ bias[CO]);  w2_or_g = w2 in (cout,kh,kw,cin) order
+ *   mode 2: out[CO,9C] += g[R,CO]^T . patches(x)[R,9C],  db[CO] += column sums of g (db may be NULL);
+ *           w2_or_g = g; out / db zeroed (or holding the running gradient) by the caller.
+ * bf16x3 matrix-core arithmetic: fp32-level error. */
+int s2t_conv3x3_gemm(int mode, const float* x, int B, int H, int W, int C, int sh, int sw, int CO,
+                     const float* w2_or_g, const float* bias, float* out, float* db, void* stream);
+
 /* ---- channel-last depthwise conv2d of the zipformer frontend (ConvNeXt 7x7,
  * model/layer/subsampling.py:47-53,121).  x,y (N,H,W,C); wgt (C,KH,KW); "same" zero padding.
  * flip=1 applies the flipped taps (= backward data).  wgrad writes dw (C,KH,KW) and db (C). */

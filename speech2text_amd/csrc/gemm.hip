@@ -46,6 +46,21 @@ constexpr int BK0 = 32;   // contraction chunk of the big tiles; the 64x64 tile 
 enum { MODE_NT = 0, MODE_NN = 1, MODE_TN = 2 };
 enum { ACT_NONE = 0, ACT_SWOOSH_L = 1, ACT_SWOOSH_R = 2 };
 
+// Implicit im2col of a 3x3 convolution on a channel-last map x (B,H,W,C): row r = (b, ho, wo) of
+// the patch matrix starts at x + b sb + ho sh + wo sw (floats) and its 9C columns are three runs
+// of seg = 3C contiguous floats, s1 = W C apart -- the operand is read straight from x.
+struct Patch {
+  int seg, hw, wo, sb, sh, sw, s1;
+};
+__device__ __forceinline__ int patch_row(const Patch& p, int r) {
+  const int b = r / p.hw, q = r - b * p.hw, ho = q / p.wo, wo = q - ho * p.wo;
+  return b * p.sb + ho * p.sh + wo * p.sw;
+}
+__device__ __forceinline__ int patch_col(const Patch& p, int j) {
+  const int kh = j / p.seg;
+  return kh * p.s1 + (j - kh * p.seg);
+}
+
 struct GemmArgs {
   const float* A;
   long lda;
@@ -72,6 +87,7 @@ struct GemmArgs {
                           // diagonal that hold same-group pairs (groups of sym_cg channels)
   int tile_force;         // NT / NN: 0 = dispatch's choice, else "tm tn" digits (11 12 21 22 23)
   int wide_ep;            // NT / NN: rows of C / residual / bias 16-byte aligned -> float4 epilogue
+  Patch pt;               // PATCH kernels: A (NT) or B (TN) is the implicit patch matrix of pt
 };
 
 __device__ __forceinline__ float log1p_fast(float e) {   // as zip_elem.hip
@@ -93,7 +109,7 @@ __device__ __forceinline__ float swoosh_deriv(float x, int kind) {
 // KM: [BK][ROWS + 4] (k-major).  ROWS = 64 * T.  Loads are unconditional (clamped addresses) so
 // that all of a chunk's global loads are in flight together; validity and the activation are
 // applied one iteration later, when the registers are written to LDS.
-template <int ROWS, bool KC, int ACT, int BK>
+template <int ROWS, bool KC, int ACT, int BK, bool PATCH = false>
 struct Tile {
   static constexpr int LD = KC ? (BK + 4) : (ROWS + 4);
   static constexpr int SIZE = KC ? ROWS * LD : BK * LD;
@@ -101,7 +117,8 @@ struct Tile {
 
   // global -> registers.  KC: src[out0 + r][k0 + 4c];  KM: src[k0 + r][out0 + 4c]
   __device__ static __forceinline__ unsigned load(float4 (&v)[NV], const float* __restrict__ src,
-                                                  long ld, int out0, int out_n, int k0, int k_n) {
+                                                  long ld, int out0, int out_n, int k0, int k_n,
+                                                  const Patch& pt) {
     unsigned ok = 0;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -118,7 +135,11 @@ struct Tile {
       const bool valid = o < out_n && k < k_n;
       ok |= (valid ? 1u : 0u) << i;
       const int oc = min(o, KC ? out_n - 1 : out_n - 4), kc = min(k, KC ? k_n - 4 : k_n - 1);
-      const float* p = KC ? src + (long)oc * ld + kc : src + (long)kc * ld + oc;
+      const float* p;
+      if (PATCH)   // patch matrix row = output index (KC, forward) or contraction index (k-major)
+        p = KC ? src + patch_row(pt, oc) + patch_col(pt, kc) : src + patch_row(pt, kc) + patch_col(pt, oc);
+      else
+        p = KC ? src + (long)oc * ld + kc : src + (long)kc * ld + oc;
       v[i] = *reinterpret_cast<const float4*>(p);
     }
     return ok;
@@ -159,14 +180,14 @@ constexpr int bk_of(int tm, int tn, int mode) {
 // exactly into three bf16 pieces when a wave reads them from LDS (8 k-strided reads per
 // fragment: the tiles are k-major) and every 16-deep step is six v_mfma_f32_32x32x16_bf16 products
 // (gemm_x3.hip: fp32-level error); 6 x 8 passes instead of 8 x 16 passes of the f32 MFMA.
-template <int TM, int TN, int MODE, int PRO, bool X3 = false>
+template <int TM, int TN, int MODE, int PRO, bool X3 = false, bool PATCH = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, const unsigned bid) {
   constexpr bool A_KC = MODE != MODE_TN, B_KC = MODE == MODE_NT;
   constexpr int BM = 64 * TM, BN = 64 * TN;
   constexpr int BK = bk_of(TM, TN, MODE);
   // the staged activation applies to A in NT (y = act(x) W^T) and to B in TN (dW = g^T act(x))
-  using TA = Tile<BM, A_KC, (MODE == MODE_NT ? PRO : ACT_NONE), BK>;
-  using TB = Tile<BN, B_KC, (MODE == MODE_TN ? PRO : ACT_NONE), BK>;
+  using TA = Tile<BM, A_KC, (MODE == MODE_NT ? PRO : ACT_NONE), BK, (PATCH && MODE == MODE_NT)>;
+  using TB = Tile<BN, B_KC, (MODE == MODE_TN ? PRO : ACT_NONE), BK, (PATCH && MODE == MODE_TN)>;
   __shared__ __attribute__((aligned(16))) float sA[TA::SIZE];
   __shared__ __attribute__((aligned(16))) float sB[TB::SIZE];
 
@@ -214,8 +235,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const unsigned bid)
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   float4 ra[TA::NV], rb[TB::NV];
-  unsigned oka = TA::load(ra, g.A, g.lda, m0, g.M, kbeg, kend);
-  unsigned okb = TB::load(rb, g.B, g.ldb, n0, g.N, kbeg, kend);
+  unsigned oka = TA::load(ra, g.A, g.lda, m0, g.M, kbeg, kend, g.pt);
+  unsigned okb = TB::load(rb, g.B, g.ldb, n0, g.N, kbeg, kend, g.pt);
   float csum = 0.f;   // TN bias gradient: thread t < BM owns column m0 + t
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
     __syncthreads();                       // previous chunk fully consumed
@@ -223,8 +244,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const unsigned bid)
     TB::store(sB, rb, okb);
     __syncthreads();
     if (k0 + BK < kend) {                  // next chunk's global loads fly under the MFMAs
-      oka = TA::load(ra, g.A, g.lda, m0, g.M, k0 + BK, kend);
-      okb = TB::load(rb, g.B, g.ldb, n0, g.N, k0 + BK, kend);
+      oka = TA::load(ra, g.A, g.lda, m0, g.M, k0 + BK, kend, g.pt);
+      okb = TB::load(rb, g.B, g.ldb, n0, g.N, k0 + BK, kend, g.pt);
     }
     if (MODE == MODE_TN && g.colsum != nullptr && tn == csum_tn && threadIdx.x < BM) {
 #pragma unroll 8
@@ -366,9 +387,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const unsigned bid)
     }
 }
 
-template <int TM, int TN, int MODE, int PRO, bool X3 = false>
+template <int TM, int TN, int MODE, int PRO, bool X3 = false, bool PATCH = false>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-  gemm_body<TM, TN, MODE, PRO, X3>(g, blockIdx.x);
+  gemm_body<TM, TN, MODE, PRO, X3, PATCH>(g, blockIdx.x);
 }
 
 // ---- grouped TN: the weight-gradient GEMMs of one layer in ONE launch.  Each problem keeps its
@@ -556,6 +577,55 @@ extern "C" int s2t_gemm_f32_tiled(int mode, const float* A, long lda, const floa
              0, nullptr, 0, 0, 0, 0, 0, 0, 1.f, 0, tile};
   hipStream_t st = (hipStream_t)stream;
   return mode == MODE_NT ? dispatch<MODE_NT>(g, st) : dispatch<MODE_NN>(g, st);
+}
+
+// 3x3 convolution products on channel-last maps with the patch matrix read in place (see Patch):
+//   mode 0: y[R, CO] = patches(x)[R, 9C] . w2[CO, 9C]^T (+ bias)          R = B Ho Wo
+//   mode 2: dw2[CO, 9C] += g[R, CO]^T . patches(x)[R, 9C],  db[CO] += column sums of g
+// w2 / dw2 are in (cout, kh, kw, cin) order; bf16x3 matrix-core arithmetic (fp32-level error).
+extern "C" int s2t_conv3x3_gemm(int mode, const float* x, int B, int H, int W, int C, int sh, int sw,
+                                int CO, const float* w2_or_g, const float* bias, float* out,
+                                float* db, void* stream) {
+  if (B <= 0 || H < 3 || W < 3 || C <= 0 || CO <= 0 || sh <= 0 || sw <= 0 || (mode != 0 && mode != 2))
+    return -1;
+  const int Ho = (H - 3) / sh + 1, Wo = (W - 3) / sw + 1;
+  const long R = (long)B * Ho * Wo, nx = (long)B * H * W * C;
+  if ((C & 3) || (CO & 3) || nx >= (1L << 31) || R >= (1L << 31) || R < 4) return -2;
+  if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(w2_or_g) & 15) ||
+      (reinterpret_cast<uintptr_t>(out) & 15))
+    return -2;
+  const Patch pt{3 * C, Ho * Wo, Wo, H * W * C, sh * W * C, sw * C, W * C};
+  const int K9 = 9 * C;
+  hipStream_t st = (hipStream_t)stream;
+  if (mode == 0) {
+    GemmArgs g{x, 0, w2_or_g, K9, out, CO, (int)R, CO, K9, bias, nullptr, 0, nullptr, 0, 0, 0,
+               0, nullptr, 0, 0, 0, 0, 0, 0, 1.f, 0, 0, 0, pt};
+    g.wide_ep = !bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0;
+    g.tiles_m = (g.M + 127) / 128;
+    g.tiles_n = CO > 64 ? (CO + 127) / 128 : 1;
+    g.splits = 1;
+    const int grid = ((g.tiles_m * g.tiles_n + 7) / 8) * 8;
+    if (CO > 64)
+      hipLaunchKernelGGL((gemm_kernel<2, 2, MODE_NT, ACT_NONE, true, true>), dim3(grid), dim3(256), 0, st, g);
+    else
+      hipLaunchKernelGGL((gemm_kernel<2, 1, MODE_NT, ACT_NONE, true, true>), dim3(grid), dim3(256), 0, st, g);
+    return (int)hipGetLastError();
+  }
+  GemmArgs g{w2_or_g, CO, x, 0, out, K9, CO, K9, (int)R, nullptr, nullptr, 0, nullptr, 0, 0, 0,
+             0, db, 0, 0, 0, 0, 0, 0, 1.f, 0, 0, 0, pt};
+  g.tiles_m = (CO + 63) / 64;
+  g.tiles_n = (K9 + 63) / 64;
+  const long tiles = (long)g.tiles_m * g.tiles_n;
+  int splits = (int)((1536 + tiles - 1) / tiles);
+  const int maxs = (g.K + 2 * KR - 1) / (2 * KR);
+  splits = std::max(1, std::min(splits, maxs));
+  int kper = (g.K + splits - 1) / splits;
+  kper = ((kper + KR - 1) / KR) * KR;
+  g.kper = kper;
+  g.splits = (g.K + kper - 1) / kper;
+  const int grid = (int)(8 * tiles * ((g.splits + 7) / 8));
+  hipLaunchKernelGGL((gemm_kernel<1, 1, MODE_TN, ACT_NONE, true, true>), dim3(grid), dim3(256), 0, st, g);
+  return (int)hipGetLastError();
 }
 
 extern "C" int s2t_tn_x3(int set) {

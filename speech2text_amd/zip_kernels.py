@@ -534,7 +534,12 @@ def _attn_bwd_call(qkp, pos, k8, a8, H, qd, pd, W, dW, dW0, pairs, delta):
     if pos is not None:
         ws = torch.empty(N.lib().s2t_relpos_attn_bwd_workspace_floats(T, B, H, pd),
                          dtype=torch.float32, device=dev)
-    N.profile_note("s2t_relpos_attn_bwd", 4.0 * (2 * qkp.numel() + 2 * W.numel()))
+    # flops per score element: dW from its factors (2 cd), dq and dk (2 qd each), dp and dpos
+    # (2 pd each) -- 192 at the C3 dims against 8 bytes: above the chip's 19.7 flop/byte balance,
+    # so the f32 matrix cores bound this launch, not HBM
+    cd = sum(int(e[3]) for e in p)
+    N.profile_note("s2t_relpos_attn_bwd", 4.0 * (2 * qkp.numel() + 2 * W.numel()),
+                   2.0 * W.numel() * (cd + 2 * qd + (2 * pd if pos is not None else 0)))
     N.check(N.lib().s2t_relpos_attn_bwd(N.fp(qkp), N.fp(pos), N.ptr(k8), N.ptr(a8), T, B, H, qd, pd,
                                         N.fp(W), N.fp(dW), N.fp(dW0), N.fp(p[0][0]), N.fp(p[0][1]),
                                         p[0][3], N.fp(p[1][0]), N.fp(p[1][1]), p[1][3], int(given),
@@ -553,7 +558,8 @@ class _RelPosAttn(torch.autograd.Function):
         k8 = None if kpm is None else kpm.to(torch.uint8).contiguous()
         a8 = None if amask is None else amask.to(torch.uint8).contiguous()
         W = torch.empty((H, B, T, T), dtype=torch.float32, device=qkp.device)
-        N.profile_note("s2t_relpos_attn_fwd", 4.0 * (qkp.numel() + W.numel()))
+        N.profile_note("s2t_relpos_attn_fwd", 4.0 * (qkp.numel() + W.numel()),
+                       2.0 * W.numel() * (qd + (pd if pos is not None else 0)))
         N.check(N.lib().s2t_relpos_attn_fwd(N.fp(qkp), N.fp(pos), N.ptr(k8), N.ptr(a8), T, B, H,
                                             qd, pd, N.fp(W), N.stream()), "s2t_relpos_attn_fwd")
         ctx.save_for_backward(qkp, pos, k8, a8, W)
@@ -1245,38 +1251,74 @@ def linear_big_m(x, weight, bias):
     return _Linear.apply(x, weight, bias, None)
 
 
+def _conv3x3_wgrad_implicit(x, g, sh, sw, has_bias):
+    """dW (Cout,Cin,3,3) view and db of a 3x3 conv on channel-last x from g (B,Ho,Wo,Cout): the TN
+    MFMA GEMM reads the patches straight from x (no im2col matrix)."""
+    B, H, W, C = x.shape
+    Cout = g.shape[-1]
+    dw2 = torch.zeros((Cout, 9 * C), dtype=torch.float32, device=x.device)
+    db = torch.zeros((Cout,), dtype=torch.float32, device=x.device) if has_bias else None
+    R = g.numel() // Cout
+    N.profile_note("s2t_conv3x3_gemm", 4.0 * (x.numel() + g.numel()), 2.0 * R * Cout * 9 * C)
+    N.check(N.lib().s2t_conv3x3_gemm(2, N.fp(x), B, H, W, C, sh, sw, Cout, N.fp(g), None, N.fp(dw2),
+                                     N.fp(db), N.stream()), "s2t_conv3x3_gemm(wgrad)")
+    return dw2.view(Cout, 3, 3, C).permute(0, 3, 1, 2), db
+
+
+def _implicit_ok(x, Cout):
+    return x.is_cuda and x.shape[-1] % 4 == 0 and Cout % 4 == 0 and x.numel() < (1 << 31)
+
+
 class _Conv3x3Nhwc(torch.autograd.Function):
-    """3x3 conv on channel-last (N,H,W,Cin) as im2col (one strided copy; each patch row is 3
-    contiguous runs of 3*Cin floats in NHWC) + one plain GEMM (hipBLASLt).  Backward: two
-    GEMMs + one col2im gather kernel (zip_front.hip).  weight keeps nn.Conv2d's (Cout,Cin,3,3) layout."""
+    """3x3 conv on channel-last (N,H,W,Cin) as an implicit-im2col GEMM: each patch row is 3
+    contiguous runs of 3*Cin floats of x, which the MFMA kernel's operand loader addresses in
+    place (s2t_conv3x3_gemm) -- no patch matrix in HBM for the forward or the weight gradient.
+    The data gradient is one GEMM into patch space + one col2im gather kernel (zip_front.hip).
+    weight keeps nn.Conv2d's (Cout,Cin,3,3) layout.  Channel counts that are not multiples of 4
+    use a materialised patch matrix."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, sh, sw):
         _dev(x, weight)
-        x = x.contiguous()
+        x = x.contiguous().float()
         B, H, W, C = x.shape
+        Cout = weight.shape[0]
         Ho, Wo = (H - 3) // sh + 1, (W - 3) // sw + 1
-        s = x.stride()
-        cols = x.as_strided((B, Ho, Wo, 3, 3 * C), (s[0], s[1] * sh, s[2] * sw, s[1], 1)) \
-            .reshape(B * Ho * Wo, 9 * C)
-        w2 = weight.permute(0, 2, 3, 1).reshape(weight.shape[0], 9 * C)         # cout x (kh,kw,cin)
-        y = lt_matmul(0, cols, w2, bias)
-        ctx.save_for_backward(cols, weight)
+        w2 = weight.permute(0, 2, 3, 1).reshape(Cout, 9 * C)                    # cout x (kh,kw,cin)
+        ctx.implicit = _implicit_ok(x, Cout)
+        if ctx.implicit:
+            y = torch.empty((B * Ho * Wo, Cout), dtype=torch.float32, device=x.device)
+            N.profile_note("s2t_conv3x3_gemm", 4.0 * (x.numel() + y.numel()),
+                           2.0 * y.numel() * 9 * C)
+            N.check(N.lib().s2t_conv3x3_gemm(0, N.fp(x), B, H, W, C, sh, sw, Cout, N.fp(w2),
+                                             N.fp(bias), N.fp(y), None, N.stream()),
+                    "s2t_conv3x3_gemm")
+            ctx.save_for_backward(x, weight)
+        else:
+            s = x.stride()
+            cols = x.as_strided((B, Ho, Wo, 3, 3 * C), (s[0], s[1] * sh, s[2] * sw, s[1], 1)) \
+                .reshape(B * Ho * Wo, 9 * C)
+            y = lt_matmul(0, cols, w2, bias)
+            ctx.save_for_backward(cols, weight)
         ctx.cfg = (B, H, W, C, Ho, Wo, sh, sw, bias is not None)
-        return y.view(B, Ho, Wo, weight.shape[0])
+        return y.view(B, Ho, Wo, Cout)
 
     @staticmethod
     def backward(ctx, dy):
-        cols, weight = ctx.saved_tensors
+        xc, weight = ctx.saved_tensors
         B, H, W, C, Ho, Wo, sh, sw, has_bias = ctx.cfg
         Cout = weight.shape[0]
         g = dy.reshape(B * Ho * Wo, Cout)
-        dwmat, db = linear_wgrad(g, cols, has_bias)                              # (Cout, 9C)
-        dweight = dwmat.view(Cout, 3, 3, C).permute(0, 3, 1, 2)
+        g = g if g.is_contiguous() else g.contiguous()
+        if ctx.implicit:
+            dweight, db = _conv3x3_wgrad_implicit(xc, g, sh, sw, has_bias)
+        else:
+            dwmat, db = linear_wgrad(g, xc, has_bias)                            # (Cout, 9C)
+            dweight = dwmat.view(Cout, 3, 3, C).permute(0, 3, 1, 2)
         dx = None
         if ctx.needs_input_grad[0]:
             w2 = weight.permute(0, 2, 3, 1).reshape(Cout, 9 * C)
-            dc = lt_matmul(1, g if g.is_contiguous() else g.contiguous(), w2)   # (B*Ho*Wo, 3*3*C)
+            dc = lt_matmul(1, g, w2)                             # (B*Ho*Wo, 3*3*C)
             dx = torch.empty((B, H, W, C), dtype=torch.float32, device=dy.device)
             N.check(N.lib().s2t_col2im3x3_nhwc(N.fp(dc), B, H, W, C, Ho, Wo, sh, sw, N.fp(dx),
                                                N.stream()), "s2t_col2im3x3_nhwc")
@@ -1354,11 +1396,14 @@ class _Conv3x3S2(torch.autograd.Function):
         CO = w.shape[0]
         Ho, Wo = dy.shape[1], dy.shape[2]
         g = dy.contiguous().float()
-        s = x.stride()
-        cols = x.as_strided((B, Ho, Wo, 3, 3 * C), (s[0], s[1] * 2, s[2] * 2, s[1], 1)) \
-            .reshape(B * Ho * Wo, 9 * C)
-        dwmat, db = linear_wgrad(g.view(B * Ho * Wo, CO), cols, ctx.has_bias)       # (CO, 9C)
-        dweight = dwmat.view(CO, 3, 3, C).permute(0, 3, 1, 2)
+        if _implicit_ok(x, CO):
+            dweight, db = _conv3x3_wgrad_implicit(x, g, 2, 2, ctx.has_bias)
+        else:
+            s = x.stride()
+            cols = x.as_strided((B, Ho, Wo, 3, 3 * C), (s[0], s[1] * 2, s[2] * 2, s[1], 1)) \
+                .reshape(B * Ho * Wo, 9 * C)
+            dwmat, db = linear_wgrad(g.view(B * Ho * Wo, CO), cols, ctx.has_bias)   # (CO, 9C)
+            dweight = dwmat.view(CO, 3, 3, C).permute(0, 3, 1, 2)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)

@@ -306,9 +306,10 @@ def test_dwconv2d_and_conv3x3_nhwc_vs_torch(dev, N_, H, W, C, K):
         torch.testing.assert_close(xg.grad.cpu().double(), xr.grad.permute(0, 1, 2, 3), atol=1e-4, rtol=1e-4)
         torch.testing.assert_close(wg.grad.cpu().double(), wr.grad, atol=2e-3, rtol=2e-4)
         torch.testing.assert_close(bg.grad.cpu().double(), br.grad, atol=2e-3, rtol=2e-4)
-    # 3x3 conv, strides (1,1) and (2,2): im2col GEMM forward, col2im gather backward
-    Cin, Cout = 8, 16
-    for stride in ((1, 1), (2, 2), (1, 2)):
+    # 3x3 conv: implicit-im2col MFMA GEMM forward / weight gradient (s2t_conv3x3_gemm), col2im
+    # gather for the input gradient; (6, 10): channel counts that take the materialised fallback
+    for Cin, Cout, stride in ((8, 16, (1, 1)), (8, 16, (2, 2)), (8, 16, (1, 2)), (32, 128, (1, 2)),
+                              (6, 10, (1, 1))):
         x3 = torch.randn(N_, H, W, Cin, generator=g)
         w3 = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.2
         b3 = torch.randn(Cout, generator=g)
@@ -322,6 +323,7 @@ def test_dwconv2d_and_conv3x3_nhwc_vs_torch(dev, N_, H, W, C, K):
         torch.testing.assert_close(y.detach().cpu().double(), yr.permute(0, 2, 3, 1).detach(), atol=1e-4, rtol=1e-4)
         torch.testing.assert_close(xg.grad.cpu().double(), xr.grad, atol=1e-4, rtol=1e-4)
         torch.testing.assert_close(wg.grad.cpu().double(), wr.grad, atol=2e-3, rtol=2e-4)
+        torch.testing.assert_close(bg.grad.cpu().double(), br.grad, atol=2e-3, rtol=2e-4)
 
 
 @pytest.mark.parametrize("T,B,C,ds", [(37, 3, 64, 2), (64, 2, 96, 4), (101, 4, 128, 8), (5, 1, 32, 4),
