@@ -394,6 +394,25 @@ def test_whiten_backward_vs_oracle(dev, monkeypatch, R, C, G):
         np.testing.assert_allclose(d, r, atol=2e-3 * np.abs(r).max(), rtol=2e-3)
 
 
+def test_whiten_backward_rank_one_input_stays_finite(dev, monkeypatch):
+    """All rows parallel (metric = C, e.g. a freshly initialised projection): d metric / dx
+    vanishes analytically and what the GEMM returns is rounding noise, which the reference (and
+    the product) normalise to grad_scale |g|: the result must stay of that size, never huge."""
+    import random
+    from speech2text_amd.model.layer.scaling import Whiten
+    torch.manual_seed(3)
+    R, C = 990, 192
+    x = torch.randn(R, 1) * torch.randn(1, C) + 0.25
+    w = torch.randn(R, C)
+    monkeypatch.setattr(random, "random", lambda: 0.0)
+    m = Whiten(num_groups=1, whitening_limit=5.0, prob=(0.025, 0.25), grad_scale=0.01).to(dev).train()
+    xg = x.to(dev).requires_grad_(True)
+    (m(xg) * w.to(dev)).sum().backward()
+    d = xg.grad.cpu() - w
+    assert torch.isfinite(d).all()
+    assert float(d.norm()) <= 0.1 * float(w.norm())         # reference: grad_scale |g| = 0.01 |g| of noise
+
+
 @pytest.mark.parametrize("T,B,H,dv", [(495, 3, 4, 12), (496, 3, 4, 12), (248, 2, 4, 12), (5, 1, 2, 4), (3, 2, 1, 4), (124, 2, 8, 12), (62, 3, 4, 12),
                                       (200, 2, 2, 16), (130, 2, 3, 4), (77, 2, 4, 12), (64, 1, 1, 8)])
 def test_attn_apply_both_ways(dev, T, B, H, dv):
