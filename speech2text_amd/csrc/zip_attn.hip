@@ -861,6 +861,94 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_k_mfma_kernel(AttnArgs a,
   }
 }
 
+// dk, shared-operand form: workgroup = (128 keys, b, h), one 32-key tile per wave, ALL waves walk
+// the same query blocks.  The kernel above is bound by the volume of L1 fills, not by the matrix
+// pipe (T = 495: 248 us against a 48 us MFMA floor; without its in-loop global loads 108 us, with
+// them prefetched a block ahead still 259 us): each of a slab's 16 key-tile workgroups re-reads the
+// query-side rows (q, dO_cat, delta -- 9 of the 13 KB a tile needs) for its own use.  Here those
+// rows are fetched ONCE per query block by the whole workgroup (coalesced, a block ahead in
+// registers) into LDS and feed four tiles; only the W tile (and head 0's dW tile) stay per wave.
+// Every wave owns its keys' dk accumulator for the whole loop: no cross-wave reduction, the
+// result leaves as 128-byte row pieces.
+template <int NS>
+__global__ __launch_bounds__(256, 2) void attn_bwd_k3_mfma_kernel(AttnArgs a,
+                                                               const float* __restrict__ W,
+                                                               const float* __restrict__ delta,
+                                                               float* __restrict__ dqkp) {
+  constexpr int NSA = NS > 0 ? NS : 1;
+  constexpr int CDP = 2 * NSA;                                          // <= 32
+  __shared__ float s_Q[32][33];                                         // q[i0+ii][d]
+  __shared__ float s_O[32][33];                                         // dO_cat[i0+ii][k]
+  __shared__ float s_dl[32];
+  int tile_, slab_;
+  if (!slab_tile((a.T + 127) / 128, a.B * a.H, tile_, slab_)) return;
+  const int b = slab_ % a.B, h = slab_ / a.B;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
+  const int j0 = tile_ * 128 + wave * 32;
+  const bool live = j0 < a.T;
+  const float* Wb = W + ((long)h * a.B + b) * a.T * a.T;
+  const float* dWb = a.dW ? a.dW + ((long)h * a.B + b) * a.T * a.T : nullptr;
+  const float* dW0b = (a.dW0 && h == 0) ? a.dW0 + (long)b * a.T * a.T : nullptr;
+  const float* dlb = delta + ((long)h * a.B + b) * a.T;
+  const int qd = a.qd;
+  float bf[NSA];   // V_cat[j0+lo][hi + 2s]
+#pragma unroll
+  for (int s = 0; s < NS; ++s) bf[s] = pair_elem(a, a.pV, j0 + lo, b, h, hi + 2 * s);
+  f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int nib = (a.T + 31) / 32;
+  // register staging of the next query block
+  float rq[4], ro[4], rd = 0.f, wn[16];
+  auto fetch = [&](int i0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = tid + 256 * q, ii = idx >> 5, d = idx & 31;
+      rq[q] = (i0 + ii < a.T && d < qd) ? q_row(a, i0 + ii, b, h)[d] : 0.f;
+      ro[q] = (NS > 0 && d < CDP) ? pair_elem(a, a.pdO, i0 + ii, b, h, d) : 0.f;
+    }
+    if (tid < 32) rd = dlb[min(i0 + tid, a.T - 1)];
+    if (live) load_tile16(Wb, a.T, i0, j0, lo, hi, wn);
+  };
+  fetch(0);
+  for (int ib = 0; ib < nib; ++ib) {
+    const int i0 = ib * 32;
+    __syncthreads();                                   // previous block's tiles fully consumed
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = tid + 256 * q, ii = idx >> 5, d = idx & 31;
+      s_Q[ii][d] = rq[q];
+      s_O[ii][d] = ro[q];
+    }
+    if (tid < 32) s_dl[tid] = rd;
+    __syncthreads();
+    f32x16 ds;
+    float qv[16];
+    if (live) {
+      float af[NSA];
+      f32x16 ndl;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) af[s] = s_O[lo][hi + 2 * s];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        ndl[r] = -s_dl[acc_row(r, hi)];
+        qv[r] = s_Q[acc_row(r, hi)][lo];               // zero beyond qd / T (staged so)
+      }
+      ds = ds_tile<NS>(a, dWb, dW0b, b, i0, j0, lo, hi, af, bf, wn, ndl);
+    }
+    if (ib + 1 < nib) fetch(i0 + 32);                  // lands while this block's products run
+    if (!live) continue;
+    // dk[j][d] += sum_i dS[i][j] q[i][d]: A = dS registers (k = query row), B[k][n = d]
+#pragma unroll
+    for (int s = 0; s < 16; ++s) z = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[s], qv[s], z, 0, 0, 0);
+  }
+  if (!live) return;
+  const int Dp = a.H * (2 * qd + a.pd);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int j = j0 + acc_row(r, hi);
+    if (j < a.T && lo < qd) dqkp[((long)j * a.B + b) * Dp + a.H * qd + h * qd + lo] = z[r];
+  }
+}
+
 // dq, dp and the per-(b,h,query block) partial sums of dpos: workgroup = (128 query rows, b, h),
 // one 32-row block per wave, loop over key blocks.  ws: [b][h][ib][(nj+1)*32][pd]; row u of
 // query block ib belongs to rel = (T-1) - (32 ib + 31) + u.
@@ -1056,7 +1144,11 @@ int launch_attn_bwd_mfma(const AttnArgs& a, const float* W, const float* delta, 
     hipLaunchKernelGGL((attn_bwd_q_mfma_kernel<NS, 8>), gq, dim3(256), 0, st, a, W, delta, dqkp,
                        a.pos ? ws : nullptr);
   S2T_CHECK_LAUNCH();
-  hipLaunchKernelGGL((attn_bwd_k_mfma_kernel<NS>), gk, dim3(256), 0, st, a, W, delta, dqkp);
+  static const bool k_old = getenv("S2T_ATTN_BWD_K_OLD") != nullptr;   // one 32-key tile per workgroup
+  if (k_old)
+    hipLaunchKernelGGL((attn_bwd_k_mfma_kernel<NS>), gk, dim3(256), 0, st, a, W, delta, dqkp);
+  else
+    hipLaunchKernelGGL((attn_bwd_k3_mfma_kernel<NS>), gq, dim3(256), 0, st, a, W, delta, dqkp);
   S2T_CHECK_LAUNCH();
   if (a.pos && a.pd > 0) {
     const int n = (2 * a.T - 1) * a.pd;
