@@ -62,7 +62,21 @@ KERNELS = [
 ]
 
 
+import re
+_GEMM = re.compile(r"gemm_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (true|false)>")
+
+
 def entry_of(kname):
+    # our NT / NN / TN kernel serves several entry points: the plan cache's launches
+    # (s2t_linear_lt, modes 0 / 1), the implicit-im2col convs (PATCH) and the single TN products
+    m = _GEMM.search(kname)
+    if m:
+        mode, patch = int(m.group(3)), m.group(6) == "true"
+        if patch:
+            return ("gemm_kernel", "s2t_conv3x3_gemm", True)
+        if mode in (0, 1):
+            return ("gemm_kernel", "s2t_linear_lt", True)
+        return ("gemm_kernel", "s2t_gemm_f32", True)
     best = None
     for sub, entry, prim in KERNELS:
         if sub in kname and (best is None or len(sub) > len(best[0])):
