@@ -979,11 +979,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_mfma_kernel(AttnArgs a,
   const int nj = (a.T + 31) / 32;
   const bool want_pos = a.pos != nullptr;
   float af[NSA];
-  f32x16 ndl;
+  // -delta of the wave's 32 rows lives in LDS and is re-read per key block: 16 fewer registers
+  // held across the loop (the kernel sits at its 256-VGPR budget and was spilling)
+  __shared__ float s_ndl[4][32];
 #pragma unroll
   for (int s = 0; s < NS; ++s) af[s] = pair_elem(a, a.pdO, i0 + lo, b, h, hi + 2 * s);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) ndl[r] = -dlb[min(i0 + acc_row(r, hi), a.T - 1)];
+  if (lane < 32) s_ndl[wave][lane] = -dlb[min(i0 + lane, a.T - 1)];
   for (int idx = lane; idx < 32 * PD; idx += 64) {
     const int rr = idx / PD, d = idx % PD;
     s_P[wave][rr][d] = (i0 + rr < a.T && d < pd) ? p_row(a, i0 + rr, b, h)[d] : 0.f;
@@ -1040,6 +1041,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_mfma_kernel(AttnArgs a,
       float bf[NSA];
 #pragma unroll
       for (int s = 0; s < NS; ++s) bf[s] = s_V[lo][hi + 2 * s];
+      f32x16 ndl;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ndl[r] = s_ndl[wave][acc_row(r, hi)];
       ds = ds_tile<NS>(a, dWb, dW0b, b, i0, j0, lo, hi, af, bf, wn, ndl);
     }
     if (jb + 1 < nj) fetch(j0 + 32);   // lands while this tile's products run
