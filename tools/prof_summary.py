@@ -40,6 +40,32 @@ def main(src, tag, steps, ms_per_step):
             return "RCCL"
         return "hand-written HIP (libs2t_mi355)"
 
+    # timeline of the window: union of all kernels' intervals (= time with at least one kernel on
+    # the chip), and the gaps between consecutive kernels of the busiest queue (the main stream)
+    iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in sel)
+    union, cur_s, cur_e = 0, iv[0][0], iv[0][1]
+    for a, b in iv[1:]:
+        if a > cur_e:
+            union += cur_e - cur_s
+            cur_s, cur_e = a, b
+        else:
+            cur_e = max(cur_e, b)
+    union += cur_e - cur_s
+    span = iv[-1][1] - iv[0][0]
+    qkey = "Queue_Id" if "Queue_Id" in sel[0] else ("Stream_Id" if "Stream_Id" in sel[0] else None)
+    tl = [f"# timeline: window {span/steps/1e6:.2f} ms/step, some kernel running {union/steps/1e6:.2f} ms/step, "
+          f"chip idle {(span-union)/steps/1e6:.2f} ms/step"]
+    if qkey:
+        byq = collections.defaultdict(list)
+        for r in sel:
+            byq[r[qkey]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+        for q, lst in sorted(byq.items(), key=lambda kv: -len(kv[1]))[:3]:
+            lst.sort()
+            busy = sum(b - a for a, b in lst)
+            gaps = sorted(max(0, lst[i + 1][0] - lst[i][1]) for i in range(len(lst) - 1))
+            short = [g for g in gaps if g < 100000]
+            tl.append(f"# {qkey} {q}: {len(lst)/steps:.0f} launches/step, busy {busy/steps/1e6:.2f} ms/step, "
+                      f"gaps < 100 us: median {short[len(short)//2]/1e3:.1f} us, sum {sum(short)/steps/1e6:.2f} ms/step")
     cls = collections.defaultdict(lambda: [0, 0])
     for k, (d, n) in agg.items():
         c = cls[klass(k)]
@@ -48,6 +74,8 @@ def main(src, tag, steps, ms_per_step):
     with open(os.path.join(out, f"{tag}_timed_region.txt"), "w") as f:
         f.write(f"# kernels whose start lies in the last {steps} steps ({ms_per_step:.1f} ms each) of the trace\n")
         f.write(f"# GPU busy {tot/steps/1e6:.2f} ms/step, {len(sel)/steps:.0f} launches/step\n")
+        for line in tl:
+            f.write(line + "\n")
         for c, (d, n) in sorted(cls.items(), key=lambda x: -x[1][0]):
             f.write(f"# class {c:36s} {d/steps/1e6:8.3f} ms/step {100*d/tot:5.1f}% {n/steps:8.1f} launches/step\n")
         for k, (d, n) in sorted(agg.items(), key=lambda x: -x[1][0])[:70]:
