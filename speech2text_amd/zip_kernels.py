@@ -1265,8 +1265,10 @@ def _conv3x3_wgrad_implicit(x, g, sh, sw, has_bias):
     return dw2.view(Cout, 3, 3, C).permute(0, 3, 1, 2), db
 
 
-def _implicit_ok(x, Cout):
-    return x.is_cuda and x.shape[-1] % 4 == 0 and Cout % 4 == 0 and x.numel() < (1 << 31)
+def _implicit_ok(x, Cout, sh=1, sw=1):
+    B, H, W, C = x.shape
+    rows = B * ((H - 3) // sh + 1) * ((W - 3) // sw + 1)          # patch rows; the kernel wants >= 4
+    return x.is_cuda and C % 4 == 0 and Cout % 4 == 0 and x.numel() < (1 << 31) and rows >= 4
 
 
 class _Conv3x3Nhwc(torch.autograd.Function):
@@ -1285,7 +1287,7 @@ class _Conv3x3Nhwc(torch.autograd.Function):
         Cout = weight.shape[0]
         Ho, Wo = (H - 3) // sh + 1, (W - 3) // sw + 1
         w2 = weight.permute(0, 2, 3, 1).reshape(Cout, 9 * C)                    # cout x (kh,kw,cin)
-        ctx.implicit = _implicit_ok(x, Cout)
+        ctx.implicit = _implicit_ok(x, Cout, sh, sw)
         if ctx.implicit:
             y = torch.empty((B * Ho * Wo, Cout), dtype=torch.float32, device=x.device)
             N.profile_note("s2t_conv3x3_gemm", 4.0 * (x.numel() + y.numel()),
@@ -1396,7 +1398,7 @@ class _Conv3x3S2(torch.autograd.Function):
         CO = w.shape[0]
         Ho, Wo = dy.shape[1], dy.shape[2]
         g = dy.contiguous().float()
-        if _implicit_ok(x, CO):
+        if _implicit_ok(x, CO, 2, 2):
             dweight, db = _conv3x3_wgrad_implicit(x, g, 2, 2, ctx.has_bias)
         else:
             s = x.stride()

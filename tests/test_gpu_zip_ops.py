@@ -255,7 +255,8 @@ def test_linear_wgrad(dev, R, Nf, Mf, bias, stride_pad):
         np.testing.assert_allclose(b.grad.cpu().numpy(), b2.grad.cpu().numpy(), atol=2 * tol, rtol=1e-4)
 
 
-@pytest.mark.parametrize("N_,H,W,C,K", [(3, 37, 19, 128, 7), (2, 9, 5, 70, 7), (5, 130, 19, 64, 3)])
+@pytest.mark.parametrize("N_,H,W,C,K", [(3, 37, 19, 128, 7), (2, 9, 5, 70, 7), (5, 130, 19, 64, 3),
+                                        (1, 3, 5, 8, 3)])     # (one patch row per stride-2 conv: fallback paths)
 def test_dwconv2d_and_conv3x3_nhwc_vs_torch(dev, N_, H, W, C, K):
     """Channel-last frontend convolutions (zip_front.hip: depthwise stencil, its two-stage weight
     gradient, the col2im gather of the 3x3 conv) against torch's NCHW convolutions in fp64."""
