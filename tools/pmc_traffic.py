@@ -89,10 +89,19 @@ def collect(d, counter):
     assert files, f"no counter_collection.csv under {d}"
     tot = collections.defaultdict(float)
     cnt = collections.defaultdict(int)
+    rows = []
     for f in files:
-        for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] != counter:
-                continue
+        rows += [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
+    # only the LAST step of the run: between the last two optimizer-apply dispatches.  The first
+    # step also holds the plan cache's tuning launches (thousands of GEMMs with a different shape
+    # mix), which made the per-launch mean of s2t_linear_lt incomparable with the in-step figure.
+    if rows and "Dispatch_Id" in rows[0]:
+        rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+        marks = [i for i, r in enumerate(rows) if "adam_apply_kernel" in r["Kernel_Name"]]
+        if len(marks) >= 2:
+            rows = rows[marks[-2] + 1:marks[-1] + 1]
+    for f in [None]:
+        for r in rows:
             e = entry_of(r["Kernel_Name"])
             if e is None:
                 continue
@@ -115,7 +124,7 @@ def main(fetch_dir, write_dir, out):
         res[e] = {"launches_sampled": n, "fetch_bytes_raw_per_launch": fetch_raw,
                   "fetch_bytes_x2_per_launch": 2.0 * fetch_raw, "write_bytes_per_launch": write,
                   "hbm_bytes_per_launch": 2.0 * fetch_raw + write,
-                  "note": "mean over the launches of the bench steps; FETCH_SIZE raw and x2 "
+                  "note": "mean over the launches of the last bench step; FETCH_SIZE raw and x2 "
                           "(gfx950 counts 128-byte requests at 64 bytes: calibrated per access "
                           "width with tools/probes/fetch_probe.hip, profiles/r03_fetch_calibration.txt"
                           "), WRITE_SIZE exact"}
