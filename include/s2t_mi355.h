@@ -259,7 +259,10 @@ int s2t_dwconv2d_nhwc_wgrad(const float* x, const float* dy, int N, int H, int W
  * and advances the group state (param_rms, scale_exp_avg_sq [nseg_g], scale_grads [P][nseg_g],
  * model_norms [period], fstate [3] = threshold / last norm / last clip factor, istate [3] =
  * has_threshold / num_clipped / non-finite-median flag); s2t_scaled_adam_apply updates
- * p, delta, exp_avg_sq in place and stores the clipped gradient (or zeros if zero_grad). */
+ * p, delta, exp_avg_sq in place and stores the clipped gradient (or zeros if zero_grad).
+ * skip (s2t_scaled_adam_coef, s2t_adam_apply): NULL, or a DEVICE flag: != 0 makes the step a no-op
+ * on parameters and optimizer state (the gradient is still cleared) -- the data-parallel reducer's
+ * "this step's gradient was dropped on every rank" flag (speech2text_amd/ddp.py), no host sync. */
 int s2t_optim_chunk_elems(void);
 int s2t_optim_segc_floats(void);
 int s2t_seg_stats(const float* p, const float* g, const int* chunk_off, const int* chunk_len,
@@ -272,7 +275,7 @@ int s2t_scaled_adam_coef(const float* partial, const int* seg_chunk_begin, const
                          int clipping_update_period, float bc2, float bc2_size, float beta2c,
                          float* param_rms, float* scale_exp_avg_sq, float* scale_grads,
                          float* model_norms, float* fstate, int* istate, float* segstat,
-                         float* segc, void* stream);
+                         float* segc, const float* skip, void* stream);
 int s2t_scaled_adam_apply(float* p, float* g, float* delta, float* exp_avg_sq,
                           const int* chunk_off, const int* chunk_len, const int* chunk_seg,
                           int nchunks, const float* segc, int zero_grad, void* stream);
@@ -562,7 +565,7 @@ typedef struct S2tAdamGroup {
 int s2t_clip_coef(const float* partial, int nchunks, float clip_val, float* out, void* stream);
 int s2t_adam_apply(float* p, float* g, float* exp_avg, float* exp_avg_sq, const int* chunk_off,
                    const int* chunk_len, int nchunks, int ngroups, const S2tAdamGroup* groups,
-                   const float* coef, int zero_grad, void* stream);
+                   const float* coef, int zero_grad, const float* skip, void* stream);
 
 /* ---- layer-norm LSTM layer of the RNN-T predictor (model/predictor/lstm_predictor.py:28-109 ->
  * torchaudio 0.13.1 _Predictor / _CustomLSTM), whole sequence per launch, one workgroup per
@@ -611,6 +614,34 @@ int s2t_split_planes_frag(const float* src, long ld, int N, int K, int transpose
 int s2t_gemm_x3f_nt(const float* A, long lda, const unsigned short* Bf, float* C, long ldc, int M,
                     int N, int K, const float* bias, const float* resid, long ldr, float beta,
                     int tnw, void* stream);
+
+/* ---- fp32 GEMM on the bf16 matrix cores with the weight operand split ahead of time
+ * (csrc/gemm_x3p.hip): the forward (y = x W^T + b) and data-gradient (dx = g W) products of the
+ * layers' Linears (reference model/encoder/zipformer.py:1924-1975,2372-2378,2643-2695,
+ * model/layer/scaling.py:1512-1583).  The three bf16 pieces of a logical matrix Bm[n][k]
+ * (= src[n*ld + k], or src[k*ld + n] when transposed) are stored fragment-major
+ * [ceil(N/32)][2 ceil(K/32)][3][64 lanes][8], zero-padded: s2t_x3p_plane_elems(N,K) bf16.
+ * s2t_x3p_split: every matrix of a model in ONE launch -- tab = DEVICE array of n S2tPlaneDesc
+ *   (src_off: floats from base; dst_off: bf16 from dst; blk_begin: first block of the descriptor,
+ *   ascending, descriptor d owns s2t_x3p_split_blocks(N,K) blocks), total_blocks = their sum.
+ * s2t_gemm_x3p: C[M,N] = A[M,K] . Bm^T (+ bias[N]) (* act'(act_src[M,N])) (+ resid[M,N]) and
+ *   optionally C2 = act2(C); act kinds 1 = SwooshL, 2 = SwooshR.  K % 8 == 0, N % 4 == 0, rows
+ *   16-byte aligned (else -2).  tile = 0 (from the shape) | 11 | 12 | 21 | 22: block tile
+ *   (64 tm) x (64 tn). */
+typedef struct {
+  long src_off;
+  long dst_off;
+  int N, K, ld, transposed;
+  unsigned blk_begin;
+  int pad_;
+} S2tPlaneDesc;
+long s2t_x3p_plane_elems(int N, int K);
+long s2t_x3p_split_blocks(int N, int K);
+int s2t_x3p_split(const float* base, const void* tab, int n, int total_blocks, unsigned short* dst,
+                  void* stream);
+int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int K, float* C, long ldc,
+                 int M, const float* bias, const float* resid, long ldr, const float* act_src,
+                 long ld_act, int act_kind, float* C2, long ldc2, int act2, int tile, void* stream);
 
 /* ---- side stream for work off the critical path (csrc/streams.hip): the weight-gradient GEMMs
  * of backward overlap the data-gradient chain.  s2t_side_stream returns the library-owned stream;

@@ -1,0 +1,364 @@
+// fp32 GEMM on the bf16 matrix cores with the WEIGHT operand split ahead of time -- the forward
+// (y = x W^T + b) and data-gradient (dx = g W) products of every Linear on the layer path
+// (reference: model/encoder/zipformer.py:1924-1975, 2372-2378, 2643-2695 and
+// model/layer/scaling.py:1512-1583 under loss.backward()).
+//
+//   C[M,N] = A[M,K] . Bm[N,K]^T (+ bias[N]) (* act'(S[M,N])) (+ R[M,N]);   C2 = act(C) (optional)
+//
+// Arithmetic as gemm.hip's X3 path: every fp32 value is the exact sum of three bf16 pieces, six
+// piece products per term on v_mfma_f32_32x32x16_bf16, fp32 accumulation (fp32-level error).
+// What is different here:
+//   * Bm is a parameter.  Its pieces are written ONCE per optimizer step (s2t_x3p_split: one launch
+//     for every weight of the model, both orientations) in fragment-major order
+//     [N/32][K/16][3][64 lanes][8 bf16]: the 1 KB one MFMA B operand needs is contiguous, a k-chunk
+//     of a column tile is one 6 KB run.  Staging B is a straight 16-byte copy global -> LDS and a
+//     fragment is ONE conflict-free ds_read_b128; no VALU work on the weight side at all.
+//   * A (activations / gradients, fp32 row-major) is split ONCE per element, when the staged
+//     registers are written to LDS, into the same fragment-major image (gemm.hip splits every
+//     fragment again in each of the two waves that read it): the split costs a quarter of the VALU
+//     cycles and the main loop is {12 ds_read_b128, 24 MFMA} per 16-deep step.
+//   * the epilogue carries the layer's elementwise neighbours: bias, residual, the activation's
+//     derivative (data gradient through Swoosh) and a second output act(C) (the kept activation).
+// Workgroup = 4 waves (2 x 2), block tile (64 TM) x (64 TN), k chunks of 32, register-prefetched.
+#include "common.h"
+#include "../../include/s2t_mi355.h"
+#include <cstdint>
+#include <cstdlib>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// (x0, x1) -> three packed bf16 pairs, exact: x = p0 + p1 + p2 to 24 bits
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& p0, unsigned& p1,
+                                           unsigned& p2) {
+  f32x2 x = {x0, x1};
+  p0 = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+  f32x2 h = {__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xFFFF0000u)};
+  x = x - h;
+  p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+  f32x2 h1 = {__uint_as_float(p1 << 16), __uint_as_float(p1 & 0xFFFF0000u)};
+  x = x - h1;
+  p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+}
+__device__ __forceinline__ void split8(const float4& v0, const float4& v1, uint4& q0, uint4& q1,
+                                       uint4& q2) {
+  split_pair(v0.x, v0.y, q0.x, q1.x, q2.x);
+  split_pair(v0.z, v0.w, q0.y, q1.y, q2.y);
+  split_pair(v1.x, v1.y, q0.z, q1.z, q2.z);
+  split_pair(v1.z, v1.w, q0.w, q1.w, q2.w);
+}
+
+enum { ACT_NONE = 0, ACT_SWOOSH_L = 1, ACT_SWOOSH_R = 2 };
+
+__device__ __forceinline__ float log1p_fast(float e) {   // as zip_elem.hip
+  const float u = 1.f + e;
+  return u == 1.f ? e : __logf(u) * __fdividef(e, u - 1.f);
+}
+__device__ __forceinline__ float swoosh(float x, int kind) {
+  // log(1 + exp(x - off)) - 0.08 x - c   (scaling.py:1340-1343, 1418-1423); as zip_elem.hip swoosh_f
+  const float off = kind == ACT_SWOOSH_L ? 4.f : 1.f;
+  const float c = kind == ACT_SWOOSH_L ? 0.035f : 0.313261687f;
+  const float z = x - off;
+  return fmaxf(z, 0.f) + log1p_fast(__expf(-fabsf(z))) - 0.08f * x - c;
+}
+__device__ __forceinline__ float swoosh_deriv(float x, int kind) {
+  const float off = kind == ACT_SWOOSH_L ? 4.f : 1.f;
+  return __fdividef(1.f, 1.f + __expf(off - x)) - 0.08f;
+}
+
+struct X3P {
+  const float* A;
+  long lda;
+  const unsigned short* Bp;   // fragment-major pieces [NT][KB][3][64][8], KB even
+  int NT, KB;
+  float* C;
+  long ldc;
+  int M, N, K;
+  const float* bias;          // [N] or NULL
+  const float* resid;         // [M][N] added last, or NULL
+  long ldr;
+  const float* act_src;       // C *= act'(act_src[m][n]) (before the residual), or NULL
+  long lds;
+  int act_kind;
+  float* C2;                  // C2 = act2(C) or NULL
+  long ldc2;
+  int act2;
+  int tiles_m, tiles_n;
+};
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256, 2) void x3p_kernel(X3P g) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int A_BYTES = 2 * TM * 2 * 3 * 1024, B_BYTES = 2 * TN * 2 * 3 * 1024;
+  constexpr int NB = 3 * TN;                 // 16-byte pieces of the B chunk per thread
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[A_BYTES + B_BYTES];
+  unsigned char* const sA = smem;
+  unsigned char* const sB = smem + A_BYTES;
+
+  // XCD-aware tile order (as gemm.hip): blocks of one XCD walk a contiguous range of tiles, n fastest
+  const int total = g.tiles_m * g.tiles_n;
+  const int per_xcd = (total + 7) / 8;
+  const int lin = (int)((blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3));
+  if (lin >= total) return;
+  const int tm = lin / g.tiles_n, tn = lin % g.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wrb = (wave >> 1) * TM, wcb = (wave & 1) * TN;   // wave's first row block / column block
+
+  // A units: (row r, k-eighth kq) = 8 consecutive k of one row = one lane's share of a fragment.
+  // 16 consecutive threads take 16 different rows at the same kq (conflict-free 16-byte LDS
+  // stores); the four kq of a row sit in one wave-instruction (whole 128-byte lines).
+  const float* asrc[TM];
+  int a_k[TM];
+  unsigned a_dst[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int u = tid + 256 * i;
+    const int r = (u & 15) + 16 * (u >> 6), kq = (u >> 4) & 3;
+    const int row = min(m0 + r, g.M - 1);
+    asrc[i] = g.A + (long)row * g.lda + 8 * kq;
+    a_k[i] = 8 * kq;
+    a_dst[i] = (unsigned)((((((r >> 5) * 2 + (kq >> 1)) * 3) * 64) + (kq & 1) * 32 + (r & 31)) * 16);
+  }
+  // B pieces: the chunk of column tile nt is one 6 KB run of the plane image; copied lane-linear
+  const uint4* bsrc[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int idx = tid + 256 * i;
+    const int seg = idx / 384, off = idx - seg * 384;
+    const int nt = min((n0 >> 5) + seg, g.NT - 1);
+    bsrc[i] = reinterpret_cast<const uint4*>(g.Bp + (long)nt * g.KB * 1536) + off;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[TM][2];
+  uint4 rb[NB];
+  const int nchunks = g.KB >> 1;
+  auto load = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const float* p = asrc[i] + ((32 * c + a_k[i] < g.K) ? 32 * c : 0);
+      ra[i][0] = *reinterpret_cast<const float4*>(p);
+      ra[i][1] = *reinterpret_cast<const float4*>(p + 4);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) rb[i] = bsrc[i][(long)c * 384];
+  };
+  load(0);
+  for (int c = 0; c < nchunks; ++c) {
+    __syncthreads();                         // previous chunk fully consumed
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      uint4 q0, q1, q2;
+      split8(ra[i][0], ra[i][1], q0, q1, q2);
+      if (32 * c + a_k[i] >= g.K) q0 = q1 = q2 = make_uint4(0u, 0u, 0u, 0u);
+      *reinterpret_cast<uint4*>(sA + a_dst[i]) = q0;
+      *reinterpret_cast<uint4*>(sA + a_dst[i] + 1024) = q1;
+      *reinterpret_cast<uint4*>(sA + a_dst[i] + 2048) = q2;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) *reinterpret_cast<uint4*>(sB + (tid + 256 * i) * 16) = rb[i];
+    __syncthreads();
+    if (c + 1 < nchunks) load(c + 1);        // next chunk's global loads fly under the MFMAs
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 fa[TM][3], fb[TN][3];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          fa[i][p] = *reinterpret_cast<const bf16x8*>(sA + ((((wrb + i) * 2 + s) * 3 + p) * 64 + lane) * 16);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          fb[j][p] = *reinterpret_cast<const bf16x8*>(sB + ((((wcb + j) * 2 + s) * 3 + p) * 64 + lane) * 16);
+      // smallest terms first; consecutive MFMAs go to different accumulators
+#define X3P_TERM(PA, PB)                                                                        \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA], fb[j][PB], acc[i][j], 0, 0, 0);
+      X3P_TERM(2, 0) X3P_TERM(1, 1) X3P_TERM(0, 2) X3P_TERM(1, 0) X3P_TERM(0, 1) X3P_TERM(0, 0)
+#undef X3P_TERM
+    }
+  }
+
+  // ---- epilogue: lane holds column (lane & 31), rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of each
+  // 32 x 32 tile; 16 rows at a time go through a per-wave LDS scratch and leave as 16-byte rows
+  const int hi = lane >> 5, lo = lane & 31;
+  __syncthreads();                                   // all waves finished reading sA / sB
+  float* scr = reinterpret_cast<float*>(smem) + wave * (16 * 36);
+  const int er = lane >> 3, ec = (lane & 7) * 4;     // this lane's row (of 8) and column quad
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + 32 * (wcb + j) + ec;
+      const bool cok = col < g.N;
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (g.bias && cok) bv = *reinterpret_cast<const float4*>(g.bias + col);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {                  // rows 16 h .. 16 h + 15 of the tile
+        float4 rv[2], sv[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int row = min(m0 + 32 * (wrb + i) + 16 * h + er + 8 * q, g.M - 1);
+          rv[q] = (g.resid && cok) ? *reinterpret_cast<const float4*>(g.resid + (long)row * g.ldr + col)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+          sv[q] = (g.act_src && cok) ? *reinterpret_cast<const float4*>(g.act_src + (long)row * g.lds + col)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+          scr[((r & 3) + 8 * (r >> 2) + 4 * hi) * 36 + lo] = acc[i][j][8 * h + r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int row = m0 + 32 * (wrb + i) + 16 * h + er + 8 * q;
+          float4 v = *reinterpret_cast<const float4*>(scr + (er + 8 * q) * 36 + ec);
+          v = make_float4(v.x + bv.x, v.y + bv.y, v.z + bv.z, v.w + bv.w);
+          if (g.act_src) {
+            v.x *= swoosh_deriv(sv[q].x, g.act_kind);
+            v.y *= swoosh_deriv(sv[q].y, g.act_kind);
+            v.z *= swoosh_deriv(sv[q].z, g.act_kind);
+            v.w *= swoosh_deriv(sv[q].w, g.act_kind);
+          }
+          v = make_float4(v.x + rv[q].x, v.y + rv[q].y, v.z + rv[q].z, v.w + rv[q].w);
+          if (row < g.M && cok) {
+            *reinterpret_cast<float4*>(g.C + (long)row * g.ldc + col) = v;
+            if (g.C2)
+              *reinterpret_cast<float4*>(g.C2 + (long)row * g.ldc2 + col) =
+                  make_float4(swoosh(v.x, g.act2), swoosh(v.y, g.act2), swoosh(v.z, g.act2),
+                              swoosh(v.w, g.act2));
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+}
+
+// ---- the weights' pieces, all matrices of a model in one launch.  Descriptor d covers blocks
+// [blk_begin[d], blk_begin[d+1]); a wave = one (column tile nt, k block kb) = three 1 KB fragments.
+__global__ __launch_bounds__(256) void x3p_split_kernel(const float* __restrict__ base,
+                                                        const S2tPlaneDesc* __restrict__ tab, int n,
+                                                        unsigned short* __restrict__ dst) {
+  int lo_d = 0, hi_d = n - 1;
+  while (lo_d < hi_d) {                       // last descriptor whose blk_begin <= blockIdx.x
+    const int mid = (lo_d + hi_d + 1) >> 1;
+    if (tab[mid].blk_begin <= blockIdx.x) lo_d = mid; else hi_d = mid - 1;
+  }
+  const S2tPlaneDesc d = tab[lo_d];
+  const int NT = (d.N + 31) >> 5, KB = 2 * ((d.K + 31) >> 5);
+  const long q = (long)(blockIdx.x - d.blk_begin) * 4 + (threadIdx.x >> 6);
+  if (q >= (long)NT * KB) return;
+  const int nt = (int)(q / KB), kb = (int)(q - (long)nt * KB);
+  const int lane = threadIdx.x & 63, lo = lane & 31, hi = lane >> 5;
+  const int nn = 32 * nt + lo, k0 = 16 * kb + 8 * hi;
+  const float* src = base + d.src_off;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = k0 + e;
+    const bool ok = nn < d.N && k < d.K;
+    const long a = d.transposed ? (long)(ok ? k : 0) * d.ld + (ok ? nn : 0)
+                                : (long)(ok ? nn : 0) * d.ld + (ok ? k : 0);
+    const float x = src[a];
+    v[e] = ok ? x : 0.f;
+  }
+  uint4 q0, q1, q2;
+  split_pair(v[0], v[1], q0.x, q1.x, q2.x);
+  split_pair(v[2], v[3], q0.y, q1.y, q2.y);
+  split_pair(v[4], v[5], q0.z, q1.z, q2.z);
+  split_pair(v[6], v[7], q0.w, q1.w, q2.w);
+  unsigned short* o = dst + d.dst_off + (((long)nt * KB + kb) * 3 * 64 + lane) * 8;
+  *reinterpret_cast<uint4*>(o) = q0;
+  *reinterpret_cast<uint4*>(o + 512) = q1;
+  *reinterpret_cast<uint4*>(o + 1024) = q2;
+}
+
+template <int TM, int TN>
+void launch_x3p(X3P& g, hipStream_t st) {
+  g.tiles_m = (g.M + 64 * TM - 1) / (64 * TM);
+  g.tiles_n = (g.N + 64 * TN - 1) / (64 * TN);
+  const int total = g.tiles_m * g.tiles_n;
+  hipLaunchKernelGGL((x3p_kernel<TM, TN>), dim3(((total + 7) / 8) * 8), dim3(256), 0, st, g);
+}
+
+// block tile from the shape: the widest tile that still gives the chip >= ~2 rounds of workgroups
+int pick_tile(int M, int N) {
+  static int force = -1;      // S2T_X3P_TILE = 11 | 12 | 21 | 22: tuning
+  if (force < 0) { const char* e = getenv("S2T_X3P_TILE"); force = e ? atoi(e) : 0; }
+  if (force > 0) return force;
+  const long t22 = (long)((M + 127) / 128) * ((N + 127) / 128);
+  if (t22 >= 768) return 22;
+  const long t21 = (long)((M + 127) / 128) * ((N + 63) / 64);
+  if (N <= 64 || t21 >= 640) return 21;
+  const long t12 = (long)((M + 63) / 64) * ((N + 127) / 128);
+  if (t12 >= 640 && N > 64) return 12;
+  return 11;
+}
+
+}  // namespace
+
+extern "C" {
+
+long s2t_x3p_plane_elems(int N, int K) {
+  if (N <= 0 || K <= 0) return 0;
+  return 3L * 512 * ((N + 31) / 32) * (2L * ((K + 31) / 32));
+}
+
+long s2t_x3p_split_blocks(int N, int K) {
+  if (N <= 0 || K <= 0) return 0;
+  return (((long)((N + 31) / 32) * (2L * ((K + 31) / 32))) + 3) / 4;
+}
+
+int s2t_x3p_split(const float* base, const void* tab, int n, int total_blocks, unsigned short* dst,
+                  void* stream) {
+  if (n <= 0 || total_blocks <= 0) return 0;
+  if (!base || !tab || !dst || (reinterpret_cast<uintptr_t>(dst) & 15)) return -1;
+  hipLaunchKernelGGL(x3p_split_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                     base, reinterpret_cast<const S2tPlaneDesc*>(tab), n, dst);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int K, float* C, long ldc,
+                 int M, const float* bias, const float* resid, long ldr, const float* act_src,
+                 long ld_act, int act_kind, float* C2, long ldc2, int act2, int tile, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || !A || !Bp || !C) return -1;
+  if (act_kind < 0 || act_kind > 2 || act2 < 0 || act2 > 2 || (act_src && act_kind == 0) ||
+      (C2 && act2 == 0))
+    return -1;
+  if (tile != 0 && tile != 11 && tile != 12 && tile != 21 && tile != 22) return -1;
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  if ((K & 7) || (N & 3) || (lda & 3) || (ldc & 3) || !al16(A) || !al16(Bp) || !al16(C) ||
+      (bias && !al16(bias)) || (resid && (!al16(resid) || (ldr & 3))) ||
+      (act_src && (!al16(act_src) || (ld_act & 3))) || (C2 && (!al16(C2) || (ldc2 & 3))))
+    return -2;
+  X3P g{A, lda, Bp, (N + 31) / 32, 2 * ((K + 31) / 32), C, ldc, M, N, K, bias, resid, ldr, act_src,
+        ld_act, act_kind, C2, ldc2, act2, 0, 0};
+  hipStream_t st = (hipStream_t)stream;
+  if (tile == 0) tile = pick_tile(M, N);
+  switch (tile) {
+    case 22: launch_x3p<2, 2>(g, st); break;
+    case 21: launch_x3p<2, 1>(g, st); break;
+    case 12: launch_x3p<1, 2>(g, st); break;
+    default: launch_x3p<1, 1>(g, st); break;
+  }
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

@@ -71,6 +71,7 @@ struct CoefArgs {
   int* istate;                 // [0] has_threshold [1] num_clipped [2] non-finite median flag
   float* segstat;              // [nseg_all][3] scratch
   float* segc;                 // [nseg_all][kSegC] out
+  const float* skip;           // device flag or NULL: != 0 -> this step leaves parameters and state alone
 };
 
 __device__ __forceinline__ bool nan_less(float a, float b) {   // torch.sort order: NaN last
@@ -85,6 +86,16 @@ __global__ __launch_bounds__(256) void scaled_adam_coef_kernel(CoefArgs A) {
   __shared__ float sh_thr;
   const int tid = threadIdx.x;
   const int ng = A.seg_hi - A.seg_lo;
+  if (A.skip != nullptr && A.skip[0] != 0.f) {
+    // the data-parallel reducer dropped this step's gradient on every rank (ddp.py: a parameter
+    // fired after its bucket had left): no norm is recorded, no moment decays, apply only clears
+    // the gradient.  The (p . g) sample of this step counts as 0.
+    for (int s = A.seg_lo + tid; s < A.seg_hi; s += 256) {
+      A.scale_grads[(long)(A.step % A.size_update_period) * ng + (s - A.seg_lo)] = 0.f;
+      A.segc[(long)s * kSegC + 9] = 2.f;
+    }
+    return;
+  }
   // ---- per-tensor sums (each thread walks its tensors' chunks in order)
   for (int s = A.seg_lo + tid; s < A.seg_hi; s += 256) {
     float a = 0.f, b = 0.f, c = 0.f;
@@ -218,9 +229,9 @@ __global__ __launch_bounds__(256) void scaled_adam_apply_kernel(
   const long off = chunk_off[b];
   const int len = chunk_len[b];
   const float* o = segc + (long)chunk_seg[b] * kSegC;
-  if (o[9] == 0.f) {
-    // trainable tensor that no optimizer group lists: it is never updated, but its gradient must
-    // not pile up across steps (it would keep growing the global clip norm)
+  if (o[9] != 1.f) {
+    // 0: trainable tensor that no optimizer group lists: it is never updated, but its gradient must
+    // not pile up across steps (it would keep growing the global clip norm); 2: dropped step
     if (zero_grad) {
       float4* z4 = reinterpret_cast<float4*>(g + off);
       for (int i = threadIdx.x; i < (len >> 2); i += 256) z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -294,10 +305,11 @@ struct AdamGroups {
 __global__ __launch_bounds__(256) void adam_apply_kernel(
     float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
     const int* __restrict__ chunk_off, const int* __restrict__ chunk_len, AdamGroups G,
-    const float* __restrict__ coef, int zero_grad) {
+    const float* __restrict__ coef, int zero_grad, const float* __restrict__ skip) {
   const int b = blockIdx.x;
   int q = 0;
   while (q < G.n && b >= G.chunk_hi[q]) ++q;
+  if (skip != nullptr && skip[0] != 0.f) q = G.n;   // dropped step (ddp.py): only clear the gradient
   const long off = chunk_off[b];
   const int len = chunk_len[b];
   float4* g4 = reinterpret_cast<float4*>(g + off);
@@ -352,7 +364,7 @@ int s2t_clip_coef(const float* partial, int nchunks, float clip_val, float* out,
 
 int s2t_adam_apply(float* p, float* g, float* exp_avg, float* exp_avg_sq, const int* chunk_off,
                    const int* chunk_len, int nchunks, int ngroups, const S2tAdamGroup* groups,
-                   const float* coef, int zero_grad, void* stream) {
+                   const float* coef, int zero_grad, const float* skip, void* stream) {
   if (nchunks <= 0 || ngroups < 0 || ngroups > S2T_ADAM_MAX_GROUPS) return -1;
   AdamGroups G;
   G.n = ngroups;
@@ -368,7 +380,7 @@ int s2t_adam_apply(float* p, float* g, float* exp_avg, float* exp_avg_sq, const 
     G.decoupled[q] = groups[q].decoupled;
   }
   hipLaunchKernelGGL(adam_apply_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, p, g,
-                     exp_avg, exp_avg_sq, chunk_off, chunk_len, G, coef, zero_grad);
+                     exp_avg, exp_avg_sq, chunk_off, chunk_len, G, coef, zero_grad, skip);
   S2T_CHECK_LAUNCH();
   return 0;
 }
@@ -393,14 +405,14 @@ int s2t_scaled_adam_coef(const float* partial, const int* seg_chunk_begin, const
                          int clipping_update_period, float bc2, float bc2_size, float beta2c,
                          float* param_rms, float* scale_exp_avg_sq, float* scale_grads,
                          float* model_norms, float* fstate, int* istate, float* segstat,
-                         float* segc, void* stream) {
+                         float* segc, const float* skip, void* stream) {
   if (seg_hi <= seg_lo || clipping_update_period < 1 || clipping_update_period > 1024 ||
       size_update_period < 1)
     return -1;
   CoefArgs A{partial, seg_chunk_begin, seg_len, nchunks_all, seg_lo, seg_hi, lr, beta1, beta2, eps,
              scalar_lr_scale, param_min_rms, param_max_rms, scalar_max, clip_val, clipping_scale,
              step, size_update_period, clipping_update_period, bc2, bc2_size, beta2c, param_rms,
-             scale_exp_avg_sq, scale_grads, model_norms, fstate, istate, segstat, segc};
+             scale_exp_avg_sq, scale_grads, model_norms, fstate, istate, segstat, segc, skip};
   hipLaunchKernelGGL(scaled_adam_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, A);
   S2T_CHECK_LAUNCH();
   return 0;

@@ -14,7 +14,10 @@ that skips a step defers its bucket (and the later ones) to finish(); a paramete
 for the first time AFTER its bucket went out cannot be merged into a collective that is already
 in flight, so that step's gradient is zeroed on EVERY rank (the ranks agree through a flag that
 rides in the step's scalar all-reduce -- no rank raises, none is left waiting in a collective),
-`dropped_steps` counts it, and from the next step on the parameter is waited for.
+the same device flag makes the optimizer step a no-op on parameters and state (`last_drop` ->
+`optimizer.skip_flag`, read by the kernels, no host sync; the host-side step count and the LR
+schedule still advance by one), `dropped_steps` counts it (the trainer logs it), and from the
+next step on the parameter is waited for.
 
 Two forms of the exchange (`algo`):
   "allreduce"  one in-place all-reduce(SUM) per bucket, then a divide over the whole bucket;
@@ -82,6 +85,7 @@ class GradReducer:
         self._late = set()                           # fired after their bucket was launched
         self.dropped_steps = 0                       # steps whose gradient was zeroed (see above)
         self._drop_flags = []                        # device flags of recent steps (read lazily)
+        self.last_drop = None                        # device flag of the last finish(): > 0 = dropped
         self._next = 0                               # next bucket to launch (fixed order)
         self._hooks = []
         if self.active:
@@ -174,6 +178,7 @@ class GradReducer:
     def finish(self, extra: Optional[torch.Tensor] = None):
         """After backward: reduce whatever was not launched by the hooks, wait, average.
         `extra` (1-D tensor of logged scalars) is mean-reduced along with the gradients."""
+        self.last_drop = None
         if not self.active:
             return extra
         while self._next < len(self.buckets):
@@ -193,9 +198,11 @@ class GradReducer:
             dist.all_reduce(pack, op=dist.ReduceOp.SUM, group=self.pg)
         if self.overlap and self._pending is not None:
             # zero the step on every rank if any rank fired late (device-side: no host sync)
-            keep = (pack[n_extra:] == 0).to(fg.dtype)
-            fg.mul_(keep)
-            self._drop_flags.append(pack[n_extra:])
+            # (masked fill, not a multiply: the late write raced with the collective in flight, so
+            # the buffer can hold inf / NaN, and 0 * NaN stays NaN)
+            self.last_drop = pack[n_extra:]
+            fg.masked_fill_(self.last_drop > 0, 0.0)
+            self._drop_flags.append(self.last_drop)
             if len(self._drop_flags) > 64:
                 self.poll_dropped()
         if extra is not None:
@@ -230,3 +237,4 @@ class GradReducer:
 def broadcast_parameters(store, src: int = 0, process_group=None):
     if dist.is_initialized() and dist.get_world_size(process_group) > 1:
         dist.broadcast(store.flat_p, src=src, group=process_group)
+        store.epoch += 1                   # parameters rewritten: the weights' bf16 pieces are stale

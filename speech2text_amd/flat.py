@@ -9,11 +9,13 @@ launches, and the data-parallel reducer all-reduces slices of the same gradient 
 A model has ONE store (the trainer creates it, ordered by optimizer param group); optimizer
 param groups are contiguous tensor ranges [seg_lo, seg_hi) of it.
 """
+import weakref
 from typing import List
 
 import torch
 
 _OWNER = {}          # id(param) -> (store, index)
+_OWNER_PTR = {}      # device address of a parameter's storage -> weakref(store)  (planes.py)
 CHUNK = 8192         # elements per optimizer workgroup (== s2t_optim_chunk_elems())
 _PAD = 4             # tensors start on 16-byte boundaries (float4 lanes)
 
@@ -48,9 +50,12 @@ class FlatStore:
                     g.copy_(p.grad)
                 p.grad = g
                 _OWNER[id(p)] = (self, i)
+                _OWNER_PTR[p.data_ptr()] = weakref.ref(self)
         self.seg_lengths = torch.tensor(self.lengths, dtype=torch.int64, device=dev)
         self._tables = None
         self.on_grad = None          # callback(index): set by the data-parallel reducer
+        self.epoch = 0               # bumped by whoever rewrites flat_p through raw pointers
+        self.arena = None            # planes.PlaneArena: bf16 pieces of the weight matrices
 
     def alive(self, p):
         i = _OWNER[id(p)][1]

@@ -34,6 +34,9 @@ class _FlatMixin:
     def _flat_setup(self):
         self.pre_clip = None
         self.zero_grad_in_step = False
+        # device flag (1 float) or None: != 0 turns this step into a no-op on parameters and state
+        # (set by the trainer from the DP reducer's "step dropped on every rank" flag; no host sync)
+        self.skip_flag = None
         self._flat = None
 
     def _flat_init(self):
@@ -79,6 +82,10 @@ class _FlatMixin:
         if self._flat is None:
             self._flat_init()
         if self._flat is False:
+            if self.skip_flag is not None and float(self.skip_flag) != 0.0:
+                if self.zero_grad_in_step:   # dropped step (ddp.py), host form: CPU tensors only
+                    self.zero_grad(set_to_none=False)
+                return None
             if self.pre_clip:
                 params = [p for g in self.param_groups for p in g["params"] if p.grad is not None]
                 torch.nn.utils.clip_grad_norm_(params, self.pre_clip)
@@ -117,8 +124,10 @@ class _FlatMixin:
         N.check(L.s2t_adam_apply(N.fp(st.flat_p), N.fp(st.flat_g), N.fp(f["m"]), N.fp(f["v"]),
                                  N.ip(tb["chunk_off"]), N.ip(tb["chunk_len"]), tb["nchunks"],
                                  len(self.param_groups), ctypes.cast(arr, ctypes.c_void_p),
-                                 N.fp(f["coef"]), int(self.zero_grad_in_step), stream),
+                                 N.fp(f["coef"]), int(self.zero_grad_in_step), N.fp(self.skip_flag),
+                                 stream),
                 "s2t_adam_apply")
+        st.epoch += 1                      # parameters rewritten: weight pieces are stale
         for p in st.params:
             s = self.state.get(p)
             if s is not None:

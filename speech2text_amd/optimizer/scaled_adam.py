@@ -44,6 +44,9 @@ class ScaledAdam(Optimizer):
         self.store = None
         self.pre_clip = None          # trainer's gradient_clip_val (norm), applied inside step()
         self.zero_grad_in_step = False
+        # device flag (1 float) or None: != 0 turns this step into a no-op on parameters and state
+        # (set by the trainer from the DP reducer's "step dropped on every rank" flag; no host sync)
+        self.skip_flag = None
         self.last_clip = None
 
     # ------------------------------------------------------------------ state
@@ -102,6 +105,9 @@ class ScaledAdam(Optimizer):
         st.check_views()
         if st.flat_p.is_cuda:
             self._step_hip()
+        elif self.skip_flag is not None and float(self.skip_flag) != 0.0:
+            if self.zero_grad_in_step:       # dropped step (ddp.py), host form: CPU tensors only
+                st.flat_g.zero_()
         else:
             self._step_torch()
         return loss
@@ -142,7 +148,8 @@ class ScaledAdam(Optimizer):
                 float(self.pre_clip or 0.0), float(cs or 0.0), k, h["P"], period, h["bc2"],
                 h["bc2_size"], h["beta2c"], N.fp(s["param_rms"]), N.fp(s["scale_exp_avg_sq"]),
                 N.fp(s["scale_grads"]), N.fp(s["model_norms"]), N.fp(s["fstate"]),
-                N.ip(s["istate"]), N.fp(self._segstat), N.fp(self._segc), stream),
+                N.ip(s["istate"]), N.fp(self._segstat), N.fp(self._segc), N.fp(self.skip_flag),
+                stream),
                 "s2t_scaled_adam_coef")
             if cs is not None and k > 0 and (k % period == 0 or (k in (10, 20, 40) and k < period)):
                 rare.append(s)
@@ -158,6 +165,7 @@ class ScaledAdam(Optimizer):
                                         N.ip(tb["chunk_len"]), N.ip(tb["chunk_seg"]), tb["nchunks"],
                                         N.fp(self._segc), int(self.zero_grad_in_step), stream),
                 "s2t_scaled_adam_apply")
+        st.epoch += 1                      # parameters rewritten: weight pieces are stale
 
     # ---- the same arithmetic as torch ops (CPU tensors: host-logic tests)
     def _step_torch(self):

@@ -27,6 +27,7 @@ class Trainer:
         self.bucket_bytes = int(float(bucket_mb) * (1 << 20))
         self.micro = 0
         self.task = None
+        self.log_every = int(unused.get("log_every_n_steps", 50))     # Lightning's default
 
     # ------------------------------------------------------------------
     def setup(self, task, device=None):
@@ -113,11 +114,16 @@ class Trainer:
             if on_gpu:
                 zk.side_sync()        # weight gradients of this step are complete before we read
             self._clip()
+            if self.reducer.active and hasattr(self.optimizer, "skip_flag"):
+                self.optimizer.skip_flag = self.reducer.last_drop
             self.optimizer.step()
             self.scheduler.step()
             if not self.fused:
                 self.store.zero_grad()
             task.global_step += 1
+            if self.reducer.active and task.global_step % self.log_every == 0:
+                # folds the recorded device flags (one host read per log_every steps)
+                task.logged["dropped_steps"] = float(self.reducer.poll_dropped())
         return loss.detach()
 
     def fit(self, task, batches, device=None):

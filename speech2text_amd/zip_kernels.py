@@ -12,6 +12,7 @@ import torch.nn.functional as F
 
 from . import _native as N
 from . import flat
+from . import planes
 
 _SW = {True: (4.0, 0.035), False: (1.0, 0.313261687)}   # SwooshL / SwooshR (offset, constant)
 
@@ -1128,6 +1129,48 @@ def _rows(t):
     if t2.stride(1) != 1 or t2.stride(0) < t2.shape[1] or t2.dtype != torch.float32:
         t2 = t2.contiguous().float()
     return t2
+
+
+_ACTK = {None: 0, "swoosh_l": 1, "swoosh_r": 2}
+X3P = {"on": os.environ.get("S2T_X3P", "1") == "1", "calls": 0, "tile": 0}
+
+
+def x3p_matmul(mode, x2, w2, bias=None, resid2=None, act_src=None, act_kind=None, act2=None, tile=0):
+    """The same products as lt_matmul on our bf16x3 kernel with pre-split weight pieces
+    (csrc/gemm_x3p.hip, planes.py): mode 0: x2 (R,K) w2 (N,K)^T (+bias) -> (R,N); mode 1: x2 (R,N)
+    w2 (N,K) -> (R,K); then (* act'(act_src)) (+ resid2); with act2 a second output act2(result).
+    Returns None when the weight has no pieces (not in a FlatStore / shape outside the kernel's
+    rules) -- the caller takes the library path."""
+    pp = planes.pieces(w2, mode)
+    if pp is None:
+        return None
+    R = x2.shape[0]
+    Nf, Kf = w2.shape
+    cols, inner = (Nf, Kf) if mode == 0 else (Kf, Nf)
+    if x2.stride(0) % 4 or x2.data_ptr() % 16 or (bias is not None and bias.data_ptr() % 16) \
+            or (resid2 is not None and (resid2.stride(0) % 4 or resid2.data_ptr() % 16)) \
+            or (act_src is not None and (act_src.stride(0) % 4 or act_src.data_ptr() % 16)):
+        return None
+    out = torch.empty((R, cols), dtype=torch.float32, device=x2.device)
+    out2 = torch.empty_like(out) if act2 is not None else None
+    if R == 0:
+        return out if out2 is None else (out, out2)
+    N.profile_note("s2t_gemm_x3p", 4.0 * (R * (Nf + Kf) + (R * cols if resid2 is not None else 0)
+                                          + (R * cols if act_src is not None else 0)
+                                          + (R * cols if out2 is not None else 0)) + 6.0 * Nf * Kf,
+                   2.0 * R * Nf * Kf)
+    rc = N.lib().s2t_gemm_x3p(N.raw(x2, torch.float32), x2.stride(0), ctypes.c_void_p(pp), cols, inner,
+                              N.fp(out), cols, R, N.fp(bias),
+                              None if resid2 is None else N.raw(resid2, torch.float32),
+                              0 if resid2 is None else resid2.stride(0),
+                              None if act_src is None else N.raw(act_src, torch.float32),
+                              0 if act_src is None else act_src.stride(0), _ACTK[act_kind],
+                              N.fp(out2), cols, _ACTK[act2], tile or X3P["tile"], N.stream())
+    if rc == -2:
+        return None
+    N.check(rc, "s2t_gemm_x3p")
+    X3P["calls"] += 1
+    return out if out2 is None else (out, out2)
 
 
 def lt_matmul(mode, x2, w2, bias=None, resid2=None, out_shape=None):

@@ -161,3 +161,85 @@ def test_late_parameter_does_not_hang_or_raise():
         assert dropped == 1, (rank, dropped)
         assert ok_last, f"rank {rank}: gradients after the drop differ from the 2-rank average"
         assert gate_abs > 0, "the late parameter's gradient is averaged from then on (rank 1 too)"
+
+
+def _late4_worker(rank, world, port, q):
+    """World 4, two parameters that begin to fire late on DIFFERENT ranks at DIFFERENT steps; the
+    late rank's gradient buffer also holds a NaN (the late write races with the collective already
+    in flight): every rank must zero that step's gradient (NaN included), the optimizer step of a
+    dropped step must leave parameters and optimizer state alone, and later steps must be the
+    4-rank average."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from speech2text_amd.ddp import GradReducer, broadcast_parameters
+    from speech2text_amd.flat import FlatStore
+    from speech2text_amd.optimizer.scaled_adam import ScaledAdam
+    torch.manual_seed(5)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16),
+                              torch.nn.Tanh(), torch.nn.Linear(16, 3))
+    gate_a = torch.nn.Parameter(torch.ones(6))          # last in the store -> first bucket
+    gate_b = torch.nn.Parameter(torch.ones(6))
+    params = list(net.parameters()) + [gate_b, gate_a]
+    opt = ScaledAdam(params, lr=0.02, clipping_scale=None)
+    opt.zero_grad_in_step = True
+    store = opt.store if getattr(opt, "store", None) is not None else FlatStore(params)
+    broadcast_parameters(store)
+    red = GradReducer(store, bucket_bytes=4 * 100)
+    g = torch.Generator().manual_seed(13)
+    xs = torch.randn(world, 8, 6, generator=g)
+    ys = torch.randn(world, 8, 3, generator=g)
+
+    def loss_fn(r, step):
+        x = xs[r]
+        if step >= 2 and r == 1:
+            x = x * gate_a                               # used first in forward: gradient comes last
+        if step >= 4 and r == 3:
+            x = x * gate_b
+        return ((net(x) - ys[r]) ** 2).mean()
+
+    norms, moved, flags = [], [], []
+    for step in range(7):
+        red.prepare()
+        loss_fn(rank, step).backward()
+        if red._late:                                    # what the race can leave behind
+            store.flat_g[store.offsets[-1]] = float("nan")
+        red.finish()
+        norms.append(float(store.flat_g.abs().sum()))
+        flags.append(float(red.last_drop) if red.last_drop is not None else 0.0)
+        before = store.flat_p.clone()
+        opt.skip_flag = red.last_drop
+        opt.step()
+        moved.append(float((store.flat_p - before).abs().sum()))
+    dropped = red.poll_dropped()
+    # replicas must still be identical (every rank applied the same updates)
+    mine = store.flat_p.clone()
+    ref = mine.clone()
+    dist.broadcast(ref, src=0)
+    q.put((rank, norms, moved, flags, dropped, bool(torch.equal(mine, ref)),
+           bool(torch.isfinite(store.flat_p).all())))
+    dist.destroy_process_group()
+
+
+def test_world4_uneven_late_parameters_drop_steps_cleanly():
+    """VERDICT r3 item 8 / ADVICE r3: late parameters on different ranks at different steps, a NaN
+    left in the buffer by the race, optimizer step of a dropped step is a no-op."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_late4_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, norms, moved, flags, dropped, same, finite in res:
+        assert dropped == 2, (rank, dropped, flags)
+        for step in range(7):
+            if step in (2, 4):
+                assert flags[step] > 0 and norms[step] == 0.0, (rank, step, norms, flags)
+                assert moved[step] == 0.0, f"rank {rank}: dropped step {step} moved the parameters"
+            else:
+                assert flags[step] == 0.0 and norms[step] > 0 and moved[step] > 0, (rank, step)
+        assert same, f"rank {rank}: replicas diverged"
+        assert finite
