@@ -185,6 +185,29 @@ def _zcfg(ec):
                 cnn_module_kernel=tup(ec["cnn_module_kernel"]), pos_dim=ec["pos_dim"])
 
 
+def _fbank_one(args):
+    """Worker of fbank_reference_style (top level: picklable for the spawn context)."""
+    from oracle import fbank as ofb
+    pcm, scale, high = args
+    return ofb.fbank(pcm * scale, 80, high_freq=high).shape[0]
+
+
+def fbank_reference_style(pcm, seconds, scale=32768.0, high=-400.0, workers=4):
+    """The frontend timed the way the reference runs it: one call per
+    utterance inside the DataLoader's worker processes (config `num_workers: 4`,
+    task_factory/ctc_task.py:100) -- here the oracle's numpy fbank in 4 spawned processes (spawn:
+    this process has already initialised the GPU), pool start-up excluded.  -> audio-s/s."""
+    import multiprocessing as mp
+    jobs = [(p, scale, high) for p in pcm]
+    with mp.get_context("spawn").Pool(workers) as pool:
+        pool.map(_fbank_one, jobs[:workers])                     # warm the workers (imports)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            pool.map(_fbank_one, jobs, chunksize=1)
+        dt = (time.perf_counter() - t0) / 3
+    return len(jobs) * seconds / dt
+
+
 def cpu_baseline(cfg, state_dict, seconds=10.0, batch=8, n_labels=50, vocab=500, steps=3,
                  warmup=1):
     """Times the ORACLE train step on the host cores: numpy fbank, torch-CPU zipformer fwd+bwd
@@ -234,12 +257,20 @@ def cpu_baseline(cfg, state_dict, seconds=10.0, batch=8, n_labels=50, vocab=500,
         if it >= warmup:
             times.append(dt)
     med = float(np.median(times))
-    return {"value": batch * seconds / med, "unit": "audio-seconds/sec", "cores": nthreads,
-            "kind": "port",
-            "sample": f"{batch} x {seconds:g}s utterances, {warmup} warm-up + {steps} timed steps "
-                      f"(median {med:.2f} s) of the oracle C3 train step (numpy fbank + torch-CPU "
-                      f"zipformer fwd/bwd + C/torch k2-style losses; parity unpinned for the k2 "
-                      f"part), loss={float(loss.detach()):.4f}"}
+    out = {"value": batch * seconds / med, "unit": "audio-seconds/sec", "cores": nthreads,
+           "kind": "port",
+           "sample": f"{batch} x {seconds:g}s utterances, {warmup} warm-up + {steps} timed steps "
+                     f"(median {med:.2f} s) of the oracle C3 train step (numpy fbank + torch-CPU "
+                     f"zipformer fwd/bwd + C/torch k2-style losses; parity unpinned for the k2 "
+                     f"part), loss={float(loss.detach()):.4f}"}
+    try:
+        out["fbank_per_utterance_4_workers"] = {
+            "value": fbank_reference_style(pcm, seconds), "unit": "audio-seconds/sec", "workers": 4,
+            "sample": f"oracle numpy fbank, one call per utterance in 4 worker processes "
+                      f"(reference DataLoader style), {batch} x {seconds:g}s, 3 passes"}
+    except Exception as e:                                  # never fatal for the bench line
+        out["fbank_per_utterance_4_workers"] = {"value": None, "sample": f"failed: {e}"}
+    return out
 
 
 def cpu_baseline_c2(cfg, state_dict, seconds=10.0, batch=4, n_labels=40, vocab=128, steps=3,
@@ -449,6 +480,15 @@ def roofline_report(prof_timed, prof_all, want, step_flops, ms_per_step, sampled
     return out
 
 
+def gemm_paths():
+    """Which code served the forward / data-gradient products of this process so far: our
+    pre-split-weight kernel, the plan cache's choice (hipBLASLt or the round-3 kernel), and the
+    ATen fallback (a shape hipBLASLt had no algorithm for) -- the last must stay 0 on the bench."""
+    from speech2text_amd import zip_kernels as zk
+    return {"x3p_calls": int(zk.X3P["calls"]), "lt_calls": int(zk.LT_STATS["calls"]),
+            "lt_own_calls": int(zk.lt_own_calls()), "aten_fallbacks": int(zk.LT_STATS["aten_fallbacks"])}
+
+
 # ------------------------------------------------------------------ launcher
 def self_launch(args, argv):
     """--gpus N>1 outside a launcher: start N ranks in child processes (this parent never
@@ -509,6 +549,11 @@ def parse_args(argv=None):
     ap.add_argument("--roofline-kernel", default=DEFAULT_ROOFLINE_KERNEL)
     ap.add_argument("--profile-steps", type=int, default=2,
                     help="extra untimed steps with every entry point bracketed by HIP events")
+    ap.add_argument("--accum", type=int, default=1,
+                    help="accumulate_grad_batches (the YAML trains with 20, "
+                         "config/training/zipformer_stateless_pruned_rnnt.yaml:124): a step is "
+                         "still ONE micro-batch pass (fbank+fwd+bwd); the gradient exchange, clip "
+                         "and optimizer run on every accum-th step; --steps should be a multiple")
     ap.add_argument("--random-chunk", action="store_true",
                     help="C3 only: the shipped YAML's chunk_size [16, 32, 64, -1] / "
                          "left_context_frames [64, 128, 256, -1] (one draw per step) instead of -1")
@@ -565,6 +610,8 @@ def main(argv=None):
         # config/training/zipformer_stateless_pruned_rnnt.yaml:65-66
         cfg["encoder"]["config"].update({"chunk_size": [16, 32, 64, -1],
                                          "left_context_frames": [64, 128, 256, -1]})
+    if args.accum > 1:
+        cfg["trainer"]["accumulate_grad_batches"] = int(args.accum)
     random.seed(1234 + rank)
     np.random.seed(1234 + rank)
     torch.manual_seed(1234)                                 # same init on every rank
@@ -664,8 +711,8 @@ def main(argv=None):
         name = {"C3": "zipformer pruned-RNN-T", "C2": "conformer-CTC",
                 "C4": "conformer CTC_Hybrid_Rnnt", "C5": "conformer BEST-RQ SSL"}[args.config]
         workload = {
-            "C3": "C3 zipformer-stateless pruned-RNN-T train step (fbank+fwd+bwd+allreduce+ScaledAdam),"
-                  " 500 BPE, prune_range 5, chunk_size -1",
+            "C3": "C3 zipformer pruned-RNN-T train step: chunk_size -1, 500 BPE, prune_range 5 "
+                  "(fbank+fwd+bwd+allreduce+ScaledAdam)",
             "C2": "C2 conformer-CTC train step (fbank+fwd+bwd+allreduce+AdamW), 12 layers d=256, V=128",
             "C4": "C4 CTC_Hybrid_Rnnt train step (fbank+conformer 12x256+CTC head+LSTM predictor+"
                   "unpruned joiner w/ out-projection+RNN-T lattice loss, 0.8/0.2), V=128",
@@ -677,8 +724,10 @@ def main(argv=None):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": workload + (" [random chunk_size 16/32/64/-1 per step]"
-                                               if args.random_chunk else ""),
+            "config": {"workload": (workload.replace("chunk_size -1", "chunk_size 16/32/64/-1 random per step")
+                                    if args.random_chunk else workload),
+                       "accumulate_grad_batches": args.accum,
+                       "gemm_paths": gemm_paths(),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "utterance_seconds": args.seconds, "labels_per_utt": args.labels,
                        "parallelism": f"dp{world}", "final_loss": final_loss},

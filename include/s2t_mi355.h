@@ -627,7 +627,7 @@ int s2t_gemm_x3f_nt(const float* A, long lda, const unsigned short* Bf, float* C
  * s2t_gemm_x3p: C[M,N] = A[M,K] . Bm^T (+ bias[N]) (* act'(act_src[M,N])) (+ resid[M,N]) and
  *   optionally C2 = act2(C); act kinds 1 = SwooshL, 2 = SwooshR.  K % 8 == 0, N % 4 == 0, rows
  *   16-byte aligned (else -2).  tile = 0 (from the shape) | 11 | 12 | 21 | 22: block tile
- *   (64 tm) x (64 tn). */
+ *   (64 tm) x (64 tn); + 100 w: w persistent workgroups per CU (tuning). */
 typedef struct {
   long src_off;
   long dst_off;

@@ -22,6 +22,7 @@
 // Workgroup = 4 waves (2 x 2), block tile (64 TM) x (64 TN), k chunks of 32, register-prefetched.
 #include "common.h"
 #include "../../include/s2t_mi355.h"
+#include <algorithm>
 #include <cstdint>
 #include <cstdlib>
 
@@ -31,6 +32,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// staging registers are native vectors (first-class values): HIP's float4 / uint4 are structs, and a
+// select between two of them goes through the stack
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // (x0, x1) -> three packed bf16 pairs, exact: x = p0 + p1 + p2 to 24 bits
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& p0, unsigned& p1,
@@ -44,12 +49,16 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& p0, uns
   x = x - h1;
   p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
 }
-__device__ __forceinline__ void split8(const float4& v0, const float4& v1, uint4& q0, uint4& q1,
-                                       uint4& q2) {
-  split_pair(v0.x, v0.y, q0.x, q1.x, q2.x);
-  split_pair(v0.z, v0.w, q0.y, q1.y, q2.y);
-  split_pair(v1.x, v1.y, q0.z, q1.z, q2.z);
-  split_pair(v1.z, v1.w, q0.w, q1.w, q2.w);
+__device__ __forceinline__ void split8(const f32x4 v0, const f32x4 v1, u32x4& q0, u32x4& q1,
+                                       u32x4& q2) {
+  unsigned a0, a1, a2, b0, b1, b2, c0, c1, c2, d0, d1, d2;
+  split_pair(v0.x, v0.y, a0, a1, a2);
+  split_pair(v0.z, v0.w, b0, b1, b2);
+  split_pair(v1.x, v1.y, c0, c1, c2);
+  split_pair(v1.z, v1.w, d0, d1, d2);
+  q0 = u32x4{a0, b0, c0, d0};
+  q1 = u32x4{a1, b1, c1, d1};
+  q2 = u32x4{a2, b2, c2, d2};
 }
 
 enum { ACT_NONE = 0, ACT_SWOOSH_L = 1, ACT_SWOOSH_R = 2 };
@@ -88,111 +97,27 @@ struct X3P {
   long ldc2;
   int act2;
   int tiles_m, tiles_n;
+  int wgs_per_cu;             // persistent form: workgroups per CU (0 = default)
+  int prio;                   // 1: wave priority by the workgroup's slot on its CU (see x3p_set_prio)
 };
 
+// The workgroups of a one-round grid start together and, left alone, run in lockstep: all of a CU's
+// workgroups multiply at the same time (sharing the matrix pipe) and then all store at the same
+// time (matrix pipe idle, HBM write-bound).  A static wave priority by the workgroup's slot on its
+// CU (HW_ID.TG_ID) lets slot 0 win the issue arbitration: it finishes its main loop first and its
+// stores drain under the other slots' MFMAs, and so on down the slots.
+__device__ __forceinline__ void x3p_set_prio(int on) {
+  if (!on) return;
+  const unsigned tg = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (16 << 6) | 4) & 15u;   // HW_ID.TG_ID
+  if (tg == 0) __builtin_amdgcn_s_setprio(3);
+  else if (tg == 1) __builtin_amdgcn_s_setprio(2);
+  else if (tg == 2) __builtin_amdgcn_s_setprio(1);
+}
+
+// ---- epilogue shared by the kernels below: bias, act' of a saved tensor, residual, second output
 template <int TM, int TN>
-__global__ __launch_bounds__(256, 2) void x3p_kernel(X3P g) {
-  constexpr int BM = 64 * TM, BN = 64 * TN;
-  constexpr int A_BYTES = 2 * TM * 2 * 3 * 1024, B_BYTES = 2 * TN * 2 * 3 * 1024;
-  constexpr int NB = 3 * TN;                 // 16-byte pieces of the B chunk per thread
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[A_BYTES + B_BYTES];
-  unsigned char* const sA = smem;
-  unsigned char* const sB = smem + A_BYTES;
-
-  // XCD-aware tile order (as gemm.hip): blocks of one XCD walk a contiguous range of tiles, n fastest
-  const int total = g.tiles_m * g.tiles_n;
-  const int per_xcd = (total + 7) / 8;
-  const int lin = (int)((blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3));
-  if (lin >= total) return;
-  const int tm = lin / g.tiles_n, tn = lin % g.tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wrb = (wave >> 1) * TM, wcb = (wave & 1) * TN;   // wave's first row block / column block
-
-  // A units: (row r, k-eighth kq) = 8 consecutive k of one row = one lane's share of a fragment.
-  // 16 consecutive threads take 16 different rows at the same kq (conflict-free 16-byte LDS
-  // stores); the four kq of a row sit in one wave-instruction (whole 128-byte lines).
-  const float* asrc[TM];
-  int a_k[TM];
-  unsigned a_dst[TM];
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int u = tid + 256 * i;
-    const int r = (u & 15) + 16 * (u >> 6), kq = (u >> 4) & 3;
-    const int row = min(m0 + r, g.M - 1);
-    asrc[i] = g.A + (long)row * g.lda + 8 * kq;
-    a_k[i] = 8 * kq;
-    a_dst[i] = (unsigned)((((((r >> 5) * 2 + (kq >> 1)) * 3) * 64) + (kq & 1) * 32 + (r & 31)) * 16);
-  }
-  // B pieces: the chunk of column tile nt is one 6 KB run of the plane image; copied lane-linear
-  const uint4* bsrc[NB];
-#pragma unroll
-  for (int i = 0; i < NB; ++i) {
-    const int idx = tid + 256 * i;
-    const int seg = idx / 384, off = idx - seg * 384;
-    const int nt = min((n0 >> 5) + seg, g.NT - 1);
-    bsrc[i] = reinterpret_cast<const uint4*>(g.Bp + (long)nt * g.KB * 1536) + off;
-  }
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  float4 ra[TM][2];
-  uint4 rb[NB];
-  const int nchunks = g.KB >> 1;
-  auto load = [&](int c) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const float* p = asrc[i] + ((32 * c + a_k[i] < g.K) ? 32 * c : 0);
-      ra[i][0] = *reinterpret_cast<const float4*>(p);
-      ra[i][1] = *reinterpret_cast<const float4*>(p + 4);
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) rb[i] = bsrc[i][(long)c * 384];
-  };
-  load(0);
-  for (int c = 0; c < nchunks; ++c) {
-    __syncthreads();                         // previous chunk fully consumed
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      uint4 q0, q1, q2;
-      split8(ra[i][0], ra[i][1], q0, q1, q2);
-      if (32 * c + a_k[i] >= g.K) q0 = q1 = q2 = make_uint4(0u, 0u, 0u, 0u);
-      *reinterpret_cast<uint4*>(sA + a_dst[i]) = q0;
-      *reinterpret_cast<uint4*>(sA + a_dst[i] + 1024) = q1;
-      *reinterpret_cast<uint4*>(sA + a_dst[i] + 2048) = q2;
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) *reinterpret_cast<uint4*>(sB + (tid + 256 * i) * 16) = rb[i];
-    __syncthreads();
-    if (c + 1 < nchunks) load(c + 1);        // next chunk's global loads fly under the MFMAs
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bf16x8 fa[TM][3], fb[TN][3];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-          fa[i][p] = *reinterpret_cast<const bf16x8*>(sA + ((((wrb + i) * 2 + s) * 3 + p) * 64 + lane) * 16);
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-          fb[j][p] = *reinterpret_cast<const bf16x8*>(sB + ((((wcb + j) * 2 + s) * 3 + p) * 64 + lane) * 16);
-      // smallest terms first; consecutive MFMAs go to different accumulators
-#define X3P_TERM(PA, PB)                                                                        \
-  _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA], fb[j][PB], acc[i][j], 0, 0, 0);
-      X3P_TERM(2, 0) X3P_TERM(1, 1) X3P_TERM(0, 2) X3P_TERM(1, 0) X3P_TERM(0, 1) X3P_TERM(0, 0)
-#undef X3P_TERM
-    }
-  }
-
+__device__ __forceinline__ void x3p_epilogue(const X3P& g, f32x16 (&acc)[TM][TN], unsigned char* smem,
+                                             int m0, int n0, int wrb, int wcb, int wave, int lane) {
   // ---- epilogue: lane holds column (lane & 31), rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of each
   // 32 x 32 tile; 16 rows at a time go through a per-wave LDS scratch and leave as 16-byte rows
   const int hi = lane >> 5, lo = lane & 31;
@@ -249,6 +174,296 @@ __global__ __launch_bounds__(256, 2) void x3p_kernel(X3P g) {
     }
 }
 
+template <int TM, int TN>
+__global__ __launch_bounds__(256, 2) void x3p_kernel(X3P g) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int A_BYTES = 2 * TM * 2 * 3 * 1024, B_BYTES = 2 * TN * 2 * 3 * 1024;
+  constexpr int NB = 3 * TN;                 // 16-byte pieces of the B chunk per thread
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[A_BYTES + B_BYTES];
+  unsigned char* const sA = smem;
+  unsigned char* const sB = smem + A_BYTES;
+
+  // XCD-aware tile order (as gemm.hip): blocks of one XCD walk a contiguous range of tiles, n fastest
+  const int total = g.tiles_m * g.tiles_n;
+  const int per_xcd = (total + 7) / 8;
+  const int lin = (int)((blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3));
+  if (lin >= total) return;
+  const int tm = lin / g.tiles_n, tn = lin % g.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wrb = (wave >> 1) * TM, wcb = (wave & 1) * TN;   // wave's first row block / column block
+  x3p_set_prio(g.prio);
+
+  // A units: (row r, k-eighth kq) = 8 consecutive k of one row = one lane's share of a fragment.
+  // 16 consecutive threads take 16 different rows at the same kq (conflict-free 16-byte LDS
+  // stores); the four kq of a row sit in one wave-instruction (whole 128-byte lines).
+  const float* asrc[TM];
+  int a_k[TM];
+  unsigned a_dst[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int u = tid + 256 * i;
+    const int r = (u & 15) + 16 * (u >> 6), kq = (u >> 4) & 3;
+    const int row = min(m0 + r, g.M - 1);
+    asrc[i] = g.A + (long)row * g.lda + 8 * kq;
+    a_k[i] = 8 * kq;
+    a_dst[i] = (unsigned)((((((r >> 5) * 2 + (kq >> 1)) * 3) * 64) + (kq & 1) * 32 + (r & 31)) * 16);
+  }
+  // B pieces: the chunk of column tile nt is one 6 KB run of the plane image; copied lane-linear
+  const u32x4* bsrc[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int idx = tid + 256 * i;
+    const int seg = idx / 384, off = idx - seg * 384;
+    const int nt = min((n0 >> 5) + seg, g.NT - 1);
+    bsrc[i] = reinterpret_cast<const u32x4*>(g.Bp + (long)nt * g.KB * 1536) + off;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // k chunks of 32: registers hold chunk c+1 while chunk c is multiplied.  The loads are
+  // unconditional (past the end the last chunk is fetched again and dropped): no branch around the
+  // staging registers, so they stay registers.
+  f32x4 ra[TM][2];
+  u32x4 rb[NB];
+  const int nchunks = g.KB >> 1;
+#define X3P_LOAD(C)                                                                          \
+  {                                                                                          \
+    const int cc_ = min((C), nchunks - 1);                                                   \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                         \
+      const bool v_ = 32 * cc_ + a_k[i] < g.K;                                               \
+      const float* p_ = asrc[i] + (v_ ? 32 * cc_ : 0);                                       \
+      const f32x4 z_ = {0.f, 0.f, 0.f, 0.f};                                                 \
+      const f32x4 x0_ = *reinterpret_cast<const f32x4*>(p_);                                 \
+      const f32x4 x1_ = *reinterpret_cast<const f32x4*>(p_ + 4);                             \
+      ra[i][0] = v_ ? x0_ : z_;                                                              \
+      ra[i][1] = v_ ? x1_ : z_;                                                              \
+    }                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < NB; ++i) rb[i] = bsrc[i][(long)cc_ * 384];         \
+  }
+  X3P_LOAD(0)
+  for (int c = 0; c < nchunks; ++c) {
+    u32x4 qa[TM][3];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) split8(ra[i][0], ra[i][1], qa[i][0], qa[i][1], qa[i][2]);
+    __syncthreads();                         // previous chunk fully consumed
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(sA + a_dst[i] + 1024 * p) = qa[i][p];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) *reinterpret_cast<u32x4*>(sB + (tid + 256 * i) * 16) = rb[i];
+    __syncthreads();
+    X3P_LOAD(c + 1)                          // next chunk's global loads fly under the MFMAs
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 fa[TM][3], fb[TN][3];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          fa[i][p] = *reinterpret_cast<const bf16x8*>(sA + ((((wrb + i) * 2 + s) * 3 + p) * 64 + lane) * 16);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          fb[j][p] = *reinterpret_cast<const bf16x8*>(sB + ((((wcb + j) * 2 + s) * 3 + p) * 64 + lane) * 16);
+      // smallest terms first; consecutive MFMAs go to different accumulators
+#define X3P_TERM(PA, PB)                                                                        \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA], fb[j][PB], acc[i][j], 0, 0, 0);
+      X3P_TERM(2, 0) X3P_TERM(1, 1) X3P_TERM(0, 2) X3P_TERM(1, 0) X3P_TERM(0, 1) X3P_TERM(0, 0)
+#undef X3P_TERM
+    }
+  }
+#undef X3P_LOAD
+  x3p_epilogue<TM, TN>(g, acc, smem, m0, n0, wrb, wcb, wave, lane);
+}
+
+// ---- software-pipelined form: k stages of 16, TWO LDS stages, one barrier per stage.  Iteration kb
+// {barrier; split + store the staged registers (stage kb+1) into the other buffer; request stage
+// kb+2 from global memory; multiply stage kb} -- a wave's staging VALU / LDS stores and its MFMAs
+// belong to the same barrier interval, so the matrix pipe of a SIMD is fed by every resident wave
+// all the time instead of by whichever workgroup happens to be in its "multiply" phase (the
+// two-barrier form above runs the workgroups of a CU in lockstep: all stage, then all multiply).
+template <int TM, int TN>
+__global__ __launch_bounds__(256, 2) void x3p_db_kernel(X3P g) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int A_ST = 2 * TM * 3 * 1024, B_ST = 2 * TN * 3 * 1024, ST = A_ST + B_ST;
+  constexpr int NAU = (128 * TM + 255) / 256;       // A units (8 k of one row) per thread and stage
+  constexpr int NBU = (384 * TN + 255) / 256;       // B 16-byte pieces per thread and stage
+  constexpr int SCR = 4 * 16 * 36 * 4;              // epilogue scratch
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * ST > SCR ? 2 * ST : SCR];
+
+  // PERSISTENT workgroups: the grid is (a multiple of 8, at most) what the chip holds at once; a
+  // workgroup walks tiles loc, loc + stride, ... of its XCD's contiguous range (n fastest: the
+  // n-tiles of an m-panel share that XCD's L2 copy of the A panel).  The output stores of tile t
+  // drain while tile t+1 is multiplied: stage 0 of the next tile is requested BEFORE the stores are
+  // issued, so its wait (vmcnt counts loads and stores in issue order) does not include them.
+  const int total = g.tiles_m * g.tiles_n;
+  const int per_xcd = (total + 7) / 8;
+  const int xcd = blockIdx.x & 7, stride = gridDim.x >> 3;
+  int loc = blockIdx.x >> 3;
+  if (loc >= per_xcd || xcd * per_xcd + loc >= total) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wrb = (wave >> 1) * TM, wcb = (wave & 1) * TN;
+  x3p_set_prio(g.prio);
+
+  // A unit u: row r = (u & 15) + 16 (u >> 5), k half kq = (u >> 4) & 1: 16 consecutive lanes store 16
+  // consecutive fragment slots (conflict-free), both halves of a row's 64 bytes in one instruction
+  int a_r[NAU], a_k[NAU];
+  unsigned a_dst[NAU];
+  bool a_on[NAU];
+#pragma unroll
+  for (int i = 0; i < NAU; ++i) {
+    const int u = tid + 256 * i;
+    a_on[i] = u < 128 * TM;
+    const int uu = a_on[i] ? u : 0;
+    const int r = (uu & 15) + 16 * (uu >> 5), kq = (uu >> 4) & 1;
+    a_r[i] = r;
+    a_k[i] = 8 * kq;
+    a_dst[i] = (unsigned)((((r >> 5) * 3) * 64 + kq * 32 + (r & 31)) * 16);
+  }
+  int b_seg[NBU], b_off[NBU];
+  bool b_on[NBU];
+#pragma unroll
+  for (int i = 0; i < NBU; ++i) {
+    const int idx = tid + 256 * i;
+    b_on[i] = idx < 384 * TN;
+    const int ii = b_on[i] ? idx : 0;
+    b_seg[i] = ii / 192;
+    b_off[i] = ii - b_seg[i] * 192;
+  }
+  const float* asrc[NAU];
+  const u32x4* bsrc[NBU];
+  int m0, n0;
+#define X3P_TILE(LOC)                                                                        \
+  {                                                                                          \
+    const int lin_ = xcd * per_xcd + (LOC);                                                  \
+    const int tm_ = lin_ / g.tiles_n, tn_ = lin_ - tm_ * g.tiles_n;                          \
+    m0 = tm_ * BM;                                                                           \
+    n0 = tn_ * BN;                                                                           \
+    _Pragma("unroll") for (int i = 0; i < NAU; ++i)                                          \
+      asrc[i] = g.A + (long)min(m0 + a_r[i], g.M - 1) * g.lda + a_k[i];                      \
+    _Pragma("unroll") for (int i = 0; i < NBU; ++i) {                                        \
+      const int nt_ = min((n0 >> 5) + b_seg[i], g.NT - 1);                                   \
+      bsrc[i] = reinterpret_cast<const u32x4*>(g.Bp + (long)nt_ * g.KB * 1536) + b_off[i];   \
+    }                                                                                        \
+  }
+
+  const int nst = (g.K + 15) >> 4;                  // stages (the pieces are zero beyond K)
+  // TWO sets of staging registers: stage kb+2 is requested at the TOP of iteration kb into the set
+  // that iteration kb-1 emptied, while iteration kb splits / stores the other set (stage kb+1): a
+  // load has a whole iteration (24 MFMAs, a barrier) before its data is touched.
+  f32x4 ra[2][NAU][2];
+  u32x4 rb[2][NBU];
+  u32x4 qa[NAU][3];
+  // global -> registers, unconditional (past the end the last stage again; a k tail is read from
+  // the row's start and zeroed when it is split): nothing here waits for the data
+#define X3P_LOAD(SET, S)                                                                     \
+  {                                                                                          \
+    const int ss_ = min((S), nst - 1);                                                       \
+    _Pragma("unroll") for (int i = 0; i < NAU; ++i) {                                        \
+      const float* p_ = asrc[i] + ((16 * ss_ + a_k[i] < g.K) ? 16 * ss_ : 0);               \
+      ra[SET][i][0] = *reinterpret_cast<const f32x4*>(p_);                                   \
+      ra[SET][i][1] = *reinterpret_cast<const f32x4*>(p_ + 4);                               \
+    }                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < NBU; ++i) rb[SET][i] = bsrc[i][(long)ss_ * 192];   \
+  }
+#define X3P_SPLIT(SET, S)                                                                    \
+  {                                                                                          \
+    const int ss_ = min((S), nst - 1);                                                       \
+    _Pragma("unroll") for (int i = 0; i < NAU; ++i) {                                        \
+      const bool v_ = 16 * ss_ + a_k[i] < g.K;                                               \
+      const f32x4 z_ = {0.f, 0.f, 0.f, 0.f};                                                 \
+      split8(v_ ? ra[SET][i][0] : z_, v_ ? ra[SET][i][1] : z_, qa[i][0], qa[i][1], qa[i][2]); \
+    }                                                                                        \
+  }
+#define X3P_STORE(SET, BUF)                                                                  \
+  {                                                                                          \
+    unsigned char* const sa_ = smem + (BUF) * ST;                                            \
+    unsigned char* const sb_ = sa_ + A_ST;                                                   \
+    _Pragma("unroll") for (int i = 0; i < NAU; ++i)                                          \
+      if (NAU * 256 == 128 * TM || a_on[i]) {                                                \
+        *reinterpret_cast<u32x4*>(sa_ + a_dst[i]) = qa[i][0];                                \
+        *reinterpret_cast<u32x4*>(sa_ + a_dst[i] + 1024) = qa[i][1];                         \
+        *reinterpret_cast<u32x4*>(sa_ + a_dst[i] + 2048) = qa[i][2];                         \
+      }                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < NBU; ++i)                                          \
+      if (NBU * 256 == 384 * TN || b_on[i])                                                  \
+        *reinterpret_cast<u32x4*>(sb_ + (tid + 256 * i) * 16) = rb[SET][i];                  \
+  }
+#define X3P_TERM(PA, PB)                                                                        \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA], fb[j][PB], acc[i][j], 0, 0, 0);
+  // one stage: CUR = the register set that holds stage KB+1, NXT = the set stage KB+2 goes into
+#define X3P_ITER(KB, CUR, NXT)                                                               \
+  {                                                                                          \
+    __syncthreads(); /* stage KB is in LDS for everyone; the other buffer's readers are done */ \
+    X3P_LOAD(NXT, (KB) + 2)                                                                  \
+    const unsigned char* const sa = smem + ((KB) & 1) * ST;                                  \
+    const unsigned char* const sb = sa + A_ST;                                               \
+    bf16x8 fa[TM][3], fb[TN][3];                                                             \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int p = 0; p < 3; ++p) \
+      fa[i][p] = *reinterpret_cast<const bf16x8*>(sa + (((wrb + i) * 3 + p) * 64 + lane) * 16); \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) _Pragma("unroll") for (int p = 0; p < 3; ++p) \
+      fb[j][p] = *reinterpret_cast<const bf16x8*>(sb + (((wcb + j) * 3 + p) * 64 + lane) * 16); \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    /* (1) the two smallest product groups with the split of stage KB+1's A registers in the  \
+       MFMAs' shadow (an MFMA holds the SIMD's issue for 8 of its 32 cycles) */              \
+    X3P_SPLIT(CUR, (KB) + 1)                                                                 \
+    X3P_TERM(2, 0) X3P_TERM(1, 1)                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    /* (2) stage KB+1 into the other LDS buffer */                                           \
+    X3P_STORE(CUR, ((KB) + 1) & 1)                                                           \
+    X3P_TERM(0, 2)                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    /* (3) the rest of the products */                                                       \
+    X3P_TERM(1, 0) X3P_TERM(0, 1) X3P_TERM(0, 0)                                             \
+  }
+  X3P_TILE(loc)
+  X3P_LOAD(0, 0)
+  for (;;) {
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    X3P_SPLIT(0, 0)
+    X3P_STORE(0, 0)
+    X3P_LOAD(0, 1)
+    for (int kb = 0; kb < nst; kb += 2) {
+      X3P_ITER(kb, 0, 1)
+      if (kb + 1 < nst) X3P_ITER(kb + 1, 1, 0)
+    }
+    // next tile: its stage 0 is requested before this tile's stores go out
+    const int em0 = m0, en0 = n0;
+    loc += stride;
+    const bool more = loc < per_xcd && xcd * per_xcd + loc < total;
+    if (more) {
+      X3P_TILE(loc)
+      X3P_LOAD(0, 0)
+    }
+    x3p_epilogue<TM, TN>(g, acc, smem, em0, en0, wrb, wcb, wave, lane);
+    if (!more) break;
+    __syncthreads();     // the epilogue's LDS scratch is the next tile's stage buffer
+  }
+#undef X3P_ITER
+#undef X3P_TERM
+#undef X3P_LOAD
+#undef X3P_SPLIT
+#undef X3P_STORE
+#undef X3P_TILE
+}
+
 // ---- the weights' pieces, all matrices of a model in one launch.  Descriptor d covers blocks
 // [blk_begin[d], blk_begin[d+1]); a wave = one (column tile nt, k block kb) = three 1 KB fragments.
 __global__ __launch_bounds__(256) void x3p_split_kernel(const float* __restrict__ base,
@@ -293,7 +508,18 @@ void launch_x3p(X3P& g, hipStream_t st) {
   g.tiles_m = (g.M + 64 * TM - 1) / (64 * TM);
   g.tiles_n = (g.N + 64 * TN - 1) / (64 * TN);
   const int total = g.tiles_m * g.tiles_n;
-  hipLaunchKernelGGL((x3p_kernel<TM, TN>), dim3(((total + 7) / 8) * 8), dim3(256), 0, st, g);
+  static int db = -1;          // S2T_X3P_DB=0: the two-barrier form (k chunks of 32, one LDS stage)
+  if (db < 0) { const char* e = getenv("S2T_X3P_DB"); db = e ? atoi(e) : 1; }
+  if (db) {
+    // persistent grid: S2T_X3P_WGS workgroups per CU (default: what registers / LDS admit, <= 3)
+    static int wgs = -1;
+    if (wgs < 0) { const char* e = getenv("S2T_X3P_WGS"); wgs = e ? atoi(e) : 0; }
+    const int per_cu = wgs > 0 ? wgs : g.wgs_per_cu > 0 ? g.wgs_per_cu : (TM * TN >= 4 ? 2 : TM * TN >= 2 ? 3 : 4);
+    const int cap = 256 * per_cu;
+    const int grid = std::min(((total + 7) / 8) * 8, cap);
+    hipLaunchKernelGGL((x3p_db_kernel<TM, TN>), dim3(grid), dim3(256), 0, st, g);
+  } else
+    hipLaunchKernelGGL((x3p_kernel<TM, TN>), dim3(((total + 7) / 8) * 8), dim3(256), 0, st, g);
 }
 
 // block tile from the shape: the widest tile that still gives the chip >= ~2 rounds of workgroups
@@ -341,14 +567,21 @@ int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int 
   if (act_kind < 0 || act_kind > 2 || act2 < 0 || act2 > 2 || (act_src && act_kind == 0) ||
       (C2 && act2 == 0))
     return -1;
-  if (tile != 0 && tile != 11 && tile != 12 && tile != 21 && tile != 22) return -1;
+  const int wgs = tile / 100;          // hundreds digit: persistent workgroups per CU (0 = default)
+  tile %= 100;
+  if ((tile != 0 && tile != 11 && tile != 12 && tile != 21 && tile != 22) || wgs < 0 || wgs > 8) return -1;
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   if ((K & 7) || (N & 3) || (lda & 3) || (ldc & 3) || !al16(A) || !al16(Bp) || !al16(C) ||
       (bias && !al16(bias)) || (resid && (!al16(resid) || (ldr & 3))) ||
       (act_src && (!al16(act_src) || (ld_act & 3))) || (C2 && (!al16(C2) || (ldc2 & 3))))
     return -2;
   X3P g{A, lda, Bp, (N + 31) / 32, 2 * ((K + 31) / 32), C, ldc, M, N, K, bias, resid, ldr, act_src,
-        ld_act, act_kind, C2, ldc2, act2, 0, 0};
+        ld_act, act_kind, C2, ldc2, act2, 0, 0, wgs, 0};
+  {
+    static int prio = -1;      // S2T_X3P_PRIO=0: no slot priority
+    if (prio < 0) { const char* e = getenv("S2T_X3P_PRIO"); prio = e ? atoi(e) : 1; }
+    g.prio = prio;
+  }
   hipStream_t st = (hipStream_t)stream;
   if (tile == 0) tile = pick_tile(M, N);
   switch (tile) {

@@ -312,11 +312,15 @@ class WhitenStats:
         if _tn_ok(xf):
             # symmetric product: only the 64x64 tiles on / above the diagonal that hold same-group
             # pairs are computed (6 of 9 at C = 192, 10 of 16 at 256, the diagonal for the keys)
-            N.profile_note("s2t_gemm_f32", 4.0 * (xf.numel() + C * C), 2.0 * n * C * cg)
+            N.profile_note("s2t_gemm_xtx", 4.0 * (xf.numel() + C * cg), 2.0 * n * C * cg)
             N.check(N.lib().s2t_gemm_xtx(N.raw(xf, torch.float32), xf.stride(0), n, C, cg,
                                          N.fp(xtx), xtx.stride(0), N.fp(colsum),
                                          side if side is not None else N.stream()), "s2t_gemm_xtx")
         else:
+            # layout the TN kernel refuses: library product on the current stream -- which must first
+            # be ordered after the side stream, whose earlier statistics use the same accumulator
+            if _Side.handle is not None:
+                N.check(N.lib().s2t_stream_order(_Side.handle, N.stream()), "s2t_stream_order(stats)")
             a, b = linear_wgrad(xf, xf, True)
             xtx.copy_(a)
             colsum.copy_(b)
@@ -324,11 +328,17 @@ class WhitenStats:
         self.mean = torch.empty((C,), dtype=torch.float32, device=dev)
         self.scal = torch.empty((4,), dtype=torch.float32, device=dev)
         self.host = _pinned_slot()
+        N.profile_note("s2t_whiten_metric", 4.0 * (2 * C * cg + C * C))
         N.check(N.lib().s2t_whiten_metric(N.fp(xtx), N.fp(colsum), n, G, cg, N.fp(self.cov),
                                           N.fp(self.mean), N.fp(self.scal),
                                           ctypes.c_void_p(self.host.data_ptr()), N.fp(ws),
                                           side if side is not None else N.stream()),
                 "s2t_whiten_metric")
+        if side is not None:
+            # the side stream may still be reading x / writing the statistics when this object (or
+            # a float() temporary of x) dies -- e.g. a forward under train() with no backward: the
+            # caching allocator must not hand the memory to main-stream work before the join
+            _Side.keep.append((xf, self.cov, self.mean, self.scal))
         self.event = torch.cuda.Event()
         if side is not None:
             self.event.record(N._launch_stream((side,)))
@@ -355,6 +365,7 @@ def whiten_backward(x, g, stats, limit, grad_scale):
     dcov = torch.empty((C, C), dtype=torch.float32, device=dev)
     bias = torch.empty((C,), dtype=torch.float32, device=dev)
     sums = torch.empty((2,), dtype=torch.float32, device=dev)
+    N.profile_note("s2t_whiten_dcov", 4.0 * (C * cg + C * C + 2 * C))
     N.check(N.lib().s2t_whiten_dcov(N.fp(stats.cov), N.fp(stats.mean), N.fp(stats.scal), G, cg,
                                     N.fp(dcov), N.fp(bias), N.fp(sums), N.stream()),
             "s2t_whiten_dcov")
@@ -778,10 +789,12 @@ class _NonlinCore(torch.autograd.Function):
         L = N.lib()
         st = N.stream()
         xs = torch.empty((B, T, C), dtype=torch.float32, device=u.device)
+        N.profile_note("s2t_nonlin_gate_fwd", 12.0 * T * B * C)
         N.check(L.s2t_nonlin_gate_fwd(N.fp(u), T, B, C, N.fp(xs), st), "nonlin_gate_fwd")
         wm = w0.reshape(B, T, T)
         z = torch.bmm(wm, xs)                                         # rocBLAS
         o = torch.empty((T, B, C), dtype=torch.float32, device=u.device)
+        N.profile_note("s2t_nonlin_out_fwd", 12.0 * T * B * C)
         N.check(L.s2t_nonlin_out_fwd(N.fp(z), N.fp(u), T, B, C, N.fp(o), st), "nonlin_out_fwd")
         ctx.save_for_backward(u, wm, xs, z)
         ctx.bal_cfg, ctx.whiten_mod = bal_cfg, whiten_mod
@@ -801,10 +814,12 @@ class _NonlinCore(torch.autograd.Function):
         g = g.contiguous().float()
         dz = torch.empty_like(z)
         du = torch.empty_like(u)
+        N.profile_note("s2t_nonlin_out_bwd", 20.0 * T * B * C)
         N.check(L.s2t_nonlin_out_bwd(N.fp(g), N.fp(z), N.fp(u), T, B, C, N.fp(dz), N.fp(du), st),
                 "nonlin_out_bwd")
         dxs = torch.bmm(wm.transpose(1, 2), dz)
         dW0 = torch.bmm(dz, xs.transpose(1, 2)) if ctx.needs_input_grad[1] else None
+        N.profile_note("s2t_nonlin_gate_bwd", 20.0 * T * B * C)
         N.check(L.s2t_nonlin_gate_bwd(N.fp(dxs), N.fp(u), T, B, C, N.fp(du), st), "nonlin_gate_bwd")
         if ctx.bal_cfg is not None:
             du[..., :C] = balancer_backward(u[..., :C], du[..., :C].contiguous(), *ctx.bal_cfg[:5],
@@ -833,6 +848,7 @@ class _Downsample(torch.autograd.Function):
         w = w.contiguous().float()
         T, B, C = src.shape
         out = torch.empty(((T + ds - 1) // ds, B, C), dtype=torch.float32, device=src.device)
+        N.profile_note("s2t_downsample_fwd", 4.0 * (src.numel() + out.numel()))
         N.check(N.lib().s2t_downsample_fwd(N.fp(src), N.fp(w), ds, T, B, C, N.fp(out), N.stream()),
                 "s2t_downsample_fwd")
         ctx.save_for_backward(src, w)
@@ -846,6 +862,7 @@ class _Downsample(torch.autograd.Function):
         g = g.contiguous().float()
         d_src = torch.empty_like(src)
         dw = torch.zeros_like(w)
+        N.profile_note("s2t_downsample_bwd", 4.0 * (2 * src.numel() + g.numel()))
         N.check(N.lib().s2t_downsample_bwd(N.fp(src), N.fp(w), N.fp(g), ctx.ds, T, B, C,
                                            N.fp(d_src), N.fp(dw), N.stream()), "s2t_downsample_bwd")
         return d_src, dw, None
@@ -1132,7 +1149,9 @@ def _rows(t):
 
 
 _ACTK = {None: 0, "swoosh_l": 1, "swoosh_r": 2}
-X3P = {"on": os.environ.get("S2T_X3P", "1") == "1", "calls": 0, "tile": 0}
+X3P = {"on": os.environ.get("S2T_X3P", "1") == "1", "calls": 0, "tile": 0,
+       "tune": os.environ.get("S2T_X3P_TUNE", "1") == "1",
+       "margin": float(os.environ.get("S2T_X3P_MARGIN", "0.97"))}
 
 
 def x3p_matmul(mode, x2, w2, bias=None, resid2=None, act_src=None, act_kind=None, act2=None, tile=0):
@@ -1173,7 +1192,82 @@ def x3p_matmul(mode, x2, w2, bias=None, resid2=None, act_src=None, act_kind=None
     return out if out2 is None else (out, out2)
 
 
-def lt_matmul(mode, x2, w2, bias=None, resid2=None, out_shape=None):
+_PLANS = {}          # shape bucket -> ("lt", 0) | ("x3p", tile): timed once per bucket
+_X3P_TILES = (222, 321, 312, 411)
+PLAN_STATS = {"timed": 0}
+
+
+def _half_octave(m):
+    import math
+    return int(math.floor(2.0 * math.log2(max(1, m))))
+
+
+def _time_call(fn, reps=3):
+    fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def lt_matmul(mode, x2, w2, bias=None, resid2=None, act_src=None, act_kind=None, act2=None):
+    """Forward / data-gradient product of a Linear with its elementwise neighbours:
+      mode 0: x2 (R,K) w2 (N,K)^T (+bias) -> (R,N);  mode 1: x2 (R,N) w2 (N,K) -> (R,K);
+      then (* act'(act_src), act_kind "swoosh_l" | "swoosh_r") (+ resid2); with act2 a second
+      output act2(result) is returned as well.
+    Served by our bf16x3 kernel with pre-split weight pieces (s2t_gemm_x3p, epilogue-fused) or by
+    the plan cache of s2t_linear_lt (+ a separate activation pass) -- whichever was faster when the
+    shape bucket {mode, half-octave of R, N, K, epilogue} was first seen (timed once, on the call's
+    own operands, on an otherwise idle chip).  Weights outside a FlatStore always take the latter."""
+    fused = act_src is not None or act2 is not None
+
+    def lib():
+        y = _lt_matmul_lib(mode, x2, w2, bias, None if act_src is not None else resid2)
+        if act_src is not None:
+            y = swoosh_backward(act_src, y, act_kind == "swoosh_l")
+            if resid2 is not None:
+                y = y + resid2
+        if act2 is not None:
+            return y, swoosh_forward(y, act2 == "swoosh_l")
+        return y
+
+    if not X3P["on"] or x2.shape[0] == 0 or planes.pieces(w2, mode) is None:
+        return lib()
+    key = (mode, _half_octave(x2.shape[0]), w2.shape[0], w2.shape[1], bias is not None,
+           resid2 is not None, act_src is not None, act2)
+    plan = _PLANS.get(key)
+    if plan is None:
+        if not X3P["tune"]:
+            plan = ("x3p", 0)
+        else:
+            torch.cuda.synchronize()           # side streams idle: candidates are compared alone
+            best, plan = _time_call(lib), ("lt", 0)
+            if not fused:
+                best *= X3P["margin"]
+            for t in _X3P_TILES:
+                if x3p_matmul(mode, x2, w2, bias, resid2, act_src, act_kind, act2, tile=t) is None:
+                    break
+                ms = _time_call(lambda: x3p_matmul(mode, x2, w2, bias, resid2, act_src, act_kind, act2,
+                                                   tile=t))
+                if ms < best:
+                    best, plan = ms, ("x3p", t)
+            PLAN_STATS["timed"] += 1
+            if os.environ.get("S2T_PLAN_DUMP"):
+                print(f"[s2t plan] mode {mode} R {x2.shape[0]} N {w2.shape[0]} K {w2.shape[1]} "
+                      f"bias {bias is not None} resid {resid2 is not None} fused {fused}: {plan} "
+                      f"{1e3 * best:.1f} us", flush=True)
+        _PLANS[key] = plan
+    if plan[0] == "x3p":
+        y = x3p_matmul(mode, x2, w2, bias, resid2, act_src, act_kind, act2, tile=plan[1])
+        if y is not None:
+            return y
+    return lib()
+
+
+def _lt_matmul_lib(mode, x2, w2, bias=None, resid2=None, out_shape=None):
     """mode 0: x2 (R,K) w2 (N,K)^T (+bias) (+resid2) -> (R,N);  mode 1: x2 (R,N) w2 (N,K) (+resid2)
     -> (R,K).  One hipBLASLt launch with the bias / residual in the epilogue (gemm_lib.hip);
     torch.matmul when the library has no algorithm for the shape."""
@@ -1194,10 +1288,24 @@ def lt_matmul(mode, x2, w2, bias=None, resid2=None, out_shape=None):
                                1.0 if resid2 is not None else 0.0, N.fp(out), cols, R, Nf, Kf,
                                ctypes.c_void_p(ws.data_ptr()), ws.numel(), N.stream())
     if rc == -2:                                   # shape without a library algorithm
+        LT_STATS["aten_fallbacks"] += 1
+        if LT_STATS["aten_fallbacks"] == 1 or os.environ.get("S2T_LT_LOG_FALLBACK"):
+            import warnings
+            warnings.warn(f"s2t_linear_lt: no hipBLASLt algorithm for mode {mode} M {R} N {Nf} K {Kf} "
+                          f"-- ATen GEMM used (counted in zip_kernels.LT_STATS)")
         y = F.linear(x2, w2, bias) if mode == 0 else x2.matmul(w2)
         return y if resid2 is None else y + resid2
     N.check(rc, "s2t_linear_lt")
+    LT_STATS["calls"] += 1
     return out
+
+
+LT_STATS = {"calls": 0, "aten_fallbacks": 0}
+
+
+def lt_own_calls():
+    """Launches of s2t_linear_lt served by the round-3 bf16x3 kernel (plan cache's choice)."""
+    return int(N.lib().s2t_linear_lt_own_calls())
 
 
 class _Linear(torch.autograd.Function):
@@ -1365,6 +1473,7 @@ class _Conv3x3Nhwc(torch.autograd.Function):
             w2 = weight.permute(0, 2, 3, 1).reshape(Cout, 9 * C)
             dc = lt_matmul(1, g, w2)                             # (B*Ho*Wo, 3*3*C)
             dx = torch.empty((B, H, W, C), dtype=torch.float32, device=dy.device)
+            N.profile_note("s2t_col2im3x3_nhwc", 4.0 * (dc.numel() + dx.numel()))
             N.check(N.lib().s2t_col2im3x3_nhwc(N.fp(dc), B, H, W, C, Ho, Wo, sh, sw, N.fp(dx),
                                                N.stream()), "s2t_col2im3x3_nhwc")
         return dx, dweight, db, None, None
@@ -1383,6 +1492,7 @@ class _Conv3x3C1(torch.autograd.Function):
         CO = weight.shape[0]
         y = torch.empty((B, H - 2, W + 2 * pw - 2, CO), dtype=torch.float32, device=x.device)
         w = weight.contiguous().float()
+        N.profile_note("s2t_conv3x3_c1", 4.0 * (x3.numel() + y.numel()))
         N.check(N.lib().s2t_conv3x3_c1(0, N.fp(x3), N.fp(w), N.fp(bias), None, B, H, W, pw, CO,
                                        N.fp(y), None, None, None, N.stream()), "s2t_conv3x3_c1")
         ctx.save_for_backward(x3, w)
@@ -1398,11 +1508,13 @@ class _Conv3x3C1(torch.autograd.Function):
         g = g.contiguous().float()
         acc = torch.zeros(CO * 10, dtype=torch.float32, device=g.device)
         L = N.lib()
+        N.profile_note("s2t_conv3x3_c1", 4.0 * (x3.numel() + g.numel()))
         N.check(L.s2t_conv3x3_c1(1, N.fp(x3), None, None, N.fp(g), B, H, W, pw, CO, None, N.fp(acc),
                                  ctypes_off(acc, CO * 9), None, N.stream()), "s2t_conv3x3_c1(wgrad)")
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x3)
+            N.profile_note("s2t_conv3x3_c1", 4.0 * (g.numel() + dx.numel()))
             N.check(L.s2t_conv3x3_c1(2, None, N.fp(w), None, N.fp(g), B, H, W, pw, CO, None, None,
                                      None, N.fp(dx), N.stream()), "s2t_conv3x3_c1(dgrad)")
             dx = dx.view(xshape)
@@ -1428,6 +1540,7 @@ class _Conv3x3S2(torch.autograd.Function):
         w = weight.contiguous().float()
         y = torch.empty((B, (H - 3) // 2 + 1, (W - 3) // 2 + 1, CO), dtype=torch.float32,
                         device=x.device)
+        N.profile_note("s2t_conv3x3_s2", 4.0 * (x.numel() + y.numel()), 2.0 * y.numel() * 9 * C)
         N.check(N.lib().s2t_conv3x3_s2(0, N.fp(x), N.fp(w), N.fp(bias), None, B, H, W, C, CO,
                                        N.fp(y), None, N.stream()), "s2t_conv3x3_s2")
         ctx.save_for_backward(x, w)
@@ -1452,6 +1565,7 @@ class _Conv3x3S2(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
+            N.profile_note("s2t_conv3x3_s2", 4.0 * (g.numel() + dx.numel()), 2.0 * g.numel() * 9 * C)
             N.check(N.lib().s2t_conv3x3_s2(2, None, N.fp(w), None, N.fp(g), B, H, W, C, CO, None,
                                            N.fp(dx), N.stream()), "s2t_conv3x3_s2(dgrad)")
         return dx, dweight, db
@@ -1491,6 +1605,7 @@ class _DwConv2dNhwc(torch.autograd.Function):
         KH, KW = weight.shape[-2], weight.shape[-1]
         w = weight.reshape(C, KH, KW).contiguous()
         y = torch.empty_like(x)
+        N.profile_note("s2t_dwconv2d_nhwc_fwd", 8.0 * x.numel())
         N.check(N.lib().s2t_dwconv2d_nhwc_fwd(N.fp(x), N.fp(w), N.fp(bias), Nn, H, W, C, KH, KW, 0,
                                               N.fp(y), N.stream()), "s2t_dwconv2d_nhwc_fwd")
         ctx.save_for_backward(x, w)
@@ -1508,12 +1623,14 @@ class _DwConv2dNhwc(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
+            N.profile_note("s2t_dwconv2d_nhwc_fwd", 8.0 * dy.numel())
             N.check(L.s2t_dwconv2d_nhwc_fwd(N.fp(dy), N.fp(w), None, Nn, H, W, C, KH, KW, 1,
                                             N.fp(dx), N.stream()), "s2t_dwconv2d_nhwc_bwd_data")
         ws = torch.empty(L.s2t_dwconv2d_wgrad_workspace_floats(Nn, H, C, KH, KW),
                          dtype=torch.float32, device=x.device)
         dw = torch.empty_like(w)
         db = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        N.profile_note("s2t_dwconv2d_nhwc_wgrad", 8.0 * x.numel())
         N.check(L.s2t_dwconv2d_nhwc_wgrad(N.fp(x), N.fp(dy), Nn, H, W, C, KH, KW, N.fp(ws),
                                           N.fp(dw), N.fp(db), N.stream()), "s2t_dwconv2d_nhwc_wgrad")
         return dx, dw.view(ctx.wshape), db
@@ -1549,12 +1666,14 @@ class _DwConv2dTap(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
+            N.profile_note("s2t_dwconv2d_nhwc_fwd_add", 12.0 * dy.numel())
             N.check(L.s2t_dwconv2d_nhwc_fwd_add(N.fp(dy), N.fp(w), None, N.fp(gp), Nn, H, W, C, KH, KW,
                                                 1, N.fp(dx), N.stream()), "s2t_dwconv2d_nhwc_bwd_data")
         ws = torch.empty(L.s2t_dwconv2d_wgrad_workspace_floats(Nn, H, C, KH, KW),
                          dtype=torch.float32, device=x.device)
         dw = torch.empty_like(w)
         db = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        N.profile_note("s2t_dwconv2d_nhwc_wgrad", 8.0 * x.numel())
         N.check(L.s2t_dwconv2d_nhwc_wgrad(N.fp(x), N.fp(dy), Nn, H, W, C, KH, KW, N.fp(ws),
                                           N.fp(dw), N.fp(db), N.stream()), "s2t_dwconv2d_nhwc_wgrad")
         return dx, dw.view(ctx.wshape), db

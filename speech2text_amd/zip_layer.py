@@ -202,6 +202,7 @@ def _commit(items):
     for q, (p, d, lo, hi, limit) in zip(arr, items):
         q.x, q.d, q.grad = p.data_ptr(), d.data_ptr(), p.grad.data_ptr()
         q.lo, q.hi, q.limit, q.n = float(lo), float(hi), int(limit), d.numel()
+    N.profile_note("s2t_param_grad_commit_n", 12.0 * sum(it[1].numel() for it in items))
     N.check(N.lib().s2t_param_grad_commit_n(len(items), ctypes.cast(arr, ctypes.c_void_p),
                                             N.stream()), "s2t_param_grad_commit_n")
     for it in items:
@@ -228,10 +229,11 @@ class _Saved:
 def _ff_fwd(m, dec, x_in):
     fb, fw, fp = dec
     sv = _Saved()
-    sv.h = zk.lt_matmul(0, x_in, m.in_proj.weight, m.in_proj.bias)
     # the activation is KEPT for the weight gradient (the reference recomputes it to save memory,
-    # scaling.py:1512-1583; 288 GB of HBM make the ~1 GB per step the cheaper side of that trade)
-    a = sv.a = zk.swoosh_forward(sv.h, True)
+    # scaling.py:1512-1583; 288 GB of HBM make the ~1 GB per step the cheaper side of that trade);
+    # it leaves the in-projection's epilogue as a second output (no separate Swoosh pass)
+    sv.h, a = zk.lt_matmul(0, x_in, m.in_proj.weight, m.in_proj.bias, act2="swoosh_l")
+    sv.a = a
     sv.y = sv.st = None
     if not (fw or fp):
         out = zk.lt_matmul(0, a, m.out_proj.weight, m.out_proj.bias, x_in)
@@ -252,11 +254,10 @@ def _ff_bwd(m, post, dec, sv, x_in, g):
         gy = _whiten_bwd(m.out_whiten, sv.y, gy, sv.st)
     W = m.out_proj.weight
     _wgrad(W, m.out_proj.bias, gy, sv.a)
-    dh = zk.lt_matmul(1, gy, W)
     if fb:                                   # Swoosh backward rides in the Balancer's update pass
-        dh = _balancer_bwd(m.hidden_balancer, sv.h, dh, swoosh_l=True)
-    else:
-        dh = zk.swoosh_backward(sv.h, dh, True)
+        dh = _balancer_bwd(m.hidden_balancer, sv.h, zk.lt_matmul(1, gy, W), swoosh_l=True)
+    else:                                    # ... or in the data-gradient GEMM's epilogue
+        dh = zk.lt_matmul(1, gy, W, act_src=sv.h, act_kind="swoosh_l")
     _wgrad(m.in_proj.weight, m.in_proj.bias, dh, x_in)
     return zk.lt_matmul(1, dh, m.in_proj.weight, None, g)
 
@@ -312,11 +313,10 @@ def _conv_bwd(m, dec, sv, x_in, g, T, B, k8):
     D = x_in.shape[1]
     W = m.out_proj.weight
     _wgrad(W, m.out_proj.bias, g, sv.a)
-    dy = zk.lt_matmul(1, g, W)
     if fb2 and not fw:                       # Swoosh backward rides in the Balancer's update pass
-        dy = _balancer_bwd(m.balancer2, sv.y, dy, swoosh_l=False)
-    else:
-        dy = zk.swoosh_backward(sv.y, dy, False)
+        dy = _balancer_bwd(m.balancer2, sv.y, zk.lt_matmul(1, g, W), swoosh_l=False)
+    else:                                    # ... or in the data-gradient GEMM's epilogue
+        dy = zk.lt_matmul(1, g, W, act_src=sv.y, act_kind="swoosh_r")
         if fw:
             dy = _whiten_bwd(m.whiten, sv.y, dy, sv.st)
         if fb2:
@@ -345,10 +345,12 @@ def _na_fwd(m, dec, x_in, W, T, B):
     sv.u = zk.lt_matmul(0, x_in, m.in_proj.weight, m.in_proj.bias)          # (R, 3C) = [s|x|y]
     C = sv.u.shape[1] // 3
     sv.xs = torch.empty((B, T, C), dtype=_F32, device=dev)
+    N.profile_note("s2t_nonlin_gate_fwd", 12.0 * T * B * C)
     N.check(L.s2t_nonlin_gate_fwd(N.fp(sv.u), T, B, C, N.fp(sv.xs), st), "nonlin_gate_fwd")
     sv.wm = W[0]                                                             # (B,T,T)
     sv.z = torch.bmm(sv.wm, sv.xs)                                           # rocBLAS
     sv.o = _e(T * B, C, dev)
+    N.profile_note("s2t_nonlin_out_fwd", 12.0 * T * B * C)
     N.check(L.s2t_nonlin_out_fwd(N.fp(sv.z), N.fp(sv.u), T, B, C, N.fp(sv.o), st),
             "nonlin_out_fwd")
     sv.st1 = zk.WhitenStats(sv.u[:, C:2 * C], m.whiten1.num_groups) if fw1 else None
@@ -377,10 +379,12 @@ def _na_bwd(m, post, dec, sv, x_in, g, T, B):
     C = sv.u.shape[1] // 3
     dz = torch.empty_like(sv.z)
     du = torch.empty_like(sv.u)
+    N.profile_note("s2t_nonlin_out_bwd", 20.0 * T * B * C)
     N.check(L.s2t_nonlin_out_bwd(N.fp(do), N.fp(sv.z), N.fp(sv.u), T, B, C, N.fp(dz), N.fp(du), st),
             "nonlin_out_bwd")
     dxs = torch.bmm(sv.wm.transpose(1, 2), dz)
     dW0 = torch.bmm(dz, sv.xs.transpose(1, 2))
+    N.profile_note("s2t_nonlin_gate_bwd", 20.0 * T * B * C)
     N.check(L.s2t_nonlin_gate_bwd(N.fp(dxs), N.fp(sv.u), T, B, C, N.fp(du), st), "nonlin_gate_bwd")
     if fb:
         _balancer_bwd(m.balancer, sv.u[:, :C], du[:, :C], inplace=True)
@@ -569,6 +573,8 @@ class _LayerFn(torch.autograd.Function):
         sa = layer.self_attn_weights
         delta = torch.empty((H, B, T), dtype=_F32, device=dev)
         (dO1, _, O1, dv1), (dO2, _, O2, dv2) = pairs
+        N.profile_note("s2t_attn_delta_pairs", 4.0 * (s.W.numel() // H + dW0.numel() + 2 * (dO1.numel()
+                                                        + dO2.numel()) + delta.numel()))
         N.check(L.s2t_attn_delta_pairs(N.fp(s.W), N.fp(dW0), N.fp(dO1), N.fp(O1), dv1, N.fp(dO2),
                                        N.fp(O2), dv2, T, B, H, N.fp(delta), st),
                 "s2t_attn_delta_pairs")

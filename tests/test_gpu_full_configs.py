@@ -90,8 +90,9 @@ def test_c3_yaml_dims_two_utterances_vs_oracle(dev):
     assert same >= 0.98, same                               # argmax ties can move a window by one
 
 
-@pytest.mark.parametrize("rv", [0.0, 0.2])
-def test_c3_yaml_dims_training_step_gradients_vs_oracle(dev, monkeypatch, rv):
+@pytest.mark.parametrize("rv,chunk", [(0.0, (-1, -1)), (0.2, (-1, -1)), (0.2, (32, 128)), (0.0, (16, 64)),
+                                      (0.2, (64, 256))])
+def test_c3_yaml_dims_training_step_gradients_vs_oracle(dev, monkeypatch, rv, chunk):
     """The code the bench times -- the layer executor's backward at D = 192 / 256, H = 4 / 8,
     K = 31 / 15, T = 495 ... 62, the stateless predictor, the joiner with the simple loss, prune
     ranges and the fused pruned lattice -- in TRAINING mode at the YAML dims: 2 x 10 s (ragged),
@@ -99,12 +100,21 @@ def test_c3_yaml_dims_training_step_gradients_vs_oracle(dev, monkeypatch, rv):
     score penalty fire; 0.2: the default-probability Balancers and every Whiten), positional
     dropout off, feature masks from the same CPU generator.  Loss (0.5 simple + 0.5 pruned,
     task_factory/rnnt_task.py:496-499) and EVERY parameter gradient against oracle/zipformer.py
-    + oracle/heads.py + oracle/k2_rnnt.py (k2 part parity unpinned)."""
+    + oracle/heads.py + oracle/k2_rnnt.py (k2 part parity unpinned).
+    `chunk` = (chunk_size, left_context_frames) of the YAML's training mode
+    (config/training/zipformer_stateless_pruned_rnnt.yaml:65-66, reference
+    model/encoder/zipformer.py:290-317,409-448): the chunk-masked attention forward / backward
+    tiles and the chunk-causal depthwise conv's edge scaling (model/layer/scaling.py:622-681) at
+    T = 495 ... 62, H = 4 / 8, K = 31 / 15."""
     from speech2text_amd import flat, rng, zip_layer
     from speech2text_amd.build_task import TaskFactory
     monkeypatch.setattr(rng, "rand", lambda *s, device=None, dtype=torch.float32:
                         torch.rand(*s, dtype=dtype).to(device))
     cfg = bench.c3_config(500)
+    cs, lcf = chunk
+    cfg["encoder"]["config"]["chunk_size"] = [cs]
+    cfg["encoder"]["config"]["left_context_frames"] = [lcf]
+    lcc = -1 if cs < 0 else max(1, lcf // cs)
     random.seed(1234)
     torch.manual_seed(1234)
     task = TaskFactory.get("Pruned_Rnnt")(cfg)
@@ -137,7 +147,7 @@ def test_c3_yaml_dims_training_step_gradients_vs_oracle(dev, monkeypatch, rv):
     lab, lab_len = batch["label"].cpu(), batch["label_length"].cpu()
     torch.manual_seed(7)
     yo, ylo = Z.zipformer_forward(enc_sd, bench._zcfg(cfg["encoder"]["config"]), feat.cpu(),
-                                  feat_len.cpu(), Z.Ctl(True, lambda: rv, pos_dropout=0.0), -1, -1)
+                                  feat_len.cpu(), Z.Ctl(True, lambda: rv, pos_dropout=0.0), cs, lcc)
     po = H.stateless_predictor(sd, "_predictor.predictor.", lab, 5)
     am, lm = H.joiner_projections(sd, "_joiner.", yo, po)
     lo, bo, ro, so = K2.joiner_pruned(am, lm, lab, lab_len, ylo, 5)
@@ -154,6 +164,35 @@ def test_c3_yaml_dims_training_step_gradients_vs_oracle(dev, monkeypatch, rv):
         if e > worst:
             worst, worst_name = e, n
     assert worst <= 5e-3, (worst_name, worst)
+
+
+def test_c3_yaml_size_prune_ranges_bit_exact_given_the_oracles_gradients(dev):
+    """Index work is bit-exact GIVEN identical float inputs (model/joiner/joiner.py:112-118 ->
+    k2.get_rnnt_prune_ranges): at the YAML size (T = 248, S = 50, C = 500, prune_range 5, ragged
+    lengths) the oracle's px_grad / py_grad go into s2t_rnnt_prune_ranges and every window must
+    equal the oracle's -- 100 %, not the >= 98 % of the end-to-end comparison above, where the
+    product's own fp32 gradients differ from the oracle's in the last bits."""
+    from speech2text_amd import kernels as k
+    g = torch.Generator().manual_seed(11)
+    B, T, S, C, R = 8, 248, 50, 500, 5
+    am = torch.randn(B, T, C, generator=g) * 2
+    lm = torch.randn(B, S + 1, C, generator=g) * 2
+    sym = torch.randint(1, C, (B, S), generator=g)
+    tl = torch.randint(20, S + 1, (B,), generator=g)
+    tl[0] = S
+    el = torch.randint(150, T + 1, (B,), generator=g)
+    el[0] = T
+    bnd = torch.zeros(B, 4, dtype=torch.int64)
+    bnd[:, 2] = tl
+    bnd[:, 3] = el
+    _, (gx, gy) = K2.rnnt_loss_smoothed(lm, am, sym, 0, bnd)
+    ref = K2.get_rnnt_prune_ranges(gx, gy, bnd, R)
+    out = k.rnnt_prune_ranges(gx.to(dev).contiguous(), gy.to(dev).contiguous(), bnd.to(dev), R)
+    assert out.dtype == torch.int64 and tuple(out.shape) == (B, T, R)
+    assert torch.equal(out.cpu(), ref), float((out.cpu() == ref).float().mean())
+    # monotone, in bounds (k2's invariants)
+    s0 = out[:, :, 0].cpu()
+    assert (s0[:, 1:] >= s0[:, :-1]).all() and (s0 >= 0).all() and (s0 + R - 1 <= S).all()
 
 
 def test_c3_full_batch_properties(dev):
@@ -348,6 +387,39 @@ def test_c5_bestrq_ssl_full_size(dev):
     losses = [float(tr.training_step(batch, i)) for i in range(3)]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
     assert 0.3 < float(task.logged["mask_rate"]) < 0.7
+
+
+def test_c5_conformer_forward_30s_vs_oracle(dev):
+    """The C5 encoder at its own length: 1 x 30 s + 1 x 25 s -> 2998 frames -> T = 748 (the
+    comparison of the conformer with the oracle otherwise stops at T = 498): Subsampling,
+    12 conformer blocks (s2t_mhsa_fwd at T = 748, conv module, LayerNorms) in evaluation mode vs
+    oracle/conformer.py on the same parameters and oracle features."""
+    from speech2text_amd.build_task import TaskFactory
+    cfg = _c2()
+    random.seed(1234)
+    torch.manual_seed(1234)
+    task = TaskFactory.get("CTC")(cfg)
+    sd = _cpu_sd(task)
+    task.to(dev).eval()
+    batch = bench.make_batch(0, 2, 30.0, 1, 128, dev)
+    batch["pcm_length"][1] = 400000
+    with torch.no_grad():
+        feat, feat_len = task.features(batch)
+        enc, enc_len = task._encoder(feat, feat_len)
+    assert feat.shape == (2, 2998, 80)
+    pcm, n = batch["pcm"].cpu().numpy(), batch["pcm_length"].cpu().numpy()
+    x = torch.zeros(2, 2998, 80)
+    for i in range(2):
+        f = ofb.fbank(pcm[i, :n[i]], 80)
+        x[i, :f.shape[0]] = torch.from_numpy(f)
+    enc_sd = {k[len("_encoder.encoder."):]: v for k, v in sd.items() if k.startswith("_encoder.encoder.")}
+    with torch.no_grad():
+        yo, ylo = OC.conformer_forward(enc_sd, x, feat_len.cpu(), 12, 4, training=False)
+    assert enc.shape == (2, 748, 256) and enc_len.cpu().tolist() == ylo.tolist() == [748, 623]
+    for b in range(2):
+        L = int(ylo[b])
+        err = (enc[b, :L].cpu() - yo[b, :L]).abs().max().item()
+        assert err <= 2e-3 * max(1.0, yo[b, :L].abs().max().item()), (b, err)
 
 
 def test_checkpoint_save_resume_continues_the_trajectory(dev, tmp_path):

@@ -24,6 +24,9 @@ FWD = [(31680, 272, 192), (31680, 432, 192), (31680, 192, 144), (31680, 48, 192)
        (3968, 256, 960), (3968, 512, 256), (3968, 256, 256)]
 
 
+CFGS = [0, 122, 222, 121, 221, 321, 112, 212, 312, 111, 211, 311, 411]
+
+
 def main():
     quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
     torch.manual_seed(0)
@@ -36,7 +39,8 @@ def main():
     plist = [p for wb in ws.values() for p in wb]
     store = flat.FlatStore(plist)
     print(f"{'mode':>4} {'M':>6} {'N':>5} {'K':>5} | {'lt us':>7} {'TF':>5} | x3p: auto  t22    t21    t12    t11  | best TF  speedup | err x3p / lt")
-    tot_lt = tot_x = 0.0
+    tot_lt = tot_x = tot_auto = 0.0
+    print("x3p configs (100 wgs/CU + tile):", CFGS)
     for mode in (0, 1):
         for (M, Nn, K) in shapes:
             W, b = ws[(Nn, K)]
@@ -54,18 +58,19 @@ def main():
             if bias is not None:
                 ref = ref + bias.detach().double()
             e1 = ((y[rows].double() - ref).abs().max() / ref.abs().max()).item()
-            yl = zk.lt_matmul(mode, x, W.detach(), bias, res)
+            yl = zk._lt_matmul_lib(mode, x, W.detach(), bias, res)
             e2 = ((yl[rows].double() - ref).abs().max() / ref.abs().max()).item()
-            t_lt = timeit(lambda: zk.lt_matmul(mode, x, W.detach(), bias, res))
-            ts = [timeit(lambda: zk.x3p_matmul(mode, x, W, bias, res, tile=t)) for t in (0, 22, 21, 12, 11)]
+            t_lt = timeit(lambda: zk._lt_matmul_lib(mode, x, W.detach(), bias, res))
+            ts = [timeit(lambda: zk.x3p_matmul(mode, x, W, bias, res, tile=t), it=15) for t in CFGS]
             fl = 2.0 * M * Nn * K
             best = min(ts)
             tot_lt += t_lt
             tot_x += best
+            tot_auto += ts[0]
             print(f"{mode:4d} {M:6d} {Nn:5d} {K:5d} | {t_lt:7.1f} {fl / t_lt / 1e6:5.0f} | "
-                  + " ".join(f"{t:6.1f}" for t in ts) + f" | {fl / best / 1e6:5.0f}  {t_lt / best:5.2f}x | {e1:.1e} {e2:.1e}",
+                  + " ".join(f"{t:5.1f}" for t in ts) + f" | {CFGS[ts.index(best)]:4d} {fl / best / 1e6:5.0f}  {t_lt / best:5.2f}x | {e1:.1e} {e2:.1e}",
                   flush=True)
-    print(f"sum lt {tot_lt:.0f} us, sum best x3p {tot_x:.0f} us ({tot_lt / tot_x:.2f}x)")
+    print(f"sum lt {tot_lt:.0f} us, sum best x3p {tot_x:.0f} us ({tot_lt / tot_x:.2f}x), auto {tot_auto:.0f} us")
 
     # fused epilogues: dgrad through Swoosh, forward with the kept activation as second output
     M, Nn, K = 15872, 768, 256

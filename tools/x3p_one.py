@@ -27,6 +27,6 @@ for t in (22, 23, 21):
                                      None, 0, t, N.stream()), "tiled")
 os.environ["S2T_LT_OWN"] = "0"
 for _ in range(iters):
-    zk.lt_matmul(0, x, W.detach(), b.detach(), None)
+    zk._lt_matmul_lib(0, x, W.detach(), b.detach(), None)
 torch.cuda.synchronize()
 print("done")
