@@ -554,6 +554,9 @@ def parse_args(argv=None):
                          "config/training/zipformer_stateless_pruned_rnnt.yaml:124): a step is "
                          "still ONE micro-batch pass (fbank+fwd+bwd); the gradient exchange, clip "
                          "and optimizer run on every accum-th step; --steps should be a multiple")
+    ap.add_argument("--ddp-force", choices=["allreduce", "rs_ag"], default=None,
+                    help="N = 1 only: run the data-parallel reducer on a 1-rank RCCL group (hooks, "
+                         "buckets, exchange stream, collectives) to measure its overhead on one GPU")
     ap.add_argument("--random-chunk", action="store_true",
                     help="C3 only: the shipped YAML's chunk_size [16, 32, 64, -1] / "
                          "left_context_frames [64, 128, 256, -1] (one draw per step) instead of -1")
@@ -596,6 +599,12 @@ def main(argv=None):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    elif args.ddp_force:
+        os.environ["S2T_DDP_FORCE"] = "1"
+        os.environ["S2T_DDP_ALGO"] = args.ddp_force
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
 
     from speech2text_amd import _native
     from speech2text_amd.build_task import TaskFactory
@@ -727,6 +736,7 @@ def main(argv=None):
             "config": {"workload": (workload.replace("chunk_size -1", "chunk_size 16/32/64/-1 random per step")
                                     if args.random_chunk else workload),
                        "accumulate_grad_batches": args.accum,
+                       "ddp_forced_on_one_rank": args.ddp_force,
                        "gemm_paths": gemm_paths(),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "utterance_seconds": args.seconds, "labels_per_utt": args.labels,
@@ -738,7 +748,7 @@ def main(argv=None):
                           "step is timed on rank 0 of the N=1 run, see that line"},
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.ddp_force:
         dist.destroy_process_group()
 
 

@@ -154,30 +154,45 @@ __global__ __launch_bounds__(256) void dwconv2d_roll_kernel(const float* __restr
   const bool live = c0 + c < C && rr < nrr;
   const int cc = (c0 + c < C) ? c0 + c : 0;
   const int w0 = part * RWO, hs = rr * RRT, he = min(H, hs + RRT);
-  float wv[KH * KW];          // MODE 0/1: taps; MODE 2: tap-gradient accumulators
+  // MODE 0/1: the taps live in LDS, [tap][channel] (conflict-free, read per FMA group): as 49
+  // registers per lane next to the 130-register window they spilled to scratch, and a scratch
+  // reload shares vmcnt with the prefetched rows -- every reload waited for the rows in flight,
+  // which serialised the very loads the ring exists to overlap (600 us for a 120 us stream).
+  // MODE 2: wv are the tap-gradient accumulators (registers).
+  __shared__ float s_w[MODE == 2 ? 1 : KH * KW][MODE == 2 ? 1 : RCT];
+  float wv[MODE == 2 ? KH * KW : 1];
   float bacc = 0.f;
+  if (MODE == 2) {
 #pragma unroll
-  for (int k = 0; k < KH * KW; ++k)
-    wv[k] = (MODE == 2) ? 0.f : wgt[(long)cc * KH * KW + (MODE == 1 ? KH * KW - 1 - k : k)];
+    for (int k = 0; k < (MODE == 2 ? KH * KW : 1); ++k) wv[k] = 0.f;
+  } else {
+    for (int k = threadIdx.x / RCT; k < KH * KW; k += 256 / RCT)
+      s_w[MODE == 2 ? 0 : k][c] = wgt[(long)cc * KH * KW + (MODE == 1 ? KH * KW - 1 - k : k)];
+    __syncthreads();
+  }
   const float bv = (MODE != 2 && bias) ? bias[cc] : 0.f;
   const float* xn = x + (long)n * H * W * C;
   float win[RING][WW];     // ring of input rows: slot (k + i) % RING holds row hs - PH + k + i
   // Out-of-range taps read a zero word instead of being patched after the load: the address
   // choice is wave-uniform (scalar), and nothing has to wait for the loaded value until the FMAs
   // that use it, RPD steps later.
-  auto load_row = [&](float (&dst)[WW], int hin) {
-    const bool rv = hin >= 0 && hin < H;
-    const float* row = xn + (long)hin * W * C;
-#pragma unroll
-    for (int v = 0; v < WW; ++v) {
-      const int ww = w0 + v - PW;
-      const float* p = (rv && ww >= 0 && ww < W) ? row + (long)ww * C : g_zero;
-      dst[v] = p[cc];
-    }
-  };
+  // (a macro, not a lambda taking the row by reference: through the reference the window array
+  // stayed an alloca in scratch memory, whose loads and stores share vmcnt with the prefetched
+  // rows and waited for them)
+#define S2T_LOAD_ROW(SLOT, HIN)                                                        \
+  {                                                                                    \
+    const int hin_ = (HIN);                                                            \
+    const bool rv_ = hin_ >= 0 && hin_ < H;                                            \
+    const float* row_ = xn + (long)hin_ * W * C;                                       \
+    _Pragma("unroll") for (int v = 0; v < WW; ++v) {                                   \
+      const int ww_ = w0 + v - PW;                                                     \
+      const float* p_ = (rv_ && ww_ >= 0 && ww_ < W) ? row_ + (long)ww_ * C : g_zero;  \
+      win[SLOT][v] = p_[cc];                                                           \
+    }                                                                                  \
+  }
   if (live) {
 #pragma unroll
-    for (int s = 0; s < RING - 1; ++s) load_row(win[s], hs - PH + s);
+    for (int s = 0; s < RING - 1; ++s) S2T_LOAD_ROW(s, hs - PH + s)
     for (int k0 = 0; hs + k0 < he; k0 += RING) {
 #pragma unroll
       for (int u = 0; u < RING; ++u) {
@@ -185,8 +200,12 @@ __global__ __launch_bounds__(256) void dwconv2d_roll_kernel(const float* __restr
         if (h < he) {                                   // uniform per wave
           // request the row that is needed RPD steps from now into the slot the oldest row left:
           // RPD + 1 rows of loads are in flight while a step's FMAs run
-          load_row(win[(u + RING - 1) % RING], h + PH + RPD);
+          S2T_LOAD_ROW((u + RING - 1) % RING, h + PH + RPD)
           if (MODE != 2) {
+            // an index the compiler cannot see through (always 0): the 49 tap reads stay inside this
+            // row step -- hoisted out of the row loop they are 49 live registers again
+            int opaque0;
+            asm volatile("v_mov_b32 %0, 0" : "=v"(opaque0));
             float acc[RWO];
             if (dy) {          // MODE 0/1: dy is an optional addend with the output's layout
               const float* ar = dy + (((long)n * H + h) * W + w0) * C + cc;
@@ -200,10 +219,12 @@ __global__ __launch_bounds__(256) void dwconv2d_roll_kernel(const float* __restr
 #pragma unroll
             for (int i = 0; i < KH; ++i)
 #pragma unroll
-              for (int j = 0; j < KW; ++j)
+              for (int j = 0; j < KW; ++j) {
+                const float tap = s_w[MODE == 2 ? 0 : i * KW + j][c + opaque0];
 #pragma unroll
                 for (int o = 0; o < RWO; ++o)
-                  acc[o] = fmaf(wv[i * KW + j], win[(u + i) % RING][o + j], acc[o]);
+                  acc[o] = fmaf(tap, win[(u + i) % RING][o + j], acc[o]);
+              }
             float* yr = out + (((long)n * H + h) * W + w0) * C + cc;
 #pragma unroll
             for (int o = 0; o < RWO; ++o)
@@ -222,12 +243,13 @@ __global__ __launch_bounds__(256) void dwconv2d_roll_kernel(const float* __restr
               for (int j = 0; j < KW; ++j)
 #pragma unroll
                 for (int o = 0; o < RWO; ++o)
-                  wv[i * KW + j] = fmaf(g[o], win[(u + i) % RING][o + j], wv[i * KW + j]);
+                  wv[MODE == 2 ? i * KW + j : 0] = fmaf(g[o], win[(u + i) % RING][o + j], wv[MODE == 2 ? i * KW + j : 0]);
           }
         }
       }
     }
   }
+#undef S2T_LOAD_ROW
   if (MODE == 2) {
     // partial layout [64-channel tile][block][slot][64]; a workgroup covers RCT / 64 tiles
     __shared__ float s_red[256 / RCT][RCT];
@@ -239,7 +261,7 @@ __global__ __launch_bounds__(256) void dwconv2d_roll_kernel(const float* __restr
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       __syncthreads();
-      s_red[r][c] = live ? (k < NV - 1 ? wv[k < NV - 1 ? k : 0] : bacc) : 0.f;
+      s_red[r][c] = live ? (k < NV - 1 ? wv[MODE == 2 ? (k < NV - 1 ? k : 0) : 0] : bacc) : 0.f;
       __syncthreads();
       if (r == 0) {
         float t = 0.f;

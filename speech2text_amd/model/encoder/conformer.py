@@ -78,8 +78,17 @@ class Subsampling(nn.Module):
             x = x.unsqueeze(1).contiguous(memory_format=torch.channels_last)
         for m in convs:
             if isinstance(m, nn.Conv2d):
-                x = F.conv2d(x, m.weight.contiguous(memory_format=torch.channels_last), m.bias,
-                             m.stride)
+                if (x.is_cuda and tuple(m.kernel_size) == (3, 3) and tuple(m.padding) == (0, 0)
+                        and tuple(m.dilation) == (1, 1) and m.groups == 1
+                        and x.shape[1] % 4 == 0 and m.out_channels % 4 == 0):
+                    # implicit-im2col MFMA GEMM on the channel-last map (s2t_conv3x3_gemm, the
+                    # kernel of the zipformer frontend): the patch rows are read in place, the
+                    # weight gradient is the split-contraction TN kernel over the same patches
+                    y = zk.conv3x3_nhwc(x.permute(0, 2, 3, 1), m.weight, m.bias, m.stride)
+                    x = y.permute(0, 3, 1, 2)
+                else:
+                    x = F.conv2d(x, m.weight.contiguous(memory_format=torch.channels_last), m.bias,
+                                 m.stride)
             else:
                 x = m(x)
         b, c, t, f = x.size()

@@ -50,11 +50,13 @@ class ConvNeXt(nn.Module):
             # the residual add rides in the second pointwise GEMM's epilogue, its gradient in the
             # depthwise backward-data pass: no add pass over the (N,T,F,C) map in either direction
             x, bypass = zk.dwconv2d_nhwc_tap(x, self.depthwise_conv.weight, self.depthwise_conv.bias)
-            x = zk.linear_big_m(x, self.pointwise_conv1.weight.flatten(1), self.pointwise_conv1.bias)
-            x = self.hidden_balancer(x)
-            x = self.activation(x)
-            x = zk.linear(x, self.pointwise_conv2.weight.flatten(1), self.pointwise_conv2.bias,
-                          residual=bypass)
+            # pointwise -> [Balancer] -> SwooshL -> pointwise + bypass as ONE node: the activation and
+            # its derivative ride in the GEMMs' epilogues (zk.ffn_block); the Balancer's random
+            # draw is taken here, where the module would take it
+            hb = self.hidden_balancer
+            x = zk.ffn_block(x, self.pointwise_conv1.weight, self.pointwise_conv1.bias,
+                             self.pointwise_conv2.weight, self.pointwise_conv2.bias, bypass,
+                             hb.cfg(2) if hb.fires(x) else None)
         else:
             bypass = x
             x = zk.dwconv2d_nhwc(x, self.depthwise_conv.weight, self.depthwise_conv.bias)

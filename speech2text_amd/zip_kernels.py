@@ -1371,6 +1371,58 @@ class _LinearPass(torch.autograd.Function):
         return dx, dw.view(weight.shape), db
 
 
+class _FfnBlock(torch.autograd.Function):
+    """y = W2 swooshL(W1 x + b1) + b2 (+ residual), with an optional Balancer on the hidden
+    pre-activation -- ConvNeXt's pointwise pair (reference model/layer/subsampling.py:47-57) as ONE
+    autograd node: the kept activation leaves the first GEMM's epilogue as a second output, and in
+    backward the Swoosh derivative rides in the second GEMM's data-gradient epilogue (or in the
+    Balancer's update pass when it fires) -- no elementwise pass over the (rows, hidden) map in
+    either direction.  Weight / bias gradients as in _Linear."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, residual, bal_cfg):
+        w1m = w1 if w1.dim() == 2 else w1.reshape(w1.shape[0], -1)
+        w2m = w2 if w2.dim() == 2 else w2.reshape(w2.shape[0], -1)
+        x2 = _rows(x)
+        r2 = None if residual is None else _rows(residual)
+        h, a = lt_matmul(0, x2, w1m, b1, act2="swoosh_l")
+        y = lt_matmul(0, a, w2m, b2, r2)
+        ctx.save_for_backward(x2, h, a, w1, w2)
+        ctx.params = (w1, b1, w2, b2)
+        ctx.bal_cfg, ctx.has_res, ctx.xshape = bal_cfg, residual is not None, x.shape
+        return y.view(x.shape[:-1] + (w2m.shape[0],))
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, h, a, w1, w2 = ctx.saved_tensors
+        w1p, b1p, w2p, b2p = ctx.params
+        w1m = w1 if w1.dim() == 2 else w1.reshape(w1.shape[0], -1)
+        w2m = w2 if w2.dim() == 2 else w2.reshape(w2.shape[0], -1)
+        g2 = _rows(g)
+        grads2 = (None, None)
+        if not wgrad_into(w2p, b2p, g2, a):
+            dw, db = linear_wgrad(g2, a, b2p is not None)
+            grads2 = (dw.view(w2.shape), db)
+        if ctx.bal_cfg is not None:              # Swoosh' rides in the Balancer's update pass
+            dh = balancer_backward(h, lt_matmul(1, g2, w2m), *ctx.bal_cfg, swoosh_l=True)
+        else:                                    # ... or in the data-gradient GEMM's epilogue
+            dh = lt_matmul(1, g2, w2m, act_src=h, act_kind="swoosh_l")
+        grads1 = (None, None)
+        if not wgrad_into(w1p, b1p, dh, x2):
+            dw, db = linear_wgrad(dh, x2, b1p is not None)
+            grads1 = (dw.view(w1.shape), db)
+        dx = lt_matmul(1, dh, w1m).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        return dx, grads1[0], grads1[1], grads2[0], grads2[1], (g if ctx.has_res else None), None
+
+
+def ffn_block(x, w1, b1, w2, b2, residual=None, balancer_cfg=None):
+    """linear(swooshL(balancer(linear(x, w1, b1))), w2, b2) [+ residual] as one autograd node;
+    balancer_cfg = Balancer.cfg(2) when the hidden Balancer fires this call, else None."""
+    if not x.is_cuda:
+        raise RuntimeError("speech2text_amd.ffn_block needs device tensors (HIP path only)")
+    return _FfnBlock.apply(x, w1, b1, w2, b2, residual, balancer_cfg)
+
+
 def linear_pass(x, weight, bias=None):
     """-> (F.linear(x, weight, bias), alias of x for the residual branch)."""
     return _LinearPass.apply(x, weight, bias)
@@ -1469,7 +1521,18 @@ class _Conv3x3Nhwc(torch.autograd.Function):
             dwmat, db = linear_wgrad(g, xc, has_bias)                            # (Cout, 9C)
             dweight = dwmat.view(Cout, 3, 3, C).permute(0, 3, 1, 2)
         dx = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and ctx.implicit and 9 * C * Cout >= (1 << 18):
+            # wide channel counts (the conformer's 256 -> 256 stride-2 conv): the patch-space form
+            # below would write and re-read a (rows, 9C) matrix (1.4 GB at C2) -- the library's
+            # NHWC implicit-GEMM backward-data kernel serves this one product (measured: C2 step
+            # 25.8 ms with the patch-space form)
+            gy = g.view(B, Ho, Wo, Cout).permute(0, 3, 1, 2)
+            xin = xc.permute(0, 3, 1, 2)
+            wcl = weight.contiguous(memory_format=torch.channels_last)
+            dxn = torch.ops.aten.convolution_backward(gy, xin, wcl, None, [sh, sw], [0, 0], [1, 1],
+                                                      False, [0, 0], 1, [True, False, False])[0]
+            dx = dxn.permute(0, 2, 3, 1)
+        elif ctx.needs_input_grad[0]:
             w2 = weight.permute(0, 2, 3, 1).reshape(Cout, 9 * C)
             dc = lt_matmul(1, g, w2)                             # (B*Ho*Wo, 3*3*C)
             dx = torch.empty((B, H, W, C), dtype=torch.float32, device=dy.device)
