@@ -429,6 +429,13 @@ def cpu_baseline_c5(cfg, state_dict, seconds=30.0, batch=2, steps=3, warmup=1):
 
 
 # ------------------------------------------------------------------ roofline bookkeeping
+# fp32 products evaluated as six bf16 MFMA products (exact three-way split): the ceiling of THAT
+# pipe is the dense bf16 peak / 6 -- reported next to the f32-MFMA fraction for the entries that
+# run on it, so that a kernel on the bf16 cores is not flattered by the smaller f32 peak
+BF16X3_CEILING_TFLOPS = 2500.0 / 6.0
+BF16X3_ENTRIES = ("s2t_gemm_x3p", "s2t_gemm_tn_grouped", "s2t_gemm_f32", "s2t_gemm_xtx", "s2t_conv3x3_gemm")
+
+
 def _bound(p):
     """mfma when the call sites' algorithmic intensity exceeds the machine balance, else hbm."""
     balance = MFMA_F32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
@@ -448,6 +455,8 @@ def roofline_report(prof_timed, prof_all, want, step_flops, ms_per_step, sampled
             if p["algo_flops"] > 0:
                 tf = p["algo_flops"] / (p["total_ms"] * 1e-3) / 1e12
                 row.update(alg_TFLOPs=tf, frac_mfma=tf / MFMA_F32_PEAK_TFLOPS)
+                if name in BF16X3_ENTRIES:
+                    row.update(frac_bf16x3_ceiling=tf / BF16X3_CEILING_TFLOPS)
         table.append(row)
     out = {"bound": "hbm", "kernel": want, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": None, "traffic": None}
@@ -458,6 +467,9 @@ def roofline_report(prof_timed, prof_all, want, step_flops, ms_per_step, sampled
             out.update(bound="mfma", achieved=ach, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
                        frac=ach / MFMA_F32_PEAK_TFLOPS,
                        algorithmic_flops_per_launch=p["algo_flops"] / p["launches"])
+            if want in BF16X3_ENTRIES:
+                out.update(frac_bf16x3_ceiling=ach / BF16X3_CEILING_TFLOPS,
+                           bf16x3_ceiling_tflops=BF16X3_CEILING_TFLOPS)
         else:
             ach = p["algo_bytes"] / (p["total_ms"] * 1e-3) / 1e9
             out.update(achieved=ach, frac=ach / HBM_PEAK_GBS)

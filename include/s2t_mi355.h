@@ -624,8 +624,10 @@ int s2t_gemm_x3f_nt(const float* A, long lda, const unsigned short* Bf, float* C
  * s2t_x3p_split: every matrix of a model in ONE launch -- tab = DEVICE array of n S2tPlaneDesc
  *   (src_off: floats from base; dst_off: bf16 from dst; blk_begin: first block of the descriptor,
  *   ascending, descriptor d owns s2t_x3p_split_blocks(N,K) blocks), total_blocks = their sum.
- * s2t_gemm_x3p: C[M,N] = A[M,K] . Bm^T (+ bias[N]) (* act'(act_src[M,N])) (+ resid[M,N]) and
- *   optionally C2 = act2(C); act kinds 1 = SwooshL, 2 = SwooshR.  K % 8 == 0, N % 4 == 0, rows
+ * s2t_gemm_x3p: C[M,N] = A[M,K] . Bm^T (+ bias[N]) (* act'(act_src[M,N])) (+ resid[M,N])
+ *   (+ resid_b[M,N]) and optionally C2 = act2(C); act kinds 1 = SwooshL, 2 = SwooshR; act2 = 3:
+ *   C2 = C + resid_b instead (C itself without resid_b: a module's output and the residual
+ *   stream after it from one launch).  K % 8 == 0, N % 4 == 0, rows
  *   16-byte aligned (else -2).  tile = 0 (from the shape) | 11 | 12 | 21 | 22: block tile
  *   (64 tm) x (64 tn); + 100 w: w persistent workgroups per CU (tuning). */
 typedef struct {
@@ -641,7 +643,8 @@ int s2t_x3p_split(const float* base, const void* tab, int n, int total_blocks, u
                   void* stream);
 int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int K, float* C, long ldc,
                  int M, const float* bias, const float* resid, long ldr, const float* act_src,
-                 long ld_act, int act_kind, float* C2, long ldc2, int act2, int tile, void* stream);
+                 long ld_act, int act_kind, float* C2, long ldc2, int act2, const float* resid_b,
+                 long ldrb, int tile, void* stream);
 
 /* ---- side stream for work off the critical path (csrc/streams.hip): the weight-gradient GEMMs
  * of backward overlap the data-gradient chain.  s2t_side_stream returns the library-owned stream;

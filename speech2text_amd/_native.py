@@ -48,6 +48,8 @@ class _Prof:
 
 
 _NO_LAUNCH = ("s2t_side_stream", "s2t_stream_order")   # stream plumbing, nothing to time
+PROF = [False]   # True while profile_begin() is active: call sites write `N.PROF[0] and
+                 # N.profile_note(...)` so that the note's arguments cost nothing on the training path
 _EXT = {}
 
 
@@ -128,6 +130,7 @@ def profile_begin(entry_point, every=1):
     if entry_point != "*" and entry_point not in parse_header():
         raise ValueError(f"{entry_point!r} is not an entry point of include/s2t_mi355.h")
     _Prof.target = entry_point
+    PROF[0] = True
     _Prof.events = {}
     _Prof.algo_bytes = {}
     _Prof.algo_flops = {}
@@ -150,6 +153,7 @@ def profile_note(entry_point, nbytes=0.0, flops=0.0):
 def profile_end():
     """-> {entry: {launches, total_ms, avg_ms, algo_bytes, algo_flops}}"""
     _Prof.target = None
+    PROF[0] = False
     if _lib is not None:
         _lib._reset()
     out = {}

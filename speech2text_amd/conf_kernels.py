@@ -37,7 +37,7 @@ def ln_fwd(x2, y2, alpha, weight, bias, eps):
     out = torch.empty_like(x2)
     stats = torch.empty((R, 2), dtype=_F32, device=x2.device)
     xsum = torch.empty_like(x2) if y2 is not None else None
-    N.profile_note("s2t_layernorm_fwd", 4.0 * R * C * (2 if y2 is None else 4))
+    N.PROF[0] and N.profile_note("s2t_layernorm_fwd", 4.0 * R * C * (2 if y2 is None else 4))
     N.check(N.lib().s2t_layernorm_fwd(N.fp(x2), N.fp(y2), float(alpha), N.fp(weight), N.fp(bias),
                                       R, C, float(eps), N.fp(xsum), N.fp(out), N.fp(stats),
                                       N.stream()), "s2t_layernorm_fwd")
@@ -57,7 +57,7 @@ def ln_bwd(x2, stats, weight, dy2, resid2, pend):
     dx = torch.empty_like(x2)
     partial = torch.empty(N.lib().s2t_layernorm_bwd_partial_floats(R, C), dtype=_F32,
                           device=x2.device)
-    N.profile_note("s2t_layernorm_bwd", 4.0 * R * C * (3 if resid2 is None else 4))
+    N.PROF[0] and N.profile_note("s2t_layernorm_bwd", 4.0 * R * C * (3 if resid2 is None else 4))
     N.check(N.lib().s2t_layernorm_bwd(N.fp(x2), N.fp(stats), N.fp(weight), N.fp(dy2),
                                       N.fp(resid2), R, C, N.fp(dx), N.fp(partial), N.stream()),
             "s2t_layernorm_bwd")
@@ -72,6 +72,7 @@ def ln_param_grad(items, C):
     for q, (partial, rows, dg, db) in zip(arr, items):
         q.partial, q.rows = partial.data_ptr(), rows
         q.dgamma, q.dbeta = dg.data_ptr(), db.data_ptr()
+    N.PROF[0] and N.profile_note("s2t_layernorm_param_grad", 4.0 * sum(it[0].numel() for it in items) + 16.0 * C * len(items))
     N.check(N.lib().s2t_layernorm_param_grad(len(items), ctypes.cast(arr, ctypes.c_void_p), C,
                                              N.stream()), "s2t_layernorm_param_grad")
 
@@ -79,7 +80,7 @@ def ln_param_grad(items, C):
 def silu_fwd(h2, p=0.0, seed=0):
     """silu(h), or drop(silu(h)) with the hashed mask of (seed, p) (nn.Dropout after the SiLU)."""
     a = torch.empty_like(h2)
-    N.profile_note("s2t_silu_fwd", 8.0 * h2.numel())
+    N.PROF[0] and N.profile_note("s2t_silu_drop_fwd" if p > 0.0 else "s2t_silu_fwd", 8.0 * h2.numel())
     if p > 0.0:
         N.check(N.lib().s2t_silu_drop_fwd(N.fp(h2), h2.numel(), float(p), int(seed), N.fp(a),
                                           N.stream()), "s2t_silu_drop_fwd")
@@ -91,7 +92,7 @@ def silu_fwd(h2, p=0.0, seed=0):
 def silu_bwd(h2, da2, scale=1.0, inplace=True, p=0.0, seed=0):
     """scale * da * silu'(h) (* the dropout mask of (seed, p)); written over da2 when `inplace`."""
     dh = da2 if inplace else torch.empty_like(da2)
-    N.profile_note("s2t_silu_bwd", 12.0 * h2.numel())
+    N.PROF[0] and N.profile_note("s2t_silu_drop_bwd" if p > 0.0 else "s2t_silu_bwd", 12.0 * h2.numel())
     if p > 0.0:
         N.check(N.lib().s2t_silu_drop_bwd(N.fp(h2), N.fp(da2), h2.numel(), float(scale), float(p),
                                           int(seed), N.fp(dh), N.stream()), "s2t_silu_drop_bwd")
@@ -105,7 +106,7 @@ def dropout_add(x2, y2, alpha, p, seed):
     """x + alpha * drop(y) in one pass (x2 None: alpha * drop(y), the gradient through the site);
     mask = the stateless hash of (seed, element index), kept values scaled by 1 / (1 - p)."""
     out = torch.empty_like(y2)
-    N.profile_note("s2t_dropout_add", 4.0 * y2.numel() * (3 if x2 is not None else 2))
+    N.PROF[0] and N.profile_note("s2t_dropout_add", 4.0 * y2.numel() * (3 if x2 is not None else 2))
     N.check(N.lib().s2t_dropout_add(N.fp(x2), N.fp(y2), y2.numel(), float(alpha), float(p),
                                     int(seed), N.fp(out), N.stream()), "s2t_dropout_add")
     return out
@@ -131,7 +132,7 @@ def bn_silu_fwd(x2, bn):
     rstd = torch.empty(C, dtype=_F32, device=x2.device)
     track = bn.track_running_stats and bn.running_mean is not None
     mom = 0.1 if bn.momentum is None else float(bn.momentum)
-    N.profile_note("s2t_bn_silu_fwd", 12.0 * R * C)
+    N.PROF[0] and N.profile_note("s2t_bn_silu_fwd", 12.0 * R * C)
     N.check(N.lib().s2t_bn_silu_fwd(N.fp(x2), N.fp(bn.weight), N.fp(bn.bias), float(bn.eps), mom,
                                     N.fp(bn.running_mean) if track else None,
                                     N.fp(bn.running_var) if track else None,
@@ -154,7 +155,7 @@ def bn_silu_eval(x2, bn):
 def bn_silu_bwd(x2, ds2, mean, rstd, weight, bias, dgamma, dbeta):
     R, C = x2.shape
     dx = torch.empty_like(x2)
-    N.profile_note("s2t_bn_silu_bwd", 20.0 * R * C)
+    N.PROF[0] and N.profile_note("s2t_bn_silu_bwd", 20.0 * R * C)
     N.check(N.lib().s2t_bn_silu_bwd(N.fp(x2), N.fp(ds2), N.fp(mean), N.fp(rstd), N.fp(weight),
                                     N.fp(bias), R, C, N.fp(dx), N.fp(dgamma), N.fp(dbeta),
                                     N.fp(_bn_ws(x2.device, C)), N.stream()), "s2t_bn_silu_bwd")
@@ -167,7 +168,7 @@ def mhsa_fwd(qkv2, lens, T, B, H, dropout_p=0.0, seed=0):
     dh = D // H
     o = torch.empty((T * B, D), dtype=_F32, device=qkv2.device)
     lse = torch.empty((B, H, T), dtype=_F32, device=qkv2.device)
-    N.profile_note("s2t_mhsa_fwd", 4.0 * (qkv2.numel() + o.numel()), 4.0 * B * H * T * T * dh)
+    N.PROF[0] and N.profile_note("s2t_mhsa_fwd", 4.0 * (qkv2.numel() + o.numel()), 4.0 * B * H * T * T * dh)
     N.check(N.lib().s2t_mhsa_fwd(N.fp(qkv2), 3 * D, 0, D, 2 * D, N.lp(lens), T, B, H, dh,
                                  1.0 / math.sqrt(dh), float(dropout_p), int(seed), N.fp(o), D,
                                  N.fp(lse), N.stream()), "s2t_mhsa_fwd")
@@ -179,7 +180,7 @@ def mhsa_bwd(qkv2, lens, T, B, H, o2, do2, lse, dropout_p=0.0, seed=0):
     dh = D // H
     dqkv = torch.empty_like(qkv2)
     delta = torch.empty((B, H, T), dtype=_F32, device=qkv2.device)
-    N.profile_note("s2t_mhsa_bwd", 4.0 * (2 * qkv2.numel() + 2 * o2.numel()),
+    N.PROF[0] and N.profile_note("s2t_mhsa_bwd", 4.0 * (2 * qkv2.numel() + 2 * o2.numel()),
                    14.0 * B * H * T * T * dh)
     N.check(N.lib().s2t_mhsa_bwd(N.fp(qkv2), 3 * D, 0, D, 2 * D, N.lp(lens), T, B, H, dh,
                                  1.0 / math.sqrt(dh), float(dropout_p), int(seed), N.fp(o2),
@@ -445,7 +446,7 @@ class _Conv1Relu(torch.autograd.Function):
         out = torch.empty((B, T1, F1, C), dtype=_F32, device=x.device)
         w2 = weight.detach().reshape(C, 9).contiguous()
         b1 = bias.detach().contiguous()
-        N.profile_note("s2t_conv1_relu_fwd", 4.0 * (x3.numel() + out.numel()))
+        N.PROF[0] and N.profile_note("s2t_conv1_relu_fwd", 4.0 * (x3.numel() + out.numel()))
         N.check(N.lib().s2t_conv1_relu_fwd(N.fp(x3), N.fp(w2), N.fp(b1), B, T, F_, C, N.fp(out),
                                            N.stream()), "s2t_conv1_relu_fwd")
         ctx.save_for_backward(x3, w2, b1)
@@ -468,7 +469,7 @@ class _Conv1Relu(torch.autograd.Function):
         else:
             dw, db = slots
         ws = torch.empty(N.lib().s2t_conv1_relu_workspace_floats(C), dtype=_F32, device=x3.device)
-        N.profile_note("s2t_conv1_relu_wgrad", 4.0 * (x3.numel() + d.numel()))
+        N.PROF[0] and N.profile_note("s2t_conv1_relu_wgrad", 4.0 * (x3.numel() + d.numel()))
         N.check(N.lib().s2t_conv1_relu_wgrad(N.fp(x3), N.fp(w2), N.fp(b1), N.fp(d), B, T, F_, C,
                                              N.raw(dw), N.raw(db), N.fp(ws), N.stream()),
                 "s2t_conv1_relu_wgrad")

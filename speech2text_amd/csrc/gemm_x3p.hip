@@ -93,9 +93,11 @@ struct X3P {
   const float* act_src;       // C *= act'(act_src[m][n]) (before the residual), or NULL
   long lds;
   int act_kind;
-  float* C2;                  // C2 = act2(C) or NULL
+  float* C2;                  // C2 = act2(C) (act2 1 | 2), or C + resid_b (act2 3), or NULL
   long ldc2;
   int act2;
+  const float* resid_b;       // second [M][N] addend: into C (no C2), or into C2 only (act2 3)
+  long ldrb;
   int tiles_m, tiles_n;
   int wgs_per_cu;             // persistent form: workgroups per CU (0 = default)
   int prio;                   // 1: wave priority by the workgroup's slot on its CU (see x3p_set_prio)
@@ -134,7 +136,7 @@ __device__ __forceinline__ void x3p_epilogue(const X3P& g, f32x16 (&acc)[TM][TN]
       if (g.bias && cok) bv = *reinterpret_cast<const float4*>(g.bias + col);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {                  // rows 16 h .. 16 h + 15 of the tile
-        float4 rv[2], sv[2];
+        float4 rv[2], sv[2], rbv[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           const int row = min(m0 + 32 * (wrb + i) + 16 * h + er + 8 * q, g.M - 1);
@@ -142,6 +144,8 @@ __device__ __forceinline__ void x3p_epilogue(const X3P& g, f32x16 (&acc)[TM][TN]
                                    : make_float4(0.f, 0.f, 0.f, 0.f);
           sv[q] = (g.act_src && cok) ? *reinterpret_cast<const float4*>(g.act_src + (long)row * g.lds + col)
                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+          rbv[q] = (g.resid_b && cok) ? *reinterpret_cast<const float4*>(g.resid_b + (long)row * g.ldrb + col)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int r = 0; r < 8; ++r)
@@ -160,9 +164,14 @@ __device__ __forceinline__ void x3p_epilogue(const X3P& g, f32x16 (&acc)[TM][TN]
             v.w *= swoosh_deriv(sv[q].w, g.act_kind);
           }
           v = make_float4(v.x + rv[q].x, v.y + rv[q].y, v.z + rv[q].z, v.w + rv[q].w);
+          if (g.resid_b && g.act2 != 3)
+            v = make_float4(v.x + rbv[q].x, v.y + rbv[q].y, v.z + rbv[q].z, v.w + rbv[q].w);
           if (row < g.M && cok) {
             *reinterpret_cast<float4*>(g.C + (long)row * g.ldc + col) = v;
-            if (g.C2)
+            if (g.C2 && g.act2 == 3)
+              *reinterpret_cast<float4*>(g.C2 + (long)row * g.ldc2 + col) =
+                  make_float4(v.x + rbv[q].x, v.y + rbv[q].y, v.z + rbv[q].z, v.w + rbv[q].w);
+            else if (g.C2)
               *reinterpret_cast<float4*>(g.C2 + (long)row * g.ldc2 + col) =
                   make_float4(swoosh(v.x, g.act2), swoosh(v.y, g.act2), swoosh(v.z, g.act2),
                               swoosh(v.w, g.act2));
@@ -562,10 +571,11 @@ int s2t_x3p_split(const float* base, const void* tab, int n, int total_blocks, u
 
 int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int K, float* C, long ldc,
                  int M, const float* bias, const float* resid, long ldr, const float* act_src,
-                 long ld_act, int act_kind, float* C2, long ldc2, int act2, int tile, void* stream) {
+                 long ld_act, int act_kind, float* C2, long ldc2, int act2, const float* resid_b,
+                 long ldrb, int tile, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || !A || !Bp || !C) return -1;
-  if (act_kind < 0 || act_kind > 2 || act2 < 0 || act2 > 2 || (act_src && act_kind == 0) ||
-      (C2 && act2 == 0))
+  if (act_kind < 0 || act_kind > 2 || act2 < 0 || act2 > 3 || (act_src && act_kind == 0) ||
+      (C2 && act2 == 0) || (act2 == 3 && (!C2 || !resid_b)))
     return -1;
   const int wgs = tile / 100;          // hundreds digit: persistent workgroups per CU (0 = default)
   tile %= 100;
@@ -573,10 +583,11 @@ int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int 
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   if ((K & 7) || (N & 3) || (lda & 3) || (ldc & 3) || !al16(A) || !al16(Bp) || !al16(C) ||
       (bias && !al16(bias)) || (resid && (!al16(resid) || (ldr & 3))) ||
-      (act_src && (!al16(act_src) || (ld_act & 3))) || (C2 && (!al16(C2) || (ldc2 & 3))))
+      (act_src && (!al16(act_src) || (ld_act & 3))) || (C2 && (!al16(C2) || (ldc2 & 3))) ||
+      (resid_b && (!al16(resid_b) || (ldrb & 3))))
     return -2;
   X3P g{A, lda, Bp, (N + 31) / 32, 2 * ((K + 31) / 32), C, ldc, M, N, K, bias, resid, ldr, act_src,
-        ld_act, act_kind, C2, ldc2, act2, 0, 0, wgs, 0};
+        ld_act, act_kind, C2, ldc2, act2, resid_b, ldrb, 0, 0, wgs, 0};
   {
     static int prio = -1;      // S2T_X3P_PRIO=0: no slot priority
     if (prio < 0) { const char* e = getenv("S2T_X3P_PRIO"); prio = e ? atoi(e) : 1; }

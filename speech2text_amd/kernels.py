@@ -78,7 +78,7 @@ def fbank_batch(pcm, num_samples, tables, cmvn_mean=None, cmvn_istd=None, scale_
     frames = torch.empty((B,), dtype=torch.int64, device=pcm.device)
     if B == 0 or max_frames == 0:
         return out, frames.zero_()
-    N.profile_note("s2t_fbank_f32", 4.0 * (pcm.numel() + out.numel()))
+    N.PROF[0] and N.profile_note("s2t_fbank_f32", 4.0 * (pcm.numel() + out.numel()))
     rc = N.lib().s2t_fbank_f32(N.fp(pcm), pcm.stride(0), N.lp(num_samples), B,
                                N.fp(tables.window), N.fp(tables.twiddle), N.ip(tables.mel_off),
                                N.ip(tables.mel_k0), N.fp(tables.mel_w), tables.nnz,
@@ -117,6 +117,8 @@ class _CtcLoss(torch.autograd.Function):
                          device=dev)
         per = torch.empty(B, dtype=torch.float32, device=dev)
         grad = torch.empty_like(logits)
+        # 2 B T V 4 (logits in, gradient out) + 3 B T (2U+1) 4 (lattice rows)
+        N.PROF[0] and N.profile_note("s2t_ctc_loss_fwd_bwd", 8.0 * B * T * V + 12.0 * B * T * (2 * U + 1))
         rc = N.lib().s2t_ctc_loss_fwd_bwd(N.fp(logits), N.lp(targets), targets.stride(0),
                                           N.lp(in_len), N.lp(tgt_len), B, T, V, U, int(blank),
                                           int(bool(zero_infinity)), N.fp(scale), N.fp(ws),
@@ -158,14 +160,14 @@ def mutual_information(px, py, boundary, want_grads=True):
     p = torch.empty((B, S + 1, T + 1), dtype=torch.float32, device=dev)
     ans = torch.empty((B,), dtype=torch.float32, device=dev)
     L = N.lib()
-    N.profile_note("s2t_mutual_info_fwd", 4.0 * (px.numel() + py.numel() + p.numel()))
+    N.PROF[0] and N.profile_note("s2t_mutual_info_fwd", 4.0 * (px.numel() + py.numel() + p.numel()))
     N.check(L.s2t_mutual_info_fwd(N.fp(px), N.fp(py), N.lp(boundary), B, S, T, N.fp(p),
                                   N.fp(ans), N.stream()), "s2t_mutual_info_fwd")
     if not want_grads:
         return ans, p, None, None
     gx = torch.empty_like(px)
     gy = torch.empty_like(py)
-    N.profile_note("s2t_mutual_info_bwd", 4.0 * (2 * px.numel() + 2 * py.numel() + p.numel()))
+    N.PROF[0] and N.profile_note("s2t_mutual_info_bwd", 4.0 * (2 * px.numel() + 2 * py.numel() + p.numel()))
     N.check(L.s2t_mutual_info_bwd(N.fp(px), N.fp(py), N.lp(boundary), N.fp(p), None, B, S, T,
                                   N.fp(gx), N.fp(gy), N.stream()), "s2t_mutual_info_bwd")
     return ans, p, gx, gy
@@ -235,7 +237,7 @@ def rnnt_prune_ranges(px_grad, py_grad, boundary, s_range):
     if s_range > S:
         s_range = S + 1
     ranges = torch.empty((B, T, s_range), dtype=torch.int64, device=px_grad.device)
-    N.profile_note("s2t_rnnt_prune_ranges", 4.0 * (px_grad.numel() + py_grad.numel()) + 8.0 * ranges.numel())
+    N.PROF[0] and N.profile_note("s2t_rnnt_prune_ranges", 4.0 * (px_grad.numel() + py_grad.numel()) + 8.0 * ranges.numel())
     N.check(N.lib().s2t_rnnt_prune_ranges(N.fp(px_grad), N.fp(py_grad), N.lp(boundary), B, S, T,
                                           int(s_range), N.lp(ranges), N.stream()),
             "s2t_rnnt_prune_ranges")
@@ -263,7 +265,7 @@ class _PrunedJoinerLoss(torch.autograd.Function):
         px = torch.empty((B, S, T + 1), dtype=torch.float32, device=dev)
         py = torch.empty((B, S + 1, T), dtype=torch.float32, device=dev)
         lse = torch.empty((B, T, R), dtype=torch.float32, device=dev)
-        N.profile_note("s2t_rnnt_pruned_fwd",
+        N.PROF[0] and N.profile_note("s2t_rnnt_pruned_fwd",
                        4.0 * (am.numel() + lm.numel() + px.numel() + py.numel() + lse.numel())
                        + 8.0 * ranges.numel())
         N.check(L.s2t_rnnt_pruned_fwd(N.fp(am), N.fp(lm), N.lp(ranges), N.lp(symbols),
@@ -285,7 +287,7 @@ class _PrunedJoinerLoss(torch.autograd.Function):
         d_lm = torch.empty_like(lm)
         # the (B,T,R,C) pruned logits are recomputed, never stored: the algorithmic traffic is the
         # operands and their gradients; the recomputation costs 2 B T R C flops of VALU per pass
-        N.profile_note("s2t_rnnt_pruned_bwd",
+        N.PROF[0] and N.profile_note("s2t_rnnt_pruned_bwd",
                        4.0 * (2 * am.numel() + 2 * lm.numel() + lse.numel() + gx.numel() + gy.numel())
                        + 8.0 * ranges.numel(), 4.0 * B * T * R * C)
         N.check(N.lib().s2t_rnnt_pruned_bwd(N.fp(am), N.fp(lm), N.lp(ranges), N.lp(symbols),
@@ -359,7 +361,7 @@ class _SmoothedNll(torch.autograd.Function):
         labels = labels.to(device=logits.device, dtype=torch.int64).contiguous()
         row = torch.empty(rows, dtype=torch.float32, device=logits.device)
         lse = torch.empty(rows, dtype=torch.float32, device=logits.device)
-        N.profile_note("s2t_smoothed_nll_fwd", 4.0 * logits.numel())
+        N.PROF[0] and N.profile_note("s2t_smoothed_nll_fwd", 4.0 * logits.numel())
         N.check(N.lib().s2t_smoothed_nll_fwd(N.fp(logits), N.lp(labels), rows, K, float(scale),
                                              float(t_other), float(t_label), float(c0),
                                              N.fp(row), N.fp(lse), N.stream()), "smoothed_nll_fwd")
@@ -373,7 +375,7 @@ class _SmoothedNll(torch.autograd.Function):
         scale, t_other, t_label = ctx.cfg
         rows, K = logits.shape
         grad = torch.empty_like(logits)
-        N.profile_note("s2t_smoothed_nll_bwd", 8.0 * logits.numel())
+        N.PROF[0] and N.profile_note("s2t_smoothed_nll_bwd", 8.0 * logits.numel())
         N.check(N.lib().s2t_smoothed_nll_bwd(N.fp(logits), N.lp(labels), N.fp(lse),
                                              N.fp(g.contiguous().float()), rows, K, scale, t_other,
                                              t_label, N.fp(grad), N.stream()), "smoothed_nll_bwd")

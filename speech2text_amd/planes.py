@@ -69,7 +69,7 @@ class PlaneArena:
     def refresh(self):
         st = self.store
         if self.ndesc:
-            N.profile_note("s2t_x3p_split", 4.0 * st.numel + 2.0 * self.planes.numel())
+            N.PROF[0] and N.profile_note("s2t_x3p_split", 4.0 * st.numel + 2.0 * self.planes.numel())
             N.check(N.lib().s2t_x3p_split(N.fp(st.flat_p), ctypes.c_void_p(self.tab.data_ptr()),
                                           self.ndesc, self.blocks,
                                           ctypes.c_void_p(self.planes.data_ptr()), N.stream()),

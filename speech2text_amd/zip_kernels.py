@@ -52,7 +52,7 @@ def swoosh_forward(x, is_l):
     off, c = _SW[is_l]
     x = _c16(x.float())
     y = torch.empty_like(x)
-    N.profile_note("s2t_swoosh_fwd", 8.0 * x.numel())
+    N.PROF[0] and N.profile_note("s2t_swoosh_fwd", 8.0 * x.numel())
     N.check(N.lib().s2t_swoosh_fwd(N.fp(x), N.fp(y), x.numel(), off, c, N.stream()), "swoosh")
     return y
 
@@ -64,7 +64,7 @@ def swoosh_backward(x, g, is_l, mask=None):
     x = _c16(x.float())
     g = _c16(g.float())
     d = torch.empty_like(x)
-    N.profile_note("s2t_swoosh_bwd", 12.0 * x.numel())
+    N.PROF[0] and N.profile_note("s2t_swoosh_bwd", 12.0 * x.numel())
     N.check(N.lib().s2t_swoosh_bwd(N.fp(x), N.fp(g), N.fp(d), x.numel(), off, N.stream()),
             "swoosh_bwd")
     return d if mask is None else d * mask
@@ -126,7 +126,7 @@ class _BiasNorm(torch.autograd.Function):
         y = torch.empty_like(x)
         scales = torch.empty(rows, dtype=torch.float32, device=x.device)
         bias = bias.contiguous().float()
-        N.profile_note("s2t_biasnorm_fwd", 8.0 * x.numel())
+        N.PROF[0] and N.profile_note("s2t_biasnorm_fwd", 8.0 * x.numel())
         N.check(N.lib().s2t_biasnorm_fwd(N.fp(x), N.fp(bias),
                                          N.fp(log_scale.reshape(1).contiguous().float()), rows, D,
                                          N.fp(y), N.fp(scales), N.stream()), "biasnorm_fwd")
@@ -141,7 +141,7 @@ class _BiasNorm(torch.autograd.Function):
         rows = x.numel() // D
         dx = torch.empty_like(x)
         acc = torch.zeros(D + 1, dtype=torch.float32, device=x.device)
-        N.profile_note("s2t_biasnorm_bwd", 12.0 * x.numel())
+        N.PROF[0] and N.profile_note("s2t_biasnorm_bwd", 12.0 * x.numel())
         N.check(N.lib().s2t_biasnorm_bwd(N.fp(x), N.fp(bias), N.fp(scales), N.fp(g), rows, D,
                                          N.fp(dx), N.fp(acc), ctypes_off(acc, D), N.stream()),
                 "biasnorm_bwd")
@@ -203,7 +203,7 @@ def balancer_backward(x, g, min_mean, max_mean, min_rms, max_rms, grad_scale, ch
             out = torch.empty_like(g2)
         ws = _balancer_workspace(x.device)
         ws[1] ^= 1
-        N.profile_note("s2t_balancer_bwd", 4.0 * rows * C * 4)     # x twice (stats, update), g, out
+        N.PROF[0] and N.profile_note("s2t_balancer_bwd", 4.0 * rows * C * 4)     # x twice (stats, update), g, out
         N.check(N.lib().s2t_balancer_bwd(N.raw(x2, torch.float32), x2.stride(0),
                                          N.raw(g2, torch.float32), g2.stride(0), rows, C, min_mean,
                                          max_mean, min_rms, max_rms, grad_scale,
@@ -312,7 +312,7 @@ class WhitenStats:
         if _tn_ok(xf):
             # symmetric product: only the 64x64 tiles on / above the diagonal that hold same-group
             # pairs are computed (6 of 9 at C = 192, 10 of 16 at 256, the diagonal for the keys)
-            N.profile_note("s2t_gemm_xtx", 4.0 * (xf.numel() + C * cg), 2.0 * n * C * cg)
+            N.PROF[0] and N.profile_note("s2t_gemm_xtx", 4.0 * (xf.numel() + C * cg), 2.0 * n * C * cg)
             N.check(N.lib().s2t_gemm_xtx(N.raw(xf, torch.float32), xf.stride(0), n, C, cg,
                                          N.fp(xtx), xtx.stride(0), N.fp(colsum),
                                          side if side is not None else N.stream()), "s2t_gemm_xtx")
@@ -328,7 +328,7 @@ class WhitenStats:
         self.mean = torch.empty((C,), dtype=torch.float32, device=dev)
         self.scal = torch.empty((4,), dtype=torch.float32, device=dev)
         self.host = _pinned_slot()
-        N.profile_note("s2t_whiten_metric", 4.0 * (2 * C * cg + C * C))
+        N.PROF[0] and N.profile_note("s2t_whiten_metric", 4.0 * (2 * C * cg + C * C))
         N.check(N.lib().s2t_whiten_metric(N.fp(xtx), N.fp(colsum), n, G, cg, N.fp(self.cov),
                                           N.fp(self.mean), N.fp(self.scal),
                                           ctypes.c_void_p(self.host.data_ptr()), N.fp(ws),
@@ -365,7 +365,7 @@ def whiten_backward(x, g, stats, limit, grad_scale):
     dcov = torch.empty((C, C), dtype=torch.float32, device=dev)
     bias = torch.empty((C,), dtype=torch.float32, device=dev)
     sums = torch.empty((2,), dtype=torch.float32, device=dev)
-    N.profile_note("s2t_whiten_dcov", 4.0 * (C * cg + C * C + 2 * C))
+    N.PROF[0] and N.profile_note("s2t_whiten_dcov", 4.0 * (C * cg + C * C + 2 * C))
     N.check(N.lib().s2t_whiten_dcov(N.fp(stats.cov), N.fp(stats.mean), N.fp(stats.scal), G, cg,
                                     N.fp(dcov), N.fp(bias), N.fp(sums), N.stream()),
             "s2t_whiten_dcov")
@@ -377,7 +377,7 @@ def whiten_backward(x, g, stats, limit, grad_scale):
     if g2.data_ptr() % 16:
         g2 = g2.clone()
     out = torch.empty_like(g2)
-    N.profile_note("s2t_whiten_apply", 12.0 * g2.numel())
+    N.PROF[0] and N.profile_note("s2t_whiten_apply", 12.0 * g2.numel())
     N.check(N.lib().s2t_whiten_apply(N.fp(g2), N.fp(pg), g2.numel(), float(grad_scale), N.fp(sums),
                                      N.fp(out), N.stream()), "s2t_whiten_apply")
     return out.view(shp), True
@@ -411,7 +411,7 @@ def zipconv_forward(u, gate_off, m8, chunk, K, wc, bc, wk, bk, scale):
     T, B, ld = u.shape
     C = wk.shape[0]
     y = torch.empty((T, B, C), dtype=torch.float32, device=u.device)
-    N.profile_note("s2t_zipconv_fwd", 4.0 * (u.numel() + y.numel()))
+    N.PROF[0] and N.profile_note("s2t_zipconv_fwd", 4.0 * (u.numel() + y.numel()))
     N.check(N.lib().s2t_zipconv_fwd(N.fp(u), ld, gate_off, N.ptr(m8), T, B, C, K, chunk,
                                     N.fp(wc), N.fp(bc), N.fp(wk), N.fp(bk), N.fp(scale), N.fp(y),
                                     N.stream()), "s2t_zipconv_fwd")
@@ -428,7 +428,7 @@ def zipconv_backward(u, gate_off, m8, chunk, K, wc, wk, bk, scale, dy, grads):
     ws = torch.empty(N.lib().s2t_zipconv_bwd_workspace_floats(T, B, C, K), dtype=torch.float32,
                      device=dev)
     dwc, dbc, dwk, dbk, dsc = grads
-    N.profile_note("s2t_zipconv_bwd", 4.0 * (2 * u.numel() + 2 * dy.numel()))
+    N.PROF[0] and N.profile_note("s2t_zipconv_bwd", 4.0 * (2 * u.numel() + 2 * dy.numel()))
     N.check(N.lib().s2t_zipconv_bwd(N.fp(u), ld, gate_off, N.ptr(m8), T, B, C, K, chunk,
                                     N.fp(wc), N.fp(wk), N.fp(bk), N.fp(scale), N.fp(dy),
                                     N.fp(du), N.raw(dwc) if dwc is not None else None,
@@ -550,7 +550,7 @@ def _attn_bwd_call(qkp, pos, k8, a8, H, qd, pd, W, dW, dW0, pairs, delta):
     # (2 pd each) -- 192 at the C3 dims against 8 bytes: above the chip's 19.7 flop/byte balance,
     # so the f32 matrix cores bound this launch, not HBM
     cd = sum(int(e[3]) for e in p)
-    N.profile_note("s2t_relpos_attn_bwd", 4.0 * (2 * qkp.numel() + 2 * W.numel()),
+    N.PROF[0] and N.profile_note("s2t_relpos_attn_bwd", 4.0 * (2 * qkp.numel() + 2 * W.numel()),
                    2.0 * W.numel() * (cd + 2 * qd + (2 * pd if pos is not None else 0)))
     N.check(N.lib().s2t_relpos_attn_bwd(N.fp(qkp), N.fp(pos), N.ptr(k8), N.ptr(a8), T, B, H, qd, pd,
                                         N.fp(W), N.fp(dW), N.fp(dW0), N.fp(p[0][0]), N.fp(p[0][1]),
@@ -570,7 +570,7 @@ class _RelPosAttn(torch.autograd.Function):
         k8 = None if kpm is None else kpm.to(torch.uint8).contiguous()
         a8 = None if amask is None else amask.to(torch.uint8).contiguous()
         W = torch.empty((H, B, T, T), dtype=torch.float32, device=qkp.device)
-        N.profile_note("s2t_relpos_attn_fwd", 4.0 * (qkp.numel() + W.numel()),
+        N.PROF[0] and N.profile_note("s2t_relpos_attn_fwd", 4.0 * (qkp.numel() + W.numel()),
                        2.0 * W.numel() * (qd + (pd if pos is not None else 0)))
         N.check(N.lib().s2t_relpos_attn_fwd(N.fp(qkp), N.fp(pos), N.ptr(k8), N.ptr(a8), T, B, H,
                                             qd, pd, N.fp(W), N.stream()), "s2t_relpos_attn_fwd")
@@ -663,7 +663,7 @@ class _AttnApplyDeferred(torch.autograd.Function):
         T, B, HD = v.shape
         dv = HD // H
         out = torch.empty_like(v)
-        N.profile_note("s2t_attn_apply", 4.0 * (W.numel() + 2 * v.numel()))
+        N.PROF[0] and N.profile_note("s2t_attn_apply", 4.0 * (W.numel() + 2 * v.numel()))
         N.check(N.lib().s2t_attn_apply(N.fp(W), N.fp(v), T, B, H, dv, 0, N.fp(out), N.stream()),
                 "s2t_attn_apply")
         ctx.save_for_backward(W, v, out)
@@ -745,7 +745,7 @@ class _Bypass(torch.autograd.Function):
         scale = scale.contiguous().float()
         C = src.shape[-1]
         out = torch.empty_like(src)
-        N.profile_note("s2t_bypass_fwd", 12.0 * src.numel())
+        N.PROF[0] and N.profile_note("s2t_bypass_fwd", 12.0 * src.numel())
         N.check(N.lib().s2t_bypass_fwd(N.fp(orig), N.fp(src), N.fp(scale), src.numel() // C, C,
                                        N.fp(out), N.stream()), "s2t_bypass_fwd")
         ctx.save_for_backward(orig, src, scale)
@@ -758,7 +758,7 @@ class _Bypass(torch.autograd.Function):
         C = src.shape[-1]
         d_orig, d_src = torch.empty_like(src), torch.empty_like(src)
         d_scale = torch.zeros_like(scale)
-        N.profile_note("s2t_bypass_bwd", 20.0 * src.numel())
+        N.PROF[0] and N.profile_note("s2t_bypass_bwd", 20.0 * src.numel())
         N.check(N.lib().s2t_bypass_bwd(N.fp(orig), N.fp(src), N.fp(scale), N.fp(g),
                                        src.numel() // C, C, N.fp(d_orig), N.fp(d_src),
                                        N.fp(d_scale), N.stream()), "s2t_bypass_bwd")
@@ -789,12 +789,12 @@ class _NonlinCore(torch.autograd.Function):
         L = N.lib()
         st = N.stream()
         xs = torch.empty((B, T, C), dtype=torch.float32, device=u.device)
-        N.profile_note("s2t_nonlin_gate_fwd", 12.0 * T * B * C)
+        N.PROF[0] and N.profile_note("s2t_nonlin_gate_fwd", 12.0 * T * B * C)
         N.check(L.s2t_nonlin_gate_fwd(N.fp(u), T, B, C, N.fp(xs), st), "nonlin_gate_fwd")
         wm = w0.reshape(B, T, T)
         z = torch.bmm(wm, xs)                                         # rocBLAS
         o = torch.empty((T, B, C), dtype=torch.float32, device=u.device)
-        N.profile_note("s2t_nonlin_out_fwd", 12.0 * T * B * C)
+        N.PROF[0] and N.profile_note("s2t_nonlin_out_fwd", 12.0 * T * B * C)
         N.check(L.s2t_nonlin_out_fwd(N.fp(z), N.fp(u), T, B, C, N.fp(o), st), "nonlin_out_fwd")
         ctx.save_for_backward(u, wm, xs, z)
         ctx.bal_cfg, ctx.whiten_mod = bal_cfg, whiten_mod
@@ -814,12 +814,12 @@ class _NonlinCore(torch.autograd.Function):
         g = g.contiguous().float()
         dz = torch.empty_like(z)
         du = torch.empty_like(u)
-        N.profile_note("s2t_nonlin_out_bwd", 20.0 * T * B * C)
+        N.PROF[0] and N.profile_note("s2t_nonlin_out_bwd", 20.0 * T * B * C)
         N.check(L.s2t_nonlin_out_bwd(N.fp(g), N.fp(z), N.fp(u), T, B, C, N.fp(dz), N.fp(du), st),
                 "nonlin_out_bwd")
         dxs = torch.bmm(wm.transpose(1, 2), dz)
         dW0 = torch.bmm(dz, xs.transpose(1, 2)) if ctx.needs_input_grad[1] else None
-        N.profile_note("s2t_nonlin_gate_bwd", 20.0 * T * B * C)
+        N.PROF[0] and N.profile_note("s2t_nonlin_gate_bwd", 20.0 * T * B * C)
         N.check(L.s2t_nonlin_gate_bwd(N.fp(dxs), N.fp(u), T, B, C, N.fp(du), st), "nonlin_gate_bwd")
         if ctx.bal_cfg is not None:
             du[..., :C] = balancer_backward(u[..., :C], du[..., :C].contiguous(), *ctx.bal_cfg[:5],
@@ -848,7 +848,7 @@ class _Downsample(torch.autograd.Function):
         w = w.contiguous().float()
         T, B, C = src.shape
         out = torch.empty(((T + ds - 1) // ds, B, C), dtype=torch.float32, device=src.device)
-        N.profile_note("s2t_downsample_fwd", 4.0 * (src.numel() + out.numel()))
+        N.PROF[0] and N.profile_note("s2t_downsample_fwd", 4.0 * (src.numel() + out.numel()))
         N.check(N.lib().s2t_downsample_fwd(N.fp(src), N.fp(w), ds, T, B, C, N.fp(out), N.stream()),
                 "s2t_downsample_fwd")
         ctx.save_for_backward(src, w)
@@ -862,7 +862,7 @@ class _Downsample(torch.autograd.Function):
         g = g.contiguous().float()
         d_src = torch.empty_like(src)
         dw = torch.zeros_like(w)
-        N.profile_note("s2t_downsample_bwd", 4.0 * (2 * src.numel() + g.numel()))
+        N.PROF[0] and N.profile_note("s2t_downsample_bwd", 4.0 * (2 * src.numel() + g.numel()))
         N.check(N.lib().s2t_downsample_bwd(N.fp(src), N.fp(w), N.fp(g), ctx.ds, T, B, C,
                                            N.fp(d_src), N.fp(dw), N.stream()), "s2t_downsample_bwd")
         return d_src, dw, None
@@ -896,7 +896,7 @@ class _BypassUp(torch.autograd.Function):
         scale = scale.contiguous().float()
         T, B, C = orig.shape
         out = torch.empty_like(orig)
-        N.profile_note("s2t_bypass_up_fwd", 4.0 * (2 * orig.numel() + src.numel()))
+        N.PROF[0] and N.profile_note("s2t_bypass_up_fwd", 4.0 * (2 * orig.numel() + src.numel()))
         N.check(N.lib().s2t_bypass_up_fwd(N.fp(orig), N.fp(src), N.fp(scale), up, T, B, C,
                                           N.fp(out), N.stream()), "s2t_bypass_up_fwd")
         ctx.save_for_backward(orig, src, scale)
@@ -910,7 +910,7 @@ class _BypassUp(torch.autograd.Function):
         g = g.contiguous().float()
         d_orig, d_src = torch.empty_like(orig), torch.empty_like(src)
         d_scale = torch.zeros_like(scale)
-        N.profile_note("s2t_bypass_up_bwd", 4.0 * (3 * orig.numel() + 2 * src.numel()))
+        N.PROF[0] and N.profile_note("s2t_bypass_up_bwd", 4.0 * (3 * orig.numel() + 2 * src.numel()))
         N.check(N.lib().s2t_bypass_up_bwd(N.fp(orig), N.fp(src), N.fp(scale), N.fp(g), ctx.up, T, B,
                                           C, N.fp(d_orig), N.fp(d_src), N.fp(d_scale), N.stream()),
                 "s2t_bypass_up_bwd")
@@ -956,7 +956,7 @@ def linear_wgrad(g2, a2, want_bias):
         db = torch.empty((Nf,), dtype=torch.float32, device=g2.device) if want_bias else None
         ws = torch.empty(N.lib().s2t_linear_wgrad_workspace_floats(R, Nf, Mf), dtype=torch.float32,
                          device=g2.device)
-        N.profile_note("s2t_linear_wgrad", 4.0 * (g2.numel() + a2.numel() + dW.numel()))
+        N.PROF[0] and N.profile_note("s2t_linear_wgrad", 4.0 * (g2.numel() + a2.numel() + dW.numel()))
         N.check(N.lib().s2t_linear_wgrad(N.raw(g2, torch.float32), g2.stride(0),
                                          N.raw(a2, torch.float32), a2.stride(0), R, Nf, Mf,
                                          N.fp(dW), N.fp(db), 0, N.fp(ws), N.stream()),
@@ -1033,7 +1033,7 @@ def gemm_tn(g2, a2, out, colsum=None, pro=0, stream=None):
     """out (N,M) += g2^T act(a2); colsum (N) += column sums of g2.   HIP: gemm.hip mode TN."""
     R, Nf = g2.shape
     Mf = a2.shape[1]
-    N.profile_note("s2t_gemm_f32", 4.0 * (g2.numel() + a2.numel() + out.numel()),
+    N.PROF[0] and N.profile_note("s2t_gemm_f32", 4.0 * (g2.numel() + a2.numel() + out.numel()),
                    2.0 * R * Nf * Mf)
     N.check(N.lib().s2t_gemm_f32(2, N.raw(g2, torch.float32), g2.stride(0),
                                  N.raw(a2, torch.float32), a2.stride(0), N.fp(out), out.stride(0),
@@ -1118,7 +1118,7 @@ def wgrad_group(items):
         q.colsum = None if b is None else b.grad.data_ptr()
         nbytes += 4.0 * (g2.numel() + a2.numel() + Nf * Mf)
         flops += 2.0 * R * Nf * Mf
-    N.profile_note("s2t_gemm_tn_grouped", nbytes, flops)
+    N.PROF[0] and N.profile_note("s2t_gemm_tn_grouped", nbytes, flops)
     st = _side_launch_stream(ok)
     N.check(N.lib().s2t_gemm_tn_grouped(n, ctypes.cast(arr, ctypes.c_void_p),
                                         st if st is not None else N.stream()),
@@ -1148,43 +1148,47 @@ def _rows(t):
     return t2
 
 
-_ACTK = {None: 0, "swoosh_l": 1, "swoosh_r": 2}
+_ACTK = {None: 0, "swoosh_l": 1, "swoosh_r": 2, "add": 3}
 X3P = {"on": os.environ.get("S2T_X3P", "1") == "1", "calls": 0, "tile": 0,
        "tune": os.environ.get("S2T_X3P_TUNE", "1") == "1",
        "margin": float(os.environ.get("S2T_X3P_MARGIN", "0.97"))}
 
 
-def x3p_matmul(mode, x2, w2, bias=None, resid2=None, act_src=None, act_kind=None, act2=None, tile=0):
+def _vp(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def x3p_matmul(mode, x2, w2, bias=None, resid2=None, act_src=None, act_kind=None, act2=None, tile=0,
+               resid_b=None, pp=None):
     """The same products as lt_matmul on our bf16x3 kernel with pre-split weight pieces
     (csrc/gemm_x3p.hip, planes.py): mode 0: x2 (R,K) w2 (N,K)^T (+bias) -> (R,N); mode 1: x2 (R,N)
     w2 (N,K) -> (R,K); then (* act'(act_src)) (+ resid2); with act2 a second output act2(result).
     Returns None when the weight has no pieces (not in a FlatStore / shape outside the kernel's
     rules) -- the caller takes the library path."""
-    pp = planes.pieces(w2, mode)
     if pp is None:
-        return None
+        pp = planes.pieces(w2, mode)
+        if pp is None:
+            return None
     R = x2.shape[0]
     Nf, Kf = w2.shape
     cols, inner = (Nf, Kf) if mode == 0 else (Kf, Nf)
-    if x2.stride(0) % 4 or x2.data_ptr() % 16 or (bias is not None and bias.data_ptr() % 16) \
-            or (resid2 is not None and (resid2.stride(0) % 4 or resid2.data_ptr() % 16)) \
-            or (act_src is not None and (act_src.stride(0) % 4 or act_src.data_ptr() % 16)):
-        return None
+    for t in (x2, bias, resid2, act_src, resid_b):       # (alignment is checked by the entry point: -2)
+        if t is not None and (t.dtype is not torch.float32 or not t.is_cuda):
+            return None
     out = torch.empty((R, cols), dtype=torch.float32, device=x2.device)
     out2 = torch.empty_like(out) if act2 is not None else None
     if R == 0:
         return out if out2 is None else (out, out2)
-    N.profile_note("s2t_gemm_x3p", 4.0 * (R * (Nf + Kf) + (R * cols if resid2 is not None else 0)
-                                          + (R * cols if act_src is not None else 0)
-                                          + (R * cols if out2 is not None else 0)) + 6.0 * Nf * Kf,
-                   2.0 * R * Nf * Kf)
-    rc = N.lib().s2t_gemm_x3p(N.raw(x2, torch.float32), x2.stride(0), ctypes.c_void_p(pp), cols, inner,
-                              N.fp(out), cols, R, N.fp(bias),
-                              None if resid2 is None else N.raw(resid2, torch.float32),
-                              0 if resid2 is None else resid2.stride(0),
-                              None if act_src is None else N.raw(act_src, torch.float32),
-                              0 if act_src is None else act_src.stride(0), _ACTK[act_kind],
-                              N.fp(out2), cols, _ACTK[act2], tile or X3P["tile"], N.stream())
+    if N._Prof.target is not None:
+        extra = sum(t is not None for t in (resid2, act_src, out2, resid_b))
+        N.PROF[0] and N.profile_note("s2t_gemm_x3p", 4.0 * R * (Nf + Kf + extra * cols) + 6.0 * Nf * Kf,
+                       2.0 * R * Nf * Kf)
+    rc = N.lib().s2t_gemm_x3p(_vp(x2), x2.stride(0), ctypes.c_void_p(pp), cols, inner, _vp(out), cols, R,
+                              _vp(bias), _vp(resid2), 0 if resid2 is None else resid2.stride(0),
+                              _vp(act_src), 0 if act_src is None else act_src.stride(0),
+                              _ACTK[act_kind], _vp(out2), cols, _ACTK[act2], _vp(resid_b),
+                              0 if resid_b is None else resid_b.stride(0), tile or X3P["tile"],
+                              N.stream())
     if rc == -2:
         return None
     N.check(rc, "s2t_gemm_x3p")
@@ -1198,8 +1202,9 @@ PLAN_STATS = {"timed": 0}
 
 
 def _half_octave(m):
-    import math
-    return int(math.floor(2.0 * math.log2(max(1, m))))
+    """floor(2 log2 m), in integers."""
+    b = max(1, m).bit_length() - 1
+    return 2 * b + (1 if m * m >= (1 << (2 * b + 1)) else 0)
 
 
 def _time_call(fn, reps=3):
@@ -1213,16 +1218,18 @@ def _time_call(fn, reps=3):
     return e0.elapsed_time(e1) / reps
 
 
-def lt_matmul(mode, x2, w2, bias=None, resid2=None, act_src=None, act_kind=None, act2=None):
+def lt_matmul(mode, x2, w2, bias=None, resid2=None, act_src=None, act_kind=None, act2=None,
+              resid_b=None):
     """Forward / data-gradient product of a Linear with its elementwise neighbours:
       mode 0: x2 (R,K) w2 (N,K)^T (+bias) -> (R,N);  mode 1: x2 (R,N) w2 (N,K) -> (R,K);
-      then (* act'(act_src), act_kind "swoosh_l" | "swoosh_r") (+ resid2); with act2 a second
-      output act2(result) is returned as well.
+      then (* act'(act_src), act_kind "swoosh_l" | "swoosh_r") (+ resid2) (+ resid_b); with act2
+      "swoosh_l" | "swoosh_r" a second output act2(result) is returned as well; act2 "add": the
+      second output is result + resid_b (the result itself then excludes resid_b).
     Served by our bf16x3 kernel with pre-split weight pieces (s2t_gemm_x3p, epilogue-fused) or by
     the plan cache of s2t_linear_lt (+ a separate activation pass) -- whichever was faster when the
     shape bucket {mode, half-octave of R, N, K, epilogue} was first seen (timed once, on the call's
     own operands, on an otherwise idle chip).  Weights outside a FlatStore always take the latter."""
-    fused = act_src is not None or act2 is not None
+    fused = act_src is not None or act2 is not None or resid_b is not None
 
     def lib():
         y = _lt_matmul_lib(mode, x2, w2, bias, None if act_src is not None else resid2)
@@ -1230,14 +1237,19 @@ def lt_matmul(mode, x2, w2, bias=None, resid2=None, act_src=None, act_kind=None,
             y = swoosh_backward(act_src, y, act_kind == "swoosh_l")
             if resid2 is not None:
                 y = y + resid2
+        if act2 == "add":
+            return y, y + resid_b
+        if resid_b is not None:
+            y = y + resid_b
         if act2 is not None:
             return y, swoosh_forward(y, act2 == "swoosh_l")
         return y
 
-    if not X3P["on"] or x2.shape[0] == 0 or planes.pieces(w2, mode) is None:
+    pp = planes.pieces(w2, mode) if (X3P["on"] and x2.shape[0]) else None
+    if pp is None:
         return lib()
     key = (mode, _half_octave(x2.shape[0]), w2.shape[0], w2.shape[1], bias is not None,
-           resid2 is not None, act_src is not None, act2)
+           resid2 is not None, act_src is not None, act2, resid_b is not None)
     plan = _PLANS.get(key)
     if plan is None:
         if not X3P["tune"]:
@@ -1248,10 +1260,10 @@ def lt_matmul(mode, x2, w2, bias=None, resid2=None, act_src=None, act_kind=None,
             if not fused:
                 best *= X3P["margin"]
             for t in _X3P_TILES:
-                if x3p_matmul(mode, x2, w2, bias, resid2, act_src, act_kind, act2, tile=t) is None:
+                if x3p_matmul(mode, x2, w2, bias, resid2, act_src, act_kind, act2, t, resid_b) is None:
                     break
                 ms = _time_call(lambda: x3p_matmul(mode, x2, w2, bias, resid2, act_src, act_kind, act2,
-                                                   tile=t))
+                                                   t, resid_b))
                 if ms < best:
                     best, plan = ms, ("x3p", t)
             PLAN_STATS["timed"] += 1
@@ -1261,7 +1273,7 @@ def lt_matmul(mode, x2, w2, bias=None, resid2=None, act_src=None, act_kind=None,
                       f"{1e3 * best:.1f} us", flush=True)
         _PLANS[key] = plan
     if plan[0] == "x3p":
-        y = x3p_matmul(mode, x2, w2, bias, resid2, act_src, act_kind, act2, tile=plan[1])
+        y = x3p_matmul(mode, x2, w2, bias, resid2, act_src, act_kind, act2, plan[1], resid_b, pp)
         if y is not None:
             return y
     return lib()
@@ -1279,7 +1291,7 @@ def _lt_matmul_lib(mode, x2, w2, bias=None, resid2=None, out_shape=None):
         return out
     w2 = w2 if (w2.stride(1) == 1 and w2.stride(0) >= w2.shape[1]) else w2.contiguous()
     ws = _lt_workspace(x2.device)
-    N.profile_note("s2t_linear_lt", 4.0 * (R * (Nf + Kf) + Nf * Kf + (R * cols if resid2 is not None else 0)),
+    N.PROF[0] and N.profile_note("s2t_linear_lt", 4.0 * (R * (Nf + Kf) + Nf * Kf + (R * cols if resid2 is not None else 0)),
                    2.0 * R * Nf * Kf)
     rc = N.lib().s2t_linear_lt(mode, N.raw(x2, torch.float32), x2.stride(0),
                                N.raw(w2, torch.float32), w2.stride(0), N.fp(bias),
@@ -1462,7 +1474,7 @@ def _conv3x3_wgrad_implicit(x, g, sh, sw, has_bias):
     dw2 = torch.zeros((Cout, 9 * C), dtype=torch.float32, device=x.device)
     db = torch.zeros((Cout,), dtype=torch.float32, device=x.device) if has_bias else None
     R = g.numel() // Cout
-    N.profile_note("s2t_conv3x3_gemm", 4.0 * (x.numel() + g.numel()), 2.0 * R * Cout * 9 * C)
+    N.PROF[0] and N.profile_note("s2t_conv3x3_gemm", 4.0 * (x.numel() + g.numel()), 2.0 * R * Cout * 9 * C)
     N.check(N.lib().s2t_conv3x3_gemm(2, N.fp(x), B, H, W, C, sh, sw, Cout, N.fp(g), None, N.fp(dw2),
                                      N.fp(db), N.stream()), "s2t_conv3x3_gemm(wgrad)")
     return dw2.view(Cout, 3, 3, C).permute(0, 3, 1, 2), db
@@ -1493,7 +1505,7 @@ class _Conv3x3Nhwc(torch.autograd.Function):
         ctx.implicit = _implicit_ok(x, Cout, sh, sw)
         if ctx.implicit:
             y = torch.empty((B * Ho * Wo, Cout), dtype=torch.float32, device=x.device)
-            N.profile_note("s2t_conv3x3_gemm", 4.0 * (x.numel() + y.numel()),
+            N.PROF[0] and N.profile_note("s2t_conv3x3_gemm", 4.0 * (x.numel() + y.numel()),
                            2.0 * y.numel() * 9 * C)
             N.check(N.lib().s2t_conv3x3_gemm(0, N.fp(x), B, H, W, C, sh, sw, Cout, N.fp(w2),
                                              N.fp(bias), N.fp(y), None, N.stream()),
@@ -1536,7 +1548,7 @@ class _Conv3x3Nhwc(torch.autograd.Function):
             w2 = weight.permute(0, 2, 3, 1).reshape(Cout, 9 * C)
             dc = lt_matmul(1, g, w2)                             # (B*Ho*Wo, 3*3*C)
             dx = torch.empty((B, H, W, C), dtype=torch.float32, device=dy.device)
-            N.profile_note("s2t_col2im3x3_nhwc", 4.0 * (dc.numel() + dx.numel()))
+            N.PROF[0] and N.profile_note("s2t_col2im3x3_nhwc", 4.0 * (dc.numel() + dx.numel()))
             N.check(N.lib().s2t_col2im3x3_nhwc(N.fp(dc), B, H, W, C, Ho, Wo, sh, sw, N.fp(dx),
                                                N.stream()), "s2t_col2im3x3_nhwc")
         return dx, dweight, db, None, None
@@ -1555,7 +1567,7 @@ class _Conv3x3C1(torch.autograd.Function):
         CO = weight.shape[0]
         y = torch.empty((B, H - 2, W + 2 * pw - 2, CO), dtype=torch.float32, device=x.device)
         w = weight.contiguous().float()
-        N.profile_note("s2t_conv3x3_c1", 4.0 * (x3.numel() + y.numel()))
+        N.PROF[0] and N.profile_note("s2t_conv3x3_c1", 4.0 * (x3.numel() + y.numel()))
         N.check(N.lib().s2t_conv3x3_c1(0, N.fp(x3), N.fp(w), N.fp(bias), None, B, H, W, pw, CO,
                                        N.fp(y), None, None, None, N.stream()), "s2t_conv3x3_c1")
         ctx.save_for_backward(x3, w)
@@ -1571,13 +1583,13 @@ class _Conv3x3C1(torch.autograd.Function):
         g = g.contiguous().float()
         acc = torch.zeros(CO * 10, dtype=torch.float32, device=g.device)
         L = N.lib()
-        N.profile_note("s2t_conv3x3_c1", 4.0 * (x3.numel() + g.numel()))
+        N.PROF[0] and N.profile_note("s2t_conv3x3_c1", 4.0 * (x3.numel() + g.numel()))
         N.check(L.s2t_conv3x3_c1(1, N.fp(x3), None, None, N.fp(g), B, H, W, pw, CO, None, N.fp(acc),
                                  ctypes_off(acc, CO * 9), None, N.stream()), "s2t_conv3x3_c1(wgrad)")
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x3)
-            N.profile_note("s2t_conv3x3_c1", 4.0 * (g.numel() + dx.numel()))
+            N.PROF[0] and N.profile_note("s2t_conv3x3_c1", 4.0 * (g.numel() + dx.numel()))
             N.check(L.s2t_conv3x3_c1(2, None, N.fp(w), None, N.fp(g), B, H, W, pw, CO, None, None,
                                      None, N.fp(dx), N.stream()), "s2t_conv3x3_c1(dgrad)")
             dx = dx.view(xshape)
@@ -1603,7 +1615,7 @@ class _Conv3x3S2(torch.autograd.Function):
         w = weight.contiguous().float()
         y = torch.empty((B, (H - 3) // 2 + 1, (W - 3) // 2 + 1, CO), dtype=torch.float32,
                         device=x.device)
-        N.profile_note("s2t_conv3x3_s2", 4.0 * (x.numel() + y.numel()), 2.0 * y.numel() * 9 * C)
+        N.PROF[0] and N.profile_note("s2t_conv3x3_s2", 4.0 * (x.numel() + y.numel()), 2.0 * y.numel() * 9 * C)
         N.check(N.lib().s2t_conv3x3_s2(0, N.fp(x), N.fp(w), N.fp(bias), None, B, H, W, C, CO,
                                        N.fp(y), None, N.stream()), "s2t_conv3x3_s2")
         ctx.save_for_backward(x, w)
@@ -1628,7 +1640,7 @@ class _Conv3x3S2(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            N.profile_note("s2t_conv3x3_s2", 4.0 * (g.numel() + dx.numel()), 2.0 * g.numel() * 9 * C)
+            N.PROF[0] and N.profile_note("s2t_conv3x3_s2", 4.0 * (g.numel() + dx.numel()), 2.0 * g.numel() * 9 * C)
             N.check(N.lib().s2t_conv3x3_s2(2, None, N.fp(w), None, N.fp(g), B, H, W, C, CO, None,
                                            N.fp(dx), N.stream()), "s2t_conv3x3_s2(dgrad)")
         return dx, dweight, db
@@ -1668,7 +1680,7 @@ class _DwConv2dNhwc(torch.autograd.Function):
         KH, KW = weight.shape[-2], weight.shape[-1]
         w = weight.reshape(C, KH, KW).contiguous()
         y = torch.empty_like(x)
-        N.profile_note("s2t_dwconv2d_nhwc_fwd", 8.0 * x.numel())
+        N.PROF[0] and N.profile_note("s2t_dwconv2d_nhwc_fwd", 8.0 * x.numel())
         N.check(N.lib().s2t_dwconv2d_nhwc_fwd(N.fp(x), N.fp(w), N.fp(bias), Nn, H, W, C, KH, KW, 0,
                                               N.fp(y), N.stream()), "s2t_dwconv2d_nhwc_fwd")
         ctx.save_for_backward(x, w)
@@ -1686,14 +1698,14 @@ class _DwConv2dNhwc(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            N.profile_note("s2t_dwconv2d_nhwc_fwd", 8.0 * dy.numel())
+            N.PROF[0] and N.profile_note("s2t_dwconv2d_nhwc_fwd", 8.0 * dy.numel())
             N.check(L.s2t_dwconv2d_nhwc_fwd(N.fp(dy), N.fp(w), None, Nn, H, W, C, KH, KW, 1,
                                             N.fp(dx), N.stream()), "s2t_dwconv2d_nhwc_bwd_data")
         ws = torch.empty(L.s2t_dwconv2d_wgrad_workspace_floats(Nn, H, C, KH, KW),
                          dtype=torch.float32, device=x.device)
         dw = torch.empty_like(w)
         db = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_bias else None
-        N.profile_note("s2t_dwconv2d_nhwc_wgrad", 8.0 * x.numel())
+        N.PROF[0] and N.profile_note("s2t_dwconv2d_nhwc_wgrad", 8.0 * x.numel())
         N.check(L.s2t_dwconv2d_nhwc_wgrad(N.fp(x), N.fp(dy), Nn, H, W, C, KH, KW, N.fp(ws),
                                           N.fp(dw), N.fp(db), N.stream()), "s2t_dwconv2d_nhwc_wgrad")
         return dx, dw.view(ctx.wshape), db
@@ -1729,14 +1741,14 @@ class _DwConv2dTap(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            N.profile_note("s2t_dwconv2d_nhwc_fwd_add", 12.0 * dy.numel())
+            N.PROF[0] and N.profile_note("s2t_dwconv2d_nhwc_fwd_add", 12.0 * dy.numel())
             N.check(L.s2t_dwconv2d_nhwc_fwd_add(N.fp(dy), N.fp(w), None, N.fp(gp), Nn, H, W, C, KH, KW,
                                                 1, N.fp(dx), N.stream()), "s2t_dwconv2d_nhwc_bwd_data")
         ws = torch.empty(L.s2t_dwconv2d_wgrad_workspace_floats(Nn, H, C, KH, KW),
                          dtype=torch.float32, device=x.device)
         dw = torch.empty_like(w)
         db = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_bias else None
-        N.profile_note("s2t_dwconv2d_nhwc_wgrad", 8.0 * x.numel())
+        N.PROF[0] and N.profile_note("s2t_dwconv2d_nhwc_wgrad", 8.0 * x.numel())
         N.check(L.s2t_dwconv2d_nhwc_wgrad(N.fp(x), N.fp(dy), Nn, H, W, C, KH, KW, N.fp(ws),
                                           N.fp(dw), N.fp(db), N.stream()), "s2t_dwconv2d_nhwc_wgrad")
         return dx, dw.view(ctx.wshape), db

@@ -202,7 +202,7 @@ def _commit(items):
     for q, (p, d, lo, hi, limit) in zip(arr, items):
         q.x, q.d, q.grad = p.data_ptr(), d.data_ptr(), p.grad.data_ptr()
         q.lo, q.hi, q.limit, q.n = float(lo), float(hi), int(limit), d.numel()
-    N.profile_note("s2t_param_grad_commit_n", 12.0 * sum(it[1].numel() for it in items))
+    N.PROF[0] and N.profile_note("s2t_param_grad_commit_n", 12.0 * sum(it[1].numel() for it in items))
     N.check(N.lib().s2t_param_grad_commit_n(len(items), ctypes.cast(arr, ctypes.c_void_p),
                                             N.stream()), "s2t_param_grad_commit_n")
     for it in items:
@@ -238,10 +238,11 @@ def _ff_fwd(m, dec, x_in):
     if not (fw or fp):
         out = zk.lt_matmul(0, a, m.out_proj.weight, m.out_proj.bias, x_in)
     else:
-        sv.y = zk.lt_matmul(0, a, m.out_proj.weight, m.out_proj.bias)
+        # the module's own output (for the Whiten / Balancer on it) AND the residual stream after
+        # it from one launch
+        sv.y, out = zk.lt_matmul(0, a, m.out_proj.weight, m.out_proj.bias, act2="add", resid_b=x_in)
         if fw:
             sv.st = zk.WhitenStats(sv.y, m.out_whiten.num_groups)
-        out = x_in + sv.y
     return out, sv
 
 
@@ -267,16 +268,15 @@ def _sa_fwd(m, fw, x_in, W, T, B, H):
     sv.v = zk.lt_matmul(0, x_in, m.in_proj.weight, m.in_proj.bias)
     dv = sv.v.shape[1] // H
     sv.o = torch.empty_like(sv.v)
-    N.profile_note("s2t_attn_apply", 4.0 * (W.numel() + 2 * sv.v.numel()))
+    N.PROF[0] and N.profile_note("s2t_attn_apply", 4.0 * (W.numel() + 2 * sv.v.numel()))
     N.check(N.lib().s2t_attn_apply(N.fp(W), N.fp(sv.v), T, B, H, dv, 0, N.fp(sv.o), N.stream()),
             "s2t_attn_apply")
     sv.y = sv.st = None
     if not fw:
         out = zk.lt_matmul(0, sv.o, m.out_proj.weight, m.out_proj.bias, x_in)
     else:
-        sv.y = zk.lt_matmul(0, sv.o, m.out_proj.weight, m.out_proj.bias)
+        sv.y, out = zk.lt_matmul(0, sv.o, m.out_proj.weight, m.out_proj.bias, act2="add", resid_b=x_in)
         sv.st = zk.WhitenStats(sv.y, m.whiten.num_groups)
-        out = x_in + sv.y
     return out, sv
 
 
@@ -286,7 +286,7 @@ def _sa_bwd(m, fw, sv, x_in, g, W, T, B, H, pairs):
     dO = zk.lt_matmul(1, gy, m.out_proj.weight)
     dv = sv.v.shape[1] // H
     dV = torch.empty_like(sv.v)
-    N.profile_note("s2t_attn_apply", 4.0 * (W.numel() + 2 * sv.v.numel()))
+    N.PROF[0] and N.profile_note("s2t_attn_apply", 4.0 * (W.numel() + 2 * sv.v.numel()))
     N.check(N.lib().s2t_attn_apply(N.fp(W), N.fp(dO), T, B, H, dv, 1, N.fp(dV), N.stream()),
             "s2t_attn_apply(T)")
     pairs.append((dO, sv.v, sv.o, dv))
@@ -345,12 +345,12 @@ def _na_fwd(m, dec, x_in, W, T, B):
     sv.u = zk.lt_matmul(0, x_in, m.in_proj.weight, m.in_proj.bias)          # (R, 3C) = [s|x|y]
     C = sv.u.shape[1] // 3
     sv.xs = torch.empty((B, T, C), dtype=_F32, device=dev)
-    N.profile_note("s2t_nonlin_gate_fwd", 12.0 * T * B * C)
+    N.PROF[0] and N.profile_note("s2t_nonlin_gate_fwd", 12.0 * T * B * C)
     N.check(L.s2t_nonlin_gate_fwd(N.fp(sv.u), T, B, C, N.fp(sv.xs), st), "nonlin_gate_fwd")
     sv.wm = W[0]                                                             # (B,T,T)
     sv.z = torch.bmm(sv.wm, sv.xs)                                           # rocBLAS
     sv.o = _e(T * B, C, dev)
-    N.profile_note("s2t_nonlin_out_fwd", 12.0 * T * B * C)
+    N.PROF[0] and N.profile_note("s2t_nonlin_out_fwd", 12.0 * T * B * C)
     N.check(L.s2t_nonlin_out_fwd(N.fp(sv.z), N.fp(sv.u), T, B, C, N.fp(sv.o), st),
             "nonlin_out_fwd")
     sv.st1 = zk.WhitenStats(sv.u[:, C:2 * C], m.whiten1.num_groups) if fw1 else None
@@ -358,10 +358,9 @@ def _na_fwd(m, dec, x_in, W, T, B):
     if not (fw2 or fp):
         out = zk.lt_matmul(0, sv.o, m.out_proj.weight, m.out_proj.bias, x_in)
     else:
-        sv.y = zk.lt_matmul(0, sv.o, m.out_proj.weight, m.out_proj.bias)
+        sv.y, out = zk.lt_matmul(0, sv.o, m.out_proj.weight, m.out_proj.bias, act2="add", resid_b=x_in)
         if fw2:
             sv.st2 = zk.WhitenStats(sv.y, m.whiten2.num_groups)
-        out = x_in + sv.y
     return out, sv
 
 
@@ -379,12 +378,12 @@ def _na_bwd(m, post, dec, sv, x_in, g, T, B):
     C = sv.u.shape[1] // 3
     dz = torch.empty_like(sv.z)
     du = torch.empty_like(sv.u)
-    N.profile_note("s2t_nonlin_out_bwd", 20.0 * T * B * C)
+    N.PROF[0] and N.profile_note("s2t_nonlin_out_bwd", 20.0 * T * B * C)
     N.check(L.s2t_nonlin_out_bwd(N.fp(do), N.fp(sv.z), N.fp(sv.u), T, B, C, N.fp(dz), N.fp(du), st),
             "nonlin_out_bwd")
     dxs = torch.bmm(sv.wm.transpose(1, 2), dz)
     dW0 = torch.bmm(dz, sv.xs.transpose(1, 2))
-    N.profile_note("s2t_nonlin_gate_bwd", 20.0 * T * B * C)
+    N.PROF[0] and N.profile_note("s2t_nonlin_gate_bwd", 20.0 * T * B * C)
     N.check(L.s2t_nonlin_gate_bwd(N.fp(dxs), N.fp(sv.u), T, B, C, N.fp(du), st), "nonlin_gate_bwd")
     if fb:
         _balancer_bwd(m.balancer, sv.u[:, :C], du[:, :C], inplace=True)
@@ -442,7 +441,7 @@ class _LayerFn(torch.autograd.Function):
             s.pos2 = pos_emb.reshape(2 * T - 1, -1).contiguous().float()
             s.posp = zk.lt_matmul(0, s.pos2, sa.linear_pos.weight, None)
         W = torch.empty((H, B, T, T), dtype=_F32, device=dev)
-        N.profile_note("s2t_relpos_attn_fwd", 4.0 * (s.qkp.numel() + W.numel()),
+        N.PROF[0] and N.profile_note("s2t_relpos_attn_fwd", 4.0 * (s.qkp.numel() + W.numel()),
                        2.0 * W.numel() * (qd + (pd if d.use_pos else 0)))
         s.pen_slot = s.pen_event = None
         if d.penalize:
@@ -468,7 +467,7 @@ class _LayerFn(torch.autograd.Function):
         x4, s.cv1 = _conv_fwd(layer.conv_module1, d.cv1, x3, T, B, chunk_size, k8)
         x5, s.ff2 = _ff_fwd(layer.feed_forward2, d.ff2, x4)
         x6 = _e(R, D, dev)
-        N.profile_note("s2t_bypass_fwd", 12.0 * R * D)
+        N.PROF[0] and N.profile_note("s2t_bypass_fwd", 12.0 * R * D)
         N.check(L.s2t_bypass_fwd(N.fp(x0), N.fp(x5), N.fp(layer.bypass_mid.bypass_scale), R, D,
                                  N.fp(x6), st), "s2t_bypass_fwd")
         x7, s.sa2 = _sa_fwd(layer.self_attn2, d.sa2, x6, W, T, B, H)
@@ -477,7 +476,7 @@ class _LayerFn(torch.autograd.Function):
         norm = layer.norm
         x10 = _e(R, D, dev)
         s.nscales = torch.empty(R, dtype=_F32, device=dev)
-        N.profile_note("s2t_biasnorm_fwd", 8.0 * R * D)
+        N.PROF[0] and N.profile_note("s2t_biasnorm_fwd", 8.0 * R * D)
         N.check(L.s2t_biasnorm_fwd(N.fp(x9), N.fp(norm.bias),
                                    ctypes.c_void_p(norm.log_scale.data_ptr()), R, D, N.fp(x10),
                                    N.fp(s.nscales), st), "biasnorm_fwd")
@@ -485,7 +484,7 @@ class _LayerFn(torch.autograd.Function):
         # the stack's feature mask rides in the last bypass unless a gradient-shaping op of this
         # call needs the unmasked output
         s.fm, s.fm_fused = fm, fm is not None and not (d.wh_out or d.bal2)
-        N.profile_note("s2t_bypass_fwd_mask" if s.fm_fused else "s2t_bypass_fwd", 12.0 * R * D)
+        N.PROF[0] and N.profile_note("s2t_bypass_fwd_mask" if s.fm_fused else "s2t_bypass_fwd", 12.0 * R * D)
         if s.fm_fused:
             N.check(L.s2t_bypass_fwd_mask(N.fp(x0), N.fp(x10), N.fp(layer.bypass.bypass_scale),
                                           N.fp(fm), B, R, D, N.fp(x11), st), "s2t_bypass_fwd_mask")
@@ -528,7 +527,7 @@ class _LayerFn(torch.autograd.Function):
         byp = layer.bypass
         d0 = _e(R, D, dev)
         g10 = _e(R, D, dev)
-        N.profile_note("s2t_bypass_bwd_mask" if s.fm_fused else "s2t_bypass_bwd", 20.0 * R * D)
+        N.PROF[0] and N.profile_note("s2t_bypass_bwd_mask" if s.fm_fused else "s2t_bypass_bwd", 20.0 * R * D)
         if s.fm_fused:
             N.check(L.s2t_bypass_bwd_mask(N.fp(x0), N.fp(x10), N.fp(byp.bypass_scale), N.fp(g),
                                           N.fp(s.fm), B, R, D, N.fp(d0), N.fp(g10), off(0), st),
@@ -539,7 +538,7 @@ class _LayerFn(torch.autograd.Function):
 
         norm = layer.norm
         g9 = _e(R, D, dev)
-        N.profile_note("s2t_biasnorm_bwd", 12.0 * R * D)
+        N.PROF[0] and N.profile_note("s2t_biasnorm_bwd", 12.0 * R * D)
         N.check(L.s2t_biasnorm_bwd(N.fp(x9), N.fp(norm.bias), N.fp(s.nscales), N.fp(g10), R, D,
                                    N.fp(g9), off(2 * D), off(3 * D), st), "biasnorm_bwd")
         if d.bal1:
@@ -553,7 +552,7 @@ class _LayerFn(torch.autograd.Function):
         mid = layer.bypass_mid
         d0m = _e(R, D, dev)
         g5 = _e(R, D, dev)
-        N.profile_note("s2t_bypass_bwd_acc", 24.0 * R * D)
+        N.PROF[0] and N.profile_note("s2t_bypass_bwd_acc", 24.0 * R * D)
         N.check(L.s2t_bypass_bwd_acc(N.fp(x0), N.fp(x5), N.fp(mid.bypass_scale), N.fp(g6),
                                      N.fp(d0), R, D, N.fp(d0m), N.fp(g5), off(D), st),
                 "s2t_bypass_bwd_acc")
@@ -573,7 +572,7 @@ class _LayerFn(torch.autograd.Function):
         sa = layer.self_attn_weights
         delta = torch.empty((H, B, T), dtype=_F32, device=dev)
         (dO1, _, O1, dv1), (dO2, _, O2, dv2) = pairs
-        N.profile_note("s2t_attn_delta_pairs", 4.0 * (s.W.numel() // H + dW0.numel() + 2 * (dO1.numel()
+        N.PROF[0] and N.profile_note("s2t_attn_delta_pairs", 4.0 * (s.W.numel() // H + dW0.numel() + 2 * (dO1.numel()
                                                         + dO2.numel()) + delta.numel()))
         N.check(L.s2t_attn_delta_pairs(N.fp(s.W), N.fp(dW0), N.fp(dO1), N.fp(O1), dv1, N.fp(dO2),
                                        N.fp(O2), dv2, T, B, H, N.fp(delta), st),
@@ -601,8 +600,7 @@ class _LayerFn(torch.autograd.Function):
         if dpos is not None:
             _wgrad(sa.linear_pos.weight, None, dpos, s.pos2)
         _wgrad(sa.in_proj.weight, sa.in_proj.bias, dqkp, x0)
-        gx = zk.lt_matmul(1, dqkp, sa.in_proj.weight, None, g0)
-        gx.add_(d0m)
+        gx = zk.lt_matmul(1, dqkp, sa.in_proj.weight, None, g0, resid_b=d0m)
         pend = list(_PEND)
         _PEND.clear()
         zk.wgrad_group(pend)

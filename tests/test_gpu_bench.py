@@ -39,3 +39,13 @@ def test_bench_line_contract_and_roofline_rows(dev, cfg):
                 assert 0 <= row[key] <= 1.0, (row["entry"], key, row[key])
     # the step's own fraction of the f32 MFMA peak
     assert 0 < rf["step_mfma"]["frac"] < 1.0
+    # no blind rows -- every entry that costs >= 0.1 ms per step carries its
+    # algorithmic bytes (and flops where it multiplies), so the table prices all of the step
+    blind = [(r["entry"], round(r["ms_per_step"], 3)) for r in rf["kernels"]
+             if r["ms_per_step"] >= 0.1 and "frac_hbm" not in r and "frac_mfma" not in r]
+    assert not blind, blind
+    # entries on the bf16 matrix cores also report against the six-product ceiling (2.5 PF / 6)
+    for row in rf["kernels"]:
+        if row["entry"] in ("s2t_gemm_x3p", "s2t_gemm_tn_grouped") and "frac_mfma" in row:
+            assert 0 < row["frac_bf16x3_ceiling"] < row["frac_mfma"]
+    assert d["config"]["gemm_paths"]["aten_fallbacks"] == 0

@@ -5,10 +5,14 @@ set -o pipefail
 TAG=${1:-r03}; CFG=${2:-C3}
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
+if [ ! -x tools/probes/fetch_probe ]; then
+  hipcc -O3 --offload-arch=gfx950 tools/probes/fetch_probe.hip -o tools/probes/fetch_probe || { echo "fetch_probe build failed"; exit 1; }
+fi
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/cal_$C
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d gpurun_out/cal_$C -o cal -- tools/probes/fetch_probe > /dev/null 2>&1
-  echo "cal $C rc=$?"
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d gpurun_out/cal_$C -o cal -- tools/probes/fetch_probe > gpurun_out/cal_$C.log 2>&1
+  rc=$?; echo "cal $C rc=$rc"
+  if [ $rc -ne 0 ]; then tail -5 gpurun_out/cal_$C.log; exit 1; fi
 done
 python - <<PY > gpurun_out/${TAG}_fetch_calibration.txt
 import csv, glob, collections
@@ -27,7 +31,7 @@ cat gpurun_out/${TAG}_fetch_calibration.txt
 rm -rf gpurun_out/cal_FETCH_SIZE gpurun_out/cal_WRITE_SIZE
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_${TAG}_$C
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_$C -o pmc -- python bench.py --config $CFG --steps 2 --warmup 2 --no-cpu-baseline --profile-steps 0 > gpurun_out/pmc_${TAG}_$C.json 2> gpurun_out/pmc_${TAG}_$C.err
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_$C -o pmc -- python bench.py --config $CFG --steps 2 --warmup 5 --no-cpu-baseline --profile-steps 0 > gpurun_out/pmc_${TAG}_$C.json 2> gpurun_out/pmc_${TAG}_$C.err
   echo "$C rc=$?"
   find gpurun_out/pmc_${TAG}_$C -name "*kernel_trace.csv" -delete
 done

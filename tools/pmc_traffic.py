@@ -16,6 +16,10 @@ import sys
 
 # kernel-name substring -> (C entry point, is_primary): the primary kernel counts the launches
 KERNELS = [
+    ("x3p_db_kernel", "s2t_gemm_x3p", True), ("x3p_kernel", "s2t_gemm_x3p", True),
+    ("x3p_split_kernel", "s2t_x3p_split", True),
+    ("dwconv2d_roll_kernel<7, 7, 2>", "s2t_dwconv2d_nhwc_wgrad", True),
+    ("dwconv2d_roll_kernel", "s2t_dwconv2d_nhwc_fwd", True),
     ("attn_fwd_mfma_kernel", "s2t_relpos_attn_fwd", True), ("attn_fwd_kernel", "s2t_relpos_attn_fwd", True),
     ("attn_bwd_q", "s2t_relpos_attn_bwd", True), ("attn_bwd_k", "s2t_relpos_attn_bwd", False),
     ("dpos_reduce", "s2t_relpos_attn_bwd", False),
