@@ -629,7 +629,8 @@ int s2t_gemm_x3f_nt(const float* A, long lda, const unsigned short* Bf, float* C
  *   C2 = C + resid_b instead (C itself without resid_b: a module's output and the residual
  *   stream after it from one launch).  K % 8 == 0, N % 4 == 0, rows
  *   16-byte aligned (else -2).  tile = 0 (from the shape) | 11 | 12 | 21 | 22: block tile
- *   (64 tm) x (64 tn); + 100 w: w persistent workgroups per CU (tuning). */
+ *   (64 tm) x (64 tn); + 100 w: w persistent workgroups per CU; + 1000: a tile's output is
+ *   stored in slices under the next tile's multiplications (persistent grids). */
 typedef struct {
   long src_off;
   long dst_off;
@@ -637,6 +638,7 @@ typedef struct {
   unsigned blk_begin;
   int pad_;
 } S2tPlaneDesc;
+int s2t_x3p_debug_stamps(void* buf);   /* diagnostics: per-workgroup phase stamps (tools/x3p_stamps.py) */
 long s2t_x3p_plane_elems(int N, int K);
 long s2t_x3p_split_blocks(int N, int K);
 int s2t_x3p_split(const float* base, const void* tab, int n, int total_blocks, unsigned short* dst,

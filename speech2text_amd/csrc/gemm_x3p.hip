@@ -63,6 +63,10 @@ __device__ __forceinline__ void split8(const f32x4 v0, const f32x4 v1, u32x4& q0
 
 enum { ACT_NONE = 0, ACT_SWOOSH_L = 1, ACT_SWOOSH_R = 2 };
 
+#ifndef X3P_STORE_LATE
+#define X3P_STORE_LATE 0     // 1: LDS stores of the next stage after ALL of a stage's products (A/B: slower)
+#endif
+
 __device__ __forceinline__ float log1p_fast(float e) {   // as zip_elem.hip
   const float u = 1.f + e;
   return u == 1.f ? e : __logf(u) * __fdividef(e, u - 1.f);
@@ -101,7 +105,15 @@ struct X3P {
   int tiles_m, tiles_n;
   int wgs_per_cu;             // persistent form: workgroups per CU (0 = default)
   int prio;                   // 1: wave priority by the workgroup's slot on its CU (see x3p_set_prio)
+  unsigned long long* stamps; // diagnostics (s2t_x3p_debug_stamps): [block][8] s_memtime stamps, or NULL
+  int drip;                   // 1: epilogue of tile t stored in slices under tile t+1 (x3p_db_kernel DRIP)
 };
+
+// diagnostics: lane 0 of wave 0 records the shader clock at a phase boundary of its workgroup
+__device__ __forceinline__ void x3p_stamp(const X3P& g, int slot) {
+  if (g.stamps && threadIdx.x == 0)
+    g.stamps[(long)blockIdx.x * 8 + slot] = __builtin_amdgcn_s_memtime();
+}
 
 // The workgroups of a one-round grid start together and, left alone, run in lockstep: all of a CU's
 // workgroups multiply at the same time (sharing the matrix pipe) and then all store at the same
@@ -116,71 +128,98 @@ __device__ __forceinline__ void x3p_set_prio(int on) {
   else if (tg == 2) __builtin_amdgcn_s_setprio(1);
 }
 
-// ---- epilogue shared by the kernels below: bias, act' of a saved tensor, residual, second output
+// ---- epilogue shared by the kernels below: bias, act' of a saved tensor, residual, second output.
+// One SLICE = rows 16 h .. 16 h + 15 of the wave's 32 x 32 sub-tile (i, j): lane holds column
+// (lane & 31), rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5); the 16 rows go through a per-wave LDS
+// scratch (16 x 36 floats) and leave as 16-byte row pieces.  Wave-local: no workgroup barrier.
+template <bool LEAN>
+__device__ __forceinline__ void x3p_epi_slice(const X3P& g, const f32x16& a, float* scr, int i, int j,
+                                              int h, int m0, int n0, int wrb, int wcb, int lane) {
+  const int hi = lane >> 5, lo = lane & 31;
+  const int er = lane >> 3, ec = (lane & 7) * 4;     // this lane's row (of 8) and column quad
+  const int col = n0 + 32 * (wcb + j) + ec;
+  const bool cok = col < g.N;
+  // !LEAN (the epilogue proper): the optional operands of both rows are requested before the LDS
+  // exchange, whose latency covers part of theirs
+  // (native vectors: a select between two float4 STRUCTS goes through the stack)
+  f32x4 pre[LEAN ? 1 : 2][3];
+  if (!LEAN) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const long rc = (long)min(m0 + 32 * (wrb + i) + 16 * h + er + 8 * q, g.M - 1);
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      f32x4 t0 = z, t1 = z, t2 = z;
+      if (g.act_src && cok) t0 = *reinterpret_cast<const f32x4*>(g.act_src + rc * g.lds + col);
+      if (g.resid && cok) t1 = *reinterpret_cast<const f32x4*>(g.resid + rc * g.ldr + col);
+      if (g.resid_b && cok) t2 = *reinterpret_cast<const f32x4*>(g.resid_b + rc * g.ldrb + col);
+      pre[LEAN ? 0 : q][0] = t0;
+      pre[LEAN ? 0 : q][1] = t1;
+      pre[LEAN ? 0 : q][2] = t2;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * hi) * 36 + lo] = a[8 * h + r];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  // the optional operands are fetched one row at a time, next to their use: a slice runs inside
+  // the next tile's k loop (DRIP), where registers matter more than this latency
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int row = m0 + 32 * (wrb + i) + 16 * h + er + 8 * q;
+    const bool ok = row < g.M && cok;
+    const long rc = (long)min(row, g.M - 1);
+    float4 v = *reinterpret_cast<const float4*>(scr + (er + 8 * q) * 36 + ec);
+    if (g.bias && cok) {
+      const float4 bv = *reinterpret_cast<const float4*>(g.bias + col);
+      v = make_float4(v.x + bv.x, v.y + bv.y, v.z + bv.z, v.w + bv.w);
+    }
+    if (g.act_src && ok) {
+      f32x4 sv = pre[LEAN ? 0 : q][0];
+      if (LEAN) sv = *reinterpret_cast<const f32x4*>(g.act_src + rc * g.lds + col);
+      v.x *= swoosh_deriv(sv.x, g.act_kind);
+      v.y *= swoosh_deriv(sv.y, g.act_kind);
+      v.z *= swoosh_deriv(sv.z, g.act_kind);
+      v.w *= swoosh_deriv(sv.w, g.act_kind);
+    }
+    if (g.resid && ok) {
+      f32x4 rv = pre[LEAN ? 0 : q][1];
+      if (LEAN) rv = *reinterpret_cast<const f32x4*>(g.resid + rc * g.ldr + col);
+      v = make_float4(v.x + rv.x, v.y + rv.y, v.z + rv.z, v.w + rv.w);
+    }
+    f32x4 rbv = {0.f, 0.f, 0.f, 0.f};
+    if (g.resid_b && ok) {
+      rbv = pre[LEAN ? 0 : q][2];
+      if (LEAN) rbv = *reinterpret_cast<const f32x4*>(g.resid_b + rc * g.ldrb + col);
+    }
+    if (g.act2 != 3) v = make_float4(v.x + rbv.x, v.y + rbv.y, v.z + rbv.z, v.w + rbv.w);
+    if (ok) {
+      *reinterpret_cast<float4*>(g.C + (long)row * g.ldc + col) = v;
+      if (g.C2 && g.act2 == 3)
+        *reinterpret_cast<float4*>(g.C2 + (long)row * g.ldc2 + col) =
+            make_float4(v.x + rbv.x, v.y + rbv.y, v.z + rbv.z, v.w + rbv.w);
+      else if (g.C2)
+        *reinterpret_cast<float4*>(g.C2 + (long)row * g.ldc2 + col) =
+            make_float4(swoosh(v.x, g.act2), swoosh(v.y, g.act2), swoosh(v.z, g.act2),
+                        swoosh(v.w, g.act2));
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
 template <int TM, int TN>
 __device__ __forceinline__ void x3p_epilogue(const X3P& g, f32x16 (&acc)[TM][TN], unsigned char* smem,
-                                             int m0, int n0, int wrb, int wcb, int wave, int lane) {
-  // ---- epilogue: lane holds column (lane & 31), rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of each
-  // 32 x 32 tile; 16 rows at a time go through a per-wave LDS scratch and leave as 16-byte rows
-  const int hi = lane >> 5, lo = lane & 31;
-  __syncthreads();                                   // all waves finished reading sA / sB
+                                             int m0, int n0, int wrb, int wcb, int wave, int lane,
+                                             bool sync = true) {
+  if (sync) __syncthreads();                         // all waves finished reading the stage buffers
   float* scr = reinterpret_cast<float*>(smem) + wave * (16 * 36);
-  const int er = lane >> 3, ec = (lane & 7) * 4;     // this lane's row (of 8) and column quad
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = n0 + 32 * (wcb + j) + ec;
-      const bool cok = col < g.N;
-      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (g.bias && cok) bv = *reinterpret_cast<const float4*>(g.bias + col);
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {                  // rows 16 h .. 16 h + 15 of the tile
-        float4 rv[2], sv[2], rbv[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const int row = min(m0 + 32 * (wrb + i) + 16 * h + er + 8 * q, g.M - 1);
-          rv[q] = (g.resid && cok) ? *reinterpret_cast<const float4*>(g.resid + (long)row * g.ldr + col)
-                                   : make_float4(0.f, 0.f, 0.f, 0.f);
-          sv[q] = (g.act_src && cok) ? *reinterpret_cast<const float4*>(g.act_src + (long)row * g.lds + col)
-                                     : make_float4(0.f, 0.f, 0.f, 0.f);
-          rbv[q] = (g.resid_b && cok) ? *reinterpret_cast<const float4*>(g.resid_b + (long)row * g.ldrb + col)
-                                      : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
-          scr[((r & 3) + 8 * (r >> 2) + 4 * hi) * 36 + lo] = acc[i][j][8 * h + r];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const int row = m0 + 32 * (wrb + i) + 16 * h + er + 8 * q;
-          float4 v = *reinterpret_cast<const float4*>(scr + (er + 8 * q) * 36 + ec);
-          v = make_float4(v.x + bv.x, v.y + bv.y, v.z + bv.z, v.w + bv.w);
-          if (g.act_src) {
-            v.x *= swoosh_deriv(sv[q].x, g.act_kind);
-            v.y *= swoosh_deriv(sv[q].y, g.act_kind);
-            v.z *= swoosh_deriv(sv[q].z, g.act_kind);
-            v.w *= swoosh_deriv(sv[q].w, g.act_kind);
-          }
-          v = make_float4(v.x + rv[q].x, v.y + rv[q].y, v.z + rv[q].z, v.w + rv[q].w);
-          if (g.resid_b && g.act2 != 3)
-            v = make_float4(v.x + rbv[q].x, v.y + rbv[q].y, v.z + rbv[q].z, v.w + rbv[q].w);
-          if (row < g.M && cok) {
-            *reinterpret_cast<float4*>(g.C + (long)row * g.ldc + col) = v;
-            if (g.C2 && g.act2 == 3)
-              *reinterpret_cast<float4*>(g.C2 + (long)row * g.ldc2 + col) =
-                  make_float4(v.x + rbv[q].x, v.y + rbv[q].y, v.z + rbv[q].z, v.w + rbv[q].w);
-            else if (g.C2)
-              *reinterpret_cast<float4*>(g.C2 + (long)row * g.ldc2 + col) =
-                  make_float4(swoosh(v.x, g.act2), swoosh(v.y, g.act2), swoosh(v.z, g.act2),
-                              swoosh(v.w, g.act2));
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-      }
-    }
+      for (int h = 0; h < 2; ++h)
+        x3p_epi_slice<false>(g, acc[i][j], scr, i, j, h, m0, n0, wrb, wcb, lane);
 }
 
 template <int TM, int TN>
@@ -301,14 +340,24 @@ __global__ __launch_bounds__(256, 2) void x3p_kernel(X3P g) {
 // belong to the same barrier interval, so the matrix pipe of a SIMD is fed by every resident wave
 // all the time instead of by whichever workgroup happens to be in its "multiply" phase (the
 // two-barrier form above runs the workgroups of a CU in lockstep: all stage, then all multiply).
-template <int TM, int TN>
+// ABL (diagnostics, wrong results): 1 = no global loads inside the k loop, 2 = no LDS stores inside
+// it, 4 = no split arithmetic, 8 = no MFMAs, 16 = no output stores, 32 / 64 = no B / no A loads
+// inside the k loop
+// DRIP: the finished accumulators of tile t are copied aside and stored in SLICES during the first
+// 2 TM TN stages of tile t+1 (one slice = 16 rows of one 32 x 32 sub-tile per wave and stage): the
+// output stores -- a third of a tile's life when every workgroup of the chip stores at once -- drain
+// under the next tile's MFMAs instead of between two main loops.  Needs >= 2 TM TN stages per tile
+// and is worth it with >= 2 tiles per workgroup (persistent grid).
+template <int TM, int TN, bool DIAG = false, int ABL = 0, bool DRIP = false>
 __global__ __launch_bounds__(256, 2) void x3p_db_kernel(X3P g) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   constexpr int A_ST = 2 * TM * 3 * 1024, B_ST = 2 * TN * 3 * 1024, ST = A_ST + B_ST;
   constexpr int NAU = (128 * TM + 255) / 256;       // A units (8 k of one row) per thread and stage
   constexpr int NBU = (384 * TN + 255) / 256;       // B 16-byte pieces per thread and stage
-  constexpr int SCR = 4 * 16 * 36 * 4;              // epilogue scratch
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * ST > SCR ? 2 * ST : SCR];
+  constexpr int SCR = 4 * 16 * 36 * 4;              // epilogue scratch (DRIP: its own region)
+  constexpr int NSL = 2 * TM * TN;                  // epilogue slices per wave and tile
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[DRIP ? 2 * ST + SCR : (2 * ST > SCR ? 2 * ST : SCR)];
+  unsigned char* const epi_smem = DRIP ? smem + 2 * ST : smem;
 
   // PERSISTENT workgroups: the grid is (a multiple of 8, at most) what the chip holds at once; a
   // workgroup walks tiles loc, loc + stride, ... of its XCD's contiguous range (n fastest: the
@@ -367,23 +416,29 @@ __global__ __launch_bounds__(256, 2) void x3p_db_kernel(X3P g) {
   }
 
   const int nst = (g.K + 15) >> 4;                  // stages (the pieces are zero beyond K)
-  // TWO sets of staging registers: stage kb+2 is requested at the TOP of iteration kb into the set
-  // that iteration kb-1 emptied, while iteration kb splits / stores the other set (stage kb+1): a
-  // load has a whole iteration (24 MFMAs, a barrier) before its data is touched.
-  f32x4 ra[2][NAU][2];
-  u32x4 rb[2][NBU];
+  // Staging registers.  Two sets (NS = 2): stage kb+2 is requested at the TOP of iteration kb into
+  // the set iteration kb-1 emptied, a whole iteration before its data is touched (same-box A/B:
+  // 3 % faster than one set).  DRIP keeps the previous tile's sums in registers and has one set:
+  // stage kb+2 is requested right after stage kb+1 left the registers for LDS.
+  constexpr int NS = DRIP ? 1 : 2;
+  f32x4 ra[NS][NAU][2];
+  u32x4 rb[NS][NBU];
   u32x4 qa[NAU][3];
   // global -> registers, unconditional (past the end the last stage again; a k tail is read from
   // the row's start and zeroed when it is split): nothing here waits for the data
 #define X3P_LOAD(SET, S)                                                                     \
   {                                                                                          \
     const int ss_ = min((S), nst - 1);                                                       \
-    _Pragma("unroll") for (int i = 0; i < NAU; ++i) {                                        \
-      const float* p_ = asrc[i] + ((16 * ss_ + a_k[i] < g.K) ? 16 * ss_ : 0);               \
-      ra[SET][i][0] = *reinterpret_cast<const f32x4*>(p_);                                   \
-      ra[SET][i][1] = *reinterpret_cast<const f32x4*>(p_ + 4);                               \
+    if (!(ABL & 64) || (S) < 2) {                                                            \
+      _Pragma("unroll") for (int i = 0; i < NAU; ++i) {                                      \
+        const float* p_ = asrc[i] + ((16 * ss_ + a_k[i] < g.K) ? 16 * ss_ : 0);             \
+        ra[SET][i][0] = *reinterpret_cast<const f32x4*>(p_);                                 \
+        ra[SET][i][1] = *reinterpret_cast<const f32x4*>(p_ + 4);                             \
+      }                                                                                      \
     }                                                                                        \
-    _Pragma("unroll") for (int i = 0; i < NBU; ++i) rb[SET][i] = bsrc[i][(long)ss_ * 192];   \
+    if (!(ABL & 32) || (S) < 2) {                                                            \
+      _Pragma("unroll") for (int i = 0; i < NBU; ++i) rb[SET][i] = bsrc[i][(long)ss_ * 192]; \
+    }                                                                                        \
   }
 #define X3P_SPLIT(SET, S)                                                                    \
   {                                                                                          \
@@ -412,10 +467,24 @@ __global__ __launch_bounds__(256, 2) void x3p_db_kernel(X3P g) {
   _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA], fb[j][PB], acc[i][j], 0, 0, 0);
   // one stage: CUR = the register set that holds stage KB+1, NXT = the set stage KB+2 goes into
+  // DIAG: per-wave sums of the shader-clock intervals of an iteration {waiting at the barrier, load
+  // issue + fragment reads landed, products 1, stores + products 2, products 3}; the six stamps of
+  // an iteration are consumed after the NEXT barrier (SMEM results share lgkmcnt with LDS)
+  unsigned long long dg[5] = {0, 0, 0, 0, 0}, ts[6] = {0, 0, 0, 0, 0, 0};
+  bool have_ts = false;
 #define X3P_ITER(KB, CUR, NXT)                                                               \
   {                                                                                          \
+    unsigned long long t0_ = 0, t1_ = 0, t2_ = 0, t3_ = 0, t4_ = 0, t5_ = 0;                 \
+    if (DIAG) t0_ = __builtin_amdgcn_s_memtime();                                            \
     __syncthreads(); /* stage KB is in LDS for everyone; the other buffer's readers are done */ \
-    X3P_LOAD(NXT, (KB) + 2)                                                                  \
+    if (DIAG) {                                                                              \
+      if (have_ts) {                                                                         \
+        dg[0] += ts[1] - ts[0]; dg[1] += ts[2] - ts[1]; dg[2] += ts[3] - ts[2];             \
+        dg[3] += ts[4] - ts[3]; dg[4] += ts[5] - ts[4];                                      \
+      }                                                                                      \
+      t1_ = __builtin_amdgcn_s_memtime();                                                    \
+    }                                                                                        \
+    if (NS == 2 && !(ABL & 1)) X3P_LOAD(NXT, (KB) + 2)                                       \
     const unsigned char* const sa = smem + ((KB) & 1) * ST;                                  \
     const unsigned char* const sb = sa + A_ST;                                               \
     bf16x8 fa[TM][3], fb[TN][3];                                                             \
@@ -423,21 +492,56 @@ __global__ __launch_bounds__(256, 2) void x3p_db_kernel(X3P g) {
       fa[i][p] = *reinterpret_cast<const bf16x8*>(sa + (((wrb + i) * 3 + p) * 64 + lane) * 16); \
     _Pragma("unroll") for (int j = 0; j < TN; ++j) _Pragma("unroll") for (int p = 0; p < 3; ++p) \
       fb[j][p] = *reinterpret_cast<const bf16x8*>(sb + (((wcb + j) * 3 + p) * 64 + lane) * 16); \
+    if (DIAG) {                                                                              \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     \
+      t2_ = __builtin_amdgcn_s_memtime();                                                    \
+    }                                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                       \
     /* (1) the two smallest product groups with the split of stage KB+1's A registers in the  \
        MFMAs' shadow (an MFMA holds the SIMD's issue for 8 of its 32 cycles) */              \
-    X3P_SPLIT(CUR, (KB) + 1)                                                                 \
-    X3P_TERM(2, 0) X3P_TERM(1, 1)                                                            \
+    if (!(ABL & 4)) X3P_SPLIT(CUR, (KB) + 1)                                                 \
+    if (!(ABL & 8)) { X3P_TERM(2, 0) X3P_TERM(1, 1) }                                        \
+    if (DIAG) t3_ = __builtin_amdgcn_s_memtime();                                            \
     __builtin_amdgcn_sched_barrier(0);                                                       \
-    /* (2) stage KB+1 into the other LDS buffer */                                           \
-    X3P_STORE(CUR, ((KB) + 1) & 1)                                                           \
-    X3P_TERM(0, 2)                                                                           \
-    __builtin_amdgcn_sched_barrier(0);                                                       \
-    /* (3) the rest of the products */                                                       \
-    X3P_TERM(1, 0) X3P_TERM(0, 1) X3P_TERM(0, 0)                                             \
+    if (X3P_STORE_LATE) {                                                                    \
+      /* all 24 products queued before this wave waits for stage KB+1's global loads */      \
+      if (!(ABL & 8)) { X3P_TERM(0, 2) X3P_TERM(1, 0) X3P_TERM(0, 1) X3P_TERM(0, 0) }        \
+      if (DIAG) t4_ = __builtin_amdgcn_s_memtime();                                          \
+      __builtin_amdgcn_sched_barrier(0);                                                     \
+      if (!(ABL & 2)) X3P_STORE(CUR, ((KB) + 1) & 1)                                         \
+      if (NS == 1 && !(ABL & 1)) X3P_LOAD(NXT, (KB) + 2)                                     \
+    } else {                                                                                 \
+      /* (2) stage KB+1 into the other LDS buffer, stage KB+2 requested */                   \
+      if (!(ABL & 2)) X3P_STORE(CUR, ((KB) + 1) & 1)                                         \
+      if (NS == 1 && !(ABL & 1)) X3P_LOAD(NXT, (KB) + 2)                                     \
+      if (!(ABL & 8)) { X3P_TERM(0, 2) }                                                     \
+      if (DIAG) t4_ = __builtin_amdgcn_s_memtime();                                          \
+      __builtin_amdgcn_sched_barrier(0);                                                     \
+      /* (3) the rest of the products */                                                     \
+      if (!(ABL & 8)) { X3P_TERM(1, 0) X3P_TERM(0, 1) X3P_TERM(0, 0) }                       \
+    }                                                                                        \
+    if (DIAG) {                                                                              \
+      t5_ = __builtin_amdgcn_s_memtime();                                                    \
+      ts[0] = t0_; ts[1] = t1_; ts[2] = t2_; ts[3] = t3_; ts[4] = t4_; ts[5] = t5_;         \
+      have_ts = true;                                                                        \
+    }                                                                                        \
+  }
+  x3p_stamp(g, 0);
+  if (g.stamps && threadIdx.x == 0) {
+    g.stamps[(long)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_getreg(((16 - 1) << 11) | (4 << 6) | 4);   // HW_ID[19:4]
+    g.stamps[(long)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);   // XCC_ID
   }
   X3P_TILE(loc)
   X3P_LOAD(0, 0)
+  int tile_no = 0;
+  f32x16 pacc[DRIP ? TM : 1][DRIP ? TN : 1];        // DRIP: the previous tile's sums, being stored
+  int pm0 = 0, pn0 = 0;
+  bool pend = false;
+  float* const scr_w = reinterpret_cast<float*>(epi_smem) + wave * (16 * 36);
+#define X3P_SLICE(SL)                                                                        \
+  if (DRIP && pend)                                                                          \
+    x3p_epi_slice<true>(g, pacc[DRIP ? (SL) / (2 * TN) : 0][DRIP ? ((SL) / 2) % TN : 0], scr_w, \
+                  (SL) / (2 * TN), ((SL) / 2) % TN, (SL) & 1, pm0, pn0, wrb, wcb, lane);
   for (;;) {
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -449,10 +553,24 @@ __global__ __launch_bounds__(256, 2) void x3p_db_kernel(X3P g) {
     X3P_SPLIT(0, 0)
     X3P_STORE(0, 0)
     X3P_LOAD(0, 1)
-    for (int kb = 0; kb < nst; kb += 2) {
-      X3P_ITER(kb, 0, 1)
-      if (kb + 1 < nst) X3P_ITER(kb + 1, 1, 0)
+    if (tile_no == 0) x3p_stamp(g, 1);
+    int kb = 0;
+    if (DRIP) {                              // the first NSL stages carry the previous tile's slices
+#pragma unroll
+      for (int sl = 0; sl < NSL; sl += 2) {
+        X3P_ITER(kb, 0, NS - 1)
+        X3P_SLICE(sl)
+        X3P_ITER(kb + 1, NS - 1, 0)
+        X3P_SLICE(sl + 1)
+        kb += 2;
+      }
+      pend = false;
     }
+    for (; kb < nst; kb += 2) {
+      X3P_ITER(kb, 0, NS - 1)
+      if (kb + 1 < nst) X3P_ITER(kb + 1, NS - 1, 0)
+    }
+    if (tile_no == 0) x3p_stamp(g, 2);
     // next tile: its stage 0 is requested before this tile's stores go out
     const int em0 = m0, en0 = n0;
     loc += stride;
@@ -461,9 +579,38 @@ __global__ __launch_bounds__(256, 2) void x3p_db_kernel(X3P g) {
       X3P_TILE(loc)
       X3P_LOAD(0, 0)
     }
-    x3p_epilogue<TM, TN>(g, acc, smem, em0, en0, wrb, wcb, wave, lane);
+    if (DRIP && more) {                      // stored while the next tile is multiplied
+#pragma unroll
+      for (int i = 0; i < (DRIP ? TM : 0); ++i)
+#pragma unroll
+        for (int j = 0; j < (DRIP ? TN : 0); ++j) pacc[i][j] = acc[i][j];
+      pm0 = em0;
+      pn0 = en0;
+      pend = true;
+    } else if (!(ABL & 16)) x3p_epilogue<TM, TN>(g, acc, epi_smem, em0, en0, wrb, wcb, wave, lane, !DRIP);
+    else {                                   // keep every product alive
+      float chk = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) chk += acc[i][j][r];
+      if (chk == 12345.678f) g.C[0] = chk;
+    }
+    if (tile_no == 0) x3p_stamp(g, 3);
+    ++tile_no;
     if (!more) break;
-    __syncthreads();     // the epilogue's LDS scratch is the next tile's stage buffer
+    __syncthreads();     // stage buffers (and, without DRIP, the epilogue scratch in them) are free
+  }
+#undef X3P_SLICE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  x3p_stamp(g, 4);
+  if (DIAG && g.stamps && lane == 0) {
+    unsigned long long* d = g.stamps + ((long)gridDim.x + (long)blockIdx.x * 4 + wave) * 8;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) d[k] = dg[k];
+    d[5] = (unsigned long long)tile_no * nst;      // iterations measured (+1: the last is not folded)
   }
 #undef X3P_ITER
 #undef X3P_TERM
@@ -526,7 +673,26 @@ void launch_x3p(X3P& g, hipStream_t st) {
     const int per_cu = wgs > 0 ? wgs : g.wgs_per_cu > 0 ? g.wgs_per_cu : (TM * TN >= 4 ? 2 : TM * TN >= 2 ? 3 : 4);
     const int cap = 256 * per_cu;
     const int grid = std::min(((total + 7) / 8) * 8, cap);
-    hipLaunchKernelGGL((x3p_db_kernel<TM, TN>), dim3(grid), dim3(256), 0, st, g);
+    static int abl = -1;       // S2T_X3P_ABL: ablation bit mask (diagnostics)
+    if (abl < 0) { const char* e = getenv("S2T_X3P_ABL"); abl = e ? atoi(e) : 0; }
+    static int diag = -1;      // S2T_X3P_DIAG=1: the instrumented build (tools/x3p_stamps.py)
+    if (diag < 0) { const char* e = getenv("S2T_X3P_DIAG"); diag = e ? atoi(e) : 0; }
+    const bool drip = g.drip == 1 && ((g.K + 15) >> 4) >= 2 * TM * TN && grid < total;
+    if (diag && g.stamps)
+      hipLaunchKernelGGL((x3p_db_kernel<TM, TN, true>), dim3(grid), dim3(256), 0, st, g);
+    else if (drip)
+      hipLaunchKernelGGL((x3p_db_kernel<TM, TN, false, 0, true>), dim3(grid), dim3(256), 0, st, g);
+    else if (abl && TM * TN >= 2 && TM <= TN) {
+#define X3P_ABL_CASE(A) case A: hipLaunchKernelGGL((x3p_db_kernel<TM, TN, false, A>), dim3(grid), dim3(256), 0, st, g); break;
+      switch (abl) {
+        X3P_ABL_CASE(1) X3P_ABL_CASE(2) X3P_ABL_CASE(3) X3P_ABL_CASE(4) X3P_ABL_CASE(7) X3P_ABL_CASE(8)
+        X3P_ABL_CASE(16) X3P_ABL_CASE(17) X3P_ABL_CASE(24) X3P_ABL_CASE(23) X3P_ABL_CASE(15)
+        X3P_ABL_CASE(32) X3P_ABL_CASE(64) X3P_ABL_CASE(48) X3P_ABL_CASE(80)
+        default: hipLaunchKernelGGL((x3p_db_kernel<TM, TN>), dim3(grid), dim3(256), 0, st, g);
+      }
+#undef X3P_ABL_CASE
+    } else
+      hipLaunchKernelGGL((x3p_db_kernel<TM, TN>), dim3(grid), dim3(256), 0, st, g);
   } else
     hipLaunchKernelGGL((x3p_kernel<TM, TN>), dim3(((total + 7) / 8) * 8), dim3(256), 0, st, g);
 }
@@ -547,7 +713,17 @@ int pick_tile(int M, int N) {
 
 }  // namespace
 
+static unsigned long long* g_stamps = nullptr;
+
 extern "C" {
+
+// diagnostics: buf (DEVICE, >= 8 * grid u64) or NULL -- later s2t_gemm_x3p launches record
+// per-workgroup s_memtime stamps {start, first stage staged, main loop done, epilogue issued,
+// stores drained, -, HW_ID[19:4], XCC_ID} (tools/x3p_stamps.py)
+int s2t_x3p_debug_stamps(void* buf) {
+  g_stamps = reinterpret_cast<unsigned long long*>(buf);
+  return 0;
+}
 
 long s2t_x3p_plane_elems(int N, int K) {
   if (N <= 0 || K <= 0) return 0;
@@ -577,9 +753,14 @@ int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int 
   if (act_kind < 0 || act_kind > 2 || act2 < 0 || act2 > 3 || (act_src && act_kind == 0) ||
       (C2 && act2 == 0) || (act2 == 3 && (!C2 || !resid_b)))
     return -1;
-  const int wgs = tile / 100;          // hundreds digit: persistent workgroups per CU (0 = default)
+  // tile = 1000 drip + 100 wgs + (10 tm + tn): drip = epilogue slices under the next tile, wgs =
+  // persistent workgroups per CU (0 = default)
+  const int drip = tile / 1000;
+  const int wgs = (tile / 100) % 10;
   tile %= 100;
-  if ((tile != 0 && tile != 11 && tile != 12 && tile != 21 && tile != 22) || wgs < 0 || wgs > 8) return -1;
+  if ((tile != 0 && tile != 11 && tile != 12 && tile != 21 && tile != 22) || wgs < 0 || wgs > 8 ||
+      drip < 0 || drip > 1)
+    return -1;
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   if ((K & 7) || (N & 3) || (lda & 3) || (ldc & 3) || !al16(A) || !al16(Bp) || !al16(C) ||
       (bias && !al16(bias)) || (resid && (!al16(resid) || (ldr & 3))) ||
@@ -587,7 +768,7 @@ int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int 
       (resid_b && (!al16(resid_b) || (ldrb & 3))))
     return -2;
   X3P g{A, lda, Bp, (N + 31) / 32, 2 * ((K + 31) / 32), C, ldc, M, N, K, bias, resid, ldr, act_src,
-        ld_act, act_kind, C2, ldc2, act2, resid_b, ldrb, 0, 0, wgs, 0};
+        ld_act, act_kind, C2, ldc2, act2, resid_b, ldrb, 0, 0, wgs, 0, g_stamps, drip};
   {
     static int prio = -1;      // S2T_X3P_PRIO=0: no slot priority
     if (prio < 0) { const char* e = getenv("S2T_X3P_PRIO"); prio = e ? atoi(e) : 1; }

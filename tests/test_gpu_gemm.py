@@ -352,7 +352,9 @@ def test_x3p_gemm_has_fp32_accuracy(dev, M, K, N):
     for mode, a, bias, res, ref, lib in ((0, x, b, r0, ref0, lib0), (1, gy, None, r1, ref1, lib1)):
         scale = ref.abs().max().item()
         e_lib = (lib - ref).abs().max().item() / scale
-        for tile in (0, 22, 21, 12, 11):
+        # (1000 + 100 w + tile: w persistent workgroups per CU, the output of a tile stored in
+        # slices under the next tile's multiplications -- active where a workgroup gets > 1 tile)
+        for tile in (0, 22, 21, 12, 11, 1111, 1112, 1121, 1122, 1211):
             y = zk.x3p_matmul(mode, a, W, bias, res, tile=tile)
             if (N if mode == 1 else K) % 8:
                 assert y is None                    # contraction not a multiple of 8: library path
@@ -369,6 +371,19 @@ def test_x3p_fused_epilogues(dev):
     M, K, N = 3001, 256, 768
     g, W, b, store = _x3p_case(dev, M, K, N)
     x = torch.randn(M, K, generator=g).to(dev)
+    # every epilogue feature through the sliced (drip) epilogue too: M large enough for > 1 tile
+    # per workgroup at one workgroup per CU
+    Mb = 40000
+    xb = torch.randn(Mb, K, generator=g).to(dev)
+    rb = torch.randn(Mb, N, generator=g).to(dev)
+    for tile in (1112, 1121, 1122, 1111):
+        y, y2 = zk.x3p_matmul(0, xb, W, b, None, act2="add", resid_b=rb, tile=tile)
+        yref = torch.nn.functional.linear(xb.double(), W.detach().double(), b.detach().double())
+        _close(y, yref)
+        _close(y2, yref + rb.double())
+        hb, ab = zk.x3p_matmul(0, xb, W, b, None, act2="swoosh_l", tile=tile)
+        _close(hb, yref)
+        _close(ab, _swoosh(yref, 1), tol=3e-5)
     for kind, name in ((1, "swoosh_l"), (2, "swoosh_r")):
         h, a = zk.x3p_matmul(0, x, W, b, None, act2=name)
         href = torch.nn.functional.linear(x.double(), W.detach().double(), b.detach().double())

@@ -24,7 +24,7 @@ FWD = [(31680, 272, 192), (31680, 432, 192), (31680, 192, 144), (31680, 48, 192)
        (3968, 256, 960), (3968, 512, 256), (3968, 256, 256)]
 
 
-CFGS = [0, 122, 222, 121, 221, 321, 112, 212, 312, 111, 211, 311, 411]
+CFGS = [0, 222, 321, 312, 411, 1222, 1221, 1212, 1211, 1312, 1321, 1311, 1411]
 
 
 def main():

@@ -1,0 +1,69 @@
+"""GPU: per-workgroup phase stamps of one s2t_gemm_x3p launch (s_memtime: shader cycles).
+usage: python tools/x3p_stamps.py M N K tile [mode]"""
+import ctypes
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from speech2text_amd import _native as N
+from speech2text_amd import flat
+from speech2text_amd import zip_kernels as zk
+from tools.bench_gemm import timeit
+
+M, Nn, K, tile = (int(a) for a in sys.argv[1:5])
+dev = torch.device("cuda")
+torch.manual_seed(0)
+W = torch.nn.Parameter(torch.randn(Nn, K, device=dev) * 0.1)
+store = flat.FlatStore([W])
+x = torch.randn(M, K, device=dev)
+res = torch.randn(M, Nn, device=dev)
+L = N.lib()
+t_us = timeit(lambda: zk.x3p_matmul(0, x, W, None, res, tile=tile), it=20)
+buf = torch.zeros(8 * 4096 * 5, dtype=torch.int64, device=dev)
+L.s2t_x3p_debug_stamps(ctypes.c_void_p(buf.data_ptr()))
+for _ in range(3):
+    buf.zero_()
+    zk.x3p_matmul(0, x, W, None, res, tile=tile)
+torch.cuda.synchronize()
+L.s2t_x3p_debug_stamps(None)
+allb = buf.cpu().numpy().reshape(-1, 8)
+s = allb[allb[:, 0] != 0]
+grid = len(s) if (allb[len(s):] == 0).all() else None
+if os.environ.get("S2T_X3P_DIAG") == "1":
+    # the instrumented kernel: per-wave interval sums after the per-block records
+    nb = int((allb[:, 6] != 0).sum())          # HW_ID slot is non-zero for block records
+    blocks = allb[:nb]
+    waves = allb[nb:nb + 4 * nb]
+    it = np.maximum(waves[:, 5] - 1, 1).astype(np.float64)
+    names = ["barrier wait", "loads issued + fragments landed", "products 1 (+ split VALU)",
+             "LDS stores + products 2", "products 3"]
+    print(f"per-iteration intervals (cycles, mean over {len(waves)} waves; {int(np.median(it)) + 1} iterations per wave)")
+    tot = 0.0
+    for k, nme in enumerate(names):
+        v = waves[:, k] / it
+        tot += v.mean()
+        print(f"  {nme:34s} mean {v.mean():8.0f}  p10 {np.percentile(v, 10):8.0f}  p90 {np.percentile(v, 90):8.0f}")
+    tm_, tn_ = (tile % 100) // 10, tile % 10
+    print(f"  sum {tot:.0f} cycles per iteration; MFMA issue floor of a wave alone {6 * tm_ * tn_ * 32}")
+    s = blocks
+t0 = s[:, 0].min()
+ph = {"stage0": s[:, 1] - s[:, 0], "main(tile 1)": s[:, 2] - s[:, 1],
+      "epilogue issue": s[:, 3] - s[:, 2], "end-last epilogue": s[:, 4] - s[:, 3], "total": s[:, 4] - s[:, 0]}
+print(f"M {M} N {Nn} K {K} tile {tile}: {t_us:.1f} us per launch, {len(s)} workgroups, "
+      f"span {int(s[:, 4].max() - t0)} cycles")
+for k, v in ph.items():
+    print(f"  {k:18s} p10 {np.percentile(v, 10):9.0f}  median {np.median(v):9.0f}  p90 {np.percentile(v, 90):9.0f}  max {v.max():9.0f}")
+nst = (K + 15) // 16
+tm, tn = (tile % 100) // 10, tile % 10
+print(f"  MFMA floor of one tile's main loop alone: {nst * 6 * tm * tn * 32} cycles ({nst} stages x {6 * tm * tn} MFMA x 32)")
+# per-CU residency: (xcc, hw_id >> 4 & 0xfff: cu/sh/se)
+cu = (s[:, 7] << 16) | ((s[:, 6] >> 4) & 0xFF)      # XCC | SE, SH, CU (HW_ID bits 15:8)
+u, cnt = np.unique(cu, return_counts=True)
+print(f"  CUs used {len(u)}, workgroups per CU: min {cnt.min()} median {int(np.median(cnt))} max {cnt.max()}")
+k = u[np.argmax(cnt)]
+rows = s[cu == k]
+rows = rows[np.argsort(rows[:, 0])]
+print("  one CU's workgroups (cycles from launch start): start / staged / main done / epilogue issued / drained, TG_ID")
+for r in rows[:8]:
+    print("   ", " ".join(f"{int(v - t0):8d}" for v in r[:5]), f" tg {int(r[6] >> 12) & 15}")
