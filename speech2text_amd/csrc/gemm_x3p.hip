@@ -107,6 +107,7 @@ struct X3P {
   int prio;                   // 1: wave priority by the workgroup's slot on its CU (see x3p_set_prio)
   unsigned long long* stamps; // diagnostics (s2t_x3p_debug_stamps): [block][8] s_memtime stamps, or NULL
   int drip;                   // 1: epilogue of tile t stored in slices under tile t+1 (x3p_db_kernel DRIP)
+  int stagger;                // > 0: workgroup slot s of a CU starts its k loop s * stagger * 64 cycles late
 };
 
 // diagnostics: lane 0 of wave 0 records the shader clock at a phase boundary of its workgroup
@@ -553,6 +554,13 @@ __global__ __launch_bounds__(256, 2) void x3p_db_kernel(X3P g) {
     X3P_SPLIT(0, 0)
     X3P_STORE(0, 0)
     X3P_LOAD(0, 1)
+    if (tile_no == 0 && g.stagger > 0) {
+      // The workgroups of a CU share its matrix pipes and, started together, run in LOCKSTEP: all
+      // multiply (sharing the pipe), then all wait for loads / LDS / the barrier (pipe idle).  A
+      // one-off delay by the workgroup's slot on its CU (HW_ID.TG_ID) puts them out of phase.
+      const int tg = (int)(__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (16 << 6) | 4) & 15u);
+      for (int i = 0; i < tg * g.stagger; ++i) __builtin_amdgcn_s_sleep(1);
+    }
     if (tile_no == 0) x3p_stamp(g, 1);
     int kb = 0;
     if (DRIP) {                              // the first NSL stages carry the previous tile's slices
@@ -768,7 +776,12 @@ int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int 
       (resid_b && (!al16(resid_b) || (ldrb & 3))))
     return -2;
   X3P g{A, lda, Bp, (N + 31) / 32, 2 * ((K + 31) / 32), C, ldc, M, N, K, bias, resid, ldr, act_src,
-        ld_act, act_kind, C2, ldc2, act2, resid_b, ldrb, 0, 0, wgs, 0, g_stamps, drip};
+        ld_act, act_kind, C2, ldc2, act2, resid_b, ldrb, 0, 0, wgs, 0, g_stamps, drip, 0};
+  {
+    static int stg = -1;       // S2T_X3P_STAGGER: start delay per workgroup slot, units of 64 cycles
+    if (stg < 0) { const char* e = getenv("S2T_X3P_STAGGER"); stg = e ? atoi(e) : 0; }
+    g.stagger = stg;
+  }
   {
     static int prio = -1;      // S2T_X3P_PRIO=0: no slot priority
     if (prio < 0) { const char* e = getenv("S2T_X3P_PRIO"); prio = e ? atoi(e) : 1; }

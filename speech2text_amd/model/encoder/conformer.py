@@ -15,6 +15,8 @@ and models whose parameters are not in a FlatStore, with the same kernels one op
 import dataclasses
 from typing import Tuple
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -78,12 +80,14 @@ class Subsampling(nn.Module):
             x = x.unsqueeze(1).contiguous(memory_format=torch.channels_last)
         for m in convs:
             if isinstance(m, nn.Conv2d):
-                if (x.is_cuda and tuple(m.kernel_size) == (3, 3) and tuple(m.padding) == (0, 0)
-                        and tuple(m.dilation) == (1, 1) and m.groups == 1
-                        and x.shape[1] % 4 == 0 and m.out_channels % 4 == 0):
-                    # implicit-im2col MFMA GEMM on the channel-last map (s2t_conv3x3_gemm, the
-                    # kernel of the zipformer frontend): the patch rows are read in place, the
-                    # weight gradient is the split-contraction TN kernel over the same patches
+                if (_OWN_CONV2 and x.is_cuda and tuple(m.kernel_size) == (3, 3)
+                        and tuple(m.padding) == (0, 0) and tuple(m.dilation) == (1, 1)
+                        and m.groups == 1 and x.shape[1] % 4 == 0 and m.out_channels % 4 == 0):
+                    # S2T_CONF_CONV2=own: implicit-im2col MFMA GEMM on the channel-last map
+                    # (s2t_conv3x3_gemm, the kernel of the zipformer frontend) for the forward and
+                    # the weight gradient.  Measured (round 4, C2): 25.3 ms/step against 24.4 with
+                    # the library's NHWC implicit-GEMM kernels (127 TFLOP/s on this 178 GFLOP
+                    # product), so the library stays the default
                     y = zk.conv3x3_nhwc(x.permute(0, 2, 3, 1), m.weight, m.bias, m.stride)
                     x = y.permute(0, 3, 1, 2)
                 else:
@@ -99,6 +103,9 @@ class Subsampling(nn.Module):
         mask = torch.arange(t, device=length.device).unsqueeze(0) >= length.unsqueeze(1)
         out = out.masked_fill(mask.unsqueeze(-1), 0.0)
         return out, length
+
+
+_OWN_CONV2 = os.environ.get("S2T_CONF_CONV2", "lib") == "own"
 
 
 class _FeedForwardModule(nn.Module):
