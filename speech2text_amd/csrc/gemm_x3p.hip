@@ -92,16 +92,16 @@ struct X3P {
   long ldc;
   int M, N, K;
   const float* bias;          // [N] or NULL
-  const float* resid;         // [M][N] added last, or NULL
-  long ldr;
-  const float* act_src;       // C *= act'(act_src[m][n]) (before the residual), or NULL
-  long lds;
+  // up to TWO [M][N] operands of the epilogue, in the order they are applied (filled by the entry
+  // point from act_src / resid / resid_b); role 1: C *= act'(op) (act_kind), 2: C += op, 3: the
+  // second addend -- C += op, or with act2 3 into C2 only
+  const float* op[2];
+  long ldop[2];
+  int role[2];
   int act_kind;
-  float* C2;                  // C2 = act2(C) (act2 1 | 2), or C + resid_b (act2 3), or NULL
+  float* C2;                  // C2 = act2(C) (act2 1 | 2), or C + (role-3 operand) (act2 3), or NULL
   long ldc2;
   int act2;
-  const float* resid_b;       // second [M][N] addend: into C (no C2), or into C2 only (act2 3)
-  long ldrb;
   int tiles_m, tiles_n;
   int wgs_per_cu;             // persistent form: workgroups per CU (0 = default)
   int prio;                   // 1: wave priority by the workgroup's slot on its CU (see x3p_set_prio)
@@ -133,79 +133,127 @@ __device__ __forceinline__ void x3p_set_prio(int on) {
 // One SLICE = rows 16 h .. 16 h + 15 of the wave's 32 x 32 sub-tile (i, j): lane holds column
 // (lane & 31), rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5); the 16 rows go through a per-wave LDS
 // scratch (16 x 36 floats) and leave as 16-byte row pieces.  Wave-local: no workgroup barrier.
-template <bool LEAN>
-__device__ __forceinline__ void x3p_epi_slice(const X3P& g, const f32x16& a, float* scr, int i, int j,
-                                              int h, int m0, int n0, int wrb, int wcb, int lane) {
-  const int hi = lane >> 5, lo = lane & 31;
+//
+// ORDER OF THE MEMORY OPERATIONS.  vmcnt counts loads and stores in issue order, so a wait for a
+// load that was issued AFTER a store also waits for that store's acknowledgement -- a bias or
+// residual load placed next to its use makes every slice wait out the previous slice's stores
+// (one write round trip per slice: the epilogue then takes 4 TM TN of them).  Hence, per row block
+// i of the wave's sub-tiles (2 TN slices), TWO PHASES: (1) ALL operand loads of the row block are
+// issued together; every slice is brought into its final form -- LDS exchange, bias / act' /
+// residuals -- and written BACK into the accumulator registers (a lane owns 16 values of a
+// 32 x 32 sub-tile in either layout); nothing is stored; (2) the row block's stores, back to back,
+// nothing waits for them (the next row block's operand wait does: TM - 1 such waits per tile, none
+// without operands).  The bias quad is loaded once per column block, before phase 1.
+// Loads and stores are BUFFER operations on straight-line code: a lane outside the matrix (or an
+// absent matrix: a resource of zero bytes) gets an out-of-range offset, which loads 0 / drops the
+// store without a branch.
+struct EpiOps {               // one slice's operands: [row of the pair][slot]
+  f32x4 v[2][2];
+};
+struct EpiRs {                // buffer resources of the epilogue's matrices (absent: zero bytes)
+  __amdgpu_buffer_rsrc_t c, c2, op[2];
+};
+constexpr unsigned kOob = 0xFFFFFFF0u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t x3p_rsrc(const float* p, long ld, int rows) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0,
+                                           p ? (int)((long)rows * ld * 4) : 0, 0x00020000);
+}
+__device__ __forceinline__ EpiRs x3p_epi_rsrc(const X3P& g) {
+  EpiRs r;
+  r.c = x3p_rsrc(g.C, g.ldc, g.M);
+  r.c2 = x3p_rsrc(g.C2, g.ldc2, g.M);
+  r.op[0] = x3p_rsrc(g.op[0], g.ldop[0], g.M);
+  r.op[1] = x3p_rsrc(g.op[1], g.ldop[1], g.M);
+  return r;
+}
+__device__ __forceinline__ f32x4 x3p_bload(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+}
+__device__ __forceinline__ void x3p_bstore(__amdgpu_buffer_rsrc_t rs, unsigned off, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, off, 0, 0);
+}
+
+__device__ __forceinline__ f32x4 x3p_epi_bias(const X3P& g, int j, int n0, int wcb, int lane) {
+  const int col = n0 + 32 * (wcb + j) + (lane & 7) * 4;
+  f32x4 b = {0.f, 0.f, 0.f, 0.f};
+  if (g.bias && col < g.N) b = *reinterpret_cast<const f32x4*>(g.bias + col);
+  return b;
+}
+
+__device__ __forceinline__ void x3p_epi_load(const X3P& g, const EpiRs& rs, EpiOps& o, int i, int j,
+                                             int h, int m0, int n0, int wrb, int wcb, int lane) {
   const int er = lane >> 3, ec = (lane & 7) * 4;     // this lane's row (of 8) and column quad
   const int col = n0 + 32 * (wcb + j) + ec;
-  const bool cok = col < g.N;
-  // !LEAN (the epilogue proper): the optional operands of both rows are requested before the LDS
-  // exchange, whose latency covers part of theirs
-  // (native vectors: a select between two float4 STRUCTS goes through the stack)
-  f32x4 pre[LEAN ? 1 : 2][3];
-  if (!LEAN) {
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const long rc = (long)min(m0 + 32 * (wrb + i) + 16 * h + er + 8 * q, g.M - 1);
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      f32x4 t0 = z, t1 = z, t2 = z;
-      if (g.act_src && cok) t0 = *reinterpret_cast<const f32x4*>(g.act_src + rc * g.lds + col);
-      if (g.resid && cok) t1 = *reinterpret_cast<const f32x4*>(g.resid + rc * g.ldr + col);
-      if (g.resid_b && cok) t2 = *reinterpret_cast<const f32x4*>(g.resid_b + rc * g.ldrb + col);
-      pre[LEAN ? 0 : q][0] = t0;
-      pre[LEAN ? 0 : q][1] = t1;
-      pre[LEAN ? 0 : q][2] = t2;
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < 8; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * hi) * 36 + lo] = a[8 * h + r];
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  // the optional operands are fetched one row at a time, next to their use: a slice runs inside
-  // the next tile's k loop (DRIP), where registers matter more than this latency
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int row = m0 + 32 * (wrb + i) + 16 * h + er + 8 * q;
-    const bool ok = row < g.M && cok;
-    const long rc = (long)min(row, g.M - 1);
-    float4 v = *reinterpret_cast<const float4*>(scr + (er + 8 * q) * 36 + ec);
-    if (g.bias && cok) {
-      const float4 bv = *reinterpret_cast<const float4*>(g.bias + col);
-      v = make_float4(v.x + bv.x, v.y + bv.y, v.z + bv.z, v.w + bv.w);
-    }
-    if (g.act_src && ok) {
-      f32x4 sv = pre[LEAN ? 0 : q][0];
-      if (LEAN) sv = *reinterpret_cast<const f32x4*>(g.act_src + rc * g.lds + col);
-      v.x *= swoosh_deriv(sv.x, g.act_kind);
-      v.y *= swoosh_deriv(sv.y, g.act_kind);
-      v.z *= swoosh_deriv(sv.z, g.act_kind);
-      v.w *= swoosh_deriv(sv.w, g.act_kind);
-    }
-    if (g.resid && ok) {
-      f32x4 rv = pre[LEAN ? 0 : q][1];
-      if (LEAN) rv = *reinterpret_cast<const f32x4*>(g.resid + rc * g.ldr + col);
-      v = make_float4(v.x + rv.x, v.y + rv.y, v.z + rv.z, v.w + rv.w);
-    }
-    f32x4 rbv = {0.f, 0.f, 0.f, 0.f};
-    if (g.resid_b && ok) {
-      rbv = pre[LEAN ? 0 : q][2];
-      if (LEAN) rbv = *reinterpret_cast<const f32x4*>(g.resid_b + rc * g.ldrb + col);
-    }
-    if (g.act2 != 3) v = make_float4(v.x + rbv.x, v.y + rbv.y, v.z + rbv.z, v.w + rbv.w);
-    if (ok) {
-      *reinterpret_cast<float4*>(g.C + (long)row * g.ldc + col) = v;
-      if (g.C2 && g.act2 == 3)
-        *reinterpret_cast<float4*>(g.C2 + (long)row * g.ldc2 + col) =
-            make_float4(v.x + rbv.x, v.y + rbv.y, v.z + rbv.z, v.w + rbv.w);
-      else if (g.C2)
-        *reinterpret_cast<float4*>(g.C2 + (long)row * g.ldc2 + col) =
-            make_float4(swoosh(v.x, g.act2), swoosh(v.y, g.act2), swoosh(v.z, g.act2),
-                        swoosh(v.w, g.act2));
+    const bool ok = row < g.M && col < g.N;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      o.v[q][k] = z;
+      if (g.role[k])                                 // (uniform)
+        o.v[q][k] = x3p_bload(rs.op[k], ok ? (unsigned)(row * (int)g.ldop[k] + col) * 4u : kOob);
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+}
+
+// phase 1 of one slice: a[8 h .. 8 h + 7] (MFMA layout) -> the final values of this lane's two row
+// pieces (q = 0, 1: a[8 h + 4 q .. + 3])
+__device__ __forceinline__ void x3p_epi_xform(const X3P& g, f32x16& a, float* scr, const EpiOps& o,
+                                              const f32x4 bq, int h, int lane) {
+  const int hi = lane >> 5, lo = lane & 31;
+  const int er = lane >> 3, ec = (lane & 7) * 4;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * hi) * 36 + lo] = a[8 * h + r];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(scr + (er + 8 * q) * 36 + ec);
+    v += bq;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const f32x4 x = o.v[q][k];
+      if (g.role[k] == 1) {
+        v.x *= swoosh_deriv(x.x, g.act_kind);
+        v.y *= swoosh_deriv(x.y, g.act_kind);
+        v.z *= swoosh_deriv(x.z, g.act_kind);
+        v.w *= swoosh_deriv(x.w, g.act_kind);
+      } else if (g.role[k] == 2 || (g.role[k] == 3 && g.act2 != 3)) {
+        v += x;
+      }
+    }
+    a[8 * h + 4 * q + 0] = v.x;
+    a[8 * h + 4 * q + 1] = v.y;
+    a[8 * h + 4 * q + 2] = v.z;
+    a[8 * h + 4 * q + 3] = v.w;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// phase 2 of one slice: the two row pieces leave (out-of-matrix lanes: dropped by the buffer check)
+__device__ __forceinline__ void x3p_epi_store(const X3P& g, const EpiRs& rs, const f32x16& a,
+                                              const EpiOps& o, int i, int j, int h, int m0, int n0,
+                                              int wrb, int wcb, int lane) {
+  const int er = lane >> 3, ec = (lane & 7) * 4;
+  const int col = n0 + 32 * (wcb + j) + ec;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int row = m0 + 32 * (wrb + i) + 16 * h + er + 8 * q;
+    const bool ok = row < g.M && col < g.N;
+    const f32x4 v = {a[8 * h + 4 * q], a[8 * h + 4 * q + 1], a[8 * h + 4 * q + 2], a[8 * h + 4 * q + 3]};
+    x3p_bstore(rs.c, ok ? (unsigned)(row * (int)g.ldc + col) * 4u : kOob, v);
+    if (g.act2 == 3) {                               // C2 = C + the role-3 operand (still in its slot)
+      const f32x4 u = v + (g.role[0] == 3 ? o.v[q][0] : o.v[q][1]);
+      x3p_bstore(rs.c2, ok ? (unsigned)(row * (int)g.ldc2 + col) * 4u : kOob, u);
+    } else if (g.act2) {
+      const f32x4 u = {swoosh(v.x, g.act2), swoosh(v.y, g.act2), swoosh(v.z, g.act2), swoosh(v.w, g.act2)};
+      x3p_bstore(rs.c2, ok ? (unsigned)(row * (int)g.ldc2 + col) * 4u : kOob, u);
+    }
+  }
 }
 
 template <int TM, int TN>
@@ -214,13 +262,22 @@ __device__ __forceinline__ void x3p_epilogue(const X3P& g, f32x16 (&acc)[TM][TN]
                                              bool sync = true) {
   if (sync) __syncthreads();                         // all waves finished reading the stage buffers
   float* scr = reinterpret_cast<float*>(smem) + wave * (16 * 36);
+  const EpiRs rs = x3p_epi_rsrc(g);
+  f32x4 bq[TN];
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int j = 0; j < TN; ++j) bq[j] = x3p_epi_bias(g, j, n0, wcb, lane);
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+  for (int i = 0; i < TM; ++i) {
+    EpiOps ops[2 * TN];                              // slice t of the row block = (j, h) = (t / 2, t & 1)
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
-        x3p_epi_slice<false>(g, acc[i][j], scr, i, j, h, m0, n0, wrb, wcb, lane);
+    for (int t = 0; t < 2 * TN; ++t) x3p_epi_load(g, rs, ops[t], i, t / 2, t & 1, m0, n0, wrb, wcb, lane);
+#pragma unroll
+    for (int t = 0; t < 2 * TN; ++t) x3p_epi_xform(g, acc[i][t / 2], scr, ops[t], bq[t / 2], t & 1, lane);
+#pragma unroll
+    for (int t = 0; t < 2 * TN; ++t)
+      x3p_epi_store(g, rs, acc[i][t / 2], ops[t], i, t / 2, t & 1, m0, n0, wrb, wcb, lane);
+    __builtin_amdgcn_sched_barrier(0);               // (the next row block's loads stay behind these stores)
+  }
 }
 
 template <int TM, int TN>
@@ -349,8 +406,11 @@ __global__ __launch_bounds__(256, 2) void x3p_kernel(X3P g) {
 // output stores -- a third of a tile's life when every workgroup of the chip stores at once -- drain
 // under the next tile's MFMAs instead of between two main loops.  Needs >= 2 TM TN stages per tile
 // and is worth it with >= 2 tiles per workgroup (persistent grid).
+// (waves per SIMD the register allocation must leave room for: 2 / 3 / 4 workgroups per CU for the
+// 2x2 / 1x2, 2x1 / 1x1 tiles -- the epilogue's operand loads are hoisted as far as this allows)
 template <int TM, int TN, bool DIAG = false, int ABL = 0, bool DRIP = false>
-__global__ __launch_bounds__(256, 2) void x3p_db_kernel(X3P g) {
+__global__ __launch_bounds__(256, (DRIP || DIAG || TM * TN == 4) ? 2 : (TM * TN == 2 ? 3 : 4))
+void x3p_db_kernel(X3P g) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   constexpr int A_ST = 2 * TM * 3 * 1024, B_ST = 2 * TN * 3 * 1024, ST = A_ST + B_ST;
   constexpr int NAU = (128 * TM + 255) / 256;       // A units (8 k of one row) per thread and stage
@@ -540,9 +600,14 @@ __global__ __launch_bounds__(256, 2) void x3p_db_kernel(X3P g) {
   bool pend = false;
   float* const scr_w = reinterpret_cast<float*>(epi_smem) + wave * (16 * 36);
 #define X3P_SLICE(SL)                                                                        \
-  if (DRIP && pend)                                                                          \
-    x3p_epi_slice<true>(g, pacc[DRIP ? (SL) / (2 * TN) : 0][DRIP ? ((SL) / 2) % TN : 0], scr_w, \
-                  (SL) / (2 * TN), ((SL) / 2) % TN, (SL) & 1, pm0, pn0, wrb, wcb, lane);
+  if (DRIP && pend) {                                                                        \
+    EpiOps o_;                                                                               \
+    const EpiRs rs_ = x3p_epi_rsrc(g);                                                       \
+    f32x16& a_ = pacc[DRIP ? (SL) / (2 * TN) : 0][DRIP ? ((SL) / 2) % TN : 0];               \
+    x3p_epi_load(g, rs_, o_, (SL) / (2 * TN), ((SL) / 2) % TN, (SL) & 1, pm0, pn0, wrb, wcb, lane); \
+    x3p_epi_xform(g, a_, scr_w, o_, x3p_epi_bias(g, ((SL) / 2) % TN, pn0, wcb, lane), (SL) & 1, lane); \
+    x3p_epi_store(g, rs_, a_, o_, (SL) / (2 * TN), ((SL) / 2) % TN, (SL) & 1, pm0, pn0, wrb, wcb, lane); \
+  }
   for (;;) {
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -555,9 +620,9 @@ __global__ __launch_bounds__(256, 2) void x3p_db_kernel(X3P g) {
     X3P_STORE(0, 0)
     X3P_LOAD(0, 1)
     if (tile_no == 0 && g.stagger > 0) {
-      // The workgroups of a CU share its matrix pipes and, started together, run in LOCKSTEP: all
-      // multiply (sharing the pipe), then all wait for loads / LDS / the barrier (pipe idle).  A
-      // one-off delay by the workgroup's slot on its CU (HW_ID.TG_ID) puts them out of phase.
+      // The workgroups of a CU share its matrix pipes and, started together, run in LOCKSTEP.  A
+      // one-off delay by the workgroup's slot on its CU (HW_ID.TG_ID) puts them out of phase
+      // (diagnostics: S2T_X3P_STAGGER; measured: the delay is simply added, 0 ... 38 k cycles)
       const int tg = (int)(__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (16 << 6) | 4) & 15u);
       for (int i = 0; i < tg * g.stagger; ++i) __builtin_amdgcn_s_sleep(1);
     }
@@ -775,8 +840,20 @@ int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int 
       (act_src && (!al16(act_src) || (ld_act & 3))) || (C2 && (!al16(C2) || (ldc2 & 3))) ||
       (resid_b && (!al16(resid_b) || (ldrb & 3))))
     return -2;
-  X3P g{A, lda, Bp, (N + 31) / 32, 2 * ((K + 31) / 32), C, ldc, M, N, K, bias, resid, ldr, act_src,
-        ld_act, act_kind, C2, ldc2, act2, resid_b, ldrb, 0, 0, wgs, 0, g_stamps, drip, 0};
+  // the epilogue addresses its matrices through 32-bit buffer offsets
+  auto fits = [M](const void* p, long ld) { return !p || (long)M * ld * 4 < 0x7FFFFF00L; };
+  if (!fits(C, ldc) || !fits(C2, ldc2) || !fits(resid, ldr) || !fits(act_src, ld_act) ||
+      !fits(resid_b, ldrb))
+    return -2;
+  if (act_src && resid && resid_b) return -2;        // two operand slots
+  X3P g{A, lda, Bp, (N + 31) / 32, 2 * ((K + 31) / 32), C, ldc, M, N, K, bias, {nullptr, nullptr},
+        {0, 0}, {0, 0}, act_kind, C2, ldc2, act2, 0, 0, wgs, 0, g_stamps, drip, 0};
+  {
+    int k = 0;
+    if (act_src) { g.op[k] = act_src; g.ldop[k] = ld_act; g.role[k++] = 1; }
+    if (resid) { g.op[k] = resid; g.ldop[k] = ldr; g.role[k++] = 2; }
+    if (resid_b) { g.op[k] = resid_b; g.ldop[k] = ldrb; g.role[k++] = 3; }
+  }
   {
     static int stg = -1;       // S2T_X3P_STAGGER: start delay per workgroup slot, units of 64 cycles
     if (stg < 0) { const char* e = getenv("S2T_X3P_STAGGER"); stg = e ? atoi(e) : 0; }

@@ -61,6 +61,10 @@ print(f"  MFMA floor of one tile's main loop alone: {nst * 6 * tm * tn * 32} cyc
 cu = (s[:, 7] << 16) | ((s[:, 6] >> 4) & 0xFF)      # XCC | SE, SH, CU (HW_ID bits 15:8)
 u, cnt = np.unique(cu, return_counts=True)
 print(f"  CUs used {len(u)}, workgroups per CU: min {cnt.min()} median {int(np.median(cnt))} max {cnt.max()}")
+bidx = np.nonzero(allb[:, 0] != 0)[0][:len(s)]
+print("  block indices resident on a CU (first 6 CUs by key; XCD = block & 7):")
+for kk in u[:6]:
+    print(f"    cu {int(kk):#08x}:", " ".join(f"{int(b)}(x{int(b) & 7},s{int(b) >> 3})" for b in bidx[cu == kk]))
 k = u[np.argmax(cnt)]
 rows = s[cu == k]
 rows = rows[np.argsort(rows[:, 0])]
