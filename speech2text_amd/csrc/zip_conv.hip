@@ -14,6 +14,7 @@
 // reduction over the 4 frame groups, one atomic per tap per block).
 #include "common.h"
 #include <algorithm>
+#include <cstdint>
 #include <cstdlib>
 
 namespace {
@@ -45,7 +46,18 @@ struct ConvArgs {
   const float* wk;      // (C,K)
   const float* bk;      // (C) or null
   const float* scale;   // (2,C,K) or null
+  // t-tile of a workgroup = blockIdx.z + z_base, + z_jump from z_split on: a launch covers either the
+  // INTERIOR tiles [n_lo, n_hi) (no frame within K of a chunk edge: edge scale == 1, no edge arrays
+  // and no scaled-gradient tile in LDS -- 36 instead of 52 / 76 KB at K = 31) or the others
+  int z_base, z_split, z_jump;
+  int nt;               // t-tiles in all (partial-sum slots of the weight kernel)
 };
+
+__device__ __forceinline__ int tile_z(const ConvArgs& a) {
+  int tz = (int)blockIdx.z + a.z_base;
+  if (tz >= a.z_split) tz += a.z_jump;
+  return tz;
+}
 
 template <int K>
 __device__ __forceinline__ void stage_weights(const ConvArgs& a, int c0, float* s_wc, float* s_wk,
@@ -182,30 +194,31 @@ __device__ __forceinline__ void stage_xg_buf(const ConvArgs& a, int b, int t0, i
   }
 }
 
-template <int K, bool GEN>
+template <int K, bool GEN, bool EDGE>
 __global__ __launch_bounds__(256) void zipconv_fwd_kernel(ConvArgs a, float* __restrict__ y) {
   constexpr int Kh = (K + 1) / 2, halo = K / 2, W = FPT + 2 * halo;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* s_x = reinterpret_cast<float*>(smem_raw);
   float* s_wc = s_x + (TT + 2 * halo) * 64;
   float* s_wk = s_wc + Kh * 64;
-  float* s_le = s_wk + K * 64;
-  float* s_re = s_le + K * 64;
+  float* s_le = EDGE ? s_wk + K * 64 : nullptr;
+  float* s_re = EDGE ? s_le + K * 64 : nullptr;
   // channel tile fastest, then utterance, then frame tile: workgroups that are dispatched together
   // read neighbouring pieces of the same (t, b) rows (rows of adjacent b are adjacent in memory)
-  const int c0 = blockIdx.x * 64, b = blockIdx.y, t0 = blockIdx.z * TT;
+  const int c0 = blockIdx.x * 64, b = blockIdx.y, t0 = tile_z(a) * TT;
   const int c = threadIdx.x & 63, tg = threadIdx.x >> 6;
   stage_weights<K>(a, c0, s_wc, s_wk, s_le, s_re,
-                   GEN || t0 - K / 2 < K || t0 + TT + K / 2 > a.T - K);
+                   EDGE && (GEN || t0 - K / 2 < K || t0 + TT + K / 2 > a.T - K));
   if (buf_ok(a)) stage_xg_buf<K>(a, b, t0, c0, s_x);
   else stage_xg<K>(a, b, t0, c0, s_x);
   __syncthreads();
-  if (c0 + c >= a.C) return;
+  const bool chan_ok = c0 + c < a.C;
+  const int cc = chan_ok ? c0 + c : 0;
   float win[W];
 #pragma unroll
   for (int w = 0; w < W; ++w) win[w] = s_x[(tg * FPT + w) * 64 + c];
-  const float bc = a.bc ? a.bc[c0 + c] : 0.f;
-  const float bk = a.bk ? a.bk[c0 + c] : 0.f;
+  const float bc = a.bc ? a.bc[cc] : 0.f;
+  const float bk = a.bk ? a.bk[cc] : 0.f;
   const int tb = t0 + tg * FPT;
   float accc[FPT], acck[FPT];
 #pragma unroll
@@ -247,36 +260,58 @@ __global__ __launch_bounds__(256) void zipconv_fwd_kernel(ConvArgs a, float* __r
 #pragma unroll
   for (int i = 0; i < FPT; ++i) {
     const int t = tb + i;
-    if (t < a.T) {
-      float v = acck[i];
-      if (a.scale) v *= edge_scale(s_le, s_re, c, t % chunk, chunk, K);
-      y[((long)t * a.B + b) * a.C + c0 + c] = v + accc[i];
+    if (EDGE && a.scale && t < a.T) acck[i] *= edge_scale(s_le, s_re, c, t % chunk, chunk, K);
+    acck[i] += accc[i];
+  }
+  if ((a.C & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0) {
+    // the tile leaves as 16-byte row pieces (lane = 4 channels; a wave-instruction = 4 whole rows
+    // of the tile): per-lane 4-byte stores of 64 channels are a quarter of that per instruction
+    __syncthreads();                               // every window is in registers: s_x is free
+#pragma unroll
+    for (int i = 0; i < FPT; ++i) s_x[(tg * FPT + i) * 64 + c] = acck[i];
+    __syncthreads();
+    const int rig = threadIdx.x >> 4, c4 = threadIdx.x & 15, ch = c0 + 4 * c4;
+#pragma unroll
+    for (int p = 0; p < TT / 16; ++p) {
+      const int r = 16 * p + rig, t = t0 + r;
+      if (t < a.T && ch < a.C)
+        *reinterpret_cast<float4*>(y + ((long)t * a.B + b) * a.C + ch) =
+            *reinterpret_cast<const float4*>(&s_x[r * 64 + 4 * c4]);
     }
+    return;
+  }
+  if (!chan_ok) return;
+#pragma unroll
+  for (int i = 0; i < FPT; ++i) {
+    const int t = tb + i;
+    if (t < a.T) y[((long)t * a.B + b) * a.C + c0 + c] = acck[i];
   }
 }
 
 // du[t'] : gradient w.r.t. the projection (x half and gate half)
-template <int K, bool GEN>
+template <int K, bool GEN, bool EDGE>
 __global__ __launch_bounds__(256) void zipconv_bwd_data_kernel(ConvArgs a,
                                                                const float* __restrict__ dy,
                                                                float* __restrict__ du) {
   constexpr int Kh = (K + 1) / 2, halo = K / 2, W = FPT + 2 * halo;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* s_g = reinterpret_cast<float*>(smem_raw);  // dy tile with halo
-  float* s_gs = s_g + (TT + 2 * halo) * 64;         // dy * edge_scale
-  float* s_wc = s_gs + (TT + 2 * halo) * 64;
+  float* s_wc = s_g + (TT + 2 * halo) * 64;
   float* s_wk = s_wc + Kh * 64;
-  float* s_le = s_wk + K * 64;
-  float* s_re = s_le + K * 64;
+  float* s_le = EDGE ? s_wk + K * 64 : nullptr;
+  float* s_re = EDGE ? s_le + K * 64 : nullptr;
   // channel tile fastest, then utterance, then frame tile: workgroups that are dispatched together
   // read neighbouring pieces of the same (t, b) rows (rows of adjacent b are adjacent in memory)
-  const int c0 = blockIdx.x * 64, b = blockIdx.y, t0 = blockIdx.z * TT;
+  const int c0 = blockIdx.x * 64, b = blockIdx.y, t0 = tile_z(a) * TT;
   const int c = threadIdx.x & 63, tg = threadIdx.x >> 6;
-  stage_weights<K>(a, c0, s_wc, s_wk, s_le, s_re,
-                   GEN || t0 - K / 2 < K || t0 + TT + K / 2 > a.T - K);
+  // (block-uniform) some frame of the tile or its halo lies within K of a chunk edge
+  const bool near_edge = EDGE && (GEN || t0 - K / 2 < K || t0 + TT + K / 2 > a.T - K);
+  stage_weights<K>(a, c0, s_wc, s_wk, s_le, s_re, near_edge);
   __syncthreads();
   const int chunk = a.chunk;
-  // two tiles: raw dy (causal taps) and dy * edge_scale (chunkwise taps)
+  // ONE tile, the raw dy (causal taps); the chunkwise taps see dy * edge_scale, applied to the
+  // register window of the tiles that have an edge frame (a second, scaled tile in LDS cost a
+  // workgroup per CU)
   const bool dy_buf = (long)a.T * a.B * a.C * 4 < 0x7FFFFF00L;
   if (dy_buf) {
     // one batch of 16-byte buffer loads (lane = 4 channels of a row; frames outside [0,T) read 0)
@@ -297,16 +332,10 @@ __global__ __launch_bounds__(256) void zipconv_bwd_data_kernel(ConvArgs a,
       if (r < rows) {
         float v[4] = {__uint_as_float(gq[p].x), __uint_as_float(gq[p].y), __uint_as_float(gq[p].z),
                       __uint_as_float(gq[p].w)};
-        float vs[4];
-        const bool tin = t >= 0 && t < a.T;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < 4; ++e)
           if (ch + e >= a.C) v[e] = 0.f;
-          vs[e] = (tin && a.scale && ch + e < a.C)
-                      ? v[e] * edge_scale(s_le, s_re, 4 * c4 + e, t % chunk, chunk, K) : v[e];
-        }
         *reinterpret_cast<float4*>(&s_g[r * 64 + 4 * c4]) = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<float4*>(&s_gs[r * 64 + 4 * c4]) = make_float4(vs[0], vs[1], vs[2], vs[3]);
       }
     }
   } else {
@@ -325,27 +354,52 @@ __global__ __launch_bounds__(256) void zipconv_bwd_data_kernel(ConvArgs a,
         const int r = r0 + 4 * i, t = t0 - halo + r;
         if (r < rows) {
           const bool ok = cok && t >= 0 && t < a.T;
-          const float v = ok ? gv[i] : 0.f;
-          s_g[r * 64 + c] = v;
-          s_gs[r * 64 + c] =
-              (ok && a.scale) ? v * edge_scale(s_le, s_re, c, t % chunk, chunk, K) : v;
+          s_g[r * 64 + c] = ok ? gv[i] : 0.f;
         }
       }
     }
   }
   __syncthreads();
-  if (c0 + c >= a.C) return;
   const int tb = t0 + tg * FPT;
-  // the projection values the gate's backward needs, issued now and consumed after the tap loops
+  const bool chan_ok = c0 + c < a.C;
+  const bool gated = a.gate_off >= 0;
+  const int nout = gated ? 2 * a.C : a.C;
+  // 16-byte form of everything that is not the tap loops: the projection values the gate's backward
+  // needs arrive as row pieces (lane = 4 channels of a row, a wave-instruction = 4 whole rows of the
+  // tile) and the result leaves the same way, through LDS -- per-lane 4-byte accesses of 64 channels
+  // move a quarter of that per instruction
+  const bool vec = (a.C & 3) == 0 && (a.ld & 3) == 0 && (!gated || (a.gate_off & 3) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(du) | reinterpret_cast<uintptr_t>(a.u)) & 15) == 0 && buf_ok(a);
+  const int rig = threadIdx.x >> 4, c4 = threadIdx.x & 15, ch = c0 + 4 * c4;
+  u32x4 qx[TT / 16], qs[TT / 16];
+  unsigned char qpad[TT / 16];
+  // the scalar form's operands, issued now and consumed after the tap loops
   float oxv[FPT], osv[FPT];
   unsigned char opad[FPT];
+  if (vec) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.u), 0, (int)((long)a.T * a.B * a.ld * 4), 0x00020000);
 #pragma unroll
-  for (int i = 0; i < FPT; ++i) {
-    const int t = min(tb + i, a.T - 1);
-    const float* row = a.u + ((long)t * a.B + b) * a.ld;
-    opad[i] = a.mask ? a.mask[(long)b * a.T + t] : (unsigned char)0;
-    oxv[i] = a.gate_off >= 0 ? row[c0 + c] : 0.f;
-    osv[i] = a.gate_off >= 0 ? row[a.gate_off + c0 + c] : 0.f;
+    for (int p = 0; p < TT / 16; ++p) {
+      const int t = t0 + 16 * p + rig;
+      const bool tin = t < a.T && ch < a.C;
+      const int off = (((t * a.B + b) * (int)a.ld) + ch) * 4;
+      qx[p] = gated ? __builtin_amdgcn_raw_buffer_load_b128(rs, tin ? off : 0x7FFFFFF0, 0, 0)
+                    : (u32x4){0u, 0u, 0u, 0u};
+      qs[p] = gated ? __builtin_amdgcn_raw_buffer_load_b128(rs, tin ? off + a.gate_off * 4 : 0x7FFFFFF0, 0, 0)
+                    : (u32x4){0u, 0u, 0u, 0u};
+      qpad[p] = a.mask ? a.mask[(long)b * a.T + min(t, a.T - 1)] : (unsigned char)0;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < FPT; ++i) {
+      const int t = min(tb + i, a.T - 1);
+      const float* row = a.u + ((long)t * a.B + b) * a.ld;
+      const int cc = chan_ok ? c0 + c : 0;
+      opad[i] = a.mask ? a.mask[(long)b * a.T + t] : (unsigned char)0;
+      oxv[i] = gated ? row[cc] : 0.f;
+      osv[i] = gated ? row[a.gate_off + cc] : 0.f;
+    }
   }
   float win[W];   // frames tb-halo .. tb+FPT-1+halo
   float acc[FPT];
@@ -363,8 +417,17 @@ __global__ __launch_bounds__(256) void zipconv_bwd_data_kernel(ConvArgs a,
     }
   }
   // chunkwise: dxg[t'] += wk[j] * (dy*sc)[t' + halo - j] when frame t'+halo-j is in t's chunk
+  if (!a.wc) {
 #pragma unroll
-  for (int w = 0; w < W; ++w) win[w] = s_gs[(tg * FPT + w) * 64 + c];
+    for (int w = 0; w < W; ++w) win[w] = s_g[(tg * FPT + w) * 64 + c];
+  }
+  if (near_edge && a.scale) {
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      const int t = tb - halo + w;
+      if (t >= 0 && t < a.T) win[w] *= edge_scale(s_le, s_re, c, GEN ? t % chunk : t, chunk, K);
+    }
+  }
   if (!GEN) {
 #pragma unroll
     for (int j = 0; j < K; ++j) {
@@ -386,14 +449,47 @@ __global__ __launch_bounds__(256) void zipconv_bwd_data_kernel(ConvArgs a,
       }
     }
   }
-  const int nout = a.gate_off >= 0 ? 2 * a.C : a.C;
+  if (vec) {
+    __syncthreads();                               // every window is in registers: s_g is free
+#pragma unroll
+    for (int i = 0; i < FPT; ++i) s_g[(tg * FPT + i) * 64 + c] = acc[i];
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < TT / 16; ++p) {
+      const int r = 16 * p + rig, t = t0 + r;
+      if (t >= a.T || ch >= a.C) continue;
+      const float4 d = *reinterpret_cast<const float4*>(&s_g[r * 64 + 4 * c4]);
+      const float dv[4] = {d.x, d.y, d.z, d.w};
+      float* o = du + ((long)t * a.B + b) * nout + ch;
+      const bool pad = qpad[p] != 0;
+      if (gated) {
+        const float xv[4] = {__uint_as_float(qx[p].x), __uint_as_float(qx[p].y), __uint_as_float(qx[p].z),
+                             __uint_as_float(qx[p].w)};
+        const float sv[4] = {__uint_as_float(qs[p].x), __uint_as_float(qs[p].y), __uint_as_float(qs[p].z),
+                             __uint_as_float(qs[p].w)};
+        float ox[4], og[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float sg = sigmoidf_(sv[e]);
+          ox[e] = pad ? 0.f : dv[e] * sg;
+          og[e] = pad ? 0.f : dv[e] * xv[e] * sg * (1.f - sg);
+        }
+        *reinterpret_cast<float4*>(o) = make_float4(ox[0], ox[1], ox[2], ox[3]);
+        *reinterpret_cast<float4*>(o + a.C) = make_float4(og[0], og[1], og[2], og[3]);
+      } else {
+        *reinterpret_cast<float4*>(o) = pad ? make_float4(0.f, 0.f, 0.f, 0.f) : d;
+      }
+    }
+    return;
+  }
+  if (!chan_ok) return;
 #pragma unroll
   for (int i = 0; i < FPT; ++i) {
     const int t = tb + i;
     if (t < a.T) {
       const bool pad = opad[i] != 0;
       float* o = du + ((long)t * a.B + b) * nout;
-      if (a.gate_off >= 0) {
+      if (gated) {
         const float xv = oxv[i], sg = sigmoidf_(osv[i]);
         o[c0 + c] = pad ? 0.f : acc[i] * sg;
         o[a.C + c0 + c] = pad ? 0.f : acc[i] * xv * sg * (1.f - sg);
@@ -407,7 +503,7 @@ __global__ __launch_bounds__(256) void zipconv_bwd_data_kernel(ConvArgs a,
 // weight / bias gradients; block = (t-tile, group of BB utterances, c-tile).  Each block
 // writes its partial sums to part[block][NV][64 ch] (NV = Kh + 1 + K + 1); zipconv_reduce_w_kernel
 // sums over blocks -- no atomics (contended float atomics on a few KB run ~14x slower).
-template <int K, bool GEN>
+template <int K, bool GEN, bool EDGE>
 __global__ __launch_bounds__(256) void zipconv_bwd_w_kernel(ConvArgs a,
                                                             const float* __restrict__ dy, int BB,
                                                             float* __restrict__ part,
@@ -417,15 +513,16 @@ __global__ __launch_bounds__(256) void zipconv_bwd_w_kernel(ConvArgs a,
   float* s_x = reinterpret_cast<float*>(smem_raw);
   float* s_wc = s_x + (TT + 2 * halo) * 64;
   float* s_wk = s_wc + Kh * 64;
-  float* s_le = s_wk + K * 64;
-  float* s_re = s_le + K * 64;
-  float* s_red = s_re + K * 64;  // [4][64] reduction scratch
-  const int c0 = blockIdx.x * 64, t0 = blockIdx.z * TT;
+  float* s_le = EDGE ? s_wk + K * 64 : nullptr;
+  float* s_re = EDGE ? s_le + K * 64 : nullptr;
+  float* s_red = s_wk + (EDGE ? 3 : 1) * K * 64;  // [4][64] reduction scratch
+  const int tz = tile_z(a);
+  const int c0 = blockIdx.x * 64, t0 = tz * TT;
   const int c = threadIdx.x & 63, tg = threadIdx.x >> 6;
   const int tb = t0 + tg * FPT;
   const int chunk = a.chunk;
   stage_weights<K>(a, c0, s_wc, s_wk, s_le, s_re,
-                   GEN || t0 - K / 2 < K || t0 + TT + K / 2 > a.T - K);
+                   EDGE && (GEN || t0 - K / 2 < K || t0 + TT + K / 2 > a.T - K));
   float pwc[Kh], pwk[K];
 #pragma unroll
   for (int j = 0; j < Kh; ++j) pwc[j] = 0.f;
@@ -441,7 +538,7 @@ __global__ __launch_bounds__(256) void zipconv_bwd_w_kernel(ConvArgs a,
     sc[i] = 1.f;
   }
   __syncthreads();
-  if (a.scale) {
+  if (EDGE && a.scale) {
 #pragma unroll
     for (int i = 0; i < FPT; ++i)
       if (tb + i < a.T) sc[i] = edge_scale(s_le, s_re, c, tb + i - cs[i], chunk, K);
@@ -450,7 +547,7 @@ __global__ __launch_bounds__(256) void zipconv_bwd_w_kernel(ConvArgs a,
   // a chunk edge: only tiles that contain such a frame compute it (block-uniform), summed over
   // this block's utterances in registers, one atomic per (frame, side) at the end
   bool edge = false;
-  if (dscale != nullptr) {
+  if (EDGE && dscale != nullptr) {
     const int p0 = t0 % chunk;
     edge = (p0 < K) || (p0 + TT - 1 >= chunk - K) || (p0 + TT > chunk);
   }
@@ -523,7 +620,7 @@ __global__ __launch_bounds__(256) void zipconv_bwd_w_kernel(ConvArgs a,
     }
   }
   // reduce the 4 frame groups of each channel through LDS, then one store per value
-  const long blk = ((long)blockIdx.x * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z;
+  const long blk = ((long)blockIdx.x * gridDim.y + blockIdx.y) * a.nt + tz;
   float* dst = part + blk * NV * 64 + c;          // [block][slot][64 channels]: coalesced stores
   auto reduce_store = [&](float v, int slot) {
     __syncthreads();
@@ -579,10 +676,20 @@ __global__ __launch_bounds__(256) void zipconv_reduce_w_kernel(
 }
 
 template <int K>
-size_t conv_smem(bool with_red, int tiles = 1) {
+size_t conv_smem(bool with_red, int tiles, bool edge) {
   constexpr int Kh = (K + 1) / 2, halo = K / 2;
-  return sizeof(float) *
-         (tiles * (TT + 2 * halo) * 64 + Kh * 64 + 3 * K * 64 + (with_red ? 256 : 0));
+  return sizeof(float) * ((edge ? tiles : 1) * (TT + 2 * halo) * 64 + Kh * 64 + (edge ? 3 : 1) * K * 64 +
+                          (with_red ? 256 : 0));
+}
+
+// t-tiles [n_lo, n_hi) are interior (single chunk: no frame of the tile or its halo within K of
+// either end of the sequence)
+inline void interior_tiles(int T, int K, int nt, int* n_lo, int* n_hi) {
+  int lo = 0, hi = nt;
+  while (lo < nt && lo * TT - K / 2 < K) ++lo;
+  while (hi > lo && (hi - 1) * TT + TT + K / 2 > T - K) --hi;
+  *n_lo = lo;
+  *n_hi = hi;
 }
 
 }  // namespace
@@ -601,22 +708,54 @@ static int conv_args_ok(int T, int B, int C, int K, int chunk) {
   return T > 0 && B > 0 && C > 0 && (K & 1) && chunk > 0;
 }
 
+// One launch: the EDGE kernel over all tiles, or -- a plain depthwise Conv1d, nothing to scale -- the
+// lean one (EDGE = false: no edge arrays in LDS).
+struct ZSplit {
+  int nt, n_lo, n_hi;
+  ZSplit(int T, int K, bool gen, bool has_scale) {
+    nt = (T + TT - 1) / TT;
+    if (gen) { n_lo = n_hi = 0; }                    // everything through the EDGE kernel
+    else if (!has_scale) { n_lo = 0; n_hi = nt; }    // nothing to scale: everything interior
+    else if (getenv("S2T_CONV_SPLIT")) interior_tiles(T, K, nt, &n_lo, &n_hi);
+    else { n_lo = n_hi = 0; }
+    // (measured at the C3 shapes: the interior kernel alone over ALL tiles is 20-40 % faster than
+    // the edge kernel, but two launches -- each with its own tail -- are 30-45 % slower than one;
+    // the split is kept for experiments: S2T_CONV_SPLIT=1)
+  }
+  int n_int() const { return n_hi - n_lo; }
+  int n_edge() const { return nt - (n_hi - n_lo); }
+  void set_int(ConvArgs& a) const { a.z_base = n_lo; a.z_split = 1 << 30; a.z_jump = 0; a.nt = nt; }
+  void set_edge(ConvArgs& a) const { a.z_base = 0; a.z_split = n_lo; a.z_jump = n_hi - n_lo; a.nt = nt; }
+};
+
 extern "C" int s2t_zipconv_fwd(const float* u, long ld, int gate_off, const unsigned char* mask,
                                int T, int B, int C, int K, int chunk, const float* wc,
                                const float* bc, const float* wk, const float* bk,
                                const float* scale, float* y, void* stream) {
   if (!conv_args_ok(T, B, C, K, chunk)) return -1;
-  ConvArgs a{u, ld, gate_off, mask, T, B, C, chunk, wc, bc, wk, bk, scale};
-  dim3 grid((C + 63) / 64, B, (T + TT - 1) / TT);
+  ConvArgs a{u, ld, gate_off, mask, T, B, C, chunk, wc, bc, wk, bk, scale, 0, 1 << 30, 0, 0};
   hipStream_t st = (hipStream_t)stream;
-  if (chunk >= T) {
-    S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_fwd_kernel<KK, false>), grid, dim3(256),
-                                            conv_smem<KK>(false), st, a, y));
-  } else {
-    S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_fwd_kernel<KK, true>), grid, dim3(256),
-                                            conv_smem<KK>(false), st, a, y));
+  const bool gen = chunk < T;
+  const ZSplit z(T, K, gen, scale != nullptr);
+  const unsigned gx = (C + 63) / 64;
+  if (z.n_int() > 0) {
+    z.set_int(a);
+    S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_fwd_kernel<KK, false, false>), dim3(gx, B, z.n_int()),
+                                            dim3(256), conv_smem<KK>(false, 1, false), st, a, y));
+    S2T_CHECK_LAUNCH();
   }
-  S2T_CHECK_LAUNCH();
+  if (z.n_edge() > 0) {
+    z.set_edge(a);
+    const dim3 grid(gx, B, z.n_edge());
+    if (!gen) {
+      S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_fwd_kernel<KK, false, true>), grid, dim3(256),
+                                              conv_smem<KK>(false, 1, true), st, a, y));
+    } else {
+      S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_fwd_kernel<KK, true, true>), grid, dim3(256),
+                                              conv_smem<KK>(false, 1, true), st, a, y));
+    }
+    S2T_CHECK_LAUNCH();
+  }
   return 0;
 }
 
@@ -633,38 +772,60 @@ extern "C" int s2t_zipconv_bwd(const float* u, long ld, int gate_off, const unsi
                                float* dbk, float* dscale, float* workspace, void* stream) {
   if (!conv_args_ok(T, B, C, K, chunk)) return -1;
   hipStream_t st = (hipStream_t)stream;
-  ConvArgs a{u, ld, gate_off, mask, T, B, C, chunk, wc, nullptr, wk, bk, scale};
-  dim3 grid((C + 63) / 64, B, (T + TT - 1) / TT);
+  ConvArgs a{u, ld, gate_off, mask, T, B, C, chunk, wc, nullptr, wk, bk, scale, 0, 1 << 30, 0, 0};
   const bool gen = chunk < T;
-  if (!gen) {
-    S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_data_kernel<KK, false>), grid, dim3(256),
-                                            conv_smem<KK>(false, 2), st, a, dy, du));
-  } else {
-    S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_data_kernel<KK, true>), grid, dim3(256),
-                                            conv_smem<KK>(false, 2), st, a, dy, du));
+  const ZSplit z(T, K, gen, scale != nullptr);
+  const unsigned gx = (C + 63) / 64;
+  if (z.n_int() > 0) {
+    z.set_int(a);
+    S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_data_kernel<KK, false, false>),
+                                            dim3(gx, B, z.n_int()), dim3(256),
+                                            conv_smem<KK>(false, 1, false), st, a, dy, du));
+    S2T_CHECK_LAUNCH();
   }
-  S2T_CHECK_LAUNCH();
+  if (z.n_edge() > 0) {
+    z.set_edge(a);
+    const dim3 grid(gx, B, z.n_edge());
+    if (!gen) {
+      S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_data_kernel<KK, false, true>), grid, dim3(256),
+                                              conv_smem<KK>(false, 1, true), st, a, dy, du));
+    } else {
+      S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_data_kernel<KK, true, true>), grid, dim3(256),
+                                              conv_smem<KK>(false, 1, true), st, a, dy, du));
+    }
+    S2T_CHECK_LAUNCH();
+  }
   // utterances per block: many -- a workgroup's fixed costs (tap staging, the 49-slot reduction
   // epilogue) are what this kernel's time is made of: at the C3 shapes 768 / 384 / 192 / 128
   // workgroups take 92 / 66 / 56 / 62 us (K = 31) and 46 / 46 / 33 / 27 us (K = 15)
-  const long tiles = (long)grid.x * grid.z;
+  const long tiles = (long)gx * z.nt;
   const char* env = getenv("S2T_CONV_BLOCKS");         // tuning / tests: workgroup-count target
   int BB = (int)((tiles * B) / (env ? std::max(1, atoi(env)) : (K >= 31 ? 192 : 128)));
   if (BB < 1) BB = 1;
   if (BB > 16) BB = 16;
-  dim3 gridw(grid.x, (B + BB - 1) / BB, grid.z);   // (c tiles, utterance groups, t tiles)
-  if (!gen) {
-    S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_w_kernel<KK, false>), gridw, dim3(256),
-                                            conv_smem<KK>(true), st, a, dy, BB, workspace,
-                                            (scale && dscale) ? dscale : nullptr));
-  } else {
-    S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_w_kernel<KK, true>), gridw, dim3(256),
-                                            conv_smem<KK>(true), st, a, dy, BB, workspace,
-                                            (scale && dscale) ? dscale : nullptr));
+  const unsigned gy = (B + BB - 1) / BB;             // utterance groups
+  float* const dsc = (scale && dscale) ? dscale : nullptr;
+  if (z.n_int() > 0) {
+    z.set_int(a);
+    S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_w_kernel<KK, false, false>), dim3(gx, gy, z.n_int()),
+                                            dim3(256), conv_smem<KK>(true, 1, false), st, a, dy, BB,
+                                            workspace, dsc));
+    S2T_CHECK_LAUNCH();
   }
-  S2T_CHECK_LAUNCH();
-  hipLaunchKernelGGL(zipconv_reduce_w_kernel, dim3((C + 63) / 64, (K + 1) / 2 + K + 2), dim3(256), 0,
-                     st, workspace, (int)(gridw.z * gridw.y), C, (K + 1) / 2, K, wc ? dwc : nullptr,
+  if (z.n_edge() > 0) {
+    z.set_edge(a);
+    const dim3 gridw(gx, gy, z.n_edge());
+    if (!gen) {
+      S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_w_kernel<KK, false, true>), gridw, dim3(256),
+                                              conv_smem<KK>(true, 1, true), st, a, dy, BB, workspace, dsc));
+    } else {
+      S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_w_kernel<KK, true, true>), gridw, dim3(256),
+                                              conv_smem<KK>(true, 1, true), st, a, dy, BB, workspace, dsc));
+    }
+    S2T_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(zipconv_reduce_w_kernel, dim3(gx, (K + 1) / 2 + K + 2), dim3(256), 0,
+                     st, workspace, (int)(z.nt * gy), C, (K + 1) / 2, K, wc ? dwc : nullptr,
                      wc ? dbc : nullptr, dwk, dbk);
   S2T_CHECK_LAUNCH();
   return 0;
