@@ -22,9 +22,12 @@ class _Conv(torch.nn.Module):
                                            (77, 4, 70, 15, 16), (50, 2, 64, 7, 8),
                                            (20, 2, 33, 31, -1), (64, 1, 64, 15, 4),
                                            (150, 7, 96, 31, -1), (90, 6, 64, 15, 16)])
-def test_glu_chunk_causal_dwconv(dev, monkeypatch, T, B, C, K, chunk):
+@pytest.mark.parametrize("fused", [False, True])
+def test_glu_chunk_causal_dwconv(dev, monkeypatch, T, B, C, K, chunk, fused):
     from speech2text_amd import zip_kernels as zk
     torch.manual_seed(0)
+    if fused:                                          # one kernel for both gradients (off by default)
+        monkeypatch.setenv("S2T_CONV_FUSED", "1")
     if B >= 6:
         monkeypatch.setenv("S2T_CONV_BLOCKS", "4")     # several utterances per workgroup
     conv = _Conv(C, K)
