@@ -23,7 +23,7 @@ for i in range(8):
 torch.cuda.synchronize()
 e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
 tf = tb = 0.0
-n = 10
+n = int(os.environ.get("FE_ITERS", "10"))
 for _ in range(n):
     e[0].record()
     y, _ = m(x, lens)
