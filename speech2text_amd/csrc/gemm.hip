@@ -176,12 +176,155 @@ constexpr int bk_of(int tm, int tn, int mode) {
   return BK0;   // (a 64-deep chunk for the 64x64 TN tile measured the same as 32)
 }
 
+// ---- TN on the bf16 matrix cores with the operands split ONCE, when they are staged (round 4).
+// The form below (X3) keeps fp32 tiles in LDS and splits every fragment in each of the two waves
+// that read it -- 8 strided ds_read_b32 + ~50 VALU instructions per fragment against 6 MFMAs per
+// 16-deep step of a 32 x 32 wave tile: the weight-gradient kernel spent more VALU cycles
+// splitting than the matrix pipe spent multiplying.  Here a staging thread owns ONE output column
+// and 8 consecutive contraction rows (8 coalesced 4-byte loads: a wave-instruction = 64
+// consecutive floats of one row), splits them once and writes the three 16-byte pieces straight
+// into the fragment-major image [32-output block][16-deep step][piece][lane][8 bf16]; the main loop
+// is {3 ds_read_b128 per fragment, 6 MFMAs}, no VALU.  Same tiles, chunks, barriers, slices and
+// atomics as the X3 form; the bias gradient (column sums of A) is taken from the staged registers.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+template <int TM, int TN, int PRO>
+__device__ __forceinline__ void tn_p3_body(const GemmArgs& g, const unsigned bid) {
+  constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32;
+  __shared__ __attribute__((aligned(16))) unsigned char sA[BM * BK * 6];
+  __shared__ __attribute__((aligned(16))) unsigned char sB[BN * BK * 6];
+  const int total = g.tiles_m * g.tiles_n;
+  const int q = (int)(bid >> 3);
+  const int zslice = (int)(bid & 7) + 8 * (q / total);
+  const int lin = q % total;
+  if (zslice >= g.splits) return;
+  const int tm = lin / g.tiles_n, tn = lin % g.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  if (g.sym_cg > 0) {
+    if (tn < tm || n0 / g.sym_cg > (m0 + BM - 1) / g.sym_cg) return;
+  }
+  const int csum_tn = g.sym_cg > 0 ? tm : 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
+  const int kbeg = zslice * g.kper;
+  const int kend = min(g.K, kbeg + g.kper);
+  if (kbeg >= kend) return;
+  const bool want_csum = g.colsum != nullptr && tn == csum_tn;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // staging: output so of each 64-column unit, contraction rows 8 kg .. 8 kg + 7 of the chunk
+  const int so = threadIdx.x & 63, kg = threadIdx.x >> 6;
+  const unsigned sdst = (unsigned)(((((so >> 5) * 2 + (kg >> 1)) * 3) * 64 + (kg & 1) * 32 + (so & 31)) * 16);
+  float ra[TM][8], rb[TN][8];
+  float csum[TM];
+#pragma unroll
+  for (int u = 0; u < TM; ++u) csum[u] = 0.f;
+#define TN3_LOAD(R, NU, SRC, LD, O0, ON, K0)                                                   \
+  _Pragma("unroll") for (int u = 0; u < NU; ++u) {                                             \
+    const int oc_ = min((O0) + 64 * u + so, (ON) - 1);                                         \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e)                                              \
+      R[u][e] = (SRC)[(long)min((K0) + 8 * kg + e, kend - 1) * (LD) + oc_];                    \
+  }
+  // registers of chunk K0 -> pieces in LDS (invalid rows / columns as zeros)
+#define TN3_STORE(R, NU, S, O0, ON, K0, ACT, CSUM)                                             \
+  _Pragma("unroll") for (int u = 0; u < NU; ++u) {                                             \
+    const bool ov_ = (O0) + 64 * u + so < (ON);                                                \
+    float v_[8];                                                                               \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                            \
+      float x_ = R[u][e];                                                                      \
+      if (ACT != ACT_NONE) x_ = swoosh(x_, ACT);                                               \
+      v_[e] = (ov_ && (K0) + 8 * kg + e < kend) ? x_ : 0.f;                                    \
+    }                                                                                          \
+    if (CSUM) csum[u] += ((v_[0] + v_[1]) + (v_[2] + v_[3])) + ((v_[4] + v_[5]) + (v_[6] + v_[7])); \
+    unsigned a0_, a1_, a2_, b0_, b1_, b2_, c0_, c1_, c2_, d0_, d1_, d2_;                       \
+    split_pair(v_[0], v_[1], a0_, a1_, a2_);                                                   \
+    split_pair(v_[2], v_[3], b0_, b1_, b2_);                                                   \
+    split_pair(v_[4], v_[5], c0_, c1_, c2_);                                                   \
+    split_pair(v_[6], v_[7], d0_, d1_, d2_);                                                   \
+    const u32x4_t q0_ = {a0_, b0_, c0_, d0_}, q1_ = {a1_, b1_, c1_, d1_}, q2_ = {a2_, b2_, c2_, d2_}; \
+    unsigned char* d_ = (S) + u * (2 * 2 * 3 * 1024) + sdst;                                   \
+    *reinterpret_cast<u32x4_t*>(d_) = q0_;                                                     \
+    *reinterpret_cast<u32x4_t*>(d_ + 1024) = q1_;                                              \
+    *reinterpret_cast<u32x4_t*>(d_ + 2048) = q2_;                                              \
+  }
+  TN3_LOAD(ra, TM, g.A, g.lda, m0, g.M, kbeg)
+  TN3_LOAD(rb, TN, g.B, g.ldb, n0, g.N, kbeg)
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    __syncthreads();                       // previous chunk fully consumed
+    if (want_csum) { TN3_STORE(ra, TM, sA, m0, g.M, k0, ACT_NONE, true) }
+    else { TN3_STORE(ra, TM, sA, m0, g.M, k0, ACT_NONE, false) }
+    TN3_STORE(rb, TN, sB, n0, g.N, k0, PRO, false)
+    __syncthreads();
+    if (k0 + BK < kend) {                  // next chunk's global loads fly under the MFMAs
+      TN3_LOAD(ra, TM, g.A, g.lda, m0, g.M, k0 + BK)
+      TN3_LOAD(rb, TN, g.B, g.ldb, n0, g.N, k0 + BK)
+    }
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      bf16x8 pa[TM][3], pb[TN][3];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          pa[i][p] = *reinterpret_cast<const bf16x8*>(sA + ((((wm >> 5) + i) * 2 + s) * 3 + p) * 1024 + lane * 16);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          pb[j][p] = *reinterpret_cast<const bf16x8*>(sB + ((((wn >> 5) + j) * 2 + s) * 3 + p) * 1024 + lane * 16);
+#define S2T_P3_TERM(PA, PB)                                                                     \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i][PA], pb[j][PB], acc[i][j], 0, 0, 0);
+      S2T_P3_TERM(2, 0) S2T_P3_TERM(1, 1) S2T_P3_TERM(0, 2) S2T_P3_TERM(1, 0) S2T_P3_TERM(0, 1)
+      S2T_P3_TERM(0, 0)
+#undef S2T_P3_TERM
+    }
+  }
+#undef TN3_LOAD
+#undef TN3_STORE
+  if (want_csum) {                         // the four row groups' partial sums -> one add per column
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(sA);
+#pragma unroll
+    for (int u = 0; u < TM; ++u) red[kg * BM + 64 * u + so] = csum[u];
+    __syncthreads();
+    if (threadIdx.x < BM && m0 + (int)threadIdx.x < g.M) {
+      const int t = threadIdx.x;
+      atomicAdd(g.colsum + m0 + t, ((red[t] + red[BM + t]) + (red[2 * BM + t] + red[3 * BM + t])) * g.alpha);
+    }
+  }
+  const int hi = lane >> 5, lo = lane & 31;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn + 32 * j + lo;
+      if (col >= g.N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (row >= g.M) continue;
+        atomicAdd(g.C + (long)row * g.ldc + col, acc[i][j][r] * g.alpha);
+      }
+    }
+}
+
 // X3 (TN only): the contraction runs on the bf16 matrix cores -- both operand fragments are split
 // exactly into three bf16 pieces when a wave reads them from LDS (8 k-strided reads per
 // fragment: the tiles are k-major) and every 16-deep step is six v_mfma_f32_32x32x16_bf16 products
 // (gemm_x3.hip: fp32-level error); 6 x 8 passes instead of 8 x 16 passes of the f32 MFMA.
-template <int TM, int TN, int MODE, int PRO, bool X3 = false, bool PATCH = false>
+template <int TM, int TN, int MODE, int PRO, bool X3 = false, bool PATCH = false, bool P3 = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, const unsigned bid) {
+  if constexpr (P3 && X3 && MODE == MODE_TN && !PATCH) {
+    tn_p3_body<TM, TN, PRO>(g, bid);
+    return;
+  }
   constexpr bool A_KC = MODE != MODE_TN, B_KC = MODE == MODE_NT;
   constexpr int BM = 64 * TM, BN = 64 * TN;
   constexpr int BK = bk_of(TM, TN, MODE);
@@ -387,9 +530,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const unsigned bid)
     }
 }
 
-template <int TM, int TN, int MODE, int PRO, bool X3 = false, bool PATCH = false>
+template <int TM, int TN, int MODE, int PRO, bool X3 = false, bool PATCH = false, bool P3 = false>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-  gemm_body<TM, TN, MODE, PRO, X3, PATCH>(g, blockIdx.x);
+  gemm_body<TM, TN, MODE, PRO, X3, PATCH, P3>(g, blockIdx.x);
 }
 
 // ---- grouped TN: the weight-gradient GEMMs of one layer in ONE launch.  Each problem keeps its
@@ -410,14 +553,14 @@ struct TnGroup {
   TnProb p[MAXG];
 };
 
-template <bool X3, int TNW = 1>
+template <bool X3, int TNW = 1, bool P3 = false>
 __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(TnGroup grp) {
   int i = 0;
   while (i + 1 < grp.n && blockIdx.x >= grp.begin[i + 1]) ++i;
   const TnProb& q = grp.p[i];
   GemmArgs g{q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, nullptr, nullptr, 0, nullptr, 0,
              0, 0, 0, q.colsum, 0, q.kper, q.tiles_m, q.tiles_n, q.splits, 0, q.alpha};
-  gemm_body<1, TNW, MODE_TN, ACT_NONE, X3>(g, blockIdx.x - grp.begin[i]);
+  gemm_body<1, TNW, MODE_TN, ACT_NONE, X3, false, P3>(g, blockIdx.x - grp.begin[i]);
 }
 
 // Weight-gradient contractions on the bf16 matrix cores (three-way exact split, six products:
@@ -435,6 +578,12 @@ extern "C" int s2t_nn_x3(int set) {
   if (set >= 0) g_nn_x3 = set ? 1 : 0;
   return nn_x3() ? 1 : 0;
 }
+// S2T_TN_P3=0: the form that splits every fragment where it is read (A/B, tests)
+static bool tn_p3() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("S2T_TN_P3"); v = e ? atoi(e) : 1; }
+  return v == 1;
+}
 static int g_tn_x3 = -1;
 static bool tn_x3() {
   if (g_tn_x3 < 0) { const char* e = getenv("S2T_TN_X3"); g_tn_x3 = e ? atoi(e) : 1; }
@@ -450,7 +599,9 @@ int launch(GemmArgs& g, int splits, hipStream_t st) {
   const int total = g.tiles_m * g.tiles_n;
   g.splits = splits;
   const int grid = MODE == MODE_TN ? 8 * total * ((splits + 7) / 8) : ((total + 7) / 8) * 8;
-  if (MODE == MODE_TN ? tn_x3() : nn_x3())
+  if (MODE == MODE_TN && tn_x3() && tn_p3())
+    hipLaunchKernelGGL((gemm_kernel<TM, TN, MODE, PRO, true, false, (MODE == MODE_TN)>), dim3(grid), dim3(256), 0, st, g);
+  else if (MODE == MODE_TN ? tn_x3() : nn_x3())
     hipLaunchKernelGGL((gemm_kernel<TM, TN, MODE, PRO, true>), dim3(grid), dim3(256), 0, st, g);
   else
     hipLaunchKernelGGL((gemm_kernel<TM, TN, MODE, PRO>), dim3(grid), dim3(256), 0, st, g);
@@ -691,7 +842,11 @@ extern "C" int s2t_gemm_tn_grouped(int n, const S2tTnProblem* probs, void* strea
       blocks += (unsigned)(8 * tiles * ((q.splits + 7) / 8));
     }
     grp.begin[grp.n] = blocks;
-    if (tn_x3() && tnw == 2)
+    if (tn_x3() && tn_p3() && tnw == 2)
+      hipLaunchKernelGGL((gemm_tn_grouped_kernel<true, 2, true>), dim3(blocks), dim3(256), 0, st, grp);
+    else if (tn_x3() && tn_p3())
+      hipLaunchKernelGGL((gemm_tn_grouped_kernel<true, 1, true>), dim3(blocks), dim3(256), 0, st, grp);
+    else if (tn_x3() && tnw == 2)
       hipLaunchKernelGGL((gemm_tn_grouped_kernel<true, 2>), dim3(blocks), dim3(256), 0, st, grp);
     else if (tn_x3())
       hipLaunchKernelGGL((gemm_tn_grouped_kernel<true, 1>), dim3(blocks), dim3(256), 0, st, grp);
