@@ -116,14 +116,18 @@ int s2t_balancer_bwd(const float* x, long ldx, const float* g, long ldg, long ro
  * 1 = padded frame (may be NULL); wc (C,(K+1)/2), bc (C): causal taps (NULL for a plain
  * depthwise conv); wk (C,K), bk (C): chunkwise/plain taps; scale (2,C,K) edge scales or NULL;
  * chunk = chunk size in frames (>= T: one chunk).  y (T,B,C).  Backward: du (T,B,2C) (or
- * (T,B,C) without gate) is written; the parameter gradients are ACCUMULATED (zero them). */
+ * (T,B,C) without gate) is written; the parameter gradients are ACCUMULATED (zero them).
+ * wstream (may be NULL = stream): the stream of the PARAMETER-gradient kernels -- they are not on
+ * the data-gradient chain; the caller orders wstream after the producers of u / dy and keeps
+ * u, dy, workspace alive until it has joined wstream. */
 int s2t_zipconv_fwd(const float* u, long ld, int gate_off, const unsigned char* mask, int T, int B,
                     int C, int K, int chunk, const float* wc, const float* bc, const float* wk,
                     const float* bk, const float* scale, float* y, void* stream);
 int s2t_zipconv_bwd(const float* u, long ld, int gate_off, const unsigned char* mask, int T, int B,
                     int C, int K, int chunk, const float* wc, const float* wk, const float* bk,
                     const float* scale, const float* dy, float* du, float* dwc, float* dbc,
-                    float* dwk, float* dbk, float* dscale, float* workspace, void* stream);
+                    float* dwk, float* dbk, float* dscale, float* workspace, void* stream,
+                    void* wstream);
 long s2t_zipconv_bwd_workspace_floats(int T, int B, int C, int K);
 
 

@@ -1014,9 +1014,11 @@ extern "C" int s2t_zipconv_bwd(const float* u, long ld, int gate_off, const unsi
                                int T, int B, int C, int K, int chunk, const float* wc,
                                const float* wk, const float* bk, const float* scale,
                                const float* dy, float* du, float* dwc, float* dbc, float* dwk,
-                               float* dbk, float* dscale, float* workspace, void* stream) {
+                               float* dbk, float* dscale, float* workspace, void* stream,
+                               void* wstream) {
   if (!conv_args_ok(T, B, C, K, chunk)) return -1;
   hipStream_t st = (hipStream_t)stream;
+  hipStream_t wst = wstream ? (hipStream_t)wstream : st;   // parameter-gradient kernels
   ConvArgs a{u, ld, gate_off, mask, T, B, C, chunk, wc, nullptr, wk, bk, scale, 0, 1 << 30, 0, 0};
   const bool gen = chunk < T;
   const ZSplit z(T, K, gen, scale != nullptr);
@@ -1085,7 +1087,7 @@ extern "C" int s2t_zipconv_bwd(const float* u, long ld, int gate_off, const unsi
   if (z.n_int() > 0) {
     z.set_int(a);
     S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_w_kernel<KK, false, false>), dim3(gx, gy, z.n_int()),
-                                            dim3(256), conv_smem<KK>(true, 1, false), st, a, dy, BB,
+                                            dim3(256), conv_smem<KK>(true, 1, false), wst, a, dy, BB,
                                             workspace, dsc));
     S2T_CHECK_LAUNCH();
   }
@@ -1094,15 +1096,15 @@ extern "C" int s2t_zipconv_bwd(const float* u, long ld, int gate_off, const unsi
     const dim3 gridw(gx, gy, z.n_edge());
     if (!gen) {
       S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_w_kernel<KK, false, true>), gridw, dim3(256),
-                                              conv_smem<KK>(true, 1, true), st, a, dy, BB, workspace, dsc));
+                                              conv_smem<KK>(true, 1, true), wst, a, dy, BB, workspace, dsc));
     } else {
       S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_w_kernel<KK, true, true>), gridw, dim3(256),
-                                              conv_smem<KK>(true, 1, true), st, a, dy, BB, workspace, dsc));
+                                              conv_smem<KK>(true, 1, true), wst, a, dy, BB, workspace, dsc));
     }
     S2T_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL(zipconv_reduce_w_kernel, dim3(gx, (K + 1) / 2 + K + 2), dim3(256), 0,
-                     st, workspace, (int)(z.nt * gy), C, (K + 1) / 2, K, wc ? dwc : nullptr,
+                     wst, workspace, (int)(z.nt * gy), C, (K + 1) / 2, K, wc ? dwc : nullptr,
                      wc ? dbc : nullptr, dwk, dbk);
   S2T_CHECK_LAUNCH();
   return 0;

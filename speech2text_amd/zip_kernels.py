@@ -418,6 +418,9 @@ def zipconv_forward(u, gate_off, m8, chunk, K, wc, bc, wk, bk, scale):
     return y
 
 
+_CONV_W_SIDE = os.environ.get("S2T_CONV_W_SIDE", "1") == "1"
+
+
 def zipconv_backward(u, gate_off, m8, chunk, K, wc, wk, bk, scale, dy, grads):
     """-> du (T,B,2C | C).  grads = (dwc, dbc, dwk, dbk, dscale) tensors the kernels ACCUMULATE the
     parameter gradients into (None where the parameter is absent)."""
@@ -428,6 +431,9 @@ def zipconv_backward(u, gate_off, m8, chunk, K, wc, wk, bk, scale, dy, grads):
     ws = torch.empty(N.lib().s2t_zipconv_bwd_workspace_floats(T, B, C, K), dtype=torch.float32,
                      device=dev)
     dwc, dbc, dwk, dbk, dsc = grads
+    # the tap / bias / edge-scale gradients only feed the optimizer: side stream, as the weight-
+    # gradient GEMMs (operands kept alive until the join)
+    wst = _side_launch_stream(u, dy, ws, m8, wc, wk, bk, scale) if _CONV_W_SIDE else None
     N.PROF[0] and N.profile_note("s2t_zipconv_bwd", 4.0 * (2 * u.numel() + 2 * dy.numel()))
     N.check(N.lib().s2t_zipconv_bwd(N.fp(u), ld, gate_off, N.ptr(m8), T, B, C, K, chunk,
                                     N.fp(wc), N.fp(wk), N.fp(bk), N.fp(scale), N.fp(dy),
@@ -435,7 +441,7 @@ def zipconv_backward(u, gate_off, m8, chunk, K, wc, wk, bk, scale, dy, grads):
                                     N.raw(dbc) if dbc is not None else None, N.raw(dwk),
                                     N.raw(dbk) if dbk is not None else None,
                                     N.raw(dsc) if dsc is not None else None, N.fp(ws),
-                                    N.stream()), "s2t_zipconv_bwd")
+                                    N.stream(), wst), "s2t_zipconv_bwd")
     return du
 
 
@@ -1029,6 +1035,41 @@ def _side_launch_stream(*tensors):
     return _Side.handle
 
 
+_EXT = {}
+_WGRAD_SIDE = os.environ.get("S2T_WGRAD_SIDE_MORE", "1") == "1"
+
+
+def side_param_grads(params, compute, keep=()):
+    """Parameter gradients that only feed the optimizer, off the data-gradient chain: when every
+    parameter of `params` (None entries allowed) is a leaf whose `.grad` is a flat-store view and a
+    backward pass is running, `compute()` -- the launches that produce the gradients, in the
+    parameters' shapes -- runs with the library's SIDE stream as torch's current stream (ordered
+    after the work enqueued so far), its results are added into the `.grad` views there, and a
+    list of None is returned for autograd; operands in `keep` stay referenced until the join.
+    Otherwise `compute()` runs on the current stream and its tensors are returned."""
+    ok = _WGRAD_SIDE and _Side.enabled
+    if ok:
+        for q in params:
+            if q is None:
+                continue
+            if not (q.is_leaf and flat.owned(q) and q.grad is not None and q.grad.is_contiguous()):
+                ok = False
+                break
+    h = _side_launch_stream(*keep) if ok else None
+    if h is None:
+        return compute()
+    ext = _EXT.get(h.value)
+    if ext is None:
+        ext = _EXT[h.value] = torch.cuda.ExternalStream(h.value)
+    with torch.cuda.stream(ext):
+        grads = compute()
+        for q, gq in zip(params, grads):
+            if q is not None and gq is not None:
+                q.grad.add_(gq.reshape(q.grad.shape) if gq.shape != q.grad.shape else gq)
+    _Side.keep.append(tuple(grads))
+    return [None] * len(grads)
+
+
 def gemm_tn(g2, a2, out, colsum=None, pro=0, stream=None):
     """out (N,M) += g2^T act(a2); colsum (N) += column sums of g2.   HIP: gemm.hip mode TN."""
     R, Nf = g2.shape
@@ -1063,8 +1104,12 @@ def wgrad_into(wparam, bparam, g2, a2, pro=0, notify=False):
         if bg is None or not bg.is_contiguous():
             return False
     # (main stream: forking to the side stream per Linear costs the host more than the overlap
-    # gives back -- measured on the conformer step; the grouped per-layer launch below does fork)
-    gemm_tn(g2, a2, wg, bg, pro)
+    # gives back -- measured on the conformer step; the grouped per-layer launch below does fork,
+    # and so do the few products big enough to matter: the frontend's 600 k-row maps)
+    st = None
+    if _WGRAD_SIDE and 2.0 * g2.shape[0] * g2.shape[1] * a2.shape[1] >= 2.0e10:
+        st = _side_launch_stream(g2, a2)
+    gemm_tn(g2, a2, wg, bg, pro, stream=st)
     if notify:
         flat.grad_written(wparam)
         if bparam is not None:
@@ -1518,6 +1563,7 @@ class _Conv3x3Nhwc(torch.autograd.Function):
             y = lt_matmul(0, cols, w2, bias)
             ctx.save_for_backward(cols, weight)
         ctx.cfg = (B, H, W, C, Ho, Wo, sh, sw, bias is not None)
+        ctx.params = (weight, bias)
         return y.view(B, Ho, Wo, Cout)
 
     @staticmethod
@@ -1528,7 +1574,8 @@ class _Conv3x3Nhwc(torch.autograd.Function):
         g = dy.reshape(B * Ho * Wo, Cout)
         g = g if g.is_contiguous() else g.contiguous()
         if ctx.implicit:
-            dweight, db = _conv3x3_wgrad_implicit(xc, g, sh, sw, has_bias)
+            dweight, db = side_param_grads(
+                ctx.params, lambda: list(_conv3x3_wgrad_implicit(xc, g, sh, sw, has_bias)), keep=(xc, g))
         else:
             dwmat, db = linear_wgrad(g, xc, has_bias)                            # (Cout, 9C)
             dweight = dwmat.view(Cout, 3, 3, C).permute(0, 3, 1, 2)
@@ -1669,6 +1716,21 @@ def conv3x3_nhwc(x, weight, bias, stride=(1, 1), pad_w=0, grad_scale=None):
     return _Conv3x3Nhwc.apply(x, weight, bias, int(stride[0]), int(stride[1]))
 
 
+def _dwconv_wgrad(x, dy, w, has_bias, wshape):
+    """[dW (weight's shape), db | None] of the depthwise conv (zip_front.hip), on the current stream."""
+    Nn, H, W, C = x.shape
+    KH, KW = w.shape[1], w.shape[2]
+    L = N.lib()
+    ws = torch.empty(L.s2t_dwconv2d_wgrad_workspace_floats(Nn, H, C, KH, KW), dtype=torch.float32,
+                     device=x.device)
+    dw = torch.empty_like(w)
+    db = torch.empty(C, dtype=torch.float32, device=x.device) if has_bias else None
+    N.PROF[0] and N.profile_note("s2t_dwconv2d_nhwc_wgrad", 8.0 * x.numel())
+    N.check(L.s2t_dwconv2d_nhwc_wgrad(N.fp(x), N.fp(dy), Nn, H, W, C, KH, KW, N.fp(ws), N.fp(dw),
+                                      N.fp(db), N.stream()), "s2t_dwconv2d_nhwc_wgrad")
+    return [dw.view(wshape), db]
+
+
 class _DwConv2dNhwc(torch.autograd.Function):
     """Depthwise 'same' conv on (N,H,W,C); HIP: zip_front.hip."""
 
@@ -1686,6 +1748,7 @@ class _DwConv2dNhwc(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         ctx.wshape = weight.shape
+        ctx.params = (weight, bias)
         return y
 
     @staticmethod
@@ -1701,14 +1764,9 @@ class _DwConv2dNhwc(torch.autograd.Function):
             N.PROF[0] and N.profile_note("s2t_dwconv2d_nhwc_fwd", 8.0 * dy.numel())
             N.check(L.s2t_dwconv2d_nhwc_fwd(N.fp(dy), N.fp(w), None, Nn, H, W, C, KH, KW, 1,
                                             N.fp(dx), N.stream()), "s2t_dwconv2d_nhwc_bwd_data")
-        ws = torch.empty(L.s2t_dwconv2d_wgrad_workspace_floats(Nn, H, C, KH, KW),
-                         dtype=torch.float32, device=x.device)
-        dw = torch.empty_like(w)
-        db = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_bias else None
-        N.PROF[0] and N.profile_note("s2t_dwconv2d_nhwc_wgrad", 8.0 * x.numel())
-        N.check(L.s2t_dwconv2d_nhwc_wgrad(N.fp(x), N.fp(dy), Nn, H, W, C, KH, KW, N.fp(ws),
-                                          N.fp(dw), N.fp(db), N.stream()), "s2t_dwconv2d_nhwc_wgrad")
-        return dx, dw.view(ctx.wshape), db
+        dw, db = side_param_grads(ctx.params, lambda: _dwconv_wgrad(x, dy, w, ctx.has_bias, ctx.wshape),
+                                  keep=(x, dy))
+        return dx, dw, db
 
 
 def dwconv2d_nhwc(x, weight, bias):
@@ -1744,14 +1802,9 @@ class _DwConv2dTap(torch.autograd.Function):
             N.PROF[0] and N.profile_note("s2t_dwconv2d_nhwc_fwd_add", 12.0 * dy.numel())
             N.check(L.s2t_dwconv2d_nhwc_fwd_add(N.fp(dy), N.fp(w), None, N.fp(gp), Nn, H, W, C, KH, KW,
                                                 1, N.fp(dx), N.stream()), "s2t_dwconv2d_nhwc_bwd_data")
-        ws = torch.empty(L.s2t_dwconv2d_wgrad_workspace_floats(Nn, H, C, KH, KW),
-                         dtype=torch.float32, device=x.device)
-        dw = torch.empty_like(w)
-        db = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_bias else None
-        N.PROF[0] and N.profile_note("s2t_dwconv2d_nhwc_wgrad", 8.0 * x.numel())
-        N.check(L.s2t_dwconv2d_nhwc_wgrad(N.fp(x), N.fp(dy), Nn, H, W, C, KH, KW, N.fp(ws),
-                                          N.fp(dw), N.fp(db), N.stream()), "s2t_dwconv2d_nhwc_wgrad")
-        return dx, dw.view(ctx.wshape), db
+        dw, db = side_param_grads(ctx.params, lambda: _dwconv_wgrad(x, dy, w, ctx.has_bias, ctx.wshape),
+                                  keep=(x, dy))
+        return dx, dw, db
 
 
 def dwconv2d_nhwc_tap(x, weight, bias):
