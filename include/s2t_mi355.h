@@ -108,6 +108,14 @@ int s2t_balancer_bwd(const float* x, long ldx, const float* g, long ldg, long ro
                      float min_mean, float max_mean, float min_rms, float max_rms,
                      float grad_scale, float* out, long ldo, float* workspace, int parity,
                      float act_off, void* stream);
+/* the two passes of s2t_balancer_bwd as separate calls: the column statistics (stats: 2 * 1024
+ * floats, zeroed by the caller) may be taken where x is produced -- forward pass, side stream --
+ * and only the update runs on the data-gradient chain */
+int s2t_balancer_stats(const float* x, long ldx, long rows, int C, float* stats, void* stream);
+int s2t_balancer_apply(const float* x, long ldx, const float* g, long ldg, long rows, int C,
+                       float min_mean, float max_mean, float min_rms, float max_rms,
+                       float grad_scale, float* out, long ldo, const float* stats, float act_off,
+                       void* stream);
 
 
 /* ---- zipformer convolution module core (model/encoder/zipformer.py:2672-2690 +
@@ -116,18 +124,26 @@ int s2t_balancer_bwd(const float* x, long ldx, const float* g, long ldg, long ro
  * 1 = padded frame (may be NULL); wc (C,(K+1)/2), bc (C): causal taps (NULL for a plain
  * depthwise conv); wk (C,K), bk (C): chunkwise/plain taps; scale (2,C,K) edge scales or NULL;
  * chunk = chunk size in frames (>= T: one chunk).  y (T,B,C).  Backward: du (T,B,2C) (or
- * (T,B,C) without gate) is written; the parameter gradients are ACCUMULATED (zero them).
- * wstream (may be NULL = stream): the stream of the PARAMETER-gradient kernels -- they are not on
- * the data-gradient chain; the caller orders wstream after the producers of u / dy and keeps
- * u, dy, workspace alive until it has joined wstream. */
+ * (T,B,C) without gate) is written; the parameter gradients are ACCUMULATED (zero them). */
 int s2t_zipconv_fwd(const float* u, long ld, int gate_off, const unsigned char* mask, int T, int B,
                     int C, int K, int chunk, const float* wc, const float* bc, const float* wk,
                     const float* bk, const float* scale, float* y, void* stream);
 int s2t_zipconv_bwd(const float* u, long ld, int gate_off, const unsigned char* mask, int T, int B,
                     int C, int K, int chunk, const float* wc, const float* wk, const float* bk,
                     const float* scale, const float* dy, float* du, float* dwc, float* dbc,
-                    float* dwk, float* dbk, float* dscale, float* workspace, void* stream,
-                    void* wstream);
+                    float* dwk, float* dbk, float* dscale, float* workspace, void* stream);
+/* the two halves of s2t_zipconv_bwd as separate calls: the parameter gradients only feed the
+ * optimizer, so a caller may run them on another stream (ordered after the producers of u / dy;
+ * u, dy and workspace alive until that stream is joined) while du stays on the chain */
+int s2t_zipconv_bwd_data(const float* u, long ld, int gate_off, const unsigned char* mask, int T,
+                         int B, int C, int K, int chunk, const float* wc, const float* wk,
+                         const float* bk, const float* scale, const float* dy, float* du,
+                         void* stream);
+int s2t_zipconv_bwd_params(const float* u, long ld, int gate_off, const unsigned char* mask, int T,
+                           int B, int C, int K, int chunk, const float* wc, const float* wk,
+                           const float* bk, const float* scale, const float* dy, float* dwc,
+                           float* dbc, float* dwk, float* dbk, float* dscale, float* workspace,
+                           void* stream);
 long s2t_zipconv_bwd_workspace_floats(int T, int B, int C, int K);
 
 

@@ -1010,15 +1010,81 @@ extern "C" long s2t_zipconv_bwd_workspace_floats(int T, int B, int C, int K) {
   return tiles * B * 64 * ((K + 1) / 2 + K + 2);
 }
 
+// the data-gradient kernels of a backward call on stream st
+static int zipconv_bwd_launch_data(ConvArgs a, int T, int B, int C, int K, bool gen, const ZSplit& z,
+                                   const float* dy, float* du, hipStream_t st) {
+  const unsigned gx = (C + 63) / 64;
+  if (z.n_int() > 0) {
+    z.set_int(a);
+    S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_data_kernel<KK, false, false>),
+                                            dim3(gx, B, z.n_int()), dim3(256),
+                                            conv_smem<KK>(false, 1, false), st, a, dy, du));
+    S2T_CHECK_LAUNCH();
+  }
+  if (z.n_edge() > 0) {
+    z.set_edge(a);
+    const dim3 grid(gx, B, z.n_edge());
+    if (!gen) {
+      S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_data_kernel<KK, false, true>), grid, dim3(256),
+                                              conv_smem<KK>(false, 1, true), st, a, dy, du));
+    } else {
+      S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_data_kernel<KK, true, true>), grid, dim3(256),
+                                              conv_smem<KK>(false, 1, true), st, a, dy, du));
+    }
+    S2T_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+// the parameter-gradient kernels (taps, biases, edge scales) + their reduction on stream st
+static int zipconv_bwd_launch_params(ConvArgs a, int T, int B, int C, int K, bool gen, const ZSplit& z,
+                                     const float* wc, const float* scale, const float* dy, float* dwc,
+                                     float* dbc, float* dwk, float* dbk, float* dscale,
+                                     float* workspace, hipStream_t st) {
+  const unsigned gx = (C + 63) / 64;
+  // utterances per block: many -- a workgroup's fixed costs (tap staging, the 49-slot reduction
+  // epilogue) are what this kernel's time is made of: at the C3 shapes 768 / 384 / 192 / 128
+  // workgroups take 92 / 66 / 56 / 62 us (K = 31) and 46 / 46 / 33 / 27 us (K = 15)
+  const long tiles = (long)gx * z.nt;
+  const char* env = getenv("S2T_CONV_BLOCKS");         // tuning / tests: workgroup-count target
+  int BB = (int)((tiles * B) / (env ? std::max(1, atoi(env)) : (K >= 31 ? 192 : 128)));
+  if (BB < 1) BB = 1;
+  if (BB > 16) BB = 16;
+  const unsigned gy = (B + BB - 1) / BB;             // utterance groups
+  float* const dsc = (scale && dscale) ? dscale : nullptr;
+  if (z.n_int() > 0) {
+    z.set_int(a);
+    S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_w_kernel<KK, false, false>), dim3(gx, gy, z.n_int()),
+                                            dim3(256), conv_smem<KK>(true, 1, false), st, a, dy, BB,
+                                            workspace, dsc));
+    S2T_CHECK_LAUNCH();
+  }
+  if (z.n_edge() > 0) {
+    z.set_edge(a);
+    const dim3 gridw(gx, gy, z.n_edge());
+    if (!gen) {
+      S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_w_kernel<KK, false, true>), gridw, dim3(256),
+                                              conv_smem<KK>(true, 1, true), st, a, dy, BB, workspace, dsc));
+    } else {
+      S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_w_kernel<KK, true, true>), gridw, dim3(256),
+                                              conv_smem<KK>(true, 1, true), st, a, dy, BB, workspace, dsc));
+    }
+    S2T_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(zipconv_reduce_w_kernel, dim3(gx, (K + 1) / 2 + K + 2), dim3(256), 0,
+                     st, workspace, (int)(z.nt * gy), C, (K + 1) / 2, K, wc ? dwc : nullptr,
+                     wc ? dbc : nullptr, dwk, dbk);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int s2t_zipconv_bwd(const float* u, long ld, int gate_off, const unsigned char* mask,
                                int T, int B, int C, int K, int chunk, const float* wc,
                                const float* wk, const float* bk, const float* scale,
                                const float* dy, float* du, float* dwc, float* dbc, float* dwk,
-                               float* dbk, float* dscale, float* workspace, void* stream,
-                               void* wstream) {
+                               float* dbk, float* dscale, float* workspace, void* stream) {
   if (!conv_args_ok(T, B, C, K, chunk)) return -1;
   hipStream_t st = (hipStream_t)stream;
-  hipStream_t wst = wstream ? (hipStream_t)wstream : st;   // parameter-gradient kernels
   ConvArgs a{u, ld, gate_off, mask, T, B, C, chunk, wc, nullptr, wk, bk, scale, 0, 1 << 30, 0, 0};
   const bool gen = chunk < T;
   const ZSplit z(T, K, gen, scale != nullptr);
@@ -1055,57 +1121,36 @@ extern "C" int s2t_zipconv_bwd(const float* u, long ld, int gate_off, const unsi
     S2T_CHECK_LAUNCH();
     return 0;
   }
-  if (z.n_int() > 0) {
-    z.set_int(a);
-    S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_data_kernel<KK, false, false>),
-                                            dim3(gx, B, z.n_int()), dim3(256),
-                                            conv_smem<KK>(false, 1, false), st, a, dy, du));
-    S2T_CHECK_LAUNCH();
-  }
-  if (z.n_edge() > 0) {
-    z.set_edge(a);
-    const dim3 grid(gx, B, z.n_edge());
-    if (!gen) {
-      S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_data_kernel<KK, false, true>), grid, dim3(256),
-                                              conv_smem<KK>(false, 1, true), st, a, dy, du));
-    } else {
-      S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_data_kernel<KK, true, true>), grid, dim3(256),
-                                              conv_smem<KK>(false, 1, true), st, a, dy, du));
-    }
-    S2T_CHECK_LAUNCH();
-  }
-  // utterances per block: many -- a workgroup's fixed costs (tap staging, the 49-slot reduction
-  // epilogue) are what this kernel's time is made of: at the C3 shapes 768 / 384 / 192 / 128
-  // workgroups take 92 / 66 / 56 / 62 us (K = 31) and 46 / 46 / 33 / 27 us (K = 15)
-  const long tiles = (long)gx * z.nt;
-  const char* env = getenv("S2T_CONV_BLOCKS");         // tuning / tests: workgroup-count target
-  int BB = (int)((tiles * B) / (env ? std::max(1, atoi(env)) : (K >= 31 ? 192 : 128)));
-  if (BB < 1) BB = 1;
-  if (BB > 16) BB = 16;
-  const unsigned gy = (B + BB - 1) / BB;             // utterance groups
-  float* const dsc = (scale && dscale) ? dscale : nullptr;
-  if (z.n_int() > 0) {
-    z.set_int(a);
-    S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_w_kernel<KK, false, false>), dim3(gx, gy, z.n_int()),
-                                            dim3(256), conv_smem<KK>(true, 1, false), wst, a, dy, BB,
-                                            workspace, dsc));
-    S2T_CHECK_LAUNCH();
-  }
-  if (z.n_edge() > 0) {
-    z.set_edge(a);
-    const dim3 gridw(gx, gy, z.n_edge());
-    if (!gen) {
-      S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_w_kernel<KK, false, true>), gridw, dim3(256),
-                                              conv_smem<KK>(true, 1, true), wst, a, dy, BB, workspace, dsc));
-    } else {
-      S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_w_kernel<KK, true, true>), gridw, dim3(256),
-                                              conv_smem<KK>(true, 1, true), wst, a, dy, BB, workspace, dsc));
-    }
-    S2T_CHECK_LAUNCH();
-  }
-  hipLaunchKernelGGL(zipconv_reduce_w_kernel, dim3(gx, (K + 1) / 2 + K + 2), dim3(256), 0,
-                     wst, workspace, (int)(z.nt * gy), C, (K + 1) / 2, K, wc ? dwc : nullptr,
-                     wc ? dbc : nullptr, dwk, dbk);
-  S2T_CHECK_LAUNCH();
-  return 0;
+  int rc = zipconv_bwd_launch_data(a, T, B, C, K, gen, z, dy, du, st);
+  if (rc != 0) return rc;
+  return zipconv_bwd_launch_params(a, T, B, C, K, gen, z, wc, scale, dy, dwc, dbc, dwk, dbk, dscale,
+                                   workspace, st);
+}
+
+// The two halves as separate calls: the parameter gradients only feed the optimizer, so a caller
+// may run them on another stream (ordered after the producers of u / dy; u, dy and workspace
+// alive until that stream is joined) while the data gradient stays on the chain.
+extern "C" int s2t_zipconv_bwd_data(const float* u, long ld, int gate_off, const unsigned char* mask,
+                                    int T, int B, int C, int K, int chunk, const float* wc,
+                                    const float* wk, const float* bk, const float* scale,
+                                    const float* dy, float* du, void* stream) {
+  if (!conv_args_ok(T, B, C, K, chunk)) return -1;
+  ConvArgs a{u, ld, gate_off, mask, T, B, C, chunk, wc, nullptr, wk, bk, scale, 0, 1 << 30, 0, 0};
+  const bool gen = chunk < T;
+  const ZSplit z(T, K, gen, scale != nullptr);
+  return zipconv_bwd_launch_data(a, T, B, C, K, gen, z, dy, du, (hipStream_t)stream);
+}
+
+extern "C" int s2t_zipconv_bwd_params(const float* u, long ld, int gate_off,
+                                      const unsigned char* mask, int T, int B, int C, int K,
+                                      int chunk, const float* wc, const float* wk, const float* bk,
+                                      const float* scale, const float* dy, float* dwc, float* dbc,
+                                      float* dwk, float* dbk, float* dscale, float* workspace,
+                                      void* stream) {
+  if (!conv_args_ok(T, B, C, K, chunk)) return -1;
+  ConvArgs a{u, ld, gate_off, mask, T, B, C, chunk, wc, nullptr, wk, bk, scale, 0, 1 << 30, 0, 0};
+  const bool gen = chunk < T;
+  const ZSplit z(T, K, gen, scale != nullptr);
+  return zipconv_bwd_launch_params(a, T, B, C, K, gen, z, wc, scale, dy, dwc, dbc, dwk, dbk, dscale,
+                                   workspace, (hipStream_t)stream);
 }

@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void balancer_apply_fused_kernel(
     s_a[c] = a * coef;
     s_b[c] = b * coef;
   }
-  if (blockIdx.x == 0)          // the whole accumulator: the previous user may have had more channels
+  if (blockIdx.x == 0 && stats_next != nullptr)   // the whole accumulator: the previous user may have had more channels
     for (int c = threadIdx.x; c < 2 * 1024; c += 256) stats_next[c] = 0.f;
   __syncthreads();
   // thread = (column within a 64-wide group, row lane): no per-element division, four rows of
@@ -386,3 +386,33 @@ extern "C" int s2t_balancer_bwd(const float* x, long ldx, const float* g, long l
   return 0;
 }
 
+// The same two passes as separate entry points: the statistics depend on x only, so the caller
+// may take them when x is PRODUCED (forward pass, side stream) and run only the update on the
+// data-gradient chain.  stats: 2 * 1024 floats (sum | sum of squares), zeroed by the caller.
+extern "C" int s2t_balancer_stats(const float* x, long ldx, long rows, int C, float* stats,
+                                  void* stream) {
+  if (rows <= 0 || C <= 0) return 0;
+  if (C > BAL_MAXC || !stats) return -1;
+  int gy = (C + 63) / 64;
+  if (gy > 16) gy = 16;
+  long gx = (rows + 4 * 16 - 1) / (4 * 16);
+  gx = gx > 256 ? 256 : (gx < 1 ? 1 : gx);
+  hipLaunchKernelGGL(col_stats_kernel, dim3((unsigned)gx, gy), dim3(64, 4), 0, (hipStream_t)stream, x,
+                     rows, C, ldx, stats, stats + BAL_MAXC);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int s2t_balancer_apply(const float* x, long ldx, const float* g, long ldg, long rows,
+                                  int C, float min_mean, float max_mean, float min_rms,
+                                  float max_rms, float grad_scale, float* out, long ldo,
+                                  const float* stats, float act_off, void* stream) {
+  if (rows <= 0 || C <= 0) return 0;
+  if (C > BAL_MAXC || !stats) return -1;
+  hipLaunchKernelGGL(balancer_apply_fused_kernel, dim3((unsigned)std::min<long>((rows + 15) / 16, 2048)),
+                     dim3(256), 0, (hipStream_t)stream, x, ldx, g, ldg, stats, (float*)nullptr,
+                     (float)rows, min_mean, max_mean, min_rms, max_rms, grad_scale, rows, C, out, ldo,
+                     act_off);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}

@@ -172,8 +172,42 @@ def _balancer_workspace(dev):
     return ws
 
 
+# (off by default: three same-box A/B pairs at C3 gave 40.83 against 40.92 ms/step -- the side
+# stream is busy with the Whiten products in forward and the fill + event per call cost what the
+# moved pass saves)
+_BAL_FWD = os.environ.get("S2T_BAL_STATS_FWD", "0") == "1"
+
+
+class BalancerStats:
+    """Column statistics of x for a Balancer that fires this call, taken in FORWARD -- they depend
+    on x only -- on the library's side stream (as WhitenStats): the backward pass then runs only
+    the update on the data-gradient chain.  `make` returns None where the two-pass entry point has
+    to serve (layout, dtype, disabled)."""
+    __slots__ = ("stats", "event", "x2")
+
+    @staticmethod
+    def make(x):
+        if not (_BAL_FWD and x.is_cuda and x.dim() == 2 and x.dtype is torch.float32
+                and x.stride(1) == 1 and x.shape[1] <= 1024 and torch.is_grad_enabled()):
+            return None
+        side = _stats_stream()
+        if side is None:
+            return None
+        self = BalancerStats()
+        self.x2 = x
+        self.stats = torch.zeros(2048, dtype=torch.float32, device=x.device)
+        N.check(N.lib().s2t_stream_order(N.stream(), side), "s2t_stream_order(bal)")   # after the fill
+        N.PROF[0] and N.profile_note("s2t_balancer_stats", 4.0 * x.numel())
+        N.check(N.lib().s2t_balancer_stats(N.raw(x, torch.float32), x.stride(0), x.shape[0],
+                                           x.shape[1], N.fp(self.stats), side), "s2t_balancer_stats")
+        _Side.keep.append((x, self.stats))
+        self.event = torch.cuda.Event()
+        self.event.record(N._launch_stream((side,)))
+        return self
+
+
 def balancer_backward(x, g, min_mean, max_mean, min_rms, max_rms, grad_scale, channel_dim,
-                      inplace=False, swoosh_l=None):
+                      inplace=False, swoosh_l=None, stats=None):
     """Closed form of reference scaling.py:741-789: the autograd-inside-backward there reduces
     to per-channel statistics (mean, E[x^2]) and a per-element affine term
         g' = g + |g| * grad_scale * (a_c + b_c x) / rms_c(a + b x).
@@ -201,6 +235,18 @@ def balancer_backward(x, g, min_mean, max_mean, min_rms, max_rms, grad_scale, ch
         else:
             g2 = g.contiguous().reshape(-1, C)
             out = torch.empty_like(g2)
+        if stats is not None and stats.x2.shape == x2.shape and stats.x2.data_ptr() == x2.data_ptr():
+            # statistics taken in forward: only the update runs here, after their event
+            torch.cuda.current_stream().wait_event(stats.event)
+            N.PROF[0] and N.profile_note("s2t_balancer_apply", 4.0 * rows * C * 3)
+            N.check(N.lib().s2t_balancer_apply(N.raw(x2, torch.float32), x2.stride(0),
+                                               N.raw(g2, torch.float32), g2.stride(0), rows, C,
+                                               min_mean, max_mean, min_rms, max_rms, grad_scale,
+                                               N.raw(out, torch.float32), out.stride(0),
+                                               N.fp(stats.stats),
+                                               -1.0 if swoosh_l is None else _SW[swoosh_l][0],
+                                               N.stream()), "s2t_balancer_apply")
+            return out if out is g else out.reshape(g.shape)
         ws = _balancer_workspace(x.device)
         ws[1] ^= 1
         N.PROF[0] and N.profile_note("s2t_balancer_bwd", 4.0 * rows * C * 4)     # x twice (stats, update), g, out
@@ -434,14 +480,24 @@ def zipconv_backward(u, gate_off, m8, chunk, K, wc, wk, bk, scale, dy, grads):
     # the tap / bias / edge-scale gradients only feed the optimizer: side stream, as the weight-
     # gradient GEMMs (operands kept alive until the join)
     wst = _side_launch_stream(u, dy, ws, m8, wc, wk, bk, scale) if _CONV_W_SIDE else None
-    N.PROF[0] and N.profile_note("s2t_zipconv_bwd", 4.0 * (2 * u.numel() + 2 * dy.numel()))
-    N.check(N.lib().s2t_zipconv_bwd(N.fp(u), ld, gate_off, N.ptr(m8), T, B, C, K, chunk,
-                                    N.fp(wc), N.fp(wk), N.fp(bk), N.fp(scale), N.fp(dy),
-                                    N.fp(du), N.raw(dwc) if dwc is not None else None,
-                                    N.raw(dbc) if dbc is not None else None, N.raw(dwk),
-                                    N.raw(dbk) if dbk is not None else None,
-                                    N.raw(dsc) if dsc is not None else None, N.fp(ws),
-                                    N.stream(), wst), "s2t_zipconv_bwd")
+    L = N.lib()
+    gptr = (N.raw(dwc) if dwc is not None else None, N.raw(dbc) if dbc is not None else None,
+            N.raw(dwk), N.raw(dbk) if dbk is not None else None,
+            N.raw(dsc) if dsc is not None else None)
+    if wst is None or os.environ.get("S2T_CONV_FUSED"):
+        N.PROF[0] and N.profile_note("s2t_zipconv_bwd", 4.0 * (2 * u.numel() + 2 * dy.numel()))
+        N.check(L.s2t_zipconv_bwd(N.fp(u), ld, gate_off, N.ptr(m8), T, B, C, K, chunk, N.fp(wc),
+                                  N.fp(wk), N.fp(bk), N.fp(scale), N.fp(dy), N.fp(du), *gptr,
+                                  N.fp(ws), N.stream()), "s2t_zipconv_bwd")
+        return du
+    N.PROF[0] and N.profile_note("s2t_zipconv_bwd_data", 4.0 * (u.numel() + dy.numel() + du.numel()))
+    N.check(L.s2t_zipconv_bwd_data(N.fp(u), ld, gate_off, N.ptr(m8), T, B, C, K, chunk, N.fp(wc),
+                                   N.fp(wk), N.fp(bk), N.fp(scale), N.fp(dy), N.fp(du), N.stream()),
+            "s2t_zipconv_bwd_data")
+    N.PROF[0] and N.profile_note("s2t_zipconv_bwd_params", 4.0 * (u.numel() + dy.numel()))
+    N.check(L.s2t_zipconv_bwd_params(N.fp(u), ld, gate_off, N.ptr(m8), T, B, C, K, chunk, N.fp(wc),
+                                     N.fp(wk), N.fp(bk), N.fp(scale), N.fp(dy), *gptr, N.fp(ws), wst),
+            "s2t_zipconv_bwd_params")
     return du
 
 

@@ -184,8 +184,11 @@ def _whiten_bwd(mod, x, g, stats):
     return out
 
 
-def _balancer_bwd(mod, x, g, inplace=False, swoosh_l=None):
-    return zk.balancer_backward(x, g, *mod.cfg(2), inplace=inplace, swoosh_l=swoosh_l)
+def _balancer_bwd(mod, x, g, inplace=False, swoosh_l=None, stats=None):
+    return zk.balancer_backward(x, g, *mod.cfg(2), inplace=inplace, swoosh_l=swoosh_l, stats=stats)
+
+
+_bst = zk.BalancerStats.make
 
 
 class _Commit(ctypes.Structure):
@@ -234,7 +237,9 @@ def _ff_fwd(m, dec, x_in):
     # it leaves the in-projection's epilogue as a second output (no separate Swoosh pass)
     sv.h, a = zk.lt_matmul(0, x_in, m.in_proj.weight, m.in_proj.bias, act2="swoosh_l")
     sv.a = a
-    sv.y = sv.st = None
+    sv.y = sv.st = sv.bh = sv.by = None
+    if fb:
+        sv.bh = _bst(sv.h)
     if not (fw or fp):
         out = zk.lt_matmul(0, a, m.out_proj.weight, m.out_proj.bias, x_in)
     else:
@@ -243,6 +248,8 @@ def _ff_fwd(m, dec, x_in):
         sv.y, out = zk.lt_matmul(0, a, m.out_proj.weight, m.out_proj.bias, act2="add", resid_b=x_in)
         if fw:
             sv.st = zk.WhitenStats(sv.y, m.out_whiten.num_groups)
+        if fp:
+            sv.by = _bst(sv.y)
     return out, sv
 
 
@@ -250,13 +257,13 @@ def _ff_bwd(m, post, dec, sv, x_in, g):
     fb, fw, fp = dec
     gy = g
     if fp:
-        gy = _balancer_bwd(post, sv.y, gy)
+        gy = _balancer_bwd(post, sv.y, gy, stats=sv.by)
     if fw:
         gy = _whiten_bwd(m.out_whiten, sv.y, gy, sv.st)
     W = m.out_proj.weight
     _wgrad(W, m.out_proj.bias, gy, sv.a)
     if fb:                                   # Swoosh backward rides in the Balancer's update pass
-        dh = _balancer_bwd(m.hidden_balancer, sv.h, zk.lt_matmul(1, gy, W), swoosh_l=True)
+        dh = _balancer_bwd(m.hidden_balancer, sv.h, zk.lt_matmul(1, gy, W), swoosh_l=True, stats=sv.bh)
     else:                                    # ... or in the data-gradient GEMM's epilogue
         dh = zk.lt_matmul(1, gy, W, act_src=sv.h, act_kind="swoosh_l")
     _wgrad(m.in_proj.weight, m.in_proj.bias, dh, x_in)
@@ -304,6 +311,8 @@ def _conv_fwd(m, dec, x_in, T, B, chunk_size, k8):
     sv.cp = zk.conv_params(m.depthwise_conv, T, chunk_size)
     sv.y = zk.zipconv_forward(sv.u.view(T, B, 2 * D), D, k8, *sv.cp).view(T * B, D)
     sv.st = zk.WhitenStats(sv.y, m.whiten.num_groups) if fw else None
+    sv.b1 = _bst(sv.u[:, D:]) if fb1 else None
+    sv.b2 = _bst(sv.y) if fb2 else None
     sv.a = zk.swoosh_forward(sv.y, False)
     return zk.lt_matmul(0, sv.a, m.out_proj.weight, m.out_proj.bias, x_in), sv
 
@@ -314,13 +323,13 @@ def _conv_bwd(m, dec, sv, x_in, g, T, B, k8):
     W = m.out_proj.weight
     _wgrad(W, m.out_proj.bias, g, sv.a)
     if fb2 and not fw:                       # Swoosh backward rides in the Balancer's update pass
-        dy = _balancer_bwd(m.balancer2, sv.y, zk.lt_matmul(1, g, W), swoosh_l=False)
+        dy = _balancer_bwd(m.balancer2, sv.y, zk.lt_matmul(1, g, W), swoosh_l=False, stats=sv.b2)
     else:                                    # ... or in the data-gradient GEMM's epilogue
         dy = zk.lt_matmul(1, g, W, act_src=sv.y, act_kind="swoosh_r")
         if fw:
             dy = _whiten_bwd(m.whiten, sv.y, dy, sv.st)
         if fb2:
-            dy = _balancer_bwd(m.balancer2, sv.y, dy)
+            dy = _balancer_bwd(m.balancer2, sv.y, dy, stats=sv.b2)
     chunk, K, wc, bc, wk, bk, scale = sv.cp
     plist = (wc, bc, wk, bk, scale)
     grads = zk.direct_grads(plist)
@@ -332,7 +341,7 @@ def _conv_bwd(m, dec, sv, x_in, g, T, B, k8):
         if p is not None:
             flat.grad_written(p)
     if fb1:
-        _balancer_bwd(m.balancer1, sv.u[:, D:], du[:, D:], inplace=True)
+        _balancer_bwd(m.balancer1, sv.u[:, D:], du[:, D:], inplace=True, stats=sv.b1)
     _wgrad(m.in_proj.weight, m.in_proj.bias, du, x_in)
     return zk.lt_matmul(1, du, m.in_proj.weight, None, g)
 
@@ -354,13 +363,16 @@ def _na_fwd(m, dec, x_in, W, T, B):
     N.check(L.s2t_nonlin_out_fwd(N.fp(sv.z), N.fp(sv.u), T, B, C, N.fp(sv.o), st),
             "nonlin_out_fwd")
     sv.st1 = zk.WhitenStats(sv.u[:, C:2 * C], m.whiten1.num_groups) if fw1 else None
-    sv.y = sv.st2 = None
+    sv.bu = _bst(sv.u[:, :C]) if fb else None
+    sv.y = sv.st2 = sv.by = None
     if not (fw2 or fp):
         out = zk.lt_matmul(0, sv.o, m.out_proj.weight, m.out_proj.bias, x_in)
     else:
         sv.y, out = zk.lt_matmul(0, sv.o, m.out_proj.weight, m.out_proj.bias, act2="add", resid_b=x_in)
         if fw2:
             sv.st2 = zk.WhitenStats(sv.y, m.whiten2.num_groups)
+        if fp:
+            sv.by = _bst(sv.y)
     return out, sv
 
 
@@ -370,7 +382,7 @@ def _na_bwd(m, post, dec, sv, x_in, g, T, B):
     L, st = N.lib(), N.stream()
     gy = g
     if fp:
-        gy = _balancer_bwd(post, sv.y, gy)
+        gy = _balancer_bwd(post, sv.y, gy, stats=sv.by)
     if fw2:
         gy = _whiten_bwd(m.whiten2, sv.y, gy, sv.st2)
     _wgrad(m.out_proj.weight, m.out_proj.bias, gy, sv.o)
@@ -386,7 +398,7 @@ def _na_bwd(m, post, dec, sv, x_in, g, T, B):
     N.PROF[0] and N.profile_note("s2t_nonlin_gate_bwd", 20.0 * T * B * C)
     N.check(L.s2t_nonlin_gate_bwd(N.fp(dxs), N.fp(sv.u), T, B, C, N.fp(du), st), "nonlin_gate_bwd")
     if fb:
-        _balancer_bwd(m.balancer, sv.u[:, :C], du[:, :C], inplace=True)
+        _balancer_bwd(m.balancer, sv.u[:, :C], du[:, :C], inplace=True, stats=sv.bu)
     if fw1:
         du[:, C:2 * C] = _whiten_bwd(m.whiten1, sv.u[:, C:2 * C], du[:, C:2 * C].contiguous(),
                                      sv.st1)
@@ -436,6 +448,7 @@ class _LayerFn(torch.autograd.Function):
         s.kst = None
         if d.k_wh:
             s.kst = zk.WhitenStats(s.qkp[:, H * qd:2 * H * qd], sa.whiten_keys.num_groups)
+        s.kbst = _bst(s.qkp[:, H * qd:2 * H * qd]) if d.k_bal else None
         s.pos2 = s.posp = None
         if d.use_pos:
             s.pos2 = pos_emb.reshape(2 * T - 1, -1).contiguous().float()
@@ -473,6 +486,7 @@ class _LayerFn(torch.autograd.Function):
         x7, s.sa2 = _sa_fwd(layer.self_attn2, d.sa2, x6, W, T, B, H)
         x8, s.cv2 = _conv_fwd(layer.conv_module2, d.cv2, x7, T, B, chunk_size, k8)
         x9, s.ff3 = _ff_fwd(layer.feed_forward3, d.ff3, x8)
+        s.bst1 = _bst(x9) if d.bal1 else None
         norm = layer.norm
         x10 = _e(R, D, dev)
         s.nscales = torch.empty(R, dtype=_F32, device=dev)
@@ -492,6 +506,7 @@ class _LayerFn(torch.autograd.Function):
             N.check(L.s2t_bypass_fwd(N.fp(x0), N.fp(x10), N.fp(layer.bypass.bypass_scale), R, D,
                                      N.fp(x11), st), "s2t_bypass_fwd")
         s.wst = zk.WhitenStats(x11, layer.whiten.num_groups) if d.wh_out else None
+        s.bst2 = _bst(x11) if d.bal2 else None
         s.x = (x1, x2, x3, x4, x5, x6, x7, x8, x9, x10, x11)
         ctx.s, ctx.layer = s, layer
         out = x11.view(T, B, D)
@@ -519,7 +534,7 @@ class _LayerFn(torch.autograd.Function):
         if d.wh_out:
             g = _whiten_bwd(layer.whiten, x11, g, s.wst)
         if d.bal2:
-            g = _balancer_bwd(layer.balancer2, x11, g)
+            g = _balancer_bwd(layer.balancer2, x11, g, stats=s.bst2)
         # per-channel parameter gradients: [bypass scale | bypass_mid scale | norm bias | log_scale]
         acc = _layer_acc(dev, D)
         off = lambda n: ctypes.c_void_p(acc.data_ptr() + 4 * n)      # noqa: E731
@@ -542,7 +557,7 @@ class _LayerFn(torch.autograd.Function):
         N.check(L.s2t_biasnorm_bwd(N.fp(x9), N.fp(norm.bias), N.fp(s.nscales), N.fp(g10), R, D,
                                    N.fp(g9), off(2 * D), off(3 * D), st), "biasnorm_bwd")
         if d.bal1:
-            g9 = _balancer_bwd(layer.balancer1, x9, g9)
+            g9 = _balancer_bwd(layer.balancer1, x9, g9, stats=s.bst1)
 
         pairs = []
         g8 = _ff_bwd(layer.feed_forward3, layer.balancer_ff3, d.ff3, s.ff3, x8, g9)
@@ -595,7 +610,7 @@ class _LayerFn(torch.autograd.Function):
             if d.k_wh:
                 gk = _whiten_bwd(sa.whiten_keys, s.qkp[:, ks], gk, s.kst)
             if d.k_bal:
-                gk = _balancer_bwd(sa.balance_keys, s.qkp[:, ks], gk)
+                gk = _balancer_bwd(sa.balance_keys, s.qkp[:, ks], gk, stats=s.kbst)
             dqkp[:, ks] = gk
         if dpos is not None:
             _wgrad(sa.linear_pos.weight, None, dpos, s.pos2)

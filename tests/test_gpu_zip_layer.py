@@ -101,3 +101,24 @@ def test_executor_matches_module_path(dev, monkeypatch, force, big, chunk, left)
     assert served == 4 * (14 if big else 6)   # every layer call, penalty draws included
     if big:
         assert zip_layer.STATS["penalty_active"] > active0
+
+
+def test_executor_with_forward_balancer_statistics(dev, monkeypatch):
+    """zk.BalancerStats (column statistics taken in forward on the side stream, off by default:
+    measured no gain): same outputs and gradients as the two-pass form, every Balancer firing."""
+    from speech2text_amd import rng, zip_kernels as zk
+    monkeypatch.setattr(rng, "rand", lambda *s, device=None, dtype=torch.float32:
+                        torch.rand(*s, dtype=dtype).to(device))
+    m, store = _build(dev, (-1,), (-1,))
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(3, 150, 80, generator=g) * 2).to(dev)
+    lens = torch.tensor([150, 120, 77]).to(dev)
+    with torch.no_grad():
+        wts = torch.randn(m(x, lens)[0].shape, generator=g).to(dev)
+    outs = []
+    for on in (False, True):
+        monkeypatch.setattr(zk, "_BAL_FWD", on)
+        _force(m, True)
+        outs.append(_step(m, store, x, lens, wts, 1, True))
+    for a, b in zip(outs[0], outs[1]):
+        torch.testing.assert_close(a, b, atol=1e-6, rtol=1e-5)
