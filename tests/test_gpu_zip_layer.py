@@ -120,5 +120,9 @@ def test_executor_with_forward_balancer_statistics(dev, monkeypatch):
         monkeypatch.setattr(zk, "_BAL_FWD", on)
         _force(m, True)
         outs.append(_step(m, store, x, lens, wts, 1, True))
-    for a, b in zip(outs[0], outs[1]):
-        torch.testing.assert_close(a, b, atol=1e-6, rtol=1e-5)
+    # (two runs of ONE form already differ in the last bits: column statistics and weight
+    # gradients are summed with fp32 atomics)
+    torch.testing.assert_close(outs[0][0], outs[1][0], atol=2e-5, rtol=1e-4)
+    torch.testing.assert_close(outs[0][1], outs[1][1], atol=2e-5, rtol=2e-3)
+    scale = outs[0][2].abs().max()
+    assert (outs[0][2] - outs[1][2]).abs().max() / scale < 2e-4
