@@ -667,6 +667,14 @@ int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int 
                  int M, const float* bias, const float* resid, long ldr, const float* act_src,
                  long ld_act, int act_kind, float* C2, long ldc2, int act2, const float* resid_b,
                  long ldrb, int tile, void* stream);
+/* the same product that also ADDS the column sums / sums of squares of C (as stored) into
+ * colstats[0..N) / colstats[1024..1024+N): the statistics a Balancer on that tensor needs in
+ * backward (s2t_balancer_apply), taken where the tensor is produced.  colstats: 2048 floats, zeroed
+ * by the caller; N <= 1024. */
+int s2t_gemm_x3p_stats(const float* A, long lda, const unsigned short* Bp, int N, int K, float* C,
+                       long ldc, int M, const float* bias, const float* resid, long ldr,
+                       const float* act_src, long ld_act, int act_kind, float* C2, long ldc2, int act2,
+                       const float* resid_b, long ldrb, int tile, float* colstats, void* stream);
 
 /* ---- side stream for work off the critical path (csrc/streams.hip): the weight-gradient GEMMs
  * of backward overlap the data-gradient chain.  s2t_side_stream returns the library-owned stream;

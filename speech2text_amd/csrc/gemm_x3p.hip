@@ -115,6 +115,8 @@ struct X3P {
   unsigned long long* stamps; // diagnostics (s2t_x3p_debug_stamps): [block][8] s_memtime stamps, or NULL
   int drip;                   // 1: epilogue of tile t stored in slices under tile t+1 (x3p_db_kernel DRIP)
   int stagger;                // > 0: workgroup slot s of a CU starts its k loop s * stagger * 64 cycles late
+  float* colstats;            // [2][1024] or NULL: += column sums / sums of squares of C (the Balancer's
+                              // statistics of the tensor this product writes; N <= 1024)
 };
 
 // diagnostics: lane 0 of wave 0 records the shader clock at a phase boundary of its workgroup
@@ -283,6 +285,44 @@ __device__ __forceinline__ void x3p_epilogue(const X3P& g, f32x16 (&acc)[TM][TN]
 #pragma unroll
     for (int t = 0; t < 2 * TN; ++t)
       x3p_epi_store(g, rs, acc[i][t / 2], ops[t], i, t / 2, t & 1, m0, n0, wrb, wcb, lane);
+    if (g.colstats) {
+      // column statistics of C: this lane's column quad over its 4 rows of the row block (the
+      // final values sit in the accumulator registers in row-piece layout), summed over the 8
+      // lanes that share the quad, one atomic pair per column and wave
+      const int er = lane >> 3, ec = (lane & 7) * 4;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        float sm[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const bool rok = m0 + 32 * (wrb + i) + 16 * h + er + 8 * q < g.M;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const float v = rok ? acc[i][j][8 * h + 4 * q + c] : 0.f;
+              sm[c] += v;
+              sq[c] = fmaf(v, v, sq[c]);
+            }
+          }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+          for (int d = 8; d < 64; d <<= 1) {
+            sm[c] += __shfl_xor(sm[c], d);
+            sq[c] += __shfl_xor(sq[c], d);
+          }
+        }
+        const int col = n0 + 32 * (wcb + j) + ec;
+        if (er == 0 && col < g.N) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            atomicAdd(g.colstats + col + c, sm[c]);
+            atomicAdd(g.colstats + 1024 + col + c, sq[c]);
+          }
+        }
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);               // (the next row block's loads stay behind these stores)
   }
 }
@@ -1099,6 +1139,8 @@ int s2t_x3p_split(const float* base, const void* tab, int n, int total_blocks, u
   return 0;
 }
 
+static float* g_colstats = nullptr;      // armed by s2t_gemm_x3p_stats for the one launch it makes
+
 int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int K, float* C, long ldc,
                  int M, const float* bias, const float* resid, long ldr, const float* act_src,
                  long ld_act, int act_kind, float* C2, long ldc2, int act2, const float* resid_b,
@@ -1128,7 +1170,11 @@ int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int 
     return -2;
   if (act_src && resid && resid_b) return -2;        // two operand slots
   X3P g{A, lda, Bp, (N + 31) / 32, 2 * ((K + 31) / 32), C, ldc, M, N, K, bias, {nullptr, nullptr},
-        {0, 0}, {0, 0}, act_kind, C2, ldc2, act2, 0, 0, wgs, 0, g_stamps, drip, 0};
+        {0, 0}, {0, 0}, act_kind, C2, ldc2, act2, 0, 0, wgs, 0, g_stamps, drip, 0, nullptr};
+  if (g_colstats) {
+    if (N > 1024 || drip || tile == 33) return -2;
+    g.colstats = g_colstats;
+  }
   {
     int k = 0;
     if (act_src) { g.op[k] = act_src; g.ldop[k] = ld_act; g.role[k++] = 1; }
@@ -1192,6 +1238,22 @@ int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int 
   }
   S2T_CHECK_LAUNCH();
   return 0;
+}
+
+// s2t_gemm_x3p that also ADDS the column sums and sums of squares of C (as stored: after bias,
+// act', residuals) into colstats[0..N) and colstats[1024..1024+N) -- the statistics a Balancer on
+// that tensor needs in backward (zip_elem.hip s2t_balancer_apply), taken where the tensor is
+// produced instead of by a pass of their own.  colstats: 2048 floats, zeroed by the caller.
+int s2t_gemm_x3p_stats(const float* A, long lda, const unsigned short* Bp, int N, int K, float* C,
+                       long ldc, int M, const float* bias, const float* resid, long ldr,
+                       const float* act_src, long ld_act, int act_kind, float* C2, long ldc2, int act2,
+                       const float* resid_b, long ldrb, int tile, float* colstats, void* stream) {
+  if (!colstats) return -1;
+  g_colstats = colstats;
+  const int rc = s2t_gemm_x3p(A, lda, Bp, N, K, C, ldc, M, bias, resid, ldr, act_src, ld_act, act_kind,
+                              C2, ldc2, act2, resid_b, ldrb, tile, stream);
+  g_colstats = nullptr;
+  return rc;
 }
 
 }  // extern "C"

@@ -206,6 +206,30 @@ class BalancerStats:
         return self
 
 
+# (off by default: the statistics are exact, but every workgroup of an n-tile adds to the SAME
+# columns at the same moment -- contended fp32 atomics: 15 872 x 768 x 256 takes 84 us with them
+# against 48 without, the pass they replace takes 18; three same-box A/B pairs at C3: 41.9 against
+# 41.2 ms/step)
+_BAL_GEMM = os.environ.get("S2T_BAL_STATS_GEMM", "0") == "1"
+
+
+class GemmColStats:
+    """Column statistics of a GEMM's output, taken in that GEMM's epilogue (s2t_gemm_x3p_stats) for a
+    Balancer that fires on the tensor -- or on a column slice of it -- this call: pass to
+    lt_matmul(colstats=...), then to balancer_backward(stats=...).  `ok` is set when the product
+    was served by the kernel that takes them; otherwise backward runs the two-pass form."""
+    __slots__ = ("buf", "ok", "out")
+
+    def __init__(self, dev):
+        self.buf = torch.zeros(2048, dtype=torch.float32, device=dev)
+        self.ok = False
+        self.out = None
+
+    @staticmethod
+    def make(fires, dev):
+        return GemmColStats(dev) if (fires and _BAL_GEMM) else None
+
+
 def balancer_backward(x, g, min_mean, max_mean, min_rms, max_rms, grad_scale, channel_dim,
                       inplace=False, swoosh_l=None, stats=None):
     """Closed form of reference scaling.py:741-789: the autograd-inside-backward there reduces
@@ -235,6 +259,20 @@ def balancer_backward(x, g, min_mean, max_mean, min_rms, max_rms, grad_scale, ch
         else:
             g2 = g.contiguous().reshape(-1, C)
             out = torch.empty_like(g2)
+        if isinstance(stats, GemmColStats):
+            o = stats.out
+            if stats.ok and o is not None and o.shape[0] == rows and x2.stride(0) == o.stride(0):
+                c0 = (x2.data_ptr() - o.data_ptr()) // 4          # column offset of the slice
+                if 0 <= c0 and c0 + C <= o.shape[1]:
+                    N.PROF[0] and N.profile_note("s2t_balancer_apply", 4.0 * rows * C * 3)
+                    N.check(N.lib().s2t_balancer_apply(
+                        N.raw(x2, torch.float32), x2.stride(0), N.raw(g2, torch.float32), g2.stride(0),
+                        rows, C, min_mean, max_mean, min_rms, max_rms, grad_scale,
+                        N.raw(out, torch.float32), out.stride(0),
+                        ctypes.c_void_p(stats.buf.data_ptr() + 4 * c0),
+                        -1.0 if swoosh_l is None else _SW[swoosh_l][0], N.stream()), "s2t_balancer_apply")
+                    return out if out is g else out.reshape(g.shape)
+            stats = None
         if stats is not None and stats.x2.shape == x2.shape and stats.x2.data_ptr() == x2.data_ptr():
             # statistics taken in forward: only the update runs here, after their event
             torch.cuda.current_stream().wait_event(stats.event)
@@ -1260,7 +1298,7 @@ def _vp(t):
 
 
 def x3p_matmul(mode, x2, w2, bias=None, resid2=None, act_src=None, act_kind=None, act2=None, tile=0,
-               resid_b=None, pp=None):
+               resid_b=None, pp=None, colstats=None):
     """The same products as lt_matmul on our bf16x3 kernel with pre-split weight pieces
     (csrc/gemm_x3p.hip, planes.py): mode 0: x2 (R,K) w2 (N,K)^T (+bias) -> (R,N); mode 1: x2 (R,N)
     w2 (N,K) -> (R,K); then (* act'(act_src)) (+ resid2); with act2 a second output act2(result).
@@ -1284,12 +1322,23 @@ def x3p_matmul(mode, x2, w2, bias=None, resid2=None, act_src=None, act_kind=None
         extra = sum(t is not None for t in (resid2, act_src, out2, resid_b))
         N.PROF[0] and N.profile_note("s2t_gemm_x3p", 4.0 * R * (Nf + Kf + extra * cols) + 6.0 * Nf * Kf,
                        2.0 * R * Nf * Kf)
-    rc = N.lib().s2t_gemm_x3p(_vp(x2), x2.stride(0), ctypes.c_void_p(pp), cols, inner, _vp(out), cols, R,
-                              _vp(bias), _vp(resid2), 0 if resid2 is None else resid2.stride(0),
-                              _vp(act_src), 0 if act_src is None else act_src.stride(0),
-                              _ACTK[act_kind], _vp(out2), cols, _ACTK[act2], _vp(resid_b),
-                              0 if resid_b is None else resid_b.stride(0), tile or X3P["tile"],
-                              N.stream())
+    if colstats is not None:
+        rc = N.lib().s2t_gemm_x3p_stats(_vp(x2), x2.stride(0), ctypes.c_void_p(pp), cols, inner, _vp(out),
+                                        cols, R, _vp(bias), _vp(resid2),
+                                        0 if resid2 is None else resid2.stride(0), _vp(act_src),
+                                        0 if act_src is None else act_src.stride(0), _ACTK[act_kind],
+                                        _vp(out2), cols, _ACTK[act2], _vp(resid_b),
+                                        0 if resid_b is None else resid_b.stride(0),
+                                        tile or X3P["tile"], _vp(colstats.buf), N.stream())
+        if rc == 0:
+            colstats.ok, colstats.out = True, out
+    else:
+        rc = N.lib().s2t_gemm_x3p(_vp(x2), x2.stride(0), ctypes.c_void_p(pp), cols, inner, _vp(out), cols, R,
+                                  _vp(bias), _vp(resid2), 0 if resid2 is None else resid2.stride(0),
+                                  _vp(act_src), 0 if act_src is None else act_src.stride(0),
+                                  _ACTK[act_kind], _vp(out2), cols, _ACTK[act2], _vp(resid_b),
+                                  0 if resid_b is None else resid_b.stride(0), tile or X3P["tile"],
+                                  N.stream())
     if rc == -2:
         return None
     N.check(rc, "s2t_gemm_x3p")
@@ -1321,7 +1370,7 @@ def _time_call(fn, reps=3):
 
 
 def lt_matmul(mode, x2, w2, bias=None, resid2=None, act_src=None, act_kind=None, act2=None,
-              resid_b=None):
+              resid_b=None, colstats=None):
     """Forward / data-gradient product of a Linear with its elementwise neighbours:
       mode 0: x2 (R,K) w2 (N,K)^T (+bias) -> (R,N);  mode 1: x2 (R,N) w2 (N,K) -> (R,K);
       then (* act'(act_src), act_kind "swoosh_l" | "swoosh_r") (+ resid2) (+ resid_b); with act2
@@ -1395,7 +1444,8 @@ def lt_matmul(mode, x2, w2, bias=None, resid2=None, act_src=None, act_kind=None,
                   f"(lt {1e3 * t_lib:.1f} us, own {'-' if t_own is None else round(1e3 * t_own, 1)} us)", flush=True)
         _PLANS[key] = plan
     if plan[0] == "x3p":
-        y = x3p_matmul(mode, x2, w2, bias, resid2, act_src, act_kind, act2, plan[1], resid_b, pp)
+        y = x3p_matmul(mode, x2, w2, bias, resid2, act_src, act_kind, act2, plan[1], resid_b, pp,
+                       colstats=colstats)
         if y is not None:
             return y
     return lib()

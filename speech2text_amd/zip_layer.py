@@ -189,6 +189,7 @@ def _balancer_bwd(mod, x, g, inplace=False, swoosh_l=None, stats=None):
 
 
 _bst = zk.BalancerStats.make
+_gcs = zk.GemmColStats.make
 
 
 class _Commit(ctypes.Structure):
@@ -235,20 +236,24 @@ def _ff_fwd(m, dec, x_in):
     # the activation is KEPT for the weight gradient (the reference recomputes it to save memory,
     # scaling.py:1512-1583; 288 GB of HBM make the ~1 GB per step the cheaper side of that trade);
     # it leaves the in-projection's epilogue as a second output (no separate Swoosh pass)
-    sv.h, a = zk.lt_matmul(0, x_in, m.in_proj.weight, m.in_proj.bias, act2="swoosh_l")
+    # (a Balancer that fires on h / y gets its column statistics from that product's epilogue)
+    sv.bh = _gcs(fb, x_in.device)
+    sv.h, a = zk.lt_matmul(0, x_in, m.in_proj.weight, m.in_proj.bias, act2="swoosh_l", colstats=sv.bh)
     sv.a = a
-    sv.y = sv.st = sv.bh = sv.by = None
-    if fb:
+    sv.y = sv.st = sv.by = None
+    if fb and not (sv.bh is not None and sv.bh.ok):
         sv.bh = _bst(sv.h)
     if not (fw or fp):
         out = zk.lt_matmul(0, a, m.out_proj.weight, m.out_proj.bias, x_in)
     else:
         # the module's own output (for the Whiten / Balancer on it) AND the residual stream after
         # it from one launch
-        sv.y, out = zk.lt_matmul(0, a, m.out_proj.weight, m.out_proj.bias, act2="add", resid_b=x_in)
+        sv.by = _gcs(fp, x_in.device)
+        sv.y, out = zk.lt_matmul(0, a, m.out_proj.weight, m.out_proj.bias, act2="add", resid_b=x_in,
+                                 colstats=sv.by)
         if fw:
             sv.st = zk.WhitenStats(sv.y, m.out_whiten.num_groups)
-        if fp:
+        if fp and not (sv.by is not None and sv.by.ok):
             sv.by = _bst(sv.y)
     return out, sv
 
@@ -307,11 +312,13 @@ def _conv_fwd(m, dec, x_in, T, B, chunk_size, k8):
     D = x_in.shape[1]
     if chunk_size >= 0:
         assert m.causal, "Must initialize model with causal=True if you use chunk_size"
-    sv.u = zk.lt_matmul(0, x_in, m.in_proj.weight, m.in_proj.bias)          # (R, 2D)
+    sv.b1 = _gcs(fb1, x_in.device)
+    sv.u = zk.lt_matmul(0, x_in, m.in_proj.weight, m.in_proj.bias, colstats=sv.b1)          # (R, 2D)
     sv.cp = zk.conv_params(m.depthwise_conv, T, chunk_size)
     sv.y = zk.zipconv_forward(sv.u.view(T, B, 2 * D), D, k8, *sv.cp).view(T * B, D)
     sv.st = zk.WhitenStats(sv.y, m.whiten.num_groups) if fw else None
-    sv.b1 = _bst(sv.u[:, D:]) if fb1 else None
+    if fb1 and not (sv.b1 is not None and sv.b1.ok):
+        sv.b1 = _bst(sv.u[:, D:])
     sv.b2 = _bst(sv.y) if fb2 else None
     sv.a = zk.swoosh_forward(sv.y, False)
     return zk.lt_matmul(0, sv.a, m.out_proj.weight, m.out_proj.bias, x_in), sv
@@ -351,7 +358,8 @@ def _na_fwd(m, dec, x_in, W, T, B):
     sv = _Saved()
     L, st = N.lib(), N.stream()
     dev = x_in.device
-    sv.u = zk.lt_matmul(0, x_in, m.in_proj.weight, m.in_proj.bias)          # (R, 3C) = [s|x|y]
+    sv.bu = _gcs(fb, x_in.device)
+    sv.u = zk.lt_matmul(0, x_in, m.in_proj.weight, m.in_proj.bias, colstats=sv.bu)          # (R, 3C) = [s|x|y]
     C = sv.u.shape[1] // 3
     sv.xs = torch.empty((B, T, C), dtype=_F32, device=dev)
     N.PROF[0] and N.profile_note("s2t_nonlin_gate_fwd", 12.0 * T * B * C)
@@ -363,15 +371,18 @@ def _na_fwd(m, dec, x_in, W, T, B):
     N.check(L.s2t_nonlin_out_fwd(N.fp(sv.z), N.fp(sv.u), T, B, C, N.fp(sv.o), st),
             "nonlin_out_fwd")
     sv.st1 = zk.WhitenStats(sv.u[:, C:2 * C], m.whiten1.num_groups) if fw1 else None
-    sv.bu = _bst(sv.u[:, :C]) if fb else None
+    if fb and not (sv.bu is not None and sv.bu.ok):
+        sv.bu = _bst(sv.u[:, :C])
     sv.y = sv.st2 = sv.by = None
     if not (fw2 or fp):
         out = zk.lt_matmul(0, sv.o, m.out_proj.weight, m.out_proj.bias, x_in)
     else:
-        sv.y, out = zk.lt_matmul(0, sv.o, m.out_proj.weight, m.out_proj.bias, act2="add", resid_b=x_in)
+        sv.by = _gcs(fp, x_in.device)
+        sv.y, out = zk.lt_matmul(0, sv.o, m.out_proj.weight, m.out_proj.bias, act2="add", resid_b=x_in,
+                                 colstats=sv.by)
         if fw2:
             sv.st2 = zk.WhitenStats(sv.y, m.whiten2.num_groups)
-        if fp:
+        if fp and not (sv.by is not None and sv.by.ok):
             sv.by = _bst(sv.y)
     return out, sv
 
@@ -444,11 +455,13 @@ class _LayerFn(torch.autograd.Function):
         s.d, s.dims, s.x0, s.a8, s.k8 = d, (T, B, D, H, qd, pd), x0, a8, k8
 
         # attention weights (reference zipformer.py:1966-2066)
-        s.qkp = zk.lt_matmul(0, x0, sa.in_proj.weight, sa.in_proj.bias)
+        s.kbst = _gcs(d.k_bal, dev)
+        s.qkp = zk.lt_matmul(0, x0, sa.in_proj.weight, sa.in_proj.bias, colstats=s.kbst)
         s.kst = None
         if d.k_wh:
             s.kst = zk.WhitenStats(s.qkp[:, H * qd:2 * H * qd], sa.whiten_keys.num_groups)
-        s.kbst = _bst(s.qkp[:, H * qd:2 * H * qd]) if d.k_bal else None
+        if d.k_bal and not (s.kbst is not None and s.kbst.ok):
+            s.kbst = _bst(s.qkp[:, H * qd:2 * H * qd])
         s.pos2 = s.posp = None
         if d.use_pos:
             s.pos2 = pos_emb.reshape(2 * T - 1, -1).contiguous().float()

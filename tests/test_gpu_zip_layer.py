@@ -103,9 +103,12 @@ def test_executor_matches_module_path(dev, monkeypatch, force, big, chunk, left)
         assert zip_layer.STATS["penalty_active"] > active0
 
 
-def test_executor_with_forward_balancer_statistics(dev, monkeypatch):
-    """zk.BalancerStats (column statistics taken in forward on the side stream, off by default:
-    measured no gain): same outputs and gradients as the two-pass form, every Balancer firing."""
+@pytest.mark.parametrize("flag", ["_BAL_FWD", "_BAL_GEMM"])
+def test_executor_with_forward_balancer_statistics(dev, monkeypatch, flag):
+    """zk.BalancerStats (column statistics taken in forward on the side stream) and
+    zk.GemmColStats (taken in the epilogue of the GEMM that writes the tensor) -- both off by
+    default, measured no gain / slower: same outputs and gradients as the two-pass form, every
+    Balancer firing."""
     from speech2text_amd import rng, zip_kernels as zk
     monkeypatch.setattr(rng, "rand", lambda *s, device=None, dtype=torch.float32:
                         torch.rand(*s, dtype=dtype).to(device))
@@ -117,7 +120,7 @@ def test_executor_with_forward_balancer_statistics(dev, monkeypatch):
         wts = torch.randn(m(x, lens)[0].shape, generator=g).to(dev)
     outs = []
     for on in (False, True):
-        monkeypatch.setattr(zk, "_BAL_FWD", on)
+        monkeypatch.setattr(zk, flag, on)
         _force(m, True)
         outs.append(_step(m, store, x, lens, wts, 1, True))
     # (two runs of ONE form already differ in the last bits: column statistics and weight
