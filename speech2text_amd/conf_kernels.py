@@ -131,7 +131,10 @@ def bn_silu_fwd(x2, bn):
     mean = torch.empty(C, dtype=_F32, device=x2.device)
     rstd = torch.empty(C, dtype=_F32, device=x2.device)
     track = bn.track_running_stats and bn.running_mean is not None
-    mom = 0.1 if bn.momentum is None else float(bn.momentum)
+    if bn.momentum is None:          # torch: cumulative moving average, factor 1 / (batches seen incl. this one)
+        mom = 1.0 / (float(bn.num_batches_tracked) + 1.0) if track else 0.0
+    else:
+        mom = float(bn.momentum)
     N.PROF[0] and N.profile_note("s2t_bn_silu_fwd", 12.0 * R * C)
     N.check(N.lib().s2t_bn_silu_fwd(N.fp(x2), N.fp(bn.weight), N.fp(bn.bias), float(bn.eps), mom,
                                     N.fp(bn.running_mean) if track else None,
@@ -228,6 +231,11 @@ class _LayerNorm(torch.autograd.Function):
 def layer_norm(x, ln):
     if not x.is_cuda:
         raise RuntimeError("speech2text_amd.layer_norm needs device tensors (HIP path only)")
+    C = x.shape[-1]
+    if C % 4 or C > 1024 or x.dtype != _F32 or ln.weight is None:
+        # outside the kernel's rules (row length a multiple of 4, <= 1024, affine): torch's device
+        # kernel -- still the GPU, never a host path
+        return torch.nn.functional.layer_norm(x, (C,), ln.weight, ln.bias, ln.eps)
     return _LayerNorm.apply(x, ln.weight, ln.bias, ln.eps)
 
 
@@ -247,6 +255,8 @@ class _SiLU(torch.autograd.Function):
 def silu(x):
     if not x.is_cuda:
         raise RuntimeError("speech2text_amd.silu needs device tensors (HIP path only)")
+    if x.numel() % 4 or x.dtype != _F32:
+        return torch.nn.functional.silu(x)             # (device kernel of torch: odd sizes / dtypes)
     return _SiLU.apply(x)
 
 
@@ -337,6 +347,16 @@ def mhsa(qkv, lengths, num_heads, dropout_p=0.0):
     if not qkv.is_cuda:
         raise RuntimeError("speech2text_amd.mhsa needs device tensors (HIP path only)")
     lens = None if lengths is None else lengths.to(device=qkv.device, dtype=torch.int64).contiguous()
+    T, B, D3 = qkv.shape
+    dh = D3 // 3 // num_heads
+    if dh not in (16, 32, 64) or qkv.dtype != _F32:
+        # head widths the flash kernel is not built for: torch's device attention, same masking
+        q, k, v = (t.reshape(T, B, num_heads, dh).permute(1, 2, 0, 3) for t in qkv.chunk(3, dim=-1))
+        mask = None
+        if lens is not None:
+            mask = (torch.arange(T, device=qkv.device)[None, :] < lens[:, None])[:, None, None, :]
+        o = torch.nn.functional.scaled_dot_product_attention(q, k, v, attn_mask=mask, dropout_p=dropout_p)
+        return o.permute(2, 0, 1, 3).reshape(T, B, D3 // 3)
     seed = draw_seed() if dropout_p > 0.0 else 0
     return _Mhsa.apply(qkv, lens, num_heads, float(dropout_p), seed)
 
@@ -362,6 +382,9 @@ class _LnLstm(torch.autograd.Function):
         cT = torch.empty((B, H), dtype=_F32, device=dev)
         h0c = None if h0 is None else h0.contiguous().float()
         c0c = None if c0 is None else c0.contiguous().float()
+        if T == 0:                   # nothing to scan: the final state is the initial one
+            hT = torch.zeros_like(hT) if h0c is None else h0c.clone()
+            cT = torch.zeros_like(cT) if c0c is None else c0c.clone()
         N.check(N.lib().s2t_lnlstm_fwd(N.fp(gx), N.fp(wp_t), N.fp(gg), N.fp(gb), N.fp(cg), N.fp(cb),
                                        N.fp(h0c), N.fp(c0c), T, B, H, float(eps), N.fp(hs),
                                        N.fp(ghat), N.fp(chat), N.fp(rstd), N.fp(hT), N.fp(cT),

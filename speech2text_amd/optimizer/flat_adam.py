@@ -73,9 +73,15 @@ class _FlatMixin:
                           partial=torch.zeros(tb["nchunks"] * 3, device=dev),
                           coef=torch.ones(2, device=dev), step=0)
         f = self._flat
-        for p, o, n in zip(st.params, st.offsets, st.lengths):      # torch's per-parameter state
-            self.state[p] = {"step": torch.tensor(0.0), "exp_avg": f["m"][o:o + n].view(p.shape),
-                             "exp_avg_sq": f["v"][o:o + n].view(p.shape)}
+        # torch's per-parameter state, for the parameters the groups list (a store may hold
+        # trainable parameters outside every group: they are only zeroed, and a state entry for
+        # them would break Optimizer.state_dict()'s id mapping)
+        grouped = {id(p) for ps in groups for p in ps}
+        f["step_t"] = torch.tensor(0.0)
+        for p, o, n in zip(st.params, st.offsets, st.lengths):
+            if id(p) in grouped:
+                self.state[p] = {"step": f["step_t"], "exp_avg": f["m"][o:o + n].view(p.shape),
+                                 "exp_avg_sq": f["v"][o:o + n].view(p.shape)}
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -128,10 +134,7 @@ class _FlatMixin:
                                  stream),
                 "s2t_adam_apply")
         st.epoch += 1                      # parameters rewritten: weight pieces are stale
-        for p in st.params:
-            s = self.state.get(p)
-            if s is not None:
-                s["step"] = torch.tensor(float(k))
+        f["step_t"].fill_(float(k))        # ONE shared host scalar: every state's "step" is this tensor
         return loss
 
     def load_state_dict(self, sd):
@@ -154,7 +157,9 @@ class _FlatMixin:
             k = max(k, int(float(s["step"])))
             s["exp_avg"] = f["m"][o:o + n].view(p.shape)
             s["exp_avg_sq"] = f["v"][o:o + n].view(p.shape)
+            s["step"] = f["step_t"]
         f["step"] = k
+        f["step_t"].fill_(float(k))
 
 
 class FlatAdamW(_FlatMixin, AdamW):

@@ -285,3 +285,42 @@ def test_layer_executor_vs_oracle_c2_dims(dev):
     cfg = dict(input_dim=256, num_heads=4, ffn_dim=2048, num_layers=12,
                depthwise_conv_kernel_size=31, dropout=0.0, output_dim=256)
     _stack_vs_oracle(dev, cfg, 2, 498, torch.tensor([498, 401]), 2e-3, 2e-2, seed=1)
+
+
+def test_shapes_outside_the_kernels_rules_use_torch_device_ops(dev):
+    """Row lengths that are not multiples of 4 / head widths other than 16, 32, 64 / a BatchNorm
+    with momentum=None / an empty LSTM sequence: the wrappers fall back to torch's DEVICE kernels
+    (or handle the case) instead of failing with -2."""
+    from speech2text_amd import conf_kernels as ck
+    torch.manual_seed(0)
+    ln = torch.nn.LayerNorm(6).to(dev)
+    x = torch.randn(5, 7, 6, device=dev, requires_grad=True)
+    torch.testing.assert_close(ck.layer_norm(x, ln), F.layer_norm(x, (6,), ln.weight, ln.bias, ln.eps))
+    y = torch.randn(3, 7, device=dev)
+    torch.testing.assert_close(ck.silu(y), F.silu(y))
+    T, B, H, dh = 9, 2, 4, 36
+    qkv = torch.randn(T, B, 3 * H * dh, device=dev)
+    lens = torch.tensor([9, 5], device=dev)
+    o = ck.mhsa(qkv, lens, H)
+    q, k, v = (t.reshape(T, B, H, dh).permute(1, 2, 0, 3).double() for t in qkv.chunk(3, dim=-1))
+    sc = q @ k.transpose(-1, -2) / math.sqrt(dh)
+    sc = sc.masked_fill(torch.arange(T, device=dev)[None, None, None, :] >= lens[:, None, None, None], -1e30)
+    ref = (sc.softmax(-1) @ v).permute(2, 0, 1, 3).reshape(T, B, H * dh)
+    torch.testing.assert_close(o.double(), ref, atol=1e-5, rtol=1e-4)
+    # cumulative-average BatchNorm (momentum=None), two batches
+    bn = torch.nn.BatchNorm1d(8, momentum=None).to(dev)
+    ref_bn = torch.nn.BatchNorm1d(8, momentum=None).to(dev)
+    for _ in range(2):
+        xb = torch.randn(12, 8, device=dev) * 2 + 1
+        ck.batchnorm_silu(xb, bn)
+        ref_bn(xb)
+    torch.testing.assert_close(bn.running_mean, ref_bn.running_mean, atol=1e-6, rtol=1e-5)
+    torch.testing.assert_close(bn.running_var, ref_bn.running_var, atol=1e-6, rtol=1e-5)
+    # empty sequence: final state = initial state
+    Hh = 8
+    h0, c0 = torch.randn(2, Hh, device=dev), torch.randn(2, Hh, device=dev)
+    hs, hT, cT = ck.lnlstm(torch.zeros(0, 2, 4 * Hh, device=dev), torch.randn(4 * Hh, Hh, device=dev),
+                           torch.nn.Identity(), torch.nn.Identity(), h0, c0)
+    assert hs.shape[0] == 0
+    torch.testing.assert_close(hT, h0)
+    torch.testing.assert_close(cT, c0)
