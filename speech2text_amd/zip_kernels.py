@@ -1294,7 +1294,7 @@ X3P = {"on": os.environ.get("S2T_X3P", "1") == "1", "calls": 0, "tile": 0,
 
 
 def _vp(t):
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    return None if t is None else t.data_ptr()       # (int: the entry points carry argtypes)
 
 
 def x3p_matmul(mode, x2, w2, bias=None, resid2=None, act_src=None, act_kind=None, act2=None, tile=0,
