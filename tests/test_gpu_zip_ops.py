@@ -113,6 +113,27 @@ def test_swoosh_and_biasnorm(dev, is_l):
     np.testing.assert_allclose(lg.grad.item(), lc.grad.item(), rtol=1e-4)
 
 
+@pytest.mark.parametrize("rows,D", [(37 * 5, 192), (1031, 256), (4, 8), (3, 64), (257, 200), (130, 384),
+                                    (66, 512), (9000, 192)])
+def test_biasnorm_backward_16_byte_path(dev, rows, D):
+    """the D % 4 == 0 kernel (a 16-lane row of a wave per matrix row, prefetched trips) against the
+    oracle: row counts that are not multiples of four, partial last column group, wide rows"""
+    from speech2text_amd import zip_kernels as zk
+    torch.manual_seed(rows + D)
+    x = torch.randn(rows, D) * 2
+    bias = torch.randn(D) * 0.1
+    ls = torch.tensor(0.3)
+    w = torch.randn_like(x)
+    xc, bc, lc = x.clone().requires_grad_(True), bias.clone().requires_grad_(True), ls.clone().requires_grad_(True)
+    (Z.bias_norm(xc, bc, lc, Z.Ctl(False)) * w).sum().backward()
+    xg, bg, lg = (t.to(dev).requires_grad_(True) for t in (x, bias, ls))
+    (zk.bias_norm(xg, bg, lg) * w.to(dev)).sum().backward()
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xc.grad.numpy(), atol=1e-5, rtol=1e-4)
+    tol = 1e-3 * max(1.0, float(bc.grad.abs().max()))
+    np.testing.assert_allclose(bg.grad.cpu().numpy(), bc.grad.numpy(), atol=tol, rtol=1e-3)
+    np.testing.assert_allclose(lg.grad.item(), lc.grad.item(), rtol=2e-4, atol=1e-3)
+
+
 def _attn_ref(qkp, pos, H, qd, pd, amask, kpm):
     T, B, _ = qkp.shape
     q = qkp[..., :H * qd].reshape(T, B, H, qd).permute(2, 1, 0, 3)

@@ -1,5 +1,5 @@
 """GPU: the layer path's streaming kernels at the C3 shapes (B = 64 x 10 s), one line each: time and
-algorithmic GB/s.  usage: python tools/bench_side.py [balancer|zipconv|whiten|all]"""
+algorithmic GB/s.  usage: python tools/bench_side.py [balancer|zipconv|whiten|biasnorm|all]"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -73,3 +73,19 @@ if what in ("whiten", "all"):
         torch.cuda.synchronize()
         rep(f"whiten stats {rows}x{C}", cold(lambda: zk.WhitenStats(x, G).metric()), 4.0 * rows * C)
         rep(f"whiten_bwd {rows}x{C}", cold(lambda: zk.whiten_backward(x, g, st, 1.0, 0.01)), 4.0 * rows * C * 5)
+
+if what in ("biasnorm", "all"):
+    import ctypes
+    for rows, D in [(31680, 192), (15872, 256), (7936, 256), (3968, 256), (7936, 512)]:
+        x = torch.randn(rows, D, device=dev)
+        b = torch.randn(D, device=dev) * 0.1
+        sc = torch.rand(rows, device=dev) + 0.5
+        g = torch.randn_like(x)
+        dx = torch.empty_like(x)
+        acc = torch.zeros(D + 1, device=dev)
+
+        def call():
+            N.check(N.lib().s2t_biasnorm_bwd(N.fp(x), N.fp(b), N.fp(sc), N.fp(g), rows, D, N.fp(dx), N.fp(acc),
+                                             ctypes.c_void_p(acc.data_ptr() + 4 * D), N.stream()), "biasnorm_bwd")
+        rep(f"biasnorm_bwd {rows}x{D} (cold)", cold(call, it=20), 12.0 * rows * D)
+        rep(f"biasnorm_bwd {rows}x{D} (back to back)", timeit(call), 12.0 * rows * D)
