@@ -154,7 +154,8 @@ long s2t_zipconv_bwd_workspace_floats(int T, int B, int C, int K);
  * of W is passed materialised (dW) and/or factored -- dW0 (B,T,T) for head 0 and up to two
  * (dO_c, V_c) pairs (T,B,H*dv_c) whose outer products are contracted on the fly, so the
  * consumers' (H,B,T,T) gradients are never written; with factors, delta_ws (H,B,T) must hold
- * sum_j W*dW on entry (delta_given=1).  dqkp (T,B,Dp) fully written, dpos ACCUMULATED. */
+ * sum_j W*dW on entry (delta_given=1).  dqkp (T,B,Dp) and dpos fully written (dpos is cleared
+ * by the entry point before the partial sums are added; the caller need not zero it). */
 int s2t_relpos_attn_fwd(const float* qkp, const float* pos, const unsigned char* kpm,
                         const unsigned char* amask, int T, int B, int H, int qd, int pd, float* W,
                         void* stream);

@@ -874,12 +874,17 @@ template <int NS>
 __global__ __launch_bounds__(256, 2) void attn_bwd_k3_mfma_kernel(AttnArgs a,
                                                                const float* __restrict__ W,
                                                                const float* __restrict__ delta,
-                                                               float* __restrict__ dqkp) {
+                                                               float* __restrict__ dqkp,
+                                                               float* __restrict__ zero_buf,
+                                                               int zero_n) {
   constexpr int NSA = NS > 0 ? NS : 1;
   constexpr int CDP = 2 * NSA;                                          // <= 32
   __shared__ float s_Q[32][33];                                         // q[i0+ii][d]
   __shared__ float s_O[32][33];                                         // dO_cat[i0+ii][k]
   __shared__ float s_dl[32];
+  // the position-gradient accumulator of the reduce pass that follows this launch is cleared
+  // here (it is not read by this kernel): no fill launch per layer
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < zero_n; i += gridDim.x * 256) zero_buf[i] = 0.f;
   int tile_, slab_;
   if (!slab_tile((a.T + 127) / 128, a.B * a.H, tile_, slab_)) return;
   const int b = slab_ % a.B, h = slab_ / a.B;
@@ -1153,10 +1158,13 @@ int launch_attn_bwd_mfma(const AttnArgs& a, const float* W, const float* delta, 
                        a.pos ? ws : nullptr);
   S2T_CHECK_LAUNCH();
   static const bool k_old = getenv("S2T_ATTN_BWD_K_OLD") != nullptr;   // one 32-key tile per workgroup
-  if (k_old)
+  const int nz = (a.pos && a.pd > 0) ? (2 * a.T - 1) * a.H * a.pd : 0;
+  if (k_old) {
+    if (nz && hipMemsetAsync(dpos, 0, sizeof(float) * (size_t)nz, st) != hipSuccess) return -3;
     hipLaunchKernelGGL((attn_bwd_k_mfma_kernel<NS>), gk, dim3(256), 0, st, a, W, delta, dqkp);
-  else
-    hipLaunchKernelGGL((attn_bwd_k3_mfma_kernel<NS>), gq, dim3(256), 0, st, a, W, delta, dqkp);
+  } else {
+    hipLaunchKernelGGL((attn_bwd_k3_mfma_kernel<NS>), gq, dim3(256), 0, st, a, W, delta, dqkp, dpos, nz);
+  }
   S2T_CHECK_LAUNCH();
   if (a.pos && a.pd > 0) {
     const int n = (2 * a.T - 1) * a.pd;
@@ -1482,6 +1490,9 @@ extern "C" int s2t_relpos_attn_bwd(const float* qkp, const float* pos, const uns
     return launch_attn_bwd_mfma<16>(a, W, delta_ws, dqkp, dpos, workspace, st);
   }
   dim3 grid((T + ROWS - 1) / ROWS, B, H);
+  if (pos && pd > 0 &&
+      hipMemsetAsync(dpos, 0, sizeof(float) * (size_t)(2 * T - 1) * H * pd, (hipStream_t)stream) != hipSuccess)
+    return -3;
   hipLaunchKernelGGL(attn_bwd_q_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, W, delta_given,
                      delta_ws, dqkp);
   S2T_CHECK_LAUNCH();

@@ -136,17 +136,25 @@ class Zipformer2(nn.Module):
         p = 0.125
         m1 = (rng.rand(1, B, 1, device=x.device) > p).to(x.dtype)
         m2 = torch.logical_and(m1, (rng.rand(1, B, 1, device=x.device) > p).to(x.dtype))
-        m = torch.cat((m1, m2), dim=-1)
-        masks = []
-        for i in range(n):
-            c = self.encoder_dim[i]
-            fm = torch.ones(1, B, c, dtype=x.dtype, device=x.device)
-            u1 = self.encoder_unmasked_dim[i]
-            u2 = u1 + (c - u1) // 2
-            fm[:, :, u1:u2] *= m[..., 0:1]
-            fm[:, :, u2:] *= m[..., 1:2]
-            masks.append(fm)
-        return masks
+        # channel -> {1, m1, m2}: one gather per stack from (ones | m1 | m2) through a cached channel
+        # selector (was ones + two sliced multiplies per stack: 30 launches of ~5 us)
+        m = torch.cat((torch.ones_like(m1), m1, m2.to(x.dtype)), dim=-1)
+        sel = self._fm_selectors(x.device)
+        return [m.index_select(-1, sel[i]) for i in range(n)]
+
+    def _fm_selectors(self, device):
+        cache = self.__dict__.setdefault("_fm_sel", {})
+        sel = cache.get(device)
+        if sel is None:
+            sel = []
+            for c, u1 in zip(self.encoder_dim, self.encoder_unmasked_dim):
+                u2 = u1 + (c - u1) // 2
+                idx = torch.zeros(c, dtype=torch.long)
+                idx[u1:u2] = 1
+                idx[u2:] = 2
+                sel.append(idx.to(device))
+            cache[device] = sel
+        return sel
 
     def get_chunk_info(self) -> Tuple[int, int]:
         if not self.causal:

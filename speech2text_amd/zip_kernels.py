@@ -435,6 +435,12 @@ class WhitenStats:
         return float(self.host[0])
 
 
+_WHITEN_X3P = os.environ.get("S2T_WHITEN_X3P", "1") == "1"
+# measured (tools/bench_side.py whiten): 73 against 94 us at 31 680 x 192, but 62 against 58 at
+# 15 872 x 256 (the piece-split launch costs what the faster product saves)
+_WHITEN_X3P_ROWS = int(os.environ.get("S2T_WHITEN_X3P_ROWS", "24000"))
+
+
 def whiten_backward(x, g, stats, limit, grad_scale):
     """Closed form of reference scaling.py:949-1028.  Returns (grad, penalty_was_active).
     d metric/d x = 2 (x - mean) dcov  (the centring's own Jacobian vanishes because the centred
@@ -456,7 +462,15 @@ def whiten_backward(x, g, stats, limit, grad_scale):
     xf = x.reshape(-1, C)
     if xf.dtype != torch.float32:
         xf = xf.float()
-    pg = torch.addmm(bias, xf, dcov)
+    # pg = x dcov + bias: for long activations on our bf16x3 kernel, with dcov's pieces written on the
+    # spot; the library's fp32 kernels otherwise
+    pg = None
+    if _WHITEN_X3P and X3P["on"] and xf.stride(1) == 1 and xf.shape[0] >= _WHITEN_X3P_ROWS:
+        pp = planes.adhoc_pieces(dcov, 1)
+        if pp is not None:
+            pg = x3p_matmul(1, xf, dcov, bias, pp=pp)
+    if pg is None:
+        pg = torch.addmm(bias, xf, dcov)
     g2 = g.contiguous().float()
     if g2.data_ptr() % 16:
         g2 = g2.clone()
@@ -637,7 +651,7 @@ def _attn_bwd_call(qkp, pos, k8, a8, H, qd, pd, W, dW, dW0, pairs, delta):
     T, B, _ = qkp.shape
     dev = qkp.device
     dqkp = torch.empty_like(qkp)
-    dpos = None if pos is None else torch.zeros_like(pos)
+    dpos = None if pos is None else torch.empty_like(pos)      # cleared by the entry point
     given = delta is not None
     if delta is None:
         delta = torch.empty((H, B, T), dtype=torch.float32, device=dev)
