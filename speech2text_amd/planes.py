@@ -104,11 +104,29 @@ def arena_of(w):
     return store.arena
 
 
+_HOT = {}            # (address, mode) -> (arena ref, entry, address of the pieces): the step's repeat lookups
+
+
 def pieces(w2, mode):
     """Device address of the bf16 pieces of matrix w2 (a parameter's 2-D view) for `mode`, or None
     when the weight is not served (not in a FlatStore, shape outside the kernel's rules)."""
+    key = (w2.data_ptr(), mode)
+    hot = _HOT.get(key)
+    if hot is not None:
+        a, e, addr = hot[0](), hot[1], hot[2]
+        if (a is not None and a.epoch == a.store.epoch and e.version == e.param._version
+                and e.N == w2.shape[0] and e.K == w2.shape[1] and w2.stride(0) == e.K):
+            return addr
+        del _HOT[key]
     a = arena_of(w2)
-    return None if a is None else a.lookup(w2, mode)
+    if a is None:
+        return None
+    addr = a.lookup(w2, mode)
+    if addr is not None:
+        if len(_HOT) > 4096:
+            _HOT.clear()
+        _HOT[key] = (weakref.ref(a), a.entries[w2.data_ptr()], addr)
+    return addr
 
 
 _ADHOC = {}          # (N, K, mode, device) -> (descriptor table, piece buffer, split workgroups)

@@ -34,7 +34,12 @@ pr.enable()
 trainer.training_step(batch, 0)
 pr.disable()
 torch.cuda.synchronize()
-for key in ("tottime", "cumtime"):
-    s = io.StringIO()
-    pstats.Stats(pr, stream=s).sort_stats(key).print_stats(45)
-    print(s.getvalue()[:9000])
+st = pstats.Stats(pr)
+rows = []
+for (fn, line, name), (cc, nc, tt, ct, callers) in st.stats.items():
+    rows.append((tt, ct, nc, "%s:%d(%s)" % (os.path.basename(fn), line, name)))
+tot = sum(r[0] for r in rows)
+print("profiled step: %.2f ms in %d functions" % (1e3 * tot, len(rows)))
+print("%9s %9s %7s  function" % ("self ms", "cum ms", "calls"))
+for tt, ct, nc, nm in sorted(rows, reverse=True)[:70]:
+    print("%9.3f %9.3f %7d  %s" % (1e3 * tt, 1e3 * ct, nc, nm))
