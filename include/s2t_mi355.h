@@ -636,6 +636,18 @@ int s2t_gemm_x3f_nt(const float* A, long lda, const unsigned short* Bf, float* C
                     int N, int K, const float* bias, const float* resid, long ldr, float beta,
                     int tnw, void* stream);
 
+/* ---- StatelessPredictor: embedding + depthwise context convolution in one pass
+ * (reference model/predictor/stateless_predictor.py:27-105: nn.Embedding -> nn.Conv1d(D, D, K,
+ * groups=D, bias=False) on the blank-left-padded labels).  tokens (B,L) int32 (values clamped to
+ * [0,V)), emb (V,D), w (D,K) = the conv weight (D,1,K), K <= 8:
+ *   out[b,u,d] = sum_k w[d,k] emb[tokens[b,u+k], d],  out (B, L-K+1, D).
+ * bwd: g (B, L-K+1, D); d_emb (V,D) and d_w (D,K) are ADDED to (fp32 atomics; the caller
+ * zeroes them); either may be NULL. */
+int s2t_predictor_ctx_fwd(const int* tokens, const float* emb, const float* w, int B, int L, int K,
+                          int D, int V, float* out, void* stream);
+int s2t_predictor_ctx_bwd(const int* tokens, const float* emb, const float* w, const float* g, int B,
+                          int L, int K, int D, int V, float* d_emb, float* d_w, void* stream);
+
 /* ---- fp32 GEMM on the bf16 matrix cores with the weight operand split ahead of time
  * (csrc/gemm_x3p.hip): the forward (y = x W^T + b) and data-gradient (dx = g W) products of the
  * layers' Linears (reference model/encoder/zipformer.py:1924-1975,2372-2378,2643-2695,

@@ -476,19 +476,25 @@ __global__ __launch_bounds__(256) void pruned_dam_kernel(
   }
 }
 
-// d_lm[b,s,:]: wave per (b,s); t-range [t_lo,t_hi) with s0[t] <= s < s0[t]+R
-// (s0 is non-decreasing in t, so the frames that visit s are contiguous).
+// d_lm[b,s,:]: one workgroup of DLM_W waves per (b,s); t-range [t_lo,t_hi) with
+// s0[t] <= s < s0[t]+R (s0 is non-decreasing in t, so the frames that visit s are contiguous).
+// The range is as long as the alignment dwells on s -- a handful of frames on a trained model,
+// up to T on a fresh one -- and every frame is a dependent chain of loads + C exponentials: a
+// single wave per row left the launch waiting for its longest rows (501 us at C3, 61 us for the
+// d_am pass over the same nodes).  The waves of the workgroup stride the range and add up
+// through LDS.
+constexpr int DLM_W = 8;
 template <int MAXC_PER_LANE>
-__global__ __launch_bounds__(256) void pruned_dlm_kernel(
+__global__ __launch_bounds__(64 * DLM_W) void pruned_dlm_kernel(
     const float* __restrict__ am, const float* __restrict__ lm, const long* __restrict__ ranges,
     const long* __restrict__ symbols, const float* __restrict__ lse,
     const float* __restrict__ dpx, const float* __restrict__ dpy, const float* __restrict__ gscale,
     int B, int S, int T, int C, int R, int blank, int act, float* __restrict__ d_lm,
     int accumulate) {
+  __shared__ float s_acc[DLM_W][64 * MAXC_PER_LANE];
   const int S1 = S + 1;
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (row >= (long)B * S1) return;
+  const long row = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = (int)(row / S1), s = (int)(row % S1);
   const float g = gscale[b];
   const long* rb = ranges + (long)b * T * R;
@@ -515,7 +521,7 @@ __global__ __launch_bounds__(256) void pruned_dlm_kernel(
     acc[j] = 0.f;
   }
   const long y = (s < S) ? symbols[(long)b * S + s] : -1;
-  for (int t = t_lo; t < t_hi; ++t) {
+  for (int t = t_lo + wave; t < t_hi; t += DLM_W) {
     const int i = s - (int)rb[(long)t * R];
     const float* amr = am + ((long)b * T + t) * C;
     const float z = lse[((long)b * T + t) * R + i];
@@ -535,11 +541,15 @@ __global__ __launch_bounds__(256) void pruned_dlm_kernel(
       }
     }
   }
-  float* o = d_lm + row * C;
 #pragma unroll
-  for (int j = 0; j < MAXC_PER_LANE; ++j) {
-    const int c = lane + 64 * j;
-    if (c < C) o[c] = accumulate ? o[c] + acc[j] : acc[j];
+  for (int j = 0; j < MAXC_PER_LANE; ++j) s_acc[wave][lane + 64 * j] = acc[j];
+  __syncthreads();
+  float* o = d_lm + row * C;
+  for (int c = threadIdx.x; c < C; c += 64 * DLM_W) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < DLM_W; ++w) v += s_acc[w][c];
+    o[c] = accumulate ? o[c] + v : v;
   }
 }
 
@@ -776,9 +786,16 @@ extern "C" int s2t_rnnt_pruned_bwd(const float* am, const float* lm, const long*
     S2T_CHECK_LAUNCH();
   }
   {
-    const long rows = (long)B * (S + 1);
-    S2T_DISPATCH_C(pruned_dlm_kernel, am, lm, ranges, symbols, lse, dpx, dpy, gscale, B, S, T, C,
-                   R, blank, act, d_lm, accumulate);
+    const unsigned nb = (unsigned)((long)B * (S + 1));      // one DLM_W-wave workgroup per (b, s)
+#define S2T_DLM(MC)                                                                              \
+  hipLaunchKernelGGL(pruned_dlm_kernel<MC>, dim3(nb), dim3(64 * DLM_W), 0, st, am, lm, ranges, \
+                     symbols, lse, dpx, dpy, gscale, B, S, T, C, R, blank, act, d_lm, accumulate)
+    if (C <= 128) S2T_DLM(2);
+    else if (C <= 256) S2T_DLM(4);
+    else if (C <= 512) S2T_DLM(8);
+    else if (C <= 1024) S2T_DLM(16);
+    else return -1;
+#undef S2T_DLM
     S2T_CHECK_LAUNCH();
   }
   return 0;

@@ -384,3 +384,46 @@ class _SmoothedNll(torch.autograd.Function):
 
 def smoothed_nll_rows(logits2d, labels, scale, t_other, t_label, c0):
     return _SmoothedNll.apply(logits2d, labels, scale, t_other, t_label, c0)
+
+
+# =============================================================== StatelessPredictor context
+PRED_MAX_CONTEXT = 8      # == PRED_MAXK (csrc/predictor.hip)
+
+
+class _PredictorContext(torch.autograd.Function):
+    """out[b,u,:] = sum_k w[:,k] * emb[tokens[b,u+k]]: nn.Embedding + depthwise nn.Conv1d of
+    reference stateless_predictor.py:27-105 as one gather pass (csrc/predictor.hip)."""
+
+    @staticmethod
+    def forward(ctx, tokens, emb, w):
+        _dev_check(tokens, emb, w)
+        B, L = tokens.shape
+        V, D = emb.shape
+        K = w.shape[-1]
+        tok = tokens.to(torch.int32).contiguous()
+        e, wk = emb.contiguous().float(), w.reshape(D, K).contiguous().float()
+        out = torch.empty((B, L - K + 1, D), dtype=torch.float32, device=emb.device)
+        N.check(N.lib().s2t_predictor_ctx_fwd(N.ip(tok), N.fp(e), N.fp(wk), B, L, K, D, V, N.fp(out),
+                                              N.stream()), "s2t_predictor_ctx_fwd")
+        ctx.save_for_backward(tok, e, wk)
+        ctx.wshape = w.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        tok, e, wk = ctx.saved_tensors
+        B, L = tok.shape
+        V, D = e.shape
+        K = wk.shape[1]
+        g = g.contiguous().float()
+        de = torch.zeros_like(e) if ctx.needs_input_grad[1] else None
+        dw = torch.zeros_like(wk) if ctx.needs_input_grad[2] else None
+        N.check(N.lib().s2t_predictor_ctx_bwd(N.ip(tok), N.fp(e), N.fp(wk), N.fp(g), B, L, K, D, V,
+                                              N.fp(de), N.fp(dw), N.stream()), "s2t_predictor_ctx_bwd")
+        return None, de, (None if dw is None else dw.view(ctx.wshape))
+
+
+def predictor_context(tokens, emb_weight, conv_weight):
+    """tokens (B, L) integer, emb_weight (V, D), conv_weight (D, 1, K) -> (B, L-K+1, D)."""
+    return _PredictorContext.apply(tokens, emb_weight, conv_weight)
+

@@ -7,6 +7,7 @@ from typing import Tuple
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+from speech2text_amd import kernels as K
 from speech2text_amd.model.layer.scaling import Linear
 
 
@@ -52,9 +53,18 @@ class StatelessPredictor(nn.Module):
         tokens = F.pad(input.to(torch.int32), (self._context_size, 0), value=self._blank_token)
         tokens[:, :self._context_size - 1] = state.to(input.device).repeat(B, 1)
         out_state = tokens[:, tokens.shape[1] - self._context_size:]
+        return self._output_linear(self._context(tokens)), lengths, out_state
+
+    def _context(self, tokens: torch.Tensor) -> torch.Tensor:
+        """Embedding -> depthwise Conv1d over the context window: (B, L) -> (B, L-ctx+1, D).  On the
+        GPU one gather kernel per pass (kernels.predictor_context); the module composition on the
+        CPU (host-side tools and tests only)."""
+        w = self._embedding.weight
+        if (w.is_cuda and w.dtype == torch.float32 and self._context_size <= K.PRED_MAX_CONTEXT
+                and self._embedding.padding_idx is None):
+            return K.predictor_context(tokens, w, self._conv.weight)
         emb = self._embedding(tokens).transpose(1, 2)               # (B, D, ctx+U)
-        out = self._conv(emb).transpose(1, 2)                       # (B, U+1, D)
-        return self._output_linear(out), lengths, out_state
+        return self._conv(emb).transpose(1, 2)                      # (B, U+1, D)
 
     def streaming_step(self, input: torch.Tensor, state: torch.Tensor):
         """One token in, one prediction out; state = the previous context-1 tokens
@@ -62,9 +72,7 @@ class StatelessPredictor(nn.Module):
         assert input.shape[1] == 1
         ctxed = torch.cat([state.to(input.device), input.to(state.dtype)], dim=1)
         out_state = ctxed[:, ctxed.shape[1] - self._context_size + 1:]
-        emb = self._embedding(ctxed).transpose(1, 2)
-        out = self._conv(emb).transpose(1, 2)
-        return self._output_linear(out), out_state
+        return self._output_linear(self._context(ctxed)), out_state
 
 
 class Predictor(nn.Module):
