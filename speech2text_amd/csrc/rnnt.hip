@@ -160,6 +160,23 @@ __global__ __launch_bounds__(256) void simple_dlm_kernel(
 // --------------------------------------------- mutual information recursion
 constexpr int MI_PD = 8;   // diagonals of operand look-ahead
 
+// Operands and results move through raw buffer accesses on STRAIGHT-LINE code: a lane outside the
+// lattice passes an out-of-range offset (the load returns 0, the store is dropped) instead of
+// branching around the access.  With the accesses inside `if (in the lattice)` the compiler closed
+// every diagonal with s_waitcnt vmcnt(0) -- 38 of them in the forward kernel -- so a step waited
+// for the loads it had just issued for eight diagonals later, and the look-ahead bought nothing
+// (134 us for 298 diagonals, an L2 round trip each).
+constexpr unsigned MI_OOB = 0xFFFFFFF0u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mi_rsrc(const float* p, long floats) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)(floats * 4), 0x00020000);
+}
+__device__ __forceinline__ float mi_load(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
+}
+__device__ __forceinline__ void mi_store(__amdgpu_buffer_rsrc_t rs, unsigned off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, off, 0, 0);
+}
+
 __global__ void mi_fwd_kernel(const float* __restrict__ px, const float* __restrict__ py,
                               const long* __restrict__ boundary, int S, int T,
                               float* __restrict__ p, float* __restrict__ ans) {
@@ -167,9 +184,9 @@ __global__ void mi_fwd_kernel(const float* __restrict__ px, const float* __restr
   float* ex = reinterpret_cast<float*>(smem_raw);  // [2][blockDim.x + 1]
   const int b = blockIdx.x, s = threadIdx.x, nt = blockDim.x;
   const int Sb = (int)boundary[b * 4 + 2], Tb = (int)boundary[b * 4 + 3];
-  const float* pxb = px + (long)b * S * (T + 1);
-  const float* pyb = py + (long)b * (S + 1) * T;
-  float* pb = p + (long)b * (S + 1) * (T + 1);
+  const __amdgpu_buffer_rsrc_t rpx = mi_rsrc(px + (long)b * S * (T + 1), (long)S * (T + 1));
+  const __amdgpu_buffer_rsrc_t rpy = mi_rsrc(py + (long)b * (S + 1) * T, (long)(S + 1) * T);
+  const __amdgpu_buffer_rsrc_t rp = mi_rsrc(p + (long)b * (S + 1) * (T + 1), (long)(S + 1) * (T + 1));
   float own = S2T_NEG_INF;  // p[s][t-1]
   ex[s] = S2T_NEG_INF;
   ex[nt + 1 + s] = S2T_NEG_INF;
@@ -180,47 +197,42 @@ __global__ void mi_fwd_kernel(const float* __restrict__ px, const float* __restr
   __syncthreads();
   const bool act = s <= Sb;
   // Operands of diagonal d (px[s-1][t], py[s][t-1], t = d - s) are requested MI_PD diagonals
-  // ahead: a step of the recursion is a few dozen cycles, a global round trip ~1 us, and with one
-  // diagonal of look-ahead every step waited for one (236 us for 298 diagonals).
+  // ahead: a step of the recursion is a few dozen cycles, a global round trip ~1 us.  The raw
+  // values are kept (0 where the cell has no such operand); validity is re-derived at use.
   float rx[MI_PD], ry[MI_PD];
-  auto fetch = [&](int dd, float& x, float& y) {
-    const int t1 = dd - s;
-    x = S2T_NEG_INF;
-    y = S2T_NEG_INF;
-    if (act && t1 >= 0 && t1 <= Tb) {
-      if (s > 0) x = pxb[(long)(s - 1) * (T + 1) + t1];
-      if (t1 > 0) y = pyb[(long)s * T + (t1 - 1)];
-    }
-  };
+#define MI_FETCH(DD, X, Y)                                                                   \
+  {                                                                                          \
+    const int t1_ = (DD) - s;                                                                \
+    const bool in_ = act && t1_ >= 0 && t1_ <= Tb;                                           \
+    X = mi_load(rpx, (in_ && s > 0) ? (unsigned)((s - 1) * (T + 1) + t1_) * 4u : MI_OOB);    \
+    Y = mi_load(rpy, (in_ && t1_ > 0) ? (unsigned)(s * T + t1_ - 1) * 4u : MI_OOB);          \
+  }
 #pragma unroll
-  for (int u = 0; u < MI_PD; ++u) fetch(u, rx[u], ry[u]);
+  for (int u = 0; u < MI_PD; ++u) MI_FETCH(u, rx[u], ry[u])
   int cur = 0;
   const int D = Sb + Tb;
+  // whole groups of MI_PD diagonals: the ones past D have no cell in the lattice (t > Tb for
+  // every s <= Sb) and fall through as no-ops -- no exit test inside the unrolled body
   for (int d0 = 0; d0 <= D; d0 += MI_PD) {
 #pragma unroll
     for (int u = 0; u < MI_PD; ++u) {
       const int d = d0 + u;
-      if (d > D) break;                                  // block-uniform
       const int t = d - s;
       const float vx = rx[u], vy = ry[u];
-      fetch(d + MI_PD, rx[u], ry[u]);
-      float val = S2T_NEG_INF;
-      if (act && t >= 0 && t <= Tb) {
-        if (d == 0) {
-          val = 0.f;
-        } else {
-          const float up = (s > 0) ? ex[(cur ^ 1) * (nt + 1) + s - 1] + vx : S2T_NEG_INF;
-          const float left = (t > 0) ? own + vy : S2T_NEG_INF;
-          val = log_add_comp(up, left);
-        }
-        pb[(long)s * (T + 1) + t] = val;
-        own = val;
-      }
+      MI_FETCH(d + MI_PD, rx[u], ry[u])
+      const bool in = act && t >= 0 && t <= Tb;
+      const float up = (s > 0) ? ex[(cur ^ 1) * (nt + 1) + (s > 0 ? s - 1 : 0)] + vx : S2T_NEG_INF;
+      const float left = (t > 0) ? own + vy : S2T_NEG_INF;
+      const float step = (d == 0) ? 0.f : log_add_comp(up, left);
+      const float val = in ? step : S2T_NEG_INF;
+      mi_store(rp, in ? (unsigned)(s * (T + 1) + t) * 4u : MI_OOB, val);
+      own = in ? val : own;
       ex[cur * (nt + 1) + s] = val;
       __syncthreads();
       cur ^= 1;
     }
   }
+#undef MI_FETCH
   if (s == Sb) ans[b] = own;
 }
 
@@ -233,11 +245,11 @@ __global__ void mi_bwd_kernel(const float* __restrict__ px, const float* __restr
   const int b = blockIdx.x, s = threadIdx.x, nt = blockDim.x;
   float* exp_ = exg + 2 * (nt + 1);                 // [2][nt+1] p
   const int Sb = (int)boundary[b * 4 + 2], Tb = (int)boundary[b * 4 + 3];
-  const float* pxb = px + (long)b * S * (T + 1);
-  const float* pyb = py + (long)b * (S + 1) * T;
-  const float* pb = p + (long)b * (S + 1) * (T + 1);
-  float* gx = px_grad + (long)b * S * (T + 1);
-  float* gy = py_grad + (long)b * (S + 1) * T;
+  const __amdgpu_buffer_rsrc_t rpx = mi_rsrc(px + (long)b * S * (T + 1), (long)S * (T + 1));
+  const __amdgpu_buffer_rsrc_t rpy = mi_rsrc(py + (long)b * (S + 1) * T, (long)(S + 1) * T);
+  const __amdgpu_buffer_rsrc_t rp = mi_rsrc(p + (long)b * (S + 1) * (T + 1), (long)(S + 1) * (T + 1));
+  const __amdgpu_buffer_rsrc_t rgx = mi_rsrc(px_grad + (long)b * S * (T + 1), (long)S * (T + 1));
+  const __amdgpu_buffer_rsrc_t rgy = mi_rsrc(py_grad + (long)b * (S + 1) * T, (long)(S + 1) * T);
   for (int i = s; i < 2 * (nt + 1); i += nt) {
     exg[i] = 0.f;
     exp_[i] = S2T_NEG_INF;
@@ -249,69 +261,84 @@ __global__ void mi_bwd_kernel(const float* __restrict__ px, const float* __restr
   int cur = 0;
   const int D = Sb + Tb;
   // operands of diagonal d (p, px, py at (s, t = d - s)) are requested MI_PD diagonals ahead
-  float rp[MI_PD], rx[MI_PD], ry[MI_PD];
-  auto fetch = [&](int dd, float& vp, float& vx, float& vy) {
-    const int t1 = dd - s;
-    vp = S2T_NEG_INF;
-    vx = S2T_NEG_INF;
-    vy = S2T_NEG_INF;
-    if (act && dd >= 0 && t1 >= 0 && t1 <= Tb) {
-      vp = pb[(long)s * (T + 1) + t1];
-      if (s < Sb) vx = pxb[(long)s * (T + 1) + t1];
-      if (t1 < Tb) vy = pyb[(long)s * T + t1];
-    }
-  };
+  // (raw buffer loads, see above); diagonals below 0 are no-ops
+  float rp_[MI_PD], rx[MI_PD], ry[MI_PD];
+#define MI_FETCH(DD, VP, VX, VY)                                                             \
+  {                                                                                          \
+    const int t1_ = (DD) - s;                                                                \
+    const bool in_ = act && (DD) >= 0 && t1_ >= 0 && t1_ <= Tb;                              \
+    VP = mi_load(rp, in_ ? (unsigned)(s * (T + 1) + t1_) * 4u : MI_OOB);                     \
+    VX = mi_load(rpx, (in_ && s < Sb) ? (unsigned)(s * (T + 1) + t1_) * 4u : MI_OOB);        \
+    VY = mi_load(rpy, (in_ && t1_ < Tb) ? (unsigned)(s * T + t1_) * 4u : MI_OOB);            \
+  }
 #pragma unroll
-  for (int u = 0; u < MI_PD; ++u) fetch(D - u, rp[u], rx[u], ry[u]);
+  for (int u = 0; u < MI_PD; ++u) MI_FETCH(D - u, rp_[u], rx[u], ry[u])
   for (int d0 = D; d0 >= 0; d0 -= MI_PD) {
 #pragma unroll
     for (int u = 0; u < MI_PD; ++u) {
       const int d = d0 - u;
-      if (d < 0) break;                                  // block-uniform
       const int t = d - s;
-      const float vp = rp[u], vx = rx[u], vy = ry[u];
-      fetch(d - MI_PD, rp[u], rx[u], ry[u]);
-      float g = 0.f;
-      if (act && t >= 0 && t <= Tb) {
-        if (d == D) {
-          g = ag;
-        } else {
-          float xg = 0.f, yg = 0.f;
-          if (s < Sb) {
-            const float pd = exp_[(cur ^ 1) * (nt + 1) + s + 1];  // p[s+1][t]
-            const float gd = exg[(cur ^ 1) * (nt + 1) + s + 1];   // p_grad[s+1][t]
-            if (pd != S2T_NEG_INF && gd != 0.f) {
-              const float e = __expf(vp + vx - pd);
-              xg = (e == e) ? gd * e : 0.f;
-            }
-          }
-          if (t < Tb) {
-            if (own_p != S2T_NEG_INF && own_g != 0.f) {
-              const float e = __expf(vp + vy - own_p);
-              yg = (e == e) ? own_g * e : 0.f;
-            }
-          }
-          if (s < Sb) gx[(long)s * (T + 1) + t] = xg;
-          if (t < Tb) gy[(long)s * T + t] = yg;
-          g = xg + yg;
-        }
-        own_g = g;
-        own_p = vp;
+      const float vp = rp_[u], vx = rx[u], vy = ry[u];
+      MI_FETCH(d - MI_PD, rp_[u], rx[u], ry[u])
+      const bool in = act && d >= 0 && t >= 0 && t <= Tb;
+      const float pd = exp_[(cur ^ 1) * (nt + 1) + s + 1];  // p[s+1][t]
+      const float gd = exg[(cur ^ 1) * (nt + 1) + s + 1];   // p_grad[s+1][t]
+      float xg = 0.f, yg = 0.f;
+      if (in && s < Sb && pd != S2T_NEG_INF && gd != 0.f) {
+        const float e = __expf(vp + vx - pd);
+        xg = (e == e) ? gd * e : 0.f;
       }
+      if (in && t < Tb && own_p != S2T_NEG_INF && own_g != 0.f) {
+        const float e = __expf(vp + vy - own_p);
+        yg = (e == e) ? own_g * e : 0.f;
+      }
+      mi_store(rgx, (in && s < Sb && d != D) ? (unsigned)(s * (T + 1) + t) * 4u : MI_OOB, xg);
+      mi_store(rgy, (in && t < Tb && d != D) ? (unsigned)(s * T + t) * 4u : MI_OOB, yg);
+      const float g = in ? (d == D ? ag : xg + yg) : 0.f;
+      own_g = in ? g : own_g;
+      own_p = in ? vp : own_p;
       exg[cur * (nt + 1) + s] = g;
-      exp_[cur * (nt + 1) + s] = (act && t >= 0 && t <= Tb) ? vp : S2T_NEG_INF;
+      exp_[cur * (nt + 1) + s] = in ? vp : S2T_NEG_INF;
       __syncthreads();
       cur ^= 1;
     }
   }
+#undef MI_FETCH
 }
 
 // ------------------------------------------------------------ prune ranges
+// v[t] <- min(v[t], v[t+1], ..., v[T-1]) for a 256-thread workgroup; v in LDS, cm = 256 longs of
+// LDS scratch.  Every thread owns a contiguous chunk; the chunk minima are combined by a
+// doubling scan.  All threads must call it; ends with a barrier.
+__device__ __forceinline__ void block_suffix_min(long* v, int T, long* cm) {
+  const long kMax = 0x7fffffffffffffffL;
+  const int tid = threadIdx.x, per = (T + 255) / 256;
+  const int lo = tid * per, hi = min(T, lo + per);
+  long m = kMax;
+  for (int t = hi - 1; t >= lo; --t) {
+    m = v[t] < m ? v[t] : m;
+    v[t] = m;
+  }
+  cm[tid] = m;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const long o = tid + off < 256 ? cm[tid + off] : kMax;
+    __syncthreads();
+    if (o < cm[tid]) cm[tid] = o;
+    __syncthreads();
+  }
+  const long ex = tid + 1 < 256 ? cm[tid + 1] : kMax;
+  for (int t = lo; t < hi; ++t)
+    if (ex < v[t]) v[t] = ex;
+  __syncthreads();
+}
+
 // k2.get_rnnt_prune_ranges + _adjust_pruning_lower_bound; one block per b.
 __global__ __launch_bounds__(256) void prune_ranges_kernel(
     const float* __restrict__ px_grad, const float* __restrict__ py_grad,
     const long* __restrict__ boundary, int S, int T, int s_range, long* __restrict__ ranges) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __shared__ long s_cm[256];
   long* sb = reinterpret_cast<long*>(smem_raw);  // [T]
   const int b = blockIdx.x;
   const int S1 = S + 1;
@@ -339,16 +366,17 @@ __global__ __launch_bounds__(256) void prune_ranges_kernel(
     sb[t] = (t < Tb - 1) ? (long)arg : pad;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  {
+    // monotonic lower bound: reverse cummin, the same after the change of variable, clamp --
+    // as workgroup-wide suffix minima (one thread walking the four passes cost ~60 us of LDS
+    // round trips per launch)
     const long k = s_range - 1;
-    // monotonic lower bound (reverse cummin)
-    for (int t = T - 2; t >= 0; --t)
-      if (sb[t] > sb[t + 1]) sb[t] = sb[t + 1];
-    for (int t = 0; t < T; ++t) sb[t] = -(sb[t] - k * t);
-    for (int t = T - 2; t >= 0; --t)
-      if (sb[t] > sb[t + 1]) sb[t] = sb[t + 1];
-    for (int t = 0; t < T; ++t) {
-      long v = sb[t] < 0 ? 0 : sb[t];  // clamp(min=0): first frame starts at symbol 0
+    block_suffix_min(sb, T, s_cm);
+    for (int t = threadIdx.x; t < T; t += blockDim.x) sb[t] = -(sb[t] - k * t);
+    __syncthreads();
+    block_suffix_min(sb, T, s_cm);
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+      const long v = sb[t] < 0 ? 0 : sb[t];  // clamp(min=0): first frame starts at symbol 0
       sb[t] = -(v - k * t);
     }
   }

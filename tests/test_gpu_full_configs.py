@@ -195,6 +195,24 @@ def test_c3_yaml_size_prune_ranges_bit_exact_given_the_oracles_gradients(dev):
     assert (s0[:, 1:] >= s0[:, :-1]).all() and (s0 >= 0).all() and (s0 + R - 1 <= S).all()
 
 
+@pytest.mark.parametrize("B,T,S,R", [(3, 600, 20, 5), (2, 257, 7, 3), (4, 31, 12, 13)])
+def test_prune_ranges_long_sequences_vs_oracle(dev, B, T, S, R):
+    """The window adjustment (two reverse running minima + clamp) is a workgroup-wide scan in the
+    kernel: sequences longer than the 256 threads of its workgroup (several frames per thread),
+    one frame over, and a window as wide as the label axis -- random gradients, ragged lengths."""
+    from speech2text_amd import kernels as k
+    g = torch.Generator().manual_seed(T + S)
+    gx = torch.randn(B, S, T + 1, generator=g)
+    gy = torch.randn(B, S + 1, T, generator=g)
+    bnd = torch.zeros(B, 4, dtype=torch.int64)
+    bnd[:, 2] = torch.randint(max(1, R - 1), S + 1, (B,), generator=g)
+    bnd[:, 3] = torch.randint(T // 2, T + 1, (B,), generator=g)
+    bnd[0, 2], bnd[0, 3] = S, T
+    ref = K2.get_rnnt_prune_ranges(gx, gy, bnd, R)
+    out = k.rnnt_prune_ranges(gx.to(dev), gy.to(dev), bnd.to(dev), R)
+    assert torch.equal(out.cpu(), ref), float((out.cpu() == ref).float().mean())
+
+
 def test_c3_full_batch_properties(dev):
     from speech2text_amd.build_task import TaskFactory
     from speech2text_amd.trainer import Trainer
