@@ -196,15 +196,19 @@ __device__ __forceinline__ float sum16(float v) {
 // accesses, the two row sums are four DPP adds each, and the next trip's rows are requested
 // before this trip's are reduced (two register sets; row and column indices are clamped instead
 // of branched on, so the loads stay on straight-line code and the compiler counts them).
-// 512-thread workgroups, at most 512 of them: <= 512 atomics per column.
+// 256-thread workgroups, at most 1024 of them.  (The first form of this kernel -- 512 threads, two
+// register sets up to NJ = 4, 204 VGPRs -- measured 29 us alone against 44 for the 4-byte kernel
+// and 92-255 us IN the step against 40: a workgroup that needs two 204-register waves on every
+// SIMD of a CU at once cannot start while the side stream's weight-gradient workgroups are
+// resident.  Main-stream kernels must fit NEXT to them: small workgroups, <= 128 registers.)
 template <int NJ>
-__global__ __launch_bounds__(512) void biasnorm_bwd_v4_kernel(
+__global__ __launch_bounds__(256) void biasnorm_bwd_v4_kernel(
     const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ scales,
     const float* __restrict__ g, long rows, int D, float* __restrict__ dx,
     float* __restrict__ dbias, float* __restrict__ dls) {
   typedef float f4 __attribute__((ext_vector_type(4)));
   const int lane = threadIdx.x & 63, l16 = lane & 15, sub = lane >> 4, wv = threadIdx.x >> 6;
-  const long wave = (long)blockIdx.x * 8 + wv, nwaves = (long)gridDim.x * 8;
+  const long wave = (long)blockIdx.x * 4 + wv, nwaves = (long)gridDim.x * 4;
   const long nquads = (rows + 3) >> 2;
   f4 b[NJ], db[NJ];
   int col[NJ];
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(512) void biasnorm_bwd_v4_kernel(
     }                                                                        \
   }
 
-  if constexpr (NJ <= 4) {
+  if constexpr (NJ <= 2) {
     f4 xa[NJ], ga[NJ], xb[NJ], gb[NJ];
     float sa, sb;
     long q = wave;
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(512) void biasnorm_bwd_v4_kernel(
       BN_LOAD(xa, ga, sa, q + 2 * nwaves)
       BN_STEP(xb, gb, sb, q + nwaves)
     }
-  } else {            // wide rows: one register set (two would spill), the other waves cover the latency
+  } else {            // wider rows: one register set; the CU's other waves cover the latency
     f4 xa[NJ], ga[NJ];
     float sa;
     for (long q = wave; q < nquads; q += nwaves) {
@@ -282,8 +286,8 @@ __global__ __launch_bounds__(512) void biasnorm_bwd_v4_kernel(
 
   // the wave's four rows-of-lanes hold partial sums of the same columns: add them up in the wave,
   // then the eight waves through LDS, then one atomic per column per workgroup
-  __shared__ float s_db[8][64 * NJ];
-  __shared__ float s_dl[8];
+  __shared__ float s_db[4][64 * NJ];
+  __shared__ float s_dl[4];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     f4 t = db[j];
@@ -299,16 +303,16 @@ __global__ __launch_bounds__(512) void biasnorm_bwd_v4_kernel(
   dl = wave_sum(dl);
   if (lane == 0) s_dl[wv] = dl;
   __syncthreads();
-  for (int c = threadIdx.x; c < D; c += 512) {
+  for (int c = threadIdx.x; c < D; c += 256) {
     float t = 0.f;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) t += s_db[w][c];
+    for (int w = 0; w < 4; ++w) t += s_db[w][c];
     if (t != 0.f) atomicAdd(&dbias[c], t);
   }
   if (threadIdx.x == 0) {
     float tl = 0.f;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) tl += s_dl[w];
+    for (int w = 0; w < 4; ++w) tl += s_dl[w];
     if (tl != 0.f) atomicAdd(dls, tl);
   }
 }
@@ -470,13 +474,18 @@ extern "C" int s2t_biasnorm_bwd(const float* x, const float* bias, const float* 
                                 float* dls, void* stream) {
   if (rows <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  static const bool v4 = [] { const char* e = getenv("S2T_BIASNORM_V4"); return !e || atoi(e) != 0; }();
+  // S2T_BIASNORM_V4=1 selects the 16-byte kernel (read per call: the tests switch it).  OFF by
+  // default: 29 / 25 us against 44 / 27 alone (31 680 x 192 / 15 872 x 256, caches flushed), but
+  // 78-99 us against 40 IN the step -- its 94-120 registers leave it two waves per SIMD next to
+  // the side stream's resident weight-gradient workgroups, where the 4-byte kernel keeps four.
+  const char* e4 = getenv("S2T_BIASNORM_V4");
+  const bool v4 = e4 && atoi(e4) != 0;
   if (v4 && D % 4 == 0 && D >= 4 && D <= 512 && rows * (long)D < (1L << 31) &&
       (((uintptr_t)x | (uintptr_t)g | (uintptr_t)dx | (uintptr_t)bias) & 15) == 0) {
     const long nquads = (rows + 3) / 4;
-    const unsigned nbv = (unsigned)std::min<long>((nquads + 7) / 8, 512);
+    const unsigned nbv = (unsigned)std::min<long>((nquads + 3) / 4, 1024);
 #define BN_V4(NJ)                                                                                 \
-  hipLaunchKernelGGL(biasnorm_bwd_v4_kernel<NJ>, dim3(nbv), dim3(512), 0, st, x, bias, scales, g, \
+  hipLaunchKernelGGL(biasnorm_bwd_v4_kernel<NJ>, dim3(nbv), dim3(256), 0, st, x, bias, scales, g, \
                      rows, D, dx, dbias, dls)
     switch ((D + 63) / 64) {
       case 1: BN_V4(1); break;

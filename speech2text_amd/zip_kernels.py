@@ -1334,8 +1334,8 @@ def x3p_matmul(mode, x2, w2, bias=None, resid2=None, act_src=None, act_kind=None
         return out if out2 is None else (out, out2)
     if N._Prof.target is not None:
         extra = sum(t is not None for t in (resid2, act_src, out2, resid_b))
-        N.PROF[0] and N.profile_note("s2t_gemm_x3p", 4.0 * R * (Nf + Kf + extra * cols) + 6.0 * Nf * Kf,
-                       2.0 * R * Nf * Kf)
+        N.profile_note("s2t_gemm_x3p", 4.0 * R * (Nf + Kf + extra * cols) + 6.0 * Nf * Kf,
+                       2.0 * R * Nf * Kf)             # (_native.SELF_NOTING: not behind N.PROF)
     if colstats is not None:
         rc = N.lib().s2t_gemm_x3p_stats(_vp(x2), x2.stride(0), ctypes.c_void_p(pp), cols, inner, _vp(out),
                                         cols, R, _vp(bias), _vp(resid2),

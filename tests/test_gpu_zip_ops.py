@@ -115,10 +115,13 @@ def test_swoosh_and_biasnorm(dev, is_l):
 
 @pytest.mark.parametrize("rows,D", [(37 * 5, 192), (1031, 256), (4, 8), (3, 64), (257, 200), (130, 384),
                                     (66, 512), (9000, 192)])
-def test_biasnorm_backward_16_byte_path(dev, rows, D):
-    """the D % 4 == 0 kernel (a 16-lane row of a wave per matrix row, prefetched trips) against the
-    oracle: row counts that are not multiples of four, partial last column group, wide rows"""
+@pytest.mark.parametrize("v4", ["1", "0"])
+def test_biasnorm_backward_16_byte_path(dev, rows, D, v4, monkeypatch):
+    """the D % 4 == 0 kernel (a 16-lane row of a wave per matrix row; S2T_BIASNORM_V4=1, off by
+    default) and the default kernel against the oracle: row counts that are not multiples of four,
+    partial last column group, wide rows"""
     from speech2text_amd import zip_kernels as zk
+    monkeypatch.setenv("S2T_BIASNORM_V4", v4)
     torch.manual_seed(rows + D)
     x = torch.randn(rows, D) * 2
     bias = torch.randn(D) * 0.1
