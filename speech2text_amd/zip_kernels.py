@@ -1147,7 +1147,13 @@ _EXT = {}
 _WGRAD_SIDE = os.environ.get("S2T_WGRAD_SIDE_MORE", "1") == "1"
 
 
-def side_param_grads(params, compute, keep=()):
+# which of the FRONTEND's parameter gradients fork to the side stream (bits: 1 = the 7x7 depthwise,
+# 2 = the 3x3 convs' implicit-im2col products, 4 = the 600 k-row Linears).  Its backward is a run of
+# HBM-bound passes over 300-900 MB maps: two of them at once share the same bandwidth.
+_FRONT_SIDE = int(os.environ.get("S2T_FRONT_W_SIDE", "7"))
+
+
+def side_param_grads(params, compute, keep=(), allow=True):
     """Parameter gradients that only feed the optimizer, off the data-gradient chain: when every
     parameter of `params` (None entries allowed) is a leaf whose `.grad` is a flat-store view and a
     backward pass is running, `compute()` -- the launches that produce the gradients, in the
@@ -1155,7 +1161,7 @@ def side_param_grads(params, compute, keep=()):
     after the work enqueued so far), its results are added into the `.grad` views there, and a
     list of None is returned for autograd; operands in `keep` stay referenced until the join.
     Otherwise `compute()` runs on the current stream and its tensors are returned."""
-    ok = _WGRAD_SIDE and _Side.enabled
+    ok = allow and _WGRAD_SIDE and _Side.enabled
     if ok:
         for q in params:
             if q is None:
@@ -1215,7 +1221,7 @@ def wgrad_into(wparam, bparam, g2, a2, pro=0, notify=False):
     # gives back -- measured on the conformer step; the grouped per-layer launch below does fork,
     # and so do the few products big enough to matter: the frontend's 600 k-row maps)
     st = None
-    if _WGRAD_SIDE and 2.0 * g2.shape[0] * g2.shape[1] * a2.shape[1] >= 2.0e10:
+    if _WGRAD_SIDE and (_FRONT_SIDE & 4) and 2.0 * g2.shape[0] * g2.shape[1] * a2.shape[1] >= 2.0e10:
         st = _side_launch_stream(g2, a2)
     gemm_tn(g2, a2, wg, bg, pro, stream=st)
     if notify:
@@ -1716,7 +1722,8 @@ class _Conv3x3Nhwc(torch.autograd.Function):
         g = g if g.is_contiguous() else g.contiguous()
         if ctx.implicit:
             dweight, db = side_param_grads(
-                ctx.params, lambda: list(_conv3x3_wgrad_implicit(xc, g, sh, sw, has_bias)), keep=(xc, g))
+                ctx.params, lambda: list(_conv3x3_wgrad_implicit(xc, g, sh, sw, has_bias)), keep=(xc, g),
+                allow=bool(_FRONT_SIDE & 2))
         else:
             dwmat, db = linear_wgrad(g, xc, has_bias)                            # (Cout, 9C)
             dweight = dwmat.view(Cout, 3, 3, C).permute(0, 3, 1, 2)
@@ -1906,7 +1913,7 @@ class _DwConv2dNhwc(torch.autograd.Function):
             N.check(L.s2t_dwconv2d_nhwc_fwd(N.fp(dy), N.fp(w), None, Nn, H, W, C, KH, KW, 1,
                                             N.fp(dx), N.stream()), "s2t_dwconv2d_nhwc_bwd_data")
         dw, db = side_param_grads(ctx.params, lambda: _dwconv_wgrad(x, dy, w, ctx.has_bias, ctx.wshape),
-                                  keep=(x, dy))
+                                  keep=(x, dy), allow=bool(_FRONT_SIDE & 1))
         return dx, dw, db
 
 
@@ -1944,7 +1951,7 @@ class _DwConv2dTap(torch.autograd.Function):
             N.check(L.s2t_dwconv2d_nhwc_fwd_add(N.fp(dy), N.fp(w), None, N.fp(gp), Nn, H, W, C, KH, KW,
                                                 1, N.fp(dx), N.stream()), "s2t_dwconv2d_nhwc_bwd_data")
         dw, db = side_param_grads(ctx.params, lambda: _dwconv_wgrad(x, dy, w, ctx.has_bias, ctx.wshape),
-                                  keep=(x, dy))
+                                  keep=(x, dy), allow=bool(_FRONT_SIDE & 1))
         return dx, dw, db
 
 
