@@ -8,8 +8,14 @@ import collections, csv, sys, bisect
 def load(path, steps, ms):
     tr = list(csv.DictReader(open(path)))
     if "Start_Timestamp" in tr[0]:
+        def grid(r):
+            if "Grid_Size_X" in r:            # work-items per dimension / workgroup size
+                g = [int(r.get("Grid_Size_" + a, 1) or 1) for a in "XYZ"]
+                w = [int(r.get("Workgroup_Size_" + a, 1) or 1) for a in "XYZ"]
+                return "%dx%d" % (g[0] * g[1] * g[2] // max(1, w[0] * w[1] * w[2]), w[0] * w[1] * w[2])
+            return r.get("Grid_Size", "")
         rows = [(r["Kernel_Name"], r.get("Queue_Id", "0"), int(r["Start_Timestamp"]), int(r["End_Timestamp"]),
-                 r.get("Grid_Size", "")) for r in tr]
+                 grid(r)) for r in tr]
     else:
         rows = [(r["name"], r["queue"], int(r["start"]), int(r["end"]), r["grid"]) for r in tr]
     tend = max(r[3] for r in rows)
