@@ -315,6 +315,14 @@ int s2t_gemm_f32(int mode, const float* A, long lda, const float* B, long ldb, f
                  const float* act_src, long lds, int act_kind, int pro_a, int pro_b, float* colsum,
                  int accumulate, void* stream);
 
+/* `batch` independent fp32 products in one launch (bf16x3 matrix cores), X_b = X + b * sX floats:
+ * mode 0: C_b[M,N] = A_b[M,K] . B_b[N,K]^T; mode 1: C_b = A_b[M,K] . B_b[K,N];
+ * mode 2: C_b[M,N] += A_b[K,M]^T . B_b[K,N] (fp32 atomics: zero C first).  Replaces torch.bmm in
+ * the nonlinear attention (reference model/encoder/zipformer.py:2438-2483: attn_weights[0] @ x and
+ * its two gradients).  -2 = alignment rules of s2t_gemm_f32 not met (keep the library). */
+int s2t_gemm_f32_batched(int mode, const float* A, long lda, long sA, const float* B, long ldb, long sB,
+                         float* C, long ldc, long sC, int M, int N, int K, int batch, void* stream);
+
 /* s2t_gemm_f32 modes 0 (NT) / 1 (NN) with the block tile chosen by the caller: tile = "tm tn"
  * digits for a (64 tm) x (64 tn) tile, one of 11 12 21 22 23; 0 = the dispatcher's choice. */
 int s2t_gemm_f32_tiled(int mode, const float* A, long lda, const float* B, long ldb, float* C,

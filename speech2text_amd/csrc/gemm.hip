@@ -535,6 +535,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   gemm_body<TM, TN, MODE, PRO, X3, PATCH, P3>(g, blockIdx.x);
 }
 
+// ---- batched: blockIdx.y = batch item, operands `stride` floats apart (the nonlinear attention's
+// W0 @ x products: 64 independent T x T x C problems that rocBLAS' strided-batched kernels run
+// at 20-30 TFLOP/s at T = 248).
+template <int TM, int TN, int MODE>
+__global__ __launch_bounds__(256) void gemm_batched_kernel(GemmArgs g, long sA, long sB, long sC) {
+  GemmArgs h = g;
+  h.A += (long)blockIdx.y * sA;
+  h.B += (long)blockIdx.y * sB;
+  h.C += (long)blockIdx.y * sC;
+  gemm_body<TM, TN, MODE, ACT_NONE, true, false, (MODE == MODE_TN)>(h, blockIdx.x);
+}
+
 // ---- grouped TN: the weight-gradient GEMMs of one layer in ONE launch.  Each problem keeps its
 // own (tiles x slices) block range (a multiple of 8 blocks, so the slice -> XCD mapping of the
 // single-problem launch holds); a block finds its problem by a scan of the prefix table.
@@ -710,6 +722,51 @@ extern "C" int s2t_gemm_f32(int mode, const float* A, long lda, const float* B, 
   else if (mode == MODE_TN) rc = dispatch<MODE_TN>(g, st);
   else return -1;
   return rc;
+}
+
+// `batch` independent products in one launch (bf16x3 matrix-core arithmetic, fp32-level error):
+//   mode 0 (NT): C_b[M,N]  = A_b[M,K] . B_b[N,K]^T      mode 1 (NN): C_b[M,N] = A_b[M,K] . B_b[K,N]
+//   mode 2 (TN): C_b[M,N] += A_b[K,M]^T . B_b[K,N]      (ADDED with fp32 atomics: zero C first)
+// X_b = X + b * sX floats.  Same alignment rules as s2t_gemm_f32 (every k-contiguous operand needs
+// K % 4 == 0, every row start 16-byte aligned, strides included): -2 when they do not hold -- the
+// caller keeps the library for such shapes (T = 495, 62 of the C3 stacks).
+extern "C" int s2t_gemm_f32_batched(int mode, const float* A, long lda, long sA, const float* B,
+                                    long ldb, long sB, float* C, long ldc, long sC, int M, int N,
+                                    int K, int batch, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return 0;
+  if (mode < 0 || mode > 2 || batch > 65535) return -1;
+  const bool a_kc = mode != MODE_TN, b_kc = mode == MODE_NT;
+  if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15) ||
+      (reinterpret_cast<uintptr_t>(C) & 15) || (lda & 3) || (ldb & 3) || (sA & 3) || (sB & 3) || (sC & 3))
+    return -2;
+  if ((a_kc || b_kc) && (K & 3)) return -2;
+  if ((!a_kc && (M & 3)) || (!b_kc && (N & 3))) return -2;
+  if (M < 4 || N < 4 || K < 4) return -2;
+  GemmArgs g{A, lda, B, ldb, C, ldc, M, N, K, nullptr, nullptr, 0, nullptr, 0, 0, 0,
+             0, nullptr, 0, 0, 0, 0, 0, 0, 1.f, 0};
+  hipStream_t st = (hipStream_t)stream;
+  g.tiles_m = (M + 63) / 64;
+  g.tiles_n = (N + 63) / 64;
+  const int total = g.tiles_m * g.tiles_n;
+  if (mode == MODE_TN) {
+    // the contraction is short (K = T): at most a few slices, each a multiple of the staging depth
+    int splits = std::max(1, std::min(8, K / (2 * KR)));
+    int kper = (K + splits - 1) / splits;
+    kper = ((kper + KR - 1) / KR) * KR;
+    g.kper = kper;
+    g.splits = (K + kper - 1) / kper;
+    const unsigned grid = (unsigned)(8 * total * ((g.splits + 7) / 8));
+    hipLaunchKernelGGL((gemm_batched_kernel<1, 1, MODE_TN>), dim3(grid, batch), dim3(256), 0, st, g, sA, sB, sC);
+  } else {
+    g.splits = 1;
+    g.wide_ep = (N & 3) == 0 && (ldc & 3) == 0;
+    const unsigned grid = (unsigned)(((total + 7) / 8) * 8);
+    if (mode == MODE_NT)
+      hipLaunchKernelGGL((gemm_batched_kernel<1, 1, MODE_NT>), dim3(grid, batch), dim3(256), 0, st, g, sA, sB, sC);
+    else
+      hipLaunchKernelGGL((gemm_batched_kernel<1, 1, MODE_NN>), dim3(grid, batch), dim3(256), 0, st, g, sA, sB, sC);
+  }
+  return (int)hipGetLastError();
 }
 
 // s2t_gemm_f32 (modes 0 / 1) with the block tile chosen by the caller: tile = "tm tn" digits, block

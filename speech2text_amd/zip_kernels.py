@@ -1231,6 +1231,45 @@ def wgrad_into(wparam, bparam, g2, a2, pro=0, notify=False):
     return True
 
 
+_BMM_OWN = os.environ.get("S2T_BMM_OWN", "1") == "1"
+
+
+def batched_matmul(mode, a, b):
+    """Batch of independent fp32 products (the nonlinear attention's attn_weights[0] @ x and its
+    two gradients, reference zipformer.py:2438-2483), contiguous 3-D operands:
+      mode 0: a (n,M,K) b (n,N,K) -> a @ b^T;  mode 1: a (n,M,K) b (n,K,N) -> a @ b;
+      mode 2: a (n,K,M) b (n,K,N) -> a^T @ b.
+    Modes 0 / 1: one launch of our bf16x3 kernel (s2t_gemm_f32_batched); torch.bmm (rocBLAS) for
+    mode 2 and for the shapes the kernel's alignment rules refuse (T = 495, 62)."""
+    n = a.shape[0]
+    if mode == 0:
+        M, K, Nn = a.shape[1], a.shape[2], b.shape[1]
+    elif mode == 1:
+        M, K, Nn = a.shape[1], a.shape[2], b.shape[2]
+    else:
+        M, K, Nn = a.shape[2], a.shape[1], b.shape[2]
+    # measured at the C3 shapes (tools/debug/bmm_test.py, 64 x 248 x 248 x 192): a @ b 26 us against
+    # 55, a @ b^T 21 against 69; the a^T @ b form (split contraction + atomics) 120 against 55 --
+    # that one stays with the library, as do the shapes the kernel's alignment rules refuse
+    if (_BMM_OWN and mode != 2 and K % 4 == 0 and (mode == 0 or Nn % 4 == 0) and min(M, Nn, K) >= 4
+            and a.is_cuda and a.dtype is torch.float32 and b.dtype is torch.float32
+            and a.is_contiguous() and b.is_contiguous() and n > 0):
+        out = torch.empty((n, M, Nn), dtype=torch.float32, device=a.device)
+        N.PROF[0] and N.profile_note("s2t_gemm_f32_batched", 4.0 * (a.numel() + b.numel() + out.numel()),
+                                     2.0 * n * M * Nn * K)
+        rc = N.lib().s2t_gemm_f32_batched(mode, N.fp(a), a.stride(1), a.stride(0), N.fp(b), b.stride(1),
+                                          b.stride(0), N.fp(out), Nn, M * Nn, M, Nn, K, n, N.stream())
+        if rc == 0:
+            return out
+        if rc != -2:
+            N.check(rc, "s2t_gemm_f32_batched")
+    if mode == 0:
+        return torch.bmm(a, b.transpose(1, 2))
+    if mode == 1:
+        return torch.bmm(a, b)
+    return torch.bmm(a.transpose(1, 2), b)
+
+
 class TnProblem(ctypes.Structure):
     """Mirror of S2tTnProblem (include/s2t_mi355.h)."""
     _fields_ = [("A", ctypes.c_void_p), ("lda", ctypes.c_long), ("B", ctypes.c_void_p),

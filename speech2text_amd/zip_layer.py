@@ -384,7 +384,7 @@ def _na_fwd(m, dec, x_in, W, T, B):
     N.PROF[0] and N.profile_note("s2t_nonlin_gate_fwd", 12.0 * T * B * C)
     N.check(L.s2t_nonlin_gate_fwd(N.fp(sv.u), T, B, C, N.fp(sv.xs), st), "nonlin_gate_fwd")
     sv.wm = W[0]                                                             # (B,T,T)
-    sv.z = torch.bmm(sv.wm, sv.xs)                                           # rocBLAS
+    sv.z = zk.batched_matmul(1, sv.wm, sv.xs)                                # W0 @ x, (B,T,C)
     sv.o = _e(T * B, C, dev)
     N.PROF[0] and N.profile_note("s2t_nonlin_out_fwd", 12.0 * T * B * C)
     N.check(L.s2t_nonlin_out_fwd(N.fp(sv.z), N.fp(sv.u), T, B, C, N.fp(sv.o), st),
@@ -424,7 +424,7 @@ def _na_bwd(m, post, dec, sv, x_in, g, T, B):
     N.check(L.s2t_nonlin_out_bwd(N.fp(do), N.fp(sv.z), N.fp(sv.u), T, B, C, N.fp(dz), N.fp(du), st),
             "nonlin_out_bwd")
     dxs = torch.bmm(sv.wm.transpose(1, 2), dz)
-    dW0 = torch.bmm(dz, sv.xs.transpose(1, 2))
+    dW0 = zk.batched_matmul(0, dz, sv.xs)                                    # dz @ x^T, (B,T,T)
     N.PROF[0] and N.profile_note("s2t_nonlin_gate_bwd", 20.0 * T * B * C)
     N.check(L.s2t_nonlin_gate_bwd(N.fp(dxs), N.fp(sv.u), T, B, C, N.fp(du), st), "nonlin_gate_bwd")
     if fb:

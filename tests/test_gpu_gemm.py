@@ -516,3 +516,33 @@ def test_nonfinite_weight_gradient_reaches_the_scaled_adam_guard(dev):
     assert torch.isfinite(opt._delta).all() and torch.isfinite(opt._eas).all()
     # the step applied only the momentum of earlier steps (its own gradient counted as zero)
     assert (W.detach() - before).abs().max().item() < 0.05
+
+
+@pytest.mark.parametrize("n,M,N,K", [(5, 100, 36, 100), (64, 248, 192, 248), (3, 124, 124, 192), (2, 8, 4, 4),
+                                     (4, 70, 52, 36)])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_batched_products_have_fp32_accuracy(dev, mode, n, M, N, K):
+    """s2t_gemm_f32_batched (the nonlinear attention's attn_weights[0] @ x and its gradients): the
+    three operand layouts against fp64, and zk.batched_matmul's routing (own kernel for a @ b and
+    a @ b^T, the library for a^T @ b and for shapes outside the alignment rules)."""
+    import ctypes
+    from speech2text_amd import _native as Nt
+    from speech2text_amd import zip_kernels as zk
+    torch.manual_seed(n + M + N + K + mode)
+    shp_a = (n, M, K) if mode != 2 else (n, K, M)
+    shp_b = (n, N, K) if mode == 0 else (n, K, N)
+    a, b = torch.randn(shp_a, device=dev), torch.randn(shp_b, device=dev)
+    ad, bd = a.double(), b.double()
+    ref = {0: lambda: ad @ bd.transpose(1, 2), 1: lambda: ad @ bd, 2: lambda: ad.transpose(1, 2) @ bd}[mode]()
+    out = torch.zeros((n, M, N), device=dev)
+    rc = Nt.lib().s2t_gemm_f32_batched(mode, Nt.fp(a), a.stride(1), a.stride(0), Nt.fp(b), b.stride(1),
+                                       b.stride(0), Nt.fp(out), N, M * N, M, N, K, n, Nt.stream())
+    ok_shape = (K % 4 == 0) if mode == 0 else ((K % 4 == 0 and N % 4 == 0) if mode == 1 else
+                                               (M % 4 == 0 and N % 4 == 0))
+    assert rc == (0 if ok_shape else -2)
+    scale = ref.abs().max().item()
+    if rc == 0:
+        assert ((out.double() - ref).abs().max().item()) <= 4e-6 * scale
+    y = zk.batched_matmul(mode, a, b)
+    assert ((y.double() - ref).abs().max().item()) <= 4e-6 * scale
+
