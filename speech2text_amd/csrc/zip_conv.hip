@@ -194,7 +194,7 @@ __device__ __forceinline__ void stage_xg_buf(const ConvArgs& a, int b, int t0, i
   }
 }
 
-template <int K, bool GEN, bool EDGE>
+template <int K, bool GEN, bool EDGE, int SB = 0>   // SB: see zipconv_bwd_w_kernel
 __global__ __launch_bounds__(256) void zipconv_fwd_kernel(ConvArgs a, float* __restrict__ y) {
   constexpr int Kh = (K + 1) / 2, halo = K / 2, W = FPT + 2 * halo;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void zipconv_fwd_kernel(ConvArgs a, float* __r
   // channel tile fastest, then utterance, then frame tile: workgroups that are dispatched together
   // read neighbouring pieces of the same (t, b) rows (rows of adjacent b are adjacent in memory)
   const int c0 = blockIdx.x * 64, b = blockIdx.y, t0 = tile_z(a) * TT;
-  const int c = threadIdx.x & 63, tg = threadIdx.x >> 6;
+  const int c = threadIdx.x & 63, tg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: frame indices and chunk tests stay wave-uniform)
   stage_weights<K>(a, c0, s_wc, s_wk, s_le, s_re,
                    EDGE && (GEN || t0 - K / 2 < K || t0 + TT + K / 2 > a.T - K));
   if (buf_ok(a)) stage_xg_buf<K>(a, b, t0, c0, s_x);
@@ -242,6 +242,22 @@ __global__ __launch_bounds__(256) void zipconv_fwd_kernel(ConvArgs a, float* __r
       const float w = s_wk[j * 64 + c];
 #pragma unroll
       for (int i = 0; i < FPT; ++i) acck[i] = fmaf(w, win[i + j], acck[i]);
+    }
+  } else if constexpr (SB > 0) {
+    // sub-blocks of SB frames inside one chunk each: mask the window once, plain multiply-adds
+#pragma unroll
+    for (int sb = 0; sb < FPT / SB; ++sb) {
+      constexpr int WM = SB + K - 1;
+      const int i0 = sb * SB, lo = ((tb + i0) / chunk) * chunk - (tb - halo + i0);
+      float wm[WM];
+#pragma unroll
+      for (int w = 0; w < WM; ++w) wm[w] = (w >= lo && w < lo + chunk) ? win[i0 + w] : 0.f;
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        const float w = s_wk[j * 64 + c];
+#pragma unroll
+        for (int i = 0; i < SB; ++i) acck[i0 + i] = fmaf(w, wm[i + j], acck[i0 + i]);
+      }
     }
   } else {
     int cs[FPT];
@@ -289,7 +305,7 @@ __global__ __launch_bounds__(256) void zipconv_fwd_kernel(ConvArgs a, float* __r
 }
 
 // du[t'] : gradient w.r.t. the projection (x half and gate half)
-template <int K, bool GEN, bool EDGE>
+template <int K, bool GEN, bool EDGE, int SB = 0>   // SB: see zipconv_bwd_w_kernel
 __global__ __launch_bounds__(256) void zipconv_bwd_data_kernel(ConvArgs a,
                                                                const float* __restrict__ dy,
                                                                float* __restrict__ du) {
@@ -303,7 +319,7 @@ __global__ __launch_bounds__(256) void zipconv_bwd_data_kernel(ConvArgs a,
   // channel tile fastest, then utterance, then frame tile: workgroups that are dispatched together
   // read neighbouring pieces of the same (t, b) rows (rows of adjacent b are adjacent in memory)
   const int c0 = blockIdx.x * 64, b = blockIdx.y, t0 = tile_z(a) * TT;
-  const int c = threadIdx.x & 63, tg = threadIdx.x >> 6;
+  const int c = threadIdx.x & 63, tg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: frame indices and chunk tests stay wave-uniform)
   // (block-uniform) some frame of the tile or its halo lies within K of a chunk edge
   const bool near_edge = EDGE && (GEN || t0 - K / 2 < K || t0 + TT + K / 2 > a.T - K);
   stage_weights<K>(a, c0, s_wc, s_wk, s_le, s_re, near_edge);
@@ -435,6 +451,21 @@ __global__ __launch_bounds__(256) void zipconv_bwd_data_kernel(ConvArgs a,
 #pragma unroll
       for (int i = 0; i < FPT; ++i) acc[i] = fmaf(w, win[i + 2 * halo - j], acc[i]);
     }
+  } else if constexpr (SB > 0) {
+#pragma unroll
+    for (int sb = 0; sb < FPT / SB; ++sb) {
+      constexpr int WM = SB + K - 1;
+      const int i0 = sb * SB, lo = ((tb + i0) / chunk) * chunk - (tb - halo + i0);
+      float wm[WM];
+#pragma unroll
+      for (int w = 0; w < WM; ++w) wm[w] = (w >= lo && w < lo + chunk) ? win[i0 + w] : 0.f;
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        const float w = s_wk[j * 64 + c];
+#pragma unroll
+        for (int i = 0; i < SB; ++i) acc[i0 + i] = fmaf(w, wm[i + 2 * halo - j], acc[i0 + i]);
+      }
+    }
   } else {
     int cs[FPT];
 #pragma unroll
@@ -503,7 +534,13 @@ __global__ __launch_bounds__(256) void zipconv_bwd_data_kernel(ConvArgs a,
 // weight / bias gradients; block = (t-tile, group of BB utterances, c-tile).  Each block
 // writes its partial sums to part[block][NV][64 ch] (NV = Kh + 1 + K + 1); zipconv_reduce_w_kernel
 // sums over blocks -- no atomics (contended float atomics on a few KB run ~14x slower).
-template <int K, bool GEN, bool EDGE>
+// GEN with SB > 0 (chunk a power of two, SB = min(chunk, FPT)): the FPT frames of a thread fall
+// into FPT / SB sub-blocks that lie in ONE chunk each, so "tap j of frame i is inside the chunk"
+// does not depend on (i, j) separately -- it is a property of the WINDOW element i + j.  Each
+// sub-block masks its SB + K - 1 window elements once and runs the plain multiply-adds; the
+// per-(frame, tap) test (SB = 0, any chunk) cost three instructions per multiply-add: 218 us
+// against 55 for the unchunked kernel at T = 495.
+template <int K, bool GEN, bool EDGE, int SB = 0>
 __global__ __launch_bounds__(256) void zipconv_bwd_w_kernel(ConvArgs a,
                                                             const float* __restrict__ dy, int BB,
                                                             float* __restrict__ part,
@@ -518,7 +555,7 @@ __global__ __launch_bounds__(256) void zipconv_bwd_w_kernel(ConvArgs a,
   float* s_red = s_wk + (EDGE ? 3 : 1) * K * 64;  // [4][64] reduction scratch
   const int tz = tile_z(a);
   const int c0 = blockIdx.x * 64, t0 = tz * TT;
-  const int c = threadIdx.x & 63, tg = threadIdx.x >> 6;
+  const int c = threadIdx.x & 63, tg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: frame indices and chunk tests stay wave-uniform)
   const int tb = t0 + tg * FPT;
   const int chunk = a.chunk;
   stage_weights<K>(a, c0, s_wc, s_wk, s_le, s_re,
@@ -570,6 +607,49 @@ __global__ __launch_bounds__(256) void zipconv_bwd_w_kernel(ConvArgs a,
     float win[W];
 #pragma unroll
     for (int w = 0; w < W; ++w) win[w] = s_x[(tg * FPT + w) * 64 + c];
+    if constexpr (GEN && SB > 0) {
+      // causal-conv taps and the bias sums first (they see the unmasked window) ...
+#pragma unroll
+      for (int i = 0; i < FPT; ++i) {
+        const float g = (tb + i < a.T) ? gpre[i] : 0.f;
+        pbc += g;
+        pbk += g * sc[i];
+        if (a.wc) {
+#pragma unroll
+          for (int j = 0; j < Kh; ++j) pwc[j] = fmaf(g, win[i + j], pwc[j]);
+        }
+      }
+      // ... then, sub-block by sub-block, the window with everything outside the sub-block's chunk
+      // zeroed (wave-uniform tests: tb, cs are scalar)
+#pragma unroll
+      for (int sb = 0; sb < FPT / SB; ++sb) {
+        constexpr int WM = SB + K - 1;
+        const int i0 = sb * SB, lo = cs[i0] - (tb - halo + i0);   // window index of the chunk's first frame
+        float wm[WM];
+#pragma unroll
+        for (int w = 0; w < WM; ++w) wm[w] = (w >= lo && w < lo + chunk) ? win[i0 + w] : 0.f;
+        if (edge) {
+          float ak[SB];
+#pragma unroll
+          for (int i = 0; i < SB; ++i) ak[i] = bkv;
+#pragma unroll
+          for (int j = 0; j < K; ++j) {
+            const float w = s_wk[j * 64 + c];                 // one LDS read per tap, SB uses
+#pragma unroll
+            for (int i = 0; i < SB; ++i) ak[i] = fmaf(w, wm[i + j], ak[i]);
+          }
+#pragma unroll
+          for (int i = 0; i < SB; ++i)
+            if (tb + i0 + i < a.T) ds[i0 + i] = fmaf(gpre[i0 + i], ak[i], ds[i0 + i]);
+        }
+#pragma unroll
+        for (int i = 0; i < SB; ++i) {
+          const float gs = ((tb + i0 + i < a.T) ? gpre[i0 + i] : 0.f) * sc[i0 + i];
+#pragma unroll
+          for (int j = 0; j < K; ++j) pwk[j] = fmaf(gs, wm[i + j], pwk[j]);
+        }
+      }
+    } else {
     if (edge) {
       float ak[FPT];
 #pragma unroll
@@ -607,6 +687,7 @@ __global__ __launch_bounds__(256) void zipconv_bwd_w_kernel(ConvArgs a,
           if (tt >= cs[i] && tt < cs[i] + chunk) pwk[j] = fmaf(gs, win[i + j], pwk[j]);
         }
       }
+    }
     }
   }
   if (edge && chan_ok) {
@@ -666,7 +747,7 @@ __global__ __launch_bounds__(256) void zipconv_bwd_fused_kernel(ConvArgs a,
   float* s_red = s_re + K * 64;                      // [4][64] reduction scratch
   const int tz = tile_z(a);
   const int c0 = blockIdx.x * 64, t0 = tz * TT;
-  const int c = threadIdx.x & 63, tg = threadIdx.x >> 6;
+  const int c = threadIdx.x & 63, tg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: frame indices and chunk tests stay wave-uniform)
   const int rig = threadIdx.x >> 4, c4 = threadIdx.x & 15, ch = c0 + 4 * c4;
   const int tb = t0 + tg * FPT;
   const int chunk = a.chunk;
@@ -973,6 +1054,21 @@ struct ZSplit {
   void set_edge(ConvArgs& a) const { a.z_base = 0; a.z_split = n_lo; a.z_jump = n_hi - n_lo; a.nt = nt; }
 };
 
+// sub-block size of the chunked (GEN) kernels' masked-window form: min(chunk, FPT) when chunk is a
+// power of two (every chunk_size / downsampling pair of the YAMLs), 0 = the per-tap test
+static int conv_subblock(int chunk) {
+  static const bool on = [] { const char* e = getenv("S2T_CONV_SUBBLOCK"); return !e || atoi(e) != 0; }();
+  return (on && chunk >= 2 && (chunk & (chunk - 1)) == 0) ? std::min(chunk, FPT) : 0;
+}
+#define S2T_CONV_GEN_SB(SBSEL, LAUNCH) \
+  switch (SBSEL) {                     \
+    case 16: { constexpr int SBV = 16; LAUNCH; } break; \
+    case 8: { constexpr int SBV = 8; LAUNCH; } break;   \
+    case 4: { constexpr int SBV = 4; LAUNCH; } break;   \
+    case 2: { constexpr int SBV = 2; LAUNCH; } break;   \
+    default: { constexpr int SBV = 0; LAUNCH; } break;  \
+  }
+
 extern "C" int s2t_zipconv_fwd(const float* u, long ld, int gate_off, const unsigned char* mask,
                                int T, int B, int C, int K, int chunk, const float* wc,
                                const float* bc, const float* wk, const float* bk,
@@ -996,8 +1092,9 @@ extern "C" int s2t_zipconv_fwd(const float* u, long ld, int gate_off, const unsi
       S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_fwd_kernel<KK, false, true>), grid, dim3(256),
                                               conv_smem<KK>(false, 1, true), st, a, y));
     } else {
-      S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_fwd_kernel<KK, true, true>), grid, dim3(256),
-                                              conv_smem<KK>(false, 1, true), st, a, y));
+      S2T_CONV_GEN_SB(conv_subblock(chunk),
+                      S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_fwd_kernel<KK, true, true, SBV>), grid,
+                                                              dim3(256), conv_smem<KK>(false, 1, true), st, a, y)));
     }
     S2T_CHECK_LAUNCH();
   }
@@ -1028,8 +1125,10 @@ static int zipconv_bwd_launch_data(ConvArgs a, int T, int B, int C, int K, bool 
       S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_data_kernel<KK, false, true>), grid, dim3(256),
                                               conv_smem<KK>(false, 1, true), st, a, dy, du));
     } else {
-      S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_data_kernel<KK, true, true>), grid, dim3(256),
-                                              conv_smem<KK>(false, 1, true), st, a, dy, du));
+      S2T_CONV_GEN_SB(conv_subblock(a.chunk),
+                      S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_data_kernel<KK, true, true, SBV>), grid,
+                                                              dim3(256), conv_smem<KK>(false, 1, true), st, a, dy,
+                                                              du)));
     }
     S2T_CHECK_LAUNCH();
   }
@@ -1066,8 +1165,10 @@ static int zipconv_bwd_launch_params(ConvArgs a, int T, int B, int C, int K, boo
       S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_w_kernel<KK, false, true>), gridw, dim3(256),
                                               conv_smem<KK>(true, 1, true), st, a, dy, BB, workspace, dsc));
     } else {
-      S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_w_kernel<KK, true, true>), gridw, dim3(256),
-                                              conv_smem<KK>(true, 1, true), st, a, dy, BB, workspace, dsc));
+      S2T_CONV_GEN_SB(conv_subblock(a.chunk),
+                      S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_w_kernel<KK, true, true, SBV>), gridw,
+                                                              dim3(256), conv_smem<KK>(true, 1, true), st, a, dy, BB,
+                                                              workspace, dsc)));
     }
     S2T_CHECK_LAUNCH();
   }

@@ -21,7 +21,8 @@ class _Conv(torch.nn.Module):
 @pytest.mark.parametrize("T,B,C,K,chunk", [(200, 3, 192, 31, -1), (130, 2, 96, 31, 32),
                                            (77, 4, 70, 15, 16), (50, 2, 64, 7, 8),
                                            (20, 2, 33, 31, -1), (64, 1, 64, 15, 4),
-                                           (150, 7, 96, 31, -1), (90, 6, 64, 15, 16)])
+                                           (150, 7, 96, 31, -1), (90, 6, 64, 15, 16),
+                                           (100, 2, 64, 15, 2), (96, 2, 64, 31, 12), (140, 2, 64, 31, 64)])
 @pytest.mark.parametrize("fused", [False, True])
 def test_glu_chunk_causal_dwconv(dev, monkeypatch, T, B, C, K, chunk, fused):
     from speech2text_amd import zip_kernels as zk

@@ -47,8 +47,10 @@ if what in ("balancer", "all"):
         cold(lambda: zk.balancer_backward(u[:, 256:], du[:, 256:], *cfg, inplace=True)), 16.0 * 15872 * 256)
 
 if what in ("zipconv", "all"):
-    for T, C, K in [(495, 192, 31), (248, 256, 31), (124, 256, 15), (62, 256, 15), (124, 256, 15), (248, 256, 31)][:4]:
+    for T, C, K, chunk in [(495, 192, 31, 0), (248, 256, 31, 0), (124, 256, 15, 0), (62, 256, 15, 0),
+                           (495, 192, 31, 32), (248, 256, 31, 16), (124, 256, 15, 8)]:
         B = 64
+        chunk = chunk or T                         # chunk < T: the chunk-causal (GEN) kernels
         u = torch.randn(T, B, 2 * C, device=dev)
         m8 = torch.zeros(B, T, dtype=torch.uint8, device=dev)
         wc = torch.randn(C, (K + 1) // 2, device=dev) * 0.1
@@ -56,13 +58,13 @@ if what in ("zipconv", "all"):
         wk = torch.randn(C, K, device=dev) * 0.1
         bk = torch.zeros(C, device=dev)
         sc = torch.randn(2, C, K, device=dev) * 0.1
-        y = zk.zipconv_forward(u, C, m8, T, K, wc, bc, wk, bk, sc)
-        rep(f"zipconv_fwd T={T} C={C} K={K}", cold(lambda: zk.zipconv_forward(u, C, m8, T, K, wc, bc, wk, bk, sc)),
+        y = zk.zipconv_forward(u, C, m8, chunk, K, wc, bc, wk, bk, sc)
+        rep(f"zipconv_fwd T={T} C={C} K={K} chunk={chunk}", cold(lambda: zk.zipconv_forward(u, C, m8, chunk, K, wc, bc, wk, bk, sc)),
             4.0 * (u.numel() + y.numel()))
         dy = torch.randn_like(y)
         grads = tuple(torch.zeros_like(t) for t in (wc, bc, wk, bk, sc))
-        rep(f"zipconv_bwd T={T} C={C} K={K}",
-            cold(lambda: zk.zipconv_backward(u, C, m8, T, K, wc, wk, bk, sc, dy, grads)),
+        rep(f"zipconv_bwd T={T} C={C} K={K} chunk={chunk}",
+            cold(lambda: zk.zipconv_backward(u, C, m8, chunk, K, wc, wk, bk, sc, dy, grads)),
             4.0 * (2 * u.numel() + 2 * y.numel() + u.numel()))
 
 if what in ("whiten", "all"):
