@@ -544,7 +544,9 @@ template <int K, bool GEN, bool EDGE, int SB = 0>
 __global__ __launch_bounds__(256) void zipconv_bwd_w_kernel(ConvArgs a,
                                                             const float* __restrict__ dy, int BB,
                                                             float* __restrict__ part,
-                                                            float* __restrict__ dscale) {
+                                                            float* __restrict__ dscale,
+                                                            float* __restrict__ dscale_t = nullptr,
+                                                            int cpad = 0) {
   constexpr int Kh = (K + 1) / 2, halo = K / 2, W = FPT + 2 * halo, NV = Kh + K + 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* s_x = reinterpret_cast<float*>(smem_raw);
@@ -696,8 +698,18 @@ __global__ __launch_bounds__(256) void zipconv_bwd_w_kernel(ConvArgs a,
       const int t = tb + i;
       if (t >= a.T) continue;
       const int pos = t - cs[i], idx = pos - chunk + K;
-      if (pos < K) atomicAdd(&dscale[(long)(c0 + c) * K + pos], ds[i]);
-      if (idx >= 0 && idx < K) atomicAdd(&dscale[((long)a.C + c0 + c) * K + idx], ds[i]);
+      if (dscale_t) {
+        // chunked launches (every tile has edge frames): into a [side][pos][channel] scratch, so
+        // that the 64 lanes of an atomic instruction add to 64 CONSECUTIVE words -- in the
+        // parameter's own (channel, pos) layout they are K words apart, one L2 transaction per
+        // lane, and that was 105 of the launch's 230 us; zipconv_dscale_commit_kernel folds the
+        // scratch into the parameter gradient
+        if (pos < K) atomicAdd(&dscale_t[(long)pos * cpad + c0 + c], ds[i]);
+        if (idx >= 0 && idx < K) atomicAdd(&dscale_t[((long)K + idx) * cpad + c0 + c], ds[i]);
+      } else {
+        if (pos < K) atomicAdd(&dscale[(long)(c0 + c) * K + pos], ds[i]);
+        if (idx >= 0 && idx < K) atomicAdd(&dscale[((long)a.C + c0 + c) * K + idx], ds[i]);
+      }
     }
   }
   // reduce the 4 frame groups of each channel through LDS, then one store per value
@@ -1101,10 +1113,25 @@ extern "C" int s2t_zipconv_fwd(const float* u, long ld, int gate_off, const unsi
   return 0;
 }
 
-// floats of scratch s2t_zipconv_bwd needs for the per-block partial sums
-extern "C" long s2t_zipconv_bwd_workspace_floats(int T, int B, int C, int K) {
+// dscale (2, C, K) += scratch [2][K][cpad] (see zipconv_bwd_w_kernel)
+__global__ __launch_bounds__(256) void zipconv_dscale_commit_kernel(const float* __restrict__ t, int C,
+                                                                    int K, int cpad,
+                                                                    float* __restrict__ dscale) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 2 * C * K) return;
+  const int side = i / (C * K), c = (i / K) % C, p = i % K;
+  const float v = t[((long)side * K + p) * cpad + c];
+  if (v != 0.f) dscale[i] += v;
+}
+
+// floats of scratch s2t_zipconv_bwd needs: the per-block partial sums + the transposed edge-scale
+// accumulator of the chunked launches
+static long zipconv_part_floats(int T, int B, int C, int K) {
   const long tiles = (long)((T + TT - 1) / TT) * ((C + 63) / 64);
   return tiles * B * 64 * ((K + 1) / 2 + K + 2);
+}
+extern "C" long s2t_zipconv_bwd_workspace_floats(int T, int B, int C, int K) {
+  return zipconv_part_floats(T, B, C, K) + 2L * K * ((C + 63) / 64) * 64;
 }
 
 // the data-gradient kernels of a backward call on stream st
@@ -1165,10 +1192,16 @@ static int zipconv_bwd_launch_params(ConvArgs a, int T, int B, int C, int K, boo
       S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_w_kernel<KK, false, true>), gridw, dim3(256),
                                               conv_smem<KK>(true, 1, true), st, a, dy, BB, workspace, dsc));
     } else {
+      const int cpad = (int)gx * 64;
+      float* dst = dsc ? workspace + zipconv_part_floats(T, B, C, K) : nullptr;
+      if (dst && hipMemsetAsync(dst, 0, sizeof(float) * 2 * K * cpad, st) != hipSuccess) return -3;
       S2T_CONV_GEN_SB(conv_subblock(a.chunk),
                       S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_w_kernel<KK, true, true, SBV>), gridw,
                                                               dim3(256), conv_smem<KK>(true, 1, true), st, a, dy, BB,
-                                                              workspace, dsc)));
+                                                              workspace, dsc, dst, cpad)));
+      S2T_CHECK_LAUNCH();
+      if (dst) hipLaunchKernelGGL(zipconv_dscale_commit_kernel, dim3((2 * C * K + 255) / 256), dim3(256), 0, st,
+                                  dst, C, K, cpad, dsc);
     }
     S2T_CHECK_LAUNCH();
   }
