@@ -288,6 +288,9 @@ void attn_fwd_mfma_kernel(AttnArgs a, float* __restrict__ W) {
   float4* sPos = reinterpret_cast<float4*>(sK + KT * 32 * MF_KLD);   // [KT*32 + MF_ROWS]
   float4* sP = sPos + (KT * 32 + MF_ROWS);                      // [MF_ROWS]
   float* sStat = reinterpret_cast<float*>(sP + MF_ROWS);        // [waves][32 rows]
+  unsigned* sMask = reinterpret_cast<unsigned*>(sStat + 8 * 32);   // AM_BITS: [MF_ROWS][KT] bit rows
+  // (short sequences keep the byte reads: at T = 124 the staging pass cost more than it saved)
+  constexpr bool AM_BITS = HAS_AM && KT >= 8;
   const int T = a.T, qd = a.qd, pd = a.pd;
   const int i0 = blockIdx.x * WG_ROWS, b = blockIdx.y, h = blockIdx.z;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -349,6 +352,36 @@ void attn_fwd_mfma_kernel(AttnArgs a, float* __restrict__ W) {
       if (w < KT * 32 + MF_ROWS) sPos[w] = wv[it];
     }
     if (threadIdx.x < MF_ROWS) sP[threadIdx.x] = pq;
+    if (AM_BITS) {
+      // the attention mask of the workgroup's 128 rows as bits (a word per 32-key tile): the byte
+      // gathers used to sit INSIDE the softmax -- 16 x NT dependent global loads per lane (chunked
+      // training: 281 us against 155 unmasked at T = 495); here they are coalesced row reads +
+      // ballots before the barrier, and the softmax reads LDS words
+      constexpr int NWV = NTH / 64, NQ = (KT + 1) / 2;
+      for (int il = wave; il < MF_ROWS; il += 2 * NWV) {        // two rows' loads in flight
+        const unsigned char* am0 = a.amask + (long)min(i0 + il, T - 1) * T;
+        const unsigned char* am1 = a.amask + (long)min(i0 + il + NWV, T - 1) * T;
+        unsigned char mb0[NQ], mb1[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          mb0[q] = am0[min(64 * q + lane, T - 1)];
+          mb1[q] = am1[min(64 * q + lane, T - 1)];
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const unsigned long long b0 = __ballot(mb0[q] != 0 && 64 * q + lane < T);
+          const unsigned long long b1 = __ballot(mb1[q] != 0 && 64 * q + lane < T);
+          if (lane == 0) {
+            sMask[il * KT + 2 * q] = (unsigned)b0;
+            sMask[(il + NWV) * KT + 2 * q] = (unsigned)b1;
+            if (2 * q + 1 < KT) {
+              sMask[il * KT + 2 * q + 1] = (unsigned)(b0 >> 32);
+              sMask[(il + NWV) * KT + 2 * q + 1] = (unsigned)(b1 >> 32);
+            }
+          }
+        }
+      }
+    }
   }
   // ---- this lane's query fragments: row (strip row lo), dims 8 s + 4 hi .. + 3
   const int strip = wave / SPLIT, half = wave % SPLIT;
@@ -403,7 +436,8 @@ void attn_fwd_mfma_kernel(AttnArgs a, float* __restrict__ W) {
     float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (HAS_POS) pv = sP[il];
     const float4* prow = sPos + (MF_ROWS - 1) - il + 32 * half * NT + lo;
-    const unsigned char* am = HAS_AM ? a.amask + (long)min(i0 + il, T - 1) * T : nullptr;
+    const unsigned* mrow = AM_BITS ? sMask + il * KT + half * NT : nullptr;
+    const unsigned char* am = (HAS_AM && !AM_BITS) ? a.amask + (long)min(i0 + il, T - 1) * T : nullptr;
     float m = S2T_NEG_INF;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -418,7 +452,8 @@ void attn_fwd_mfma_kernel(AttnArgs a, float* __restrict__ W) {
       }
       big |= (fabsf(x) > a.pen_limit) && j < T && (i0 + il) < T;
       bool masked = (pad_bits >> t) & 1u;
-      if (HAS_AM) masked = masked || am[min(j, T - 1)] != 0;
+      if (AM_BITS) masked = masked || ((mrow[t] >> lo) & 1u);
+      else if (HAS_AM) masked = masked || am[min(j, T - 1)] != 0;
       x = masked ? -1000.f : x;
       x = (j >= T) ? S2T_NEG_INF : x;
       acc[t][r] = x;
@@ -1377,7 +1412,8 @@ extern "C" int s2t_attn_apply(const float* W, const float* v, int T, int B, int 
 template <int NT, int SPLIT, bool HAS_POS, bool HAS_AM>
 int launch_fwd_mfma_v(const AttnArgs& a, float* W, hipStream_t st) {
   auto kern = attn_fwd_mfma_kernel<NT, SPLIT, HAS_POS, HAS_AM>;
-  const size_t smem = attn_mfma_smem<NT * SPLIT>();
+  const size_t smem = attn_mfma_smem<NT * SPLIT>() +
+                      ((HAS_AM && NT * SPLIT >= 8) ? sizeof(unsigned) * MF_ROWS * NT * SPLIT : 0);
   static bool attr = false;                       // per instantiation
   if (!attr && smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
