@@ -776,13 +776,27 @@ __device__ __forceinline__ void load_tile16(const float* __restrict__ base, int 
 }
 
 // bit r set <=> element (i0 + acc_row(r,hi), j0 + lo) takes part in the softmax
+// mbits (optional, LDS): the attention mask of the tile's 32 rows as bit words -- row acc_row(r, hi)
+// at mbits[acc_row * mstride], bit lo = key j0 + lo -- staged once per workgroup by the MFMA
+// backward kernels (attn_stage_mask_*): the 16 byte gathers per tile sat inside the tile loop
+// (chunked training: +200 us per T = 495 layer)
 __device__ __forceinline__ unsigned tile_ok(const AttnArgs& a, int b, int i0, int j0, int lo,
-                                            int hi) {
+                                            int hi, const unsigned* mbits = nullptr,
+                                            int mstride = 0) {
   const int j = j0 + lo;
   const int jc = min(j, a.T - 1);
   bool jok = j < a.T;
   if (a.kpm) jok = jok && !a.kpm[(long)b * a.T + jc];
   unsigned ok = 0;
+  if (mbits) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ar = acc_row(r, hi);
+      const bool v = jok && i0 + ar < a.T && !((mbits[ar * mstride] >> lo) & 1u);
+      ok |= (v ? 1u : 0u) << r;
+    }
+    return ok;
+  }
   const unsigned last = (unsigned)a.T * (unsigned)a.T - 1u;
   const unsigned o0 = (unsigned)(i0 + 4 * hi) * (unsigned)a.T + (unsigned)jc;
 #pragma unroll
@@ -800,7 +814,8 @@ template <int NS>
 __device__ __forceinline__ f32x16 ds_tile(const AttnArgs& a, const float* __restrict__ dWb,
                                           const float* __restrict__ dW0b, int b, int i0, int j0,
                                           int lo, int hi, const float* af, const float* bf,
-                                          const float (&w)[16], f32x16 acc) {
+                                          const float (&w)[16], f32x16 acc,
+                                          const unsigned* mbits = nullptr, int mstride = 0) {
   // acc enters as -delta_i (row constants as the initial accumulator)
 #pragma unroll
   for (int s = 0; s < NS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[s], acc, 0, 0, 0);
@@ -816,11 +831,14 @@ __device__ __forceinline__ f32x16 ds_tile(const AttnArgs& a, const float* __rest
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] += t[r];
   }
-  const unsigned ok = tile_ok(a, b, i0, j0, lo, hi);
+  const unsigned ok = tile_ok(a, b, i0, j0, lo, hi, mbits, mstride);
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = ((ok >> r) & 1u) ? w[r] * acc[r] : 0.f;
   return acc;
 }
+
+constexpr int AM_MAXT = 512;      // sequences up to here get the bit-staged mask (8 KB of LDS)
+
 
 // dk: workgroup = (32 keys, b, h); the 4 waves split the query blocks and their partial
 // sums meet in LDS.
@@ -936,6 +954,27 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_k3_mfma_kernel(AttnArgs a,
   for (int s = 0; s < NS; ++s) bf[s] = pair_elem(a, a.pV, j0 + lo, b, h, hi + 2 * s);
   f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int nib = (a.T + 31) / 32;
+  // attention mask of this wave's 32 keys, one word per query row (wave-private: no barrier)
+  __shared__ unsigned s_mb[4][AM_MAXT];
+  const bool mbit = a.amask != nullptr && a.T <= AM_MAXT;
+  if (mbit && live) {
+    const int jc = min(j0 + lo, a.T - 1);
+    for (int i = 0; i < a.T; i += 16) {                // 8 loads (2 rows each) in flight
+      unsigned char mbv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) mbv[q] = a.amask[(long)min(i + 2 * q + hi, a.T - 1) * a.T + jc];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const unsigned long long bal = __ballot(mbv[q] != 0);
+        if (lane == 0 && i + 2 * q < a.T) {
+          s_mb[wave][i + 2 * q] = (unsigned)bal;
+          if (i + 2 * q + 1 < a.T) s_mb[wave][i + 2 * q + 1] = (unsigned)(bal >> 32);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
   // register staging of the next query block
   float rq[4], ro[4], rd = 0.f, wn[16];
   auto fetch = [&](int i0) {
@@ -972,7 +1011,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_k3_mfma_kernel(AttnArgs a,
         ndl[r] = -s_dl[acc_row(r, hi)];
         qv[r] = s_Q[acc_row(r, hi)][lo];               // zero beyond qd / T (staged so)
       }
-      ds = ds_tile<NS>(a, dWb, dW0b, b, i0, j0, lo, hi, af, bf, wn, ndl);
+      ds = ds_tile<NS>(a, dWb, dW0b, b, i0, j0, lo, hi, af, bf, wn, ndl,
+                       mbit ? &s_mb[wave][min(i0, AM_MAXT - 32)] : nullptr, 1);
     }
     if (ib + 1 < nib) fetch(i0 + 32);                  // lands while this block's products run
     if (!live) continue;
@@ -1029,6 +1069,31 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_mfma_kernel(AttnArgs a,
     const int rr = idx / PD, d = idx % PD;
     s_P[wave][rr][d] = (i0 + rr < a.T && d < pd) ? p_row(a, i0 + rr, b, h)[d] : 0.f;
   }
+  // attention mask of this wave's 32 query rows, a word per 32-key block (wave-private)
+  __shared__ unsigned s_mq[4][32][AM_MAXT / 32];
+  const bool mbit = a.amask != nullptr && a.T <= AM_MAXT;
+  if (mbit && live) {
+    for (int rr = 0; rr < 32; rr += 2) {               // 2 rows x 8 loads of 64 keys in flight
+      const unsigned char* am0 = a.amask + (long)min(i0 + rr, a.T - 1) * a.T;
+      const unsigned char* am1 = a.amask + (long)min(i0 + rr + 1, a.T - 1) * a.T;
+      unsigned char m0[AM_MAXT / 64], m1[AM_MAXT / 64];
+#pragma unroll
+      for (int q = 0; q < AM_MAXT / 64; ++q) {
+        m0[q] = am0[min(64 * q + lane, a.T - 1)];
+        m1[q] = am1[min(64 * q + lane, a.T - 1)];
+      }
+#pragma unroll
+      for (int q = 0; q < AM_MAXT / 64; ++q) {
+        const unsigned long long b0 = __ballot(m0[q] != 0), b1 = __ballot(m1[q] != 0);
+        if (lane == 0) {
+          s_mq[wave][rr][2 * q] = (unsigned)b0;
+          s_mq[wave][rr][2 * q + 1] = (unsigned)(b0 >> 32);
+          s_mq[wave][rr + 1][2 * q] = (unsigned)b1;
+          s_mq[wave][rr + 1][2 * q + 1] = (unsigned)(b1 >> 32);
+        }
+      }
+    }
+  }
   f32x16 zq = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float dp[PD], dacc[PD];
 #pragma unroll
@@ -1084,7 +1149,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_mfma_kernel(AttnArgs a,
       f32x16 ndl;
 #pragma unroll
       for (int r = 0; r < 16; ++r) ndl[r] = s_ndl[wave][acc_row(r, hi)];
-      ds = ds_tile<NS>(a, dWb, dW0b, b, i0, j0, lo, hi, af, bf, wn, ndl);
+      ds = ds_tile<NS>(a, dWb, dW0b, b, i0, j0, lo, hi, af, bf, wn, ndl,
+                       mbit ? &s_mq[wave][0][min(jb, AM_MAXT / 32 - 1)] : nullptr, AM_MAXT / 32);
     }
     if (jb + 1 < nj) fetch(j0 + 32);   // lands while this tile's products run
     if (!live) continue;
