@@ -703,6 +703,18 @@ int s2t_gemm_x3p_stats(const float* A, long lda, const unsigned short* Bp, int N
 void* s2t_side_stream(void);
 int s2t_stream_order(void* from, void* to);
 
+/* ---- kernel-attached timing (bench.py's roofline figure).  s2t_prof_pair_arm hands a created
+ * (start, stop) HIP event pair to the NEXT s2t_gemm_x3p launch of the calling thread, which is then
+ * issued with hipExtLaunchKernelGGL: the pair holds the kernel's own begin / end times (what rocprof
+ * reports), not the times of marker packets recorded around it.  s2t_prof_pair_consumed: 1 if a
+ * launch took the armed pair, 0 if it was still armed (either way it is disarmed afterwards).
+ * s2t_prof_pair_ms waits for the stop event and returns the elapsed milliseconds in *ms. */
+int s2t_prof_pair_create(void** start, void** stop);
+int s2t_prof_pair_arm(void* start, void* stop);
+int s2t_prof_pair_consumed(void);
+int s2t_prof_pair_ms(void* start, void* stop, float* ms);
+int s2t_prof_pair_destroy(void* start, void* stop);
+
 #ifdef __cplusplus
 }
 #endif

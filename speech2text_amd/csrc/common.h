@@ -4,6 +4,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// kernel-attached timing: the (start, stop) pair armed for this thread's next instrumented launch
+// (csrc/streams.hip: s2t_prof_pair_arm)
+extern thread_local hipEvent_t s2t_prof_start, s2t_prof_stop;
+
 #define S2T_WAVE 64
 #define S2T_NEG_INF (-__builtin_huge_valf())
 

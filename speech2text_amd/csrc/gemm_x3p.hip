@@ -22,6 +22,7 @@
 // Workgroup = 4 waves (2 x 2), block tile (64 TM) x (64 TN), k chunks of 32, register-prefetched.
 #include "common.h"
 #include "../../include/s2t_mi355.h"
+#include <hip/hip_ext.h>
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
@@ -1053,6 +1054,19 @@ __global__ __launch_bounds__(256) void x3p_split_kernel(const float* __restrict_
   *reinterpret_cast<uint4*>(o + 1024) = q2;
 }
 
+// a launch that hands an armed (start, stop) event pair (csrc/streams.hip, declared in common.h)
+// to the kernel itself
+#define X3P_LAUNCH(KERNEL, GRID, BLOCK, SMEM)                                                     \
+  do {                                                                                            \
+    if (s2t_prof_start) {                                                                         \
+      hipExtLaunchKernelGGL(KERNEL, dim3(GRID), dim3(BLOCK), SMEM, st, s2t_prof_start,            \
+                            s2t_prof_stop, 0, g);                                                 \
+      s2t_prof_start = s2t_prof_stop = nullptr;                                                   \
+    } else {                                                                                      \
+      hipLaunchKernelGGL(KERNEL, dim3(GRID), dim3(BLOCK), SMEM, st, g);                           \
+    }                                                                                             \
+  } while (0)
+
 template <int TM, int TN>
 void launch_x3p(X3P& g, hipStream_t st) {
   g.tiles_m = (g.M + 64 * TM - 1) / (64 * TM);
@@ -1075,7 +1089,7 @@ void launch_x3p(X3P& g, hipStream_t st) {
     if (diag && g.stamps)
       hipLaunchKernelGGL((x3p_db_kernel<TM, TN, true>), dim3(grid), dim3(256), 0, st, g);
     else if (drip)
-      hipLaunchKernelGGL((x3p_db_kernel<TM, TN, false, 0, true>), dim3(grid), dim3(256), 0, st, g);
+      X3P_LAUNCH((x3p_db_kernel<TM, TN, false, 0, true>), grid, 256, 0);
     else if (abl && TM * TN >= 2 && TM <= TN) {
 #define X3P_ABL_CASE(A) case A: hipLaunchKernelGGL((x3p_db_kernel<TM, TN, false, A>), dim3(grid), dim3(256), 0, st, g); break;
       switch (abl) {
@@ -1086,9 +1100,9 @@ void launch_x3p(X3P& g, hipStream_t st) {
       }
 #undef X3P_ABL_CASE
     } else
-      hipLaunchKernelGGL((x3p_db_kernel<TM, TN>), dim3(grid), dim3(256), 0, st, g);
+      X3P_LAUNCH((x3p_db_kernel<TM, TN>), grid, 256, 0);
   } else
-    hipLaunchKernelGGL((x3p_kernel<TM, TN>), dim3(((total + 7) / 8) * 8), dim3(256), 0, st, g);
+    X3P_LAUNCH((x3p_kernel<TM, TN>), ((total + 7) / 8) * 8, 256, 0);
 }
 
 // block tile from the shape: the widest tile that still gives the chip >= ~2 rounds of workgroups

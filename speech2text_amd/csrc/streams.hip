@@ -54,3 +54,40 @@ extern "C" int s2t_stream_order(void* from, void* to) {
   rc = hipStreamWaitEvent((hipStream_t)to, e, 0);
   return (int)rc;
 }
+
+// ---- kernel-attached timing.  A (start, stop) pair armed here is handed to the NEXT instrumented
+// launch of this thread (csrc/gemm_x3p.hip: hipExtLaunchKernelGGL), which stamps the pair with
+// the kernel's own begin / end times -- the same interval rocprof reports.  Events recorded AROUND
+// a launch (marker packets before and after) add their dispatch latency to a ~40 us kernel:
+// bench.py's in-step figure for s2t_gemm_x3p read 37-44 us where rocprof read 34-37.
+thread_local hipEvent_t s2t_prof_start = nullptr, s2t_prof_stop = nullptr;
+
+extern "C" int s2t_prof_pair_create(void** start, void** stop) {
+  hipEvent_t a, b;
+  if (hipEventCreate(&a) != hipSuccess) return -1;
+  if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); return -1; }
+  *start = (void*)a;
+  *stop = (void*)b;
+  return 0;
+}
+extern "C" int s2t_prof_pair_arm(void* start, void* stop) {
+  s2t_prof_start = (hipEvent_t)start;
+  s2t_prof_stop = (hipEvent_t)stop;
+  return 0;
+}
+// 1 = the armed pair was consumed by a launch (and is now disarmed), 0 = still armed (disarms it)
+extern "C" int s2t_prof_pair_consumed(void) {
+  const int used = s2t_prof_start == nullptr;
+  s2t_prof_start = s2t_prof_stop = nullptr;
+  return used;
+}
+extern "C" int s2t_prof_pair_ms(void* start, void* stop, float* ms) {
+  if (hipEventSynchronize((hipEvent_t)stop) != hipSuccess) return -1;
+  return hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop) == hipSuccess ? 0 : -1;
+}
+extern "C" int s2t_prof_pair_destroy(void* start, void* stop) {
+  (void)hipEventDestroy((hipEvent_t)start);
+  (void)hipEventDestroy((hipEvent_t)stop);
+  return 0;
+}
+
