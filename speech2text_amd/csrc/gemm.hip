@@ -737,8 +737,11 @@ extern "C" int s2t_gemm_f32_batched(int mode, const float* A, long lda, long sA,
   if (mode < 0 || mode > 2 || batch > 65535) return -1;
   const bool a_kc = mode != MODE_TN, b_kc = mode == MODE_NT;
   if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15) ||
-      (reinterpret_cast<uintptr_t>(C) & 15) || (lda & 3) || (ldb & 3) || (sA & 3) || (sB & 3) || (sC & 3))
+      (lda & 3) || (ldb & 3) || (sA & 3) || (sB & 3))
     return -2;
+  // (the output needs 16-byte rows only for the float4 epilogue; T = 495 outputs take the scalar one)
+  const bool c_vec = (reinterpret_cast<uintptr_t>(C) & 15) == 0 && (sC & 3) == 0 && (ldc & 3) == 0 && (N & 3) == 0;
+  if (mode == MODE_TN && !c_vec) return -2;
   if ((a_kc || b_kc) && (K & 3)) return -2;
   if ((!a_kc && (M & 3)) || (!b_kc && (N & 3))) return -2;
   if (M < 4 || N < 4 || K < 4) return -2;
@@ -759,7 +762,7 @@ extern "C" int s2t_gemm_f32_batched(int mode, const float* A, long lda, long sA,
     hipLaunchKernelGGL((gemm_batched_kernel<1, 1, MODE_TN>), dim3(grid, batch), dim3(256), 0, st, g, sA, sB, sC);
   } else {
     g.splits = 1;
-    g.wide_ep = (N & 3) == 0 && (ldc & 3) == 0;
+    g.wide_ep = c_vec;
     const unsigned grid = (unsigned)(((total + 7) / 8) * 8);
     if (mode == MODE_NT)
       hipLaunchKernelGGL((gemm_batched_kernel<1, 1, MODE_NT>), dim3(grid, batch), dim3(256), 0, st, g, sA, sB, sC);
