@@ -633,8 +633,12 @@ def main(argv=None):
                                          "left_context_frames": [64, 128, 256, -1]})
     if args.accum > 1:
         cfg["trainer"]["accumulate_grad_batches"] = int(args.accum)
-    random.seed(1234 + rank)
-    np.random.seed(1234 + rank)
+    # reference build_task.py:47-48: EVERY rank seeds torch and `random` with 1234 -- all ranks then
+    # draw the same chunk_size / Balancer / Whiten decisions per step (equal-cost steps: no rank
+    # waits for another's slower launch list); only the DATA differs per rank (DistributedSampler
+    # there, make_batch(rank) here)
+    random.seed(1234)
+    np.random.seed(1234)
     torch.manual_seed(1234)                                 # same init on every rank
     task = TaskFactory.get(cfg["task"]["type"])(cfg)        # parameters are created on the host
     cpu = None
@@ -661,6 +665,7 @@ def main(argv=None):
     task.train()
     torch.manual_seed(1234 + rank)
     batch = make_batch(rank, args.batch, args.seconds, args.labels, args.vocab, device)
+    torch.manual_seed(1234)                                 # the training stream: as the reference, rank-independent
 
     def sync():
         if world > 1:

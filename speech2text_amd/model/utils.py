@@ -1,7 +1,9 @@
 """Metrics for evaluation (mirror of the reference's model/utils.py:23-136): word / character
 error rate over decoded texts and the AsrMetric callable the tasks' validation_step uses."""
 import dataclasses
-from typing import List
+from typing import List, Tuple
+
+import torch
 
 from speech2text_amd.model.decoding import (CtcGreedyDecoding, RnntGreedyDecoding, batch_search,
                                             reference_decoder)
@@ -55,3 +57,30 @@ class AsrMetric(object):
         references = reference_decoder(ground_truth, self._tokenizer)
         hypotheses = batch_search(hidden_states, inputs_length, self._decode_sess)
         return word_error_rate(hypotheses=hypotheses, references=references)
+
+
+@dataclasses.dataclass
+class SslMetricConfig:
+    top_ks: Tuple[int] = (1, 5)
+
+
+class SslMetric(object):
+    """Top-k accuracy of the SSL task over the masked label positions (reference
+    model/utils.py:139-191): a position counts when its label is among the k largest logits;
+    the denominator is the number of masked positions (+1e-7)."""
+
+    def __init__(self, config: SslMetricConfig):
+        self._top_ks = tuple(config.top_ks)
+
+    @staticmethod
+    def _accuracy(logits, labels, masked_dim, top_k):
+        top = logits.topk(top_k, dim=-1, largest=True, sorted=True).indices       # (B,T,k)
+        keep = masked_dim.to(torch.bool)
+        hit = (top == labels.unsqueeze(-1)).any(dim=-1) & keep
+        # (a masked-out position never matches in the reference either: its candidates are set
+        # to -1 and its label to 0)
+        return hit.sum().float() / (masked_dim.sum() + 1e-7)
+
+    def __call__(self, logits, labels, masked_dim):
+        return {"top_{}_acc".format(k): self._accuracy(logits, labels, masked_dim, k)
+                for k in self._top_ks}

@@ -18,6 +18,8 @@ class BaseRnntTask(TaskBase):
         self._decoder = Decoder(config["decoder"])
         self._predictor = Predictor(config["predictor"])
         self._joiner = Joiner(config=JoinerConfig(**config["joiner"]))
+        # reference rnnt_task.py:65-69: the metric decodes with this task's predictor / joiner
+        self._metric = self._asr_metric(predictor=self._predictor, joiner=self._joiner)
 
     def _optimizer_params(self):
         sep = self._optim_config["seperate_lr"]
@@ -49,6 +51,22 @@ class RnntTask(BaseRnntTask):
         return loss.mean()
 
 
+    @torch.no_grad()
+    def validation_step(self, batch, batch_idx):
+        """reference rnnt_task.py:244-284."""
+        feat, feat_len = self.features(batch)
+        enc, enc_len = self._encoder(feat, feat_len)
+        dec, dec_len = self._decoder(enc, enc_len)
+        pred, pred_len, _ = self._predictor(batch["label"], batch["label_length"],
+                                            self._predictor.init_state())
+        joint, _, _, _ = self._joiner(dec, dec_len, pred, pred_len, batch["label"])
+        loss = self._loss({"logits": joint, "logits_length": dec_len, "targets": batch["label"],
+                           "targets_length": batch["label_length"]})
+        wer = self._wer(dec, dec_len, batch["label"])
+        self.log_dict({"val_loss": loss, "wer": wer}, sync_dist=True, prog_bar=True)
+        return {"val_loss": loss, "wer": wer}
+
+
 class CtcHybridRnnt(BaseRnntTask):
     """Shared encoder, CTC head on decoder_out, RNN-T branch on encoder_out (reference :287-420)."""
 
@@ -77,6 +95,29 @@ class CtcHybridRnnt(BaseRnntTask):
                        "train_loss/loss_ctc": loss_ctc}, sync_dist=True, prog_bar=True,
                       logger=True)
         return loss.mean()
+
+
+    @torch.no_grad()
+    def validation_step(self, batch, batch_idx):
+        """reference rnnt_task.py:365-420: the WER decodes encoder_out (the RNN-T branch's input)."""
+        feat, feat_len = self.features(batch)
+        enc, enc_len = self._encoder(feat, feat_len)
+        dec, dec_len = self._decoder(enc, enc_len)
+        pred, pred_len, _ = self._predictor(batch["label"], batch["label_length"],
+                                            self._predictor.init_state())
+        joint, _, _, _ = self._joiner(enc, enc_len, pred, pred_len, batch["label"])
+        loss_rnnt = self._rnnt_loss({"logits": joint, "logits_length": enc_len,
+                                     "targets": batch["label"],
+                                     "targets_length": batch["label_length"]})
+        loss_ctc = self._ctc_loss({"logits": dec, "logits_length": dec_len,
+                                   "targets": batch["label"],
+                                   "targets_length": batch["label_length"]})
+        loss = self._rnnt_weight * loss_rnnt + self._ctc_weight * loss_ctc
+        wer = self._wer(enc, enc_len, batch["label"])
+        info = {"val_loss": loss, "val_loss/loss_rnnt": loss_rnnt, "val_loss/loss_ctc": loss_ctc,
+                "wer": wer}
+        self.log_dict(info, sync_dist=True, prog_bar=True, logger=True)
+        return info
 
 
 class PrunedRnntTask(BaseRnntTask):
@@ -125,3 +166,31 @@ class PrunedRnntTask(BaseRnntTask):
                        "train_loss/pruned_loss": pruned_loss, "train_loss/ctc_loss": ctc_loss},
                       sync_dist=True, prog_bar=True, logger=True)
         return loss.mean()
+
+    @torch.no_grad()
+    def validation_step(self, batch, batch_idx):
+        """reference rnnt_task.py:516-594."""
+        feat, feat_len = self.features(batch)
+        enc, enc_len = self._encoder(feat, feat_len)
+        dec, dec_len = self._decoder(enc, enc_len)
+        pred, pred_len, _ = self._predictor(batch["label"], batch["label_length"],
+                                            self._predictor.init_state())
+        joint, boundary, ranges, simple_loss = self._joiner(dec, dec_len, pred, pred_len,
+                                                            batch["label"])
+        pruned_loss = self._loss({"logits": joint, "logits_length": dec_len,
+                                  "targets": batch["label"],
+                                  "targets_length": batch["label_length"],
+                                  "boundary": boundary, "ranges": ranges})
+        loss = self._simple_loss_scale * simple_loss + self._pruned_loss_scale * pruned_loss
+        ctc_loss = 0.0
+        if self._enable_ctc:
+            logits, logits_len = self._ctc_projector(dec, dec_len)
+            ctc_loss = self._ctc_loss({"logits": logits, "logits_length": logits_len,
+                                       "targets": batch["label"],
+                                       "targets_length": batch["label_length"]})
+            loss = loss + ctc_loss
+        wer = self._wer(dec, dec_len, batch["label"])
+        info = {"val_loss": loss, "val_loss/simple_loss": simple_loss,
+                "val_loss/pruned_loss": pruned_loss, "val_loss/ctc_loss": ctc_loss, "wer": wer}
+        self.log_dict(info, sync_dist=True, prog_bar=True, logger=True)
+        return info

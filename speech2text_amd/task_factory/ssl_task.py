@@ -1,5 +1,7 @@
 """BEST-RQ self-supervised task (reference task_factory/ssl_task.py:31-180): cmvn(raw),
 cmvn(auged) -> BestRQLayer -> encoder -> logits layer -> per-codebook masked / total loss."""
+import torch
+
 from speech2text_amd.model.decoder.decoder import Decoder
 from speech2text_amd.model.encoder.encoder import Encoder
 from speech2text_amd.model.loss.loss import Loss
@@ -19,6 +21,8 @@ class SslTask(TaskBase):
         self._encoder = Encoder(config["encoder"])
         self._logits_layer = Decoder(config["logits_layer"])
         self._loss = Loss(self._loss_config)
+        from speech2text_amd.model.utils import SslMetric, SslMetricConfig
+        self._metric = SslMetric(config=SslMetricConfig(**(config.get("metric") or {})))
 
     def training_step(self, batch, batch_idx):
         if "raw_feat" in batch:
@@ -45,3 +49,32 @@ class SslTask(TaskBase):
         self.log_dict({"train_loss": loss, "train_loss/tot_loss": tot_loss,
                        "train_loss/mask_loss": mask_loss}, sync_dist=True)
         return loss.mean()
+
+    @torch.no_grad()
+    def validation_step(self, batch, batch_idx):
+        """reference ssl_task.py:182-254: the raw features stand in for the augmented ones; per
+        codebook masked / total loss and top-k accuracy over the masked positions, averaged."""
+        if "raw_feat" in batch:
+            raw = self._global_cmvn(batch["raw_feat"])
+            feat_len = batch["feat_length"]
+        else:
+            raw, feat_len = self.features(batch)
+        out = self._ssl_layer(raw, raw, feat_len)
+        enc, enc_len = self._encoder(out["masked_feats"], feat_len)
+        logits, logits_len = self._logits_layer(enc, enc_len)
+        n = self._ssl_layer.num_codebooks
+        mask_losses, tot_losses, accs = [], [], {}
+        for cb in range(n):
+            lab = out["labels"][cb]
+            mask_losses.append(self._loss({"logits": logits, "ori_labels": lab,
+                                           "mask": out["masked_dim"]}))
+            tot_losses.append(self._loss({"logits": logits, "ori_labels": lab, "mask": logits_len}))
+            preds = self._loss.predict(logits)
+            for k, v in self._metric(logits=preds, labels=lab, masked_dim=out["masked_dim"]).items():
+                accs[k] = accs.get(k, 0.0) + v / n
+        mask_loss, tot_loss = sum(mask_losses) / n, sum(tot_losses) / n
+        loss = tot_loss if self._loss_config["loss_select"] == "tot_loss" else mask_loss
+        info = {"val_loss": loss, "val_loss/tot_loss": tot_loss, "val_loss/mask_loss": mask_loss,
+                **accs}
+        self.log_dict(info, sync_dist=True, prog_bar=True, logger=True)
+        return info

@@ -519,9 +519,13 @@ def zipconv_forward(u, gate_off, m8, chunk, K, wc, bc, wk, bk, scale):
 _CONV_W_SIDE = os.environ.get("S2T_CONV_W_SIDE", "1") == "1"
 
 
-def zipconv_backward(u, gate_off, m8, chunk, K, wc, wk, bk, scale, dy, grads):
+def zipconv_backward(u, gate_off, m8, chunk, K, wc, wk, bk, scale, dy, grads, side=True):
     """-> du (T,B,2C | C).  grads = (dwc, dbc, dwk, dbk, dscale) tensors the kernels ACCUMULATE the
-    parameter gradients into (None where the parameter is absent)."""
+    parameter gradients into (None where the parameter is absent).  side: the parameter-gradient
+    kernel may run on the side stream -- ONLY when `grads` are the flat-store views, which nothing
+    reads before the end-of-backward join; a scratch buffer that is handed back to autograd
+    (AccumulateGrad reads it on the main stream right away, and the allocator may reuse it) must
+    be written on the current stream."""
     T, B, ld = u.shape
     C = wk.shape[0]
     dev = u.device
@@ -531,7 +535,7 @@ def zipconv_backward(u, gate_off, m8, chunk, K, wc, wk, bk, scale, dy, grads):
     dwc, dbc, dwk, dbk, dsc = grads
     # the tap / bias / edge-scale gradients only feed the optimizer: side stream, as the weight-
     # gradient GEMMs (operands kept alive until the join)
-    wst = _side_launch_stream(u, dy, ws, m8, wc, wk, bk, scale) if _CONV_W_SIDE else None
+    wst = _side_launch_stream(u, dy, ws, m8, wc, wk, bk, scale) if (_CONV_W_SIDE and side) else None
     L = N.lib()
     gptr = (N.raw(dwc) if dwc is not None else None, N.raw(dbc) if dbc is not None else None,
             N.raw(dwk), N.raw(dbk) if dbk is not None else None,
@@ -607,7 +611,7 @@ class _ZipConv(torch.autograd.Function):
             parts.append(buf[o:o + n] if n else None)
             o += n
         dwc, dbc, dwk, dbk, dsc = parts
-        du = zipconv_backward(u, gate_off, m8, chunk, K, wc, wk, bk, scale, dy, parts)
+        du = zipconv_backward(u, gate_off, m8, chunk, K, wc, wk, bk, scale, dy, parts, side=False)
         return (du, None, None, None, None,
                 None if dwc is None else dwc.view(C, 1, Kh),
                 dbc if has_bc else None, dwk.view(C, 1, K), dbk,

@@ -45,6 +45,24 @@ def test_product_wer_and_reference_decoder_host_logic():
         word_error_rate(["a"], ["a", "b"])
 
 
+def test_ssl_metric_topk_host_logic():
+    """SslMetric against the reference's formula (model/utils.py:153-181), CPU tensors."""
+    from speech2text_amd.model.utils import SslMetric, SslMetricConfig
+    rng = np.random.default_rng(0)
+    lg = rng.standard_normal((3, 17, 40)).astype(np.float32)
+    lab = rng.integers(1, 40, (3, 17))
+    md = (rng.random((3, 17)) < 0.5).astype(np.float32)
+    m = SslMetric(SslMetricConfig(top_ks=(1, 5)))(torch.from_numpy(lg), torch.from_numpy(lab),
+                                                   torch.from_numpy(md))
+    for k in (1, 5):
+        top = np.argsort(-lg, axis=-1, kind="stable")[..., :k]
+        top = np.where((1 - md)[..., None].astype(bool), -1, top)
+        ref = float((top == (md * lab)[..., None]).sum() / (md.sum() + 1e-7))
+        assert float(m[f"top_{k}_acc"]) == pytest.approx(ref, rel=1e-6)
+    none = SslMetric(SslMetricConfig())(torch.from_numpy(lg), torch.from_numpy(lab), torch.zeros(3, 17))
+    assert float(none["top_1_acc"]) == 0.0
+
+
 @pytest.mark.skipif(not os.path.exists("/root/reference/sample_data/spm/tokenizer.model"),
                     reason="reference sample_data not present")
 def test_subword_tokenizer_roundtrip_as_reference_test():

@@ -1,0 +1,172 @@
+"""GPU: every task's validation_step (reference task_factory/ctc_task.py:159-190,
+rnnt_task.py:244-284 / 365-420 / 516-594, ssl_task.py:182-254) on a synthetic batch: logged
+scalar names, and the metric against the oracle's decoders / a restatement of the reference's
+top-k accuracy."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import decoding as OD
+from test_gpu_conformer_tasks import _CONF, _base_cfg, _pcm_batch
+
+pytestmark = pytest.mark.gpu
+
+_V = 32
+_TOK = {"type": "char", "config": {"labels": [chr(97 + i) for i in range(_V - 3)]}}
+
+
+def _task(name, cfg, dev):
+    from speech2text_amd.build_task import TaskFactory
+    torch.manual_seed(0)
+    task = TaskFactory.get(name)(cfg).to(dev)
+    task.eval()
+    return task
+
+
+def _refs(task, labels):
+    from speech2text_amd.model.decoding import reference_decoder
+    return reference_decoder(labels, task._tokenizer)
+
+
+def test_ctc_validation_step_vs_oracle(dev):
+    cfg = _base_cfg()
+    cfg.update({"task": {"type": "CTC"}, "tokenizer": _TOK, "encoder": _CONF,
+                "decoder": {"model": "Projector", "config": {"input_dim": 64, "output_dim": _V, "dropout_p": 0.1}},
+                "loss": {"model": "CTC", "config": {"blank_label": 0, "reduction": "mean", "zero_infinity": True}},
+                "metric": {"decode_method": "ctc_greedy_search", "max_token_step": 5}})
+    task = _task("CTC", cfg, dev)
+    batch = _pcm_batch(dev, V=_V)
+    info = task.validation_step(batch, 0)
+    assert set(task.logged) >= {"val_loss", "wer"} and np.isfinite(float(info["val_loss"]))
+    with torch.no_grad():
+        feat, n = task.features(batch)
+        enc, el = task._encoder(feat, n)
+        dec, dl = task._decoder(enc, el)
+    hyps = [task._tokenizer.decode(torch.tensor(OD.ctc_greedy(dec[b].cpu().numpy(), int(dl[b]))))
+            for b in range(dec.shape[0])]
+    assert info["wer"] == pytest.approx(OD.word_error_rate(hyps, _refs(task, batch["label"])))
+    # training still works after a validation pass (no stale no_grad state, BatchNorm untouched)
+    task.train()
+    assert task.training_step(batch, 0).requires_grad
+
+
+def _pruned_cfg():
+    import bench
+    cfg = bench.c3_config(_V)
+    cfg["encoder"]["config"].update({"downsampling_factor": [1, 2], "num_encoder_layers": [1, 1],
+                                     "feedforward_dim": [96, 128], "encoder_dim": [48, 64],
+                                     "encoder_unmasked_dim": [32, 48], "num_heads": [4, 4],
+                                     "query_head_dim": 8, "value_head_dim": 4, "pos_dim": 16,
+                                     "cnn_module_kernel": [15, 7], "chunk_size": [-1],
+                                     "left_context_frames": [-1]})
+    cfg["predictor"]["config"].update({"output_dim": 64, "symbol_embedding_dim": 32})
+    cfg["joiner"].update({"input_dim": 64})
+    cfg["tokenizer"] = _TOK
+    cfg["metric"] = {"decode_method": "rnnt_greedy_search", "max_token_step": 1}
+    return cfg
+
+
+def test_pruned_rnnt_validation_step_vs_oracle(dev):
+    cfg = _pruned_cfg()
+    task = _task("Pruned_Rnnt", cfg, dev)
+    with torch.no_grad():
+        for p in list(task._predictor.parameters()) + list(task._joiner.parameters()):
+            p.mul_(3.0)
+    batch = _pcm_batch(dev, V=_V)
+    info = task.validation_step(batch, 0)
+    assert set(task.logged) >= {"val_loss", "val_loss/simple_loss", "val_loss/pruned_loss",
+                                "val_loss/ctc_loss", "wer"}
+    assert np.isfinite(float(info["val_loss"]))
+    with torch.no_grad():
+        feat, n = task.features(batch)
+        enc, el = task._encoder(feat, n)
+        dec, dl = task._decoder(enc, el)
+    sd = {"p." + k: v.detach().cpu() for k, v in task._predictor.predictor.state_dict().items()}
+    sd.update({"j." + k: v.detach().cpu() for k, v in task._joiner.state_dict().items()})
+    ctx = cfg["predictor"]["config"]["context_size"]
+    hyps = []
+    for b in range(dec.shape[0]):
+        ids = OD.rnnt_greedy_stateless(sd, "p.", "j.", dec[b].cpu(), int(dl[b]), ctx,
+                                       cfg["joiner"]["activation"], 1)
+        hyps.append(task._tokenizer.decode(torch.tensor(ids, dtype=torch.int64)))
+    assert info["wer"] == pytest.approx(OD.word_error_rate(hyps, _refs(task, batch["label"])))
+
+
+def test_hybrid_and_rnnt_validation_steps(dev):
+    cfg = _base_cfg()
+    cfg.update({"task": {"type": "CTC_Hybrid_Rnnt"}, "tokenizer": _TOK, "encoder": _CONF,
+                "decoder": {"model": "Projector", "config": {"input_dim": 64, "output_dim": _V, "dropout_p": 0.1}},
+                "predictor": {"model": "Lstm", "config": {"num_symbols": _V, "output_dim": 64,
+                                                          "symbol_embedding_dim": 32, "num_lstm_layers": 2,
+                                                          "lstm_hidden_dim": 48, "lstm_layer_norm": True,
+                                                          "lstm_layer_norm_epsilon": 1e-3, "lstm_dropout": 0.1}},
+                "joiner": {"input_dim": 64, "output_dim": _V, "inner_dim": 48, "activation": "tanh",
+                           "prune_range": -1},
+                "metric": {"decode_method": "rnnt_greedy_search", "max_token_step": 2},
+                "loss": {"rnnt_weight": 0.8, "ctc_weight": 0.2,
+                         "rnnt_loss": {"model": "Rnnt", "config": {"blank_label": 0, "reduction": "mean"}},
+                         "ctc_loss": {"model": "CTC", "config": {"blank_label": 0, "reduction": "mean"}}}})
+    batch = _pcm_batch(dev, B=2, sec=1.0, V=_V)
+    task = _task("CTC_Hybrid_Rnnt", cfg, dev)
+    info = task.validation_step(batch, 0)
+    assert set(task.logged) >= {"val_loss", "val_loss/loss_rnnt", "val_loss/loss_ctc", "wer"}
+    assert float(info["val_loss"]) == pytest.approx(
+        0.8 * float(info["val_loss/loss_rnnt"]) + 0.2 * float(info["val_loss/loss_ctc"]), rel=1e-5)
+    # the LSTM predictor takes the reference's per-utterance lattice walk (model/decoding.py:237-271):
+    # the task's WER must equal the one of hypotheses decoded one utterance at a time
+    with torch.no_grad():
+        feat, n = task.features(batch)
+        enc, el = task._encoder(feat, n)
+    sess = task._metric._decode_sess
+    hyps = [sess.decode(enc[b:b + 1, :int(el[b])]) for b in range(enc.shape[0])]
+    assert info["wer"] == pytest.approx(OD.word_error_rate(hyps, _refs(task, batch["label"])))
+    cfg2 = copy.deepcopy(cfg)
+    cfg2["task"] = {"type": "Rnnt"}
+    cfg2["decoder"] = {"model": "Identity", "config": {"dummy": -1}}
+    cfg2["loss"] = {"model": "Rnnt", "config": {"blank_label": 0, "reduction": "mean"}}
+    task2 = _task("Rnnt", cfg2, dev)
+    info2 = task2.validation_step(batch, 0)
+    assert set(task2.logged) >= {"val_loss", "wer"} and np.isfinite(float(info2["val_loss"]))
+
+
+def _ref_topk_acc(logits, labels, masked_dim, k):
+    """reference model/utils.py:153-181, restated in numpy."""
+    top = np.argsort(-logits, axis=-1, kind="stable")[..., :k]
+    top = np.where((1 - masked_dim)[..., None].astype(bool), -1, top)
+    valid = (masked_dim * labels)[..., None]
+    return float((top == valid).sum() / (masked_dim.sum() + 1e-7))
+
+
+def test_ssl_validation_step_topk(dev):
+    cfg = _base_cfg()
+    cfg.update({"task": {"type": "SSL"}, "encoder": _CONF, "metric": {"top_ks": [1, 5]},
+                "ssl_layer": {"model": "Best-RQ",
+                              "layer_config": {"cnn_kernel_size": [3, 3], "cnn_stride": [2, 2], "feat_dim": 80,
+                                               "num_codebooks": 2, "codebook_dim": 16, "codebook_size": 256,
+                                               "label_basis": "cosine"},
+                              "masking_config": {"mask_proportion": 0.5, "mean_span_length": 1,
+                                                 "span_select_type": "static", "min_num_spans": 1,
+                                                 "no_overlap": False, "min_space": 0, "seed": 1234}},
+                "logits_layer": {"model": "Projector", "config": {"input_dim": 64, "output_dim": 257, "dropout_p": 0.0}},
+                "loss": {"loss_select": "mask_loss", "model": "MaskedKLDiv",
+                         "config": {"num_classes": 257, "scale_factor": 1.0, "label_smoothing": 0.1}}})
+    task = _task("SSL", cfg, dev)
+    g = torch.Generator().manual_seed(2)
+    feats = torch.randn(3, 203, 80, generator=g).to(dev)
+    batch = {"raw_feat": feats, "auged_feat": feats.clone(), "feat_length": torch.tensor([203, 180, 151]).to(dev)}
+    info = task.validation_step(batch, 0)
+    assert set(task.logged) >= {"val_loss", "val_loss/tot_loss", "val_loss/mask_loss", "top_1_acc", "top_5_acc"}
+    assert float(info["val_loss"]) == pytest.approx(float(info["val_loss/mask_loss"]))
+    assert 0.0 <= float(info["top_1_acc"]) <= float(info["top_5_acc"]) <= 1.0
+    # the metric itself against the reference's formula on random logits
+    from speech2text_amd.model.utils import SslMetric, SslMetricConfig
+    rng = np.random.default_rng(0)
+    lg = rng.standard_normal((3, 17, 40)).astype(np.float32)
+    lab = rng.integers(1, 40, (3, 17))
+    md = (rng.random((3, 17)) < 0.5).astype(np.float32)
+    m = SslMetric(SslMetricConfig(top_ks=(1, 5)))(torch.from_numpy(lg).to(dev), torch.from_numpy(lab).to(dev),
+                                                   torch.from_numpy(md).to(dev))
+    for k in (1, 5):
+        assert float(m[f"top_{k}_acc"]) == pytest.approx(_ref_topk_acc(lg, lab, md, k), rel=1e-6)

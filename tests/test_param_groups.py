@@ -62,7 +62,9 @@ def test_ctc_task_seperate_lr_groups():
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_CFG), reason="reference tree not present")
-def test_shipped_yamls_build_and_group_every_parameter():
+def test_shipped_yamls_build_and_group_every_parameter(monkeypatch):
+    # the YAMLs name their tokenizer files relative to the reference's root (its tests run from there)
+    monkeypatch.chdir(os.path.dirname(os.path.dirname(REF_CFG)))
     n = 0
     for path in sorted(glob.glob(os.path.join(REF_CFG, "*.yaml"))):
         cfg = yaml.safe_load(open(path))
@@ -72,6 +74,7 @@ def test_shipped_yamls_build_and_group_every_parameter():
         cfg = copy.deepcopy(cfg)
         task = TaskFactory.get(cfg["task"]["type"])(cfg)
         _check_groups(task)
+        assert task._metric is not None and callable(getattr(task, "validation_step"))
         n += 1
     assert n >= 6
 
