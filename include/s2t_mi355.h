@@ -715,6 +715,150 @@ int s2t_prof_pair_consumed(void);
 int s2t_prof_pair_ms(void* start, void* stop, float* ms);
 int s2t_prof_pair_destroy(void* start, void* stop);
 
+
+/* ---- element-wise helpers of the layer executor's library-GEMM path (csrc/zip_elem.hip):
+ * out = a + b (out may alias an operand; 16-byte aligned); the parity sequence 0, 1, 0, ... of
+ * s2t_balancer_bwd's two alternating accumulators, shared by every caller of the process. */
+int s2t_add_f32(const float* a, const float* b, float* out, long n, void* stream);
+int s2t_balancer_next_parity(void);
+
+/* ---- batch of dense row-major fp32 products through hipBLASLt's strided-batch API (csrc/gemm_lib.hip):
+ * the shapes of the nonlinear attention's products (model/encoder/zipformer.py:2468-2473 and their
+ * gradients) that s2t_gemm_f32_batched refuses (rows that are not 16-byte multiples: T = 495, 62)
+ * and the a^T b form.  mode 0: C_b[M,N] = A_b[M,K] B_b[N,K]^T; 1: C_b = A_b[M,K] B_b[K,N];
+ * 2: C_b[M,N] = A_b[K,M]^T B_b[K,N].  Batch strides = rows * cols.  -2: no library algorithm. */
+int s2t_bmm_lt(int mode, const float* A, const float* B, float* C, int batch, int M, int N, int K,
+               void* workspace, long ws_bytes, void* stream);
+
+/* ---- native per-layer executor (csrc/zip_layer.hip): ONE call per Zipformer2EncoderLayer forward and
+ * one per backward issues every launch of the layer (model/encoder/zipformer.py:909-1338 under
+ * loss.backward(); gradient shaping model/layer/scaling.py:741-789, 994-1028, 1153-1190).  The Python
+ * side (speech2text_amd/zip_native.py) draws the layer's random decisions where the reference draws
+ * them and passes them as `dec`; C++ only reads them.
+ *   desc  : the layer's shapes, parameter / gradient addresses (views of the FlatStore), bf16 piece
+ *           addresses of its weights (planes.py; NULL = library path) and module constants;
+ *   call  : this call's shapes, inputs, masks, decisions, persistent scratch, switches;
+ *   state : s2t_zip_layer_state_bytes() bytes of HOST memory, written by fwd, read by bwd;
+ *   ws    : device workspace, >= s2t_zip_layer_ws_floats(desc, call, backward) floats; the forward's
+ *           must stay alive (and untouched) until the backward has been enqueued.
+ * Decision indices (dec[]): 0 balance_keys, 1 whiten_keys, 2 use positional scores, 3 score penalty
+ * drawn; feed-forward i (hidden balancer, out whiten, post balancer): 4-6, 15-17, 23-25; nonlinear
+ * attention (balancer, whiten1, whiten2, post balancer) 7-10; self_attn whiten 11, 19; conv module
+ * (balancer1, balancer2, whiten) 12-14, 20-22; limit_param_value of bypass_mid 18, norm.log_scale 27,
+ * bypass 28; layer balancer1 26, balancer2 29, whiten 30.
+ * Whiten sites (s2t_zip_layer_info(state, 0, site) after bwd: 1 penalty applied, 0 below the limit,
+ * -1 did not fire): 0 keys, 1 ff1, 2 nonlin whiten1, 3 nonlin whiten2, 4 self_attn1, 5 conv1, 6 ff2,
+ * 7 self_attn2, 8 conv2, 9 ff3, 10 layer output.
+ * Returns 0; -4 workspace too small; -5 a product's shape bucket has no plan entry yet (nothing was
+ * launched: run the Python executor for this call, it times the shapes); bwd returns 1 when the
+ * score penalty of this call is non-zero (it stopped before the attention-weights backward: write
+ * dqkp / dpos -- addresses from s2t_zip_layer_info -- and call again with phase 2). */
+#define S2T_ZL_NDEC 32
+#define S2T_ZL_NWHITEN 11
+typedef struct S2tZlLin {          /* nn.Linear, weight (N,K) row-major */
+  const float* w;
+  const float* b;                  /* NULL: no bias */
+  float* gw;
+  float* gb;
+  const unsigned short* pf;        /* pieces for x W^T, or NULL */
+  const unsigned short* pb;        /* pieces for g W, or NULL */
+  int N, K;
+} S2tZlLin;
+typedef struct S2tZlBal {          /* Balancer.cfg(): scaling.py:792-902 */
+  float min_mean, max_mean, min_rms, max_rms, grad_scale;
+} S2tZlBal;
+typedef struct S2tZlWh {           /* Whiten: scaling.py:1031-1095 */
+  int groups;
+  float limit, grad_scale;
+} S2tZlWh;
+typedef struct S2tZlFf {
+  S2tZlLin in, out;
+  S2tZlBal hidden;
+  S2tZlWh out_wh;
+  S2tZlBal post;                   /* balancer_ff2 / balancer_ff3 of the layer (unused for ff1) */
+} S2tZlFf;
+typedef struct S2tZlSa {
+  S2tZlLin in, out;
+  S2tZlWh wh;
+} S2tZlSa;
+typedef struct S2tZlConv {
+  S2tZlLin in, out;
+  S2tZlBal bal1, bal2;
+  S2tZlWh wh;
+  int K, causal;
+  const float *wc, *bc, *wk, *bk, *scale;
+  float *gwc, *gbc, *gwk, *gbk, *gscale;
+} S2tZlConv;
+typedef struct S2tZlNa {
+  S2tZlLin in, out;
+  S2tZlBal bal;
+  S2tZlWh wh1, wh2;
+  S2tZlBal post;                   /* balancer_na of the layer */
+} S2tZlNa;
+typedef struct S2tZlParam {
+  const float* x;
+  float* grad;
+  float lo, hi;
+} S2tZlParam;
+typedef struct S2tZipLayerDesc {
+  int D, H, qd, pd, pos_dim;
+  S2tZlLin attn_in, attn_pos;
+  S2tZlBal bal_keys;
+  S2tZlWh wh_keys;
+  S2tZlFf ff[3];
+  S2tZlNa na;
+  S2tZlSa sa[2];
+  S2tZlConv cv[2];
+  S2tZlParam byp_mid, byp, norm_bias, norm_ls;
+  S2tZlBal bal1, bal2;
+  S2tZlWh wh_out;
+} S2tZipLayerDesc;
+typedef struct S2tZlWhScratch {    /* persistent scratch of the Whiten statistics, per channel count */
+  int C;
+  float* acc;                      /* (C+1, C), zeroed once */
+  float* ws;                       /* 4 + 2 C floats, zeroed once */
+  const void* tab;                 /* S2tPlaneDesc of a (C,C) matrix for mode 1, or NULL */
+  unsigned short* buf;             /* its piece buffer, or NULL */
+  int blocks;
+} S2tZlWhScratch;
+typedef struct S2tZipLayerCall {
+  int T, B, chunk_size;
+  const float* x0;                 /* (T*B, D) layer input */
+  const float* pos;                /* (2T-1, pos_dim) positional embedding */
+  const unsigned char* k8;         /* (B,T) key padding mask or NULL */
+  const unsigned char* a8;         /* (T,T) attention mask or NULL */
+  const float* fm;                 /* (B,D) feature mask or NULL */
+  float* out;                      /* forward: (T*B, D) layer output */
+  const float* g;                  /* backward: gradient w.r.t. out */
+  float* gx;                       /* backward: gradient w.r.t. x0 */
+  int dec[S2T_ZL_NDEC];
+  float* bal_ws;                   /* s2t_balancer_bwd_workspace_floats(), zeroed once */
+  float* layer_acc;                /* 3 D + 4 floats, zeroed once (per D) */
+  S2tZlWhScratch wh[8];
+  int nwh;
+  void* lt_ws;
+  long lt_ws_bytes;
+  int x3p_on, x3p_tile;
+  float x3p_margin;
+  int whiten_x3p;
+  long whiten_x3p_rows;
+  int conv_w_side, conv_fused, stats_side, wgrad_side, bmm_own;
+} S2tZipLayerCall;
+long s2t_zip_layer_state_bytes(void);
+long s2t_zip_layer_ws_floats(const S2tZipLayerDesc* desc, const S2tZipLayerCall* call, int backward);
+int s2t_zip_layer_plans_missing(const S2tZipLayerDesc* desc, int T, int B);
+int s2t_zip_layer_fwd(const S2tZipLayerDesc* desc, const S2tZipLayerCall* call, void* state, float* ws,
+                      long ws_floats, void* stream, void* side);
+int s2t_zip_layer_bwd(const S2tZipLayerDesc* desc, const S2tZipLayerCall* call, void* state, float* ws,
+                      long ws_floats, int phase, void* stream, void* side);
+long s2t_zip_layer_info(const void* state, int what, int idx);
+void* s2t_zip_layer_error(void);
+/* the timings zip_kernels.lt_matmul took for a shape bucket {mode, half-octave of the rows, N, K} of a
+ * Linear: library ms, own-kernel ms (< 0: none) and its tile -- what the executor's plan is made of */
+int s2t_zl_plan_put(int mode, int half_oct, int N, int K, double t_lib_ms, double t_own_ms, int tile);
+int s2t_zl_plan_clear(void);
+long s2t_zl_plan_count(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -350,3 +350,84 @@ extern "C" int s2t_linear_lt(int mode, const float* X, long ldx, const float* W,
 
 // launches served by our own kernel so far (diagnostics / tests)
 extern "C" long s2t_linear_lt_own_calls(void) { return g_own_calls; }
+
+// ---- batch of independent row-major fp32 products through hipBLASLt (strided batch): the shapes the
+// nonlinear attention's products (model/encoder/zipformer.py:2468-2473 and their gradients) hand to
+// the library -- rows that are not 16-byte multiples (T = 495, 62) and the a^T . b form:
+//   mode 0: C_b[M,N] = A_b[M,K] . B_b[N,K]^T;  mode 1: C_b = A_b[M,K] . B_b[K,N];
+//   mode 2: C_b[M,N] = A_b[K,M]^T . B_b[K,N].   Dense operands, batch stride = rows * cols.
+// Column-major view: C^T (N x M) = op(Bc) . op(Ac).
+namespace {
+struct BPlan {
+  hipblasLtMatmulDesc_t desc = nullptr;
+  hipblasLtMatrixLayout_t a = nullptr, b = nullptr, d = nullptr;
+  hipblasLtMatmulAlgo_t algo;
+  size_t ws = 0;
+  bool ok = false;
+};
+using BmmKey = std::tuple<int, int, int, int, int>;
+std::map<BmmKey, BPlan> g_bplans;
+
+int set_batch(hipblasLtMatrixLayout_t l, int batch, long stride) {
+  int32_t bc = batch;
+  int64_t so = stride;
+  LT_CHECK(hipblasLtMatrixLayoutSetAttribute(l, HIPBLASLT_MATRIX_LAYOUT_BATCH_COUNT, &bc, sizeof(bc)));
+  LT_CHECK(hipblasLtMatrixLayoutSetAttribute(l, HIPBLASLT_MATRIX_LAYOUT_STRIDED_BATCH_OFFSET, &so, sizeof(so)));
+  return 0;
+}
+
+int make_bplan(BPlan& p, int mode, int M, int N, int K, int batch, size_t ws_bytes) {
+  if (!g_handle) LT_CHECK(hipblasLtCreate(&g_handle));
+  LT_CHECK(hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F));
+  // lt "A" = our B as a column-major matrix, lt "B" = our A
+  hipblasOperation_t opa = mode == 0 ? HIPBLAS_OP_T : HIPBLAS_OP_N;
+  hipblasOperation_t opb = mode == 2 ? HIPBLAS_OP_T : HIPBLAS_OP_N;
+  LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &opa, sizeof(opa)));
+  LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &opb, sizeof(opb)));
+  if (mode == 0) LT_CHECK(hipblasLtMatrixLayoutCreate(&p.a, HIP_R_32F, K, N, K));     // B[N,K] rows
+  else LT_CHECK(hipblasLtMatrixLayoutCreate(&p.a, HIP_R_32F, N, K, N));               // B[K,N] rows
+  if (mode == 2) LT_CHECK(hipblasLtMatrixLayoutCreate(&p.b, HIP_R_32F, M, K, M));     // A[K,M] rows
+  else LT_CHECK(hipblasLtMatrixLayoutCreate(&p.b, HIP_R_32F, K, M, K));               // A[M,K] rows
+  LT_CHECK(hipblasLtMatrixLayoutCreate(&p.d, HIP_R_32F, N, M, N));
+  int rc = set_batch(p.a, batch, (long)N * K);
+  if (rc) return rc;
+  rc = set_batch(p.b, batch, (long)M * K);
+  if (rc) return rc;
+  rc = set_batch(p.d, batch, (long)M * N);
+  if (rc) return rc;
+  hipblasLtMatmulPreference_t pref;
+  LT_CHECK(hipblasLtMatmulPreferenceCreate(&pref));
+  LT_CHECK(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES,
+                                                 &ws_bytes, sizeof(ws_bytes)));
+  hipblasLtMatmulHeuristicResult_t res[4];
+  int n = 0;
+  hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(g_handle, p.desc, p.a, p.b, p.d, p.d, pref, 4, res, &n);
+  hipblasLtMatmulPreferenceDestroy(pref);
+  if (st != HIPBLAS_STATUS_SUCCESS || n < 1) return -2;
+  p.algo = res[0].algo;
+  p.ws = res[0].workspaceSize;
+  p.ok = true;
+  return 0;
+}
+}  // namespace
+
+extern "C" int s2t_bmm_lt(int mode, const float* A, const float* B, float* C, int batch, int M, int N,
+                          int K, void* workspace, long ws_bytes, void* stream) {
+  if (batch <= 0 || M <= 0 || N <= 0 || K <= 0 || mode < 0 || mode > 2 || !A || !B || !C) return -1;
+  std::lock_guard<std::mutex> lock(g_mu);
+  const BmmKey key{mode, M, N, K, batch};
+  auto it = g_bplans.find(key);
+  if (it == g_bplans.end()) {
+    if (g_bplans.size() >= 512) return -2;
+    BPlan p;
+    const int rc = make_bplan(p, mode, M, N, K, batch, (size_t)ws_bytes);
+    it = g_bplans.emplace(key, p).first;
+    if (rc != 0 && rc != -2) return rc;
+  }
+  BPlan& p = it->second;
+  if (!p.ok || p.ws > (size_t)ws_bytes) return -2;
+  const float alpha = 1.f, beta = 0.f;
+  LT_CHECK(hipblasLtMatmul(g_handle, p.desc, &alpha, B, p.a, A, p.b, &beta, C, p.d, C, p.d, &p.algo,
+                           workspace, p.ws, (hipStream_t)stream));
+  return 0;
+}

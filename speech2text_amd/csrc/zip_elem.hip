@@ -451,6 +451,43 @@ extern "C" int s2t_swoosh_fwd(const float* x, float* y, long n, float offset, fl
   return 0;
 }
 
+// out = a + b (out may be a or b): the residual adds the library GEMM path of the layer executor
+// cannot take in its epilogue (zip_layer.hip lt_matmul)
+namespace {
+__global__ __launch_bounds__(256) void add_kernel(const float* a, const float* b, float* out, long n) {
+  const long n4 = n >> 2;
+  const long stride = (long)gridDim.x * blockDim.x;
+  const float4* a4 = reinterpret_cast<const float4*>(a);
+  const float4* b4 = reinterpret_cast<const float4*>(b);
+  float4* o4 = reinterpret_cast<float4*>(out);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 u = a4[i], v = b4[i];
+    o4[i] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = a[i] + b[i];
+}
+}  // namespace
+
+extern "C" int s2t_add_f32(const float* a, const float* b, float* out, long n, void* stream) {
+  if (n <= 0) return 0;
+  if (!a || !b || !out || ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) |
+                            reinterpret_cast<uintptr_t>(out)) & 15))
+    return -1;
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, a, b,
+                     out, n);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+// The two alternating accumulators of s2t_balancer_bwd are shared by every caller of the process
+// (the Python call sites and the native layer executor): one parity sequence for all of them.
+static int g_bal_parity = 0;
+extern "C" int s2t_balancer_next_parity(void) {
+  g_bal_parity ^= 1;
+  return g_bal_parity;
+}
+
 extern "C" int s2t_swoosh_bwd(const float* x, const float* g, float* d, long n, float offset,
                               void* stream) {
   if (n <= 0) return 0;

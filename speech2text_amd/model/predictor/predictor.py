@@ -44,7 +44,11 @@ class StatelessPredictor(nn.Module):
         return self._blank_token
 
     def init_state(self, batch_size: int = 1) -> torch.Tensor:
-        return torch.zeros(batch_size, self._context_size - 1).to(torch.int32)
+        # on the parameters' device: the reference builds it on the CPU and forward() moves it
+        # (stateless_predictor.py:60-62, 86) -- a pageable host-to-device copy, i.e. a full stream
+        # synchronisation in the middle of every training step's forward pass
+        return torch.zeros(batch_size, self._context_size - 1, dtype=torch.int32,
+                           device=self._embedding.weight.device)
 
     def forward(self, input: torch.Tensor, lengths: torch.Tensor,
                 state: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:

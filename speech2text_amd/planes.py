@@ -132,6 +132,26 @@ def pieces(w2, mode):
 _ADHOC = {}          # (N, K, mode, device) -> (descriptor table, piece buffer, split workgroups)
 
 
+def adhoc_entry(Nw, Kw, mode, device):
+    """(descriptor table, piece buffer, split workgroups) of the ad-hoc piece slot of an (Nw, Kw)
+    matrix for `mode`, created on first use; None when the shape is outside the kernel's rules."""
+    if min(Nw, Kw) < 16:
+        return None
+    if not ((Kw % 8 == 0 and Nw % 4 == 0) if mode == 0 else (Nw % 8 == 0 and Kw % 4 == 0)):
+        return None
+    key = (Nw, Kw, mode, device.index)
+    e = _ADHOC.get(key)
+    if e is None:
+        L = N.lib()
+        n, k = (Nw, Kw) if mode == 0 else (Kw, Nw)
+        tab = np.array([(0, 0, n, k, Kw, 1 if mode else 0, 0, 0)], dtype=_DESC)
+        e = (torch.from_numpy(tab.view(np.uint8).copy()).to(device),
+             torch.empty(max(int(L.s2t_x3p_plane_elems(n, k)), 8), dtype=torch.int16, device=device),
+             int(L.s2t_x3p_split_blocks(n, k)))
+        _ADHOC[key] = e
+    return e
+
+
 def adhoc_pieces(w2, mode):
     """Pieces of a matrix that is NOT a parameter (e.g. the Whiten penalty's d metric / d cov),
     written now, on the current stream, into a scratch buffer that the next call with the same
@@ -140,20 +160,11 @@ def adhoc_pieces(w2, mode):
     if w2.dim() != 2 or w2.dtype is not torch.float32 or not w2.is_cuda or not w2.is_contiguous():
         return None
     Nw, Kw = int(w2.shape[0]), int(w2.shape[1])
-    if min(Nw, Kw) < 16 or w2.data_ptr() % 16:
+    if w2.data_ptr() % 16:
         return None
-    if not ((Kw % 8 == 0 and Nw % 4 == 0) if mode == 0 else (Nw % 8 == 0 and Kw % 4 == 0)):
-        return None
-    key = (Nw, Kw, mode, w2.device.index)
-    e = _ADHOC.get(key)
+    e = adhoc_entry(Nw, Kw, mode, w2.device)
     if e is None:
-        L = N.lib()
-        n, k = (Nw, Kw) if mode == 0 else (Kw, Nw)
-        tab = np.array([(0, 0, n, k, Kw, 1 if mode else 0, 0, 0)], dtype=_DESC)
-        e = (torch.from_numpy(tab.view(np.uint8).copy()).to(w2.device),
-             torch.empty(max(int(L.s2t_x3p_plane_elems(n, k)), 8), dtype=torch.int16, device=w2.device),
-             int(L.s2t_x3p_split_blocks(n, k)))
-        _ADHOC[key] = e
+        return None
     tab, buf, blocks = e
     N.PROF[0] and N.profile_note("s2t_x3p_split", 4.0 * Nw * Kw + 2.0 * buf.numel())
     N.check(N.lib().s2t_x3p_split(w2.data_ptr(), tab.data_ptr(), 1, blocks, buf.data_ptr(), N.stream()),

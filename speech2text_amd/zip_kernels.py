@@ -286,7 +286,7 @@ def balancer_backward(x, g, min_mean, max_mean, min_rms, max_rms, grad_scale, ch
                                                N.stream()), "s2t_balancer_apply")
             return out if out is g else out.reshape(g.shape)
         ws = _balancer_workspace(x.device)
-        ws[1] ^= 1
+        ws[1] = N.lib().s2t_balancer_next_parity()      # (one sequence for this path and zip_layer.hip)
         N.PROF[0] and N.profile_note("s2t_balancer_bwd", 4.0 * rows * C * 4)     # x twice (stats, update), g, out
         N.check(N.lib().s2t_balancer_bwd(N.raw(x2, torch.float32), x2.stride(0),
                                          N.raw(g2, torch.float32), g2.stride(0), rows, C, min_mean,
@@ -470,7 +470,16 @@ def whiten_backward(x, g, stats, limit, grad_scale):
         if pp is not None:
             pg = x3p_matmul(1, xf, dcov, bias, pp=pp)
     if pg is None:
-        pg = torch.addmm(bias, xf, dcov)
+        # (our NN kernel with the bias in its epilogue: the same call csrc/zip_layer.hip makes)
+        pg = torch.empty((xf.shape[0], C), dtype=torch.float32, device=dev)
+        N.PROF[0] and N.profile_note("s2t_gemm_f32", 4.0 * (xf.numel() + pg.numel() + C * C), 2.0 * xf.shape[0] * C * C)
+        rc = N.lib().s2t_gemm_f32(1, N.raw(xf, torch.float32), xf.stride(0), N.fp(dcov), C, N.fp(pg), C,
+                                  xf.shape[0], C, C, N.fp(bias), None, 0, None, 0, 0, 0, 0, None, 0,
+                                  N.stream()) if xf.stride(1) == 1 else -2
+        if rc == -2:
+            pg = torch.addmm(bias, xf, dcov)
+        else:
+            N.check(rc, "s2t_gemm_f32(whiten)")
     g2 = g.contiguous().float()
     if g2.data_ptr() % 16:
         g2 = g2.clone()
@@ -1267,6 +1276,18 @@ def batched_matmul(mode, a, b):
             return out
         if rc != -2:
             N.check(rc, "s2t_gemm_f32_batched")
+    if a.is_cuda and a.dtype is torch.float32 and b.dtype is torch.float32 and a.is_contiguous() \
+            and b.is_contiguous() and n > 0:
+        # the library's strided-batch product through our C ABI (the call csrc/zip_layer.hip makes)
+        out = torch.empty((n, M, Nn), dtype=torch.float32, device=a.device)
+        ws = _lt_workspace(a.device)
+        N.PROF[0] and N.profile_note("s2t_bmm_lt", 4.0 * (a.numel() + b.numel() + out.numel()), 2.0 * n * M * Nn * K)
+        rc = N.lib().s2t_bmm_lt(mode, N.fp(a), N.fp(b), N.fp(out), n, M, Nn, K, ws.data_ptr(), ws.numel(),
+                                N.stream())
+        if rc == 0:
+            return out
+        if rc != -2:
+            N.check(rc, "s2t_bmm_lt")
     if mode == 0:
         return torch.bmm(a, b.transpose(1, 2))
     if mode == 1:
@@ -1489,6 +1510,9 @@ def lt_matmul(mode, x2, w2, bias=None, resid2=None, act_src=None, act_kind=None,
                 b = (t_lib, t_own, tile)
                 PLAN_STATS["timed"] += 1
             _BASE[base] = b
+            # the native layer executor (csrc/zip_layer.hip) decides from the same numbers
+            N.lib().s2t_zl_plan_put(base[0], base[1], base[2], base[3], float(b[0]),
+                                    -1.0 if b[1] is None else float(b[1]), int(b[2]))
         t_lib, t_own, tile = b
         if t_own is None:
             plan = ("lt", 0)

@@ -28,6 +28,7 @@ import torch
 from . import _native as N
 from . import flat
 from . import zip_kernels as zk
+from . import zip_native as zn
 from .model.layer import scaling as S
 
 _F32 = torch.float32
@@ -178,8 +179,13 @@ def run(layer, src, pos_emb, chunk_size, attn_mask=None, key_padding_mask=None, 
         fm = feature_mask.reshape(src.shape[1], src.shape[2])
         if fm.dtype != _F32 or not fm.is_contiguous():
             fm = fm.contiguous().float()
-    return _LayerFn.apply(src, pos_emb, layer, chunk_size, d, _mask8(attn_mask),
-                          _mask8(key_padding_mask), fm)
+    a8, k8 = _mask8(attn_mask), _mask8(key_padding_mask)
+    # one C call per pass (csrc/zip_layer.hip) once the layer's GEMM shapes have been timed;
+    # the Python executor below is the same launch sequence and times them on first sight
+    L = zn.usable(layer, src.shape[0], src.shape[1])
+    if L is not None:
+        return zn.run(layer, L, src, pos_emb, chunk_size, d, a8, k8, fm)
+    return _LayerFn.apply(src, pos_emb, layer, chunk_size, d, a8, k8, fm)
 
 
 # ----------------------------------------------------------------------------- raw helpers
@@ -423,7 +429,7 @@ def _na_bwd(m, post, dec, sv, x_in, g, T, B):
     N.PROF[0] and N.profile_note("s2t_nonlin_out_bwd", 20.0 * T * B * C)
     N.check(L.s2t_nonlin_out_bwd(N.fp(do), N.fp(sv.z), N.fp(sv.u), T, B, C, N.fp(dz), N.fp(du), st),
             "nonlin_out_bwd")
-    dxs = torch.bmm(sv.wm.transpose(1, 2), dz)
+    dxs = zk.batched_matmul(2, sv.wm, dz)                                    # W0^T @ dz, (B,T,C)
     dW0 = zk.batched_matmul(0, dz, sv.xs)                                    # dz @ x^T, (B,T,T)
     N.PROF[0] and N.profile_note("s2t_nonlin_gate_bwd", 20.0 * T * B * C)
     N.check(L.s2t_nonlin_gate_bwd(N.fp(dxs), N.fp(sv.u), T, B, C, N.fp(du), st), "nonlin_gate_bwd")

@@ -89,7 +89,7 @@ def test_pruned_rnnt_validation_step_vs_oracle(dev):
     hyps = []
     for b in range(dec.shape[0]):
         ids = OD.rnnt_greedy_stateless(sd, "p.", "j.", dec[b].cpu(), int(dl[b]), ctx,
-                                       cfg["joiner"]["activation"], 1)
+                                       cfg["joiner"].get("activation", "relu"), 1)
         hyps.append(task._tokenizer.decode(torch.tensor(ids, dtype=torch.int64)))
     assert info["wer"] == pytest.approx(OD.word_error_rate(hyps, _refs(task, batch["label"])))
 

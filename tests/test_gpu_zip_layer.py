@@ -129,3 +129,54 @@ def test_executor_with_forward_balancer_statistics(dev, monkeypatch, flag):
     torch.testing.assert_close(outs[0][1], outs[1][1], atol=2e-5, rtol=2e-3)
     scale = outs[0][2].abs().max()
     assert (outs[0][2] - outs[1][2]).abs().max() / scale < 2e-4
+
+
+@pytest.mark.parametrize("chunk,left", [((-1,), (-1,)), ((8,), (16,))])
+@pytest.mark.parametrize("rv", [0.0, 0.2, 0.5])
+def test_native_executor_matches_python_executor(dev, monkeypatch, rv, chunk, left):
+    """csrc/zip_layer.hip (one C call per layer pass) against zip_layer._LayerFn, the same launch
+    sequence issued from Python, with every random draw pinned to rv: 0.0 fires every Balancer /
+    Whiten / limit / the score penalty, 0.2 the Balancers and limits, 0.5 the limits only.  The
+    forward output is bit-identical; so is the input gradient when no statistics kernel runs
+    (rv 0.5) -- the Balancer / Whiten statistics and the weight gradients are summed with fp32
+    atomics, so two runs of ONE path already differ in the last bits there."""
+    from speech2text_amd import rng, zip_layer, zip_native
+    from speech2text_amd.model.layer import scaling as S
+    monkeypatch.setattr(rng, "rand", lambda *s, device=None, dtype=torch.float32:
+                        torch.rand(*s, dtype=dtype).to(device))
+    monkeypatch.setattr(S, "_rand", lambda: rv)
+    m, store = _build(dev, chunk, left)
+    g = torch.Generator().manual_seed(11)
+    B, T = 4, 203
+    x = (torch.randn(B, T, 80, generator=g) * 2).to(dev)
+    lens = torch.tensor([203, 180, 97, 64]).to(dev)
+    with torch.no_grad():
+        wts = torch.randn(m(x, lens)[0].shape, generator=g).to(dev)
+
+    def step(native):
+        monkeypatch.setattr(zip_native, "ENABLED", native)
+        _force(m, False)
+        return _step(m, store, x, lens, wts, 3, True)
+
+    step(False)                                   # times the GEMM shape buckets (Python executor)
+    n0 = list(zip_native.CALLS)
+    y1, gx1, gp1 = step(True)
+    assert zip_native.CALLS[0] - n0[0] == 4 and zip_native.CALLS[1] - n0[1] == 4    # every layer call
+    y0, gx0, gp0 = step(False)
+    assert zip_native.CALLS[0] - n0[0] == 4
+    assert torch.equal(y1, y0)
+    if rv == 0.5:
+        assert torch.equal(gx1, gx0)
+    else:
+        torch.testing.assert_close(gx1, gx0, atol=2e-5, rtol=2e-3)
+    for p, (o, n) in zip(store.params, zip(store.offsets, store.lengths)):
+        a, b = gp1[o:o + n], gp0[o:o + n]
+        assert (a - b).abs().max() <= 2e-3 * b.abs().max() + 1e-6, tuple(p.shape)
+    # the Whiten modules' probabilities moved the same way in both backward passes
+    from speech2text_amd.model.layer.scaling import Whiten
+    probs1 = None
+    for native in (True, False):
+        step(native)
+        probs = [w.prob for w in m.modules() if isinstance(w, Whiten)]
+        assert probs1 is None or probs == probs1
+        probs1 = probs

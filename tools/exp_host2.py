@@ -1,45 +1,53 @@
-"""Host-side profile of one C3 training step with the backward pass on the calling thread
-(autograd multithreading off), GPU queue drained first: where the Python time of a step goes."""
-import os, sys, time, random, cProfile, pstats, io
+"""Host time of a C3 training step by phase (no GPU synchronisation inside the step): forward,
+loss.backward() (the autograd thread's enqueue time), optimizer; B from argv."""
+import os, sys, time, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from speech2text_amd.task_factory.rnnt_task import PrunedRnntTask
 from speech2text_amd.trainer import Trainer
 
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 dev = torch.device("cuda", 0)
 cfg = bench.c3_config(500)
 torch.manual_seed(1234); random.seed(1234)
 task = PrunedRnntTask(cfg)
 trainer = Trainer(**cfg["trainer"]).setup(task, dev)
 task.train()
-batch = bench.make_batch(0, 64, 10.0, 50, 500, dev)
-for i in range(4):
+batch = bench.make_batch(0, B, 10.0, 50, 500, dev)
+for i in range(5):
     trainer.training_step(batch, i)
 torch.cuda.synchronize()
-torch.autograd.set_multithreading_enabled(False)
-for i in range(2):
-    trainer.training_step(batch, i)
-hs = []
-for i in range(5):
+marks = {}
+orig_bwd = torch.Tensor.backward
+
+
+def timed_bwd(self, *a, **k):
+    t = time.perf_counter()
+    r = orig_bwd(self, *a, **k)
+    marks["bwd"] = marks.get("bwd", 0.0) + time.perf_counter() - t
+    marks["bwd_start"] = t
+    return r
+
+
+torch.Tensor.backward = timed_bwd
+rows = []
+for i in range(8):
     torch.cuda.synchronize()
+    marks.clear()
     t0 = time.perf_counter()
     trainer.training_step(batch, i)
-    hs.append(time.perf_counter() - t0)
+    t1 = time.perf_counter()
     torch.cuda.synchronize()
-print("host enqueue (single thread): %.1f ms" % (1e3 * sorted(hs)[2]), flush=True)
-pr = cProfile.Profile()
-torch.cuda.synchronize()
-pr.enable()
-trainer.training_step(batch, 0)
-pr.disable()
-torch.cuda.synchronize()
-st = pstats.Stats(pr)
-rows = []
-for (fn, line, name), (cc, nc, tt, ct, callers) in st.stats.items():
-    rows.append((tt, ct, nc, "%s:%d(%s)" % (os.path.basename(fn), line, name)))
-tot = sum(r[0] for r in rows)
-print("profiled step: %.2f ms in %d functions" % (1e3 * tot, len(rows)))
-print("%9s %9s %7s  function" % ("self ms", "cum ms", "calls"))
-for tt, ct, nc, nm in sorted(rows, reverse=True)[:70]:
-    print("%9.3f %9.3f %7d  %s" % (1e3 * tt, 1e3 * ct, nc, nm))
+    t2 = time.perf_counter()
+    rows.append((marks["bwd_start"] - t0, marks["bwd"], t1 - marks["bwd_start"] - marks["bwd"], t1 - t0, t2 - t0))
+rows.sort(key=lambda r: r[3])
+f, b, o, h, g = rows[len(rows) // 2]
+print("B=%d  one step from an empty queue: forward %.1f ms, backward %.1f ms, after backward %.1f ms, host total %.1f ms, GPU done %.1f ms"
+      % (B, 1e3 * f, 1e3 * b, 1e3 * o, 1e3 * h, 1e3 * g), flush=True)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for i in range(20):
+    trainer.training_step(batch, i)
+th = time.perf_counter() - t0
+torch.cuda.synchronize(); t = time.perf_counter() - t0
+print("20 steps back to back: %.2f ms/step (host returned after %.2f ms/step)" % (50 * t, 50 * th), flush=True)
