@@ -497,7 +497,9 @@ def gemm_paths():
     pre-split-weight kernel, the plan cache's choice (hipBLASLt or the round-3 kernel), and the
     ATen fallback (a shape hipBLASLt had no algorithm for) -- the last must stay 0 on the bench."""
     from speech2text_amd import zip_kernels as zk
-    return {"x3p_calls": int(zk.X3P["calls"]), "lt_calls": int(zk.LT_STATS["calls"]),
+    from speech2text_amd import _native as N
+    # (counted inside the library: the native layer executor's launches never pass through Python)
+    return {"x3p_calls": int(N.lib().s2t_gemm_x3p_calls()), "lt_calls": int(N.lib().s2t_linear_lt_calls()),
             "lt_own_calls": int(zk.lt_own_calls()), "aten_fallbacks": int(zk.LT_STATS["aten_fallbacks"])}
 
 

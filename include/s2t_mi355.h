@@ -709,6 +709,15 @@ int s2t_stream_order(void* from, void* to);
  * reports), not the times of marker packets recorded around it.  s2t_prof_pair_consumed: 1 if a
  * launch took the armed pair, 0 if it was still armed (either way it is disarmed afterwards).
  * s2t_prof_pair_ms waits for the stop event and returns the elapsed milliseconds in *ms. */
+/* the same for a SAMPLE of launches, counted inside s2t_gemm_x3p itself (so the launches the native
+ * layer executor issues are sampled like the Python call sites'): every `every`-th launch between
+ * begin and end carries its own event pair; end waits for them and reports how many were timed, their
+ * total milliseconds and the algorithmic bytes / flops of exactly those launches
+ * (4 M (N + K + operands N) + 6 N K bytes, 2 M N K flops).  s2t_gemm_x3p_calls: launches so far. */
+int s2t_x3p_sample_begin(int every);
+int s2t_x3p_sample_end(long* launches, double* total_ms, double* bytes, double* flops);
+long s2t_gemm_x3p_calls(void);
+long s2t_linear_lt_calls(void);
 int s2t_prof_pair_create(void** start, void** stop);
 int s2t_prof_pair_arm(void* start, void* stop);
 int s2t_prof_pair_consumed(void);

@@ -106,6 +106,7 @@ void destroy_plan(Plan& p) {
 }
 std::mutex g_mu;
 hipblasLtHandle_t g_handle = nullptr;
+long g_lt_calls = 0;
 
 #define LT_CHECK(x)                                   \
   do {                                                \
@@ -310,6 +311,7 @@ extern "C" int s2t_linear_lt(int mode, const float* X, long ldx, const float* W,
   }
   Plan& p = it->second;
   if (!p.ok || p.ws > (size_t)ws_bytes) return -2;
+  ++g_lt_calls;
   if (bias)
     LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)));
   if (!p.tuned) {
@@ -348,6 +350,7 @@ extern "C" int s2t_linear_lt(int mode, const float* X, long ldx, const float* W,
   return 0;
 }
 
+extern "C" long s2t_linear_lt_calls(void) { return g_lt_calls; }
 // launches served by our own kernel so far (diagnostics / tests)
 extern "C" long s2t_linear_lt_own_calls(void) { return g_own_calls; }
 

@@ -26,6 +26,8 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
+#include <utility>
+#include <vector>
 
 namespace {
 
@@ -1155,6 +1157,20 @@ int s2t_x3p_split(const float* base, const void* tab, int n, int total_blocks, u
 
 static float* g_colstats = nullptr;      // armed by s2t_gemm_x3p_stats for the one launch it makes
 
+// ---- sampled kernel-attached timing of this entry point, kept HERE so that launches issued by the
+// native layer executor (csrc/zip_layer.hip) and by the Python call sites are sampled alike: while a
+// sample is open every `every`-th launch is issued with its own (start, stop) event pair
+// (hipExtLaunchKernelGGL: the kernel's begin / end times) and its algorithmic bytes / flops are added up.
+namespace {
+struct Sampler {
+  int every = 0;
+  long count = 0, launches = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pool, used;
+  double bytes = 0.0, flops = 0.0;
+} g_samp;
+}  // namespace
+static long g_x3p_calls = 0;
+
 int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int K, float* C, long ldc,
                  int M, const float* bias, const float* resid, long ldr, const float* act_src,
                  long ld_act, int act_kind, float* C2, long ldc2, int act2, const float* resid_b,
@@ -1206,6 +1222,26 @@ int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int 
     g.prio = prio;
   }
   hipStream_t st = (hipStream_t)stream;
+  ++g_x3p_calls;
+  if (g_samp.every > 0 && !s2t_prof_start && (g_samp.count++ % g_samp.every) == 0) {
+    std::pair<hipEvent_t, hipEvent_t> pr;
+    bool ok = true;
+    if (!g_samp.pool.empty()) {
+      pr = g_samp.pool.back();
+      g_samp.pool.pop_back();
+    } else {
+      ok = hipEventCreate(&pr.first) == hipSuccess && hipEventCreate(&pr.second) == hipSuccess;
+    }
+    if (ok) {
+      g_samp.used.push_back(pr);
+      s2t_prof_start = pr.first;
+      s2t_prof_stop = pr.second;
+      const int extra = (resid != nullptr) + (act_src != nullptr) + (C2 != nullptr) + (resid_b != nullptr);
+      g_samp.bytes += 4.0 * M * ((double)N + K + (double)extra * N) + 6.0 * (double)N * K;
+      g_samp.flops += 2.0 * (double)M * N * K;
+      ++g_samp.launches;
+    }
+  }
   if (tile == 33) {
     if ((K + 15) / 16 < Q_NQ + 2) return -2;         // (E must be drained before the next tile refills it)
     g.tiles_m = (M + 127) / 128;
@@ -1251,6 +1287,38 @@ int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int 
     default: launch_x3p<1, 1>(g, st); break;
   }
   S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+long s2t_gemm_x3p_calls(void) { return g_x3p_calls; }
+
+// every > 0: open a sample (every n-th launch from now on); s2t_x3p_sample_end closes it, waits for
+// the sampled kernels and reports {launches, their total ms, algorithmic bytes, flops}
+int s2t_x3p_sample_begin(int every) {
+  for (auto& pr : g_samp.used) g_samp.pool.push_back(pr);
+  g_samp.used.clear();
+  g_samp.every = every > 0 ? every : 0;
+  g_samp.count = g_samp.launches = 0;
+  g_samp.bytes = g_samp.flops = 0.0;
+  return 0;
+}
+int s2t_x3p_sample_end(long* launches, double* total_ms, double* bytes, double* flops) {
+  g_samp.every = 0;
+  double ms = 0.0;
+  long n = 0;
+  for (auto& pr : g_samp.used) {
+    float t = 0.f;
+    if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&t, pr.first, pr.second) == hipSuccess) {
+      ms += t;
+      ++n;
+    }
+    g_samp.pool.push_back(pr);
+  }
+  g_samp.used.clear();
+  if (launches) *launches = n;
+  if (total_ms) *total_ms = ms;
+  if (bytes) *bytes = g_samp.bytes;
+  if (flops) *flops = g_samp.flops;
   return 0;
 }
 

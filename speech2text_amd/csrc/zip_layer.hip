@@ -228,9 +228,15 @@ int lt_matmul(Ctx& c, int mode, const float* x, long ldx, long R, const S2tZlLin
   float* y = out;
   float* tmp = nullptr;
   if (e.act_src) y = tmp = c.ar.alloc(n);
-  RUN(s2t_linear_lt(mode, x, ldx, L.w, L.K, e.bias, e.act_src ? nullptr : e.resid2, cols,
-                    (!e.act_src && e.resid2) ? 1.0f : 0.0f, y, cols, (int)R, L.N, L.K, c.c.lt_ws,
-                    c.c.lt_ws_bytes, (void*)c.st));
+  if (!c.dry) {
+    const float* res = e.act_src ? nullptr : e.resid2;
+    int rc = s2t_linear_lt(mode, x, ldx, L.w, L.K, e.bias, res, cols, res ? 1.0f : 0.0f, y, cols, (int)R, L.N,
+                           L.K, c.c.lt_ws, c.c.lt_ws_bytes, (void*)c.st);
+    if (rc == -2)     // no library algorithm for this shape: our NT / NN kernel (the Python path takes ATen's)
+      rc = s2t_gemm_f32(mode, x, ldx, L.w, L.K, y, cols, (int)R, cols, inner, e.bias, res, cols, nullptr, 0, 0, 0,
+                        0, nullptr, 0, (void*)c.st);
+    if (rc != 0) return fail(rc, "s2t_linear_lt");
+  }
   if (e.act_src) {
     RUN(s2t_swoosh_bwd(e.act_src, tmp, out, n, kSwOff[e.act_kind], (void*)c.st));
     if (e.resid2) RUN(s2t_add_f32(out, e.resid2, out, n, (void*)c.st));

@@ -94,3 +94,13 @@ class LstmPredictor(nn.Module):
     def forward(self, input: torch.Tensor, lengths: torch.Tensor, state: List[List[torch.Tensor]]):
         x = F.pad(input.to(torch.int32), (1, 0), value=self._blank_token)     # (B, 1+U)
         return self._predictor(x, lengths, None if len(state) == 0 else state)
+
+    @torch.no_grad()
+    def streaming_step(self, input: torch.Tensor, state: List[List[torch.Tensor]]):
+        """One token in, one prediction out (reference lstm_predictor.py:90-109): no left padding;
+        [] = the initial state."""
+        assert input.shape[0] == 1 and input.shape[1] == 1
+        lengths = torch.ones(1, dtype=torch.int64, device=input.device)
+        out, _, state_out = self._predictor(input.to(torch.int32), lengths,
+                                            None if len(state) == 0 else state)
+        return out, state_out

@@ -291,7 +291,7 @@ def _side_handle():
 def usable(layer, T, B):
     """Can the native executor serve this layer call?  (zip_layer.eligible has passed already.)"""
     if not ENABLED or N._Prof.target == "*" or zk._BAL_GEMM or zk._BAL_FWD \
-            or "S2T_ATTN_FWD_OLD" in os.environ or zk.LT_STATS["aten_fallbacks"]:
+            or "S2T_ATTN_FWD_OLD" in os.environ:
         return None
     L = _static(layer)
     if not L.ok:
