@@ -481,7 +481,13 @@ def roofline_report(prof_timed, prof_all, want, step_flops, ms_per_step, sampled
     tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
     if os.path.exists(tpath):
         try:
-            out["traffic"] = json.load(open(tpath)).get(want, {}).get("hbm_bytes_per_launch")
+            ent = json.load(open(tpath)).get(want, {})
+            out["traffic"] = ent.get("hbm_bytes_per_launch")
+            # the algorithmic bytes of the SAME launches the counters were read over (the PMC passes
+            # run bench.py --steps 1 --sample-every 1: their timed step is the counted step)
+            if ent.get("algorithmic_bytes_per_launch"):
+                out["traffic_algorithmic_bytes_per_launch"] = ent["algorithmic_bytes_per_launch"]
+                out["traffic_over_algorithmic"] = out["traffic"] / ent["algorithmic_bytes_per_launch"]
         except Exception:
             pass
     out["kernels"] = table
@@ -574,6 +580,11 @@ def parse_args(argv=None):
     ap.add_argument("--random-chunk", action="store_true",
                     help="C3 only: the shipped YAML's chunk_size [16, 32, 64, -1] / "
                          "left_context_frames [64, 128, 256, -1] (one draw per step) instead of -1")
+    ap.add_argument("--sample-every", type=int, default=0,
+                    help="bracket every n-th launch of the roofline entry inside the timed region "
+                         "(0 = chosen from its launches per step; 1 = every launch: the PMC passes of "
+                         "tools/gpu_pmc2.sh use it so that traffic and algorithmic bytes cover the "
+                         "same launches)")
     ap.add_argument("--launcher-selftest", action="store_true")
     args = ap.parse_args(argv)
     # per-rank batch, labels per utterance, vocabulary, utterance seconds
@@ -702,7 +713,9 @@ def main(argv=None):
     # launch, n coprime to the launches per step): two event records per launch would cost the
     # timed step several per cent
     every = 1
-    if want_launches > 48:
+    if args.sample_every > 0:
+        every = args.sample_every
+    elif want_launches > 48:
         every = max(2, want_launches // 32)
         while want_launches % every == 0 or (every > 2 and every % 2 == 0):
             every += 1

@@ -268,13 +268,32 @@ __device__ __forceinline__ void x3p_epi_store(const X3P& g, const EpiRs& rs, con
   }
 }
 
-template <int TM, int TN>
+// LEAN: one slice at a time (operands of ONE slice live: 16 registers instead of 32 TN) -- for the
+// kernels that run three or more workgroups per CU on a tight register budget, where the other
+// workgroups cover a slice's load -> store round trip
+template <int TM, int TN, bool LEAN = false>
 __device__ __forceinline__ void x3p_epilogue(const X3P& g, f32x16 (&acc)[TM][TN], unsigned char* smem,
                                              int m0, int n0, int wrb, int wcb, int wave, int lane,
                                              bool sync = true) {
   if (sync) __syncthreads();                         // all waves finished reading the stage buffers
   float* scr = reinterpret_cast<float*>(smem) + wave * (16 * 36);
   const EpiRs rs = x3p_epi_rsrc(g);
+  if (LEAN) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const f32x4 bqj = x3p_epi_bias(g, j, n0, wcb, lane);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          EpiOps o;
+          x3p_epi_load(g, rs, o, i, j, h, m0, n0, wrb, wcb, lane);
+          x3p_epi_xform(g, acc[i][j], scr, o, bqj, h, lane);
+          x3p_epi_store(g, rs, acc[i][j], o, i, j, h, m0, n0, wrb, wcb, lane);
+        }
+    }
+    return;
+  }
   f32x4 bq[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) bq[j] = x3p_epi_bias(g, j, n0, wcb, lane);
@@ -743,6 +762,196 @@ void x3p_db_kernel(X3P g) {
 #undef X3P_TILE
 }
 
+// ---- LDS-DMA form (round 5): the weight pieces of a stage go global -> LDS directly
+// (global_load_lds_dwordx4: the fragment-major image makes a stage of B one straight run), no
+// staging registers and no ds_write for them; A as before (registers, split once, stored as
+// pieces), ONE set of staging registers.  What that buys is registers and LDS-store cycles: the
+// 2 x 2 tile fits THREE workgroups per CU (<= 168 registers, 48 KB of LDS), 2 x 1 / 1 x 2 four --
+// one more wave per SIMD to cover a workgroup's dependent chain barrier -> fragment reads -> MFMAs,
+// and a grid of 768 slots, which holds the 744 tiles of the 15 872-row products in ONE round where
+// 512 slots ran 1.45 rounds (the second less than half full).
+// The DMA is inline asm (as a builtin the compiler would drain vmcnt(0) before every LDS read that
+// follows it in program order) and is waited for by hand; the A loads stay ordinary loads, and the
+// schedule keeps the two kinds of wait from seeing each other's operations: a DMA is issued AFTER
+// the point where the compiler waits for the A registers and has landed (hand-counted wait at the
+// top of the next iteration) BEFORE the compiler waits again.  (A loads as inline asm do not work:
+// the compiler may copy an asm output to other registers, or reuse it as a temporary, before the
+// hand-written wait -- the pending load then lands on top of an address computation.)
+//   iteration kb:  wait B(kb) landed (vmcnt = the A loads in flight);  barrier;
+//                  fragments of stage kb;  split A(kb+1) (the compiler's wait: only A is in flight);
+//                  DMA B(kb+1) -> buffer (kb+1) & 1;  request A(kb+2);  first products;
+//                  store A(kb+1)'s pieces -> buffer (kb+1) & 1;  the other products.
+// (the form csrc/gemm_x3f.hip has run with since round 3: per-lane 64-bit address, no SGPR base)
+__device__ __forceinline__ void x3p_glds16(const void* g, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_addr)
+               : "memory", "m0");
+}
+__device__ __forceinline__ unsigned x3p_lds_addr(const void* p) {
+  return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+
+template <int TM, int TN, int WPC>
+__global__ __launch_bounds__(256, WPC) void x3p_dma_kernel(X3P g) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int A_ST = 2 * TM * 3 * 1024, B_ST = 2 * TN * 3 * 1024, ST = A_ST + B_ST;
+  constexpr int NAU = (128 * TM + 255) / 256;       // A units (8 k of one row) per thread and stage
+  constexpr int NBW = (6 * TN + 3) / 4;             // B DMA wave-instructions (1 KB each) per wave and stage
+  constexpr int SCR = 4 * 16 * 36 * 4;
+  static_assert(128 * TM % 256 == 0 || TM == 1, "A units");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * ST > SCR ? 2 * ST : SCR];
+  const unsigned lds0 = x3p_lds_addr(smem);
+
+  const int total = g.tiles_m * g.tiles_n;
+  const int per_xcd = (total + 7) / 8;
+  const int xcd = blockIdx.x & 7, stride = gridDim.x >> 3;
+  int loc = blockIdx.x >> 3;
+  if (loc >= per_xcd || xcd * per_xcd + loc >= total) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wrb = (wave >> 1) * TM, wcb = (wave & 1) * TN;
+
+  int a_r[NAU], a_k[NAU];
+  unsigned a_dst[NAU];
+  bool a_on[NAU];
+#pragma unroll
+  for (int i = 0; i < NAU; ++i) {
+    const int u = tid + 256 * i;
+    a_on[i] = u < 128 * TM;
+    const int uu = a_on[i] ? u : 0;
+    const int r = (uu & 15) + 16 * (uu >> 5), kq = (uu >> 4) & 1;
+    a_r[i] = r;
+    a_k[i] = 8 * kq;
+    a_dst[i] = (unsigned)((((r >> 5) * 3) * 64 + kq * 32 + (r & 31)) * 16);
+  }
+  // B: wave-instruction q of this wave moves the 1 KB run pw = wave + 4 q = (32-column block) * 3 +
+  // piece of the stage's 6 TN KB (a wave past the end repeats the last run: same bytes to the same
+  // place, no branch); a block's 16-deep chunk is 3 KB = 1536 bf16 of the plane image
+  const int nst = (g.K + 15) >> 4;
+  const int lane8 = lane * 8;                       // (bf16 elements: 16 bytes per lane)
+  const float* asrc[NAU];
+  const unsigned short* bsrc[NBW];
+  unsigned b_dst[NBW];
+#pragma unroll
+  for (int q = 0; q < NBW; ++q) {
+    const int pw = min(wave + 4 * q, 6 * TN - 1);
+    b_dst[q] = (unsigned)(A_ST + pw * 1024);
+  }
+  int m0, n0;
+#define XD_TILE(LOC)                                                                         \
+  {                                                                                          \
+    const int lin_ = xcd * per_xcd + (LOC);                                                  \
+    const int tm_ = lin_ / g.tiles_n, tn_ = lin_ - tm_ * g.tiles_n;                          \
+    m0 = tm_ * BM;                                                                           \
+    n0 = tn_ * BN;                                                                           \
+    _Pragma("unroll") for (int i = 0; i < NAU; ++i)                                          \
+      asrc[i] = g.A + (long)min(m0 + a_r[i], g.M - 1) * g.lda + a_k[i];                      \
+    _Pragma("unroll") for (int q = 0; q < NBW; ++q) {                                        \
+      const int pw_ = min(wave + 4 * q, 6 * TN - 1);                                         \
+      const int nt_ = min((n0 >> 5) + pw_ / 3, g.NT - 1);     /* 32-column block, piece */   \
+      bsrc[q] = g.Bp + (long)nt_ * g.KB * 1536 + (pw_ % 3) * 512;                            \
+    }                                                                                        \
+  }
+  f32x4 ra[NAU][2];
+  u32x4 qa[NAU][3];
+#define XD_LOAD_A(S)                                                                         \
+  {                                                                                          \
+    const int ss_ = min((S), nst - 1);                                                       \
+    _Pragma("unroll") for (int i = 0; i < NAU; ++i) {                                        \
+      gf32p p_ = (gf32p)(asrc[i] + ((16 * ss_ + a_k[i] < g.K) ? 16 * ss_ : 0));             \
+      ra[i][0] = *reinterpret_cast<gf32x4p>(p_);                                             \
+      ra[i][1] = *reinterpret_cast<gf32x4p>(p_ + 4);                                         \
+    }                                                                                        \
+  }
+#define XD_DMA_B(S, BUF)                                                                     \
+  {                                                                                          \
+    const int ss_ = min((S), nst - 1);                                                       \
+    _Pragma("unroll") for (int q = 0; q < NBW; ++q)                                          \
+      x3p_glds16(bsrc[q] + (long)ss_ * 1536 + lane8, lds0 + (BUF) * ST + b_dst[q]);          \
+  }
+#define XD_SPLIT(S)                                                                          \
+  {                                                                                          \
+    const int ss_ = min((S), nst - 1);                                                       \
+    _Pragma("unroll") for (int i = 0; i < NAU; ++i) {                                        \
+      const bool v_ = 16 * ss_ + a_k[i] < g.K;                                               \
+      const f32x4 z_ = {0.f, 0.f, 0.f, 0.f};                                                 \
+      split8(v_ ? ra[i][0] : z_, v_ ? ra[i][1] : z_, qa[i][0], qa[i][1], qa[i][2]);          \
+    }                                                                                        \
+  }
+#define XD_STORE_A(BUF)                                                                      \
+  {                                                                                          \
+    unsigned char* const sa_ = smem + (BUF) * ST;                                            \
+    _Pragma("unroll") for (int i = 0; i < NAU; ++i)                                          \
+      if (NAU * 256 == 128 * TM || a_on[i]) {                                                \
+        *reinterpret_cast<u32x4*>(sa_ + a_dst[i]) = qa[i][0];                                \
+        *reinterpret_cast<u32x4*>(sa_ + a_dst[i] + 1024) = qa[i][1];                         \
+        *reinterpret_cast<u32x4*>(sa_ + a_dst[i] + 2048) = qa[i][2];                         \
+      }                                                                                      \
+  }
+#define XD_TERM(PA, PB)                                                                         \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA], fb[j][PB], acc[i][j], 0, 0, 0);
+
+  for (;;) {
+    XD_TILE(loc)
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // prologue: B(0) by DMA, A(0) through the registers into buffer 0, A(1) requested
+    XD_DMA_B(0, 0)
+    XD_LOAD_A(0)
+    XD_SPLIT(0)
+    XD_STORE_A(0)
+    XD_LOAD_A(1)
+    for (int kb = 0; kb < nst; ++kb) {
+      // B(kb) landed (its DMAs are older than the 2 NAU loads of A(kb+1), which stay in flight);
+      // stage kb's A pieces were stored before this barrier by every wave
+      asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * NAU) : "memory");
+      __syncthreads();
+      const unsigned char* const sa = smem + (kb & 1) * ST;
+      const unsigned char* const sb = sa + A_ST;
+      bf16x8 fa[TM][3], fb[TN][3];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          fa[i][p] = *reinterpret_cast<const bf16x8*>(sa + (((wrb + i) * 3 + p) * 64 + lane) * 16);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          fb[j][p] = *reinterpret_cast<const bf16x8*>(sb + (((wcb + j) * 3 + p) * 64 + lane) * 16);
+      __builtin_amdgcn_sched_barrier(0);
+      XD_SPLIT(kb + 1)                 // (the compiler's wait for A(kb+1): nothing else is in flight)
+      __builtin_amdgcn_sched_barrier(0);
+      XD_DMA_B(kb + 1, (kb + 1) & 1)   // every wave is past this iteration's barrier: the buffer's readers are done
+      XD_LOAD_A(kb + 2)                // (the registers are free again: their values sit in qa)
+      XD_TERM(2, 0) XD_TERM(1, 1)
+      __builtin_amdgcn_sched_barrier(0);
+      XD_STORE_A((kb + 1) & 1)
+      XD_TERM(0, 2)
+      __builtin_amdgcn_sched_barrier(0);
+      XD_TERM(1, 0) XD_TERM(0, 1) XD_TERM(0, 0)
+    }
+    // the trailing (dummy) DMA and loads must have landed before the stage buffers become the
+    // epilogue's scratch / the next tile's stages
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    x3p_epilogue<TM, TN, true>(g, acc, smem, m0, n0, wrb, wcb, wave, lane, true);
+    loc += stride;
+    if (!(loc < per_xcd && xcd * per_xcd + loc < total)) break;
+    __syncthreads();
+  }
+#undef XD_TILE
+#undef XD_LOAD_A
+#undef XD_DMA_B
+#undef XD_SPLIT
+#undef XD_STORE_A
+#undef XD_TERM
+}
+
 // ---- producer / consumer form (one workgroup of 8 waves per CU, persistent; 128 x 128 tiles).
 // Waves 0-3 (CONSUMERS, 2 x 2, 64 x 64 each) only read fragments from LDS, issue MFMAs and, at the
 // end of a tile, drop their sums into a 64 KB LDS tile E: they never touch global memory.  Waves
@@ -1069,6 +1278,16 @@ __global__ __launch_bounds__(256) void x3p_split_kernel(const float* __restrict_
     }                                                                                             \
   } while (0)
 
+// LDS-DMA form: WPC workgroups per CU (the register allocation is bounded accordingly)
+template <int TM, int TN, int WPC>
+void launch_x3p_dma(X3P& g, hipStream_t st) {
+  g.tiles_m = (g.M + 64 * TM - 1) / (64 * TM);
+  g.tiles_n = (g.N + 64 * TN - 1) / (64 * TN);
+  const int total = g.tiles_m * g.tiles_n;
+  const int grid = std::min(((total + 7) / 8) * 8, 256 * WPC);
+  X3P_LAUNCH((x3p_dma_kernel<TM, TN, WPC>), grid, 256, 0);
+}
+
 template <int TM, int TN>
 void launch_x3p(X3P& g, hipStream_t st) {
   g.tiles_m = (g.M + 64 * TM - 1) / (64 * TM);
@@ -1181,11 +1400,13 @@ int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int 
     return -1;
   // tile = 1000 drip + 100 wgs + (10 tm + tn): drip = epilogue slices under the next tile, wgs =
   // persistent workgroups per CU (0 = default)
-  const int drip = tile / 1000;
+  // (2000 + tm tn: the LDS-DMA form at its own occupancy: 3 / 4 / 4 / 5 workgroups per CU)
+  const int dma = tile / 1000 == 2;
+  const int drip = dma ? 0 : tile / 1000;
   const int wgs = (tile / 100) % 10;
   tile %= 100;
   if ((tile != 0 && tile != 11 && tile != 12 && tile != 21 && tile != 22 && tile != 33) || wgs < 0 || wgs > 8 ||
-      drip < 0 || drip > 1)
+      drip < 0 || drip > 1 || (dma && (tile == 0 || tile == 33)))
     return -1;
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   if ((K & 7) || (N & 3) || (lda & 3) || (ldc & 3) || !al16(A) || !al16(Bp) || !al16(C) ||
@@ -1276,6 +1497,17 @@ int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int 
       default: X3Q_LAUNCH(0) break;
     }
 #undef X3Q_LAUNCH
+    S2T_CHECK_LAUNCH();
+    return 0;
+  }
+  if (dma) {
+    if (g_colstats) return -2;
+    switch (tile) {
+      case 22: launch_x3p_dma<2, 2, 3>(g, st); break;
+      case 21: launch_x3p_dma<2, 1, 4>(g, st); break;
+      case 12: launch_x3p_dma<1, 2, 4>(g, st); break;
+      default: launch_x3p_dma<1, 1, 5>(g, st); break;
+    }
     S2T_CHECK_LAUNCH();
     return 0;
   }

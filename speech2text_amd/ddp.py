@@ -28,6 +28,7 @@ collective is bandwidth- rather than latency-bound and few collectives are in fl
 """
 import contextlib
 import os
+import time
 from typing import List, Optional
 
 import torch
@@ -87,6 +88,11 @@ class GradReducer:
         self._drop_flags = []                        # device flags of recent steps (read lazily)
         self.last_drop = None                        # device flag of the last finish(): > 0 = dropped
         self._next = 0                               # next bucket to launch (fixed order)
+        # overlap evidence of the last synchronised step: (bucket, host time, launched by a gradient
+        # signal inside backward?) per collective, and the host time finish() was entered
+        self.launch_log = []
+        self.finish_t = None
+        self._in_finish = False
         self._hooks = []
         if self.active:
             store.on_grad = self._grad_ready
@@ -142,6 +148,7 @@ class GradReducer:
 
     def _launch(self, b):
         assert b == self._next
+        self.launch_log.append((b, time.perf_counter(), not self._in_finish))
         s, e = self.buckets[b]
         buf = self.store.flat_g[s:e]
         self._next = b + 1
@@ -169,6 +176,8 @@ class GradReducer:
         self._fired = {}
         self._late = set()
         self._next = 0
+        self.launch_log = []
+        self.finish_t = None
         if self._expected is not None and self.overlap:
             self._pending = [sum(self._expected.get(q, 0) for q in m)
                              for m in self.bucket_members]
@@ -181,8 +190,13 @@ class GradReducer:
         self.last_drop = None
         if not self.active:
             return extra
-        while self._next < len(self.buckets):
-            self._launch(self._next)
+        self.finish_t = time.perf_counter()
+        self._in_finish = True
+        try:
+            while self._next < len(self.buckets):
+                self._launch(self._next)
+        finally:
+            self._in_finish = False
         # one small all-reduce per step: [logged scalars ..., "some rank fired late" flag]
         fg = self.store.flat_g
         flag = torch.full((1,), 1.0 if self._late else 0.0, dtype=fg.dtype, device=fg.device)
@@ -215,6 +229,15 @@ class GradReducer:
                 if c > self._expected.get(q, 0):
                     self._expected[q] = c
         return extra
+
+    def overlap_report(self):
+        """Of the last synchronised step: how many of the buckets went to the exchange stream from
+        inside backward (a gradient signal completed them) rather than from finish(), and how long
+        before finish() the first one did (host clock, ms)."""
+        early = [t for (_, t, in_bwd) in self.launch_log if in_bwd]
+        lead = None if (not early or self.finish_t is None) else 1e3 * (self.finish_t - early[0])
+        return {"buckets": len(self.buckets), "launched_in_backward": len(early),
+                "first_launch_ms_before_finish": lead}
 
     def poll_dropped(self):
         """Folds the recorded device flags into `dropped_steps` (a host read: call it off the

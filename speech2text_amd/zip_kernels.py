@@ -1432,7 +1432,10 @@ def x3p_matmul(mode, x2, w2, bias=None, resid2=None, act_src=None, act_kind=None
 
 _PLANS = {}          # shape bucket + epilogue -> ("lt", 0) | ("x3p", tile)
 _BASE = {}           # shape bucket -> (library ms, best own ms | None, its tile): timed once, on the plain product
-_X3P_TILES = (222, 321, 312, 411)
+# tile / occupancy candidates timed per shape bucket: 100 w + tile = the register-staged form at w
+# workgroups per CU; 2000 + tile = the LDS-DMA form (weight pieces global -> LDS directly) at 3 / 4 /
+# 4 workgroups per CU (S2T_X3P_DMA=1 adds them: same-box A/B at C3 38.6 ms/step with and without)
+_X3P_TILES = (222, 321, 312, 411) + ((2022, 2021, 2012) if os.environ.get("S2T_X3P_DMA", "0") == "1" else ())
 PLAN_STATS = {"timed": 0}
 
 

@@ -151,3 +151,59 @@ def test_rccl_world1_reducer_is_a_noop(dev, algo):
     np.testing.assert_allclose(b, a, rtol=5e-4, atol=2e-5)
     np.testing.assert_allclose(l1, l0, rtol=1e-4)
     assert i0[4].keys() == i1[4].keys()
+
+
+def _overlap_worker(port, q):
+    """RCCL world 1, reducer forced active, the C3 model at the YAML dims (B = 4 x 10 s): which
+    buckets go to the exchange stream from INSIDE backward once the per-parameter counts are learned?"""
+    import random
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["S2T_DDP_FORCE"] = "1"
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    import bench
+    from speech2text_amd import zip_native
+    from speech2text_amd.build_task import TaskFactory
+    from speech2text_amd.trainer import Trainer
+    cfg = bench.c3_config(500)
+    random.seed(1234)
+    torch.manual_seed(1234)
+    task = TaskFactory.get("Pruned_Rnnt")(cfg)
+    tr = Trainer(**cfg["trainer"]).setup(task, dev)
+    task.train()
+    batch = bench.make_batch(0, 4, 10.0, 50, 500, dev)
+    reports = []
+    for i in range(5):
+        tr.training_step(batch, i)
+        reports.append(tr.reducer.overlap_report())
+    torch.cuda.synchronize()
+    q.put((reports, tr.reducer.poll_dropped(), list(zip_native.CALLS)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_buckets_leave_during_backward_on_the_c3_model(dev):
+    """DP overlap that one GPU can prove: with the layer executors (Python on the first step, native
+    afterwards) telling the reducer which gradients are complete, all buckets but the last leave
+    for the exchange stream from inside backward -- not from finish() -- from the second
+    synchronised step on, and no step is dropped when the executor changes."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_overlap_worker, args=(_free_port(), q))
+    p.start()
+    reports, dropped, native_calls = q.get(timeout=600)
+    p.join(timeout=60)
+    print("overlap reports:", reports)
+    assert dropped == 0
+    assert native_calls[1] >= 12 * 3                       # the native executor served the later steps
+    nb = reports[0]["buckets"]
+    assert nb >= 3
+    assert reports[0]["launched_in_backward"] == 0         # the learning step defers everything
+    for r in reports[2:]:
+        assert r["launched_in_backward"] >= nb - 1, r
+        assert r["first_launch_ms_before_finish"] > 0.0

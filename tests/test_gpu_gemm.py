@@ -355,7 +355,8 @@ def test_x3p_gemm_has_fp32_accuracy(dev, M, K, N):
         # (1000 + 100 w + tile: w persistent workgroups per CU, the output of a tile stored in
         # slices under the next tile's multiplications -- active where a workgroup gets > 1 tile)
         # 33: the producer / consumer form (8-wave workgroups, 128 x 128 tiles)
-        for tile in (0, 22, 21, 12, 11, 33, 1111, 1112, 1121, 1122, 1211):
+        # 2000 + tile: the LDS-DMA form (weight pieces global -> LDS directly; 3 / 4 / 4 / 5 workgroups per CU)
+        for tile in (0, 22, 21, 12, 11, 33, 1111, 1112, 1121, 1122, 1211, 2022, 2021, 2012, 2011):
             y = zk.x3p_matmul(mode, a, W, bias, res, tile=tile)
             kc = N if mode == 1 else K
             if kc % 8 or (tile == 33 and (kc + 15) // 16 < 10):
@@ -380,7 +381,7 @@ def test_x3p_fused_epilogues(dev):
     Mb = 40000
     xb = torch.randn(Mb, K, generator=g).to(dev)
     rb = torch.randn(Mb, N, generator=g).to(dev)
-    for tile in (1112, 1121, 1122, 1111, 33):
+    for tile in (1112, 1121, 1122, 1111, 33, 2022, 2021, 2012, 2011):
         y, y2 = zk.x3p_matmul(0, xb, W, b, None, act2="add", resid_b=rb, tile=tile)
         yref = torch.nn.functional.linear(xb.double(), W.detach().double(), b.detach().double())
         _close(y, yref)

@@ -24,7 +24,7 @@ FWD = [(31680, 272, 192), (31680, 432, 192), (31680, 192, 144), (31680, 48, 192)
        (3968, 256, 960), (3968, 512, 256), (3968, 256, 256)]
 
 
-CFGS = [0, 222, 321, 312, 411, 1222, 1221, 1212, 1211, 1312, 1321, 1311, 1411]
+CFGS = [int(c) for c in os.environ.get("X3P_CFGS", "0,222,321,312,411,2022,2021,2012,2011").split(",")]
 
 
 def main():

@@ -31,9 +31,9 @@ cat gpurun_out/${TAG}_fetch_calibration.txt
 rm -rf gpurun_out/cal_FETCH_SIZE gpurun_out/cal_WRITE_SIZE
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_${TAG}_$C
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_$C -o pmc -- python bench.py --config $CFG --steps 2 --warmup 5 --no-cpu-baseline --profile-steps 0 > gpurun_out/pmc_${TAG}_$C.json 2> gpurun_out/pmc_${TAG}_$C.err
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_$C -o pmc -- python3 bench.py --config $CFG --steps 1 --warmup 5 --sample-every 1 --no-cpu-baseline --profile-steps 0 > gpurun_out/pmc_${TAG}_$C.json 2> gpurun_out/pmc_${TAG}_$C.err
   echo "$C rc=$?"
   find gpurun_out/pmc_${TAG}_$C -name "*kernel_trace.csv" -delete
 done
-python tools/pmc_traffic.py gpurun_out/pmc_${TAG}_FETCH_SIZE gpurun_out/pmc_${TAG}_WRITE_SIZE gpurun_out/roofline_traffic_${TAG}_${CFG}.json | head -40
+python tools/pmc_traffic.py gpurun_out/pmc_${TAG}_FETCH_SIZE gpurun_out/pmc_${TAG}_WRITE_SIZE gpurun_out/roofline_traffic_${TAG}_${CFG}.json gpurun_out/pmc_${TAG}_WRITE_SIZE.json | head -40
 rm -rf gpurun_out/pmc_${TAG}_FETCH_SIZE gpurun_out/pmc_${TAG}_WRITE_SIZE

@@ -115,7 +115,7 @@ def collect(d, counter):
     return tot, cnt
 
 
-def main(fetch_dir, write_dir, out):
+def main(fetch_dir, write_dir, out, bench_json=None):
     ft, fc = collect(fetch_dir, "FETCH_SIZE")
     wt, wc = collect(write_dir, "WRITE_SIZE")
     res = {}
@@ -132,6 +132,16 @@ def main(fetch_dir, write_dir, out):
                           "(gfx950 counts 128-byte requests at 64 bytes: calibrated per access "
                           "width with tools/probes/fetch_probe.hip, profiles/r03_fetch_calibration.txt"
                           "), WRITE_SIZE exact"}
+    if bench_json and os.path.exists(bench_json):
+        # the bench line of the PMC pass itself (--steps 1 --sample-every 1): algorithmic bytes of
+        # exactly the launches counted above
+        try:
+            r = json.loads(open(bench_json).read().strip().splitlines()[-1])["roofline"]
+            if r.get("kernel") in res and r.get("algorithmic_bytes_per_launch"):
+                res[r["kernel"]]["algorithmic_bytes_per_launch"] = r["algorithmic_bytes_per_launch"]
+                res[r["kernel"]]["algorithmic_launches"] = r.get("launches")
+        except Exception as e:                       # noqa: BLE001
+            print("bench line not usable:", e)
     json.dump(res, open(out, "w"), indent=1)
     for e, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
         print(f"{e:28s} n={v['launches_sampled']:5d} fetch(x2) {v['fetch_bytes_x2_per_launch']/1e6:9.2f} MB "
@@ -141,4 +151,5 @@ def main(fetch_dir, write_dir, out):
 if __name__ == "__main__":
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     main(sys.argv[1], sys.argv[2],
-         sys.argv[3] if len(sys.argv) > 3 else os.path.join(root, "profiles", "roofline_traffic.json"))
+         sys.argv[3] if len(sys.argv) > 3 else os.path.join(root, "profiles", "roofline_traffic.json"),
+         sys.argv[4] if len(sys.argv) > 4 else None)
