@@ -1547,8 +1547,10 @@ int s2t_x3p_sample_end(long* launches, double* total_ms, double* bytes, double* 
     g_samp.pool.push_back(pr);
   }
   g_samp.used.clear();
-  if (launches) *launches = n;
-  if (total_ms) *total_ms = ms;
+  // (every sampled launch is counted; a pair the profiler left without timestamps -- PMC passes --
+  //  drops out of the average only: the total is scaled back to the sampled count)
+  if (launches) *launches = g_samp.launches;
+  if (total_ms) *total_ms = n > 0 ? ms * (double)g_samp.launches / (double)n : 0.0;
   if (bytes) *bytes = g_samp.bytes;
   if (flops) *flops = g_samp.flops;
   return 0;
