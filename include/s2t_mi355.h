@@ -697,6 +697,18 @@ int s2t_gemm_x3p_stats(const float* A, long lda, const unsigned short* Bp, int N
                        const float* act_src, long ld_act, int act_kind, float* C2, long ldc2, int act2,
                        const float* resid_b, long ldrb, int tile, float* colstats, void* stream);
 
+/* s2t_gemm_x3p for a data gradient through an activation with the Balancer on the activation's input
+ * in the epilogue (the hidden Balancer of FeedforwardModule / ConvolutionModule / ConvNeXt,
+ * model/encoder/zipformer.py:2372-2378, 2643-2695, model/layer/subsampling.py:106-132; update rule
+ * model/layer/scaling.py:741-789): C = act'(act_src) (A Bm^T) (+ resid), then C += |C| (a[c] + b[c]
+ * act_src) with a, b derived from bal_stats = column sums [0..N) and sums of squares [1024..1024+N) of
+ * act_src over its M rows (s2t_balancer_stats into a zeroed buffer).  Replaces the separate
+ * s2t_balancer_apply pass over the (M, N) gradient.  -2: shape / tile outside the kernel's rules. */
+int s2t_gemm_x3p_bal(const float* A, long lda, const unsigned short* Bp, int N, int K, float* C, long ldc,
+                     int M, const float* resid, long ldr, const float* act_src, long ld_act, int act_kind,
+                     int tile, const float* bal_stats, float min_mean, float max_mean, float min_rms,
+                     float max_rms, float grad_scale, void* stream);
+
 /* ---- side stream for work off the critical path (csrc/streams.hip): the weight-gradient GEMMs
  * of backward overlap the data-gradient chain.  s2t_side_stream returns the library-owned stream;
  * s2t_stream_order(from, to) makes later work on `to` wait for the work enqueued so far on `from`. */
@@ -852,6 +864,7 @@ typedef struct S2tZipLayerCall {
   int whiten_x3p;
   long whiten_x3p_rows;
   int conv_w_side, conv_fused, stats_side, wgrad_side, bmm_own;
+  int bal_epi;                     /* hidden Balancers in the dgrad epilogue (s2t_gemm_x3p_bal) */
 } S2tZipLayerCall;
 long s2t_zip_layer_state_bytes(void);
 long s2t_zip_layer_ws_floats(const S2tZipLayerDesc* desc, const S2tZipLayerCall* call, int backward);

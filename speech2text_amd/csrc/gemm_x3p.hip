@@ -120,6 +120,12 @@ struct X3P {
   int stagger;                // > 0: workgroup slot s of a CU starts its k loop s * stagger * 64 cycles late
   float* colstats;            // [2][1024] or NULL: += column sums / sums of squares of C (the Balancer's
                               // statistics of the tensor this product writes; N <= 1024)
+  // Balancer update in the epilogue (s2t_gemm_x3p_bal): C = act'(S) (A Bm^T) is the gradient w.r.t. S
+  // coming through the activation, and the Balancer on S (scaling.py:741-789 in closed form, as
+  // zip_elem.hip balancer_apply_fused_kernel) adds |C| (a[c] + b[c] S): bal_stats = [2][1024] column
+  // sums / sums of squares of S over bal_n rows, or NULL
+  const float* bal_stats;
+  float bal_n, bal_min_mean, bal_max_mean, bal_min_rms, bal_max_rms, bal_gs;
 };
 
 // diagnostics: lane 0 of wave 0 records the shader clock at a phase boundary of its workgroup
@@ -211,10 +217,48 @@ __device__ __forceinline__ void x3p_epi_load(const X3P& g, const EpiRs& rs, EpiO
   }
 }
 
+// per-channel coefficients of the Balancer update for this lane's column quad (formulas and clamps
+// of zip_elem.hip balancer_apply_fused_kernel)
+struct BalQ {
+  f32x4 a, b;
+};
+__device__ __forceinline__ BalQ x3p_epi_balcoef(const X3P& g, int j, int n0, int wcb, int lane) {
+  BalQ r;
+  r.a = r.b = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int col = n0 + 32 * (wcb + j) + (lane & 7) * 4;
+  if (col >= g.N) return r;
+  const f32x4 sm = *reinterpret_cast<const f32x4*>(g.bal_stats + col);
+  const f32x4 sq = *reinterpret_cast<const f32x4*>(g.bal_stats + 1024 + col);
+  const float inv_n = 1.f / g.bal_n;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float mean = sm[c] * inv_n, uvar = sq[c] * inv_n;
+    const float raw_var = uvar - mean * mean;
+    const bool live_v = raw_var > 1.0e-20f, live_r = uvar > 1.0e-20f;
+    const float var = fmaxf(raw_var, 1.0e-20f);
+    const float sd = sqrtf(var);
+    const float rms = sqrtf(fmaxf(uvar, 1.0e-20f));
+    const float m = mean / sd;
+    const float mc = fminf(fmaxf(m, g.bal_min_mean), g.bal_max_mean);
+    const float s_m = (m > mc) ? 1.f : ((m < mc) ? -1.f : 0.f);
+    const float rc = fminf(fmaxf(rms, g.bal_min_rms), g.bal_max_rms);
+    const float lq = logf(rc / rms);
+    const float s_r = (lq > 0.f) ? -1.f : ((lq < 0.f) ? 1.f : 0.f);
+    const float a = s_m * inv_n * (live_v ? (1.f / sd + mean * mean / (sd * var)) : 1.f / sd);
+    const float b = (live_v ? -s_m * inv_n * mean / (sd * var) : 0.f) + (live_r ? s_r * inv_n / (rms * rms) : 0.f);
+    const float lg_rms = fmaxf(sqrtf(fmaxf(a * a + 2.f * a * b * mean + b * b * uvar, 0.f)), 1.0e-20f);
+    const float coef = g.bal_gs / lg_rms;
+    r.a[c] = a * coef;
+    r.b[c] = b * coef;
+  }
+  return r;
+}
+
 // phase 1 of one slice: a[8 h .. 8 h + 7] (MFMA layout) -> the final values of this lane's two row
 // pieces (q = 0, 1: a[8 h + 4 q .. + 3])
+template <bool BAL = false>
 __device__ __forceinline__ void x3p_epi_xform(const X3P& g, f32x16& a, float* scr, const EpiOps& o,
-                                              const f32x4 bq, int h, int lane) {
+                                              const f32x4 bq, int h, int lane, const BalQ& bal = BalQ{}) {
   const int hi = lane >> 5, lo = lane & 31;
   const int er = lane >> 3, ec = (lane & 7) * 4;
 #pragma unroll
@@ -233,6 +277,12 @@ __device__ __forceinline__ void x3p_epi_xform(const X3P& g, f32x16& a, float* sc
         v.y *= swoosh_deriv(x.y, g.act_kind);
         v.z *= swoosh_deriv(x.z, g.act_kind);
         v.w *= swoosh_deriv(x.w, g.act_kind);
+        if (BAL) {                                   // the Balancer on the activation's input
+          v.x += fabsf(v.x) * fmaf(bal.b.x, x.x, bal.a.x);
+          v.y += fabsf(v.y) * fmaf(bal.b.y, x.y, bal.a.y);
+          v.z += fabsf(v.z) * fmaf(bal.b.z, x.z, bal.a.z);
+          v.w += fabsf(v.w) * fmaf(bal.b.w, x.w, bal.a.w);
+        }
       } else if (g.role[k] == 2 || (g.role[k] == 3 && g.act2 != 3)) {
         v += x;
       }
@@ -271,7 +321,9 @@ __device__ __forceinline__ void x3p_epi_store(const X3P& g, const EpiRs& rs, con
 // LEAN: one slice at a time (operands of ONE slice live: 16 registers instead of 32 TN) -- for the
 // kernels that run three or more workgroups per CU on a tight register budget, where the other
 // workgroups cover a slice's load -> store round trip
-template <int TM, int TN, bool LEAN = false>
+// BAL: the Balancer update of s2t_gemm_x3p_bal is compiled in (its own instantiations: the others pay
+// no registers for it)
+template <int TM, int TN, bool LEAN = false, bool BAL = false>
 __device__ __forceinline__ void x3p_epilogue(const X3P& g, f32x16 (&acc)[TM][TN], unsigned char* smem,
                                              int m0, int n0, int wrb, int wcb, int wave, int lane,
                                              bool sync = true) {
@@ -282,13 +334,14 @@ __device__ __forceinline__ void x3p_epilogue(const X3P& g, f32x16 (&acc)[TM][TN]
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const f32x4 bqj = x3p_epi_bias(g, j, n0, wcb, lane);
+      const BalQ balj = BAL ? x3p_epi_balcoef(g, j, n0, wcb, lane) : BalQ{};
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           EpiOps o;
           x3p_epi_load(g, rs, o, i, j, h, m0, n0, wrb, wcb, lane);
-          x3p_epi_xform(g, acc[i][j], scr, o, bqj, h, lane);
+          x3p_epi_xform<BAL>(g, acc[i][j], scr, o, bqj, h, lane, balj);
           x3p_epi_store(g, rs, acc[i][j], o, i, j, h, m0, n0, wrb, wcb, lane);
         }
     }
@@ -477,7 +530,7 @@ __global__ __launch_bounds__(256, 2) void x3p_kernel(X3P g) {
 // and is worth it with >= 2 tiles per workgroup (persistent grid).
 // (waves per SIMD the register allocation must leave room for: 2 / 3 / 4 workgroups per CU for the
 // 2x2 / 1x2, 2x1 / 1x1 tiles -- the epilogue's operand loads are hoisted as far as this allows)
-template <int TM, int TN, bool DIAG = false, int ABL = 0, bool DRIP = false>
+template <int TM, int TN, bool DIAG = false, int ABL = 0, bool DRIP = false, bool BAL = false>
 __global__ __launch_bounds__(256, (DRIP || DIAG || TM * TN == 4) ? 2 : (TM * TN == 2 ? 3 : 4))
 void x3p_db_kernel(X3P g) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -729,7 +782,7 @@ void x3p_db_kernel(X3P g) {
       pm0 = em0;
       pn0 = en0;
       pend = true;
-    } else if (!(ABL & 16)) x3p_epilogue<TM, TN>(g, acc, epi_smem, em0, en0, wrb, wcb, wave, lane, !DRIP);
+    } else if (!(ABL & 16)) x3p_epilogue<TM, TN, BAL, BAL>(g, acc, epi_smem, em0, en0, wrb, wcb, wave, lane, !DRIP);
     else {                                   // keep every product alive
       float chk = 0.f;
 #pragma unroll
@@ -1307,7 +1360,9 @@ void launch_x3p(X3P& g, hipStream_t st) {
     static int diag = -1;      // S2T_X3P_DIAG=1: the instrumented build (tools/x3p_stamps.py)
     if (diag < 0) { const char* e = getenv("S2T_X3P_DIAG"); diag = e ? atoi(e) : 0; }
     const bool drip = g.drip == 1 && ((g.K + 15) >> 4) >= 2 * TM * TN && grid < total;
-    if (diag && g.stamps)
+    if (g.bal_stats)
+      X3P_LAUNCH((x3p_db_kernel<TM, TN, false, 0, false, true>), grid, 256, 0);
+    else if (diag && g.stamps)
       hipLaunchKernelGGL((x3p_db_kernel<TM, TN, true>), dim3(grid), dim3(256), 0, st, g);
     else if (drip)
       X3P_LAUNCH((x3p_db_kernel<TM, TN, false, 0, true>), grid, 256, 0);
@@ -1375,6 +1430,11 @@ int s2t_x3p_split(const float* base, const void* tab, int n, int total_blocks, u
 }
 
 static float* g_colstats = nullptr;      // armed by s2t_gemm_x3p_stats for the one launch it makes
+struct BalArm {
+  const float* stats = nullptr;
+  float n = 0.f, min_mean = 0.f, max_mean = 0.f, min_rms = 0.f, max_rms = 0.f, gs = 0.f;
+};
+static thread_local BalArm g_bal;        // armed by s2t_gemm_x3p_bal for the one launch it makes
 
 // ---- sampled kernel-attached timing of this entry point, kept HERE so that launches issued by the
 // native layer executor (csrc/zip_layer.hip) and by the Python call sites are sampled alike: while a
@@ -1401,7 +1461,7 @@ int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int 
   // tile = 1000 drip + 100 wgs + (10 tm + tn): drip = epilogue slices under the next tile, wgs =
   // persistent workgroups per CU (0 = default)
   // (2000 + tm tn: the LDS-DMA form at its own occupancy: 3 / 4 / 4 / 5 workgroups per CU)
-  const int dma = tile / 1000 == 2;
+  int dma = tile / 1000 == 2;
   const int drip = dma ? 0 : tile / 1000;
   const int wgs = (tile / 100) % 10;
   tile %= 100;
@@ -1421,7 +1481,18 @@ int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int 
     return -2;
   if (act_src && resid && resid_b) return -2;        // two operand slots
   X3P g{A, lda, Bp, (N + 31) / 32, 2 * ((K + 31) / 32), C, ldc, M, N, K, bias, {nullptr, nullptr},
-        {0, 0}, {0, 0}, act_kind, C2, ldc2, act2, 0, 0, wgs, 0, g_stamps, drip, 0, nullptr};
+        {0, 0}, {0, 0}, act_kind, C2, ldc2, act2, 0, 0, wgs, 0, g_stamps, drip, 0, nullptr,
+        nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (g_bal.stats) {
+    if (!act_src || N > 1024 || tile == 33 || drip) return -2;
+    g.bal_stats = g_bal.stats;
+    g.bal_n = g_bal.n;
+    g.bal_min_mean = g_bal.min_mean;
+    g.bal_max_mean = g_bal.max_mean;
+    g.bal_min_rms = g_bal.min_rms;
+    g.bal_max_rms = g_bal.max_rms;
+    g.bal_gs = g_bal.gs;
+  }
   if (g_colstats) {
     if (N > 1024 || drip || tile == 33) return -2;
     g.colstats = g_colstats;
@@ -1500,6 +1571,7 @@ int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int 
     S2T_CHECK_LAUNCH();
     return 0;
   }
+  if (dma && g.bal_stats) dma = 0;       // (the Balancer epilogue lives in the register-staged form)
   if (dma) {
     if (g_colstats) return -2;
     switch (tile) {
@@ -1554,6 +1626,30 @@ int s2t_x3p_sample_end(long* launches, double* total_ms, double* bytes, double* 
   if (bytes) *bytes = g_samp.bytes;
   if (flops) *flops = g_samp.flops;
   return 0;
+}
+
+// s2t_gemm_x3p for the data gradient through an activation WITH the Balancer that sits on the
+// activation's input folded into the epilogue: C = act'(S) (A Bm^T), then C += |C| (a[c] + b[c] S)
+// with the per-channel a, b of model/layer/scaling.py:741-789 (closed form, zip_elem.hip) derived in
+// the epilogue from bal_stats = [2][1024] column sums / sums of squares of S over its M rows
+// (s2t_balancer_stats).  Replaces s2t_balancer_apply's pass over the (M, N) gradient.  act_src (= S)
+// is required; N <= 1024.
+int s2t_gemm_x3p_bal(const float* A, long lda, const unsigned short* Bp, int N, int K, float* C, long ldc,
+                     int M, const float* resid, long ldr, const float* act_src, long ld_act, int act_kind,
+                     int tile, const float* bal_stats, float min_mean, float max_mean, float min_rms,
+                     float max_rms, float grad_scale, void* stream) {
+  if (!bal_stats || !act_src) return -1;
+  g_bal.stats = bal_stats;
+  g_bal.n = (float)M;
+  g_bal.min_mean = min_mean;
+  g_bal.max_mean = max_mean;
+  g_bal.min_rms = min_rms;
+  g_bal.max_rms = max_rms;
+  g_bal.gs = grad_scale;
+  const int rc = s2t_gemm_x3p(A, lda, Bp, N, K, C, ldc, M, nullptr, resid, ldr, act_src, ld_act, act_kind, nullptr,
+                              0, 0, nullptr, 0, tile, stream);
+  g_bal.stats = nullptr;
+  return rc;
 }
 
 // s2t_gemm_x3p that also ADDS the column sums and sums of squares of C (as stored: after bias,

@@ -181,6 +181,7 @@ struct Epi {
   int act2 = 0;
   float* out2 = nullptr;
   const float* resid_b = nullptr;
+  const S2tZlBal* bal = nullptr;     // Balancer on act_src, folded into the epilogue (s2t_gemm_x3p_bal)
 };
 constexpr float kSwOff[3] = {0.f, 4.0f, 1.0f};
 constexpr float kSwC[3] = {0.f, 0.035f, 0.313261687f};
@@ -191,6 +192,9 @@ int plan_missing(const Ctx& c, int mode, long R, const S2tZlLin& L) {
   if (!pp) return 0;
   return g_plans.find(plan_key(mode, half_octave(R), L.N, L.K)) == g_plans.end();
 }
+
+int balancer_bwd(Ctx& c, const S2tZlBal& b, const float* x, long ldx, const float* g, long ldg, long R,
+                 int C, float* out, long ldo, float act_off);
 
 int lt_matmul(Ctx& c, int mode, const float* x, long ldx, long R, const S2tZlLin& L, const Epi& e,
               float* out) {
@@ -210,21 +214,39 @@ int lt_matmul(Ctx& c, int mode, const float* x, long ldx, long R, const S2tZlLin
       const double rc = (double)R * cols;
       const double pass_ms = 4.0e-3 + 12.0 * rc / 3.0e9;
       const int n_pass = (e.act_src != nullptr) + (e.act_src && e.resid2) + (e.resid_b != nullptr) +
-                         (e.act2 == 1 || e.act2 == 2);
-      const int n_ops = (e.act_src != nullptr) + (e.resid_b != nullptr) + (e.act2 != 0);
+                         (e.act2 == 1 || e.act2 == 2) + (e.bal != nullptr);
+      const int n_ops = (e.act_src != nullptr) + (e.resid_b != nullptr) + (e.act2 != 0) + (e.bal != nullptr);
       const double cost_lt = b.t_lib * (fused ? 1.0 : (double)c.c.x3p_margin) + n_pass * pass_ms;
       const double cost_own = b.t_own + n_ops * 4.0 * rc / 3.0e9;
       own = cost_own < cost_lt;
       tile = b.tile;
     }
   }
-  if (own && !c.dry) {
+  if (e.bal && !c.c.bal_epi) own = false;          // (A/B switch: plain product + the two-pass update)
+  float* bstats = (e.bal && own) ? c.ar.alloc(2048) : nullptr;
+  if (own && !c.dry && e.bal) {
+    if (cols <= 1024) {
+      HIPRUN(hipMemsetAsync(bstats, 0, 2048 * sizeof(float), c.st));
+      RUN(s2t_balancer_stats(e.act_src, cols, R, cols, bstats, (void*)c.st));
+      const int rc = s2t_gemm_x3p_bal(x, ldx, pp, cols, inner, out, cols, (int)R, e.resid2, cols, e.act_src, cols,
+                                      e.act_kind, tile, bstats, e.bal->min_mean, e.bal->max_mean, e.bal->min_rms,
+                                      e.bal->max_rms, e.bal->grad_scale, (void*)c.st);
+      if (rc == 0) return 0;
+      if (rc != -2) return fail(rc, "s2t_gemm_x3p_bal");
+    }
+  } else if (own && !c.dry) {
     const int rc = s2t_gemm_x3p(x, ldx, pp, cols, inner, out, cols, (int)R, e.bias, e.resid2, cols, e.act_src,
                                 cols, e.act_kind, e.out2, cols, e.act2, e.resid_b, cols, tile, (void*)c.st);
     if (rc == 0) return 0;
     if (rc != -2) return fail(rc, "s2t_gemm_x3p");
   }
   // library path: bias + one residual in the GEMM, the rest as separate passes
+  if (e.bal) {                        // plain product, then the Balancer's two-pass update through act'
+    float* t = c.ar.alloc(n);
+    Epi plain;
+    TRY(lt_matmul(c, mode, x, ldx, R, L, plain, t));
+    return balancer_bwd(c, *e.bal, e.act_src, cols, t, cols, R, cols, out, cols, kSwOff[e.act_kind]);
+  }
   float* y = out;
   float* tmp = nullptr;
   if (e.act_src) y = tmp = c.ar.alloc(n);
@@ -573,11 +595,12 @@ int ff_bwd(Ctx& c, int i, int d0, const float* x_in, const float* g, const float
   if (fw) TRY(whiten_bwd(c, site, m.out_wh, sv.st, sv.y, D, R, D, gy, &gy));
   TRY(wgrad(c, m.out, gy, D, sv.a, F, R));
   float* dh = c.ar.alloc(R * F);
-  if (fb) {                                  // Swoosh backward rides in the Balancer's update pass
-    float* t = c.ar.alloc(R * F);
+  if (fb) {                                  // Swoosh backward AND the Balancer's update in the dgrad epilogue
     Epi e;
-    TRY(lt_matmul(c, 1, gy, D, R, m.out, e, t));
-    TRY(balancer_bwd(c, m.hidden, sv.h, F, t, F, R, F, dh, F, kSwOff[1]));
+    e.act_src = sv.h;
+    e.act_kind = 1;
+    e.bal = &m.hidden;
+    TRY(lt_matmul(c, 1, gy, D, R, m.out, e, dh));
   } else {                                   // ... or in the data-gradient GEMM's epilogue
     Epi e;
     e.act_src = sv.h;
@@ -628,12 +651,13 @@ int conv_bwd(Ctx& c, int i, int d0, const float* x_in, const float* g, const flo
   const int D = c.d.D, T = c.c.T, B = c.c.B;
   TRY(wgrad(c, m.out, g, D, sv.a, D, R));
   const float* dy;
-  if (fb2 && !fw) {                          // Swoosh backward rides in the Balancer's update pass
-    float* t = c.ar.alloc(R * D);
-    Epi e;
-    TRY(lt_matmul(c, 1, g, D, R, m.out, e, t));
+  if (fb2 && !fw) {                          // Swoosh backward AND the Balancer's update in the dgrad epilogue
     float* o = c.ar.alloc(R * D);
-    TRY(balancer_bwd(c, m.bal2, sv.y, D, t, D, R, D, o, D, kSwOff[2]));
+    Epi e;
+    e.act_src = sv.y;
+    e.act_kind = 2;
+    e.bal = &m.bal2;
+    TRY(lt_matmul(c, 1, g, D, R, m.out, e, o));
     dy = o;
   } else {                                   // ... or in the data-gradient GEMM's epilogue
     float* t = c.ar.alloc(R * D);

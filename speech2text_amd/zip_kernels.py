@@ -1382,7 +1382,7 @@ def _vp(t):
 
 
 def x3p_matmul(mode, x2, w2, bias=None, resid2=None, act_src=None, act_kind=None, act2=None, tile=0,
-               resid_b=None, pp=None, colstats=None):
+               resid_b=None, pp=None, colstats=None, bal=None):
     """The same products as lt_matmul on our bf16x3 kernel with pre-split weight pieces
     (csrc/gemm_x3p.hip, planes.py): mode 0: x2 (R,K) w2 (N,K)^T (+bias) -> (R,N); mode 1: x2 (R,N)
     w2 (N,K) -> (R,K); then (* act'(act_src)) (+ resid2); with act2 a second output act2(result).
@@ -1406,7 +1406,19 @@ def x3p_matmul(mode, x2, w2, bias=None, resid2=None, act_src=None, act_kind=None
         extra = sum(t is not None for t in (resid2, act_src, out2, resid_b))
         N.profile_note("s2t_gemm_x3p", 4.0 * R * (Nf + Kf + extra * cols) + 6.0 * Nf * Kf,
                        2.0 * R * Nf * Kf)             # (_native.SELF_NOTING: not behind N.PROF)
-    if colstats is not None:
+    if bal is not None:
+        # Balancer on act_src in the epilogue: its column statistics first (one read of act_src)
+        if act_src is None or bias is not None or out2 is not None or resid_b is not None or cols > 1024:
+            return None
+        stats = torch.zeros(2048, dtype=torch.float32, device=x2.device)
+        N.PROF[0] and N.profile_note("s2t_balancer_stats", 4.0 * act_src.numel())
+        N.check(N.lib().s2t_balancer_stats(_vp(act_src), act_src.stride(0), R, cols, _vp(stats), N.stream()),
+                "s2t_balancer_stats")
+        rc = N.lib().s2t_gemm_x3p_bal(_vp(x2), x2.stride(0), ctypes.c_void_p(pp), cols, inner, _vp(out), cols, R,
+                                      _vp(resid2), 0 if resid2 is None else resid2.stride(0), _vp(act_src),
+                                      act_src.stride(0), _ACTK[act_kind], tile or X3P["tile"], _vp(stats),
+                                      bal[0], bal[1], bal[2], bal[3], bal[4], N.stream())
+    elif colstats is not None:
         rc = N.lib().s2t_gemm_x3p_stats(_vp(x2), x2.stride(0), ctypes.c_void_p(pp), cols, inner, _vp(out),
                                         cols, R, _vp(bias), _vp(resid2),
                                         0 if resid2 is None else resid2.stride(0), _vp(act_src),
@@ -1456,8 +1468,11 @@ def _time_call(fn, reps=3):
     return e0.elapsed_time(e1) / reps
 
 
+_BAL_EPI = os.environ.get("S2T_BAL_EPI", "1") == "1"
+
+
 def lt_matmul(mode, x2, w2, bias=None, resid2=None, act_src=None, act_kind=None, act2=None,
-              resid_b=None, colstats=None):
+              resid_b=None, colstats=None, bal=None):
     """Forward / data-gradient product of a Linear with its elementwise neighbours:
       mode 0: x2 (R,K) w2 (N,K)^T (+bias) -> (R,N);  mode 1: x2 (R,N) w2 (N,K) -> (R,K);
       then (* act'(act_src), act_kind "swoosh_l" | "swoosh_r") (+ resid2) (+ resid_b); with act2
@@ -1468,8 +1483,18 @@ def lt_matmul(mode, x2, w2, bias=None, resid2=None, act_src=None, act_kind=None,
     shape bucket {mode, half-octave of R, N, K} was first seen (the plain product timed once, on the
     call's own operands, on an otherwise idle chip; epilogue variants are decided from those times).  Weights outside a FlatStore always take the latter."""
     fused = act_src is not None or act2 is not None or resid_b is not None
+    # bal = Balancer.cfg(2) of a Balancer that sits on act_src (the activation's input) and fires this
+    # call: result = balancer(act'(act_src) * product) -- folded into our kernel's epilogue
+    # (s2t_gemm_x3p_bal), or the two-pass s2t_balancer_bwd after the library product
+    assert bal is None or (act_src is not None and bias is None and resid2 is None and act2 is None
+                           and resid_b is None)
+    if bal is not None and not _BAL_EPI:           # (A/B switch: the separate two-pass update)
+        return balancer_backward(act_src, lt_matmul(mode, x2, w2), *bal, swoosh_l=(act_kind == "swoosh_l"))
 
     def lib():
+        if bal is not None:
+            y = _lt_matmul_lib(mode, x2, w2)
+            return balancer_backward(act_src, y, *bal, swoosh_l=(act_kind == "swoosh_l"))
         y = _lt_matmul_lib(mode, x2, w2, bias, None if act_src is not None else resid2)
         if act_src is not None:
             y = swoosh_backward(act_src, y, act_kind == "swoosh_l")
@@ -1487,7 +1512,8 @@ def lt_matmul(mode, x2, w2, bias=None, resid2=None, act_src=None, act_kind=None,
     if pp is None:
         return lib()
     base = (mode, _half_octave(x2.shape[0]), w2.shape[0], w2.shape[1])
-    key = base + (bias is not None, resid2 is not None, act_src is not None, act2, resid_b is not None)
+    key = base + (bias is not None, resid2 is not None, act_src is not None, act2, resid_b is not None,
+                  bal is not None)
     plan = _PLANS.get(key)
     if plan is None:
         # TIMING happens once per SHAPE bucket, on the plain product (the first call's bias /
@@ -1523,8 +1549,8 @@ def lt_matmul(mode, x2, w2, bias=None, resid2=None, act_src=None, act_kind=None,
             rc = float(x2.shape[0]) * (w2.shape[0] if mode == 0 else w2.shape[1])
             pass_ms = 4.0e-3 + 12.0 * rc / 3.0e9                 # one elementwise pass: 2 reads + 1 write at 3 TB/s
             n_pass = ((act_src is not None) + (act_src is not None and resid2 is not None)
-                      + (resid_b is not None) + (act2 in ("swoosh_l", "swoosh_r")))
-            n_ops = (act_src is not None) + (resid_b is not None) + (act2 is not None)
+                      + (resid_b is not None) + (act2 in ("swoosh_l", "swoosh_r")) + (bal is not None))
+            n_ops = (act_src is not None) + (resid_b is not None) + (act2 is not None) + (bal is not None)
             cost_lt = t_lib * (1.0 if fused else X3P["margin"]) + n_pass * pass_ms
             cost_own = t_own + n_ops * 4.0 * rc / 3.0e9          # each extra operand / output: one more stream
             plan = ("x3p", tile) if cost_own < cost_lt else ("lt", 0)
@@ -1535,7 +1561,7 @@ def lt_matmul(mode, x2, w2, bias=None, resid2=None, act_src=None, act_kind=None,
         _PLANS[key] = plan
     if plan[0] == "x3p":
         y = x3p_matmul(mode, x2, w2, bias, resid2, act_src, act_kind, act2, plan[1], resid_b, pp,
-                       colstats=colstats)
+                       colstats=colstats, bal=bal)
         if y is not None:
             return y
     return lib()
@@ -1677,8 +1703,8 @@ class _FfnBlock(torch.autograd.Function):
         if not wgrad_into(w2p, b2p, g2, a):
             dw, db = linear_wgrad(g2, a, b2p is not None)
             grads2 = (dw.view(w2.shape), db)
-        if ctx.bal_cfg is not None:              # Swoosh' rides in the Balancer's update pass
-            dh = balancer_backward(h, lt_matmul(1, g2, w2m), *ctx.bal_cfg, swoosh_l=True)
+        if ctx.bal_cfg is not None:              # Swoosh' AND the Balancer's update in that epilogue
+            dh = lt_matmul(1, g2, w2m, act_src=h, act_kind="swoosh_l", bal=ctx.bal_cfg)
         else:                                    # ... or in the data-gradient GEMM's epilogue
             dh = lt_matmul(1, g2, w2m, act_src=h, act_kind="swoosh_l")
         grads1 = (None, None)

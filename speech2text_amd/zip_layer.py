@@ -292,7 +292,9 @@ def _ff_bwd(m, post, dec, sv, x_in, g):
         gy = _whiten_bwd(m.out_whiten, sv.y, gy, sv.st)
     W = m.out_proj.weight
     _wgrad(W, m.out_proj.bias, gy, sv.a)
-    if fb:                                   # Swoosh backward rides in the Balancer's update pass
+    if fb and sv.bh is None:                 # Swoosh backward AND the Balancer's update in the dgrad epilogue
+        dh = zk.lt_matmul(1, gy, W, act_src=sv.h, act_kind="swoosh_l", bal=m.hidden_balancer.cfg(2))
+    elif fb:                                 # (statistics variants: the Balancer's own update pass)
         dh = _balancer_bwd(m.hidden_balancer, sv.h, zk.lt_matmul(1, gy, W), swoosh_l=True, stats=sv.bh)
     else:                                    # ... or in the data-gradient GEMM's epilogue
         dh = zk.lt_matmul(1, gy, W, act_src=sv.h, act_kind="swoosh_l")
@@ -354,7 +356,9 @@ def _conv_bwd(m, dec, sv, x_in, g, T, B, k8):
     D = x_in.shape[1]
     W = m.out_proj.weight
     _wgrad(W, m.out_proj.bias, g, sv.a)
-    if fb2 and not fw:                       # Swoosh backward rides in the Balancer's update pass
+    if fb2 and not fw and sv.b2 is None:     # Swoosh backward AND the Balancer's update in the dgrad epilogue
+        dy = zk.lt_matmul(1, g, W, act_src=sv.y, act_kind="swoosh_r", bal=m.balancer2.cfg(2))
+    elif fb2 and not fw:                     # (statistics variants: the Balancer's own update pass)
         dy = _balancer_bwd(m.balancer2, sv.y, zk.lt_matmul(1, g, W), swoosh_l=False, stats=sv.b2)
     else:                                    # ... or in the data-gradient GEMM's epilogue
         dy = zk.lt_matmul(1, g, W, act_src=sv.y, act_kind="swoosh_r")

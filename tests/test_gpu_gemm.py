@@ -548,3 +548,45 @@ def test_batched_products_have_fp32_accuracy(dev, mode, n, M, N, K):
     y = zk.batched_matmul(mode, a, b)
     assert ((y.double() - ref).abs().max().item()) <= 4e-6 * scale
 
+
+
+@pytest.mark.parametrize("kind", ["swoosh_l", "swoosh_r"])
+def test_x3p_balancer_epilogue_matches_two_pass_update(dev, kind):
+    """s2t_gemm_x3p_bal: the hidden Balancer's update (model/layer/scaling.py:741-789) folded into the
+    data-gradient GEMM's epilogue, behind the activation's derivative, against s2t_balancer_apply on
+    the plain product WITH THE SAME column statistics (var = E[x^2] - mean^2 cancels: two runs of the
+    atomically summed statistics already move the coefficients by 1e-3 where |mean| >> std) -- every
+    block tile, channels on both sides of every clamp."""
+    import ctypes
+    from speech2text_amd import flat, planes
+    M, K, N = 3001, 256, 768
+    g = torch.Generator().manual_seed(4)
+    gy = torch.randn(M, K, generator=g).to(dev)                    # gradient w.r.t. the module's output
+    h = (torch.randn(M, N, generator=g) * torch.logspace(-1.0, 1.0, N) + torch.linspace(-2, 2, N)).to(dev)
+    Wt = torch.nn.Parameter(torch.randn(K, N, generator=g).to(dev) * 0.1)   # (K, N): gy (M,K) @ Wt -> (M,N)
+    store = flat.FlatStore([Wt])
+    cfg = (-0.05, 0.6, 0.3, 4.0, 0.04)                             # min_mean, max_mean, min_rms, max_rms, grad_scale
+    off = 4.0 if kind == "swoosh_l" else 1.0
+    from speech2text_amd import _native as Nt
+    L = Nt.lib()
+    plain = zk.x3p_matmul(1, gy, Wt)
+    assert plain is not None
+    stats = torch.zeros(2048, device=dev)
+    Nt.check(L.s2t_balancer_stats(h.data_ptr(), N, M, N, stats.data_ptr(), Nt.stream()), "stats")
+    ref = torch.empty_like(plain)
+    Nt.check(L.s2t_balancer_apply(h.data_ptr(), N, plain.data_ptr(), N, M, N, *cfg, ref.data_ptr(), N,
+                                  stats.data_ptr(), off, Nt.stream()), "apply")
+    assert (ref - plain).abs().max() > 1e-3 * plain.abs().max()     # the update is really there
+    pp = planes.pieces(Wt, 1)
+    for tile in (0, 22, 21, 12, 11):
+        y = torch.empty_like(plain)
+        rc = L.s2t_gemm_x3p_bal(gy.data_ptr(), K, ctypes.c_void_p(pp), N, K, y.data_ptr(), N, M, None, 0,
+                                h.data_ptr(), N, 1 if kind == "swoosh_l" else 2, tile, stats.data_ptr(), *cfg,
+                                Nt.stream())
+        assert rc == 0, (tile, rc)
+        err = (y - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 5e-6, (tile, err)
+    # and through lt_matmul (plan cache: our kernel with its own statistics pass, or the library +
+    # the two-pass update): agreement to the statistics' own reproducibility
+    y = zk.lt_matmul(1, gy, Wt, act_src=h, act_kind=kind, bal=cfg + (1,))
+    assert (y - ref).abs().max().item() / ref.abs().max().item() < 2e-4

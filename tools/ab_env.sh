@@ -1,10 +1,9 @@
 #!/bin/bash
-# same-box A/B of environment settings: bash tools/ab_env.sh REPS "A=1" "A=0 B=2" ...  (bench args via BENCH_ARGS)
-REPS=${1:-2}; shift
-for i in $(seq $REPS); do
-  for s in "$@"; do
-    ms=$(env $s python bench.py --steps 20 --warmup 4 --no-cpu-baseline --profile-steps 0 $BENCH_ARGS 2>/dev/null \
-         | python -c "import json,sys;print(round(json.loads(sys.stdin.read())['ms_per_step'],2))")
-    echo "$s  $ms ms/step"
+# same-box A/B of one environment switch on the default bench: bash tools/ab_env.sh VAR A B [ROUNDS] [bench args]
+VAR=$1; A=$2; B=$3; R=${4:-3}; shift 4
+for i in $(seq 1 $R); do
+  for V in $A $B; do
+    MS=$(env $VAR=$V python bench.py --steps 20 --warmup 5 --no-cpu-baseline --profile-steps 0 "$@" 2>/dev/null | python -c "import sys,json; print('%.2f' % json.loads(sys.stdin.read().strip().splitlines()[-1])['ms_per_step'])")
+    echo "$VAR=$V  $MS ms/step"
   done
 done
