@@ -782,7 +782,7 @@ void x3p_db_kernel(X3P g) {
       pm0 = em0;
       pn0 = en0;
       pend = true;
-    } else if (!(ABL & 16)) x3p_epilogue<TM, TN, BAL, BAL>(g, acc, epi_smem, em0, en0, wrb, wcb, wave, lane, !DRIP);
+    } else if (!(ABL & 16)) x3p_epilogue<TM, TN, BAL || (TM == 1 && TN == 2), BAL>(g, acc, epi_smem, em0, en0, wrb, wcb, wave, lane, !DRIP);
     else {                                   // keep every product alive
       float chk = 0.f;
 #pragma unroll
