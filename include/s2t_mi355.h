@@ -709,6 +709,23 @@ int s2t_gemm_x3p_bal(const float* A, long lda, const unsigned short* Bp, int N, 
                      int tile, const float* bal_stats, float min_mean, float max_mean, float min_rms,
                      float max_rms, float grad_scale, void* stream);
 
+/* s2t_gemm_x3p with IMPLICIT operands: C = A' Bm^T (+ bias[N]) where row r of A' is `nseg` (<= 4) segments
+ * of `seg` (multiple of 16) contiguous floats of the buffer A, segment s at amap(r) + segoff[s], and row
+ * r of C lies at cmap(r) (cmap NULL: plain rows of ldc floats); K = seg * nseg; Bp = pieces of Bm (N, K).
+ * map(r) = base + b sb + i sh + j sw for r = (b, i, j), b = r / hw, i = (r % hw) / w, j = r % w (all
+ * offsets in floats, multiples of 4).  c_elems: elements of the mapped C buffer.  Serves the 3x3 /
+ * stride-2 convolution of the conformer's Subsampling (model/encoder/conformer.py:47-57, 114-126)
+ * without a patch matrix: forward (3 segments of 3 C floats per output position of the channel-last
+ * map) and the data gradient (one launch per input-pixel parity class gathering 1 / 2 / 2 / 4 taps of
+ * the zero-bordered output gradient and writing every second pixel).  tile: 22 (default) 21 12 11. */
+typedef struct S2tRowMap {
+  int hw, w;
+  long sb, sh, sw, base;
+} S2tRowMap;
+int s2t_gemm_x3p_map(const float* A, const S2tRowMap* amap, int seg, int nseg, const long* segoff,
+                     const unsigned short* Bp, int N, float* C, long ldc, const S2tRowMap* cmap,
+                     long c_elems, int M, const float* bias, int tile, void* stream);
+
 /* ---- side stream for work off the critical path (csrc/streams.hip): the weight-gradient GEMMs
  * of backward overlap the data-gradient chain.  s2t_side_stream returns the library-owned stream;
  * s2t_stream_order(from, to) makes later work on `to` wait for the work enqueued so far on `from`. */

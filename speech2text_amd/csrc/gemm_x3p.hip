@@ -93,6 +93,15 @@ __device__ __forceinline__ float swoosh_deriv(float x, int kind) {
   return __fdividef(1.f, 1.f + __expf(off - x)) - 0.08f;
 }
 
+struct X3PMap {
+  int on, hw, w;
+  long sb, sh, sw, base;
+};
+__device__ __forceinline__ long x3p_maprow(const X3PMap& m, int r) {
+  const int b = r / m.hw, q = r - b * m.hw, i = q / m.w, j = q - i * m.w;
+  return m.base + b * m.sb + i * m.sh + j * m.sw;
+}
+
 struct X3P {
   const float* A;
   long lda;
@@ -126,6 +135,14 @@ struct X3P {
   // sums / sums of squares of S over bal_n rows, or NULL
   const float* bal_stats;
   float bal_n, bal_min_mean, bal_max_mean, bal_min_rms, bal_max_rms, bal_gs;
+  // implicit operands (s2t_gemm_x3p_map, the 3x3 convolutions of model/encoder/conformer.py:47-57):
+  // row r of A / C is not at r * ld but at map(r) = base + b sb + i sh + j sw with r = (b, i, j) over a
+  // (hw = rows per image, w = columns per image row) grid, and the K axis of A is nseg segments of seg16
+  // stages (16 floats each) that start segoff[s] floats from the row's base
+  X3PMap amap, cmap;
+  int seg16, nseg;
+  long segoff[4];
+  long c_elems;               // elements of the mapped C buffer (its buffer resource)
 };
 
 // diagnostics: lane 0 of wave 0 records the shader clock at a phase boundary of its workgroup
@@ -297,6 +314,7 @@ __device__ __forceinline__ void x3p_epi_xform(const X3P& g, f32x16& a, float* sc
 }
 
 // phase 2 of one slice: the two row pieces leave (out-of-matrix lanes: dropped by the buffer check)
+template <bool CMAP = false>
 __device__ __forceinline__ void x3p_epi_store(const X3P& g, const EpiRs& rs, const f32x16& a,
                                               const EpiOps& o, int i, int j, int h, int m0, int n0,
                                               int wrb, int wcb, int lane) {
@@ -307,6 +325,10 @@ __device__ __forceinline__ void x3p_epi_store(const X3P& g, const EpiRs& rs, con
     const int row = m0 + 32 * (wrb + i) + 16 * h + er + 8 * q;
     const bool ok = row < g.M && col < g.N;
     const f32x4 v = {a[8 * h + 4 * q], a[8 * h + 4 * q + 1], a[8 * h + 4 * q + 2], a[8 * h + 4 * q + 3]};
+    if (CMAP) {                                      // (mapped output rows; no second output)
+      x3p_bstore(rs.c, ok ? (unsigned)(x3p_maprow(g.cmap, min(row, g.M - 1)) + col) * 4u : kOob, v);
+      continue;
+    }
     x3p_bstore(rs.c, ok ? (unsigned)(row * (int)g.ldc + col) * 4u : kOob, v);
     if (g.act2 == 3) {                               // C2 = C + the role-3 operand (still in its slot)
       const f32x4 u = v + (g.role[0] == 3 ? o.v[q][0] : o.v[q][1]);
@@ -323,13 +345,14 @@ __device__ __forceinline__ void x3p_epi_store(const X3P& g, const EpiRs& rs, con
 // workgroups cover a slice's load -> store round trip
 // BAL: the Balancer update of s2t_gemm_x3p_bal is compiled in (its own instantiations: the others pay
 // no registers for it)
-template <int TM, int TN, bool LEAN = false, bool BAL = false>
+template <int TM, int TN, bool LEAN = false, bool BAL = false, bool CMAP = false>
 __device__ __forceinline__ void x3p_epilogue(const X3P& g, f32x16 (&acc)[TM][TN], unsigned char* smem,
                                              int m0, int n0, int wrb, int wcb, int wave, int lane,
                                              bool sync = true) {
   if (sync) __syncthreads();                         // all waves finished reading the stage buffers
   float* scr = reinterpret_cast<float*>(smem) + wave * (16 * 36);
-  const EpiRs rs = x3p_epi_rsrc(g);
+  EpiRs rs = x3p_epi_rsrc(g);
+  if (CMAP) rs.c = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (int)(g.c_elems * 4), 0x00020000);
   if (LEAN) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -342,7 +365,7 @@ __device__ __forceinline__ void x3p_epilogue(const X3P& g, f32x16 (&acc)[TM][TN]
           EpiOps o;
           x3p_epi_load(g, rs, o, i, j, h, m0, n0, wrb, wcb, lane);
           x3p_epi_xform<BAL>(g, acc[i][j], scr, o, bqj, h, lane, balj);
-          x3p_epi_store(g, rs, acc[i][j], o, i, j, h, m0, n0, wrb, wcb, lane);
+          x3p_epi_store<CMAP>(g, rs, acc[i][j], o, i, j, h, m0, n0, wrb, wcb, lane);
         }
     }
     return;
@@ -837,13 +860,13 @@ void x3p_db_kernel(X3P g) {
 // (the form csrc/gemm_x3f.hip has run with since round 3: per-lane 64-bit address, no SGPR base)
 __device__ __forceinline__ void x3p_glds16(const void* g, unsigned lds_addr) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_addr)
-               : "memory", "m0");
+               : "memory");     // (m0 is reserved: the compiler keeps nothing in it across statements)
 }
 __device__ __forceinline__ unsigned x3p_lds_addr(const void* p) {
   return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
 }
 
-template <int TM, int TN, int WPC>
+template <int TM, int TN, int WPC, bool MAP = false>
 __global__ __launch_bounds__(256, WPC) void x3p_dma_kernel(X3P g) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   constexpr int A_ST = 2 * TM * 3 * 1024, B_ST = 2 * TN * 3 * 1024, ST = A_ST + B_ST;
@@ -897,7 +920,8 @@ __global__ __launch_bounds__(256, WPC) void x3p_dma_kernel(X3P g) {
     m0 = tm_ * BM;                                                                           \
     n0 = tn_ * BN;                                                                           \
     _Pragma("unroll") for (int i = 0; i < NAU; ++i)                                          \
-      asrc[i] = g.A + (long)min(m0 + a_r[i], g.M - 1) * g.lda + a_k[i];                      \
+      asrc[i] = g.A + (MAP ? x3p_maprow(g.amap, min(m0 + a_r[i], g.M - 1))                   \
+                           : (long)min(m0 + a_r[i], g.M - 1) * g.lda) + a_k[i];              \
     _Pragma("unroll") for (int q = 0; q < NBW; ++q) {                                        \
       const int pw_ = min(wave + 4 * q, 6 * TN - 1);                                         \
       const int nt_ = min((n0 >> 5) + pw_ / 3, g.NT - 1);     /* 32-column block, piece */   \
@@ -909,8 +933,13 @@ __global__ __launch_bounds__(256, WPC) void x3p_dma_kernel(X3P g) {
 #define XD_LOAD_A(S)                                                                         \
   {                                                                                          \
     const int ss_ = min((S), nst - 1);                                                       \
+    long ko_ = 16L * ss_;                                                                    \
+    if (MAP) {                         /* stage -> (segment, offset inside it): uniform */    \
+      const int sg_ = ss_ / g.seg16;                                                         \
+      ko_ = g.segoff[sg_] + 16L * (ss_ - sg_ * g.seg16);                                     \
+    }                                                                                        \
     _Pragma("unroll") for (int i = 0; i < NAU; ++i) {                                        \
-      gf32p p_ = (gf32p)(asrc[i] + ((16 * ss_ + a_k[i] < g.K) ? 16 * ss_ : 0));             \
+      gf32p p_ = (gf32p)(asrc[i] + ((16 * ss_ + a_k[i] < g.K) ? ko_ : 0L));                 \
       ra[i][0] = *reinterpret_cast<gf32x4p>(p_);                                             \
       ra[i][1] = *reinterpret_cast<gf32x4p>(p_ + 4);                                         \
     }                                                                                        \
@@ -992,7 +1021,8 @@ __global__ __launch_bounds__(256, WPC) void x3p_dma_kernel(X3P g) {
     // the trailing (dummy) DMA and loads must have landed before the stage buffers become the
     // epilogue's scratch / the next tile's stages
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    x3p_epilogue<TM, TN, true>(g, acc, smem, m0, n0, wrb, wcb, wave, lane, true);
+    if (MAP && g.cmap.on) x3p_epilogue<TM, TN, true, false, true>(g, acc, smem, m0, n0, wrb, wcb, wave, lane, true);
+    else x3p_epilogue<TM, TN, true>(g, acc, smem, m0, n0, wrb, wcb, wave, lane, true);
     loc += stride;
     if (!(loc < per_xcd && xcd * per_xcd + loc < total)) break;
     __syncthreads();
@@ -1341,6 +1371,15 @@ void launch_x3p_dma(X3P& g, hipStream_t st) {
   X3P_LAUNCH((x3p_dma_kernel<TM, TN, WPC>), grid, 256, 0);
 }
 
+template <int TM, int TN, int WPC>
+void launch_x3p_map(X3P& g, hipStream_t st) {
+  g.tiles_m = (g.M + 64 * TM - 1) / (64 * TM);
+  g.tiles_n = (g.N + 64 * TN - 1) / (64 * TN);
+  const int total = g.tiles_m * g.tiles_n;
+  const int grid = std::min(((total + 7) / 8) * 8, 256 * WPC);
+  X3P_LAUNCH((x3p_dma_kernel<TM, TN, WPC, true>), grid, 256, 0);
+}
+
 template <int TM, int TN>
 void launch_x3p(X3P& g, hipStream_t st) {
   g.tiles_m = (g.M + 64 * TM - 1) / (64 * TM);
@@ -1482,7 +1521,8 @@ int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int 
   if (act_src && resid && resid_b) return -2;        // two operand slots
   X3P g{A, lda, Bp, (N + 31) / 32, 2 * ((K + 31) / 32), C, ldc, M, N, K, bias, {nullptr, nullptr},
         {0, 0}, {0, 0}, act_kind, C2, ldc2, act2, 0, 0, wgs, 0, g_stamps, drip, 0, nullptr,
-        nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, X3PMap{0, 1, 1, 0, 0, 0, 0}, X3PMap{0, 1, 1, 0, 0, 0, 0}, 1, 1,
+        {0, 0, 0, 0}, 0};
   if (g_bal.stats) {
     if (!act_src || N > 1024 || tile == 33 || drip) return -2;
     g.bal_stats = g_bal.stats;
@@ -1625,6 +1665,44 @@ int s2t_x3p_sample_end(long* launches, double* total_ms, double* bytes, double* 
   if (total_ms) *total_ms = n > 0 ? ms * (double)g_samp.launches / (double)n : 0.0;
   if (bytes) *bytes = g_samp.bytes;
   if (flops) *flops = g_samp.flops;
+  return 0;
+}
+
+// C = A' . Bm^T (+ bias) with IMPLICIT operands: row r of A' is nseg segments of `seg` contiguous floats
+// of the buffer A, at amap(r) + segoff[s]; row r of C is at cmap(r) (cmap NULL: plain rows of ldc).
+// map(r) = base + b sb + i sh + j sw for r = (b, i, j) over (hw rows per image, w per image row).
+// The 3x3 / stride-2 convolution of the conformer's Subsampling (model/encoder/conformer.py:47-57)
+// without a patch matrix: forward = 3 segments of 3 C floats per output position; data gradient =
+// one launch per input-pixel parity class, whose rows gather 1 / 2 / 2 / 4 taps of the zero-bordered
+// output gradient and scatter to every second pixel (speech2text_amd/conf_kernels.py).
+int s2t_gemm_x3p_map(const float* A, const S2tRowMap* amap, int seg, int nseg, const long* segoff,
+                     const unsigned short* Bp, int N, float* C, long ldc, const S2tRowMap* cmap,
+                     long c_elems, int M, const float* bias, int tile, void* stream) {
+  if (!A || !amap || !segoff || !Bp || !C || M <= 0 || N <= 0 || seg <= 0 || nseg < 1 || nseg > 4) return -1;
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  auto m4 = [](const S2tRowMap* m) { return !((m->sb | m->sh | m->sw | m->base) & 3); };
+  if ((seg & 15) || (N & 3) || !al16(A) || !al16(Bp) || !al16(C) || (bias && !al16(bias)) || !m4(amap) ||
+      (cmap && (!m4(cmap) || c_elems * 4 >= 0x7FFFFF00L)) || (!cmap && ((ldc & 3) || (long)M * ldc * 4 >= 0x7FFFFF00L)))
+    return -2;
+  for (int i = 0; i < nseg; ++i)
+    if (segoff[i] & 3) return -2;
+  const int K = seg * nseg;
+  X3P g{A, 0, Bp, (N + 31) / 32, 2 * ((K + 31) / 32), C, ldc, M, N, K, bias, {nullptr, nullptr},
+        {0, 0}, {0, 0}, 0, nullptr, 0, 0, 0, 0, 0, 0, nullptr, 0, 0, nullptr,
+        nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
+        X3PMap{1, amap->hw, amap->w, amap->sb, amap->sh, amap->sw, amap->base},
+        cmap ? X3PMap{1, cmap->hw, cmap->w, cmap->sb, cmap->sh, cmap->sw, cmap->base} : X3PMap{0, 1, 1, 0, 0, 0, 0},
+        seg / 16, nseg, {0, 0, 0, 0}, c_elems};
+  for (int i = 0; i < nseg; ++i) g.segoff[i] = segoff[i];
+  hipStream_t st = (hipStream_t)stream;
+  ++g_x3p_calls;
+  switch (tile) {
+    case 21: launch_x3p_map<2, 1, 4>(g, st); break;
+    case 12: launch_x3p_map<1, 2, 4>(g, st); break;
+    case 11: launch_x3p_map<1, 1, 5>(g, st); break;
+    default: launch_x3p_map<2, 2, 3>(g, st); break;
+  }
+  S2T_CHECK_LAUNCH();
   return 0;
 }
 

@@ -80,10 +80,17 @@ class Subsampling(nn.Module):
             x = x.unsqueeze(1).contiguous(memory_format=torch.channels_last)
         for m in convs:
             if isinstance(m, nn.Conv2d):
-                if (_OWN_CONV2 and x.is_cuda and tuple(m.kernel_size) == (3, 3)
-                        and tuple(m.padding) == (0, 0) and tuple(m.dilation) == (1, 1)
-                        and m.groups == 1 and x.shape[1] % 4 == 0 and m.out_channels % 4 == 0):
-                    # S2T_CONF_CONV2=own: implicit-im2col MFMA GEMM on the channel-last map
+                own = os.environ.get("S2T_CONF_CONV2", "own")          # (read per call: own | gemm | lib)
+                plain = (x.is_cuda and tuple(m.kernel_size) == (3, 3) and tuple(m.padding) == (0, 0)
+                         and tuple(m.dilation) == (1, 1) and m.groups == 1)
+                if own == "own" and plain and zk.conv3x3_s2_map_ok(x.permute(0, 2, 3, 1), m.weight, m.stride):
+                    # the pre-split bf16x3 GEMM with implicit operands, forward and data gradient
+                    # (zk._Conv3x3S2Map; weight gradient: the implicit-im2col TN kernel): no library
+                    # convolution and no patch matrix on the default path
+                    y = zk.conv3x3_s2_map(x.permute(0, 2, 3, 1), m.weight, m.bias)
+                    x = y.permute(0, 3, 1, 2)
+                elif (own == "gemm" and plain and x.shape[1] % 4 == 0 and m.out_channels % 4 == 0):
+                    # S2T_CONF_CONV2=gemm: implicit-im2col MFMA GEMM on the channel-last map
                     # (s2t_conv3x3_gemm, the kernel of the zipformer frontend) for the forward and
                     # the weight gradient.  Measured (round 4, C2): 25.3 ms/step against 24.4 with
                     # the library's NHWC implicit-GEMM kernels (127 TFLOP/s on this 178 GFLOP
@@ -105,7 +112,6 @@ class Subsampling(nn.Module):
         return out, length
 
 
-_OWN_CONV2 = os.environ.get("S2T_CONF_CONV2", "lib") == "own"
 
 
 class _FeedForwardModule(nn.Module):

@@ -1845,6 +1845,96 @@ class _Conv3x3Nhwc(torch.autograd.Function):
         return dx, dweight, db, None, None
 
 
+class RowMap(ctypes.Structure):
+    """Mirror of S2tRowMap (include/s2t_mi355.h): row r = (b, i, j) -> base + b sb + i sh + j sw floats."""
+    _fields_ = [("hw", ctypes.c_int), ("w", ctypes.c_int), ("sb", ctypes.c_long), ("sh", ctypes.c_long),
+                ("sw", ctypes.c_long), ("base", ctypes.c_long)]
+
+
+def _x3p_map(a, amap, seg, segoff, pp, ncols, out, ldc, cmap, c_elems, M, bias, tile=22):
+    so = (ctypes.c_long * len(segoff))(*segoff)
+    N.PROF[0] and N.profile_note("s2t_gemm_x3p_map", 4.0 * (a.numel() + out.numel()) + 6.0 * ncols * seg * len(segoff),
+                                 2.0 * M * ncols * seg * len(segoff))
+    return N.lib().s2t_gemm_x3p_map(_vp(a), ctypes.byref(amap), seg, len(segoff), so, ctypes.c_void_p(pp), ncols,
+                                    _vp(out), ldc, None if cmap is None else ctypes.byref(cmap), c_elems, M,
+                                    _vp(bias), tile, N.stream())
+
+
+class _Conv3x3S2Map(torch.autograd.Function):
+    """3x3 / stride-2 convolution on a channel-last map (N,H,W,C) with wide channels -- the second
+    convolution of the conformer's Subsampling (reference model/encoder/conformer.py:47-57, 114-126:
+    256 -> 256, 178 GFLOP per pass at C2) -- on the pre-split bf16x3 GEMM with IMPLICIT operands
+    (s2t_gemm_x3p_map): no patch matrix in either direction.
+      forward       a patch row = 3 runs of 3 C contiguous floats of x;
+      weight grad   the split-contraction TN kernel reading the same patches (s2t_conv3x3_gemm);
+      data grad     input pixels by parity class (h % 2, w % 2): a pixel of class (0,0) receives 4 taps,
+                    (0,1) / (1,0) two, (1,1) one; one launch per class whose rows gather those taps from the
+                    zero-bordered output gradient (K = taps * Cout) and write every second pixel of dx."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _dev(x, weight)
+        x = x.contiguous().float()
+        B, H, W, C = x.shape
+        Cout = weight.shape[0]
+        Ho, Wo = (H - 3) // 2 + 1, (W - 3) // 2 + 1
+        w2 = weight.detach().permute(0, 2, 3, 1).reshape(Cout, 9 * C).contiguous()      # cout x (kh, kw, cin)
+        pp = planes.adhoc_pieces(w2, 0)
+        if pp is None:
+            raise RuntimeError("conv3x3 (map): weight shape outside the piece kernel's rules")
+        M = B * Ho * Wo
+        y = torch.empty((M, Cout), dtype=torch.float32, device=x.device)
+        amap = RowMap(Ho * Wo, Wo, H * W * C, 2 * W * C, 2 * C, 0)
+        N.check(_x3p_map(x, amap, 3 * C, [0, W * C, 2 * W * C], pp, Cout, y, Cout, None, 0, M,
+                         None if bias is None else bias.detach()), "s2t_gemm_x3p_map(fwd)")
+        ctx.save_for_backward(x, weight)
+        ctx.params = (weight, bias)
+        ctx.dims = (B, H, W, C, Ho, Wo, Cout)
+        return y.view(B, Ho, Wo, Cout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        B, H, W, C, Ho, Wo, Cout = ctx.dims
+        g = dy.contiguous().float()
+        has_bias = ctx.params[1] is not None
+        dweight, db = side_param_grads(
+            ctx.params, lambda: list(_conv3x3_wgrad_implicit(x, g.view(-1, Cout), 2, 2, has_bias)), keep=(x, g),
+            allow=bool(_FRONT_SIDE & 2))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            gp = F.pad(g, (0, 0, 1, 1, 1, 1))                                  # zero border: every tap in range
+            dx = torch.empty((B, H, W, C), dtype=torch.float32, device=g.device)
+            wd = weight.detach()
+            P2 = Wo + 2
+            for ph in (0, 1):
+                for pw in (0, 1):
+                    taps = [(kh, kw) for kh in ((0, 2) if ph == 0 else (1,)) for kw in ((0, 2) if pw == 0 else (1,))]
+                    # (Cin, taps * Cout): column t * Cout + cout = W[cout, cin, kh_t, kw_t]
+                    bc = torch.cat([wd[:, :, kh, kw].t() for kh, kw in taps], dim=1).contiguous()
+                    pp = planes.adhoc_pieces(bc, 0)
+                    if pp is None:
+                        raise RuntimeError("conv3x3 (map): class weight outside the piece kernel's rules")
+                    Hc, Wc = (H - ph + 1) // 2, (W - pw + 1) // 2
+                    amap = RowMap(Hc * Wc, Wc, (Ho + 2) * P2 * Cout, P2 * Cout, Cout, (P2 + 1) * Cout)
+                    segoff = [((-1 if kh == 2 else 0) * P2 + (-1 if kw == 2 else 0)) * Cout for kh, kw in taps]
+                    cmap = RowMap(Hc * Wc, Wc, H * W * C, 2 * W * C, 2 * C, (ph * W + pw) * C)
+                    N.check(_x3p_map(gp, amap, Cout, segoff, pp, C, dx, C, cmap, dx.numel(), B * Hc * Wc, None),
+                            "s2t_gemm_x3p_map(dgrad)")
+        return dx, dweight, db
+
+
+def conv3x3_s2_map_ok(x, weight, stride):
+    """The implicit-operand GEMM serves this 3x3 convolution (channel-last x): stride 2 both ways, channel
+    counts whose runs are whole 16-float stages."""
+    return (x.is_cuda and tuple(stride) == (2, 2) and x.shape[-1] % 16 == 0 and weight.shape[0] % 16 == 0
+            and x.shape[1] >= 3 and x.shape[2] >= 3 and x.numel() < (1 << 29) and weight.shape[1] == x.shape[-1])
+
+
+def conv3x3_s2_map(x, weight, bias):
+    return _Conv3x3S2Map.apply(x, weight, bias)
+
+
 class _Conv3x3C1(torch.autograd.Function):
     """Conv2d(1, 8, 3, padding=(0, pw)) on (N,H,W,1) as a direct stencil (zip_front.hip): no
     padded copy, no im2col matrix, no 12-wide GEMM."""

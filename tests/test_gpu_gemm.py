@@ -590,3 +590,27 @@ def test_x3p_balancer_epilogue_matches_two_pass_update(dev, kind):
     # the two-pass update): agreement to the statistics' own reproducibility
     y = zk.lt_matmul(1, gy, Wt, act_src=h, act_kind=kind, bal=cfg + (1,))
     assert (y - ref).abs().max().item() / ref.abs().max().item() < 2e-4
+
+
+@pytest.mark.parametrize("B,H,W,C,Cout", [(2, 33, 12, 32, 48), (3, 40, 39, 64, 64), (1, 17, 9, 256, 256)])
+def test_conv3x3_stride2_on_the_implicit_operand_gemm(dev, B, H, W, C, Cout):
+    """zk._Conv3x3S2Map (s2t_gemm_x3p_map): the conformer Subsampling's second convolution
+    (reference model/encoder/conformer.py:47-57) without a patch matrix -- forward, the parity-class data
+    gradient and the weight / bias gradient against torch's fp64 convolution; odd and even map sizes
+    (the last row / column of an even-sized map is covered by no window: its gradient must be zero)."""
+    g = torch.Generator().manual_seed(B * 100 + H)
+    x = torch.randn(B, H, W, C, generator=g).to(dev).requires_grad_(True)
+    w = (torch.randn(Cout, C, 3, 3, generator=g) * 0.05).to(dev).requires_grad_(True)
+    b = torch.randn(Cout, generator=g).to(dev).requires_grad_(True)
+    assert zk.conv3x3_s2_map_ok(x, w, (2, 2))
+    y = zk.conv3x3_s2_map(x, w, b)
+    xd, wd, bd = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+    yr = torch.nn.functional.conv2d(xd.permute(0, 3, 1, 2), wd, bd, stride=2).permute(0, 2, 3, 1)
+    assert y.shape == yr.shape
+    _close(y, yr, tol=2e-6)
+    gy = torch.randn(y.shape, generator=g).to(dev)
+    y.backward(gy)
+    yr.backward(gy.double())
+    _close(x.grad, xd.grad, tol=2e-6)
+    _close(w.grad, wd.grad, tol=2e-5)
+    _close(b.grad, bd.grad, tol=2e-5)
