@@ -1774,6 +1774,9 @@ def _implicit_ok(x, Cout, sh=1, sw=1):
     return x.is_cuda and C % 4 == 0 and Cout % 4 == 0 and x.numel() < (1 << 31) and rows >= 4
 
 
+_CONV_MAP_FWD = os.environ.get("S2T_CONV_MAP_FWD", "1") == "1"
+
+
 class _Conv3x3Nhwc(torch.autograd.Function):
     """3x3 conv on channel-last (N,H,W,Cin) as an implicit-im2col GEMM: each patch row is 3
     contiguous runs of 3*Cin floats of x, which the MFMA kernel's operand loader addresses in
@@ -1791,7 +1794,18 @@ class _Conv3x3Nhwc(torch.autograd.Function):
         Ho, Wo = (H - 3) // sh + 1, (W - 3) // sw + 1
         w2 = weight.permute(0, 2, 3, 1).reshape(Cout, 9 * C)                    # cout x (kh,kw,cin)
         ctx.implicit = _implicit_ok(x, Cout, sh, sw)
-        if ctx.implicit:
+        pp = None
+        if ctx.implicit and _CONV_MAP_FWD and C % 16 == 0 and Cout % 16 == 0:
+            # forward on the pre-split bf16x3 GEMM with implicit operands (s2t_gemm_x3p_map: 150 TFLOP/s
+            # on the conformer's 256 -> 256 product where the NT kernel below reaches ~ 90)
+            pp = planes.adhoc_pieces(w2.detach().contiguous(), 0)
+        if pp is not None:
+            y = torch.empty((B * Ho * Wo, Cout), dtype=torch.float32, device=x.device)
+            amap = RowMap(Ho * Wo, Wo, H * W * C, sh * W * C, sw * C, 0)
+            N.check(_x3p_map(x, amap, 3 * C, [0, W * C, 2 * W * C], pp, Cout, y, Cout, None, 0, B * Ho * Wo,
+                             None if bias is None else bias.detach()), "s2t_gemm_x3p_map(fwd)")
+            ctx.save_for_backward(x, weight)
+        elif ctx.implicit:
             y = torch.empty((B * Ho * Wo, Cout), dtype=torch.float32, device=x.device)
             N.PROF[0] and N.profile_note("s2t_conv3x3_gemm", 4.0 * (x.numel() + y.numel()),
                            2.0 * y.numel() * 9 * C)
