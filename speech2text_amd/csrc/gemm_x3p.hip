@@ -367,6 +367,43 @@ __device__ __forceinline__ void x3p_epilogue(const X3P& g, f32x16 (&acc)[TM][TN]
           x3p_epi_xform<BAL>(g, acc[i][j], scr, o, bqj, h, lane, balj);
           x3p_epi_store<CMAP>(g, rs, acc[i][j], o, i, j, h, m0, n0, wrb, wcb, lane);
         }
+      if (g.colstats) {
+        // column statistics of C (s2t_gemm_x3p_stats): the final values of column block j sit in the
+        // accumulator registers in row-piece layout -- this lane's column quad over its rows, summed
+        // over the 8 lanes that share the quad, one atomic pair per column and wave
+        const int er = lane >> 3, ec = (lane & 7) * 4;
+        float sm[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              const bool rok = m0 + 32 * (wrb + i) + 16 * h + er + 8 * q < g.M;
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                const float v = rok ? acc[i][j][8 * h + 4 * q + c] : 0.f;
+                sm[c] += v;
+                sq[c] = fmaf(v, v, sq[c]);
+              }
+            }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+          for (int d = 8; d < 64; d <<= 1) {
+            sm[c] += __shfl_xor(sm[c], d);
+            sq[c] += __shfl_xor(sq[c], d);
+          }
+        }
+        const int col = n0 + 32 * (wcb + j) + ec;
+        if (er == 0 && col < g.N) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            atomicAdd(g.colstats + col + c, sm[c]);
+            atomicAdd(g.colstats + 1024 + col + c, sq[c]);
+          }
+        }
+      }
     }
     return;
   }

@@ -1412,6 +1412,7 @@ def x3p_matmul(mode, x2, w2, bias=None, resid2=None, act_src=None, act_kind=None
             return None
         stats = torch.zeros(2048, dtype=torch.float32, device=x2.device)
         N.PROF[0] and N.profile_note("s2t_balancer_stats", 4.0 * act_src.numel())
+        N.PROF[0] and N.profile_note("s2t_gemm_x3p_bal", 4.0 * R * (Nf + Kf + cols) + 6.0 * Nf * Kf, 2.0 * R * Nf * Kf)
         N.check(N.lib().s2t_balancer_stats(_vp(act_src), act_src.stride(0), R, cols, _vp(stats), N.stream()),
                 "s2t_balancer_stats")
         rc = N.lib().s2t_gemm_x3p_bal(_vp(x2), x2.stride(0), ctypes.c_void_p(pp), cols, inner, _vp(out), cols, R,
