@@ -20,6 +20,7 @@
 #include "../../include/s2t_mi355.h"
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 
 namespace {
@@ -299,6 +300,7 @@ __device__ __forceinline__ void tn_p3_body(const GemmArgs& g, const unsigned bid
       atomicAdd(g.colsum + m0 + t, ((red[t] + red[BM + t]) + (red[2 * BM + t] + red[3 * BM + t])) * g.alpha);
     }
   }
+  if (g.debug & 1) return;
   const int hi = lane >> 5, lo = lane & 31;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -314,6 +316,202 @@ __device__ __forceinline__ void tn_p3_body(const GemmArgs& g, const unsigned bid
       }
     }
 }
+
+// ---- TN "W" form (round 5): wave-specialised, (64 MI) x (64 NJ) output tile per workgroup of 8 waves.
+// The 64 x 64 form above spends as many VALU cycles splitting fragments (4.5 instructions per
+// element) as the matrix cores spend on the products, in the SAME waves, so the two serialize.
+// Here waves 4-7 (PRODUCERS) load 16-byte runs of four adjacent columns x 8 contraction rows,
+// transpose in registers, split and write the piece image of chunk c+1 into one LDS buffer, while
+// waves 0-3 (CONSUMERS, one per SIMD, 32 MI x 32 NJ each) run the 6 x MI x NJ x 2 MFMAs of chunk c
+// out of the other -- the splitting rides under the matrix work of the same SIMD, one barrier per
+// chunk.  One workgroup per CU (96-120 KB of LDS), so a launch wants ~256-512 workgroups: fewer,
+// longer contraction slices, i.e. fewer atomic bytes than the 64 x 64 form's ~6000.
+// The lane slots of a fragment are permuted (tnw_perm32) so that the four-column 16-byte writes
+// (8-lane groups, 32 banks) and the fragment reads (16-lane groups, 64 banks) are conflict-free.
+__device__ __forceinline__ int tnw_perm32(int t) {        // t = 4 a + mi  ->  ((a + 2 mi) & 7) + 8 mi
+  const int a = t >> 2, mi = t & 3;
+  return ((a + 2 * mi) & 7) + 8 * mi;
+}
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+struct TnwUnit {           // a producer's unit: four columns x eight contraction rows of one operand
+  const float* src;        // column-quad base (row 0 of the operand)
+  long ld;
+  unsigned dst;            // byte offset of (mi = 0) slot base in a buffer (without the permutation)
+  int a, kg;
+  bool valid, colok, isA;
+};
+template <int MI, int NJ, int PRO>
+__device__ __forceinline__ void tn_w_body(const GemmArgs& g, const unsigned bid, unsigned char* sm) {
+  constexpr int BM = 64 * MI, BN = 64 * NJ, BK = 32;
+  constexpr int IMG_A = BM * BK * 6, IMG_B = BN * BK * 6, BUF = IMG_A + IMG_B;
+  constexpr int UNITS = BM + BN, NSLOT = (UNITS + 255) / 256;
+  const int total = g.tiles_m * g.tiles_n;
+  const int q = (int)(bid >> 3);
+  const int zslice = (int)(bid & 7) + 8 * (q / total);
+  const int lin = q % total;
+  if (zslice >= g.splits) return;
+  const int tm = lin / g.tiles_n, tn = lin % g.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool producer = wave >= 4;
+  const int kbeg = zslice * g.kper;
+  const int kend = min(g.K, kbeg + g.kper);
+  if (kbeg >= kend) return;
+  const int nchunk = (kend - kbeg + BK - 1) / BK;
+  const bool want_csum = g.colsum != nullptr && tn == 0;
+
+  // ---- producer state
+  TnwUnit un[NSLOT];
+  f32x4_t r[NSLOT][8];
+  float cs[NSLOT][4];
+#pragma unroll
+  for (int j = 0; j < NSLOT; ++j) {
+    const int u = (tid & 255) + 256 * j;
+    TnwUnit& t = un[j];
+    t.valid = producer && u < UNITS;
+    t.isA = u < BM;
+    const int idx = t.isA ? u : u - BM;
+    const int Q = t.isA ? BM / 4 : BN / 4;
+    const int kg = idx / Q, mq = idx - kg * Q;
+    const int col = (t.isA ? m0 : n0) + 4 * mq;
+    t.colok = col < (t.isA ? g.M : g.N);                  // (column counts are multiples of 4)
+    t.ld = t.isA ? g.lda : g.ldb;
+    t.src = (t.isA ? g.A : g.B) + (t.colok ? col : 0);
+    t.kg = kg;
+    t.a = mq & 7;
+    t.dst = (unsigned)((t.isA ? 0 : IMG_A) + (((mq >> 3) * 2 + (kg >> 1)) * 3) * 1024 + (kg & 1) * 512);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) cs[j][mi] = 0.f;
+  }
+  auto load = [&](int c) {
+    const int k0 = kbeg + c * BK;
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j)
+      if (un[j].valid) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          r[j][e] = *reinterpret_cast<const f32x4_t*>(un[j].src + (long)min(k0 + 8 * un[j].kg + e, kend - 1) * un[j].ld);
+      }
+  };
+  auto store = [&](int c) {
+    const int k0 = kbeg + c * BK;
+    unsigned char* const buf = sm + (c & 1) * BUF;
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j)
+      if (un[j].valid) {
+        const TnwUnit& t = un[j];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float x = r[j][e][mi];
+            if (PRO != ACT_NONE && !t.isA) x = swoosh(x, PRO);
+            v[e] = (t.colok && k0 + 8 * t.kg + e < kend) ? x : 0.f;
+          }
+          if (want_csum && t.isA)
+            cs[j][mi] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+          unsigned a0, a1, a2, b0, b1, b2, c0, c1, c2, d0, d1, d2;
+          split_pair(v[0], v[1], a0, a1, a2);
+          split_pair(v[2], v[3], b0, b1, b2);
+          split_pair(v[4], v[5], c0, c1, c2);
+          split_pair(v[6], v[7], d0, d1, d2);
+          const u32x4_t q0 = {a0, b0, c0, d0}, q1 = {a1, b1, c1, d1}, q2 = {a2, b2, c2, d2};
+          unsigned char* const d = buf + t.dst + ((((t.a + 2 * mi) & 7) + 8 * mi) << 4);
+          *reinterpret_cast<u32x4_t*>(d) = q0;
+          *reinterpret_cast<u32x4_t*>(d + 1024) = q1;
+          *reinterpret_cast<u32x4_t*>(d + 2048) = q2;
+        }
+      }
+  };
+
+  // ---- consumer state
+  f32x16 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int wm = (wave >> 1) * 32 * MI, wn = (wave & 1) * 32 * NJ;    // (consumers: wave < 4)
+  const unsigned fslot = (unsigned)(((lane >> 5) * 32 + tnw_perm32(lane & 31)) * 16);
+
+  if (producer) {
+    load(0);
+    store(0);
+    if (nchunk > 1) load(1);
+  }
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    if (producer) {
+      if (c + 1 < nchunk) {
+        if (!(g.debug & 2)) store(c + 1);
+        if (c + 2 < nchunk && !(g.debug & 8)) load(c + 2);
+      }
+    } else if (!(g.debug & 4)) {
+      const unsigned char* const sA = sm + (c & 1) * BUF;
+      const unsigned char* const sB = sA + IMG_A;
+#pragma unroll
+      for (int s = 0; s < BK / 16; ++s) {
+        bf16x8 pa[MI][3], pb[NJ][3];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+            pa[i][p] = *reinterpret_cast<const bf16x8*>(sA + ((((wm >> 5) + i) * 2 + s) * 3 + p) * 1024 + fslot);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+            pb[j][p] = *reinterpret_cast<const bf16x8*>(sB + ((((wn >> 5) + j) * 2 + s) * 3 + p) * 1024 + fslot);
+#define S2T_W_TERM(PA, PB)                                                                       \
+  _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < NJ; ++j)  \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i][PA], pb[j][PB], acc[i][j], 0, 0, 0);
+        S2T_W_TERM(2, 0) S2T_W_TERM(1, 1) S2T_W_TERM(0, 2) S2T_W_TERM(1, 0) S2T_W_TERM(0, 1) S2T_W_TERM(0, 0)
+#undef S2T_W_TERM
+      }
+    }
+    __syncthreads();
+  }
+  if (want_csum) {                         // the four row groups' partial sums -> one add per column
+    float* red = reinterpret_cast<float*>(sm);
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j)
+      if (un[j].valid && un[j].isA) {
+        const int idx = (tid & 255) + 256 * j;              // = kg (BM / 4) + mq
+        const int kg = idx / (BM / 4), mq = idx - kg * (BM / 4);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) red[kg * BM + 4 * mq + mi] = cs[j][mi];
+      }
+    __syncthreads();
+    if (tid < BM && m0 + tid < g.M)
+      atomicAdd(g.colsum + m0 + tid, ((red[tid] + red[BM + tid]) + (red[2 * BM + tid] + red[3 * BM + tid])) * g.alpha);
+  }
+  if (producer || (g.debug & 1)) return;
+  const int hi = lane >> 5, lo = lane & 31;
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = n0 + wn + 32 * j + lo;
+      if (c >= g.N) continue;
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const int row = m0 + wm + 32 * i + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
+        if (row >= g.M) continue;
+        atomicAdd(g.C + (long)row * g.ldc + c, acc[i][j][rr] * g.alpha);
+      }
+    }
+}
+// tile shape of a problem on the W form: 0 = 128 x 128, 1 = 128 x 192, 2 = 192 x 128
+template <int PRO>
+__device__ __forceinline__ void tn_w_shape(const GemmArgs& g, int shape, unsigned bid, unsigned char* sm) {
+  if (shape == 1) tn_w_body<2, 3, PRO>(g, bid, sm);
+  else if (shape == 2) tn_w_body<3, 2, PRO>(g, bid, sm);
+  else tn_w_body<2, 2, PRO>(g, bid, sm);
+}
+constexpr int TNW_LDS = 2 * (128 + 192) * 32 * 6;   // 120 KB: the widest shape's two buffers
+constexpr int TNW_LDS0 = 2 * (128 + 128) * 32 * 6;  // 96 KB: 128 x 128 tiles
 
 // X3 (TN only): the contraction runs on the bf16 matrix cores -- both operand fragments are split
 // exactly into three bf16 pieces when a wave reads them from LDS (8 k-strided reads per
@@ -558,9 +756,11 @@ struct TnProb {
   float* colsum;
   int lda, ldb, ldc, M, N, K, kper, tiles_m, tiles_n, splits;
   float alpha;
+  int shape;               // W form: 0 = 128 x 128 tiles, 1 = 128 x 192, 2 = 192 x 128
 };
 struct TnGroup {
   int n;
+  int debug;
   unsigned begin[MAXG + 1];
   TnProb p[MAXG];
 };
@@ -571,8 +771,24 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(TnGroup grp) {
   while (i + 1 < grp.n && blockIdx.x >= grp.begin[i + 1]) ++i;
   const TnProb& q = grp.p[i];
   GemmArgs g{q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, nullptr, nullptr, 0, nullptr, 0,
-             0, 0, 0, q.colsum, 0, q.kper, q.tiles_m, q.tiles_n, q.splits, 0, q.alpha};
+             0, 0, 0, q.colsum, 0, q.kper, q.tiles_m, q.tiles_n, q.splits, grp.debug, q.alpha};
   gemm_body<1, TNW, MODE_TN, ACT_NONE, X3, false, P3>(g, blockIdx.x - grp.begin[i]);
+}
+
+// the grouped launch on the W form (tiles_m / tiles_n of the problems count that problem's tiles)
+__global__ __launch_bounds__(512) void gemm_tn_grouped_w_kernel(TnGroup grp) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char tnw_sm[];
+  int i = 0;
+  while (i + 1 < grp.n && blockIdx.x >= grp.begin[i + 1]) ++i;
+  const TnProb& q = grp.p[i];
+  GemmArgs g{q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, nullptr, nullptr, 0, nullptr, 0,
+             0, 0, 0, q.colsum, 0, q.kper, q.tiles_m, q.tiles_n, q.splits, grp.debug, q.alpha};
+  tn_w_shape<ACT_NONE>(g, q.shape, blockIdx.x - grp.begin[i], tnw_sm);
+}
+template <int PRO>
+__global__ __launch_bounds__(512) void gemm_tn_w_kernel(GemmArgs g, int shape) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char tnw_sm[];
+  tn_w_shape<PRO>(g, shape, blockIdx.x, tnw_sm);
 }
 
 // Weight-gradient contractions on the bf16 matrix cores (three-way exact split, six products:
@@ -595,6 +811,36 @@ static bool tn_p3() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("S2T_TN_P3"); v = e ? atoi(e) : 1; }
   return v == 1;
+}
+// S2T_TN_W=0: weight gradients on the 64 x 64 form instead of the wave-specialised "W" form;
+// S2T_TN_W_BLOCKS: workgroups a W launch aims at (one is resident per CU)
+static bool tn_w() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("S2T_TN_W"); v = e ? atoi(e) : 1; }
+  return v == 1;
+}
+static long tn_w_blocks() {
+  static long v = -1;
+  if (v < 0) { const char* e = getenv("S2T_TN_W_BLOCKS"); v = e ? atol(e) : 512; }
+  return v;
+}
+// tile shape of an (M x N) output on the W form and its tile counts
+static int tn_w_shape_of(int M, int N, int& tiles_m, int& tiles_n) {
+  const auto waste = [](int n, int t) { return ((n + t - 1) / t) * t - n; };
+  static int wide = -1;      // S2T_TN_W_WIDE=0: 128 x 128 tiles only (96 KB of LDS instead of 120)
+  if (wide < 0) { const char* e = getenv("S2T_TN_W_WIDE"); wide = e ? atoi(e) : 1; }
+  int shape = 0;
+  if (!wide) shape = 0;
+  else if (waste(N, 192) < waste(N, 128)) shape = 1;
+  else if (waste(M, 192) < waste(M, 128)) shape = 2;
+  tiles_m = (M + (shape == 2 ? 191 : 127)) / (shape == 2 ? 192 : 128);
+  tiles_n = (N + (shape == 1 ? 191 : 127)) / (shape == 1 ? 192 : 128);
+  return shape;
+}
+template <typename K>
+static bool tn_w_prepare(K kern) {      // the kernels take 120 KB of dynamic LDS
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             TNW_LDS) == hipSuccess;
 }
 static int g_tn_x3 = -1;
 static bool tn_x3() {
@@ -658,9 +904,40 @@ int dispatch(GemmArgs& g, hipStream_t st) {
     // C3 shapes from ~50 to ~75 TFLOP/s against 128x192 tiles at 2 per CU (tools/bench_tn.py);
     // 64x128 once the output is wide enough to give the slices enough tiles.
     // S2T_TN_TILE ("11", "12", "21", "22", "23") / S2T_TN_BLOCKS override the choice for tuning.
+    // Round 5: aligned, non-symmetric problems take the wave-specialised W form first (tn_w_body).
+    // Alone on the chip it is SLOWER than the 64 x 64 form (10 C3 shapes: 700 against 535 us: one
+    // workgroup per CU, 40 KB of loads in flight), inside the training step it is faster (same box:
+    // 39.2 -> 38.55 ms/step): the step runs these launches beside the main stream's GEMMs, where
+    // what counts is the issue slots and LDS/L2 bytes a launch takes from them, and the W form
+    // takes fewer of each per flop (bigger tiles, 16-byte loads, half the split work per product).
+    // S2T_GEMM_DEBUG bits (timing ablations, results wrong): 1 no output adds, 2 no split/store,
+    // 4 no MFMA, 8 no loads, 16 print the launch.
     static int force = -1, user_blocks = -2;
     if (force < 0) { const char* e = getenv("S2T_TN_TILE"); force = e ? atoi(e) : 0; }
     if (user_blocks == -2) { const char* e = getenv("S2T_TN_BLOCKS"); user_blocks = e ? atoi(e) : -1; }
+    if (tn_w() && tn_x3() && tn_p3() && !g.sym_cg && force <= 0 && !((g.M | g.N | g.lda | g.ldb) & 3) &&
+        !((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.B)) & 15)) {
+      const int shape = tn_w_shape_of(g.M, g.N, g.tiles_m, g.tiles_n);
+      { const char* e = getenv("S2T_GEMM_DEBUG"); g.debug = e ? atoi(e) : 0; }
+      const long tiles = (long)g.tiles_m * g.tiles_n;
+      const long target = user_blocks > 0 ? user_blocks : tn_w_blocks();
+      int splits = (int)((target + tiles - 1) / tiles);
+      splits = std::max(1, std::min(splits, (g.K + 2 * KR - 1) / (2 * KR)));
+      int kper = (g.K + splits - 1) / splits;
+      kper = ((kper + KR - 1) / KR) * KR;
+      g.kper = kper;
+      g.splits = (g.K + kper - 1) / kper;
+      const int grid = (int)(8 * tiles * ((g.splits + 7) / 8));
+      if (g.debug & 16) fprintf(stderr, "[tn_w] M %d N %d K %d shape %d splits %d kper %d grid %d pro %d\n", g.M, g.N, g.K, shape, g.splits, g.kper, grid, pro);
+      static const bool ok = tn_w_prepare(gemm_tn_w_kernel<ACT_NONE>) && tn_w_prepare(gemm_tn_w_kernel<ACT_SWOOSH_L>) &&
+                             tn_w_prepare(gemm_tn_w_kernel<ACT_SWOOSH_R>);
+      if (!ok) return -3;
+      const int lds = shape ? TNW_LDS : TNW_LDS0;
+      if (pro == ACT_NONE) hipLaunchKernelGGL((gemm_tn_w_kernel<ACT_NONE>), dim3(grid), dim3(512), lds, st, g, shape);
+      else if (pro == ACT_SWOOSH_L) hipLaunchKernelGGL((gemm_tn_w_kernel<ACT_SWOOSH_L>), dim3(grid), dim3(512), lds, st, g, shape);
+      else hipLaunchKernelGGL((gemm_tn_w_kernel<ACT_SWOOSH_R>), dim3(grid), dim3(512), lds, st, g, shape);
+      return (int)hipGetLastError();
+    }
     const int ttm = (force > 0 && !g.sym_cg) ? force / 10 : 1;
     const int ttn = g.sym_cg ? 1 : (force > 0 ? force % 10 : (g.N >= 512 ? 2 : 1));
     const long tiles = (long)((g.M + 64 * ttm - 1) / (64 * ttm)) * ((g.N + 64 * ttn - 1) / (64 * ttn));
@@ -871,8 +1148,59 @@ extern "C" int s2t_gemm_tn_grouped(int n, const S2tTnProblem* probs, void* strea
   }
   static int tnw = -1;      // output tile 64 x (64 tnw): S2T_TN_GROUP_TILE = 11 | 12
   if (tnw < 0) { const char* e = getenv("S2T_TN_GROUP_TILE"); tnw = (e && atoi(e) == 12) ? 2 : 1; }
+  const long qtarget = tn_w_blocks();
+  bool useq = tn_w() && tn_x3() && tn_p3();
+  for (int i = 0; i < n && useq; ++i) {
+    const S2tTnProblem& s = probs[i];
+    useq = !((s.M & 3) || (s.N & 3) || (s.lda & 3) || (s.ldb & 3) ||
+             (reinterpret_cast<uintptr_t>(s.A) & 15) || (reinterpret_cast<uintptr_t>(s.B) & 15));
+  }
+  if (useq) {
+    static const bool ok = tn_w_prepare(gemm_tn_grouped_w_kernel);
+    if (!ok) return -3;
+  }
+  for (int base = 0; base < n && useq; base += MAXG) {
+    TnGroup grp;
+    { const char* e = getenv("S2T_GEMM_DEBUG"); grp.debug = e ? atoi(e) : 0; }
+    grp.n = std::min(MAXG, n - base);
+    long total_tiles = 0;
+    for (int i = 0; i < grp.n; ++i) {
+      const S2tTnProblem& s = probs[base + i];
+      if (s.M <= 0 || s.N <= 0 || s.K <= 0 || s.lda > INT32_MAX || s.ldb > INT32_MAX || s.ldc > INT32_MAX)
+        return -2;
+      int tmm, tnn;
+      tn_w_shape_of(s.M, s.N, tmm, tnn);
+      total_tiles += (long)tmm * tnn;
+    }
+    int want = (int)((qtarget + total_tiles - 1) / total_tiles);
+    want = std::max(8, ((want + 4) / 8) * 8);
+    unsigned blocks = 0;
+    int lds = TNW_LDS0;
+    for (int i = 0; i < grp.n; ++i) {
+      const S2tTnProblem& s = probs[base + i];
+      TnProb& q = grp.p[i];
+      q = TnProb{s.A, s.B, s.C, s.colsum, (int)s.lda, (int)s.ldb, (int)s.ldc, s.M, s.N, s.K,
+                 0, 0, 0, 0, s.alpha, 0};
+      q.shape = tn_w_shape_of(s.M, s.N, q.tiles_m, q.tiles_n);
+      if (q.shape) lds = TNW_LDS;
+      const long tiles = (long)q.tiles_m * q.tiles_n;
+      const int maxs = (s.K + 2 * KR - 1) / (2 * KR);
+      int splits = std::max(1, std::min(want, maxs));
+      int kper = (s.K + splits - 1) / splits;
+      kper = ((kper + KR - 1) / KR) * KR;
+      q.kper = kper;
+      q.splits = (s.K + kper - 1) / kper;
+      grp.begin[i] = blocks;
+      blocks += (unsigned)(8 * tiles * ((q.splits + 7) / 8));
+    }
+    grp.begin[grp.n] = blocks;
+    hipLaunchKernelGGL(gemm_tn_grouped_w_kernel, dim3(blocks), dim3(512), lds, st, grp);
+    if (hipGetLastError() != hipSuccess) return -3;
+  }
+  if (useq) return 0;
   for (int base = 0; base < n; base += MAXG) {
     TnGroup grp;
+    { const char* e = getenv("S2T_GEMM_DEBUG"); grp.debug = e ? atoi(e) : 0; }
     grp.n = std::min(MAXG, n - base);
     long total_tiles = 0;
     for (int i = 0; i < grp.n; ++i) {
