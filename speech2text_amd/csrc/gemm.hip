@@ -22,6 +22,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -393,7 +394,10 @@ __device__ __forceinline__ void tn_w_body(const GemmArgs& g, const unsigned bid,
           r[j][e] = *reinterpret_cast<const f32x4_t*>(un[j].src + (long)min(k0 + 8 * un[j].kg + e, kend - 1) * un[j].ld);
       }
   };
-  auto store = [&](int c) {
+  // (columns past M / N need no zeroing: they only reach output rows / columns that are never
+  // written; contraction rows past kend do, in the slice's last chunk only)
+  auto store_t = [&](int c, auto tailc) {
+    constexpr bool TAIL = decltype(tailc)::value;
     const int k0 = kbeg + c * BK;
     unsigned char* const buf = sm + (c & 1) * BUF;
 #pragma unroll
@@ -407,7 +411,7 @@ __device__ __forceinline__ void tn_w_body(const GemmArgs& g, const unsigned bid,
           for (int e = 0; e < 8; ++e) {
             float x = r[j][e][mi];
             if (PRO != ACT_NONE && !t.isA) x = swoosh(x, PRO);
-            v[e] = (t.colok && k0 + 8 * t.kg + e < kend) ? x : 0.f;
+            v[e] = (!TAIL || k0 + 8 * t.kg + e < kend) ? x : 0.f;
           }
           if (want_csum && t.isA)
             cs[j][mi] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
@@ -423,6 +427,11 @@ __device__ __forceinline__ void tn_w_body(const GemmArgs& g, const unsigned bid,
           *reinterpret_cast<u32x4_t*>(d + 2048) = q2;
         }
       }
+  };
+
+  auto store = [&](int c) {
+    if (kbeg + (c + 1) * BK <= kend) store_t(c, std::false_type{});
+    else store_t(c, std::true_type{});
   };
 
   // ---- consumer state

@@ -273,6 +273,110 @@ __global__ __launch_bounds__(256) void dwconv2d_roll_kernel(const float* __restr
   }
 }
 
+// Weight / bias gradient of the 7x7 depthwise conv, ring form (round 5).  The roll kernel's MODE 2
+// kept the KH-row INPUT window (130 registers) next to the 49 tap accumulators: 256 VGPRs plus
+// AGPR spill space, one wave per SIMD, 1.08 ms for a 0.6 GB stream.  Here the thread keeps a ring of
+// the last KH rows of dy (7 values each) and streams the input rows through once: input row
+// r = hs - PH + t meets dy row hh = t - i under tap row i.  49 accumulators + 9 x 7 dy + 3 x 13 input
+// registers (GPD = 2 rows requested ahead of use) -> 3 waves per SIMD.
+//   part[c-tile][block][tap | bias][64], as the roll kernel's MODE 2.
+template <int KH, int KW, int GPD>
+__global__ __launch_bounds__(256) void dwconv2d_wgrad_ring_kernel(const float* __restrict__ x,
+                                                                  const float* __restrict__ dy, int N,
+                                                                  int H, int W, int C, int nparts,
+                                                                  int nrr, int rrt,
+                                                                  float* __restrict__ out) {
+  constexpr int GR = KH + GPD, XR = 1 + GPD;
+  static_assert(GR % XR == 0, "the unrolled step loop must keep both ring slots compile-time");
+  constexpr int PH = KH / 2, PW = KW / 2, WW = RWO + KW - 1, NV = KH * KW + 1;
+  const int c0 = blockIdx.z * RCT, c = threadIdx.x % RCT, n = blockIdx.y;
+  const int q = blockIdx.x * (256 / RCT) + (threadIdx.x / RCT);
+  const int part = q % nparts, rr = q / nparts;
+  const bool live = c0 + c < C && rr < nrr;
+  const int cc = (c0 + c < C) ? c0 + c : 0;
+  const int w0 = part * RWO, hs = rr * rrt, nrows = min(H, hs + rrt) - hs;
+  float wv[KH * KW];
+  float bacc = 0.f;
+#pragma unroll
+  for (int k = 0; k < KH * KW; ++k) wv[k] = 0.f;
+  const float* xn = x + (long)n * H * W * C;
+  const float* gn = dy + (long)n * H * W * C;
+  float gd[GR][RWO];       // dy rows: slot hh % GR
+  float xw[XR][WW];        // input rows: slot t % XR
+#define S2T_LOADX(SLOT, T)                                                             \
+  {                                                                                    \
+    const int r_ = hs - PH + (T);                                                      \
+    const bool rv_ = r_ >= 0 && r_ < H;                                                \
+    const float* row_ = xn + (long)r_ * W * C;                                         \
+    _Pragma("unroll") for (int v = 0; v < WW; ++v) {                                   \
+      const int ww_ = w0 + v - PW;                                                     \
+      const float* p_ = (rv_ && ww_ >= 0 && ww_ < W) ? row_ + (long)ww_ * C : g_zero;  \
+      xw[SLOT][v] = p_[cc];                                                            \
+    }                                                                                  \
+  }
+#define S2T_LOADG(SLOT, HH)                                                            \
+  {                                                                                    \
+    const int hh_ = (HH);                                                              \
+    const bool rv_ = hh_ < nrows;                                                      \
+    const float* row_ = gn + ((long)(hs + hh_) * W + w0) * C;                          \
+    _Pragma("unroll") for (int o = 0; o < RWO; ++o) {                                  \
+      const float* p_ = (rv_ && w0 + o < W) ? row_ + (long)o * C : g_zero;             \
+      gd[SLOT][o] = p_[cc];                                                            \
+    }                                                                                  \
+  }
+  if (live && nrows > 0) {
+#pragma unroll
+    for (int s = 0; s < GPD; ++s) {
+      S2T_LOADX(s % XR, s)
+      S2T_LOADG(s % GR, s)
+    }
+    const int nsteps = nrows + KH - 1;
+    for (int k0 = 0; k0 < nsteps; k0 += GR) {
+#pragma unroll
+      for (int u = 0; u < GR; ++u) {
+        const int t = k0 + u;
+        if (t < nsteps) {                              // uniform per wave
+          S2T_LOADX((u + GPD) % XR, t + GPD)
+          S2T_LOADG((u + GPD) % GR, t + GPD)
+          if (t < nrows) {
+#pragma unroll
+            for (int o = 0; o < RWO; ++o) bacc += gd[u][o];
+          }
+#pragma unroll
+          for (int i = 0; i < KH; ++i)
+            if ((unsigned)(t - i) < (unsigned)nrows) {
+#pragma unroll
+              for (int j = 0; j < KW; ++j)
+#pragma unroll
+                for (int o = 0; o < RWO; ++o)
+                  wv[i * KW + j] = fmaf(gd[(u - i + GR) % GR][o], xw[u % XR][o + j], wv[i * KW + j]);
+            }
+        }
+      }
+    }
+  }
+#undef S2T_LOADX
+#undef S2T_LOADG
+  __shared__ float s_red[256 / RCT][RCT];
+  const int r = threadIdx.x / RCT;
+  const long nblk = (long)gridDim.y * gridDim.x;
+  const long blk = (long)blockIdx.y * gridDim.x + blockIdx.x;
+  const long tile = (long)blockIdx.z * (RCT / 64) + c / 64;
+  float* dst = out + ((tile * nblk + blk) * NV) * 64 + (c & 63);
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    __syncthreads();
+    s_red[r][c] = live ? (k < NV - 1 ? wv[k < NV - 1 ? k : 0] : bacc) : 0.f;
+    __syncthreads();
+    if (r == 0) {
+      float t = 0.f;
+#pragma unroll
+      for (int rr2 = 0; rr2 < 256 / RCT; ++rr2) t += s_red[rr2][c];
+      dst[k * 64] = t;
+    }
+  }
+}
+
 __global__ __launch_bounds__(1024) void dwconv2d_wreduce_kernel(const float* __restrict__ part,
                                                                 int nblk, int C, int NV,
                                                                 float* __restrict__ dw,
@@ -353,6 +457,26 @@ extern "C" int s2t_dwconv2d_nhwc_wgrad(const float* x, const float* dy, int N, i
   const int nparts = (W + RWO - 1) / RWO, nrr = (H + RRT - 1) / RRT;
   // (the workspace is sized for (H + 7) / 8 partial blocks per (n, c-tile): holds for W <= 98)
   constexpr int CPB = 256 / RCT;
+  static int ring = -1;      // S2T_DWCONV_WGRAD_RING=0: the roll kernel's MODE 2
+  if (ring < 0) { const char* e = getenv("S2T_DWCONV_WGRAD_RING"); ring = e ? atoi(e) : 1; }
+  if (KH == 7 && KW == 7 && ring) {
+    // rows per thread: the 2 workgroups per CU that fit (210 VGPRs) in ONE round where the map is
+    // tall enough (each thread pays KH - 1 extra row steps, so not below 24 rows)
+    const long per_row = (long)nparts * N * ((C + RCT - 1) / RCT);   // thread groups per row range
+    const int nr = std::max(1, (int)((512L * CPB) / per_row));
+    const int rrt = std::max(24, (H + nr - 1) / nr);
+    const int nrr2 = (H + rrt - 1) / rrt;
+    if ((nparts * nrr2 + CPB - 1) / CPB <= (H + 7) / 8) {
+      dim3 gr((nparts * nrr2 + CPB - 1) / CPB, N, (C + RCT - 1) / RCT);
+      hipLaunchKernelGGL((dwconv2d_wgrad_ring_kernel<7, 7, 2>), gr, dim3(256), 0, st, x, dy, N, H, W, C,
+                         nparts, nrr2, rrt, workspace);
+      S2T_CHECK_LAUNCH();
+      hipLaunchKernelGGL(dwconv2d_wreduce_kernel, dim3((C + 63) / 64, KH * KW + 1), dim3(1024), 0, st,
+                         workspace, (int)(gr.x * gr.y), C, KH * KW + 1, dw, db);
+      S2T_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   if (KH == 7 && KW == 7 && (nparts * nrr + CPB - 1) / CPB <= (H + 7) / 8) {
     dim3 gr((nparts * nrr + CPB - 1) / CPB, N, (C + RCT - 1) / RCT);
     const float* nf = nullptr;

@@ -19,6 +19,9 @@ KERNELS = [
     ("x3p_db_kernel", "s2t_gemm_x3p", True), ("x3p_kernel", "s2t_gemm_x3p", True),
     ("x3p_split_kernel", "s2t_x3p_split", True),
     ("dwconv2d_roll_kernel<7, 7, 2>", "s2t_dwconv2d_nhwc_wgrad", True),
+    ("dwconv2d_wgrad_ring_kernel", "s2t_dwconv2d_nhwc_wgrad", True),
+    ("gemm_tn_grouped_w_kernel", "s2t_gemm_tn_grouped", True), ("gemm_tn_w_kernel", "s2t_gemm_f32", True),
+    ("x3p_dma_kernel", "s2t_gemm_x3p", True),
     ("dwconv2d_roll_kernel", "s2t_dwconv2d_nhwc_fwd", True),
     ("attn_fwd_mfma_kernel", "s2t_relpos_attn_fwd", True), ("attn_fwd_kernel", "s2t_relpos_attn_fwd", True),
     ("attn_bwd_q", "s2t_relpos_attn_bwd", True), ("attn_bwd_k", "s2t_relpos_attn_bwd", False),
