@@ -334,6 +334,12 @@ int s2t_gemm_f32_tiled(int mode, const float* A, long lda, const float* B, long 
  * pieces, six v_mfma_f32_32x32x16_bf16 products per 16-deep step, fp32 accumulation (fp32-level
  * error); 0 = v_mfma_f32_32x32x2_f32.  set >= 0 selects, set < 0 queries; returns the mode. */
 int s2t_tn_x3(int set);
+/* Kernel form of the bf16-split TN products (round 5): 1 (default, or S2T_TN_W=1) = wave-specialised
+ * 128x128 / 128x192 / 192x128 tiles (producer waves load 16-byte runs and split, consumer waves run
+ * the MFMAs; aligned non-symmetric problems: s2t_gemm_f32 mode 2, s2t_gemm_tn_grouped, and
+ * s2t_conv3x3_gemm mode 2 with its implicit patch operand); 0 = the 64x64 form.  Same arithmetic,
+ * different summation order.  set >= 0 selects, set < 0 queries; returns the form. */
+int s2t_tn_w(int set);
 /* the same switch for the NT / NN products of s2t_gemm_f32 (default 1) */
 int s2t_nn_x3(int set);
 

@@ -341,7 +341,7 @@ struct TnwUnit {           // a producer's unit: four columns x eight contractio
   int a, kg;
   bool valid, colok, isA;
 };
-template <int MI, int NJ, int PRO>
+template <int MI, int NJ, int PRO, bool PATCH = false>
 __device__ __forceinline__ void tn_w_body(const GemmArgs& g, const unsigned bid, unsigned char* sm) {
   constexpr int BM = 64 * MI, BN = 64 * NJ, BK = 32;
   constexpr int IMG_A = BM * BK * 6, IMG_B = BN * BK * 6, BUF = IMG_A + IMG_B;
@@ -377,7 +377,9 @@ __device__ __forceinline__ void tn_w_body(const GemmArgs& g, const unsigned bid,
     const int col = (t.isA ? m0 : n0) + 4 * mq;
     t.colok = col < (t.isA ? g.M : g.N);                  // (column counts are multiples of 4)
     t.ld = t.isA ? g.lda : g.ldb;
-    t.src = (t.isA ? g.A : g.B) + (t.colok ? col : 0);
+    // PATCH: B is the implicit patch matrix of g.pt (row k = output pixel, 9C columns in three runs
+    // of 3C contiguous floats: a column quad never straddles a run, seg % 4 == 0)
+    t.src = (t.isA ? g.A : g.B) + (t.colok ? ((PATCH && !t.isA) ? patch_col(g.pt, col) : col) : 0);
     t.kg = kg;
     t.a = mq & 7;
     t.dst = (unsigned)((t.isA ? 0 : IMG_A) + (((mq >> 3) * 2 + (kg >> 1)) * 3) * 1024 + (kg & 1) * 512);
@@ -389,9 +391,32 @@ __device__ __forceinline__ void tn_w_body(const GemmArgs& g, const unsigned bid,
 #pragma unroll
     for (int j = 0; j < NSLOT; ++j)
       if (un[j].valid) {
+        if (PATCH && !un[j].isA) {
+          // the unit's eight consecutive output pixels: one (image, row, column) decomposition, then
+          // steps of one pixel; pixels past the slice's end repeat its last one (zeroed in store)
+          int k = min(k0 + 8 * un[j].kg, kend - 1);
+          const int rows = g.pt.hw / g.pt.wo;
+          int b = k / g.pt.hw, q = k - b * g.pt.hw, ho = q / g.pt.wo, wo = q - ho * g.pt.wo;
+          int off = b * g.pt.sb + ho * g.pt.sh + wo * g.pt.sw;
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-          r[j][e] = *reinterpret_cast<const f32x4_t*>(un[j].src + (long)min(k0 + 8 * un[j].kg + e, kend - 1) * un[j].ld);
+          for (int e = 0; e < 8; ++e) {
+            r[j][e] = *reinterpret_cast<const f32x4_t*>(un[j].src + off);
+            if (k + 1 < kend) {
+              ++k;
+              if (++wo == g.pt.wo) {
+                wo = 0;
+                off += g.pt.sh - (g.pt.wo - 1) * g.pt.sw;
+                if (++ho == rows) { ho = 0; off += g.pt.sb - rows * g.pt.sh; }
+              } else {
+                off += g.pt.sw;
+              }
+            }
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            r[j][e] = *reinterpret_cast<const f32x4_t*>(un[j].src + (long)min(k0 + 8 * un[j].kg + e, kend - 1) * un[j].ld);
+        }
       }
   };
   // (columns past M / N need no zeroing: they only reach output rows / columns that are never
@@ -513,11 +538,11 @@ __device__ __forceinline__ void tn_w_body(const GemmArgs& g, const unsigned bid,
     }
 }
 // tile shape of a problem on the W form: 0 = 128 x 128, 1 = 128 x 192, 2 = 192 x 128
-template <int PRO>
+template <int PRO, bool PATCH = false>
 __device__ __forceinline__ void tn_w_shape(const GemmArgs& g, int shape, unsigned bid, unsigned char* sm) {
-  if (shape == 1) tn_w_body<2, 3, PRO>(g, bid, sm);
-  else if (shape == 2) tn_w_body<3, 2, PRO>(g, bid, sm);
-  else tn_w_body<2, 2, PRO>(g, bid, sm);
+  if (shape == 1) tn_w_body<2, 3, PRO, PATCH>(g, bid, sm);
+  else if (shape == 2) tn_w_body<3, 2, PRO, PATCH>(g, bid, sm);
+  else tn_w_body<2, 2, PRO, PATCH>(g, bid, sm);
 }
 constexpr int TNW_LDS = 2 * (128 + 192) * 32 * 6;   // 120 KB: the widest shape's two buffers
 constexpr int TNW_LDS0 = 2 * (128 + 128) * 32 * 6;  // 96 KB: 128 x 128 tiles
@@ -799,6 +824,11 @@ __global__ __launch_bounds__(512) void gemm_tn_w_kernel(GemmArgs g, int shape) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char tnw_sm[];
   tn_w_shape<PRO>(g, shape, blockIdx.x, tnw_sm);
 }
+// the implicit-patch form: B = the 3x3 patch matrix of a channel-last map (conv weight gradient)
+__global__ __launch_bounds__(512) void gemm_tn_w_patch_kernel(GemmArgs g, int shape) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char tnw_sm[];
+  tn_w_shape<ACT_NONE, true>(g, shape, blockIdx.x, tnw_sm);
+}
 
 // Weight-gradient contractions on the bf16 matrix cores (three-way exact split, six products:
 // fp32-level error, tests/test_gpu_gemm.py) -- on by default: in the training step the TN GEMMs
@@ -823,10 +853,10 @@ static bool tn_p3() {
 }
 // S2T_TN_W=0: weight gradients on the 64 x 64 form instead of the wave-specialised "W" form;
 // S2T_TN_W_BLOCKS: workgroups a W launch aims at (one is resident per CU)
+static int g_tn_w = -1;
 static bool tn_w() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("S2T_TN_W"); v = e ? atoi(e) : 1; }
-  return v == 1;
+  if (g_tn_w < 0) { const char* e = getenv("S2T_TN_W"); g_tn_w = e ? atoi(e) : 1; }
+  return g_tn_w == 1;
 }
 static long tn_w_blocks() {
   static long v = -1;
@@ -1110,6 +1140,22 @@ extern "C" int s2t_conv3x3_gemm(int mode, const float* x, int B, int H, int W, i
   }
   GemmArgs g{w2_or_g, CO, x, 0, out, K9, CO, K9, (int)R, nullptr, nullptr, 0, nullptr, 0, 0, 0,
              0, db, 0, 0, 0, 0, 0, 0, 1.f, 0, 0, 0, pt};
+  { const char* e = getenv("S2T_GEMM_DEBUG"); g.debug = e ? atoi(e) : 0; }
+  if (tn_w() && tn_x3() && tn_p3() && CO >= 64 && K9 >= 128) {   // the wave-specialised form (tn_w_body)
+    const int shape = tn_w_shape_of(g.M, g.N, g.tiles_m, g.tiles_n);
+    const long tiles = (long)g.tiles_m * g.tiles_n;
+    int splits = (int)((tn_w_blocks() + tiles - 1) / tiles);
+    splits = std::max(1, std::min(splits, (g.K + 2 * KR - 1) / (2 * KR)));
+    int kper = (g.K + splits - 1) / splits;
+    kper = ((kper + KR - 1) / KR) * KR;
+    g.kper = kper;
+    g.splits = (g.K + kper - 1) / kper;
+    const int grid = (int)(8 * tiles * ((g.splits + 7) / 8));
+    static const bool ok = tn_w_prepare(gemm_tn_w_patch_kernel);
+    if (!ok) return -3;
+    hipLaunchKernelGGL(gemm_tn_w_patch_kernel, dim3(grid), dim3(512), shape ? TNW_LDS : TNW_LDS0, st, g, shape);
+    return (int)hipGetLastError();
+  }
   g.tiles_m = (CO + 63) / 64;
   g.tiles_n = (K9 + 63) / 64;
   const long tiles = (long)g.tiles_m * g.tiles_n;
@@ -1125,6 +1171,10 @@ extern "C" int s2t_conv3x3_gemm(int mode, const float* x, int B, int H, int W, i
   return (int)hipGetLastError();
 }
 
+extern "C" int s2t_tn_w(int set) {
+  if (set >= 0) g_tn_w = set ? 1 : 0;
+  return tn_w() ? 1 : 0;
+}
 extern "C" int s2t_tn_x3(int set) {
   if (set >= 0) g_tn_x3 = set ? 1 : 0;
   return tn_x3() ? 1 : 0;

@@ -328,8 +328,7 @@ def test_tn_wave_specialised_form(dev, R, Nf, Mf, pro):
     """The round-5 weight-gradient form (producer waves split, consumer waves multiply; tiles
     128 x 192 / 192 x 128 / 128 x 128 by the output's shape): ragged contraction lengths, outputs that
     are no multiple of a tile, the Swoosh prologue on x and the bias column sums, against fp64, and
-    against the 64 x 64 form through the same entry (S2T_TN_W is read once per process, so the other
-    form is reached with an unaligned view: a leading dimension that is no multiple of 4)."""
+    against the 64 x 64 form through the same entry (s2t_tn_w selects the form)."""
     from speech2text_amd import _native as Nt
     L = Nt.lib()
     gen = torch.Generator().manual_seed(R + pro)
@@ -342,24 +341,25 @@ def test_tn_wave_specialised_form(dev, R, Nf, Mf, pro):
     ref = g.double().t() @ xa
     refc = g.double().sum(0)
 
-    def run(gv, xv):
+    def run():
         dW = torch.full((Nf, Mf), 0.25, device=dev)
         db = torch.full((Nf,), 0.25, device=dev)
-        rc = L.s2t_gemm_f32(2, Nt.fp(gv), gv.stride(0), Nt.fp(xv), xv.stride(0), Nt.fp(dW), Mf, Nf, Mf, R,
+        rc = L.s2t_gemm_f32(2, Nt.fp(g), Nf, Nt.fp(x), Mf, Nt.fp(dW), Mf, Nf, Mf, R,
                             None, None, 0, None, 0, 0, 0, pro, Nt.fp(db), 0, Nt.stream())
         assert rc == 0
         return dW.double() - 0.25, db.double() - 0.25
-    dW, db = run(g, x)
+    was = L.s2t_tn_w(-1)
+    try:
+        assert L.s2t_tn_w(1) == 1
+        dW, db = run()
+        assert L.s2t_tn_w(0) == 0
+        dW2, db2 = run()
+    finally:
+        L.s2t_tn_w(was)
     scale = ref.abs().max().item()
-    assert (dW - ref).abs().max().item() / scale < 2e-6
-    assert (db - refc).abs().max().item() / refc.abs().max().item() < 2e-6
-    # the other form: the same operands inside buffers whose rows are 4 k + 1 floats long
-    gp = torch.zeros(R, Nf + 1, device=dev)
-    gp[:, :Nf] = g
-    xp = torch.zeros(R, Mf + 1, device=dev)
-    xp[:, :Mf] = x
-    dW2, db2 = run(gp[:, :Nf], xp[:, :Mf])
-    assert (dW2 - ref).abs().max().item() / scale < 2e-6
+    for a, c in ((dW, db), (dW2, db2)):
+        assert (a - ref).abs().max().item() / scale < 2e-6
+        assert (c - refc).abs().max().item() / refc.abs().max().item() < 2e-6
     assert (dW - dW2).abs().max().item() / scale < 2e-6
 
 
