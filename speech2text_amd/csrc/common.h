@@ -8,6 +8,21 @@
 // (csrc/streams.hip: s2t_prof_pair_arm)
 extern thread_local hipEvent_t s2t_prof_start, s2t_prof_stop;
 
+// Diagnostic switches that make a kernel compute WRONG results on purpose (timing ablations:
+// S2T_GEMM_DEBUG, S2T_X3P_ABL, S2T_X3Q_ABL) are honoured only when S2T_DEBUG_KERNELS=1 is set as
+// well: a stray variable in a production environment must not change any product.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+static inline int s2t_debug_env(const char* name) {
+  const char* e = getenv(name);
+  if (!e || atoi(e) == 0) return 0;
+  const char* gate = getenv("S2T_DEBUG_KERNELS");
+  if (gate && strcmp(gate, "1") == 0) return atoi(e);
+  fprintf(stderr, "[s2t] %s=%s ignored: ablation switches need S2T_DEBUG_KERNELS=1\n", name, e);
+  return 0;
+}
+
 #define S2T_WAVE 64
 #define S2T_NEG_INF (-__builtin_huge_valf())
 

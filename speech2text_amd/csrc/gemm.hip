@@ -892,7 +892,7 @@ int launch(GemmArgs& g, int splits, hipStream_t st) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   g.tiles_m = (g.M + BM - 1) / BM;
   g.tiles_n = (g.N + BN - 1) / BN;
-  { const char* e = getenv("S2T_GEMM_DEBUG"); g.debug = e ? atoi(e) : 0; }
+  { static const int dbg = s2t_debug_env("S2T_GEMM_DEBUG"); g.debug = dbg; }
   const int total = g.tiles_m * g.tiles_n;
   g.splits = splits;
   const int grid = MODE == MODE_TN ? 8 * total * ((splits + 7) / 8) : ((total + 7) / 8) * 8;
@@ -957,7 +957,7 @@ int dispatch(GemmArgs& g, hipStream_t st) {
     if (tn_w() && tn_x3() && tn_p3() && !g.sym_cg && force <= 0 && !((g.M | g.N | g.lda | g.ldb) & 3) &&
         !((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.B)) & 15)) {
       const int shape = tn_w_shape_of(g.M, g.N, g.tiles_m, g.tiles_n);
-      { const char* e = getenv("S2T_GEMM_DEBUG"); g.debug = e ? atoi(e) : 0; }
+      { static const int dbg = s2t_debug_env("S2T_GEMM_DEBUG"); g.debug = dbg; }
       const long tiles = (long)g.tiles_m * g.tiles_n;
       const long target = user_blocks > 0 ? user_blocks : tn_w_blocks();
       int splits = (int)((target + tiles - 1) / tiles);
@@ -1140,7 +1140,7 @@ extern "C" int s2t_conv3x3_gemm(int mode, const float* x, int B, int H, int W, i
   }
   GemmArgs g{w2_or_g, CO, x, 0, out, K9, CO, K9, (int)R, nullptr, nullptr, 0, nullptr, 0, 0, 0,
              0, db, 0, 0, 0, 0, 0, 0, 1.f, 0, 0, 0, pt};
-  { const char* e = getenv("S2T_GEMM_DEBUG"); g.debug = e ? atoi(e) : 0; }
+  { static const int dbg = s2t_debug_env("S2T_GEMM_DEBUG"); g.debug = dbg; }
   if (tn_w() && tn_x3() && tn_p3() && CO >= 64 && K9 >= 128) {   // the wave-specialised form (tn_w_body)
     const int shape = tn_w_shape_of(g.M, g.N, g.tiles_m, g.tiles_n);
     const long tiles = (long)g.tiles_m * g.tiles_n;
@@ -1220,7 +1220,7 @@ extern "C" int s2t_gemm_tn_grouped(int n, const S2tTnProblem* probs, void* strea
   }
   for (int base = 0; base < n && useq; base += MAXG) {
     TnGroup grp;
-    { const char* e = getenv("S2T_GEMM_DEBUG"); grp.debug = e ? atoi(e) : 0; }
+    { static const int dbg = s2t_debug_env("S2T_GEMM_DEBUG"); grp.debug = dbg; }
     grp.n = std::min(MAXG, n - base);
     long total_tiles = 0;
     for (int i = 0; i < grp.n; ++i) {
@@ -1259,7 +1259,7 @@ extern "C" int s2t_gemm_tn_grouped(int n, const S2tTnProblem* probs, void* strea
   if (useq) return 0;
   for (int base = 0; base < n; base += MAXG) {
     TnGroup grp;
-    { const char* e = getenv("S2T_GEMM_DEBUG"); grp.debug = e ? atoi(e) : 0; }
+    { static const int dbg = s2t_debug_env("S2T_GEMM_DEBUG"); grp.debug = dbg; }
     grp.n = std::min(MAXG, n - base);
     long total_tiles = 0;
     for (int i = 0; i < grp.n; ++i) {

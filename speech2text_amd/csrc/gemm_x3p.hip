@@ -1432,7 +1432,7 @@ void launch_x3p(X3P& g, hipStream_t st) {
     const int cap = 256 * per_cu;
     const int grid = std::min(((total + 7) / 8) * 8, cap);
     static int abl = -1;       // S2T_X3P_ABL: ablation bit mask (diagnostics)
-    if (abl < 0) { const char* e = getenv("S2T_X3P_ABL"); abl = e ? atoi(e) : 0; }
+    if (abl < 0) abl = s2t_debug_env("S2T_X3P_ABL");
     static int diag = -1;      // S2T_X3P_DIAG=1: the instrumented build (tools/x3p_stamps.py)
     if (diag < 0) { const char* e = getenv("S2T_X3P_DIAG"); diag = e ? atoi(e) : 0; }
     const bool drip = g.drip == 1 && ((g.K + 15) >> 4) >= 2 * TM * TN && grid < total;
@@ -1505,7 +1505,7 @@ int s2t_x3p_split(const float* base, const void* tab, int n, int total_blocks, u
   return 0;
 }
 
-static float* g_colstats = nullptr;      // armed by s2t_gemm_x3p_stats for the one launch it makes
+static thread_local float* g_colstats = nullptr;      // (per thread: ctypes releases the GIL) armed by s2t_gemm_x3p_stats for the one launch it makes
 struct BalArm {
   const float* stats = nullptr;
   float n = 0.f, min_mean = 0.f, max_mean = 0.f, min_rms = 0.f, max_rms = 0.f, gs = 0.f;
@@ -1618,7 +1618,7 @@ int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int 
     const int totalq = g.tiles_m * g.tiles_n;
     const int gridq = std::min(((totalq + 7) / 8) * 8, 256);
     static int qabl = -1;      // S2T_X3Q_ABL: ablation mask (diagnostics)
-    if (qabl < 0) { const char* e = getenv("S2T_X3Q_ABL"); qabl = e ? atoi(e) : 0; }
+    if (qabl < 0) qabl = s2t_debug_env("S2T_X3Q_ABL");
 #define X3Q_LAUNCH(A)                                                                            \
   {                                                                                              \
     static bool attr_ = false;                                                                   \

@@ -94,6 +94,12 @@ __global__ __launch_bounds__(256) void scaled_adam_coef_kernel(CoefArgs A) {
       A.scale_grads[(long)(A.step % A.size_update_period) * ng + (s - A.seg_lo)] = 0.f;
       A.segc[(long)s * kSegC + 9] = 2.f;
     }
+    // the clipping threshold's window gets the previous step's norm again, not a stale entry from
+    // one period ago (the step count advances on a dropped step, as on the host path)
+    if (tid == 0 && A.clipping_scale > 0.f && A.step > 0) {
+      const int period = A.clipping_update_period;
+      A.model_norms[A.step % period] = A.model_norms[(A.step - 1) % period];
+    }
     return;
   }
   // ---- per-tensor sums (each thread walks its tensors' chunks in order)

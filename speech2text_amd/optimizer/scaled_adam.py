@@ -106,7 +106,17 @@ class ScaledAdam(Optimizer):
         if st.flat_p.is_cuda:
             self._step_hip()
         elif self.skip_flag is not None and float(self.skip_flag) != 0.0:
-            if self.zero_grad_in_step:       # dropped step (ddp.py), host form: CPU tensors only
+            # dropped step (ddp.py), host form (CPU tensors only).  As on the GPU path the step
+            # count (bias correction, LR schedule position) advances, parameters and moments stay,
+            # and the clipping window repeats the previous norm.
+            for s in self._gstate:
+                k = s["step"]
+                mn = s.get("model_norms")
+                if mn is not None and k > 0:
+                    P = mn.numel()
+                    mn[k % P] = mn[(k - 1) % P]
+                s["step"] = k + 1
+            if self.zero_grad_in_step:
                 st.flat_g.zero_()
         else:
             self._step_torch()

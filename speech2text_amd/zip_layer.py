@@ -79,14 +79,16 @@ _PIN_ATTRS = os.environ.get("S2T_PIN_ATTRS", "1") == "1"
 
 
 def _pin_attrs(root):
-    """Parameters, buffers and submodules of `root`'s tree also become plain instance attributes:
+    """Parameters and submodules of `root`'s tree also become plain instance attributes:
     nn.Module finds them through its Python-level __getattr__ (three dict probes, ~0.7 us), and a
     step of 12 layers asks 3 800 times.  Safe under this framework's standing invariant that
     parameter OBJECTS never change after setup (FlatStore and the fused optimizers rebind
-    `.data` only); Module.__setattr__ drops the shortcut if a name is ever re-assigned."""
+    `.data` only); Module.__setattr__ drops the shortcut if a Parameter / Module name is
+    re-assigned.  Buffers are NOT pinned: re-assigning one (or Module._apply replacing it) does not
+    go through that path and would leave a stale shadow."""
     for m in root.modules():
         d = m.__dict__
-        for table in (m._parameters, m._buffers, m._modules):
+        for table in (m._parameters, m._modules):
             for name, v in table.items():
                 if v is not None and name not in d:
                     d[name] = v

@@ -1,4 +1,5 @@
 #!/bin/bash
+export S2T_DEBUG_KERNELS=1   # the ablation switches are ignored without it
 # ablations of the x3p main loop on one shape (inside gpurun): bash tools/x3p_abl.sh M N K tile [list]
 LIST=${5:-"0 1 2 3 4 7 8 16 17 24 23"}
 for a in $LIST; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+export S2T_DEBUG_KERNELS=1   # the ablation switches are ignored without it
 # GPU: ablation builds of the producer / consumer GEMM (wrong results; timing only):
 #   bash tools/x3q_abl.sh
 cd $GRAFT_REPO_ROOT
