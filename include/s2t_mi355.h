@@ -621,35 +621,6 @@ int s2t_lnlstm_bwd(const float* wp, const float* g_gamma, const float* g_beta,
                    float* dgx, float* d_g_gamma, float* d_g_beta, float* d_c_gamma,
                    float* d_c_beta, void* stream);
 
-/* ---- fp32 GEMM on the bf16 matrix cores (csrc/gemm_x3.hip): every fp32 value is split exactly
- * into three bf16 pieces and the product evaluated as the six piece products of weight <= 2 with
- * fp32 accumulation -- fp32-level error at 6/16 of the f32-MFMA cost.  Serves the forward
- * (y = x W^T) and data-gradient (dx = g W = g (W^T)^T) products of every nn.Linear.
- * s2t_split_planes: src[n] fp32 -> planes[p * plane + i], p = 0..2 (bf16 bits), n % 4 == 0.
- * s2t_split_planes_t: the planes of the TRANSPOSES of ntab row-major matrices of one flat buffer
- *   (tab: DEVICE array of {long off; int R, C, tile_begin}).
- * s2t_gemm_x3_nt: C[M,N] = A[M,K] . W[N,K]^T (+ bias[N]) (+ beta R[M,N]); A fp32 (split while
- *   staged), W = planes (row n of piece p at W + p * plane + n * ldw); K % 8 == 0. */
-int s2t_split_planes(const float* src, long n, unsigned short* planes, long plane, void* stream);
-int s2t_split_planes_t(const float* src, const void* tab, int ntab, int total_tiles,
-                       unsigned short* planes_t, long plane, void* stream);
-int s2t_gemm_x3_nt(const float* A, long lda, const unsigned short* W, long ldw, long plane,
-                   float* C, long ldc, int M, int N, int K, const float* bias, const float* resid,
-                   long ldr, float beta, void* stream);
-
-/* Pipelined form (csrc/gemm_x3f.hip).  s2t_split_planes_frag writes the three bf16 pieces of the
- * logical matrix Bm[n][k] (= src[n*ld + k], or src[k*ld + n] when transposed) in FRAGMENT-MAJOR order
- * [N/32][K/16][3][64 lanes][8]: the 1 KB one v_mfma_f32_32x32x16_bf16 B operand needs is one
- * contiguous piece (N % 32 == 0, K % 16 == 0, else -2; dst holds s2t_split_planes_frag_elems(N,K)
- * bf16 = 3 N K).  s2t_gemm_x3f_nt: C[M,N] = A[M,K] . Bm^T (+ bias[N]) (+ beta R[M,N]); tnw = column
- * tiles per wave (block tile 128 x 64 tnw), 0 = chosen from the shape. */
-long s2t_split_planes_frag_elems(int N, int K);
-int s2t_split_planes_frag(const float* src, long ld, int N, int K, int transposed,
-                          unsigned short* dst, void* stream);
-int s2t_gemm_x3f_nt(const float* A, long lda, const unsigned short* Bf, float* C, long ldc, int M,
-                    int N, int K, const float* bias, const float* resid, long ldr, float beta,
-                    int tnw, void* stream);
-
 /* ---- StatelessPredictor: embedding + depthwise context convolution in one pass
  * (reference model/predictor/stateless_predictor.py:27-105: nn.Embedding -> nn.Conv1d(D, D, K,
  * groups=D, bias=False) on the blank-left-padded labels).  tokens (B,L) int32 (values clamped to
@@ -694,15 +665,6 @@ int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int 
                  int M, const float* bias, const float* resid, long ldr, const float* act_src,
                  long ld_act, int act_kind, float* C2, long ldc2, int act2, const float* resid_b,
                  long ldrb, int tile, void* stream);
-/* the same product that also ADDS the column sums / sums of squares of C (as stored) into
- * colstats[0..N) / colstats[1024..1024+N): the statistics a Balancer on that tensor needs in
- * backward (s2t_balancer_apply), taken where the tensor is produced.  colstats: 2048 floats, zeroed
- * by the caller; N <= 1024. */
-int s2t_gemm_x3p_stats(const float* A, long lda, const unsigned short* Bp, int N, int K, float* C,
-                       long ldc, int M, const float* bias, const float* resid, long ldr,
-                       const float* act_src, long ld_act, int act_kind, float* C2, long ldc2, int act2,
-                       const float* resid_b, long ldrb, int tile, float* colstats, void* stream);
-
 /* s2t_gemm_x3p for a data gradient through an activation with the Balancer on the activation's input
  * in the epilogue (the hidden Balancer of FeedforwardModule / ConvolutionModule / ConvNeXt,
  * model/encoder/zipformer.py:2372-2378, 2643-2695, model/layer/subsampling.py:106-132; update rule

@@ -31,7 +31,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// (x0, x1) -> three packed bf16 pairs, exact: x = p0 + p1 + p2 to 24 bits (gemm_x3.hip)
+// (x0, x1) -> three packed bf16 pairs, exact: x = p0 + p1 + p2 to 24 bits
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& p0, unsigned& p1,
                                            unsigned& p2) {
   f32x2 x = {x0, x1};
@@ -550,7 +550,7 @@ constexpr int TNW_LDS0 = 2 * (128 + 128) * 32 * 6;  // 96 KB: 128 x 128 tiles
 // X3 (TN only): the contraction runs on the bf16 matrix cores -- both operand fragments are split
 // exactly into three bf16 pieces when a wave reads them from LDS (8 k-strided reads per
 // fragment: the tiles are k-major) and every 16-deep step is six v_mfma_f32_32x32x16_bf16 products
-// (gemm_x3.hip: fp32-level error); 6 x 8 passes instead of 8 x 16 passes of the f32 MFMA.
+// (fp32-level error); 6 x 8 passes instead of 8 x 16 passes of the f32 MFMA.
 template <int TM, int TN, int MODE, int PRO, bool X3 = false, bool PATCH = false, bool P3 = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, const unsigned bid) {
   if constexpr (P3 && X3 && MODE == MODE_TN && !PATCH) {

@@ -127,8 +127,6 @@ struct X3P {
   unsigned long long* stamps; // diagnostics (s2t_x3p_debug_stamps): [block][8] s_memtime stamps, or NULL
   int drip;                   // 1: epilogue of tile t stored in slices under tile t+1 (x3p_db_kernel DRIP)
   int stagger;                // > 0: workgroup slot s of a CU starts its k loop s * stagger * 64 cycles late
-  float* colstats;            // [2][1024] or NULL: += column sums / sums of squares of C (the Balancer's
-                              // statistics of the tensor this product writes; N <= 1024)
   // Balancer update in the epilogue (s2t_gemm_x3p_bal): C = act'(S) (A Bm^T) is the gradient w.r.t. S
   // coming through the activation, and the Balancer on S (scaling.py:741-789 in closed form, as
   // zip_elem.hip balancer_apply_fused_kernel) adds |C| (a[c] + b[c] S): bal_stats = [2][1024] column
@@ -367,43 +365,6 @@ __device__ __forceinline__ void x3p_epilogue(const X3P& g, f32x16 (&acc)[TM][TN]
           x3p_epi_xform<BAL>(g, acc[i][j], scr, o, bqj, h, lane, balj);
           x3p_epi_store<CMAP>(g, rs, acc[i][j], o, i, j, h, m0, n0, wrb, wcb, lane);
         }
-      if (g.colstats) {
-        // column statistics of C (s2t_gemm_x3p_stats): the final values of column block j sit in the
-        // accumulator registers in row-piece layout -- this lane's column quad over its rows, summed
-        // over the 8 lanes that share the quad, one atomic pair per column and wave
-        const int er = lane >> 3, ec = (lane & 7) * 4;
-        float sm[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-              const bool rok = m0 + 32 * (wrb + i) + 16 * h + er + 8 * q < g.M;
-#pragma unroll
-              for (int c = 0; c < 4; ++c) {
-                const float v = rok ? acc[i][j][8 * h + 4 * q + c] : 0.f;
-                sm[c] += v;
-                sq[c] = fmaf(v, v, sq[c]);
-              }
-            }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-#pragma unroll
-          for (int d = 8; d < 64; d <<= 1) {
-            sm[c] += __shfl_xor(sm[c], d);
-            sq[c] += __shfl_xor(sq[c], d);
-          }
-        }
-        const int col = n0 + 32 * (wcb + j) + ec;
-        if (er == 0 && col < g.N) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            atomicAdd(g.colstats + col + c, sm[c]);
-            atomicAdd(g.colstats + 1024 + col + c, sq[c]);
-          }
-        }
-      }
     }
     return;
   }
@@ -420,44 +381,6 @@ __device__ __forceinline__ void x3p_epilogue(const X3P& g, f32x16 (&acc)[TM][TN]
 #pragma unroll
     for (int t = 0; t < 2 * TN; ++t)
       x3p_epi_store(g, rs, acc[i][t / 2], ops[t], i, t / 2, t & 1, m0, n0, wrb, wcb, lane);
-    if (g.colstats) {
-      // column statistics of C: this lane's column quad over its 4 rows of the row block (the
-      // final values sit in the accumulator registers in row-piece layout), summed over the 8
-      // lanes that share the quad, one atomic pair per column and wave
-      const int er = lane >> 3, ec = (lane & 7) * 4;
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        float sm[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-          for (int q = 0; q < 2; ++q) {
-            const bool rok = m0 + 32 * (wrb + i) + 16 * h + er + 8 * q < g.M;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              const float v = rok ? acc[i][j][8 * h + 4 * q + c] : 0.f;
-              sm[c] += v;
-              sq[c] = fmaf(v, v, sq[c]);
-            }
-          }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-#pragma unroll
-          for (int d = 8; d < 64; d <<= 1) {
-            sm[c] += __shfl_xor(sm[c], d);
-            sq[c] += __shfl_xor(sq[c], d);
-          }
-        }
-        const int col = n0 + 32 * (wcb + j) + ec;
-        if (er == 0 && col < g.N) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            atomicAdd(g.colstats + col + c, sm[c]);
-            atomicAdd(g.colstats + 1024 + col + c, sq[c]);
-          }
-        }
-      }
-    }
     __builtin_amdgcn_sched_barrier(0);               // (the next row block's loads stay behind these stores)
   }
 }
@@ -1072,280 +995,6 @@ __global__ __launch_bounds__(256, WPC) void x3p_dma_kernel(X3P g) {
 #undef XD_TERM
 }
 
-// ---- producer / consumer form (one workgroup of 8 waves per CU, persistent; 128 x 128 tiles).
-// Waves 0-3 (CONSUMERS, 2 x 2, 64 x 64 each) only read fragments from LDS, issue MFMAs and, at the
-// end of a tile, drop their sums into a 64 KB LDS tile E: they never touch global memory.  Waves
-// 4-7 (PRODUCERS) move everything: stage s (16 deep) is requested Q_P steps before it is split /
-// copied into slot s % 4 of an LDS ring, which happens two steps before the consumers multiply it
-// (they read its fragments one step ahead, into the second fragment set, under the current
-// stage's MFMAs); and the previous tile's E leaves in Q_NQ chunks of 8 KB, one per step, under
-// the next tile's stages (bias, act', residuals, second output: the same epilogue as above).
-// One barrier per step for all 8 waves; the stage sequence runs on across tiles.
-//   step S:  producers  write stage S+2 -> slot (S+2) % 4;  request stage S+2+Q_P;
-//                       operands of E chunk q requested, chunk q-1 finished and stored
-//            consumers  read fragments of stage S+1 (slot (S+1) % 4);  24 MFMAs on stage S;
-//                       last stage of a tile: sums -> E
-// Slot (S+2) % 4 was last read (stage S-2) during step S-3: free.  E is drained during the Q_NQ
-// + 1 steps after its tile ended and refilled nst steps after: K > 16 (Q_NQ + 1) is required.
-// EVERY memory operation of the producers' loop is unconditional (an idle chunk slot gets an
-// out-of-range buffer offset): with one of them inside a branch the compiler cannot count what is
-// in flight and waits for everything, i.e. for the stage it requested a moment ago.
-constexpr int Q_RING = 4, Q_P = 3, Q_NQ = 8;
-constexpr int Q_AST = 4 * 3 * 1024, Q_ST = 2 * Q_AST;          // A pieces + B pieces of a stage: 24 KB
-constexpr int Q_E = 128 * 128 * 4;                              // the finished tile, fp32 row-major
-constexpr int Q_SMEM = Q_RING * Q_ST + Q_E;                     // 160 KB
-
-// QABL (diagnostics, wrong results): 1 = no global loads inside the loop, 2 = no LDS stage writes,
-// 4 = no split arithmetic, 8 = no MFMAs, 16 = no epilogue work in the loop, 32 = no fragment reads
-template <int QABL = 0>
-__global__ __launch_bounds__(512, 1) void x3q_kernel(X3P g) {
-  extern __shared__ __attribute__((aligned(1024))) unsigned char qsm[];
-  float* const sE = reinterpret_cast<float*>(qsm + Q_RING * Q_ST);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int total = g.tiles_m * g.tiles_n;
-  const int per_xcd = (total + 7) / 8;
-  const int xcd = blockIdx.x & 7, stride = gridDim.x >> 3;
-  const int loc0 = blockIdx.x >> 3;
-  // this workgroup's tiles: loc0, loc0 + stride, ... below min(per_xcd, total - xcd * per_xcd)
-  const int lim = min(per_xcd, total - xcd * per_xcd);
-  if (loc0 >= lim) return;
-  const int ntile = (lim - loc0 + stride - 1) / stride;
-  const int nst = (g.K + 15) >> 4;
-  const int nsteps = ntile * nst;                     // stages of this workgroup, all tiles
-  x3p_stamp(g, 0);
-
-#define X3Q_BARRIER()                                                    \
-  if (!(QABL & 64)) {                                                    \
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");      \
-    __builtin_amdgcn_s_barrier();                                        \
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");      \
-  }
-
-  if (wave >= 4) {
-    // ------------------------------------------------------------------ producers
-    const int pt = tid - 256;
-    const int ar = (pt & 15) + 16 * (pt >> 5), akq = (pt >> 4) & 1, ak = 8 * akq;
-    const unsigned adst = (unsigned)((((ar >> 5) * 3) * 64 + akq * 32 + (ar & 31)) * 16);
-    int bseg[3], boff[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int idx = pt + 256 * i;
-      bseg[i] = idx / 192;
-      boff[i] = idx - bseg[i] * 192;
-    }
-    // load cursor: stage lk of tile lloc
-    int lloc = loc0, lk = 0;
-    const float* asrc;
-    const u32x4* bsrc[3];
-#define X3Q_TILE_ADDR()                                                                      \
-  {                                                                                          \
-    const int lin_ = xcd * per_xcd + lloc;                                                   \
-    const int tm_ = lin_ / g.tiles_n, tn_ = lin_ - tm_ * g.tiles_n;                          \
-    asrc = g.A + (long)min(tm_ * 128 + ar, g.M - 1) * g.lda + ak;                            \
-    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                          \
-      const int nt_ = min((tn_ * 128 >> 5) + bseg[i], g.NT - 1);                             \
-      bsrc[i] = reinterpret_cast<const u32x4*>(g.Bp + (long)nt_ * g.KB * 1536) + boff[i];    \
-    }                                                                                        \
-  }
-    X3Q_TILE_ADDR()
-    f32x4 ra[Q_P][2];
-    u32x4 rb[Q_P][3];
-    bool rv[Q_P];                                     // the A unit's k range lies inside K
-    // request the cursor's stage into set SET and advance the cursor (it stays on the last stage
-    // of the last tile: past the end that stage is simply requested again)
-#define X3Q_LOAD(SET)                                                                        \
-  {                                                                                          \
-    const bool v_ = 16 * lk + ak < g.K;                                                      \
-    gf32p p_ = (gf32p)(asrc + (v_ ? 16 * lk : 0));                                           \
-    ra[SET][0] = *reinterpret_cast<gf32x4p>(p_);                                             \
-    ra[SET][1] = *reinterpret_cast<gf32x4p>(p_ + 4);                                         \
-    _Pragma("unroll") for (int i = 0; i < 3; ++i) rb[SET][i] = ((gu32x4p)bsrc[i])[(long)lk * 192]; \
-    rv[SET] = v_;                                                                            \
-    if (lk + 1 < nst) ++lk;                                                                  \
-    else if (lloc + stride < lim) {                                                          \
-      lk = 0;                                                                                \
-      lloc += stride;                                                                        \
-      X3Q_TILE_ADDR()                                                                        \
-    }                                                                                        \
-  }
-    // ---- the epilogue's share of a step.  E chunk q = rows 16 q .. 16 q + 15 of the tile; a thread
-    // owns column quad c4 = pt & 31 of rows 16 q + 8 c + (pt >> 5), c = 0, 1.
-    const EpiRs rs = x3p_epi_rsrc(g);
-    const __amdgpu_buffer_rsrc_t rs_bias = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(g.bias), 0, g.bias ? g.N * 4 : 0, 0x00020000);
-    const int ec4 = pt & 31, erw = pt >> 5;
-    int ck = 0, cloc = loc0;                          // consume cursor (what the consumers multiply)
-    int em0 = 0, en0 = 0, eq = Q_NQ + 1;              // tile in E and the chunk whose OPERANDS are next
-    f32x4 eo[2][2];                                   // operands of the chunk being finished: [c][slot]
-    f32x4 ebq = {0.f, 0.f, 0.f, 0.f};
-    const f32x4 zq = {0.f, 0.f, 0.f, 0.f};
-    eo[0][0] = eo[0][1] = eo[1][0] = eo[1][1] = zq;
-#define X3Q_EPI()                                                                            \
-  {                                                                                          \
-    /* operands of chunk eq (requested first: the wait for them next step then leaves this   \
-       step's stores in flight); chunk eq - 1 finished below with last step's operands */    \
-    f32x4 no_[2][2];                                                                         \
-    const int col_ = en0 + 4 * ec4;                                                          \
-    _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                          \
-      const int row_ = em0 + 16 * eq + 8 * c + erw;                                          \
-      const bool ok_ = eq < Q_NQ && row_ < g.M && col_ < g.N;                                \
-      _Pragma("unroll") for (int k = 0; k < 2; ++k)                                          \
-        no_[c][k] = x3p_bload(rs.op[k], ok_ ? (unsigned)(row_ * (int)g.ldop[k] + col_) * 4u : kOob); \
-    }                                                                                        \
-    const f32x4 nb_ = x3p_bload(rs_bias, (eq < Q_NQ && col_ < g.N) ? (unsigned)col_ * 4u : kOob); \
-    _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                          \
-      const int qp_ = eq - 1;                                                                \
-      const int lr_ = 16 * (qp_ & (Q_NQ - 1)) + 8 * c + erw;                                 \
-      const int row_ = em0 + 16 * qp_ + 8 * c + erw;                                         \
-      const bool ok_ = qp_ >= 0 && qp_ < Q_NQ && row_ < g.M && col_ < g.N;                   \
-      f32x4 v = *reinterpret_cast<const f32x4*>(sE + lr_ * 128 + 4 * ec4);                   \
-      v += ebq;                                                                              \
-      _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                        \
-        const f32x4 x = eo[c][k];                                                            \
-        if (g.role[k] == 1) {                                                                \
-          v.x *= swoosh_deriv(x.x, g.act_kind);                                              \
-          v.y *= swoosh_deriv(x.y, g.act_kind);                                              \
-          v.z *= swoosh_deriv(x.z, g.act_kind);                                              \
-          v.w *= swoosh_deriv(x.w, g.act_kind);                                              \
-        } else if (g.role[k] == 2 || (g.role[k] == 3 && g.act2 != 3)) {                      \
-          v += x;                                                                            \
-        }                                                                                    \
-      }                                                                                      \
-      x3p_bstore(rs.c, ok_ ? (unsigned)(row_ * (int)g.ldc + col_) * 4u : kOob, v);           \
-      f32x4 u = v + (g.role[0] == 3 ? eo[c][0] : eo[c][1]);                                  \
-      if (g.act2 == 1 || g.act2 == 2)                                                        \
-        u = f32x4{swoosh(v.x, g.act2), swoosh(v.y, g.act2), swoosh(v.z, g.act2), swoosh(v.w, g.act2)}; \
-      x3p_bstore(rs.c2, ok_ ? (unsigned)(row_ * (int)g.ldc2 + col_) * 4u : kOob, u);         \
-      eo[c][0] = no_[c][0];                                                                  \
-      eo[c][1] = no_[c][1];                                                                  \
-    }                                                                                        \
-    ebq = nb_;                                                                               \
-    if (eq <= Q_NQ) ++eq;                                                                    \
-  }
-    // step: stage W (in set SET) -> LDS slot W % 4, then the set takes stage W + Q_P
-#define X3Q_PSTEP(SET, W)                                                                    \
-  {                                                                                          \
-    unsigned char* const sa_ = qsm + ((W) & 3) * Q_ST;                                       \
-    const f32x4 z_ = {0.f, 0.f, 0.f, 0.f};                                                   \
-    u32x4 q0_, q1_, q2_;                                                                     \
-    if (QABL & 4) {                                                                          \
-      q0_ = __builtin_bit_cast(u32x4, ra[SET][0]);                                           \
-      q1_ = __builtin_bit_cast(u32x4, ra[SET][1]);                                           \
-      q2_ = q0_;                                                                             \
-    } else                                                                                   \
-      split8(rv[SET] ? ra[SET][0] : z_, rv[SET] ? ra[SET][1] : z_, q0_, q1_, q2_);           \
-    if (!(QABL & 2)) {                                                                       \
-      *reinterpret_cast<u32x4*>(sa_ + adst) = q0_;                                           \
-      *reinterpret_cast<u32x4*>(sa_ + adst + 1024) = q1_;                                    \
-      *reinterpret_cast<u32x4*>(sa_ + adst + 2048) = q2_;                                    \
-      _Pragma("unroll") for (int i = 0; i < 3; ++i)                                          \
-        *reinterpret_cast<u32x4*>(sa_ + Q_AST + (pt + 256 * i) * 16) = rb[SET][i];           \
-    } else if (q0_.x == 0x12345u && q1_.y == 7u && rb[SET][0].x == 3u && rb[SET][1].y == 4u && rb[SET][2].z == 5u) \
-      *reinterpret_cast<u32x4*>(sa_ + adst) = q2_;                                           \
-    if (!(QABL & 1)) X3Q_LOAD(SET)                                                           \
-    if (!(QABL & 16)) X3Q_EPI()                                                              \
-    /* the consumers' cursor: step S = W - 2 multiplies stage S; at a tile's last stage its   \
-       sums go to E during this step and are drained from the next one on */                 \
-    if ((W) >= 2) {                                                                          \
-      if (++ck == nst) {                                                                     \
-        const int lin_ = xcd * per_xcd + cloc;                                               \
-        const int tm_ = lin_ / g.tiles_n;                                                    \
-        em0 = tm_ * 128;                                                                     \
-        en0 = (lin_ - tm_ * g.tiles_n) * 128;                                                \
-        eq = 0;                                                                              \
-        ck = 0;                                                                              \
-        cloc += stride;                                                                      \
-      }                                                                                      \
-    }                                                                                        \
-    X3Q_BARRIER()                                                                            \
-  }
-    X3Q_LOAD(0)
-    X3Q_LOAD(1)
-    X3Q_LOAD(2)
-    // steps S = -2 .. nsteps - 1: step S writes stage W = S + 2 (stages past the end: the last
-    // stage again, into a slot nobody reads any more)
-    int w = 0;
-    for (; w + 2 < nsteps + 2; w += 3) {
-      X3Q_PSTEP(0, w)
-      X3Q_PSTEP(1, w + 1)
-      X3Q_PSTEP(2, w + 2)
-    }
-    if (w < nsteps + 2) {
-      X3Q_PSTEP(0, w)
-      if (w + 1 < nsteps + 2) X3Q_PSTEP(1, w + 1)
-    }
-    // the last tile's E: Q_NQ chunks + the pipeline's flush, no barrier needed any more
-#pragma unroll 1
-    for (int t = 0; t <= Q_NQ; ++t) X3Q_EPI()
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (g.stamps && pt == 0) g.stamps[(long)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memtime();
-#undef X3Q_PSTEP
-#undef X3Q_EPI
-#undef X3Q_LOAD
-#undef X3Q_TILE_ADDR
-    return;
-  }
-
-  // -------------------------------------------------------------------- consumers
-  const int wr = wave >> 1, wc = wave & 1;            // 64 x 64 quadrant of the tile
-  bf16x8 fa[2][2][3], fb[2][2][3];                     // [fragment set][sub-tile][piece]
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  int ck = 0;
-  bool first = true;
-#define X3Q_FRAGS(F, SLOT)                                                                   \
-  {                                                                                          \
-    const unsigned char* const sa_ = qsm + (SLOT) * Q_ST;                                    \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int p = 0; p < 3; ++p) { \
-      fa[F][i][p] = *reinterpret_cast<const bf16x8*>(sa_ + (((2 * wr + i) * 3 + p) * 64 + lane) * 16); \
-      fb[F][i][p] = *reinterpret_cast<const bf16x8*>(sa_ + Q_AST + (((2 * wc + i) * 3 + p) * 64 + lane) * 16); \
-    }                                                                                        \
-  }
-#define X3Q_TERM(F, PA, PB)                                                                  \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[F][i][PA], fb[F][j][PB], acc[i][j], 0, 0, 0);
-  // step S (S >= -1): fragments of stage S+1 into set FN, then stage S from set FC
-#define X3Q_CSTEP(FC, FN, S)                                                                 \
-  {                                                                                          \
-    if ((S) + 1 < nsteps && (!(QABL & 32) || (S) < 1)) X3Q_FRAGS(FN, ((S) + 1) & 3)          \
-    if ((S) >= 0) {                                                                          \
-      if (!(QABL & 8)) {                                                                     \
-        X3Q_TERM(FC, 2, 0) X3Q_TERM(FC, 1, 1) X3Q_TERM(FC, 0, 2)                             \
-        X3Q_TERM(FC, 1, 0) X3Q_TERM(FC, 0, 1) X3Q_TERM(FC, 0, 0)                             \
-      }                                                                                      \
-      if (++ck == nst) {                                                                     \
-        if (first) x3p_stamp(g, 2);                                                          \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
-          _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                   \
-            const int row_ = 32 * (2 * wr + i) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);   \
-            sE[row_ * 128 + 32 * (2 * wc + j) + (lane & 31)] = acc[i][j][r];                 \
-            acc[i][j][r] = 0.f;                                                              \
-          }                                                                                  \
-        if (first) x3p_stamp(g, 3);                                                          \
-        first = false;                                                                       \
-        ck = 0;                                                                              \
-      }                                                                                      \
-    }                                                                                        \
-    X3Q_BARRIER()                                                                            \
-  }
-  // S = -2: barrier only (stage 0 is being written); then pairs
-  X3Q_BARRIER()
-  if (tid == 0) x3p_stamp(g, 1);
-  for (int s0 = -1; s0 < nsteps; s0 += 2) {
-    X3Q_CSTEP(1, 0, s0)                                // S odd (-1, 1, ...): stage S in set 1, S+1 -> set 0
-    if (s0 + 1 < nsteps) X3Q_CSTEP(0, 1, s0 + 1)
-  }
-#undef X3Q_CSTEP
-#undef X3Q_TERM
-#undef X3Q_FRAGS
-#undef X3Q_BARRIER
-}
-
 // ---- the weights' pieces, all matrices of a model in one launch.  Descriptor d covers blocks
 // [blk_begin[d], blk_begin[d+1]); a wave = one (column tile nt, k block kb) = three 1 KB fragments.
 __global__ __launch_bounds__(256) void x3p_split_kernel(const float* __restrict__ base,
@@ -1505,7 +1154,6 @@ int s2t_x3p_split(const float* base, const void* tab, int n, int total_blocks, u
   return 0;
 }
 
-static thread_local float* g_colstats = nullptr;      // (per thread: ctypes releases the GIL) armed by s2t_gemm_x3p_stats for the one launch it makes
 struct BalArm {
   const float* stats = nullptr;
   float n = 0.f, min_mean = 0.f, max_mean = 0.f, min_rms = 0.f, max_rms = 0.f, gs = 0.f;
@@ -1557,7 +1205,7 @@ int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int 
     return -2;
   if (act_src && resid && resid_b) return -2;        // two operand slots
   X3P g{A, lda, Bp, (N + 31) / 32, 2 * ((K + 31) / 32), C, ldc, M, N, K, bias, {nullptr, nullptr},
-        {0, 0}, {0, 0}, act_kind, C2, ldc2, act2, 0, 0, wgs, 0, g_stamps, drip, 0, nullptr,
+        {0, 0}, {0, 0}, act_kind, C2, ldc2, act2, 0, 0, wgs, 0, g_stamps, drip, 0,
         nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, X3PMap{0, 1, 1, 0, 0, 0, 0}, X3PMap{0, 1, 1, 0, 0, 0, 0}, 1, 1,
         {0, 0, 0, 0}, 0};
   if (g_bal.stats) {
@@ -1569,10 +1217,6 @@ int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int 
     g.bal_min_rms = g_bal.min_rms;
     g.bal_max_rms = g_bal.max_rms;
     g.bal_gs = g_bal.gs;
-  }
-  if (g_colstats) {
-    if (N > 1024 || drip || tile == 33) return -2;
-    g.colstats = g_colstats;
   }
   {
     int k = 0;
@@ -1611,46 +1255,9 @@ int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int 
       ++g_samp.launches;
     }
   }
-  if (tile == 33) {
-    if ((K + 15) / 16 < Q_NQ + 2) return -2;         // (E must be drained before the next tile refills it)
-    g.tiles_m = (M + 127) / 128;
-    g.tiles_n = (N + 127) / 128;
-    const int totalq = g.tiles_m * g.tiles_n;
-    const int gridq = std::min(((totalq + 7) / 8) * 8, 256);
-    static int qabl = -1;      // S2T_X3Q_ABL: ablation mask (diagnostics)
-    if (qabl < 0) qabl = s2t_debug_env("S2T_X3Q_ABL");
-#define X3Q_LAUNCH(A)                                                                            \
-  {                                                                                              \
-    static bool attr_ = false;                                                                   \
-    if (!attr_) {                                                                                \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(x3q_kernel<A>),                      \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, Q_SMEM) != hipSuccess) \
-        return -3;                                                                               \
-      attr_ = true;                                                                              \
-    }                                                                                            \
-    hipLaunchKernelGGL(x3q_kernel<A>, dim3(gridq), dim3(512), Q_SMEM, st, g);                    \
-  }
-    switch (qabl) {
-      case 1: X3Q_LAUNCH(1) break;
-      case 2: X3Q_LAUNCH(2) break;
-      case 4: X3Q_LAUNCH(4) break;
-      case 8: X3Q_LAUNCH(8) break;
-      case 16: X3Q_LAUNCH(16) break;
-      case 17: X3Q_LAUNCH(17) break;
-      case 23: X3Q_LAUNCH(23) break;
-      case 32: X3Q_LAUNCH(32) break;
-      case 40: X3Q_LAUNCH(40) break;
-      case 55: X3Q_LAUNCH(55) break;
-      case 119: X3Q_LAUNCH(119) break;
-      default: X3Q_LAUNCH(0) break;
-    }
-#undef X3Q_LAUNCH
-    S2T_CHECK_LAUNCH();
-    return 0;
-  }
+  if (tile == 33) return -2;                        // (the producer / consumer form: removed in round 5)
   if (dma && g.bal_stats) dma = 0;       // (the Balancer epilogue lives in the register-staged form)
   if (dma) {
-    if (g_colstats) return -2;
     switch (tile) {
       case 22: launch_x3p_dma<2, 2, 3>(g, st); break;
       case 21: launch_x3p_dma<2, 1, 4>(g, st); break;
@@ -1725,7 +1332,7 @@ int s2t_gemm_x3p_map(const float* A, const S2tRowMap* amap, int seg, int nseg, c
     if (segoff[i] & 3) return -2;
   const int K = seg * nseg;
   X3P g{A, 0, Bp, (N + 31) / 32, 2 * ((K + 31) / 32), C, ldc, M, N, K, bias, {nullptr, nullptr},
-        {0, 0}, {0, 0}, 0, nullptr, 0, 0, 0, 0, 0, 0, nullptr, 0, 0, nullptr,
+        {0, 0}, {0, 0}, 0, nullptr, 0, 0, 0, 0, 0, 0, nullptr, 0, 0,
         nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
         X3PMap{1, amap->hw, amap->w, amap->sb, amap->sh, amap->sw, amap->base},
         cmap ? X3PMap{1, cmap->hw, cmap->w, cmap->sb, cmap->sh, cmap->sw, cmap->base} : X3PMap{0, 1, 1, 0, 0, 0, 0},
@@ -1764,22 +1371,6 @@ int s2t_gemm_x3p_bal(const float* A, long lda, const unsigned short* Bp, int N, 
   const int rc = s2t_gemm_x3p(A, lda, Bp, N, K, C, ldc, M, nullptr, resid, ldr, act_src, ld_act, act_kind, nullptr,
                               0, 0, nullptr, 0, tile, stream);
   g_bal.stats = nullptr;
-  return rc;
-}
-
-// s2t_gemm_x3p that also ADDS the column sums and sums of squares of C (as stored: after bias,
-// act', residuals) into colstats[0..N) and colstats[1024..1024+N) -- the statistics a Balancer on
-// that tensor needs in backward (zip_elem.hip s2t_balancer_apply), taken where the tensor is
-// produced instead of by a pass of their own.  colstats: 2048 floats, zeroed by the caller.
-int s2t_gemm_x3p_stats(const float* A, long lda, const unsigned short* Bp, int N, int K, float* C,
-                       long ldc, int M, const float* bias, const float* resid, long ldr,
-                       const float* act_src, long ld_act, int act_kind, float* C2, long ldc2, int act2,
-                       const float* resid_b, long ldrb, int tile, float* colstats, void* stream) {
-  if (!colstats) return -1;
-  g_colstats = colstats;
-  const int rc = s2t_gemm_x3p(A, lda, Bp, N, K, C, ldc, M, bias, resid, ldr, act_src, ld_act, act_kind,
-                              C2, ldc2, act2, resid_b, ldrb, tile, stream);
-  g_colstats = nullptr;
   return rc;
 }
 

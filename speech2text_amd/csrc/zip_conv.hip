@@ -729,251 +729,6 @@ __global__ __launch_bounds__(256) void zipconv_bwd_w_kernel(ConvArgs a,
   reduce_store(pbk, Kh + 1 + K);
 }
 
-// ---- data AND weight gradients from ONE staged pair of tiles.  The two kernels above each stage
-// the projection (x, gate: 2 C floats per row) and the output gradient once per call -- 8 C floats
-// per frame and channel against the 5 C the op needs; here a workgroup = (c tile, t tile, group of
-// BB utterances) stages, per utterance, dy and the gated input for frames t0 - 16 .. t0 + 79 once
-// (rows r = 16 p + rig, so the centre rows p = 1 .. 4 are the rows this thread later STORES:
-// x and sigmoid(gate) stay in its registers for the gate's backward), then runs
-//   (1) the transposed taps over the dy window  -> d(gated input), kept in registers,
-//   (2) the tap / bias partial sums over the gated-input window with dy's centre values,
-//   (3) du = (d xg * sigmoid, d xg * x * sigmoid') through LDS as 16-byte row pieces.
-// The taps are staged once per workgroup.  Needs 16-byte-aligned operands, C % 4 == 0 and a gate;
-// the entry point falls back to the two kernels otherwise.
-template <int K, bool GEN>
-__global__ __launch_bounds__(256) void zipconv_bwd_fused_kernel(ConvArgs a,
-                                                                const float* __restrict__ dy,
-                                                                float* __restrict__ du, int BB,
-                                                                float* __restrict__ part,
-                                                                float* __restrict__ dscale) {
-  constexpr int Kh = (K + 1) / 2, halo = K / 2, W = FPT + 2 * halo, NV = Kh + K + 2;
-  constexpr int RH = 16, ROWS = TT + 2 * RH, NP = ROWS / 16;   // staged rows: frames t0-16 .. t0+79
-  static_assert(halo <= RH, "tap half-width beyond the staged halo");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float* s_g = reinterpret_cast<float*>(smem_raw);   // dy
-  float* s_x = s_g + ROWS * 64;                      // x * sigmoid(gate), 0 on padded frames
-  float* s_wc = s_x + ROWS * 64;
-  float* s_wk = s_wc + Kh * 64;
-  float* s_le = s_wk + K * 64;
-  float* s_re = s_le + K * 64;
-  float* s_red = s_re + K * 64;                      // [4][64] reduction scratch
-  const int tz = tile_z(a);
-  const int c0 = blockIdx.x * 64, t0 = tz * TT;
-  const int c = threadIdx.x & 63, tg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: frame indices and chunk tests stay wave-uniform)
-  const int rig = threadIdx.x >> 4, c4 = threadIdx.x & 15, ch = c0 + 4 * c4;
-  const int tb = t0 + tg * FPT;
-  const int chunk = a.chunk;
-  const bool near_edge = GEN || t0 - K / 2 < K || t0 + TT + K / 2 > a.T - K;
-  stage_weights<K>(a, c0, s_wc, s_wk, s_le, s_re, near_edge);
-  float pwc[Kh], pwk[K];
-#pragma unroll
-  for (int j = 0; j < Kh; ++j) pwc[j] = 0.f;
-#pragma unroll
-  for (int j = 0; j < K; ++j) pwk[j] = 0.f;
-  float pbc = 0.f, pbk = 0.f;
-  const bool chan_ok = c0 + c < a.C;
-  int cs[FPT];
-  float sc[FPT];
-#pragma unroll
-  for (int i = 0; i < FPT; ++i) {
-    cs[i] = GEN ? ((tb + i) / chunk) * chunk : 0;
-    sc[i] = 1.f;
-  }
-  __syncthreads();
-  if (a.scale && near_edge) {
-#pragma unroll
-    for (int i = 0; i < FPT; ++i)
-      if (tb + i < a.T) sc[i] = edge_scale(s_le, s_re, c, tb + i - cs[i], chunk, K);
-  }
-  bool edge = false;                                 // (see zipconv_bwd_w_kernel)
-  if (dscale != nullptr) {
-    const int p0 = t0 % chunk;
-    edge = (p0 < K) || (p0 + TT - 1 >= chunk - K) || (p0 + TT > chunk);
-  }
-  const float bkv = (a.bk && chan_ok) ? a.bk[c0 + c] : 0.f;
-  float ds[FPT];
-#pragma unroll
-  for (int i = 0; i < FPT; ++i) ds[i] = 0.f;
-  const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.u), 0, (int)((long)a.T * a.B * a.ld * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(dy), 0, (int)((long)a.T * a.B * a.C * 4), 0x00020000);
-  const int b_end = min(a.B, (int)(blockIdx.y + 1) * BB);
-  for (int b = blockIdx.y * BB; b < b_end; ++b) {
-    // ---- stage: one batch of 16-byte buffer loads (frames outside [0, T) read as 0)
-    u32x4 qg[NP], qx[NP], qs[NP];
-    unsigned char mk[NP];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      const int t = t0 - RH + 16 * p + rig;
-      const bool tin = t >= 0 && t < a.T && ch < a.C;
-      const int offu = (((t * a.B + b) * (int)a.ld) + ch) * 4;
-      const int offg = ((t * a.B + b) * a.C + ch) * 4;
-      qg[p] = __builtin_amdgcn_raw_buffer_load_b128(rs_g, tin ? offg : 0x7FFFFFF0, 0, 0);
-      qx[p] = __builtin_amdgcn_raw_buffer_load_b128(rs_u, tin ? offu : 0x7FFFFFF0, 0, 0);
-      qs[p] = __builtin_amdgcn_raw_buffer_load_b128(rs_u, tin ? offu + a.gate_off * 4 : 0x7FFFFFF0, 0, 0);
-      mk[p] = a.mask ? a.mask[(long)b * a.T + min(max(t, 0), a.T - 1)] : (unsigned char)0;
-    }
-    __syncthreads();                                 // the previous utterance's LDS readers are done
-    float xc[TT / 16][4], sgc[TT / 16][4];           // centre rows: x and sigmoid(gate)
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      const float xv[4] = {__uint_as_float(qx[p].x), __uint_as_float(qx[p].y), __uint_as_float(qx[p].z),
-                           __uint_as_float(qx[p].w)};
-      const float gv[4] = {__uint_as_float(qs[p].x), __uint_as_float(qs[p].y), __uint_as_float(qs[p].z),
-                           __uint_as_float(qs[p].w)};
-      float v[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float sg = sigmoidf_(gv[e]);
-        v[e] = mk[p] ? 0.f : xv[e] * sg;
-        if (p >= 1 && p <= TT / 16) {
-          xc[(p - 1) & (TT / 16 - 1)][e] = xv[e];
-          sgc[(p - 1) & (TT / 16 - 1)][e] = sg;
-        }
-      }
-      const int r = 16 * p + rig;
-      *reinterpret_cast<float4*>(&s_x[r * 64 + 4 * c4]) = make_float4(v[0], v[1], v[2], v[3]);
-      *reinterpret_cast<u32x4*>(&s_g[r * 64 + 4 * c4]) = qg[p];
-    }
-    __syncthreads();
-    // ---- (1) data gradient: dxg[t'] += w[j] * dy[t' + halo - j]
-    const int rb = tg * FPT + RH - halo;             // first window row of this thread
-    float win[W];
-#pragma unroll
-    for (int w = 0; w < W; ++w) win[w] = s_g[(rb + w) * 64 + c];
-    float gpre[FPT];                                 // dy at this thread's own 16 frames
-#pragma unroll
-    for (int i = 0; i < FPT; ++i) gpre[i] = win[i + halo];
-    float acc[FPT];
-#pragma unroll
-    for (int i = 0; i < FPT; ++i) acc[i] = 0.f;
-    if (a.wc) {
-#pragma unroll
-      for (int j = 0; j < Kh; ++j) {
-        const float w = s_wc[j * 64 + c];
-#pragma unroll
-        for (int i = 0; i < FPT; ++i) acc[i] = fmaf(w, win[i + 2 * halo - j], acc[i]);
-      }
-    }
-    if (near_edge && a.scale) {
-#pragma unroll
-      for (int w = 0; w < W; ++w) {
-        const int t = tb - halo + w;
-        if (t >= 0 && t < a.T) win[w] *= edge_scale(s_le, s_re, c, GEN ? t % chunk : t, chunk, K);
-      }
-    }
-    if (!GEN) {
-#pragma unroll
-      for (int j = 0; j < K; ++j) {
-        const float w = s_wk[j * 64 + c];
-#pragma unroll
-        for (int i = 0; i < FPT; ++i) acc[i] = fmaf(w, win[i + 2 * halo - j], acc[i]);
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < K; ++j) {
-        const float w = s_wk[j * 64 + c];
-#pragma unroll
-        for (int i = 0; i < FPT; ++i) {
-          const int t = tb + i + halo - j;
-          if (t >= cs[i] && t < cs[i] + chunk) acc[i] = fmaf(w, win[i + 2 * halo - j], acc[i]);
-        }
-      }
-    }
-    // ---- (2) tap / bias partial sums over the gated-input window
-#pragma unroll
-    for (int w = 0; w < W; ++w) win[w] = s_x[(rb + w) * 64 + c];
-    if (chan_ok) {
-      if (edge) {
-        float ak[FPT];
-#pragma unroll
-        for (int i = 0; i < FPT; ++i) ak[i] = bkv;
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-          const float w = s_wk[j * 64 + c];
-#pragma unroll
-          for (int i = 0; i < FPT; ++i) {
-            const int tt = tb + i - halo + j;
-            if (!GEN || (tt >= cs[i] && tt < cs[i] + chunk)) ak[i] = fmaf(w, win[i + j], ak[i]);
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < FPT; ++i)
-          if (tb + i < a.T) ds[i] = fmaf(gpre[i], ak[i], ds[i]);
-      }
-#pragma unroll
-      for (int i = 0; i < FPT; ++i) {
-        const int t = tb + i;
-        const float g = (t < a.T) ? gpre[i] : 0.f;
-        const float gs = g * sc[i];
-        pbc += g;
-        pbk += gs;
-        if (a.wc) {
-#pragma unroll
-          for (int j = 0; j < Kh; ++j) pwc[j] = fmaf(g, win[i + j], pwc[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-          if (!GEN) {
-            pwk[j] = fmaf(gs, win[i + j], pwk[j]);
-          } else {
-            const int tt = t - halo + j;
-            if (tt >= cs[i] && tt < cs[i] + chunk) pwk[j] = fmaf(gs, win[i + j], pwk[j]);
-          }
-        }
-      }
-    }
-    // ---- (3) du through LDS as row pieces
-    __syncthreads();                                 // every window is in registers
-#pragma unroll
-    for (int i = 0; i < FPT; ++i) s_g[(tg * FPT + i) * 64 + c] = acc[i];
-    __syncthreads();
-#pragma unroll
-    for (int p = 0; p < TT / 16; ++p) {
-      const int r = 16 * p + rig, t = t0 + r;
-      if (t >= a.T || ch >= a.C) continue;
-      const float4 d = *reinterpret_cast<const float4*>(&s_g[r * 64 + 4 * c4]);
-      const float dv[4] = {d.x, d.y, d.z, d.w};
-      const bool pad = mk[p + 1] != 0;
-      float ox[4], og[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float sg = sgc[p][e];
-        ox[e] = pad ? 0.f : dv[e] * sg;
-        og[e] = pad ? 0.f : dv[e] * xc[p][e] * sg * (1.f - sg);
-      }
-      float* o = du + ((long)t * a.B + b) * (2 * a.C) + ch;
-      *reinterpret_cast<float4*>(o) = make_float4(ox[0], ox[1], ox[2], ox[3]);
-      *reinterpret_cast<float4*>(o + a.C) = make_float4(og[0], og[1], og[2], og[3]);
-    }
-  }
-  if (edge && chan_ok) {
-#pragma unroll
-    for (int i = 0; i < FPT; ++i) {
-      const int t = tb + i;
-      if (t >= a.T) continue;
-      const int pos = t - cs[i], idx = pos - chunk + K;
-      if (pos < K) atomicAdd(&dscale[(long)(c0 + c) * K + pos], ds[i]);
-      if (idx >= 0 && idx < K) atomicAdd(&dscale[((long)a.C + c0 + c) * K + idx], ds[i]);
-    }
-  }
-  const long blk = ((long)blockIdx.x * gridDim.y + blockIdx.y) * a.nt + tz;
-  float* dst = part + blk * NV * 64 + c;
-  auto reduce_store = [&](float v, int slot) {
-    __syncthreads();
-    s_red[tg * 64 + c] = v;
-    __syncthreads();
-    if (tg == 0) dst[slot * 64] = s_red[c] + s_red[64 + c] + s_red[128 + c] + s_red[192 + c];
-  };
-#pragma unroll
-  for (int j = 0; j < Kh; ++j) reduce_store(pwc[j], j);
-  reduce_store(pbc, Kh);
-#pragma unroll
-  for (int j = 0; j < K; ++j) reduce_store(pwk[j], Kh + 1 + j);
-  reduce_store(pbk, Kh + 1 + K);
-}
-
 // out[c][slot] = sum over the (t-tile, b-group) blocks of part.  Grid (c tiles, slots); thread =
 // (channel, block group): every read is a 256-byte row of 64 channels.
 __global__ __launch_bounds__(256) void zipconv_reduce_w_kernel(
@@ -1223,38 +978,9 @@ extern "C" int s2t_zipconv_bwd(const float* u, long ld, int gate_off, const unsi
   const bool gen = chunk < T;
   const ZSplit z(T, K, gen, scale != nullptr);
   const unsigned gx = (C + 63) / 64;
-  // MEASURED (C3 shapes, same box): the fused kernel is SLOWER than the two kernels -- 137 / 105 /
-  // 82 / 49 us against 112 / 89 / 49 / 44 (T = 495 / 248 / 124 / 62): the union of the two bodies
-  // needs 358 (K = 15) and 510 (K = 31) registers = one workgroup per CU, and capping them spills.
-  // These kernels are bound by the length of a workgroup's dependent chain at the occupancy they
-  // get, not by the 1.5x re-staged bytes.  Kept selectable (S2T_CONV_FUSED=1) and parity-tested.
-  const bool fused = getenv("S2T_CONV_FUSED") != nullptr;
-  if (fused && gate_off >= 0 && (C & 3) == 0 && (ld & 3) == 0 && (gate_off & 3) == 0 &&
-      ((reinterpret_cast<uintptr_t>(u) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(du)) & 15) == 0 &&
-      (long)T * B * ld * 4 < 0x7FFFFF00L) {
-    // one kernel for both gradients; ~2 workgroups per CU in one round
-    a.z_base = 0; a.z_split = 1 << 30; a.z_jump = 0; a.nt = z.nt;
-    const long tiles = (long)gx * z.nt;
-    const char* envb = getenv("S2T_CONV_BLOCKS");
-    int BB = (int)((tiles * B + (envb ? std::max(1, atoi(envb)) : 512) - 1) / (envb ? std::max(1, atoi(envb)) : 512));
-    BB = std::max(1, std::min(BB, 16));
-    const unsigned gy = (B + BB - 1) / BB;
-    auto smem = [](int K_) { return sizeof(float) * (2 * (TT + 32) * 64 + ((K_ + 1) / 2 + 3 * K_) * 64 + 256); };
-    float* const dsc = (scale && dscale) ? dscale : nullptr;
-    if (!gen) {
-      S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_fused_kernel<KK, false>), dim3(gx, gy, z.nt), dim3(256),
-                                              smem(KK), st, a, dy, du, BB, workspace, dsc));
-    } else {
-      S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_bwd_fused_kernel<KK, true>), dim3(gx, gy, z.nt), dim3(256),
-                                              smem(KK), st, a, dy, du, BB, workspace, dsc));
-    }
-    S2T_CHECK_LAUNCH();
-    hipLaunchKernelGGL(zipconv_reduce_w_kernel, dim3(gx, (K + 1) / 2 + K + 2), dim3(256), 0,
-                       st, workspace, (int)(z.nt * gy), C, (K + 1) / 2, K, wc ? dwc : nullptr,
-                       wc ? dbc : nullptr, dwk, dbk);
-    S2T_CHECK_LAUNCH();
-    return 0;
-  }
+  // (a one-kernel form of both gradients was built in round 3 and measured SLOWER -- 137 / 105 / 82 /
+  // 49 us against 112 / 89 / 49 / 44 at T = 495 / 248 / 124 / 62: the union of the two bodies needs
+  // 358 - 510 registers = one workgroup per CU -- and removed in round 5)
   int rc = zipconv_bwd_launch_data(a, T, B, C, K, gen, z, dy, du, st);
   if (rc != 0) return rc;
   return zipconv_bwd_launch_params(a, T, B, C, K, gen, z, wc, scale, dy, dwc, dbc, dwk, dbk, dscale,

@@ -181,142 +181,6 @@ __global__ __launch_bounds__(256) void biasnorm_bwd_kernel(
   }
 }
 
-// sum over each 16-lane DPP row (every lane of the row gets it): quad butterflies, then the two
-// mirrors -- four DPP adds, no LDS permutes
-__device__ __forceinline__ float sum16(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
-  return v;
-}
-
-// The same pass for D % 4 == 0, D <= 64 * NJ: a 16-lane DPP row owns one matrix row (lane l holds
-// the 16-byte pieces at columns 4 l + 64 j), so a wave walks FOUR rows per trip with 16-byte
-// accesses, the two row sums are four DPP adds each, and the next trip's rows are requested
-// before this trip's are reduced (two register sets; row and column indices are clamped instead
-// of branched on, so the loads stay on straight-line code and the compiler counts them).
-// 256-thread workgroups, at most 1024 of them.  (The first form of this kernel -- 512 threads, two
-// register sets up to NJ = 4, 204 VGPRs -- measured 29 us alone against 44 for the 4-byte kernel
-// and 92-255 us IN the step against 40: a workgroup that needs two 204-register waves on every
-// SIMD of a CU at once cannot start while the side stream's weight-gradient workgroups are
-// resident.  Main-stream kernels must fit NEXT to them: small workgroups, <= 128 registers.)
-template <int NJ>
-__global__ __launch_bounds__(256) void biasnorm_bwd_v4_kernel(
-    const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ scales,
-    const float* __restrict__ g, long rows, int D, float* __restrict__ dx,
-    float* __restrict__ dbias, float* __restrict__ dls) {
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  const int lane = threadIdx.x & 63, l16 = lane & 15, sub = lane >> 4, wv = threadIdx.x >> 6;
-  const long wave = (long)blockIdx.x * 4 + wv, nwaves = (long)gridDim.x * 4;
-  const long nquads = (rows + 3) >> 2;
-  f4 b[NJ], db[NJ];
-  int col[NJ];
-  bool on[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int c = 4 * l16 + 64 * j;
-    on[j] = c < D;
-    col[j] = on[j] ? c : D - 4;
-    b[j] = on[j] ? *reinterpret_cast<const f4*>(bias + c) : f4{0.f, 0.f, 0.f, 0.f};
-    db[j] = f4{0.f, 0.f, 0.f, 0.f};
-  }
-  float dl = 0.f;
-
-#define BN_LOAD(XV, GV, SV, Q)                                               \
-  {                                                                          \
-    long r_ = 4 * (Q) + sub;                                                 \
-    r_ = r_ < rows ? r_ : rows - 1;                                          \
-    const float* xp_ = x + r_ * D;                                           \
-    const float* gp_ = g + r_ * D;                                           \
-    _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                         \
-      XV[j] = *reinterpret_cast<const f4*>(xp_ + col[j]);                    \
-      GV[j] = *reinterpret_cast<const f4*>(gp_ + col[j]);                    \
-    }                                                                        \
-    SV = scales[r_];                                                         \
-  }
-#define BN_STEP(XV, GV, SV, Q)                                               \
-  {                                                                          \
-    const long r_ = 4 * (Q) + sub;                                           \
-    const bool ok_ = r_ < rows;                                              \
-    float A_ = 0.f, ss_ = 0.f;                                               \
-    _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                         \
-      const f4 xz_ = on[j] ? XV[j] : f4{0.f, 0.f, 0.f, 0.f};                 \
-      const f4 d_ = xz_ - b[j];                                              \
-      A_ += GV[j].x * xz_.x + GV[j].y * xz_.y + GV[j].z * xz_.z + GV[j].w * xz_.w; \
-      ss_ += d_.x * d_.x + d_.y * d_.y + d_.z * d_.z + d_.w * d_.w;          \
-    }                                                                        \
-    A_ = sum16(A_);                                                          \
-    ss_ = sum16(ss_);                                                        \
-    const float coef_ = SV * A_ / ss_;                                       \
-    if (ok_) {                                                               \
-      if (l16 == 0) dl += A_ * SV;                                           \
-      float* dp_ = dx + r_ * D;                                              \
-      _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                       \
-        if (on[j]) {                                                         \
-          const f4 t_ = coef_ * (XV[j] - b[j]);                              \
-          *reinterpret_cast<f4*>(dp_ + col[j]) = SV * GV[j] - t_;            \
-          db[j] += t_;                                                       \
-        }                                                                    \
-      }                                                                      \
-    }                                                                        \
-  }
-
-  if constexpr (NJ <= 2) {
-    f4 xa[NJ], ga[NJ], xb[NJ], gb[NJ];
-    float sa, sb;
-    long q = wave;
-    BN_LOAD(xa, ga, sa, q)
-    for (; q < nquads; q += 2 * nwaves) {
-      BN_LOAD(xb, gb, sb, q + nwaves)
-      BN_STEP(xa, ga, sa, q)
-      BN_LOAD(xa, ga, sa, q + 2 * nwaves)
-      BN_STEP(xb, gb, sb, q + nwaves)
-    }
-  } else {            // wider rows: one register set; the CU's other waves cover the latency
-    f4 xa[NJ], ga[NJ];
-    float sa;
-    for (long q = wave; q < nquads; q += nwaves) {
-      BN_LOAD(xa, ga, sa, q)
-      BN_STEP(xa, ga, sa, q)
-    }
-  }
-#undef BN_LOAD
-#undef BN_STEP
-
-  // the wave's four rows-of-lanes hold partial sums of the same columns: add them up in the wave,
-  // then the eight waves through LDS, then one atomic per column per workgroup
-  __shared__ float s_db[4][64 * NJ];
-  __shared__ float s_dl[4];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    f4 t = db[j];
-#pragma unroll
-    for (int o = 16; o <= 32; o <<= 1) {
-      t.x += __shfl_xor(t.x, o, 64);
-      t.y += __shfl_xor(t.y, o, 64);
-      t.z += __shfl_xor(t.z, o, 64);
-      t.w += __shfl_xor(t.w, o, 64);
-    }
-    if (sub == 0) *reinterpret_cast<f4*>(&s_db[wv][4 * l16 + 64 * j]) = t;
-  }
-  dl = wave_sum(dl);
-  if (lane == 0) s_dl[wv] = dl;
-  __syncthreads();
-  for (int c = threadIdx.x; c < D; c += 256) {
-    float t = 0.f;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) t += s_db[w][c];
-    if (t != 0.f) atomicAdd(&dbias[c], t);
-  }
-  if (threadIdx.x == 0) {
-    float tl = 0.f;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) tl += s_dl[w];
-    if (tl != 0.f) atomicAdd(dls, tl);
-  }
-}
-
 // ---------------------------------------------------------------- column statistics
 // x viewed as [rows][ld] with C used columns: sum[c] += x, sumsq[c] += x^2 (atomics once per
 // block).  Each thread owns column (threadIdx.x % cols_per_pass) and strides over rows.
@@ -511,33 +375,9 @@ extern "C" int s2t_biasnorm_bwd(const float* x, const float* bias, const float* 
                                 float* dls, void* stream) {
   if (rows <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  // S2T_BIASNORM_V4=1 selects the 16-byte kernel (read per call: the tests switch it).  OFF by
-  // default: 29 / 25 us against 44 / 27 alone (31 680 x 192 / 15 872 x 256, caches flushed), but
-  // 78-99 us against 40 IN the step -- its 94-120 registers leave it two waves per SIMD next to
-  // the side stream's resident weight-gradient workgroups, where the 4-byte kernel keeps four.
-  const char* e4 = getenv("S2T_BIASNORM_V4");
-  const bool v4 = e4 && atoi(e4) != 0;
-  if (v4 && D % 4 == 0 && D >= 4 && D <= 512 && rows * (long)D < (1L << 31) &&
-      (((uintptr_t)x | (uintptr_t)g | (uintptr_t)dx | (uintptr_t)bias) & 15) == 0) {
-    const long nquads = (rows + 3) / 4;
-    const unsigned nbv = (unsigned)std::min<long>((nquads + 3) / 4, 1024);
-#define BN_V4(NJ)                                                                                 \
-  hipLaunchKernelGGL(biasnorm_bwd_v4_kernel<NJ>, dim3(nbv), dim3(256), 0, st, x, bias, scales, g, \
-                     rows, D, dx, dbias, dls)
-    switch ((D + 63) / 64) {
-      case 1: BN_V4(1); break;
-      case 2: BN_V4(2); break;
-      case 3: BN_V4(3); break;
-      case 4: BN_V4(4); break;
-      case 5: BN_V4(5); break;
-      case 6: BN_V4(6); break;
-      case 7: BN_V4(7); break;
-      default: BN_V4(8); break;
-    }
-#undef BN_V4
-    S2T_CHECK_LAUNCH();
-    return 0;
-  }
+  // (a 16-byte form -- a 16-lane row of a wave per matrix row -- measured 29 / 25 us against 44 / 27
+  // alone and 78-99 us against 40 IN the step: 94-120 registers leave it two waves per SIMD next to
+  // the side stream's resident workgroups, where this kernel keeps four.  Removed in round 5.)
   const unsigned nb = std::min(grid_for(rows, 4 * 8), 1024u);
   if (D <= 64)
     hipLaunchKernelGGL(biasnorm_bwd_kernel<1>, dim3(nb), dim3(256), 0, st, x, bias, scales, g,

@@ -172,66 +172,8 @@ def _balancer_workspace(dev):
     return ws
 
 
-# (off by default: three same-box A/B pairs at C3 gave 40.83 against 40.92 ms/step -- the side
-# stream is busy with the Whiten products in forward and the fill + event per call cost what the
-# moved pass saves)
-_BAL_FWD = os.environ.get("S2T_BAL_STATS_FWD", "0") == "1"
-
-
-class BalancerStats:
-    """Column statistics of x for a Balancer that fires this call, taken in FORWARD -- they depend
-    on x only -- on the library's side stream (as WhitenStats): the backward pass then runs only
-    the update on the data-gradient chain.  `make` returns None where the two-pass entry point has
-    to serve (layout, dtype, disabled)."""
-    __slots__ = ("stats", "event", "x2")
-
-    @staticmethod
-    def make(x):
-        if not (_BAL_FWD and x.is_cuda and x.dim() == 2 and x.dtype is torch.float32
-                and x.stride(1) == 1 and x.shape[1] <= 1024 and torch.is_grad_enabled()):
-            return None
-        side = _stats_stream()
-        if side is None:
-            return None
-        self = BalancerStats()
-        self.x2 = x
-        self.stats = torch.zeros(2048, dtype=torch.float32, device=x.device)
-        N.check(N.lib().s2t_stream_order(N.stream(), side), "s2t_stream_order(bal)")   # after the fill
-        N.PROF[0] and N.profile_note("s2t_balancer_stats", 4.0 * x.numel())
-        N.check(N.lib().s2t_balancer_stats(N.raw(x, torch.float32), x.stride(0), x.shape[0],
-                                           x.shape[1], N.fp(self.stats), side), "s2t_balancer_stats")
-        _Side.keep.append((x, self.stats))
-        self.event = torch.cuda.Event()
-        self.event.record(N._launch_stream((side,)))
-        return self
-
-
-# (off by default: the statistics are exact, but every workgroup of an n-tile adds to the SAME
-# columns at the same moment -- contended fp32 atomics: 15 872 x 768 x 256 takes 84 us with them
-# against 48 without, the pass they replace takes 18; three same-box A/B pairs at C3: 41.9 against
-# 41.2 ms/step)
-_BAL_GEMM = os.environ.get("S2T_BAL_STATS_GEMM", "0") == "1"
-
-
-class GemmColStats:
-    """Column statistics of a GEMM's output, taken in that GEMM's epilogue (s2t_gemm_x3p_stats) for a
-    Balancer that fires on the tensor -- or on a column slice of it -- this call: pass to
-    lt_matmul(colstats=...), then to balancer_backward(stats=...).  `ok` is set when the product
-    was served by the kernel that takes them; otherwise backward runs the two-pass form."""
-    __slots__ = ("buf", "ok", "out")
-
-    def __init__(self, dev):
-        self.buf = torch.zeros(2048, dtype=torch.float32, device=dev)
-        self.ok = False
-        self.out = None
-
-    @staticmethod
-    def make(fires, dev):
-        return GemmColStats(dev) if (fires and _BAL_GEMM) else None
-
-
 def balancer_backward(x, g, min_mean, max_mean, min_rms, max_rms, grad_scale, channel_dim,
-                      inplace=False, swoosh_l=None, stats=None):
+                      inplace=False, swoosh_l=None):
     """Closed form of reference scaling.py:741-789: the autograd-inside-backward there reduces
     to per-channel statistics (mean, E[x^2]) and a per-element affine term
         g' = g + |g| * grad_scale * (a_c + b_c x) / rms_c(a + b x).
@@ -259,32 +201,6 @@ def balancer_backward(x, g, min_mean, max_mean, min_rms, max_rms, grad_scale, ch
         else:
             g2 = g.contiguous().reshape(-1, C)
             out = torch.empty_like(g2)
-        if isinstance(stats, GemmColStats):
-            o = stats.out
-            if stats.ok and o is not None and o.shape[0] == rows and x2.stride(0) == o.stride(0):
-                c0 = (x2.data_ptr() - o.data_ptr()) // 4          # column offset of the slice
-                if 0 <= c0 and c0 + C <= o.shape[1]:
-                    N.PROF[0] and N.profile_note("s2t_balancer_apply", 4.0 * rows * C * 3)
-                    N.check(N.lib().s2t_balancer_apply(
-                        N.raw(x2, torch.float32), x2.stride(0), N.raw(g2, torch.float32), g2.stride(0),
-                        rows, C, min_mean, max_mean, min_rms, max_rms, grad_scale,
-                        N.raw(out, torch.float32), out.stride(0),
-                        ctypes.c_void_p(stats.buf.data_ptr() + 4 * c0),
-                        -1.0 if swoosh_l is None else _SW[swoosh_l][0], N.stream()), "s2t_balancer_apply")
-                    return out if out is g else out.reshape(g.shape)
-            stats = None
-        if stats is not None and stats.x2.shape == x2.shape and stats.x2.data_ptr() == x2.data_ptr():
-            # statistics taken in forward: only the update runs here, after their event
-            torch.cuda.current_stream().wait_event(stats.event)
-            N.PROF[0] and N.profile_note("s2t_balancer_apply", 4.0 * rows * C * 3)
-            N.check(N.lib().s2t_balancer_apply(N.raw(x2, torch.float32), x2.stride(0),
-                                               N.raw(g2, torch.float32), g2.stride(0), rows, C,
-                                               min_mean, max_mean, min_rms, max_rms, grad_scale,
-                                               N.raw(out, torch.float32), out.stride(0),
-                                               N.fp(stats.stats),
-                                               -1.0 if swoosh_l is None else _SW[swoosh_l][0],
-                                               N.stream()), "s2t_balancer_apply")
-            return out if out is g else out.reshape(g.shape)
         ws = _balancer_workspace(x.device)
         ws[1] = N.lib().s2t_balancer_next_parity()      # (one sequence for this path and zip_layer.hip)
         N.PROF[0] and N.profile_note("s2t_balancer_bwd", 4.0 * rows * C * 4)     # x twice (stats, update), g, out
@@ -549,7 +465,7 @@ def zipconv_backward(u, gate_off, m8, chunk, K, wc, wk, bk, scale, dy, grads, si
     gptr = (N.raw(dwc) if dwc is not None else None, N.raw(dbc) if dbc is not None else None,
             N.raw(dwk), N.raw(dbk) if dbk is not None else None,
             N.raw(dsc) if dsc is not None else None)
-    if wst is None or os.environ.get("S2T_CONV_FUSED"):
+    if wst is None:
         N.PROF[0] and N.profile_note("s2t_zipconv_bwd", 4.0 * (2 * u.numel() + 2 * dy.numel()))
         N.check(L.s2t_zipconv_bwd(N.fp(u), ld, gate_off, N.ptr(m8), T, B, C, K, chunk, N.fp(wc),
                                   N.fp(wk), N.fp(bk), N.fp(scale), N.fp(dy), N.fp(du), *gptr,
@@ -1382,7 +1298,7 @@ def _vp(t):
 
 
 def x3p_matmul(mode, x2, w2, bias=None, resid2=None, act_src=None, act_kind=None, act2=None, tile=0,
-               resid_b=None, pp=None, colstats=None, bal=None):
+               resid_b=None, pp=None, bal=None):
     """The same products as lt_matmul on our bf16x3 kernel with pre-split weight pieces
     (csrc/gemm_x3p.hip, planes.py): mode 0: x2 (R,K) w2 (N,K)^T (+bias) -> (R,N); mode 1: x2 (R,N)
     w2 (N,K) -> (R,K); then (* act'(act_src)) (+ resid2); with act2 a second output act2(result).
@@ -1419,16 +1335,6 @@ def x3p_matmul(mode, x2, w2, bias=None, resid2=None, act_src=None, act_kind=None
                                       _vp(resid2), 0 if resid2 is None else resid2.stride(0), _vp(act_src),
                                       act_src.stride(0), _ACTK[act_kind], tile or X3P["tile"], _vp(stats),
                                       bal[0], bal[1], bal[2], bal[3], bal[4], N.stream())
-    elif colstats is not None:
-        rc = N.lib().s2t_gemm_x3p_stats(_vp(x2), x2.stride(0), ctypes.c_void_p(pp), cols, inner, _vp(out),
-                                        cols, R, _vp(bias), _vp(resid2),
-                                        0 if resid2 is None else resid2.stride(0), _vp(act_src),
-                                        0 if act_src is None else act_src.stride(0), _ACTK[act_kind],
-                                        _vp(out2), cols, _ACTK[act2], _vp(resid_b),
-                                        0 if resid_b is None else resid_b.stride(0),
-                                        tile or X3P["tile"], _vp(colstats.buf), N.stream())
-        if rc == 0:
-            colstats.ok, colstats.out = True, out
     else:
         rc = N.lib().s2t_gemm_x3p(_vp(x2), x2.stride(0), ctypes.c_void_p(pp), cols, inner, _vp(out), cols, R,
                                   _vp(bias), _vp(resid2), 0 if resid2 is None else resid2.stride(0),
@@ -1473,7 +1379,7 @@ _BAL_EPI = os.environ.get("S2T_BAL_EPI", "1") == "1"
 
 
 def lt_matmul(mode, x2, w2, bias=None, resid2=None, act_src=None, act_kind=None, act2=None,
-              resid_b=None, colstats=None, bal=None):
+              resid_b=None, bal=None):
     """Forward / data-gradient product of a Linear with its elementwise neighbours:
       mode 0: x2 (R,K) w2 (N,K)^T (+bias) -> (R,N);  mode 1: x2 (R,N) w2 (N,K) -> (R,K);
       then (* act'(act_src), act_kind "swoosh_l" | "swoosh_r") (+ resid2) (+ resid_b); with act2
@@ -1562,7 +1468,7 @@ def lt_matmul(mode, x2, w2, bias=None, resid2=None, act_src=None, act_kind=None,
         _PLANS[key] = plan
     if plan[0] == "x3p":
         y = x3p_matmul(mode, x2, w2, bias, resid2, act_src, act_kind, act2, plan[1], resid_b, pp,
-                       colstats=colstats, bal=bal)
+                       bal=bal)
         if y is not None:
             return y
     return lib()

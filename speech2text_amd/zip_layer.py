@@ -211,12 +211,8 @@ def _whiten_bwd(mod, x, g, stats):
     return out
 
 
-def _balancer_bwd(mod, x, g, inplace=False, swoosh_l=None, stats=None):
-    return zk.balancer_backward(x, g, *mod.cfg(2), inplace=inplace, swoosh_l=swoosh_l, stats=stats)
-
-
-_bst = zk.BalancerStats.make
-_gcs = zk.GemmColStats.make
+def _balancer_bwd(mod, x, g, inplace=False, swoosh_l=None):
+    return zk.balancer_backward(x, g, *mod.cfg(2), inplace=inplace, swoosh_l=swoosh_l)
 
 
 class _Commit(ctypes.Structure):
@@ -263,25 +259,17 @@ def _ff_fwd(m, dec, x_in):
     # the activation is KEPT for the weight gradient (the reference recomputes it to save memory,
     # scaling.py:1512-1583; 288 GB of HBM make the ~1 GB per step the cheaper side of that trade);
     # it leaves the in-projection's epilogue as a second output (no separate Swoosh pass)
-    # (a Balancer that fires on h / y gets its column statistics from that product's epilogue)
-    sv.bh = _gcs(fb, x_in.device)
-    sv.h, a = zk.lt_matmul(0, x_in, m.in_proj.weight, m.in_proj.bias, act2="swoosh_l", colstats=sv.bh)
+    sv.h, a = zk.lt_matmul(0, x_in, m.in_proj.weight, m.in_proj.bias, act2="swoosh_l")
     sv.a = a
-    sv.y = sv.st = sv.by = None
-    if fb and not (sv.bh is not None and sv.bh.ok):
-        sv.bh = _bst(sv.h)
+    sv.y = sv.st = None
     if not (fw or fp):
         out = zk.lt_matmul(0, a, m.out_proj.weight, m.out_proj.bias, x_in)
     else:
         # the module's own output (for the Whiten / Balancer on it) AND the residual stream after
         # it from one launch
-        sv.by = _gcs(fp, x_in.device)
-        sv.y, out = zk.lt_matmul(0, a, m.out_proj.weight, m.out_proj.bias, act2="add", resid_b=x_in,
-                                 colstats=sv.by)
+        sv.y, out = zk.lt_matmul(0, a, m.out_proj.weight, m.out_proj.bias, act2="add", resid_b=x_in)
         if fw:
             sv.st = zk.WhitenStats(sv.y, m.out_whiten.num_groups)
-        if fp and not (sv.by is not None and sv.by.ok):
-            sv.by = _bst(sv.y)
     return out, sv
 
 
@@ -289,16 +277,14 @@ def _ff_bwd(m, post, dec, sv, x_in, g):
     fb, fw, fp = dec
     gy = g
     if fp:
-        gy = _balancer_bwd(post, sv.y, gy, stats=sv.by)
+        gy = _balancer_bwd(post, sv.y, gy)
     if fw:
         gy = _whiten_bwd(m.out_whiten, sv.y, gy, sv.st)
     W = m.out_proj.weight
     _wgrad(W, m.out_proj.bias, gy, sv.a)
-    if fb and sv.bh is None:                 # Swoosh backward AND the Balancer's update in the dgrad epilogue
+    if fb:                                   # Swoosh backward AND the Balancer's update in the dgrad epilogue
         dh = zk.lt_matmul(1, gy, W, act_src=sv.h, act_kind="swoosh_l", bal=m.hidden_balancer.cfg(2))
-    elif fb:                                 # (statistics variants: the Balancer's own update pass)
-        dh = _balancer_bwd(m.hidden_balancer, sv.h, zk.lt_matmul(1, gy, W), swoosh_l=True, stats=sv.bh)
-    else:                                    # ... or in the data-gradient GEMM's epilogue
+    else:                                    # Swoosh backward in the data-gradient GEMM's epilogue
         dh = zk.lt_matmul(1, gy, W, act_src=sv.h, act_kind="swoosh_l")
     _wgrad(m.in_proj.weight, m.in_proj.bias, dh, x_in)
     return zk.lt_matmul(1, dh, m.in_proj.weight, None, g)
@@ -341,14 +327,10 @@ def _conv_fwd(m, dec, x_in, T, B, chunk_size, k8):
     D = x_in.shape[1]
     if chunk_size >= 0:
         assert m.causal, "Must initialize model with causal=True if you use chunk_size"
-    sv.b1 = _gcs(fb1, x_in.device)
-    sv.u = zk.lt_matmul(0, x_in, m.in_proj.weight, m.in_proj.bias, colstats=sv.b1)          # (R, 2D)
+    sv.u = zk.lt_matmul(0, x_in, m.in_proj.weight, m.in_proj.bias)                          # (R, 2D)
     sv.cp = zk.conv_params(m.depthwise_conv, T, chunk_size)
     sv.y = zk.zipconv_forward(sv.u.view(T, B, 2 * D), D, k8, *sv.cp).view(T * B, D)
     sv.st = zk.WhitenStats(sv.y, m.whiten.num_groups) if fw else None
-    if fb1 and not (sv.b1 is not None and sv.b1.ok):
-        sv.b1 = _bst(sv.u[:, D:])
-    sv.b2 = _bst(sv.y) if fb2 else None
     sv.a = zk.swoosh_forward(sv.y, False)
     return zk.lt_matmul(0, sv.a, m.out_proj.weight, m.out_proj.bias, x_in), sv
 
@@ -358,16 +340,14 @@ def _conv_bwd(m, dec, sv, x_in, g, T, B, k8):
     D = x_in.shape[1]
     W = m.out_proj.weight
     _wgrad(W, m.out_proj.bias, g, sv.a)
-    if fb2 and not fw and sv.b2 is None:     # Swoosh backward AND the Balancer's update in the dgrad epilogue
+    if fb2 and not fw:                       # Swoosh backward AND the Balancer's update in the dgrad epilogue
         dy = zk.lt_matmul(1, g, W, act_src=sv.y, act_kind="swoosh_r", bal=m.balancer2.cfg(2))
-    elif fb2 and not fw:                     # (statistics variants: the Balancer's own update pass)
-        dy = _balancer_bwd(m.balancer2, sv.y, zk.lt_matmul(1, g, W), swoosh_l=False, stats=sv.b2)
-    else:                                    # ... or in the data-gradient GEMM's epilogue
+    else:                                    # Swoosh backward in the data-gradient GEMM's epilogue
         dy = zk.lt_matmul(1, g, W, act_src=sv.y, act_kind="swoosh_r")
         if fw:
             dy = _whiten_bwd(m.whiten, sv.y, dy, sv.st)
         if fb2:
-            dy = _balancer_bwd(m.balancer2, sv.y, dy, stats=sv.b2)
+            dy = _balancer_bwd(m.balancer2, sv.y, dy)
     chunk, K, wc, bc, wk, bk, scale = sv.cp
     plist = (wc, bc, wk, bk, scale)
     grads = zk.direct_grads(plist)
@@ -379,7 +359,7 @@ def _conv_bwd(m, dec, sv, x_in, g, T, B, k8):
         if p is not None:
             flat.grad_written(p)
     if fb1:
-        _balancer_bwd(m.balancer1, sv.u[:, D:], du[:, D:], inplace=True, stats=sv.b1)
+        _balancer_bwd(m.balancer1, sv.u[:, D:], du[:, D:], inplace=True)
     _wgrad(m.in_proj.weight, m.in_proj.bias, du, x_in)
     return zk.lt_matmul(1, du, m.in_proj.weight, None, g)
 
@@ -389,8 +369,7 @@ def _na_fwd(m, dec, x_in, W, T, B):
     sv = _Saved()
     L, st = N.lib(), N.stream()
     dev = x_in.device
-    sv.bu = _gcs(fb, x_in.device)
-    sv.u = zk.lt_matmul(0, x_in, m.in_proj.weight, m.in_proj.bias, colstats=sv.bu)          # (R, 3C) = [s|x|y]
+    sv.u = zk.lt_matmul(0, x_in, m.in_proj.weight, m.in_proj.bias)                          # (R, 3C) = [s|x|y]
     C = sv.u.shape[1] // 3
     sv.xs = torch.empty((B, T, C), dtype=_F32, device=dev)
     N.PROF[0] and N.profile_note("s2t_nonlin_gate_fwd", 12.0 * T * B * C)
@@ -402,19 +381,13 @@ def _na_fwd(m, dec, x_in, W, T, B):
     N.check(L.s2t_nonlin_out_fwd(N.fp(sv.z), N.fp(sv.u), T, B, C, N.fp(sv.o), st),
             "nonlin_out_fwd")
     sv.st1 = zk.WhitenStats(sv.u[:, C:2 * C], m.whiten1.num_groups) if fw1 else None
-    if fb and not (sv.bu is not None and sv.bu.ok):
-        sv.bu = _bst(sv.u[:, :C])
-    sv.y = sv.st2 = sv.by = None
+    sv.y = sv.st2 = None
     if not (fw2 or fp):
         out = zk.lt_matmul(0, sv.o, m.out_proj.weight, m.out_proj.bias, x_in)
     else:
-        sv.by = _gcs(fp, x_in.device)
-        sv.y, out = zk.lt_matmul(0, sv.o, m.out_proj.weight, m.out_proj.bias, act2="add", resid_b=x_in,
-                                 colstats=sv.by)
+        sv.y, out = zk.lt_matmul(0, sv.o, m.out_proj.weight, m.out_proj.bias, act2="add", resid_b=x_in)
         if fw2:
             sv.st2 = zk.WhitenStats(sv.y, m.whiten2.num_groups)
-        if fp and not (sv.by is not None and sv.by.ok):
-            sv.by = _bst(sv.y)
     return out, sv
 
 
@@ -424,7 +397,7 @@ def _na_bwd(m, post, dec, sv, x_in, g, T, B):
     L, st = N.lib(), N.stream()
     gy = g
     if fp:
-        gy = _balancer_bwd(post, sv.y, gy, stats=sv.by)
+        gy = _balancer_bwd(post, sv.y, gy)
     if fw2:
         gy = _whiten_bwd(m.whiten2, sv.y, gy, sv.st2)
     _wgrad(m.out_proj.weight, m.out_proj.bias, gy, sv.o)
@@ -440,7 +413,7 @@ def _na_bwd(m, post, dec, sv, x_in, g, T, B):
     N.PROF[0] and N.profile_note("s2t_nonlin_gate_bwd", 20.0 * T * B * C)
     N.check(L.s2t_nonlin_gate_bwd(N.fp(dxs), N.fp(sv.u), T, B, C, N.fp(du), st), "nonlin_gate_bwd")
     if fb:
-        _balancer_bwd(m.balancer, sv.u[:, :C], du[:, :C], inplace=True, stats=sv.bu)
+        _balancer_bwd(m.balancer, sv.u[:, :C], du[:, :C], inplace=True)
     if fw1:
         du[:, C:2 * C] = _whiten_bwd(m.whiten1, sv.u[:, C:2 * C], du[:, C:2 * C].contiguous(),
                                      sv.st1)
@@ -486,13 +459,10 @@ class _LayerFn(torch.autograd.Function):
         s.d, s.dims, s.x0, s.a8, s.k8 = d, (T, B, D, H, qd, pd), x0, a8, k8
 
         # attention weights (reference zipformer.py:1966-2066)
-        s.kbst = _gcs(d.k_bal, dev)
-        s.qkp = zk.lt_matmul(0, x0, sa.in_proj.weight, sa.in_proj.bias, colstats=s.kbst)
+        s.qkp = zk.lt_matmul(0, x0, sa.in_proj.weight, sa.in_proj.bias)
         s.kst = None
         if d.k_wh:
             s.kst = zk.WhitenStats(s.qkp[:, H * qd:2 * H * qd], sa.whiten_keys.num_groups)
-        if d.k_bal and not (s.kbst is not None and s.kbst.ok):
-            s.kbst = _bst(s.qkp[:, H * qd:2 * H * qd])
         s.pos2 = s.posp = None
         if d.use_pos:
             s.pos2 = pos_emb.reshape(2 * T - 1, -1).contiguous().float()
@@ -530,7 +500,6 @@ class _LayerFn(torch.autograd.Function):
         x7, s.sa2 = _sa_fwd(layer.self_attn2, d.sa2, x6, W, T, B, H)
         x8, s.cv2 = _conv_fwd(layer.conv_module2, d.cv2, x7, T, B, chunk_size, k8)
         x9, s.ff3 = _ff_fwd(layer.feed_forward3, d.ff3, x8)
-        s.bst1 = _bst(x9) if d.bal1 else None
         norm = layer.norm
         x10 = _e(R, D, dev)
         s.nscales = torch.empty(R, dtype=_F32, device=dev)
@@ -550,7 +519,6 @@ class _LayerFn(torch.autograd.Function):
             N.check(L.s2t_bypass_fwd(N.fp(x0), N.fp(x10), N.fp(layer.bypass.bypass_scale), R, D,
                                      N.fp(x11), st), "s2t_bypass_fwd")
         s.wst = zk.WhitenStats(x11, layer.whiten.num_groups) if d.wh_out else None
-        s.bst2 = _bst(x11) if d.bal2 else None
         s.x = (x1, x2, x3, x4, x5, x6, x7, x8, x9, x10, x11)
         ctx.s, ctx.layer = s, layer
         out = x11.view(T, B, D)
@@ -578,7 +546,7 @@ class _LayerFn(torch.autograd.Function):
         if d.wh_out:
             g = _whiten_bwd(layer.whiten, x11, g, s.wst)
         if d.bal2:
-            g = _balancer_bwd(layer.balancer2, x11, g, stats=s.bst2)
+            g = _balancer_bwd(layer.balancer2, x11, g)
         # per-channel parameter gradients: [bypass scale | bypass_mid scale | norm bias | log_scale]
         acc = _layer_acc(dev, D)
         off = lambda n: ctypes.c_void_p(acc.data_ptr() + 4 * n)      # noqa: E731
@@ -601,7 +569,7 @@ class _LayerFn(torch.autograd.Function):
         N.check(L.s2t_biasnorm_bwd(N.fp(x9), N.fp(norm.bias), N.fp(s.nscales), N.fp(g10), R, D,
                                    N.fp(g9), off(2 * D), off(3 * D), st), "biasnorm_bwd")
         if d.bal1:
-            g9 = _balancer_bwd(layer.balancer1, x9, g9, stats=s.bst1)
+            g9 = _balancer_bwd(layer.balancer1, x9, g9)
 
         pairs = []
         g8 = _ff_bwd(layer.feed_forward3, layer.balancer_ff3, d.ff3, s.ff3, x8, g9)
@@ -654,7 +622,7 @@ class _LayerFn(torch.autograd.Function):
             if d.k_wh:
                 gk = _whiten_bwd(sa.whiten_keys, s.qkp[:, ks], gk, s.kst)
             if d.k_bal:
-                gk = _balancer_bwd(sa.balance_keys, s.qkp[:, ks], gk, stats=s.kbst)
+                gk = _balancer_bwd(sa.balance_keys, s.qkp[:, ks], gk)
             dqkp[:, ks] = gk
         if dpos is not None:
             _wgrad(sa.linear_pos.weight, None, dpos, s.pos2)

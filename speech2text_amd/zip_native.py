@@ -290,8 +290,7 @@ def _side_handle():
 
 def usable(layer, T, B):
     """Can the native executor serve this layer call?  (zip_layer.eligible has passed already.)"""
-    if not ENABLED or N._Prof.target == "*" or zk._BAL_GEMM or zk._BAL_FWD \
-            or "S2T_ATTN_FWD_OLD" in os.environ:
+    if not ENABLED or N._Prof.target == "*" or "S2T_ATTN_FWD_OLD" in os.environ:
         return None
     L = _static(layer)
     if not L.ok:
@@ -328,7 +327,7 @@ def _fill_call(L, T, B, D, chunk_size, x0, pos2, a8, k8, fm, dec, dev):
     c.whiten_x3p, c.whiten_x3p_rows = int(zk._WHITEN_X3P), int(zk._WHITEN_X3P_ROWS)
     side = zk._Side.enabled
     c.conv_w_side = int(zk._CONV_W_SIDE and side)
-    c.conv_fused = int(bool(os.environ.get("S2T_CONV_FUSED")))
+    c.conv_fused = 0                      # (the one-kernel conv backward: removed in round 5)
     c.stats_side = int(zk._STATS_SIDE and side)
     c.wgrad_side = int(side)
     c.bmm_own = int(zk._BMM_OWN)

@@ -33,10 +33,16 @@ def test_bench_line_contract_and_roofline_rows(dev, cfg):
     # every row of the per-entry table must stay below its roofline: a fraction above 1 means the
     # algorithmic bytes / flops were noted under the wrong entry (round-2 verdict, item 9)
     assert len(rf["kernels"]) >= 10
+    # (an entry that multiplies on the bf16 matrix cores with the six-product split may exceed the
+    # f32-MFMA peak the table quotes -- the implicit-operand conv GEMM does, 158 TFLOP/s -- and is
+    # held to the six-product ceiling instead)
     for row in rf["kernels"]:
         for key in ("frac_hbm", "frac_mfma"):
             if row.get(key) is not None:
-                assert 0 <= row[key] <= 1.0, (row["entry"], key, row[key])
+                top = 1.0 if (key == "frac_hbm" or "frac_bf16x3_ceiling" not in row) else 2.65
+                assert 0 <= row[key] <= top, (row["entry"], key, row[key])
+        if "frac_bf16x3_ceiling" in row:
+            assert 0 <= row["frac_bf16x3_ceiling"] <= 1.0, (row["entry"], row["frac_bf16x3_ceiling"])
     # the step's own fraction of the f32 MFMA peak
     assert 0 < rf["step_mfma"]["frac"] < 1.0
     # no blind rows -- every entry that costs >= 0.1 ms per step carries its

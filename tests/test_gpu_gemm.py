@@ -212,86 +212,6 @@ def test_lt_plan_cache_survives_dynamic_batching(dev):
     assert (y.double() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
 
 
-@pytest.mark.parametrize("M,K,N", [(4097, 256, 768), (1001, 136, 72), (15872, 960, 256), (300, 8, 40)])
-def test_bf16x3_split_gemm_has_fp32_accuracy(dev, M, K, N):
-    """s2t_gemm_x3_nt: fp32 operands split exactly into three bf16 pieces, six bf16 MFMA products
-    with fp32 accumulation (csrc/gemm_x3.hip; verified, not on the step's path).  Its error
-    against fp64 must not exceed the fp32 library GEMM's; bias + residual epilogue included; the
-    planes reproduce the weights to the last bit."""
-    from speech2text_amd import _native as Nt
-    from speech2text_amd import zip_kernels as zk
-    L = Nt.lib()
-    g = torch.Generator().manual_seed(M + K)
-    x = (torch.randn(M, K, generator=g) * torch.logspace(-3, 3, K)).to(dev)     # wide dynamic range
-    W = (torch.randn(N, K, generator=g) * 0.1).to(dev)
-    b = torch.randn(N, generator=g).to(dev)
-    res = torch.randn(M, N, generator=g).to(dev)
-    n = W.numel()
-    pl = torch.empty(3 * n, dtype=torch.int16, device=dev)
-    Nt.check(L.s2t_split_planes(Nt.fp(W), n, Nt.raw(pl), n, Nt.stream()), "split")
-    pieces = pl.view(3, n).view(torch.bfloat16).float()
-    assert torch.equal((pieces[0].double() + pieces[1].double() + pieces[2].double()).float(),
-                       W.reshape(-1)), "the three bf16 pieces must add up to the fp32 value exactly"
-    y = torch.empty(M, N, device=dev)
-    Nt.check(L.s2t_gemm_x3_nt(Nt.fp(x), K, Nt.raw(pl), K, n, Nt.fp(y), N, M, N, K, Nt.fp(b), Nt.fp(res), N,
-                              0.5, Nt.stream()), "x3")
-    ref = torch.nn.functional.linear(x.double(), W.double(), b.double()) + 0.5 * res.double()
-    lib = zk.lt_matmul(0, x, W, b).double() + 0.5 * res.double()
-    scale = ref.abs().max().item()
-    e_x3 = (y.double() - ref).abs().max().item() / scale
-    e_lib = (lib - ref).abs().max().item() / scale
-    assert e_x3 <= max(1.5 * e_lib, 2e-7), (e_x3, e_lib)
-    # transposed planes of a table of matrices (the data-gradient operand)
-    import numpy as np
-    rec = np.zeros(1, dtype=[("off", "<i8"), ("R", "<i4"), ("C", "<i4"), ("tb", "<i4"), ("pad", "<i4")])
-    rec["off"], rec["R"], rec["C"], rec["tb"] = 0, N, K, 0
-    dt = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
-    plt_ = torch.empty(3 * n, dtype=torch.int16, device=dev)
-    tiles = ((N + 31) // 32) * ((K + 31) // 32)
-    Nt.check(L.s2t_split_planes_t(Nt.fp(W), Nt.raw(dt), 1, tiles, Nt.raw(plt_), n, Nt.stream()), "split_t")
-    pt = plt_.view(3, K, N).view(torch.bfloat16).double().sum(0).float()
-    assert torch.equal(pt, W.t().contiguous())
-
-
-@pytest.mark.parametrize("M,K,N", [(4097, 256, 768), (1000, 192, 96), (15872, 960, 256), (130, 16, 32)])
-def test_bf16x3_pipelined_gemm_has_fp32_accuracy(dev, M, K, N):
-    """s2t_gemm_x3f_nt (csrc/gemm_x3f.hip: fragment-major bf16 pieces, LDS-DMA rings; verified, not
-    on the step's path): error against fp64 within the fp32 library's, for every tile width, with
-    the bias + residual epilogue, a ragged last row tile and a column tile that overhangs N; the
-    transposed-source pieces (data-gradient operand) give the same product."""
-    from speech2text_amd import _native as Nt
-    from speech2text_amd import zip_kernels as zk
-    L = Nt.lib()
-    g = torch.Generator().manual_seed(M + 3 * K)
-    x = (torch.randn(M, K, generator=g) * torch.logspace(-2, 2, K)).to(dev)
-    W = (torch.randn(N, K, generator=g) * 0.1).to(dev)
-    b = torch.randn(N, generator=g).to(dev)
-    res = torch.randn(M, N, generator=g).to(dev)
-    assert L.s2t_split_planes_frag_elems(N, K) == 3 * N * K
-    pf = torch.empty(3 * N * K, dtype=torch.int16, device=dev)
-    Nt.check(L.s2t_split_planes_frag(Nt.fp(W), K, N, K, 0, Nt.raw(pf), Nt.stream()), "split_frag")
-    Wt = W.t().contiguous()                                   # (K,N) storage of the same matrix
-    pft = torch.empty_like(pf)
-    Nt.check(L.s2t_split_planes_frag(Nt.fp(Wt), N, N, K, 1, Nt.raw(pft), Nt.stream()), "split_frag(T)")
-    assert torch.equal(pf, pft)
-    # the pieces of element (n, k) add up to it exactly
-    v = pf.view(N // 32, K // 16, 3, 2, 32, 8).view(torch.bfloat16).double().sum(dim=2)   # nt,kb,hi,lo,e
-    back = v.permute(0, 3, 1, 2, 4).reshape(N, K).float()
-    assert torch.equal(back, W)
-    ref = torch.nn.functional.linear(x.double(), W.double(), b.double()) + 0.5 * res.double()
-    lib = zk.lt_matmul(0, x, W, b).double() + 0.5 * res.double()
-    scale = ref.abs().max().item()
-    e_lib = (lib - ref).abs().max().item() / scale
-    for tnw in (0, 1, 2, 3, 4):
-        y = torch.full((M, N), float("nan"), device=dev)
-        Nt.check(L.s2t_gemm_x3f_nt(Nt.fp(x), K, Nt.raw(pf), Nt.fp(y), N, M, N, K, Nt.fp(b), Nt.fp(res), N,
-                                   0.5, tnw, Nt.stream()), "x3f")
-        e = (y.double() - ref).abs().max().item() / scale
-        assert e <= max(1.5 * e_lib, 2e-7), (tnw, e, e_lib)
-    assert L.s2t_gemm_x3f_nt(Nt.fp(x), K, Nt.raw(pf), Nt.fp(y), N, M, N, 24, None, None, 0, 0.0, 0,
-                             Nt.stream()) == -2               # K % 16 != 0: caller uses the library
-
-
 @pytest.mark.parametrize("R,Nf,Mf", [(31680, 384, 192), (5000, 768, 256), (1234, 68, 500), (257, 8, 12)])
 def test_tn_on_bf16_matrix_cores_has_fp32_accuracy(dev, R, Nf, Mf):
     """The weight-gradient contraction dW = g^T x (+ column sums) in its two arithmetic forms
@@ -395,14 +315,12 @@ def test_x3p_gemm_has_fp32_accuracy(dev, M, K, N):
         e_lib = (lib - ref).abs().max().item() / scale
         # (1000 + 100 w + tile: w persistent workgroups per CU, the output of a tile stored in
         # slices under the next tile's multiplications -- active where a workgroup gets > 1 tile)
-        # 33: the producer / consumer form (8-wave workgroups, 128 x 128 tiles)
         # 2000 + tile: the LDS-DMA form (weight pieces global -> LDS directly; 3 / 4 / 4 / 5 workgroups per CU)
-        for tile in (0, 22, 21, 12, 11, 33, 1111, 1112, 1121, 1122, 1211, 2022, 2021, 2012, 2011):
+        for tile in (0, 22, 21, 12, 11, 1111, 1112, 1121, 1122, 1211, 2022, 2021, 2012, 2011):
             y = zk.x3p_matmul(mode, a, W, bias, res, tile=tile)
             kc = N if mode == 1 else K
-            if kc % 8 or (tile == 33 and (kc + 15) // 16 < 10):
-                # contraction not a multiple of 8: library path; the producer / consumer form needs
-                # 10 stages per tile to drain its output tile under the next one
+            if kc % 8:
+                # contraction not a multiple of 8: library path
                 assert y is None
                 continue
             assert y is not None, (mode, tile)
@@ -422,7 +340,7 @@ def test_x3p_fused_epilogues(dev):
     Mb = 40000
     xb = torch.randn(Mb, K, generator=g).to(dev)
     rb = torch.randn(Mb, N, generator=g).to(dev)
-    for tile in (1112, 1121, 1122, 1111, 33, 2022, 2021, 2012, 2011):
+    for tile in (1112, 1121, 1122, 1111, 2022, 2021, 2012, 2011):
         y, y2 = zk.x3p_matmul(0, xb, W, b, None, act2="add", resid_b=rb, tile=tile)
         yref = torch.nn.functional.linear(xb.double(), W.detach().double(), b.detach().double())
         _close(y, yref)

@@ -103,34 +103,6 @@ def test_executor_matches_module_path(dev, monkeypatch, force, big, chunk, left)
         assert zip_layer.STATS["penalty_active"] > active0
 
 
-@pytest.mark.parametrize("flag", ["_BAL_FWD", "_BAL_GEMM"])
-def test_executor_with_forward_balancer_statistics(dev, monkeypatch, flag):
-    """zk.BalancerStats (column statistics taken in forward on the side stream) and
-    zk.GemmColStats (taken in the epilogue of the GEMM that writes the tensor) -- both off by
-    default, measured no gain / slower: same outputs and gradients as the two-pass form, every
-    Balancer firing."""
-    from speech2text_amd import rng, zip_kernels as zk
-    monkeypatch.setattr(rng, "rand", lambda *s, device=None, dtype=torch.float32:
-                        torch.rand(*s, dtype=dtype).to(device))
-    m, store = _build(dev, (-1,), (-1,))
-    g = torch.Generator().manual_seed(3)
-    x = (torch.randn(3, 150, 80, generator=g) * 2).to(dev)
-    lens = torch.tensor([150, 120, 77]).to(dev)
-    with torch.no_grad():
-        wts = torch.randn(m(x, lens)[0].shape, generator=g).to(dev)
-    outs = []
-    for on in (False, True):
-        monkeypatch.setattr(zk, flag, on)
-        _force(m, True)
-        outs.append(_step(m, store, x, lens, wts, 1, True))
-    # (two runs of ONE form already differ in the last bits: column statistics and weight
-    # gradients are summed with fp32 atomics)
-    torch.testing.assert_close(outs[0][0], outs[1][0], atol=2e-5, rtol=1e-4)
-    torch.testing.assert_close(outs[0][1], outs[1][1], atol=2e-5, rtol=2e-3)
-    scale = outs[0][2].abs().max()
-    assert (outs[0][2] - outs[1][2]).abs().max() / scale < 2e-4
-
-
 @pytest.mark.parametrize("chunk,left", [((-1,), (-1,)), ((8,), (16,))])
 @pytest.mark.parametrize("rv", [0.0, 0.2, 0.5])
 def test_native_executor_matches_python_executor(dev, monkeypatch, rv, chunk, left):
