@@ -817,7 +817,7 @@ void x3p_db_kernel(X3P g) {
 //                  fragments of stage kb;  split A(kb+1) (the compiler's wait: only A is in flight);
 //                  DMA B(kb+1) -> buffer (kb+1) & 1;  request A(kb+2);  first products;
 //                  store A(kb+1)'s pieces -> buffer (kb+1) & 1;  the other products.
-// (the form csrc/gemm_x3f.hip has run with since round 3: per-lane 64-bit address, no SGPR base)
+// (per-lane 64-bit address, no SGPR base: the form the round-3 LDS-DMA kernel ran with)
 __device__ __forceinline__ void x3p_glds16(const void* g, unsigned lds_addr) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_addr)
                : "memory");     // (m0 is reserved: the compiler keeps nothing in it across statements)
