@@ -323,6 +323,18 @@ int s2t_gemm_f32(int mode, const float* A, long lda, const float* B, long ldb, f
 int s2t_gemm_f32_batched(int mode, const float* A, long lda, long sA, const float* B, long ldb, long sB,
                          float* C, long ldc, long sC, int M, int N, int K, int batch, void* stream);
 
+/* s2t_gemm_f32 modes 0 / 1 (bias only) that also ADDS sums[0] += ||other||_F^2 and sums[1] += ||C||_F^2,
+ * other = an (M, N) matrix with rows ld_other apart: the two norms Whiten's backward combines
+ * (reference model/layer/scaling.py:1024-1027: x_grad + |x_grad| / |penalty_grad| * grad_scale *
+ * penalty_grad), taken while C = x dcov + bias leaves the accumulators instead of by a pass over both
+ * tensors.  s2t_whiten_combine is the update that follows (s2t_whiten_apply without its own sums
+ * pass).  -2: operands outside the 16-byte epilogue's rules (run s2t_gemm_f32 + s2t_whiten_apply). */
+int s2t_gemm_f32_sq(int mode, const float* A, long lda, const float* B, long ldb, float* C, long ldc,
+                    int M, int N, int K, const float* bias, const float* other, long ld_other,
+                    float* sums, void* stream);
+int s2t_whiten_combine(const float* g, const float* pg, long numel, float grad_scale, const float* sums,
+                       float* out, void* stream);
+
 /* s2t_gemm_f32 modes 0 (NT) / 1 (NN) with the block tile chosen by the caller: tile = "tm tn"
  * digits for a (64 tm) x (64 tn) tile, one of 11 12 21 22 23; 0 = the dispatcher's choice. */
 int s2t_gemm_f32_tiled(int mode, const float* A, long lda, const float* B, long ldb, float* C,
@@ -850,6 +862,7 @@ typedef struct S2tZipLayerCall {
   long whiten_x3p_rows;
   int conv_w_side, conv_fused, stats_side, wgrad_side, bmm_own;
   int bal_epi;                     /* hidden Balancers in the dgrad epilogue (s2t_gemm_x3p_bal) */
+  int whiten_sq;                   /* Whiten's norms in the x dcov product's epilogue (s2t_gemm_f32_sq) */
 } S2tZipLayerCall;
 long s2t_zip_layer_state_bytes(void);
 long s2t_zip_layer_ws_floats(const S2tZipLayerDesc* desc, const S2tZipLayerCall* call, int backward);

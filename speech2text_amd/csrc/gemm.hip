@@ -90,6 +90,12 @@ struct GemmArgs {
   int tile_force;         // NT / NN: 0 = dispatch's choice, else "tm tn" digits (11 12 21 22 23)
   int wide_ep;            // NT / NN: rows of C / residual / bias 16-byte aligned -> float4 epilogue
   Patch pt;               // PATCH kernels: A (NT) or B (TN) is the implicit patch matrix of pt
+  // NT / NN, 16-byte epilogue only (s2t_gemm_f32_sq): sq_sums[0] += sum of squares of the (M, N)
+  // matrix sq_other (rows ld_sq apart), sq_sums[1] += sum of squares of C as stored -- the two norms
+  // Whiten's backward needs (scaling.py:1024-1027), taken while C leaves the accumulators
+  const float* sq_other;
+  long ld_sq;
+  float* sq_sums;
 };
 
 __device__ __forceinline__ float log1p_fast(float e) {   // as zip_elem.hip
@@ -698,6 +704,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const unsigned bid)
     __syncthreads();                                   // all waves finished reading sA / sB
     float* scr = sA + wave * (16 * 36);                // 16 rows at a time: 4 x 2.3 KB fit in sA
     const int er = lane >> 3, ec = (lane & 7) * 4;     // this lane's row (of 8) and column quad
+    float sq_c = 0.f, sq_o = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -724,15 +731,32 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const unsigned bid)
           for (int q = 0; q < 2; ++q) {
             const int row = m0 + wm + 32 * i + 16 * h + er + 8 * q;
             const float4 v = *reinterpret_cast<const float4*>(scr + (er + 8 * q) * 36 + ec);
-            if (row < g.M && col < g.N)
-              *reinterpret_cast<float4*>(g.C + (long)row * g.ldc + col) =
-                  make_float4(v.x + bv.x + rv[q].x, v.y + bv.y + rv[q].y, v.z + bv.z + rv[q].z,
-                              v.w + bv.w + rv[q].w);
+            if (row < g.M && col < g.N) {
+              const float4 o = make_float4(v.x + bv.x + rv[q].x, v.y + bv.y + rv[q].y, v.z + bv.z + rv[q].z,
+                                           v.w + bv.w + rv[q].w);
+              *reinterpret_cast<float4*>(g.C + (long)row * g.ldc + col) = o;
+              if (g.sq_sums) {
+                const float4 t = *reinterpret_cast<const float4*>(g.sq_other + (long)row * g.ld_sq + col);
+                sq_c += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+                sq_o += (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w);
+              }
+            }
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
           __builtin_amdgcn_wave_barrier();
         }
       }
+    if (g.sq_sums) {                                   // one atomic pair per workgroup
+      sq_c = wave_sum(sq_c);
+      sq_o = wave_sum(sq_o);
+      __syncthreads();
+      if (lane == 0) { sB[2 * wave] = sq_o; sB[2 * wave + 1] = sq_c; }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        atomicAdd(g.sq_sums, (sB[0] + sB[2]) + (sB[4] + sB[6]));
+        atomicAdd(g.sq_sums + 1, (sB[1] + sB[3]) + (sB[5] + sB[7]));
+      }
+    }
     return;
   }
 #pragma unroll
@@ -1046,6 +1070,32 @@ extern "C" int s2t_gemm_f32(int mode, const float* A, long lda, const float* B, 
 // X_b = X + b * sX floats.  Same alignment rules as s2t_gemm_f32 (every k-contiguous operand needs
 // K % 4 == 0, every row start 16-byte aligned, strides included): -2 when they do not hold -- the
 // caller keeps the library for such shapes (T = 495, 62 of the C3 stacks).
+// s2t_gemm_f32 modes 0 / 1 (no residual / activation) that also ADDS sums[0] += ||other||_F^2 and
+// sums[1] += ||C||_F^2 (other: an (M, N) matrix, rows ld_other apart): Whiten's backward needs both norms
+// of (g, x dcov) before it can combine them (reference model/layer/scaling.py:1024-1027).
+// -2: operands outside the 16-byte epilogue's rules (the caller runs the separate pass).
+extern "C" int s2t_gemm_f32_sq(int mode, const float* A, long lda, const float* B, long ldb, float* C,
+                               long ldc, int M, int N, int K, const float* bias, const float* other,
+                               long ld_other, float* sums, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || !other || !sums || (mode != MODE_NT && mode != MODE_NN)) return -1;
+  const bool b_kc = mode == MODE_NT;
+  if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15) || (lda & 3) || (ldb & 3) ||
+      (K & 3) || (!b_kc && (N & 3)) || M < 4 || N < 4 || K < 4)
+    return -2;
+  if ((N & 3) || (ldc & 3) || (ld_other & 3) || (reinterpret_cast<uintptr_t>(C) & 15) ||
+      (reinterpret_cast<uintptr_t>(other) & 15) || (bias && (reinterpret_cast<uintptr_t>(bias) & 15)))
+    return -2;
+  static const bool wide_on = [] { const char* e = getenv("S2T_GEMM_WIDE_EP"); return !e || atoi(e) != 0; }();
+  if (!wide_on) return -2;
+  GemmArgs g{A, lda, B, ldb, C, ldc, M, N, K, bias, nullptr, 0, nullptr, 0, 0, 0,
+             0, nullptr, 0, 0, 0, 0, 0, 0, 1.f, 0};
+  g.sq_other = other;
+  g.ld_sq = ld_other;
+  g.sq_sums = sums;
+  hipStream_t st = (hipStream_t)stream;
+  return mode == MODE_NT ? dispatch<MODE_NT>(g, st) : dispatch<MODE_NN>(g, st);
+}
+
 extern "C" int s2t_gemm_f32_batched(int mode, const float* A, long lda, long sA, const float* B,
                                     long ldb, long sB, float* C, long ldc, long sC, int M, int N,
                                     int K, int batch, void* stream) {

@@ -262,6 +262,21 @@ extern "C" int s2t_whiten_apply(const float* g, const float* pg, long numel, flo
   return 0;
 }
 
+// the update alone: sums = (||g||^2, ||pg||^2) were taken by the product that wrote pg (s2t_gemm_f32_sq)
+extern "C" int s2t_whiten_combine(const float* g, const float* pg, long numel, float grad_scale,
+                                  const float* sums, float* out, void* stream) {
+  if (numel <= 0) return 0;
+  if (!sums || ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(pg) |
+                 reinterpret_cast<uintptr_t>(out)) & 15))
+    return -1;
+  const long n4 = numel >> 2;
+  const unsigned blocks = (unsigned)std::min<long>(2048, std::max<long>(1, (n4 + 255) / 256));
+  hipLaunchKernelGGL(whiten_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, pg,
+                     numel, grad_scale, sums, out);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int s2t_limit_param_grad(const float* x, const float* g, float lo, float hi, long n,
                                     float* out, void* stream) {
   if (n <= 0) return 0;

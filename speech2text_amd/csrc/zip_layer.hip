@@ -351,6 +351,15 @@ int whiten_bwd(Ctx& c, int site, const S2tZlWh& w, WStat& s, const float* x, lon
     if (rc == 0) done = true;
     else if (rc != -2) return fail(rc, "s2t_gemm_x3p(whiten)");
   }
+  if (!done && c.c.whiten_sq) {      // the two norms of (g, pg) from the product's own epilogue
+    const int rc = s2t_gemm_f32_sq(1, x, ldx, dcov, C, pg, C, (int)R, C, C, bias, g, C, sums, (void*)c.st);
+    if (rc == 0) {
+      RUN(s2t_whiten_combine(g, pg, R * C, w.grad_scale, sums, o, (void*)c.st));
+      *out = o;
+      return 0;
+    }
+    if (rc != -2) return fail(rc, "s2t_gemm_f32_sq(whiten)");
+  }
   if (!done)
     RUN(s2t_gemm_f32(1, x, ldx, dcov, C, pg, C, (int)R, C, C, bias, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, 0,
                      (void*)c.st));

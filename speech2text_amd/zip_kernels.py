@@ -351,7 +351,11 @@ class WhitenStats:
         return float(self.host[0])
 
 
-_WHITEN_X3P = os.environ.get("S2T_WHITEN_X3P", "1") == "1"
+# (round 5: off -- the NN kernel that takes the two norms in its epilogue (below) beats the bf16x3
+# product + a separate norm pass also for the 31 680-row activations: 37.61 against 37.72 ms/step)
+_WHITEN_X3P = os.environ.get("S2T_WHITEN_X3P", "0") == "1"
+# the norms of (g, x dcov) taken in the product's epilogue (s2t_gemm_f32_sq) instead of by a pass over both
+_WHITEN_SQ = os.environ.get("S2T_WHITEN_SQ", "1") == "1"
 # measured (tools/bench_side.py whiten): 73 against 94 us at 31 680 x 192, but 62 against 58 at
 # 15 872 x 256 (the piece-split launch costs what the faster product saves)
 _WHITEN_X3P_ROWS = int(os.environ.get("S2T_WHITEN_X3P_ROWS", "24000"))
@@ -385,9 +389,27 @@ def whiten_backward(x, g, stats, limit, grad_scale):
         pp = planes.adhoc_pieces(dcov, 1)
         if pp is not None:
             pg = x3p_matmul(1, xf, dcov, bias, pp=pp)
+    g2 = g.contiguous().float()
+    if g2.data_ptr() % 16:
+        g2 = g2.clone()
+    out = torch.empty_like(g2)
     if pg is None:
-        # (our NN kernel with the bias in its epilogue: the same call csrc/zip_layer.hip makes)
+        # (our NN kernel with the bias in its epilogue: the same calls csrc/zip_layer.hip makes);
+        # first the form that takes the two norms of (g, pg) while pg leaves the accumulators
         pg = torch.empty((xf.shape[0], C), dtype=torch.float32, device=dev)
+        if _WHITEN_SQ and xf.stride(1) == 1:
+            N.PROF[0] and N.profile_note("s2t_gemm_f32_sq", 4.0 * (xf.numel() + 2 * pg.numel() + C * C),
+                                         2.0 * xf.shape[0] * C * C)
+            rc = N.lib().s2t_gemm_f32_sq(1, N.raw(xf, torch.float32), xf.stride(0), N.fp(dcov), C, N.fp(pg), C,
+                                         xf.shape[0], C, C, N.fp(bias), N.fp(g2.view(-1, C)), C, N.fp(sums),
+                                         N.stream())
+            if rc == 0:
+                N.PROF[0] and N.profile_note("s2t_whiten_combine", 12.0 * g2.numel())
+                N.check(N.lib().s2t_whiten_combine(N.fp(g2), N.fp(pg), g2.numel(), float(grad_scale),
+                                                   N.fp(sums), N.fp(out), N.stream()), "s2t_whiten_combine")
+                return out.view(shp), True
+            if rc != -2:
+                N.check(rc, "s2t_gemm_f32_sq(whiten)")
         N.PROF[0] and N.profile_note("s2t_gemm_f32", 4.0 * (xf.numel() + pg.numel() + C * C), 2.0 * xf.shape[0] * C * C)
         rc = N.lib().s2t_gemm_f32(1, N.raw(xf, torch.float32), xf.stride(0), N.fp(dcov), C, N.fp(pg), C,
                                   xf.shape[0], C, C, N.fp(bias), None, 0, None, 0, 0, 0, 0, None, 0,
@@ -396,10 +418,6 @@ def whiten_backward(x, g, stats, limit, grad_scale):
             pg = torch.addmm(bias, xf, dcov)
         else:
             N.check(rc, "s2t_gemm_f32(whiten)")
-    g2 = g.contiguous().float()
-    if g2.data_ptr() % 16:
-        g2 = g2.clone()
-    out = torch.empty_like(g2)
     N.PROF[0] and N.profile_note("s2t_whiten_apply", 12.0 * g2.numel())
     N.check(N.lib().s2t_whiten_apply(N.fp(g2), N.fp(pg), g2.numel(), float(grad_scale), N.fp(sums),
                                      N.fp(out), N.stream()), "s2t_whiten_apply")

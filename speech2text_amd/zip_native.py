@@ -90,7 +90,8 @@ class Call(ctypes.Structure):
                 ("x3p_on", ctypes.c_int), ("x3p_tile", ctypes.c_int), ("x3p_margin", ctypes.c_float),
                 ("whiten_x3p", ctypes.c_int), ("whiten_x3p_rows", ctypes.c_long),
                 ("conv_w_side", ctypes.c_int), ("conv_fused", ctypes.c_int), ("stats_side", ctypes.c_int),
-                ("wgrad_side", ctypes.c_int), ("bmm_own", ctypes.c_int), ("bal_epi", ctypes.c_int)]
+                ("wgrad_side", ctypes.c_int), ("bmm_own", ctypes.c_int), ("bal_epi", ctypes.c_int),
+                ("whiten_sq", ctypes.c_int)]
 
 
 def _dp(t):
@@ -332,6 +333,7 @@ def _fill_call(L, T, B, D, chunk_size, x0, pos2, a8, k8, fm, dec, dev):
     c.wgrad_side = int(side)
     c.bmm_own = int(zk._BMM_OWN)
     c.bal_epi = int(zk._BAL_EPI)
+    c.whiten_sq = int(zk._WHITEN_SQ)
     return c
 
 

@@ -283,6 +283,32 @@ def test_tn_wave_specialised_form(dev, R, Nf, Mf, pro):
     assert (dW - dW2).abs().max().item() / scale < 2e-6
 
 
+@pytest.mark.parametrize("M,N,K", [(15872, 256, 256), (3968, 512, 512), (1001, 192, 192), (77, 64, 64)])
+def test_nn_gemm_with_the_norms_of_its_output_and_a_companion(dev, M, N, K):
+    """s2t_gemm_f32_sq: C = A B + bias as s2t_gemm_f32 mode 1 writes it, plus sums[0] += ||other||^2 and
+    sums[1] += ||C||^2 from the epilogue (Whiten's backward: other = the incoming gradient)."""
+    from speech2text_amd import _native as Nt
+    L = Nt.lib()
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, K, generator=g).to(dev)
+    b = (torch.randn(K, N, generator=g) * 0.1).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    other = torch.randn(M, N, generator=g).to(dev)
+    c0 = torch.empty(M, N, device=dev)
+    assert L.s2t_gemm_f32(1, Nt.fp(a), K, Nt.fp(b), N, Nt.fp(c0), N, M, N, K, Nt.fp(bias), None, 0, None, 0,
+                          0, 0, 0, None, 0, Nt.stream()) == 0
+    c1 = torch.empty(M, N, device=dev)
+    sums = torch.tensor([0.5, 0.25], device=dev)
+    assert L.s2t_gemm_f32_sq(1, Nt.fp(a), K, Nt.fp(b), N, Nt.fp(c1), N, M, N, K, Nt.fp(bias), Nt.fp(other), N,
+                             Nt.fp(sums), Nt.stream()) == 0
+    assert torch.equal(c0, c1)
+    ref = torch.stack([(other.double() ** 2).sum() + 0.5, (c0.double() ** 2).sum() + 0.25])
+    assert ((sums.double() - ref).abs() / ref).max().item() < 2e-6
+    # rows that are not 16-byte aligned: refused, the caller keeps the separate pass
+    assert L.s2t_gemm_f32_sq(1, Nt.fp(a), K, Nt.fp(b), N, Nt.fp(c1), N, M, N, K, Nt.fp(bias), Nt.fp(other), N + 1,
+                             Nt.fp(sums), Nt.stream()) == -2
+
+
 # ------------------------------------------------------------------ pre-split weight pieces
 def _x3p_case(dev, M, K, N, seed=0):
     from speech2text_amd import flat

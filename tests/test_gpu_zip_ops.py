@@ -391,12 +391,16 @@ def test_downsample_and_upsampled_bypass_vs_torch(dev, T, B, C, ds):
 
 @pytest.mark.parametrize("R,C,G", [(700, 192, 1), (1000, 128, 4), (333, 96, 2), (2000, 512, 1),
                                    (500, 256, 8), (260, 64, 1)])
-def test_whiten_backward_vs_oracle(dev, monkeypatch, R, C, G):
+@pytest.mark.parametrize("sq", [True, False])
+def test_whiten_backward_vs_oracle(dev, monkeypatch, R, C, G, sq):
     """Whiten (scaling.py:949-1095): x^T x comes from the symmetric TN GEMM (only the 64x64 tiles on /
     above the diagonal with same-group pairs; cg = 48 straddles tiles), the metric kernel mirrors
-    them; the backward term against the oracle's autograd-in-backward statement."""
+    them; the backward term against the oracle's autograd-in-backward statement.  sq: the norms of
+    (g, x dcov) from the product's epilogue (s2t_gemm_f32_sq) or from the pass over both tensors."""
     import random
+    from speech2text_amd import zip_kernels as zkm
     from speech2text_amd.model.layer.scaling import Whiten
+    monkeypatch.setattr(zkm, "_WHITEN_SQ", sq)
     torch.manual_seed(R + C)
     x = torch.randn(R, C) @ (torch.eye(C) + 0.3 * torch.randn(C, C))      # correlated channels
     x = x + 0.5 * torch.randn(C)
