@@ -128,6 +128,13 @@ int s2t_balancer_apply(const float* x, long ldx, const float* g, long ldg, long 
 int s2t_zipconv_fwd(const float* u, long ld, int gate_off, const unsigned char* mask, int T, int B,
                     int C, int K, int chunk, const float* wc, const float* bc, const float* wk,
                     const float* bk, const float* scale, float* y, void* stream);
+/* s2t_zipconv_fwd that also writes y_act = Swoosh(y) (act_kind 1 = SwooshL, 2 = SwooshR): the
+ * activation between the depthwise conv and out_proj (model/encoder/zipformer.py:2700-2703) leaves
+ * with the conv's output tile instead of re-reading y. */
+int s2t_zipconv_fwd_act(const float* u, long ld, int gate_off, const unsigned char* mask, int T, int B,
+                        int C, int K, int chunk, const float* wc, const float* bc, const float* wk,
+                        const float* bk, const float* scale, float* y, float* y_act, int act_kind,
+                        void* stream);
 int s2t_zipconv_bwd(const float* u, long ld, int gate_off, const unsigned char* mask, int T, int B,
                     int C, int K, int chunk, const float* wc, const float* wk, const float* bk,
                     const float* scale, const float* dy, float* du, float* dwc, float* dbc,

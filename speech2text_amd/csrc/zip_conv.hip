@@ -194,8 +194,21 @@ __device__ __forceinline__ void stage_xg_buf(const ConvArgs& a, int b, int t0, i
   }
 }
 
+// Swoosh as zip_elem.hip swoosh_f (the same instruction sequence: the fused output equals s2t_swoosh_fwd's)
+__device__ __forceinline__ float conv_swoosh(float x, float off, float c) {
+  const float z = x - off;
+  const float e = __expf(-fabsf(z));
+  const float u = 1.f + e;
+  const float l1p = u == 1.f ? e : __logf(u) * __fdividef(e, u - 1.f);
+  return fmaxf(z, 0.f) + l1p - 0.08f * x - c;
+}
+
 template <int K, bool GEN, bool EDGE, int SB = 0>   // SB: see zipconv_bwd_w_kernel
-__global__ __launch_bounds__(256) void zipconv_fwd_kernel(ConvArgs a, float* __restrict__ y) {
+__global__ __launch_bounds__(256) void zipconv_fwd_kernel(ConvArgs a, float* __restrict__ y,
+                                                          float* __restrict__ y2, float act_off,
+                                                          float act_c) {
+  // y2 (optional): Swoosh(y) as a second output -- the conv module's activation (zipformer.py:
+  // 2700-2703) leaves with the tile instead of re-reading y in a pass of its own
   constexpr int Kh = (K + 1) / 2, halo = K / 2, W = FPT + 2 * halo;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* s_x = reinterpret_cast<float*>(smem_raw);
@@ -290,9 +303,14 @@ __global__ __launch_bounds__(256) void zipconv_fwd_kernel(ConvArgs a, float* __r
 #pragma unroll
     for (int p = 0; p < TT / 16; ++p) {
       const int r = 16 * p + rig, t = t0 + r;
-      if (t < a.T && ch < a.C)
-        *reinterpret_cast<float4*>(y + ((long)t * a.B + b) * a.C + ch) =
-            *reinterpret_cast<const float4*>(&s_x[r * 64 + 4 * c4]);
+      if (t < a.T && ch < a.C) {
+        const float4 v = *reinterpret_cast<const float4*>(&s_x[r * 64 + 4 * c4]);
+        *reinterpret_cast<float4*>(y + ((long)t * a.B + b) * a.C + ch) = v;
+        if (y2)
+          *reinterpret_cast<float4*>(y2 + ((long)t * a.B + b) * a.C + ch) =
+              make_float4(conv_swoosh(v.x, act_off, act_c), conv_swoosh(v.y, act_off, act_c),
+                          conv_swoosh(v.z, act_off, act_c), conv_swoosh(v.w, act_off, act_c));
+      }
     }
     return;
   }
@@ -300,7 +318,10 @@ __global__ __launch_bounds__(256) void zipconv_fwd_kernel(ConvArgs a, float* __r
 #pragma unroll
   for (int i = 0; i < FPT; ++i) {
     const int t = tb + i;
-    if (t < a.T) y[((long)t * a.B + b) * a.C + c0 + c] = acck[i];
+    if (t < a.T) {
+      y[((long)t * a.B + b) * a.C + c0 + c] = acck[i];
+      if (y2) y2[((long)t * a.B + b) * a.C + c0 + c] = conv_swoosh(acck[i], act_off, act_c);
+    }
   }
 }
 
@@ -836,10 +857,11 @@ static int conv_subblock(int chunk) {
     default: { constexpr int SBV = 0; LAUNCH; } break;  \
   }
 
-extern "C" int s2t_zipconv_fwd(const float* u, long ld, int gate_off, const unsigned char* mask,
-                               int T, int B, int C, int K, int chunk, const float* wc,
-                               const float* bc, const float* wk, const float* bk,
-                               const float* scale, float* y, void* stream) {
+static int zipconv_fwd_impl(const float* u, long ld, int gate_off, const unsigned char* mask,
+                            int T, int B, int C, int K, int chunk, const float* wc,
+                            const float* bc, const float* wk, const float* bk,
+                            const float* scale, float* y, float* y2, float act_off, float act_c,
+                            void* stream) {
   if (!conv_args_ok(T, B, C, K, chunk)) return -1;
   ConvArgs a{u, ld, gate_off, mask, T, B, C, chunk, wc, bc, wk, bk, scale, 0, 1 << 30, 0, 0};
   hipStream_t st = (hipStream_t)stream;
@@ -849,7 +871,7 @@ extern "C" int s2t_zipconv_fwd(const float* u, long ld, int gate_off, const unsi
   if (z.n_int() > 0) {
     z.set_int(a);
     S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_fwd_kernel<KK, false, false>), dim3(gx, B, z.n_int()),
-                                            dim3(256), conv_smem<KK>(false, 1, false), st, a, y));
+                                            dim3(256), conv_smem<KK>(false, 1, false), st, a, y, y2, act_off, act_c));
     S2T_CHECK_LAUNCH();
   }
   if (z.n_edge() > 0) {
@@ -857,15 +879,36 @@ extern "C" int s2t_zipconv_fwd(const float* u, long ld, int gate_off, const unsi
     const dim3 grid(gx, B, z.n_edge());
     if (!gen) {
       S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_fwd_kernel<KK, false, true>), grid, dim3(256),
-                                              conv_smem<KK>(false, 1, true), st, a, y));
+                                              conv_smem<KK>(false, 1, true), st, a, y, y2, act_off, act_c));
     } else {
       S2T_CONV_GEN_SB(conv_subblock(chunk),
                       S2T_CONV_DISPATCH(K, hipLaunchKernelGGL((zipconv_fwd_kernel<KK, true, true, SBV>), grid,
-                                                              dim3(256), conv_smem<KK>(false, 1, true), st, a, y)));
+                                                              dim3(256), conv_smem<KK>(false, 1, true), st, a, y,
+                                                              y2, act_off, act_c)));
     }
     S2T_CHECK_LAUNCH();
   }
   return 0;
+}
+
+extern "C" int s2t_zipconv_fwd(const float* u, long ld, int gate_off, const unsigned char* mask,
+                               int T, int B, int C, int K, int chunk, const float* wc,
+                               const float* bc, const float* wk, const float* bk,
+                               const float* scale, float* y, void* stream) {
+  return zipconv_fwd_impl(u, ld, gate_off, mask, T, B, C, K, chunk, wc, bc, wk, bk, scale, y, nullptr, 0.f, 0.f,
+                          stream);
+}
+
+// the same pass with act(y) as a second output: act_kind 1 = SwooshL, 2 = SwooshR (the conv module's
+// activation between the depthwise conv and out_proj, model/encoder/zipformer.py:2700-2703)
+extern "C" int s2t_zipconv_fwd_act(const float* u, long ld, int gate_off, const unsigned char* mask,
+                                   int T, int B, int C, int K, int chunk, const float* wc,
+                                   const float* bc, const float* wk, const float* bk,
+                                   const float* scale, float* y, float* y_act, int act_kind,
+                                   void* stream) {
+  if (!y_act || (act_kind != 1 && act_kind != 2)) return -1;
+  return zipconv_fwd_impl(u, ld, gate_off, mask, T, B, C, K, chunk, wc, bc, wk, bk, scale, y, y_act,
+                          act_kind == 1 ? 4.0f : 1.0f, act_kind == 1 ? 0.035f : 0.313261687f, stream);
 }
 
 // dscale (2, C, K) += scratch [2][K][cpad] (see zipconv_bwd_w_kernel)

@@ -474,12 +474,12 @@ int conv_fwd(Ctx& c, int i, int d0, const float* x_in, const float** x_out) {
   TRY(lt_matmul(c, 0, x_in, D, R, m.in, e, sv.u));
   sv.chunk = (c.c.chunk_size < 0 || c.c.chunk_size > T) ? T : c.c.chunk_size;
   sv.y = c.ar.alloc(R * D);
-  RUN(s2t_zipconv_fwd(sv.u, 2 * D, D, c.c.k8, T, B, D, m.K, sv.chunk, m.wc, m.bc, m.wk, m.bk, m.scale, sv.y,
-                      (void*)c.st));
+  sv.a = c.ar.alloc(R * D);
+  // (SwooshR(y) leaves with the conv's output tile: no activation pass)
+  RUN(s2t_zipconv_fwd_act(sv.u, 2 * D, D, c.c.k8, T, B, D, m.K, sv.chunk, m.wc, m.bc, m.wk, m.bk, m.scale, sv.y,
+                          sv.a, 2, (void*)c.st));
   sv.st.on = 0;
   if (fw) TRY(whiten_stats(c, sv.st, sv.y, D, R, D, m.wh.groups));
-  sv.a = c.ar.alloc(R * D);
-  RUN(s2t_swoosh_fwd(sv.y, sv.a, R * D, kSwOff[2], kSwC[2], (void*)c.st));
   float* out = c.ar.alloc(R * D);
   Epi e2;
   e2.bias = m.out.b;

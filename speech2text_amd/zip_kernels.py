@@ -447,11 +447,19 @@ def conv_params(conv, T, chunk_size):
             conv.chunkwise_conv.weight, conv.chunkwise_conv.bias, conv.chunkwise_conv_scale)
 
 
-def zipconv_forward(u, gate_off, m8, chunk, K, wc, bc, wk, bk, scale):
-    """u (T,B,ld) contiguous fp32 -> y (T,B,C).   HIP: zip_conv.hip."""
+def zipconv_forward(u, gate_off, m8, chunk, K, wc, bc, wk, bk, scale, act=None):
+    """u (T,B,ld) contiguous fp32 -> y (T,B,C); with act = True (SwooshL) / False (SwooshR) ->
+    (y, act(y)), the activation written by the same pass.   HIP: zip_conv.hip."""
     T, B, ld = u.shape
     C = wk.shape[0]
     y = torch.empty((T, B, C), dtype=torch.float32, device=u.device)
+    if act is not None:
+        ya = torch.empty_like(y)
+        N.PROF[0] and N.profile_note("s2t_zipconv_fwd_act", 4.0 * (u.numel() + 2 * y.numel()))
+        N.check(N.lib().s2t_zipconv_fwd_act(N.fp(u), ld, gate_off, N.ptr(m8), T, B, C, K, chunk,
+                                            N.fp(wc), N.fp(bc), N.fp(wk), N.fp(bk), N.fp(scale), N.fp(y),
+                                            N.fp(ya), 1 if act else 2, N.stream()), "s2t_zipconv_fwd_act")
+        return y, ya
     N.PROF[0] and N.profile_note("s2t_zipconv_fwd", 4.0 * (u.numel() + y.numel()))
     N.check(N.lib().s2t_zipconv_fwd(N.fp(u), ld, gate_off, N.ptr(m8), T, B, C, K, chunk,
                                     N.fp(wc), N.fp(bc), N.fp(wk), N.fp(bk), N.fp(scale), N.fp(y),

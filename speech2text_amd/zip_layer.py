@@ -329,9 +329,9 @@ def _conv_fwd(m, dec, x_in, T, B, chunk_size, k8):
         assert m.causal, "Must initialize model with causal=True if you use chunk_size"
     sv.u = zk.lt_matmul(0, x_in, m.in_proj.weight, m.in_proj.bias)                          # (R, 2D)
     sv.cp = zk.conv_params(m.depthwise_conv, T, chunk_size)
-    sv.y = zk.zipconv_forward(sv.u.view(T, B, 2 * D), D, k8, *sv.cp).view(T * B, D)
+    y, a = zk.zipconv_forward(sv.u.view(T, B, 2 * D), D, k8, *sv.cp, act=False)   # (y, SwooshR(y))
+    sv.y, sv.a = y.view(T * B, D), a.view(T * B, D)
     sv.st = zk.WhitenStats(sv.y, m.whiten.num_groups) if fw else None
-    sv.a = zk.swoosh_forward(sv.y, False)
     return zk.lt_matmul(0, sv.a, m.out_proj.weight, m.out_proj.bias, x_in), sv
 
 

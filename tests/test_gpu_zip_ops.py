@@ -111,6 +111,25 @@ def test_swoosh_and_biasnorm(dev, is_l):
     np.testing.assert_allclose(lg.grad.item(), lc.grad.item(), rtol=1e-4)
 
 
+@pytest.mark.parametrize("T,B,C,K,chunk", [(200, 3, 192, 31, -1), (77, 4, 70, 15, 16), (64, 1, 64, 15, 4)])
+def test_conv_module_activation_as_second_output(dev, T, B, C, K, chunk):
+    """s2t_zipconv_fwd_act: y as s2t_zipconv_fwd writes it, and SwooshR / SwooshL of y equal to the
+    separate activation pass bit for bit (16-byte and scalar store paths, chunked and not)."""
+    from speech2text_amd import zip_kernels as zk
+    torch.manual_seed(T + C)
+    conv = _Conv(C, K).to(dev)
+    u = torch.randn(T, B, 2 * C, device=dev)
+    lens = torch.randint(T // 2, T + 1, (B,)); lens[0] = T
+    m8 = (torch.arange(T).unsqueeze(0) >= lens.unsqueeze(1)).to(torch.uint8).to(dev)
+    cp = zk.conv_params(conv, T, chunk)
+    with torch.no_grad():
+        y0 = zk.zipconv_forward(u, C, m8, *cp)
+        for swl in (False, True):
+            y, a = zk.zipconv_forward(u, C, m8, *cp, act=swl)
+            assert torch.equal(y, y0)
+            assert torch.equal(a, zk.swoosh_forward(y0.view(T * B, C), swl).view(T, B, C))
+
+
 @pytest.mark.parametrize("rows,D", [(37 * 5, 192), (1031, 256), (4, 8), (3, 64), (257, 200), (130, 384),
                                     (66, 512), (9000, 192)])
 def test_biasnorm_backward_ragged_shapes(dev, rows, D):
