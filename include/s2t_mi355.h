@@ -91,6 +91,20 @@ int s2t_swoosh_fwd(const float* x, float* y, long n, float offset, float constan
 int s2t_swoosh_bwd(const float* x, const float* g, float* d, long n, float offset, void* stream);
 int s2t_biasnorm_fwd(const float* x, const float* bias, const float* log_scale, long rows, int D,
                      float* y, float* scales, void* stream);
+/* BiasNorm + the layer's bypass as ONE pass each way (the end of Zipformer2EncoderLayer.forward,
+ * model/encoder/zipformer.py:1330-1337): out = orig + (x * scales[row] - orig) * bypass_scale[c]
+ * (* fm[row % B, c] when fm is given: the stack's feature mask); scales[row] = exp(log_scale) /
+ * rms(x - bias) is written for backward, the normalised tensor itself is not.  bwd: g' = g * fm;
+ * d_orig = g' (1 - bypass_scale); dx = BiasNorm's backward of g' bypass_scale; d_bypass_scale, dbias,
+ * dls are ADDED to.  Equals s2t_biasnorm_fwd + s2t_bypass_fwd[_mask] and s2t_bypass_bwd[_mask] +
+ * s2t_biasnorm_bwd. */
+int s2t_norm_bypass_fwd(const float* x, const float* bias, const float* log_scale, const float* orig,
+                        const float* bypass_scale, const float* fm, int B, long rows, int D, float* out,
+                        float* scales, void* stream);
+int s2t_norm_bypass_bwd(const float* x, const float* bias, const float* scales, const float* orig,
+                        const float* bypass_scale, const float* g, const float* fm, int B, long rows, int D,
+                        float* dx, float* d_orig, float* d_bypass_scale, float* dbias, float* dls,
+                        void* stream);
 int s2t_biasnorm_bwd(const float* x, const float* bias, const float* scales, const float* g,
                      long rows, int D, float* dx, float* dbias, float* dls, void* stream);
 /* The whole Balancer backward (model/layer/scaling.py:741-789) in two launches and no fills:

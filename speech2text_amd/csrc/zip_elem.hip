@@ -181,6 +181,163 @@ __global__ __launch_bounds__(256) void biasnorm_bwd_kernel(
   }
 }
 
+// x * y rounded on its own (never contracted into a following add / subtract): the fused passes
+// below must produce the value the separate passes STORED
+__device__ __forceinline__ float mul_rounded(float x, float y) {
+#pragma clang fp contract(off)
+  const float p = x * y;
+  return p;
+}
+
+// ---------------------------------------------------------------- BiasNorm + bypass, fused
+// The end of a Zipformer2EncoderLayer (model/encoder/zipformer.py:1330-1337): out = orig +
+// (norm(x) - orig) * scale[c] (* fm[b, c]: the stack's feature mask).  One wave per row: the row's
+// scale, the normalised row and the bypass combination in ONE pass -- norm(x) itself is never
+// stored (backward recomputes it as x * scales[row]).
+__global__ __launch_bounds__(256) void norm_bypass_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ ls,
+    const float* __restrict__ orig, const float* __restrict__ bscale, const float* __restrict__ fm,
+    int B, long rows, int D, float* __restrict__ out, float* __restrict__ scales) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + row * D;
+  float acc = 0.f;
+  for (int c = lane; c < D; c += 64) {
+    const float d = xr[c] - bias[c];
+    acc = fmaf(d, d, acc);
+  }
+  acc = wave_sum(acc);
+  const float s = rsqrtf(acc / D) * expf(ls[0]);
+  if (lane == 0) scales[row] = s;
+  const float* orow = orig + row * D;
+  const float* mrow = fm ? fm + (row % B) * D : nullptr;
+  float* yr = out + row * D;
+  for (int c = lane; c < D; c += 64) {
+    const float a = orow[c];
+    float v = fmaf(mul_rounded(xr[c], s) - a, bscale[c], a);   // (the product rounded as the stored norm(x) was)
+    if (mrow) v *= mrow[c];
+    yr[c] = v;
+  }
+}
+
+// Backward of the pair: g' = g * fm;  d_orig = g' (1 - scale),  g10 = g' scale,  d_scale[c] += sum g'
+// (x s - orig);  then BiasNorm's backward on g10 (biasnorm_bwd_kernel's formulas).  One wave per row,
+// two rows per trip; the per-column sums stay in registers over all rows of a wave.
+template <int CPL>
+__global__ __launch_bounds__(256) void norm_bypass_bwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ scales,
+    const float* __restrict__ orig, const float* __restrict__ bscale, const float* __restrict__ g,
+    const float* __restrict__ fm, int B, long rows, int D, float* __restrict__ dx,
+    float* __restrict__ d_orig, float* __restrict__ d_bscale, float* __restrict__ dbias,
+    float* __restrict__ dls) {
+  const int lane = threadIdx.x & 63;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long nwaves = (long)gridDim.x * 4;
+  float b[CPL], k[CPL], db[CPL], dk[CPL];
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) {
+    const int c = lane + 64 * j;
+    b[j] = c < D ? bias[c] : 0.f;
+    k[j] = c < D ? bscale[c] : 0.f;
+    db[j] = 0.f;
+    dk[j] = 0.f;
+  }
+  float dl = 0.f;
+  for (long row = wave; row < rows; row += 2 * nwaves) {
+    const long row2 = row + nwaves;
+    const bool has2 = row2 < rows;
+    const long ra = row, rb = has2 ? row2 : row;
+    float xv[CPL], gv[CPL], ov[CPL], xw[CPL], gw[CPL], ow[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const int c = lane + 64 * j;
+      const bool ok = c < D;
+      xv[j] = ok ? x[ra * D + c] : 0.f;
+      gv[j] = ok ? g[ra * D + c] : 0.f;
+      ov[j] = ok ? orig[ra * D + c] : 0.f;
+      xw[j] = ok ? x[rb * D + c] : 0.f;
+      gw[j] = ok ? g[rb * D + c] : 0.f;
+      ow[j] = ok ? orig[rb * D + c] : 0.f;
+      if (fm) {
+        gv[j] *= ok ? fm[(ra % B) * D + c] : 0.f;
+        gw[j] *= ok ? fm[(rb % B) * D + c] : 0.f;
+      }
+    }
+    const float s = scales[ra], s2 = scales[rb];
+    float A = 0.f, ss = 0.f, A2 = 0.f, ss2 = 0.f;
+    float* d0 = d_orig + ra * D;
+    float* d02 = d_orig + rb * D;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const int c = lane + 64 * j;
+      if (c < D) {
+        // the bypass: this row's share of d_scale, the gradient that stays on orig, and g10
+        const float t = gv[j] * k[j];
+        dk[j] = fmaf(gv[j], mul_rounded(xv[j], s) - ov[j], dk[j]);
+        d0[c] = gv[j] - t;
+        gv[j] = t;
+        if (has2) {
+          const float t2 = gw[j] * k[j];
+          dk[j] = fmaf(gw[j], mul_rounded(xw[j], s2) - ow[j], dk[j]);
+          d02[c] = gw[j] - t2;
+          gw[j] = t2;
+        }
+      }
+      A = fmaf(gv[j], xv[j], A);
+      A2 = fmaf(gw[j], xw[j], A2);
+      const float d = c < D ? xv[j] - b[j] : 0.f, d2 = c < D ? xw[j] - b[j] : 0.f;
+      ss = fmaf(d, d, ss);
+      ss2 = fmaf(d2, d2, ss2);
+    }
+    A = wave_sum(A);
+    ss = wave_sum(ss);
+    A2 = wave_sum(A2);
+    ss2 = wave_sum(ss2);
+    const float coef = s * A / ss, coef2 = has2 ? s2 * A2 / ss2 : 0.f;   // ss = D * mean((x - b)^2)
+    dl += A * s + (has2 ? A2 * s2 : 0.f);
+    float* dr = dx + ra * D;
+    float* dr2 = dx + rb * D;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const int c = lane + 64 * j;
+      if (c < D) {
+        const float t = coef * (xv[j] - b[j]);
+        dr[c] = s * gv[j] - t;
+        db[j] += t;
+        if (has2) {
+          const float t2 = coef2 * (xw[j] - b[j]);
+          dr2[c] = s2 * gw[j] - t2;
+          db[j] += t2;
+        }
+      }
+    }
+  }
+  // one atomic per column per WORKGROUP (the four waves add up through LDS first)
+  __shared__ float s_db[4][64 * CPL], s_dk[4][64 * CPL];
+  __shared__ float s_dl[4];
+  const int wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) {
+    s_db[wv][lane + 64 * j] = db[j];
+    s_dk[wv][lane + 64 * j] = dk[j];
+  }
+  if (lane == 0) s_dl[wv] = dl;
+  __syncthreads();
+  if (wv == 0) {
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const int c = lane + 64 * j;
+      const float t = (s_db[0][c] + s_db[1][c]) + (s_db[2][c] + s_db[3][c]);
+      const float u = (s_dk[0][c] + s_dk[1][c]) + (s_dk[2][c] + s_dk[3][c]);
+      if (c < D && t != 0.f) atomicAdd(&dbias[c], t);
+      if (c < D && u != 0.f) atomicAdd(&d_bscale[c], u);
+    }
+    const float tl = (s_dl[0] + s_dl[1]) + (s_dl[2] + s_dl[3]);
+    if (lane == 0 && tl != 0.f) atomicAdd(dls, tl);
+  }
+}
+
 // ---------------------------------------------------------------- column statistics
 // x viewed as [rows][ld] with C used columns: sum[c] += x, sumsq[c] += x^2 (atomics once per
 // block).  Each thread owns column (threadIdx.x % cols_per_pass) and strides over rows.
@@ -366,6 +523,38 @@ extern "C" int s2t_biasnorm_fwd(const float* x, const float* bias, const float* 
   if (rows <= 0) return 0;
   hipLaunchKernelGGL(biasnorm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
                      (hipStream_t)stream, x, bias, log_scale, rows, D, y, scales);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int s2t_norm_bypass_fwd(const float* x, const float* bias, const float* log_scale,
+                                   const float* orig, const float* bypass_scale, const float* fm, int B,
+                                   long rows, int D, float* out, float* scales, void* stream) {
+  if (rows <= 0) return 0;
+  if (D <= 0 || B <= 0) return -1;
+  hipLaunchKernelGGL(norm_bypass_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                     (hipStream_t)stream, x, bias, log_scale, orig, bypass_scale, fm, B, rows, D, out, scales);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int s2t_norm_bypass_bwd(const float* x, const float* bias, const float* scales,
+                                   const float* orig, const float* bypass_scale, const float* g,
+                                   const float* fm, int B, long rows, int D, float* dx, float* d_orig,
+                                   float* d_bypass_scale, float* dbias, float* dls, void* stream) {
+  if (rows <= 0) return 0;
+  if (D <= 0 || D > 1024 || B <= 0) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned nb = std::min(grid_for(rows, 4 * 8), 1024u);
+#define NB_BWD(CPL)                                                                                    \
+  hipLaunchKernelGGL(norm_bypass_bwd_kernel<CPL>, dim3(nb), dim3(256), 0, st, x, bias, scales, orig,   \
+                     bypass_scale, g, fm, B, rows, D, dx, d_orig, d_bypass_scale, dbias, dls)
+  if (D <= 64) NB_BWD(1);
+  else if (D <= 128) NB_BWD(2);
+  else if (D <= 256) NB_BWD(4);
+  else if (D <= 512) NB_BWD(8);
+  else NB_BWD(16);
+#undef NB_BWD
   S2T_CHECK_LAUNCH();
   return 0;
 }

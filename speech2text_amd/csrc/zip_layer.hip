@@ -570,18 +570,14 @@ int layer_fwd(Ctx& c) {
   TRY(sa_fwd(c, 1, 19, s.x[6], &s.x[7]));
   TRY(conv_fwd(c, 1, 20, s.x[7], &s.x[8]));
   TRY(ff_fwd(c, 2, 23, s.x[8], &s.x[9]));
-  float* x10 = c.ar.alloc(R * D);
   s.nscales = c.ar.alloc(R);
-  RUN(s2t_biasnorm_fwd(s.x[9], d.norm_bias.x, d.norm_ls.x, R, D, x10, s.nscales, (void*)c.st));
-  s.x[10] = x10;
+  s.x[10] = nullptr;                     // norm(x9) is never stored: backward recomputes x9 * nscales
   s.x[11] = c.c.out;
-  // the stack's feature mask rides in the last bypass unless a gradient-shaping op of this call
-  // needs the unmasked output
+  // BiasNorm + the layer's bypass in one pass; the stack's feature mask rides in it unless a
+  // gradient-shaping op of this call needs the unmasked output
   s.fm_fused = c.c.fm != nullptr && !(dec(c, 30) || dec(c, 29));
-  if (s.fm_fused)
-    RUN(s2t_bypass_fwd_mask(s.x[0], x10, d.byp.x, c.c.fm, B, R, D, c.c.out, (void*)c.st));
-  else
-    RUN(s2t_bypass_fwd(s.x[0], x10, d.byp.x, R, D, c.c.out, (void*)c.st));
+  RUN(s2t_norm_bypass_fwd(s.x[9], d.norm_bias.x, d.norm_ls.x, s.x[0], d.byp.x, s.fm_fused ? c.c.fm : nullptr, B, R,
+                          D, c.c.out, s.nscales, (void*)c.st));
   s.wst.on = 0;
   if (dec(c, 30)) TRY(whiten_stats(c, s.wst, c.c.out, D, R, D, d.wh_out.groups));
   return 0;
@@ -776,13 +772,9 @@ int layer_bwd(Ctx& c, int phase) {
     // per-channel parameter gradients: [bypass scale | bypass_mid scale | norm bias | log_scale]
     float* acc = c.c.layer_acc;
     float* d0 = c.ar.alloc(R * D);
-    float* g10 = c.ar.alloc(R * D);
-    if (s.fm_fused)
-      RUN(s2t_bypass_bwd_mask(s.x[0], s.x[10], d.byp.x, g, c.c.fm, B, R, D, d0, g10, acc, (void*)c.st));
-    else
-      RUN(s2t_bypass_bwd(s.x[0], s.x[10], d.byp.x, g, R, D, d0, g10, acc, (void*)c.st));
     float* g9w = c.ar.alloc(R * D);
-    RUN(s2t_biasnorm_bwd(s.x[9], d.norm_bias.x, s.nscales, g10, R, D, g9w, acc + 2 * D, acc + 3 * D, (void*)c.st));
+    RUN(s2t_norm_bypass_bwd(s.x[9], d.norm_bias.x, s.nscales, s.x[0], d.byp.x, g, s.fm_fused ? c.c.fm : nullptr, B,
+                            R, D, g9w, d0, acc, acc + 2 * D, acc + 3 * D, (void*)c.st));
     const float* g9 = g9w;
     if (dec(c, 26)) {
       float* o = c.ar.alloc(R * D);

@@ -501,25 +501,18 @@ class _LayerFn(torch.autograd.Function):
         x8, s.cv2 = _conv_fwd(layer.conv_module2, d.cv2, x7, T, B, chunk_size, k8)
         x9, s.ff3 = _ff_fwd(layer.feed_forward3, d.ff3, x8)
         norm = layer.norm
-        x10 = _e(R, D, dev)
         s.nscales = torch.empty(R, dtype=_F32, device=dev)
-        N.PROF[0] and N.profile_note("s2t_biasnorm_fwd", 8.0 * R * D)
-        N.check(L.s2t_biasnorm_fwd(N.fp(x9), N.fp(norm.bias),
-                                   ctypes.c_void_p(norm.log_scale.data_ptr()), R, D, N.fp(x10),
-                                   N.fp(s.nscales), st), "biasnorm_fwd")
         x11 = _e(R, D, dev)
-        # the stack's feature mask rides in the last bypass unless a gradient-shaping op of this
-        # call needs the unmasked output
+        # BiasNorm + the layer's bypass in one pass (norm(x9) is never stored); the stack's feature
+        # mask rides in it unless a gradient-shaping op of this call needs the unmasked output
         s.fm, s.fm_fused = fm, fm is not None and not (d.wh_out or d.bal2)
-        N.PROF[0] and N.profile_note("s2t_bypass_fwd_mask" if s.fm_fused else "s2t_bypass_fwd", 12.0 * R * D)
-        if s.fm_fused:
-            N.check(L.s2t_bypass_fwd_mask(N.fp(x0), N.fp(x10), N.fp(layer.bypass.bypass_scale),
-                                          N.fp(fm), B, R, D, N.fp(x11), st), "s2t_bypass_fwd_mask")
-        else:
-            N.check(L.s2t_bypass_fwd(N.fp(x0), N.fp(x10), N.fp(layer.bypass.bypass_scale), R, D,
-                                     N.fp(x11), st), "s2t_bypass_fwd")
+        N.PROF[0] and N.profile_note("s2t_norm_bypass_fwd", 12.0 * R * D)
+        N.check(L.s2t_norm_bypass_fwd(N.fp(x9), N.fp(norm.bias), ctypes.c_void_p(norm.log_scale.data_ptr()),
+                                      N.fp(x0), N.fp(layer.bypass.bypass_scale),
+                                      N.fp(fm) if s.fm_fused else None, B, R, D, N.fp(x11),
+                                      N.fp(s.nscales), st), "s2t_norm_bypass_fwd")
         s.wst = zk.WhitenStats(x11, layer.whiten.num_groups) if d.wh_out else None
-        s.x = (x1, x2, x3, x4, x5, x6, x7, x8, x9, x10, x11)
+        s.x = (x1, x2, x3, x4, x5, x6, x7, x8, x9, None, x11)
         ctx.s, ctx.layer = s, layer
         out = x11.view(T, B, D)
         return out * fm if (fm is not None and not s.fm_fused) else out
@@ -552,22 +545,14 @@ class _LayerFn(torch.autograd.Function):
         off = lambda n: ctypes.c_void_p(acc.data_ptr() + 4 * n)      # noqa: E731
 
         byp = layer.bypass
-        d0 = _e(R, D, dev)
-        g10 = _e(R, D, dev)
-        N.PROF[0] and N.profile_note("s2t_bypass_bwd_mask" if s.fm_fused else "s2t_bypass_bwd", 20.0 * R * D)
-        if s.fm_fused:
-            N.check(L.s2t_bypass_bwd_mask(N.fp(x0), N.fp(x10), N.fp(byp.bypass_scale), N.fp(g),
-                                          N.fp(s.fm), B, R, D, N.fp(d0), N.fp(g10), off(0), st),
-                    "s2t_bypass_bwd_mask")
-        else:
-            N.check(L.s2t_bypass_bwd(N.fp(x0), N.fp(x10), N.fp(byp.bypass_scale), N.fp(g), R, D,
-                                     N.fp(d0), N.fp(g10), off(0), st), "s2t_bypass_bwd")
-
         norm = layer.norm
+        d0 = _e(R, D, dev)
         g9 = _e(R, D, dev)
-        N.PROF[0] and N.profile_note("s2t_biasnorm_bwd", 12.0 * R * D)
-        N.check(L.s2t_biasnorm_bwd(N.fp(x9), N.fp(norm.bias), N.fp(s.nscales), N.fp(g10), R, D,
-                                   N.fp(g9), off(2 * D), off(3 * D), st), "biasnorm_bwd")
+        N.PROF[0] and N.profile_note("s2t_norm_bypass_bwd", 20.0 * R * D)
+        N.check(L.s2t_norm_bypass_bwd(N.fp(x9), N.fp(norm.bias), N.fp(s.nscales), N.fp(x0),
+                                      N.fp(byp.bypass_scale), N.fp(g), N.fp(s.fm) if s.fm_fused else None,
+                                      B, R, D, N.fp(g9), N.fp(d0), off(0), off(2 * D), off(3 * D), st),
+                "s2t_norm_bypass_bwd")
         if d.bal1:
             g9 = _balancer_bwd(layer.balancer1, x9, g9)
 

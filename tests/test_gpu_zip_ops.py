@@ -111,6 +111,55 @@ def test_swoosh_and_biasnorm(dev, is_l):
     np.testing.assert_allclose(lg.grad.item(), lc.grad.item(), rtol=1e-4)
 
 
+@pytest.mark.parametrize("T,B,D,masked", [(50, 3, 192, True), (33, 2, 256, False), (20, 5, 68, True),
+                                         (9, 1, 512, True)])
+def test_norm_and_bypass_in_one_pass(dev, T, B, D, masked):
+    """s2t_norm_bypass_fwd / _bwd (the end of a zipformer layer: BiasNorm, then the bypass, then the
+    stack's feature mask) against the separate entry points they replace: outputs and data gradients
+    bit for bit, the per-channel parameter gradients to summation order."""
+    import ctypes
+    from speech2text_amd import _native as Nt
+    L, st = Nt.lib(), Nt.stream()
+    g = torch.Generator().manual_seed(T * D)
+    R = T * B
+    x = (torch.randn(R, D, generator=g) * 2).to(dev)
+    orig = torch.randn(R, D, generator=g).to(dev)
+    bias = (torch.randn(D, generator=g) * 0.1).to(dev)
+    ls = torch.tensor([0.3], device=dev)
+    k = torch.rand(D, generator=g).to(dev)
+    fm = (torch.rand(B, D, generator=g) > 0.3).float().to(dev) if masked else None
+    gy = torch.randn(R, D, generator=g).to(dev)
+    e = lambda *shape: torch.empty(*shape, device=dev)                         # noqa: E731
+    z = lambda *shape: torch.zeros(*shape, device=dev)                         # noqa: E731
+    # the separate passes
+    x10, sc0, out0 = e(R, D), e(R), e(R, D)
+    assert L.s2t_biasnorm_fwd(Nt.fp(x), Nt.fp(bias), Nt.fp(ls), R, D, Nt.fp(x10), Nt.fp(sc0), st) == 0
+    if masked:
+        assert L.s2t_bypass_fwd_mask(Nt.fp(orig), Nt.fp(x10), Nt.fp(k), Nt.fp(fm), B, R, D, Nt.fp(out0), st) == 0
+    else:
+        assert L.s2t_bypass_fwd(Nt.fp(orig), Nt.fp(x10), Nt.fp(k), R, D, Nt.fp(out0), st) == 0
+    d0, g10, dk0, dx0, db0, dl0 = e(R, D), e(R, D), z(D), e(R, D), z(D), z(1)
+    if masked:
+        assert L.s2t_bypass_bwd_mask(Nt.fp(orig), Nt.fp(x10), Nt.fp(k), Nt.fp(gy), Nt.fp(fm), B, R, D, Nt.fp(d0),
+                                     Nt.fp(g10), Nt.fp(dk0), st) == 0
+    else:
+        assert L.s2t_bypass_bwd(Nt.fp(orig), Nt.fp(x10), Nt.fp(k), Nt.fp(gy), R, D, Nt.fp(d0), Nt.fp(g10),
+                                Nt.fp(dk0), st) == 0
+    assert L.s2t_biasnorm_bwd(Nt.fp(x), Nt.fp(bias), Nt.fp(sc0), Nt.fp(g10), R, D, Nt.fp(dx0), Nt.fp(db0),
+                              Nt.fp(dl0), st) == 0
+    # the fused pair
+    sc1, out1 = e(R), e(R, D)
+    assert L.s2t_norm_bypass_fwd(Nt.fp(x), Nt.fp(bias), Nt.fp(ls), Nt.fp(orig), Nt.fp(k), Nt.fp(fm), B, R, D,
+                                 Nt.fp(out1), Nt.fp(sc1), st) == 0
+    d1, dk1, dx1, db1, dl1 = e(R, D), z(D), e(R, D), z(D), z(1)
+    assert L.s2t_norm_bypass_bwd(Nt.fp(x), Nt.fp(bias), Nt.fp(sc1), Nt.fp(orig), Nt.fp(k), Nt.fp(gy), Nt.fp(fm),
+                                 B, R, D, Nt.fp(dx1), Nt.fp(d1), Nt.fp(dk1), Nt.fp(db1), Nt.fp(dl1), st) == 0
+    assert torch.equal(sc0, sc1) and torch.equal(out0, out1)
+    assert torch.equal(d0, d1) and torch.equal(dx0, dx1)
+    for a, b in ((dk0, dk1), (db0, db1), (dl0, dl1)):
+        assert (a - b).abs().max().item() <= 2e-5 * max(1.0, a.abs().max().item())
+
+
 @pytest.mark.parametrize("T,B,C,K,chunk", [(200, 3, 192, 31, -1), (77, 4, 70, 15, 16), (64, 1, 64, 15, 4)])
 def test_conv_module_activation_as_second_output(dev, T, B, C, K, chunk):
     """s2t_zipconv_fwd_act: y as s2t_zipconv_fwd writes it, and SwooshR / SwooshL of y equal to the
