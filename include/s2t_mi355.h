@@ -91,6 +91,14 @@ int s2t_swoosh_fwd(const float* x, float* y, long n, float offset, float constan
 int s2t_swoosh_bwd(const float* x, const float* g, float* d, long n, float offset, void* stream);
 int s2t_biasnorm_fwd(const float* x, const float* bias, const float* log_scale, long rows, int D,
                      float* y, float* scales, void* stream);
+/* s2t_biasnorm_fwd / _bwd with the (B,T,D) -> (T,B,D) transposition of the zipformer frontend's output
+ * (model/encoder/zipformer.py:183 `x.transpose(0, 1)` on the output of Conv2dSubsampling.out_norm,
+ * model/layer/subsampling.py:262) riding in the pass: x, dx are batch-major (row b T + t), y and g
+ * time-major (row t B + b); scales stay in x's row order. */
+int s2t_biasnorm_fwd_tb(const float* x, const float* bias, const float* log_scale, int T, int B, int D,
+                        float* y, float* scales, void* stream);
+int s2t_biasnorm_bwd_tb(const float* x, const float* bias, const float* scales, const float* g, int T,
+                        int B, int D, float* dx, float* dbias, float* dls, void* stream);
 /* BiasNorm + the layer's bypass as ONE pass each way (the end of Zipformer2EncoderLayer.forward,
  * model/encoder/zipformer.py:1330-1337): out = orig + (x * scales[row] - orig) * bypass_scale[c]
  * (* fm[row % B, c] when fm is given: the stack's feature mask); scales[row] = exp(log_scale) /
@@ -508,6 +516,12 @@ int s2t_downsample_fwd(const float* src, const float* w, int ds, int T, int B, i
                        void* stream);
 int s2t_downsample_bwd(const float* src, const float* w, const float* g, int ds, int T, int B, int C,
                        float* d_src, float* dw, void* stream);
+/* the same pair with the OUTPUT (and its gradient g) batch-major, (B, ceil(T/ds), C): the encoder's
+ * final x.transpose(0, 1) (model/encoder/zipformer.py:199) rides in the pass that writes / reads it. */
+int s2t_downsample_fwd_bt(const float* src, const float* w, int ds, int T, int B, int C, float* out,
+                          void* stream);
+int s2t_downsample_bwd_bt(const float* src, const float* w, const float* g, int ds, int T, int B, int C,
+                          float* d_src, float* dw, void* stream);
 int s2t_bypass_up_fwd(const float* orig, const float* src, const float* scale, int up, int T, int B,
                       int C, float* out, void* stream);
 int s2t_bypass_up_bwd(const float* orig, const float* src, const float* scale, const float* g, int up,

@@ -70,9 +70,11 @@ __global__ __launch_bounds__(256) void swoosh_bwd_kernel(const float* __restrict
 
 // ---------------------------------------------------------------- BiasNorm
 // one wave per row of D channels; scales[row] = exp(ls) * mean((x-b)^2)^-0.5
+// tbT > 0: input row r = b tbT + t (batch-major) is WRITTEN as row t tbB + b (time-major): the
+// (B,T,C) -> (T,B,C) transposition of the frontend's output rides in this pass
 __global__ __launch_bounds__(256) void biasnorm_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ ls,
-    long rows, int D, float* __restrict__ y, float* __restrict__ scales) {
+    long rows, int D, float* __restrict__ y, float* __restrict__ scales, int tbT, int tbB) {
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
@@ -85,7 +87,8 @@ __global__ __launch_bounds__(256) void biasnorm_fwd_kernel(
   acc = wave_sum(acc);
   const float s = rsqrtf(acc / D) * expf(ls[0]);
   if (lane == 0) scales[row] = s;
-  float* yr = y + row * D;
+  const long orow = tbT > 0 ? (row % tbT) * tbB + row / tbT : row;
+  float* yr = y + orow * D;
   for (int c = lane; c < D; c += 64) yr[c] = xr[c] * s;
 }
 
@@ -96,7 +99,8 @@ template <int CPL>  // columns per lane: D <= 64*CPL
 __global__ __launch_bounds__(256) void biasnorm_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ scales,
     const float* __restrict__ g, long rows, int D, float* __restrict__ dx,
-    float* __restrict__ dbias, float* __restrict__ dls) {
+    float* __restrict__ dbias, float* __restrict__ dls, int tbT, int tbB) {
+  // tbT > 0: g is in the time-major row order the forward wrote (row r = b tbT + t <-> t tbB + b)
   const int lane = threadIdx.x & 63;
   const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long nwaves = (long)gridDim.x * 4;
@@ -113,10 +117,11 @@ __global__ __launch_bounds__(256) void biasnorm_bwd_kernel(
   for (long row = wave; row < rows; row += 2 * nwaves) {
     const long row2 = row + nwaves;
     const bool has2 = row2 < rows;
+    const long rowb = has2 ? row2 : row;
     const float* xr = x + row * D;
-    const float* gr = g + row * D;
-    const float* xr2 = x + (has2 ? row2 : row) * D;
-    const float* gr2 = g + (has2 ? row2 : row) * D;
+    const float* gr = g + (tbT > 0 ? (row % tbT) * tbB + row / tbT : row) * D;
+    const float* xr2 = x + rowb * D;
+    const float* gr2 = g + (tbT > 0 ? (rowb % tbT) * tbB + rowb / tbT : rowb) * D;
     float xv[CPL], gv[CPL], xw[CPL], gw[CPL];
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
@@ -522,7 +527,18 @@ extern "C" int s2t_biasnorm_fwd(const float* x, const float* bias, const float* 
                                 long rows, int D, float* y, float* scales, void* stream) {
   if (rows <= 0) return 0;
   hipLaunchKernelGGL(biasnorm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
-                     (hipStream_t)stream, x, bias, log_scale, rows, D, y, scales);
+                     (hipStream_t)stream, x, bias, log_scale, rows, D, y, scales, 0, 0);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
+// the same pass with the output rows written time-major: x (B,T,D) -> y (T,B,D)
+extern "C" int s2t_biasnorm_fwd_tb(const float* x, const float* bias, const float* log_scale, int T,
+                                   int B, int D, float* y, float* scales, void* stream) {
+  if (T <= 0 || B <= 0) return 0;
+  const long rows = (long)T * B;
+  hipLaunchKernelGGL(biasnorm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                     (hipStream_t)stream, x, bias, log_scale, rows, D, y, scales, T, B);
   S2T_CHECK_LAUNCH();
   return 0;
 }
@@ -559,34 +575,39 @@ extern "C" int s2t_norm_bypass_bwd(const float* x, const float* bias, const floa
   return 0;
 }
 
-extern "C" int s2t_biasnorm_bwd(const float* x, const float* bias, const float* scales,
-                                const float* g, long rows, int D, float* dx, float* dbias,
-                                float* dls, void* stream) {
-  if (rows <= 0) return 0;
-  hipStream_t st = (hipStream_t)stream;
+static int biasnorm_bwd_launch(const float* x, const float* bias, const float* scales, const float* g,
+                               long rows, int D, float* dx, float* dbias, float* dls, int tbT, int tbB,
+                               hipStream_t st) {
   // (a 16-byte form -- a 16-lane row of a wave per matrix row -- measured 29 / 25 us against 44 / 27
   // alone and 78-99 us against 40 IN the step: 94-120 registers leave it two waves per SIMD next to
   // the side stream's resident workgroups, where this kernel keeps four.  Removed in round 5.)
   const unsigned nb = std::min(grid_for(rows, 4 * 8), 1024u);
-  if (D <= 64)
-    hipLaunchKernelGGL(biasnorm_bwd_kernel<1>, dim3(nb), dim3(256), 0, st, x, bias, scales, g,
-                       rows, D, dx, dbias, dls);
-  else if (D <= 128)
-    hipLaunchKernelGGL(biasnorm_bwd_kernel<2>, dim3(nb), dim3(256), 0, st, x, bias, scales, g,
-                       rows, D, dx, dbias, dls);
-  else if (D <= 256)
-    hipLaunchKernelGGL(biasnorm_bwd_kernel<4>, dim3(nb), dim3(256), 0, st, x, bias, scales, g,
-                       rows, D, dx, dbias, dls);
-  else if (D <= 512)
-    hipLaunchKernelGGL(biasnorm_bwd_kernel<8>, dim3(nb), dim3(256), 0, st, x, bias, scales, g,
-                       rows, D, dx, dbias, dls);
-  else if (D <= 1024)
-    hipLaunchKernelGGL(biasnorm_bwd_kernel<16>, dim3(nb), dim3(256), 0, st, x, bias, scales, g,
-                       rows, D, dx, dbias, dls);
-  else
-    return -1;
+#define BN_BWD(CPL)                                                                                  \
+  hipLaunchKernelGGL(biasnorm_bwd_kernel<CPL>, dim3(nb), dim3(256), 0, st, x, bias, scales, g, rows, \
+                     D, dx, dbias, dls, tbT, tbB)
+  if (D <= 64) BN_BWD(1);
+  else if (D <= 128) BN_BWD(2);
+  else if (D <= 256) BN_BWD(4);
+  else if (D <= 512) BN_BWD(8);
+  else if (D <= 1024) BN_BWD(16);
+  else return -1;
+#undef BN_BWD
   S2T_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int s2t_biasnorm_bwd(const float* x, const float* bias, const float* scales,
+                                const float* g, long rows, int D, float* dx, float* dbias,
+                                float* dls, void* stream) {
+  if (rows <= 0) return 0;
+  return biasnorm_bwd_launch(x, bias, scales, g, rows, D, dx, dbias, dls, 0, 0, (hipStream_t)stream);
+}
+
+// backward of s2t_biasnorm_fwd_tb: g (T,B,D) time-major as the forward wrote y; x, dx (B,T,D)
+extern "C" int s2t_biasnorm_bwd_tb(const float* x, const float* bias, const float* scales, const float* g,
+                                   int T, int B, int D, float* dx, float* dbias, float* dls, void* stream) {
+  if (T <= 0 || B <= 0) return 0;
+  return biasnorm_bwd_launch(x, bias, scales, g, (long)T * B, D, dx, dbias, dls, T, B, (hipStream_t)stream);
 }
 
 // workspace: two alternating (sum[C], sumsq[C]) accumulators of 2 * BAL_MAXC floats each

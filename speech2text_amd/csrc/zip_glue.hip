@@ -237,10 +237,12 @@ __global__ __launch_bounds__(256) void param_grad_commit_n_kernel(CommitGroup gr
 // SimpleDownsample (zipformer.py:1653-1695): out[tt,b,c] = sum_k w[k] src[min(tt*ds + k, T-1), b, c]
 // (the reference pads by repeating the last frame), w = softmax(bias) computed by the caller.
 // rowlen = B*C; one thread per output element, coalesced over (b,c).
+// btC > 0: the output is written batch-major, out[b][tt][c] with C = btC (the encoder's final
+// x.transpose(0, 1), zipformer.py:199, rides in this pass), dT = frames of the output
 __global__ __launch_bounds__(256) void downsample_fwd_kernel(const float* __restrict__ src,
                                                              const float* __restrict__ w, int ds,
                                                              int T, long rowlen, long n_out,
-                                                             float* __restrict__ out) {
+                                                             float* __restrict__ out, int btC, int dT) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_out; i += (long)gridDim.x * 256) {
     const long tt = i / rowlen, e = i - tt * rowlen;
     float acc = 0.f;
@@ -248,7 +250,12 @@ __global__ __launch_bounds__(256) void downsample_fwd_kernel(const float* __rest
       const long t = min((long)tt * ds + k, (long)T - 1);
       acc = fmaf(w[k], src[t * rowlen + e], acc);
     }
-    out[i] = acc;
+    if (btC > 0) {
+      const long b = e / btC, c = e - b * btC;
+      out[(b * dT + tt) * btC + c] = acc;
+    } else {
+      out[i] = acc;
+    }
   }
 }
 
@@ -260,7 +267,8 @@ __global__ __launch_bounds__(256) void downsample_bwd_any_kernel(const float* __
                                                              const float* __restrict__ g, int ds,
                                                              int T, int dT, long rowlen,
                                                              float* __restrict__ d_src,
-                                                             float* __restrict__ dw) {
+                                                             float* __restrict__ dw, int btC) {
+  // btC > 0: g is batch-major, g[b][tt][c] with C = btC (as downsample_fwd_kernel wrote the output)
   __shared__ float s_dw[8][4];
   float pw[8];
 #pragma unroll
@@ -268,7 +276,7 @@ __global__ __launch_bounds__(256) void downsample_bwd_any_kernel(const float* __
   const long n = (long)dT * rowlen;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const long tt = i / rowlen, e = i - tt * rowlen;
-    const float gv = g[i];
+    const float gv = btC > 0 ? g[((e / btC) * dT + tt) * btC + (e % btC)] : g[i];
     float last = 0.f;                                    // contributions landing on frame T-1
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -298,9 +306,9 @@ __global__ __launch_bounds__(256) void downsample_bwd_kernel(const float* __rest
                                                              const float* __restrict__ g, int ds,
                                                              int T, int dT, long rowlen,
                                                              float* __restrict__ d_src,
-                                                             float* __restrict__ dw) {
+                                                             float* __restrict__ dw, int btC4) {
   // workgroup = (output frame tt, slice of the row): float4 everywhere, no index division, the
-  // ds source rows of a frame are loaded as one batch
+  // ds source rows of a frame are loaded as one batch.  btC4 > 0: g is batch-major (C / 4 = btC4)
   __shared__ float s_dw[8][4];
   float pw[8], wk[8];
 #pragma unroll
@@ -310,9 +318,9 @@ __global__ __launch_bounds__(256) void downsample_bwd_kernel(const float* __rest
   }
   const long n4 = rowlen >> 2;
   for (int tt = blockIdx.x; tt < dT; tt += gridDim.x) {
-    const float4* g4 = reinterpret_cast<const float4*>(g + (long)tt * rowlen);
+    const float4* g4 = reinterpret_cast<const float4*>(g + (btC4 > 0 ? 0 : (long)tt * rowlen));
     for (long e = (long)blockIdx.y * 256 + threadIdx.x; e < n4; e += (long)gridDim.y * 256) {
-      const float4 gv = g4[e];
+      const float4 gv = btC4 > 0 ? g4[((e / btC4) * dT + tt) * btC4 + (e % btC4)] : g4[e];
       float4 sv[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k)
@@ -561,29 +569,51 @@ extern "C" int s2t_param_grad_commit_n(int n, const S2tCommit* items, void* stre
   return 0;
 }
 
-extern "C" int s2t_downsample_fwd(const float* src, const float* w, int ds, int T, int B, int C,
-                                  float* out, void* stream) {
+static int downsample_fwd_impl(const float* src, const float* w, int ds, int T, int B, int C, float* out,
+                               int bt, void* stream) {
   if (T <= 0 || B <= 0 || C <= 0) return 0;
   if (ds < 1 || ds > 8) return -1;
-  const long rowlen = (long)B * C, n_out = (long)((T + ds - 1) / ds) * rowlen;
+  const int dT = (T + ds - 1) / ds;
+  const long rowlen = (long)B * C, n_out = (long)dT * rowlen;
   hipLaunchKernelGGL(downsample_fwd_kernel, dim3(grid1(n_out)), dim3(256), 0, (hipStream_t)stream,
-                     src, w, ds, T, rowlen, n_out, out);
+                     src, w, ds, T, rowlen, n_out, out, bt ? C : 0, dT);
   S2T_CHECK_LAUNCH();
   return 0;
 }
+static int downsample_bwd_impl(const float* src, const float* w, const float* g, int ds, int T, int B, int C,
+                               float* d_src, float* dw, int bt, void* stream);
 
+extern "C" int s2t_downsample_fwd(const float* src, const float* w, int ds, int T, int B, int C,
+                                  float* out, void* stream) {
+  return downsample_fwd_impl(src, w, ds, T, B, C, out, 0, stream);
+}
+// out (B, dT, C) batch-major / g (B, dT, C): the transposition the encoder applies to its output
+// (model/encoder/zipformer.py:199) done by the pass that writes / reads it
+extern "C" int s2t_downsample_fwd_bt(const float* src, const float* w, int ds, int T, int B, int C,
+                                     float* out, void* stream) {
+  return downsample_fwd_impl(src, w, ds, T, B, C, out, 1, stream);
+}
 extern "C" int s2t_downsample_bwd(const float* src, const float* w, const float* g, int ds, int T,
                                   int B, int C, float* d_src, float* dw, void* stream) {
+  return downsample_bwd_impl(src, w, g, ds, T, B, C, d_src, dw, 0, stream);
+}
+extern "C" int s2t_downsample_bwd_bt(const float* src, const float* w, const float* g, int ds, int T,
+                                     int B, int C, float* d_src, float* dw, void* stream) {
+  return downsample_bwd_impl(src, w, g, ds, T, B, C, d_src, dw, 1, stream);
+}
+
+static int downsample_bwd_impl(const float* src, const float* w, const float* g, int ds, int T, int B, int C,
+                               float* d_src, float* dw, int bt, void* stream) {
   if (T <= 0 || B <= 0 || C <= 0) return 0;
   if (ds < 1 || ds > 8) return -1;
   const int dT = (T + ds - 1) / ds;
   const long rowlen = (long)B * C;
-  if ((rowlen & 3) || ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(g) |
-                        reinterpret_cast<uintptr_t>(d_src)) & 15)) {
+  if ((rowlen & 3) || (C & 3) || ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(g) |
+                                  reinterpret_cast<uintptr_t>(d_src)) & 15)) {
     long blocks = ((long)dT * rowlen + 1023) / 1024;
     blocks = blocks > 1024 ? 1024 : (blocks < 1 ? 1 : blocks);
     hipLaunchKernelGGL(downsample_bwd_any_kernel, dim3((unsigned)blocks), dim3(256), 0,
-                       (hipStream_t)stream, src, w, g, ds, T, dT, rowlen, d_src, dw);
+                       (hipStream_t)stream, src, w, g, ds, T, dT, rowlen, d_src, dw, bt ? C : 0);
     S2T_CHECK_LAUNCH();
     return 0;
   }
@@ -592,7 +622,7 @@ extern "C" int s2t_downsample_bwd(const float* src, const float* w, const float*
   if (gy < 1) gy = 1;
   const int gx = dT < 1024 ? dT : 1024;
   hipLaunchKernelGGL(downsample_bwd_kernel, dim3(gx, gy), dim3(256), 0,
-                     (hipStream_t)stream, src, w, g, ds, T, dT, rowlen, d_src, dw);
+                     (hipStream_t)stream, src, w, g, ds, T, dT, rowlen, d_src, dw, bt ? C / 4 : 0);
   S2T_CHECK_LAUNCH();
   return 0;
 }

@@ -193,7 +193,7 @@ class Zipformer2(nn.Module):
                       src_key_padding_mask=pad_mask[..., ::ds], attn_mask=attn_mask)
             outputs.append(x)
         x = self._get_full_dim_output(outputs)
-        x = self.downsample_output(x)
+        x = self.downsample_output(x, batch_major=True)   # (stored (B,T,C): the transpose below is free)
         assert self.output_downsampling_factor == 2
         lengths = (x_lens + 1) // 2
         x = x.transpose(0, 1)
@@ -271,8 +271,8 @@ class SimpleDownsample(nn.Module):
         self.dropout = copy.deepcopy(dropout)
         self.downsample = downsample
 
-    def forward(self, src: Tensor) -> Tensor:
-        return zk.simple_downsample(src, self.bias, self.downsample)
+    def forward(self, src: Tensor, batch_major: bool = False) -> Tensor:
+        return zk.simple_downsample(src, self.bias, self.downsample, batch_major)
 
 
 class SimpleUpsample(nn.Module):

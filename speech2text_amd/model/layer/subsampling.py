@@ -11,7 +11,7 @@ from speech2text_amd import zip_kernels as zk
 
 from speech2text_amd.model.layer.scaling import (Linear, Balancer, BiasNorm, Dropout3, FloatLike,
                                                  ScaledConv2d, ScaleGrad, ScheduledFloat, SwooshL,
-                                                 SwooshR, Whiten, balancer_swoosh)
+                                                 SwooshR, Whiten, balancer_swoosh, limit_param_value)
 
 
 class ConvNeXt(nn.Module):
@@ -134,7 +134,15 @@ class Conv2dSubsampling(nn.Module):
         w = self.out.weight.view(-1, c, f).permute(0, 2, 1).reshape(-1, f * c)
         x = zk.linear(x.reshape(b, t, f * c), w, self.out.bias)
         x = self.out_whiten(x)
-        x = self.out_norm(x)
+        nm = self.out_norm
+        if x.is_cuda and x.dim() == 3:
+            # stored time-major: the encoder's x.transpose(0, 1) right after this module is then a
+            # contiguous (T,B,C) tensor without a copy (and so is the gradient on the way back)
+            ls = limit_param_value(nm.log_scale, min=float(nm.log_scale_min), max=float(nm.log_scale_max),
+                                   training=nm.training)
+            x = zk.bias_norm_time_major(x, nm.bias, ls)
+        else:
+            x = nm(x)
         x = self.dropout(x)
         x_lens = (x_lens - 7) // 2
         return x, x_lens

@@ -157,6 +157,47 @@ def bias_norm(x, bias, log_scale):
     return _BiasNorm.apply(x, bias, log_scale)
 
 
+class _BiasNormTB(torch.autograd.Function):
+    """BiasNorm of a batch-major (B,T,D) tensor whose result is STORED time-major: the returned
+    (B,T,D) tensor is a transposed view of a contiguous (T,B,D) buffer, so the encoder's
+    `x.transpose(0, 1)` (zipformer.py:183) is contiguous without a copy, and the gradient that comes
+    back through it is read in that order."""
+
+    @staticmethod
+    def forward(ctx, x, bias, log_scale):
+        _dev(x, bias, log_scale)
+        Bn, T, D = x.shape
+        x = x.contiguous().float()
+        y = torch.empty((T, Bn, D), dtype=torch.float32, device=x.device)
+        scales = torch.empty(Bn * T, dtype=torch.float32, device=x.device)
+        bias = bias.contiguous().float()
+        N.PROF[0] and N.profile_note("s2t_biasnorm_fwd", 8.0 * x.numel())
+        N.check(N.lib().s2t_biasnorm_fwd_tb(N.fp(x), N.fp(bias), N.fp(log_scale.reshape(1).contiguous().float()),
+                                            T, Bn, D, N.fp(y), N.fp(scales), N.stream()), "biasnorm_fwd_tb")
+        ctx.save_for_backward(x, bias, scales)
+        return y.transpose(0, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, bias, scales = ctx.saved_tensors
+        Bn, T, D = x.shape
+        gt = g.transpose(0, 1)                       # (T,B,D): contiguous when it comes from the encoder
+        if not gt.is_contiguous() or gt.dtype != torch.float32:
+            gt = gt.contiguous().float()
+        dx = torch.empty_like(x)
+        acc = torch.zeros(D + 1, dtype=torch.float32, device=x.device)
+        N.PROF[0] and N.profile_note("s2t_biasnorm_bwd", 12.0 * x.numel())
+        N.check(N.lib().s2t_biasnorm_bwd_tb(N.fp(x), N.fp(bias), N.fp(scales), N.fp(gt), T, Bn, D,
+                                            N.fp(dx), N.fp(acc), ctypes_off(acc, D), N.stream()),
+                "biasnorm_bwd_tb")
+        return dx, acc[:D], acc[D].reshape(())
+
+
+def bias_norm_time_major(x, bias, log_scale):
+    """bias_norm(x) for x (B,T,D), stored time-major (see _BiasNormTB)."""
+    return _BiasNormTB.apply(x, bias, log_scale)
+
+
 # ------------------------------------------------------------------ Balancer / Whiten backward
 _BAL_WS = {}
 
@@ -912,35 +953,51 @@ class _Downsample(torch.autograd.Function):
     tap gradients; the softmax over the learnable bias stays in autograd)."""
 
     @staticmethod
-    def forward(ctx, src, w, ds):
+    def forward(ctx, src, w, ds, batch_major=False):
         src = src.contiguous().float()
         w = w.contiguous().float()
         T, B, C = src.shape
-        out = torch.empty(((T + ds - 1) // ds, B, C), dtype=torch.float32, device=src.device)
-        N.PROF[0] and N.profile_note("s2t_downsample_fwd", 4.0 * (src.numel() + out.numel()))
+        dT = (T + ds - 1) // ds
+        N.PROF[0] and N.profile_note("s2t_downsample_fwd", 4.0 * (src.numel() + dT * B * C))
+        ctx.save_for_backward(src, w)
+        ctx.ds, ctx.bm = ds, bool(batch_major)
+        if batch_major:
+            # stored (B, dT, C): the returned (dT, B, C) tensor is a transposed view, so the caller's
+            # x.transpose(0, 1) is contiguous without a copy (and so is the gradient coming back)
+            out = torch.empty((B, dT, C), dtype=torch.float32, device=src.device)
+            N.check(N.lib().s2t_downsample_fwd_bt(N.fp(src), N.fp(w), ds, T, B, C, N.fp(out), N.stream()),
+                    "s2t_downsample_fwd_bt")
+            return out.transpose(0, 1)
+        out = torch.empty((dT, B, C), dtype=torch.float32, device=src.device)
         N.check(N.lib().s2t_downsample_fwd(N.fp(src), N.fp(w), ds, T, B, C, N.fp(out), N.stream()),
                 "s2t_downsample_fwd")
-        ctx.save_for_backward(src, w)
-        ctx.ds = ds
         return out
 
     @staticmethod
     def backward(ctx, g):
         src, w = ctx.saved_tensors
         T, B, C = src.shape
-        g = g.contiguous().float()
         d_src = torch.empty_like(src)
         dw = torch.zeros_like(w)
         N.PROF[0] and N.profile_note("s2t_downsample_bwd", 4.0 * (2 * src.numel() + g.numel()))
+        if ctx.bm:
+            gb = g.transpose(0, 1)
+            if not gb.is_contiguous() or gb.dtype != torch.float32:
+                gb = gb.contiguous().float()
+            N.check(N.lib().s2t_downsample_bwd_bt(N.fp(src), N.fp(w), N.fp(gb), ctx.ds, T, B, C,
+                                                  N.fp(d_src), N.fp(dw), N.stream()), "s2t_downsample_bwd_bt")
+            return d_src, dw, None, None
+        g = g.contiguous().float()
         N.check(N.lib().s2t_downsample_bwd(N.fp(src), N.fp(w), N.fp(g), ctx.ds, T, B, C,
                                            N.fp(d_src), N.fp(dw), N.stream()), "s2t_downsample_bwd")
-        return d_src, dw, None
+        return d_src, dw, None, None
 
 
-def simple_downsample(src, bias, ds):
-    """SimpleDownsample (reference zipformer.py:1653-1695).  HIP: zip_glue.hip."""
+def simple_downsample(src, bias, ds, batch_major=False):
+    """SimpleDownsample (reference zipformer.py:1653-1695).  HIP: zip_glue.hip.  batch_major: the
+    result is STORED (B, T', C) and returned as its (T', B, C) view (values unchanged)."""
     if src.is_cuda and src.dim() == 3 and 1 <= ds <= 8:
-        return _Downsample.apply(src, bias.softmax(dim=0), ds)
+        return _Downsample.apply(src, bias.softmax(dim=0), ds, batch_major)
     T, B, C = src.shape
     dT = (T + ds - 1) // ds
     pad = dT * ds - T

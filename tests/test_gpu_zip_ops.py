@@ -111,6 +111,47 @@ def test_swoosh_and_biasnorm(dev, is_l):
     np.testing.assert_allclose(lg.grad.item(), lc.grad.item(), rtol=1e-4)
 
 
+@pytest.mark.parametrize("B,T,D", [(3, 50, 192), (2, 33, 70), (5, 7, 256)])
+def test_layout_carrying_passes_keep_values_and_save_the_copy(dev, B, T, D):
+    """bias_norm_time_major (frontend output stored (T,B,D)) and simple_downsample(batch_major=True)
+    (encoder output stored (B,T',D)): same values and gradients as the plain forms followed by a
+    transpose, and the transposed result IS contiguous (no copy downstream)."""
+    from speech2text_amd import zip_kernels as zk
+    g = torch.Generator().manual_seed(B * T + D)
+    x = (torch.randn(B, T, D, generator=g) * 2).to(dev)
+    bias = (torch.randn(D, generator=g) * 0.1).to(dev)
+    ls = torch.tensor(0.3, device=dev)
+    w = torch.randn(T, B, D, generator=g).to(dev)
+    outs = []
+    for tm in (False, True):
+        xg, bg, lg = (t.clone().requires_grad_(True) for t in (x, bias, ls))
+        y = (zk.bias_norm_time_major if tm else zk.bias_norm)(xg, bg, lg)
+        assert y.shape == (B, T, D)
+        yt = y.transpose(0, 1)
+        assert yt.is_contiguous() == tm
+        (yt * w).sum().backward()
+        outs.append((y.detach().clone(), xg.grad, bg.grad, lg.grad))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    torch.testing.assert_close(outs[0][2], outs[1][2], atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(outs[0][3], outs[1][3], atol=1e-3, rtol=1e-4)
+    # the encoder's last downsample
+    src = torch.randn(T, B, D, generator=g).to(dev)
+    dsb = torch.randn(2, generator=g).to(dev)
+    dT = (T + 1) // 2
+    w2 = torch.randn(B, dT, D, generator=g).to(dev)
+    outs = []
+    for bm in (False, True):
+        sg, bb = src.clone().requires_grad_(True), dsb.clone().requires_grad_(True)
+        y = zk.simple_downsample(sg, bb, 2, batch_major=bm)
+        assert y.shape == (dT, B, D)
+        yb = y.transpose(0, 1)
+        assert yb.is_contiguous() == bm
+        (yb * w2).sum().backward()
+        outs.append((y.detach().clone(), sg.grad, bb.grad))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    torch.testing.assert_close(outs[0][2], outs[1][2], atol=1e-4, rtol=1e-4)
+
+
 @pytest.mark.parametrize("T,B,D,masked", [(50, 3, 192, True), (33, 2, 256, False), (20, 5, 68, True),
                                          (9, 1, 512, True)])
 def test_norm_and_bypass_in_one_pass(dev, T, B, D, masked):
