@@ -433,7 +433,7 @@ def cpu_baseline_c5(cfg, state_dict, seconds=30.0, batch=2, steps=3, warmup=1):
 # pipe is the dense bf16 peak / 6 -- reported next to the f32-MFMA fraction for the entries that
 # run on it, so that a kernel on the bf16 cores is not flattered by the smaller f32 peak
 BF16X3_CEILING_TFLOPS = 2500.0 / 6.0
-BF16X3_ENTRIES = ("s2t_gemm_x3p", "s2t_gemm_x3p_bal", "s2t_gemm_x3p_map", "s2t_gemm_tn_grouped", "s2t_gemm_f32",
+BF16X3_ENTRIES = ("s2t_gemm_x3p", "s2t_gemm_x3p_bal", "s2t_gemm_x3p_map", "s2t_gemm_tn_grouped", "s2t_gemm_f32", "s2t_gemm_f32_sq",
                   "s2t_gemm_xtx", "s2t_conv3x3_gemm")
 
 

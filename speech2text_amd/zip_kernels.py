@@ -171,7 +171,7 @@ class _BiasNormTB(torch.autograd.Function):
         y = torch.empty((T, Bn, D), dtype=torch.float32, device=x.device)
         scales = torch.empty(Bn * T, dtype=torch.float32, device=x.device)
         bias = bias.contiguous().float()
-        N.PROF[0] and N.profile_note("s2t_biasnorm_fwd", 8.0 * x.numel())
+        N.PROF[0] and N.profile_note("s2t_biasnorm_fwd_tb", 8.0 * x.numel())
         N.check(N.lib().s2t_biasnorm_fwd_tb(N.fp(x), N.fp(bias), N.fp(log_scale.reshape(1).contiguous().float()),
                                             T, Bn, D, N.fp(y), N.fp(scales), N.stream()), "biasnorm_fwd_tb")
         ctx.save_for_backward(x, bias, scales)
@@ -186,7 +186,7 @@ class _BiasNormTB(torch.autograd.Function):
             gt = gt.contiguous().float()
         dx = torch.empty_like(x)
         acc = torch.zeros(D + 1, dtype=torch.float32, device=x.device)
-        N.PROF[0] and N.profile_note("s2t_biasnorm_bwd", 12.0 * x.numel())
+        N.PROF[0] and N.profile_note("s2t_biasnorm_bwd_tb", 12.0 * x.numel())
         N.check(N.lib().s2t_biasnorm_bwd_tb(N.fp(x), N.fp(bias), N.fp(scales), N.fp(gt), T, Bn, D,
                                             N.fp(dx), N.fp(acc), ctypes_off(acc, D), N.stream()),
                 "biasnorm_bwd_tb")
@@ -958,7 +958,8 @@ class _Downsample(torch.autograd.Function):
         w = w.contiguous().float()
         T, B, C = src.shape
         dT = (T + ds - 1) // ds
-        N.PROF[0] and N.profile_note("s2t_downsample_fwd", 4.0 * (src.numel() + dT * B * C))
+        N.PROF[0] and N.profile_note("s2t_downsample_fwd_bt" if batch_major else "s2t_downsample_fwd",
+                                     4.0 * (src.numel() + dT * B * C))
         ctx.save_for_backward(src, w)
         ctx.ds, ctx.bm = ds, bool(batch_major)
         if batch_major:
@@ -979,7 +980,8 @@ class _Downsample(torch.autograd.Function):
         T, B, C = src.shape
         d_src = torch.empty_like(src)
         dw = torch.zeros_like(w)
-        N.PROF[0] and N.profile_note("s2t_downsample_bwd", 4.0 * (2 * src.numel() + g.numel()))
+        N.PROF[0] and N.profile_note("s2t_downsample_bwd_bt" if ctx.bm else "s2t_downsample_bwd",
+                                     4.0 * (2 * src.numel() + g.numel()))
         if ctx.bm:
             gb = g.transpose(0, 1)
             if not gb.is_contiguous() or gb.dtype != torch.float32:
