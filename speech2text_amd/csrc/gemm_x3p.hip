@@ -385,118 +385,8 @@ __device__ __forceinline__ void x3p_epilogue(const X3P& g, f32x16 (&acc)[TM][TN]
   }
 }
 
-template <int TM, int TN>
-__global__ __launch_bounds__(256, 2) void x3p_kernel(X3P g) {
-  constexpr int BM = 64 * TM, BN = 64 * TN;
-  constexpr int A_BYTES = 2 * TM * 2 * 3 * 1024, B_BYTES = 2 * TN * 2 * 3 * 1024;
-  constexpr int NB = 3 * TN;                 // 16-byte pieces of the B chunk per thread
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[A_BYTES + B_BYTES];
-  unsigned char* const sA = smem;
-  unsigned char* const sB = smem + A_BYTES;
-
-  // XCD-aware tile order (as gemm.hip): blocks of one XCD walk a contiguous range of tiles, n fastest
-  const int total = g.tiles_m * g.tiles_n;
-  const int per_xcd = (total + 7) / 8;
-  const int lin = (int)((blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3));
-  if (lin >= total) return;
-  const int tm = lin / g.tiles_n, tn = lin % g.tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wrb = (wave >> 1) * TM, wcb = (wave & 1) * TN;   // wave's first row block / column block
-  x3p_set_prio(g.prio);
-
-  // A units: (row r, k-eighth kq) = 8 consecutive k of one row = one lane's share of a fragment.
-  // 16 consecutive threads take 16 different rows at the same kq (conflict-free 16-byte LDS
-  // stores); the four kq of a row sit in one wave-instruction (whole 128-byte lines).
-  const float* asrc[TM];
-  int a_k[TM];
-  unsigned a_dst[TM];
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int u = tid + 256 * i;
-    const int r = (u & 15) + 16 * (u >> 6), kq = (u >> 4) & 3;
-    const int row = min(m0 + r, g.M - 1);
-    asrc[i] = g.A + (long)row * g.lda + 8 * kq;
-    a_k[i] = 8 * kq;
-    a_dst[i] = (unsigned)((((((r >> 5) * 2 + (kq >> 1)) * 3) * 64) + (kq & 1) * 32 + (r & 31)) * 16);
-  }
-  // B pieces: the chunk of column tile nt is one 6 KB run of the plane image; copied lane-linear
-  const u32x4* bsrc[NB];
-#pragma unroll
-  for (int i = 0; i < NB; ++i) {
-    const int idx = tid + 256 * i;
-    const int seg = idx / 384, off = idx - seg * 384;
-    const int nt = min((n0 >> 5) + seg, g.NT - 1);
-    bsrc[i] = reinterpret_cast<const u32x4*>(g.Bp + (long)nt * g.KB * 1536) + off;
-  }
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // k chunks of 32: registers hold chunk c+1 while chunk c is multiplied.  The loads are
-  // unconditional (past the end the last chunk is fetched again and dropped): no branch around the
-  // staging registers, so they stay registers.
-  f32x4 ra[TM][2];
-  u32x4 rb[NB];
-  const int nchunks = g.KB >> 1;
-#define X3P_LOAD(C)                                                                          \
-  {                                                                                          \
-    const int cc_ = min((C), nchunks - 1);                                                   \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                         \
-      const bool v_ = 32 * cc_ + a_k[i] < g.K;                                               \
-      gf32p p_ = (gf32p)(asrc[i] + (v_ ? 32 * cc_ : 0));                                     \
-      const f32x4 z_ = {0.f, 0.f, 0.f, 0.f};                                                 \
-      const f32x4 x0_ = *reinterpret_cast<gf32x4p>(p_);                                 \
-      const f32x4 x1_ = *reinterpret_cast<gf32x4p>(p_ + 4);                             \
-      ra[i][0] = v_ ? x0_ : z_;                                                              \
-      ra[i][1] = v_ ? x1_ : z_;                                                              \
-    }                                                                                        \
-    _Pragma("unroll") for (int i = 0; i < NB; ++i) rb[i] = ((gu32x4p)bsrc[i])[(long)cc_ * 384]; \
-  }
-  X3P_LOAD(0)
-  for (int c = 0; c < nchunks; ++c) {
-    u32x4 qa[TM][3];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) split8(ra[i][0], ra[i][1], qa[i][0], qa[i][1], qa[i][2]);
-    __syncthreads();                         // previous chunk fully consumed
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(sA + a_dst[i] + 1024 * p) = qa[i][p];
-#pragma unroll
-    for (int i = 0; i < NB; ++i) *reinterpret_cast<u32x4*>(sB + (tid + 256 * i) * 16) = rb[i];
-    __syncthreads();
-    X3P_LOAD(c + 1)                          // next chunk's global loads fly under the MFMAs
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bf16x8 fa[TM][3], fb[TN][3];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-          fa[i][p] = *reinterpret_cast<const bf16x8*>(sA + ((((wrb + i) * 2 + s) * 3 + p) * 64 + lane) * 16);
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-          fb[j][p] = *reinterpret_cast<const bf16x8*>(sB + ((((wcb + j) * 2 + s) * 3 + p) * 64 + lane) * 16);
-      // smallest terms first; consecutive MFMAs go to different accumulators
-#define X3P_TERM(PA, PB)                                                                        \
-  _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA], fb[j][PB], acc[i][j], 0, 0, 0);
-      X3P_TERM(2, 0) X3P_TERM(1, 1) X3P_TERM(0, 2) X3P_TERM(1, 0) X3P_TERM(0, 1) X3P_TERM(0, 0)
-#undef X3P_TERM
-    }
-  }
-#undef X3P_LOAD
-  x3p_epilogue<TM, TN>(g, acc, smem, m0, n0, wrb, wcb, wave, lane);
-}
-
+// (the first form of this kernel -- one LDS stage, two barriers per 32-deep chunk -- and the ablation /
+// stamp instantiations of the form below were removed in round 5: their measurements are DESIGN 3f)
 // ---- software-pipelined form: k stages of 16, TWO LDS stages, one barrier per stage.  Iteration kb
 // {barrier; split + store the staged registers (stage kb+1) into the other buffer; request stage
 // kb+2 from global memory; multiply stage kb} -- a wave's staging VALU / LDS stores and its MFMAs
@@ -1071,39 +961,21 @@ void launch_x3p(X3P& g, hipStream_t st) {
   g.tiles_m = (g.M + 64 * TM - 1) / (64 * TM);
   g.tiles_n = (g.N + 64 * TN - 1) / (64 * TN);
   const int total = g.tiles_m * g.tiles_n;
-  static int db = -1;          // S2T_X3P_DB=0: the two-barrier form (k chunks of 32, one LDS stage)
-  if (db < 0) { const char* e = getenv("S2T_X3P_DB"); db = e ? atoi(e) : 1; }
-  if (db) {
+  {
     // persistent grid: S2T_X3P_WGS workgroups per CU (default: what registers / LDS admit, <= 3)
     static int wgs = -1;
     if (wgs < 0) { const char* e = getenv("S2T_X3P_WGS"); wgs = e ? atoi(e) : 0; }
     const int per_cu = wgs > 0 ? wgs : g.wgs_per_cu > 0 ? g.wgs_per_cu : (TM * TN >= 4 ? 2 : TM * TN >= 2 ? 3 : 4);
     const int cap = 256 * per_cu;
     const int grid = std::min(((total + 7) / 8) * 8, cap);
-    static int abl = -1;       // S2T_X3P_ABL: ablation bit mask (diagnostics)
-    if (abl < 0) abl = s2t_debug_env("S2T_X3P_ABL");
-    static int diag = -1;      // S2T_X3P_DIAG=1: the instrumented build (tools/x3p_stamps.py)
-    if (diag < 0) { const char* e = getenv("S2T_X3P_DIAG"); diag = e ? atoi(e) : 0; }
     const bool drip = g.drip == 1 && ((g.K + 15) >> 4) >= 2 * TM * TN && grid < total;
     if (g.bal_stats)
       X3P_LAUNCH((x3p_db_kernel<TM, TN, false, 0, false, true>), grid, 256, 0);
-    else if (diag && g.stamps)
-      hipLaunchKernelGGL((x3p_db_kernel<TM, TN, true>), dim3(grid), dim3(256), 0, st, g);
     else if (drip)
       X3P_LAUNCH((x3p_db_kernel<TM, TN, false, 0, true>), grid, 256, 0);
-    else if (abl && TM * TN >= 2 && TM <= TN) {
-#define X3P_ABL_CASE(A) case A: hipLaunchKernelGGL((x3p_db_kernel<TM, TN, false, A>), dim3(grid), dim3(256), 0, st, g); break;
-      switch (abl) {
-        X3P_ABL_CASE(1) X3P_ABL_CASE(2) X3P_ABL_CASE(3) X3P_ABL_CASE(4) X3P_ABL_CASE(7) X3P_ABL_CASE(8)
-        X3P_ABL_CASE(16) X3P_ABL_CASE(17) X3P_ABL_CASE(24) X3P_ABL_CASE(23) X3P_ABL_CASE(15)
-        X3P_ABL_CASE(32) X3P_ABL_CASE(64) X3P_ABL_CASE(48) X3P_ABL_CASE(80)
-        default: hipLaunchKernelGGL((x3p_db_kernel<TM, TN>), dim3(grid), dim3(256), 0, st, g);
-      }
-#undef X3P_ABL_CASE
-    } else
+    else
       X3P_LAUNCH((x3p_db_kernel<TM, TN>), grid, 256, 0);
-  } else
-    X3P_LAUNCH((x3p_kernel<TM, TN>), ((total + 7) / 8) * 8, 256, 0);
+  }
 }
 
 // block tile from the shape: the widest tile that still gives the chip >= ~2 rounds of workgroups
