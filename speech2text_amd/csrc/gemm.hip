@@ -1191,12 +1191,11 @@ extern "C" int s2t_conv3x3_gemm(int mode, const float* x, int B, int H, int W, i
   GemmArgs g{w2_or_g, CO, x, 0, out, K9, CO, K9, (int)R, nullptr, nullptr, 0, nullptr, 0, 0, 0,
              0, db, 0, 0, 0, 0, 0, 0, 1.f, 0, 0, 0, pt};
   { static const int dbg = s2t_debug_env("S2T_GEMM_DEBUG"); g.debug = dbg; }
-  // the wave-specialised form (tn_w_body).  The zipformer frontend's 32 -> 128 conv (128 x 288 output
-  // over 600 k rows: 2 tiles, 256 slices) lasts 1.16 ms on it against 0.48 ms on the 64 x 64 form and
-  // the STEP is the same either way (37.64 / 37.66 ms, three pairs) -- as with the 600 k-row Linears,
-  // where sending them back to the 64 x 64 form costs +0.35 ms/step: on the side stream a launch's
-  // length is not its price.
-  if (tn_w() && tn_x3() && tn_p3() && CO >= 64 && K9 >= 128) {
+  // the wave-specialised form (tn_w_body) for outputs of >= 128 x 1024 (the conformer's 256 -> 256 conv:
+  // 24 tiles of 128 x 192).  The zipformer frontend's 32 -> 128 conv (128 x 288 output over 600 k rows:
+  // 2 tiles, 256 slices) lasts 1.16 ms on it against 0.48 ms on the 64 x 64 form; the STEP is the same
+  // either way (37.64 / 37.66 ms, three pairs), so the shorter launch is kept.
+  if (tn_w() && tn_x3() && tn_p3() && CO >= 128 && K9 >= 1024) {
     const int shape = tn_w_shape_of(g.M, g.N, g.tiles_m, g.tiles_n);
     const long tiles = (long)g.tiles_m * g.tiles_n;
     int splits = (int)((tn_w_blocks() + tiles - 1) / tiles);
