@@ -41,7 +41,7 @@ class TaskFactory(Enum):
         return cls[name].value
 
 
-def run_task(config, batches=None):
+def run_task(config, batches=None, val_batches=None):
     random.seed(1234)
     np.random.seed(1234)
     torch.manual_seed(1234)
@@ -51,7 +51,7 @@ def run_task(config, batches=None):
         raise NotImplementedError(
             "dataset loading is outside the accelerated path (SURVEY.md 8f); pass an iterable "
             "of batch dicts following dataset/utils.py:182-202 (or carrying 'pcm'/'pcm_length')")
-    trainer.fit(task, batches)
+    trainer.fit(task, batches, val_batches=val_batches)     # validation: Trainer.validate / val_history
     return task, trainer
 
 

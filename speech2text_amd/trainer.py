@@ -28,6 +28,10 @@ class Trainer:
         self.micro = 0
         self.task = None
         self.log_every = int(unused.get("log_every_n_steps", 50))     # Lightning's default
+        # Lightning's val_check_interval: a float = fraction of the training epoch between two
+        # validation passes (1.0 = once at the end of every epoch), an int = every n training batches
+        self.val_check_interval = unused.get("val_check_interval", 1.0)
+        self.val_history = []          # one dict of averaged validation metrics per validation pass
 
     # ------------------------------------------------------------------
     def setup(self, task, device=None):
@@ -126,12 +130,58 @@ class Trainer:
                 task.logged["dropped_steps"] = float(self.reducer.poll_dropped())
         return loss.detach()
 
-    def fit(self, task, batches, device=None):
+    def validate(self, task, val_batches):
+        """One validation pass (reference task_factory/*_task.py validation_step under Lightning's
+        validation loop): eval mode, no gradients, every logged scalar averaged over the batches --
+        and over the ranks when the job is data-parallel (Lightning's sync_dist=True).  Returns the
+        averaged dict and appends it to `val_history`."""
+        was_training = task.training
+        task.eval()
+        sums, n = {}, 0
+        with torch.no_grad():
+            for i, batch in enumerate(val_batches):
+                batch = {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+                out = task.validation_step(batch, i)
+                vals = out if isinstance(out, dict) else dict(getattr(task, "logged", {}))
+                for k, v in vals.items():
+                    sums[k] = sums.get(k, 0.0) + float(v)
+                n += 1
+        if was_training:
+            task.train()
+        if n == 0:
+            return {}
+        keys = sorted(sums)
+        t = torch.tensor([sums[k] for k in keys] + [float(n)], dtype=torch.float64)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            t = t.to(self.device) if dist.get_backend() == "nccl" else t
+            dist.all_reduce(t)
+            t = t.cpu()
+        res = {k: float(t[i] / t[-1]) for i, k in enumerate(keys)}
+        res["epoch"], res["global_step"] = task.current_epoch, task.global_step
+        self.val_history.append(res)
+        return res
+
+    def fit(self, task, batches, device=None, val_batches=None):
         if self.task is None:
             self.setup(task, device)
         task.train()
+        vci = self.val_check_interval
+        n_train = len(batches) if hasattr(batches, "__len__") else None
+        if isinstance(vci, float) and n_train:
+            every = max(1, int(round(vci * n_train)))          # fraction of an epoch
+        elif isinstance(vci, int) and vci > 0:
+            every = vci                                        # every n training batches
+        else:
+            every = None                                       # unknown length: at the end of the epoch
         for epoch in range(self.max_epochs):
             task.current_epoch = epoch
+            done = False
             for i, batch in enumerate(batches):
                 batch = {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in batch.items()}
                 self.training_step(batch, i)
+                done = False
+                if val_batches is not None and every and (i + 1) % every == 0:
+                    self.validate(task, val_batches)
+                    done = True
+            if val_batches is not None and not done:
+                self.validate(task, val_batches)

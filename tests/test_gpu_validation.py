@@ -170,3 +170,33 @@ def test_ssl_validation_step_topk(dev):
                                                    torch.from_numpy(md).to(dev))
     for k in (1, 5):
         assert float(m[f"top_{k}_acc"]) == pytest.approx(_ref_topk_acc(lg, lab, md, k), rel=1e-6)
+
+
+def test_trainer_fit_runs_validation_passes(dev):
+    """Trainer.fit(..., val_batches=...) (reference: Lightning's validation loop at val_check_interval):
+    a float interval is a fraction of the training epoch, an int a number of training batches; every
+    pass leaves one dict of batch-averaged metrics in val_history, the task is back in training mode
+    afterwards and training continues."""
+    from speech2text_amd.build_task import TaskFactory
+    from speech2text_amd.trainer import Trainer
+    cfg = _base_cfg()
+    cfg.update({"task": {"type": "CTC"}, "tokenizer": _TOK, "encoder": _CONF,
+                "decoder": {"model": "Projector", "config": {"input_dim": 64, "output_dim": _V, "dropout_p": 0.1}},
+                "loss": {"model": "CTC", "config": {"blank_label": 0, "reduction": "mean", "zero_infinity": True}},
+                "metric": {"decode_method": "ctc_greedy_search", "max_token_step": 5}})
+    cfg["trainer"].update({"max_epochs": 2, "accumulate_grad_batches": 1, "val_check_interval": 0.5})
+    torch.manual_seed(0)
+    task = TaskFactory.get("CTC")(cfg)
+    trainer = Trainer(**cfg["trainer"])
+    batch = _pcm_batch(dev, V=_V)
+    trainer.fit(task, [batch] * 4, device=dev, val_batches=[batch, batch])
+    assert len(trainer.val_history) == 4                      # twice per epoch, two epochs
+    for h in trainer.val_history:
+        assert {"val_loss", "wer", "epoch", "global_step"} <= set(h) and np.isfinite(h["val_loss"])
+    assert [h["global_step"] for h in trainer.val_history] == [2, 4, 6, 8]
+    assert trainer.val_history[-1]["val_loss"] < trainer.val_history[0]["val_loss"]
+    assert task.training
+    # an integer interval counts training batches; a pass is added at the end of an epoch that had none
+    trainer2 = Trainer(**dict(cfg["trainer"], max_epochs=1, val_check_interval=3))
+    trainer2.fit(TaskFactory.get("CTC")(cfg), [batch] * 4, device=dev, val_batches=[batch])
+    assert [h["global_step"] for h in trainer2.val_history] == [3, 4]
