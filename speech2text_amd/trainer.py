@@ -161,7 +161,31 @@ class Trainer:
         self.val_history.append(res)
         return res
 
-    def fit(self, task, batches, device=None, val_batches=None):
+    def _checkpoint(self, ck, res):
+        """ModelCheckpoint(dirpath, filename, monitor, mode, save_top_k) after a validation pass
+        (reference build_task.py:96-103): rank 0 writes `<name>-epoch=E-val_loss=L-<monitor>=S.ckpt`
+        when the monitored score enters the top-k table; the file that leaves the table is removed."""
+        from speech2text_amd import checkpoint as C
+        if dist.is_available() and dist.is_initialized() and dist.get_rank() != 0:
+            return None
+        tracker = ck.get("_tracker")
+        if tracker is None:
+            cfg = ck.get("config") or {}
+            tracker = ck["_tracker"] = C.BestK(monitor=cfg.get("monitor", "val_loss"),
+                                               save_top_k=cfg.get("save_top_k", 3), mode=cfg.get("mode", "min"))
+        if tracker.monitor not in res:
+            raise KeyError("checkpoint monitor %r is not among the validation metrics %s"
+                           % (tracker.monitor, sorted(res)))
+        score = res[tracker.monitor]
+        name = "%s-epoch=%d-val_loss=%.2f" % (ck.get("name", "task"), res["epoch"], res.get("val_loss", float("nan")))
+        if tracker.monitor != "val_loss":
+            name += "-%s=%.2f" % (tracker.monitor, score)
+        path = os.path.join(ck["dirpath"], name + ".ckpt")
+        return path if C.save_checkpoint(self, path, score=score, tracker=tracker) else None
+
+    def fit(self, task, batches, device=None, val_batches=None, checkpoint=None):
+        """checkpoint (optional): {"dirpath": ..., "name": ..., "config": the YAML's
+        callbacks.model_chkpt_config} -- a file is considered after every validation pass."""
         if self.task is None:
             self.setup(task, device)
         task.train()
@@ -181,7 +205,11 @@ class Trainer:
                 self.training_step(batch, i)
                 done = False
                 if val_batches is not None and every and (i + 1) % every == 0:
-                    self.validate(task, val_batches)
+                    res = self.validate(task, val_batches)
+                    if checkpoint is not None and res:
+                        self._checkpoint(checkpoint, res)
                     done = True
             if val_batches is not None and not done:
-                self.validate(task, val_batches)
+                res = self.validate(task, val_batches)
+                if checkpoint is not None and res:
+                    self._checkpoint(checkpoint, res)

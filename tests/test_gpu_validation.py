@@ -200,3 +200,44 @@ def test_trainer_fit_runs_validation_passes(dev):
     trainer2 = Trainer(**dict(cfg["trainer"], max_epochs=1, val_check_interval=3))
     trainer2.fit(TaskFactory.get("CTC")(cfg), [batch] * 4, device=dev, val_batches=[batch])
     assert [h["global_step"] for h in trainer2.val_history] == [3, 4]
+
+
+def test_run_task_checkpoints_resume_and_finetune(dev, tmp_path):
+    """run_task as the reference's (build_task.py:44-148) around the accelerated path: validation at
+    val_check_interval, ModelCheckpoint's top-k table on the monitored metric (files that fall out
+    are removed), `resume` continues the counters and the optimizer, `finetune.base_model` = the
+    checkpoint DIRECTORY starts from the average of its top-k files."""
+    import glob
+    import os
+    from speech2text_amd import build_task
+    cfg = _base_cfg()
+    cfg.update({"task": {"type": "CTC"}, "tokenizer": _TOK, "encoder": _CONF,
+                "decoder": {"model": "Projector", "config": {"input_dim": 64, "output_dim": _V, "dropout_p": 0.1}},
+                "loss": {"model": "CTC", "config": {"blank_label": 0, "reduction": "mean", "zero_infinity": True}},
+                "metric": {"decode_method": "ctc_greedy_search", "max_token_step": 5},
+                "callbacks": {"model_chkpt_config": {"monitor": "val_loss", "mode": "min", "save_top_k": 2}},
+                "finetune": {"base_model": None}, "resume": None})
+    cfg["trainer"].update({"max_epochs": 3, "accumulate_grad_batches": 1, "val_check_interval": 1.0})
+    batch = _pcm_batch(dev, V=_V)
+    exp = str(tmp_path / "exp")
+    task, trainer = build_task.run_task(cfg, [batch] * 3, [batch], export_dir=exp, name="ctc")
+    files = sorted(glob.glob(os.path.join(exp, "checkpoints", "*.ckpt")))
+    assert len(trainer.val_history) == 3 and len(files) == 2          # top-2 of three passes
+    assert all(os.path.basename(f).startswith("ctc-epoch=") and "val_loss=" in f for f in files)
+    ck = torch.load(max(files, key=os.path.getctime), map_location="cpu", weights_only=False)
+    assert ck["global_step"] == 9 and len(next(iter(ck["callbacks"].values()))["best_k_models"]) == 2
+    assert set(ck["state_dict"]) == set(task.state_dict())
+    # resume: counters and optimizer state continue
+    cfg2 = copy.deepcopy(cfg)
+    cfg2["resume"] = max(files, key=os.path.getctime)
+    cfg2["trainer"]["max_epochs"] = 1
+    task2, trainer2 = build_task.run_task(cfg2, [batch] * 3, [batch])
+    assert task2.global_step == 12 and trainer2.val_history[-1]["global_step"] == 12
+    assert trainer2.val_history[-1]["val_loss"] < trainer.val_history[0]["val_loss"]
+    # finetune from the directory: the average of the top-k files is written and loaded
+    cfg3 = copy.deepcopy(cfg)
+    cfg3["finetune"]["base_model"] = os.path.join(exp, "checkpoints")
+    cfg3["trainer"]["max_epochs"] = 1
+    task3, trainer3 = build_task.run_task(cfg3, [batch], [batch])
+    assert os.path.exists(os.path.join(exp, "checkpoints", "averaged.chkpt"))
+    assert task3.global_step == 1 and trainer3.val_history[0]["val_loss"] < trainer.val_history[0]["val_loss"]
