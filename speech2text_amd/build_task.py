@@ -66,12 +66,12 @@ def run_task(config, batches=None, val_batches=None, export_dir=None, name="task
             "dataset loading is outside the accelerated path (SURVEY.md 8f); pass an iterable "
             "of batch dicts following dataset/utils.py:182-202 (or carrying 'pcm'/'pcm_length')")
     trainer.setup(task)
-    if config.get("resume"):
-        C.resume(trainer, config["resume"])
+    resumed = C.resume(trainer, config["resume"]) if config.get("resume") else None
     ck = None
     chk_cfg = (config.get("callbacks") or {}).get("model_chkpt_config")
     if export_dir is not None and chk_cfg:
-        ck = {"dirpath": os.path.join(export_dir, "checkpoints"), "name": name, "config": chk_cfg}
+        ck = {"dirpath": os.path.join(export_dir, "checkpoints"), "name": name, "config": chk_cfg,
+              "resumed_best_k": C.resumed_best_k(resumed) if resumed else None}
     trainer.fit(task, batches, val_batches=val_batches, checkpoint=ck)
     return task, trainer
 

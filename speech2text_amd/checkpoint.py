@@ -115,7 +115,20 @@ def resume(trainer, path):
         trainer.scheduler.load_state_dict(ck["lr_schedulers"][0])
     trainer.task.current_epoch = int(ck.get("epoch", 0))
     trainer.task.global_step = int(ck.get("global_step", 0))
+    # the files ModelCheckpoint writes are end-of-validation files of epoch E: fit continues at
+    # E + 1 and stops at max_epochs (Lightning's fit loop after ckpt_path)
+    trainer.start_epoch = trainer.task.current_epoch + 1
     return ck
+
+
+def resumed_best_k(ck):
+    """The checkpoint callback's path -> score table stored in a resumed file (all callbacks'
+    entries merged), for the new run's BestK tracker: files written before the resume stay in the
+    top-k bookkeeping (eviction, `model_average`'s pool)."""
+    table = {}
+    for state in (ck.get("callbacks") or {}).values():
+        table.update(state.get("best_k_models") or {})
+    return table
 
 
 def _latest(chkpt_dir):

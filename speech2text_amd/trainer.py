@@ -132,30 +132,45 @@ class Trainer:
 
     def validate(self, task, val_batches):
         """One validation pass (reference task_factory/*_task.py validation_step under Lightning's
-        validation loop): eval mode, no gradients, every logged scalar averaged over the batches --
-        and over the ranks when the job is data-parallel (Lightning's sync_dist=True).  Returns the
-        averaged dict and appends it to `val_history`."""
+        validation loop): eval mode, no gradients, every logged scalar averaged over the SAMPLES of
+        the pass (Lightning's epoch-level log_dict reduction weights a batch by its size) -- and over
+        the ranks when the job is data-parallel (sync_dist=True).  Every rank takes part in the
+        reduction, also one whose shard of the validation set is empty.  Returns the averaged dict
+        (empty when no rank saw a batch) and appends it to `val_history`."""
         was_training = task.training
         task.eval()
-        sums, n = {}, 0
+        sums, n = {}, 0.0
         with torch.no_grad():
             for i, batch in enumerate(val_batches):
                 batch = {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in batch.items()}
                 out = task.validation_step(batch, i)
                 vals = out if isinstance(out, dict) else dict(getattr(task, "logged", {}))
+                bs = 1.0
+                for v in batch.values():                       # batch size = leading dimension
+                    if torch.is_tensor(v) and v.dim() >= 1:
+                        bs = float(v.shape[0])
+                        break
                 for k, v in vals.items():
-                    sums[k] = sums.get(k, 0.0) + float(v)
-                n += 1
+                    sums[k] = sums.get(k, 0.0) + float(v) * bs
+                n += bs
         if was_training:
             task.train()
-        if n == 0:
-            return {}
-        keys = sorted(sums)
-        t = torch.tensor([sums[k] for k in keys] + [float(n)], dtype=torch.float64)
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if multi:
+            # the metric names of a task are fixed (its `_metric` / loss keys): a rank without
+            # batches learns them from the others so that all ranks reduce the same vector
+            names = [None] * dist.get_world_size()
+            dist.all_gather_object(names, sorted(sums))
+            keys = sorted(set().union(*[set(x) for x in names]))
+        else:
+            keys = sorted(sums)
+        t = torch.tensor([sums.get(k, 0.0) for k in keys] + [n], dtype=torch.float64)
+        if multi:
             t = t.to(self.device) if dist.get_backend() == "nccl" else t
             dist.all_reduce(t)
             t = t.cpu()
+        if float(t[-1]) == 0.0:
+            return {}
         res = {k: float(t[i] / t[-1]) for i, k in enumerate(keys)}
         res["epoch"], res["global_step"] = task.current_epoch, task.global_step
         self.val_history.append(res)
@@ -163,29 +178,37 @@ class Trainer:
 
     def _checkpoint(self, ck, res):
         """ModelCheckpoint(dirpath, filename, monitor, mode, save_top_k) after a validation pass
-        (reference build_task.py:96-103): rank 0 writes `<name>-epoch=E-val_loss=L-<monitor>=S.ckpt`
-        when the monitored score enters the top-k table; the file that leaves the table is removed."""
+        (reference build_task.py:94-103): rank 0 writes `<name>-epoch=E-val_loss=L-<monitor>=S.ckpt`
+        (the monitor field is ALWAYS appended, as the reference's filename template does -- also when
+        the monitor is val_loss) when the monitored score enters the top-k table; the file that
+        leaves the table is removed; a name already in the table gets Lightning's `-vN` suffix."""
         from speech2text_amd import checkpoint as C
-        if dist.is_available() and dist.is_initialized() and dist.get_rank() != 0:
-            return None
         tracker = ck.get("_tracker")
         if tracker is None:
             cfg = ck.get("config") or {}
             tracker = ck["_tracker"] = C.BestK(monitor=cfg.get("monitor", "val_loss"),
                                                save_top_k=cfg.get("save_top_k", 3), mode=cfg.get("mode", "min"))
-        if tracker.monitor not in res:
+            tracker.best_k_models.update(ck.get("resumed_best_k") or {})
+        if tracker.monitor not in res:                       # (raised on every rank alike)
             raise KeyError("checkpoint monitor %r is not among the validation metrics %s"
                            % (tracker.monitor, sorted(res)))
+        if dist.is_available() and dist.is_initialized() and dist.get_rank() != 0:
+            return None
         score = res[tracker.monitor]
-        name = "%s-epoch=%d-val_loss=%.2f" % (ck.get("name", "task"), res["epoch"], res.get("val_loss", float("nan")))
-        if tracker.monitor != "val_loss":
-            name += "-%s=%.2f" % (tracker.monitor, score)
-        path = os.path.join(ck["dirpath"], name + ".ckpt")
+        name = "%s-epoch=%d-val_loss=%.2f-%s=%.2f" % (ck.get("name", "task"), res["epoch"],
+                                                      res.get("val_loss", float("nan")), tracker.monitor, score)
+        path, v = os.path.join(ck["dirpath"], name + ".ckpt"), 0
+        while path in tracker.best_k_models or os.path.exists(path):
+            v += 1
+            path = os.path.join(ck["dirpath"], "%s-v%d.ckpt" % (name, v))
         return path if C.save_checkpoint(self, path, score=score, tracker=tracker) else None
 
     def fit(self, task, batches, device=None, val_batches=None, checkpoint=None):
         """checkpoint (optional): {"dirpath": ..., "name": ..., "config": the YAML's
-        callbacks.model_chkpt_config} -- a file is considered after every validation pass."""
+        callbacks.model_chkpt_config} -- a file is considered after every validation pass.
+        After `checkpoint.resume` (an end-of-epoch file of epoch E) the loop continues at epoch
+        E + 1 and stops at max_epochs, as `trainer.fit(ckpt_path=...)` does in the reference
+        (build_task.py:148)."""
         if self.task is None:
             self.setup(task, device)
         task.train()
@@ -197,7 +220,7 @@ class Trainer:
             every = vci                                        # every n training batches
         else:
             every = None                                       # unknown length: at the end of the epoch
-        for epoch in range(self.max_epochs):
+        for epoch in range(int(getattr(self, "start_epoch", 0)), self.max_epochs):
             task.current_epoch = epoch
             done = False
             for i, batch in enumerate(batches):

@@ -130,7 +130,7 @@ def _param(dst, p, lo=0.0, hi=0.0):
 
 class _Layer:
     """Everything static about one layer object: descriptor, module lists, workspace sizes."""
-    __slots__ = ("desc", "ok", "whitens", "params", "store", "weights", "sizes", "key")
+    __slots__ = ("desc", "ok", "whitens", "params", "store", "weights", "sizes", "key", "versions")
 
 
 def _build(layer):
@@ -225,6 +225,7 @@ def _build(layer):
     ent = flat._OWNER.get(id(mid.bypass_scale))
     L.store = ent[0] if ent is not None else None
     L.weights = weights
+    L.versions = None
     L.sizes = {}
     L.key = (id(L.store), None if L.store is None else L.store.flat_p.data_ptr())
     return L
@@ -291,15 +292,32 @@ def _side_handle():
 
 def usable(layer, T, B):
     """Can the native executor serve this layer call?  (zip_layer.eligible has passed already.)"""
-    if not ENABLED or N._Prof.target == "*" or "S2T_ATTN_FWD_OLD" in os.environ:
+    if not ENABLED or "S2T_ATTN_FWD_OLD" in os.environ:
+        return None
+    # a profile of an entry point whose launches are only seen from the Python call sites ("*", or any
+    # single entry that is not sampled inside the library) needs the Python executor
+    if N._Prof.target is not None and N._Prof.target not in N.KERNEL_TIMED:
         return None
     L = _static(layer)
     if not L.ok:
         return None
-    # weight pieces current? (refreshes them when the optimizer has moved the parameters)
-    for w in L.weights:
-        planes.pieces(w, 0)
-        break
+    # weight pieces current?  The first lookup refreshes ALL of them when the store's epoch moved
+    # (the optimizers, the DP broadcast); an in-place torch edit of any single matrix of the layer
+    # (partial load_state_dict, weight.mul_) shows in that parameter's _version: one integer
+    # compare per weight, and a refresh through the owning arena when one moved
+    planes.pieces(L.weights[0], 0)
+    if L.versions is None:                         # (weight, its arena entry) pairs, once per layer object
+        L.versions = []
+        for w in L.weights:
+            a = planes.arena_of(w)
+            e = None if a is None else a.entries.get(w.data_ptr())
+            if e is not None:
+                L.versions.append((w, e, a))
+    for w, e, a in L.versions:
+        if e.version != w._version:
+            a.refresh()
+            planes._HOT.clear()
+            break
     if N.lib().s2t_zip_layer_plans_missing(ctypes.byref(L.desc), T, B) != 0:
         return None
     return L

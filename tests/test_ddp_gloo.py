@@ -243,3 +243,48 @@ def test_world4_uneven_late_parameters_drop_steps_cleanly():
                 assert flags[step] == 0.0 and norms[step] > 0 and moved[step] > 0, (rank, step)
         assert same, f"rank {rank}: replicas diverged"
         assert finite
+
+
+class _ValTask(torch.nn.Module):
+    """Stand-in for a task's validation surface (task_factory/*_task.py validation_step): the
+    metric of a batch is its mean, so the expected job-wide result is known in closed form."""
+    current_epoch, global_step = 0, 0
+
+    def validation_step(self, batch, i):
+        return {"val_loss": batch["x"].mean(), "wer": batch["x"].max()}
+
+
+def _val_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from speech2text_amd.trainer import Trainer
+    tr = Trainer()
+    tr.device = torch.device("cpu")
+    task = _ValTask()
+    task.train()
+    # rank 0: a batch of 3 samples (all 1.0) and one of 1 sample (5.0); rank 1: NO batch at all
+    batches = [{"x": torch.full((3, 2), 1.0)}, {"x": torch.full((1, 2), 5.0)}] if rank == 0 else []
+    res = tr.validate(task, batches)
+    empty = tr.validate(task, [])                       # nobody has a batch: {} on every rank, no hang
+    q.put((rank, res.get("val_loss"), res.get("wer"), empty, task.training))
+    dist.destroy_process_group()
+
+
+def test_validate_every_rank_reduces_and_weights_by_batch_size():
+    """Trainer.validate in a data-parallel job: a rank whose validation shard is empty still takes
+    part in the all-reduce (no hang) and gets the job-wide result; the mean is over SAMPLES
+    (Lightning's epoch-level reduction): (3 * 1.0 + 1 * 5.0) / 4 = 2.0, not the batch mean 3.0."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_val_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, vl, wer, empty, training in got:
+        assert vl == pytest.approx(2.0) and wer == pytest.approx(2.0)
+        assert empty == {} and training

@@ -90,10 +90,32 @@ def test_c3_yaml_dims_two_utterances_vs_oracle(dev):
     assert same >= 0.98, same                               # argmax ties can move a window by one
 
 
-@pytest.mark.parametrize("rv,chunk", [(0.0, (-1, -1)), (0.2, (-1, -1)), (0.2, (32, 128)), (0.0, (16, 64)),
-                                      (0.2, (64, 256))])
-def test_c3_yaml_dims_training_step_gradients_vs_oracle(dev, monkeypatch, rv, chunk):
-    """The code the bench times -- the layer executor's backward at D = 192 / 256, H = 4 / 8,
+def _warm_gemm_plans(cfg, fb, dev, rv):
+    """One untimed training step on a SECOND task object of the same shapes: the first step of a
+    process runs the Python layer executor, which times the step's GEMM shape buckets
+    (zip_kernels.lt_matmul -> s2t_zl_plan_put); the table is per process, not per model, so the step
+    that is compared afterwards is served by the native executor (csrc/zip_layer.hip) -- the code
+    bench.py times from its second step on -- while the compared task's own state (Whiten.prob,
+    Balancer counters, parameters) is untouched."""
+    from speech2text_amd import flat
+    from speech2text_amd.build_task import TaskFactory
+    st = random.getstate()
+    warm = TaskFactory.get("Pruned_Rnnt")(cfg).to(dev)
+    flat.get_store([p for p in warm.parameters() if p.requires_grad])
+    warm.train()
+    warm.training_step(fb, 0).backward()
+    torch.cuda.synchronize()
+    del warm
+    random.setstate(st)
+
+
+@pytest.mark.parametrize("rv,chunk,native", [(0.0, (-1, -1), True), (0.2, (-1, -1), True),
+                                             (0.2, (32, 128), True), (0.0, (16, 64), True),
+                                             (0.2, (64, 256), True), (0.2, (-1, -1), False)])
+def test_c3_yaml_dims_training_step_gradients_vs_oracle(dev, monkeypatch, rv, chunk, native):
+    """The code the bench times -- the NATIVE per-layer executor (csrc/zip_layer.hip; `native`
+    False: the Python executor of the same launch sequence, zip_layer._LayerFn, so that both stay
+    pinned to the oracle) -- i.e. the layer executor's backward at D = 192 / 256, H = 4 / 8,
     K = 31 / 15, T = 495 ... 62, the stateless predictor, the joiner with the simple loss, prune
     ranges and the fused pruned lattice -- in TRAINING mode at the YAML dims: 2 x 10 s (ragged),
     Python `random` pinned (0.0: every Balancer / Whiten / limit_param_value and the attention
@@ -106,7 +128,7 @@ def test_c3_yaml_dims_training_step_gradients_vs_oracle(dev, monkeypatch, rv, ch
     model/encoder/zipformer.py:290-317,409-448): the chunk-masked attention forward / backward
     tiles and the chunk-causal depthwise conv's edge scaling (model/layer/scaling.py:622-681) at
     T = 495 ... 62, H = 4 / 8, K = 31 / 15."""
-    from speech2text_amd import flat, rng, zip_layer
+    from speech2text_amd import flat, rng, zip_layer, zip_native
     from speech2text_amd.build_task import TaskFactory
     monkeypatch.setattr(rng, "rand", lambda *s, device=None, dtype=torch.float32:
                         torch.rand(*s, dtype=dtype).to(device))
@@ -135,13 +157,19 @@ def test_c3_yaml_dims_training_step_gradients_vs_oracle(dev, monkeypatch, rv, ch
             mod.dropout.p = 0.0
     fb = {"feat": feat, "feat_length": feat_len, "label": batch["label"],
           "label_length": batch["label_length"]}
-    calls0 = zip_layer.CALLS[0]
     monkeypatch.setattr(random, "random", lambda: rv)
+    monkeypatch.setattr(zip_native, "ENABLED", native)
+    if native:
+        _warm_gemm_plans(cfg, fb, dev, rv)
+    calls0, nat0 = zip_layer.CALLS[0], list(zip_native.CALLS)
     torch.manual_seed(7)
     loss = task.training_step(fb, 0)
     loss.backward()
     torch.cuda.synchronize()
     assert zip_layer.CALLS[0] - calls0 == 12, "the layer executor did not serve every layer"
+    moved = [zip_native.CALLS[0] - nat0[0], zip_native.CALLS[1] - nat0[1]]
+    assert moved == ([12, 12] if native else [0, 0]), \
+        f"native executor served {moved} forward / backward layer calls of 12 / 12"
     # ---- oracle, same parameters / features / decisions
     enc_sd = {k[len("_encoder.encoder."):]: v for k, v in sd.items() if k.startswith("_encoder.encoder.")}
     lab, lab_len = batch["label"].cpu(), batch["label_length"].cpu()

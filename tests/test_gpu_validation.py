@@ -227,13 +227,27 @@ def test_run_task_checkpoints_resume_and_finetune(dev, tmp_path):
     ck = torch.load(max(files, key=os.path.getctime), map_location="cpu", weights_only=False)
     assert ck["global_step"] == 9 and len(next(iter(ck["callbacks"].values()))["best_k_models"]) == 2
     assert set(ck["state_dict"]) == set(task.state_dict())
-    # resume: counters and optimizer state continue
+    # the reference's file name template always carries the monitor field (build_task.py:94-95)
+    assert all(os.path.basename(f).count("val_loss=") == 2 for f in files)
+    # resume (Lightning's fit(ckpt_path=...)): counters, optimizer state AND the epoch loop continue
+    # -- the epoch-2 file resumed with max_epochs 4 trains exactly one more epoch (epoch 3), the
+    # top-k table of the resumed file stays in force (2 files on disk, the old worst one evicted)
     cfg2 = copy.deepcopy(cfg)
     cfg2["resume"] = max(files, key=os.path.getctime)
-    cfg2["trainer"]["max_epochs"] = 1
-    task2, trainer2 = build_task.run_task(cfg2, [batch] * 3, [batch])
-    assert task2.global_step == 12 and trainer2.val_history[-1]["global_step"] == 12
+    cfg2["trainer"]["max_epochs"] = 4
+    task2, trainer2 = build_task.run_task(cfg2, [batch] * 3, [batch], export_dir=exp, name="ctc")
+    assert task2.global_step == 12 and task2.current_epoch == 3
+    assert [h["global_step"] for h in trainer2.val_history] == [12]
     assert trainer2.val_history[-1]["val_loss"] < trainer.val_history[0]["val_loss"]
+    files2 = sorted(glob.glob(os.path.join(exp, "checkpoints", "*.ckpt")))
+    assert len(files2) == 2 and any("epoch=3" in os.path.basename(f) for f in files2)
+    ck2 = torch.load(max(files2, key=os.path.getctime), map_location="cpu", weights_only=False)
+    assert set(next(iter(ck2["callbacks"].values()))["best_k_models"]) == set(files2)
+    # resuming a finished run trains nothing
+    cfg2b = copy.deepcopy(cfg2)
+    cfg2b["trainer"]["max_epochs"] = 3
+    task2b, trainer2b = build_task.run_task(cfg2b, [batch] * 3, [batch])
+    assert task2b.global_step == 9 and trainer2b.val_history == []
     # finetune from the directory: the average of the top-k files is written and loaded
     cfg3 = copy.deepcopy(cfg)
     cfg3["finetune"]["base_model"] = os.path.join(exp, "checkpoints")

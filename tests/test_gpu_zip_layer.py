@@ -152,3 +152,40 @@ def test_native_executor_matches_python_executor(dev, monkeypatch, rv, chunk, le
         probs = [w.prob for w in m.modules() if isinstance(w, Whiten)]
         assert probs1 is None or probs == probs1
         probs1 = probs
+
+
+def test_native_executor_sees_an_in_place_edit_of_any_weight(dev, monkeypatch):
+    """The native executor's descriptor holds the addresses of the weights' pre-split bf16 pieces
+    (planes.py).  An in-place torch edit of ONE matrix of a layer -- not the first the freshness
+    check looks at, no optimizer step, no epoch bump (a partial load_state_dict, a manual
+    weight.mul_) -- must be seen through that parameter's _version: the forward after the edit is
+    bit-identical to the Python executor's, which looks every weight up."""
+    from speech2text_amd import rng, zip_layer, zip_native
+    from speech2text_amd.model.layer import scaling as S
+    monkeypatch.setattr(rng, "rand", lambda *s, device=None, dtype=torch.float32:
+                        torch.rand(*s, dtype=dtype).to(device))
+    monkeypatch.setattr(S, "_rand", lambda: 0.5)
+    m, store = _build(dev, (-1,), (-1,))
+    g = torch.Generator().manual_seed(11)
+    B, T = 4, 203
+    x = (torch.randn(B, T, 80, generator=g) * 2).to(dev)
+    lens = torch.tensor([203, 180, 97, 64]).to(dev)
+    with torch.no_grad():
+        wts = torch.randn(m(x, lens)[0].shape, generator=g).to(dev)
+
+    def step(native):
+        monkeypatch.setattr(zip_native, "ENABLED", native)
+        _force(m, False)
+        return _step(m, store, x, lens, wts, 3, True)
+
+    step(False)
+    y_before, _, _ = step(True)
+    layer = [mod for mod in m.modules() if mod.__class__.__name__ == "Zipformer2EncoderLayer"][-1]
+    with torch.no_grad():
+        layer.feed_forward3.out_proj.weight.mul_(1.5)          # (a late weight of the last layer)
+    n0 = list(zip_native.CALLS)
+    y1, gx1, _ = step(True)
+    assert zip_native.CALLS[0] - n0[0] == 4
+    y0, gx0, _ = step(False)
+    assert not torch.equal(y1, y_before)
+    assert torch.equal(y1, y0) and torch.equal(gx1, gx0)
