@@ -433,6 +433,15 @@ def cpu_baseline_c5(cfg, state_dict, seconds=30.0, batch=2, steps=3, warmup=1):
 # pipe is the dense bf16 peak / 6 -- reported next to the f32-MFMA fraction for the entries that
 # run on it, so that a kernel on the bf16 cores is not flattered by the smaller f32 peak
 BF16X3_CEILING_TFLOPS = 2500.0 / 6.0
+# ... and as THREE products of the two-piece split (S2T_GEMM_ARITH=2, "bf16x2/3"): dense bf16 peak / 3
+BF16X2_CEILING_TFLOPS = 2500.0 / 3.0
+
+
+def gemm_arith():
+    """(name, ceiling TFLOP/s fp32-equivalent) of the arithmetic the library's bf16 GEMMs run in."""
+    from speech2text_amd import zip_kernels as zk
+    a = zk.gemm_arith()
+    return zk.gemm_arith_name(a), (BF16X3_CEILING_TFLOPS if a == 3 else BF16X2_CEILING_TFLOPS)
 BF16X3_ENTRIES = ("s2t_gemm_x3p", "s2t_gemm_x3p_bal", "s2t_gemm_x3p_map", "s2t_gemm_tn_grouped", "s2t_gemm_f32", "s2t_gemm_f32_sq",
                   "s2t_gemm_xtx", "s2t_conv3x3_gemm")
 
@@ -447,6 +456,7 @@ def roofline_report(prof_timed, prof_all, want, step_flops, ms_per_step, sampled
     """`prof_timed`: HIP-event timings of the chosen entry point taken INSIDE the timed region.
     `prof_all`: every hand-written entry point, timed over extra (untimed) steps."""
     table = []
+    arith_name, ceiling = gemm_arith()
     for name, p in sorted(prof_all.items(), key=lambda kv: -kv[1]["total_ms"]):
         row = {"entry": name, "launches_per_step": p["launches_per_step"],
                "ms_per_step": p["ms_per_step"], "avg_us": 1000.0 * p["avg_ms"]}
@@ -457,7 +467,7 @@ def roofline_report(prof_timed, prof_all, want, step_flops, ms_per_step, sampled
                 tf = p["algo_flops"] / (p["total_ms"] * 1e-3) / 1e12
                 row.update(alg_TFLOPs=tf, frac_mfma=tf / MFMA_F32_PEAK_TFLOPS)
                 if name in BF16X3_ENTRIES:
-                    row.update(frac_bf16x3_ceiling=tf / BF16X3_CEILING_TFLOPS)
+                    row.update(frac_bf16_ceiling=tf / ceiling)
         table.append(row)
     out = {"bound": "hbm", "kernel": want, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": None, "traffic": None}
@@ -469,14 +479,18 @@ def roofline_report(prof_timed, prof_all, want, step_flops, ms_per_step, sampled
                        frac=ach / MFMA_F32_PEAK_TFLOPS,
                        algorithmic_flops_per_launch=p["algo_flops"] / p["launches"])
             if want in BF16X3_ENTRIES:
-                out.update(frac_bf16x3_ceiling=ach / BF16X3_CEILING_TFLOPS,
-                           bf16x3_ceiling_tflops=BF16X3_CEILING_TFLOPS)
+                # the pipe this entry runs on: dense bf16 peak / products per fp32 term of the arithmetic
+                out.update(gemm_arith=arith_name, frac_bf16_ceiling=ach / ceiling, bf16_ceiling_tflops=ceiling)
         else:
             ach = p["algo_bytes"] / (p["total_ms"] * 1e-3) / 1e9
             out.update(achieved=ach, frac=ach / HBM_PEAK_GBS)
         out.update(launches=p["launches"], sampled_every=sampled_every,
                    avg_launch_ms=p["avg_ms"],
                    algorithmic_bytes_per_launch=p["algo_bytes"] / p["launches"])
+        if p.get("algo_bytes_min"):
+            # operands every such product must move (A, C, the weight pieces) WITHOUT the epilogue's
+            # extra operands and second outputs, which algorithmic_bytes_per_launch includes
+            out["algorithmic_bytes_min_per_launch"] = p["algo_bytes_min"] / p["launches"]
     else:
         out["note"] = f"{want} was not launched in the timed region"
     tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
@@ -771,6 +785,7 @@ def main(argv=None):
                        "accumulate_grad_batches": args.accum,
                        "ddp_forced_on_one_rank": args.ddp_force,
                        "gemm_paths": gemm_paths(),
+                       "gemm_arith": gemm_arith()[0],
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "utterance_seconds": args.seconds, "labels_per_utt": args.labels,
                        "parallelism": f"dp{world}", "final_loss": final_loss},

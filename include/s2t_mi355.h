@@ -695,7 +695,22 @@ int s2t_predictor_ctx_bwd(const int* tokens, const float* emb, const float* w, c
  *   stream after it from one launch).  K % 8 == 0, N % 4 == 0, rows
  *   16-byte aligned (else -2).  tile = 0 (from the shape) | 11 | 12 | 21 | 22: block tile
  *   (64 tm) x (64 tn); + 100 w: w persistent workgroups per CU; + 1000: a tile's output is
- *   stored in slices under the next tile's multiplications (persistent grids). */
+ *   stored in slices under the next tile's multiplications (persistent grids, three pieces only);
+ *   2000 + tm tn: the form that moves the weight pieces global -> LDS directly, + 200 (two-piece
+ *   arithmetic only): 32-deep barrier intervals.  -2: a tile code the current arithmetic has not. */
+/* ---- the arithmetic of every bf16 matrix-core GEMM of the library (s2t_gemm_x3p*, the weight-gradient /
+ * NT / NN / batched kernels of csrc/gemm.hip): pieces per fp32 operand.
+ *   3 ("bf16x3/6"): x = p0 + p1 + p2 exactly, six piece products per term: fp32-level error
+ *       (<= 2e-6 of the result's max against fp64);
+ *   2 ("bf16x2/3"): x ~ p0 + p1 (2^-18 relative), the products a0 b0 + a0 b1 + a1 b0: ~ 2^-17 per
+ *       term -- torch's float32 matmul precision "high"; the reference trains under the looser
+ *       "medium" (reference build_task.py:79, inference.py:58).
+ * s2t_gemm_arith() is consulted PER CALL by every such entry point: s2t_gemm_arith_set's value
+ * (2 | 3) if one is pinned (0 = unpinned), else the environment's S2T_GEMM_ARITH ("2" | "3" |
+ * "bf16x2" | "bf16x3" | "bf16x2/3" | "bf16x3/6"), else the built-in default.  The weights' piece
+ * image (s2t_x3p_split) is the same for both: two-piece launches read its first two pieces. */
+int s2t_gemm_arith(void);
+int s2t_gemm_arith_set(int arith);
 typedef struct {
   long src_off;
   long dst_off;
@@ -757,9 +772,12 @@ int s2t_stream_order(void* from, void* to);
  * layer executor issues are sampled like the Python call sites'): every `every`-th launch between
  * begin and end carries its own event pair; end waits for them and reports how many were timed, their
  * total milliseconds and the algorithmic bytes / flops of exactly those launches
- * (4 M (N + K + operands N) + 6 N K bytes, 2 M N K flops).  s2t_gemm_x3p_calls: launches so far. */
+ * (4 M (N + K + operands N) + 2 P N K bytes for P pieces, 2 M N K flops).  s2t_gemm_x3p_calls: launches so far. */
 int s2t_x3p_sample_begin(int every);
 int s2t_x3p_sample_end(long* launches, double* total_ms, double* bytes, double* flops);
+/* of the sample closed last: 4 M (N + K) + 2 P N K summed -- A, C and the weight pieces only, without the
+ * epilogue operands and second outputs the figure above includes */
+int s2t_x3p_sample_min_bytes(double* bytes_min);
 long s2t_gemm_x3p_calls(void);
 long s2t_linear_lt_calls(void);
 int s2t_prof_pair_create(void** start, void** stop);
@@ -909,7 +927,8 @@ int s2t_zip_layer_bwd(const S2tZipLayerDesc* desc, const S2tZipLayerCall* call, 
 long s2t_zip_layer_info(const void* state, int what, int idx);
 void* s2t_zip_layer_error(void);
 /* the timings zip_kernels.lt_matmul took for a shape bucket {mode, half-octave of the rows, N, K} of a
- * Linear: library ms, own-kernel ms (< 0: none) and its tile -- what the executor's plan is made of */
+ * Linear: library ms, own-kernel ms (< 0: none) and its tile -- what the executor's plan is made of.
+ * mode = (0 forward | 1 data gradient) | (the arithmetic the bucket was timed under, s2t_gemm_arith()) << 4 */
 int s2t_zl_plan_put(int mode, int half_oct, int N, int K, double t_lib_ms, double t_own_ms, int tile);
 int s2t_zl_plan_clear(void);
 long s2t_zl_plan_count(void);

@@ -222,10 +222,12 @@ def profile_end():
         n, ms, nb, fl = ctypes.c_long(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
         check(_lib._cdll.s2t_x3p_sample_end(ctypes.byref(n), ctypes.byref(ms), ctypes.byref(nb),
                                             ctypes.byref(fl)), "s2t_x3p_sample_end")
+        nmin = ctypes.c_double()
+        check(_lib._cdll.s2t_x3p_sample_min_bytes(ctypes.byref(nmin)), "s2t_x3p_sample_min_bytes")
         if n.value > 0:
             out[sampled] = {"launches": int(n.value), "total_ms": float(ms.value),
                             "avg_ms": float(ms.value) / n.value, "algo_bytes": float(nb.value),
-                            "algo_flops": float(fl.value)}
+                            "algo_flops": float(fl.value), "algo_bytes_min": float(nmin.value)}
     return out
 
 

@@ -23,6 +23,11 @@ static inline int s2t_debug_env(const char* name) {
   return 0;
 }
 
+// arithmetic of the bf16 GEMMs: pieces per fp32 operand, 3 (six products, fp32-exact) or 2 (three
+// products); read per call from S2T_GEMM_ARITH (csrc/gemm_x3p.hip)
+#define S2T_GEMM_ARITH_DEFAULT 3
+extern "C" int s2t_gemm_arith(void);
+
 #define S2T_WAVE 64
 #define S2T_NEG_INF (-__builtin_huge_valf())
 

@@ -44,6 +44,15 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& p0, uns
   p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
 }
 
+// the two leading pieces only (S2T_GEMM_ARITH=2, csrc/gemm_x3p.hip: x = p0 + p1 + O(2^-18 |x|))
+__device__ __forceinline__ void split_pair2(float x0, float x1, unsigned& p0, unsigned& p1) {
+  f32x2 x = {x0, x1};
+  p0 = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+  f32x2 h = {__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xFFFF0000u)};
+  x = x - h;
+  p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+}
+
 constexpr int BK0 = 32;   // contraction chunk of the big tiles; the 64x64 tile uses 64
 enum { MODE_NT = 0, MODE_NN = 1, MODE_TN = 2 };
 enum { ACT_NONE = 0, ACT_SWOOSH_L = 1, ACT_SWOOSH_R = 2 };
@@ -96,6 +105,10 @@ struct GemmArgs {
   const float* sq_other;
   long ld_sq;
   float* sq_sums;
+  // bf16 pieces per fp32 operand of the matrix-core paths: 2 = the three leading products of the
+  // two-piece split, anything else = three pieces, six products (s2t_gemm_arith(), read per call
+  // by the entry points; uniform over the launch)
+  int np;
 };
 
 __device__ __forceinline__ float log1p_fast(float e) {   // as zip_elem.hip
@@ -217,6 +230,7 @@ __device__ __forceinline__ void tn_p3_body(const GemmArgs& g, const unsigned bid
   const int kend = min(g.K, kbeg + g.kper);
   if (kbeg >= kend) return;
   const bool want_csum = g.colsum != nullptr && tn == csum_tn;
+  const bool np3 = g.np != 2;            // (uniform: three pieces / six products, or two / three)
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -251,15 +265,23 @@ __device__ __forceinline__ void tn_p3_body(const GemmArgs& g, const unsigned bid
     }                                                                                          \
     if (CSUM) csum[u] += ((v_[0] + v_[1]) + (v_[2] + v_[3])) + ((v_[4] + v_[5]) + (v_[6] + v_[7])); \
     unsigned a0_, a1_, a2_, b0_, b1_, b2_, c0_, c1_, c2_, d0_, d1_, d2_;                       \
-    split_pair(v_[0], v_[1], a0_, a1_, a2_);                                                   \
-    split_pair(v_[2], v_[3], b0_, b1_, b2_);                                                   \
-    split_pair(v_[4], v_[5], c0_, c1_, c2_);                                                   \
-    split_pair(v_[6], v_[7], d0_, d1_, d2_);                                                   \
-    const u32x4_t q0_ = {a0_, b0_, c0_, d0_}, q1_ = {a1_, b1_, c1_, d1_}, q2_ = {a2_, b2_, c2_, d2_}; \
     unsigned char* d_ = (S) + u * (2 * 2 * 3 * 1024) + sdst;                                   \
+    if (np3) {                                                                                 \
+      split_pair(v_[0], v_[1], a0_, a1_, a2_);                                                 \
+      split_pair(v_[2], v_[3], b0_, b1_, b2_);                                                 \
+      split_pair(v_[4], v_[5], c0_, c1_, c2_);                                                 \
+      split_pair(v_[6], v_[7], d0_, d1_, d2_);                                                 \
+      const u32x4_t q2_ = {a2_, b2_, c2_, d2_};                                                \
+      *reinterpret_cast<u32x4_t*>(d_ + 2048) = q2_;                                            \
+    } else {                                                                                   \
+      split_pair2(v_[0], v_[1], a0_, a1_);                                                     \
+      split_pair2(v_[2], v_[3], b0_, b1_);                                                     \
+      split_pair2(v_[4], v_[5], c0_, c1_);                                                     \
+      split_pair2(v_[6], v_[7], d0_, d1_);                                                     \
+    }                                                                                          \
+    const u32x4_t q0_ = {a0_, b0_, c0_, d0_}, q1_ = {a1_, b1_, c1_, d1_};                      \
     *reinterpret_cast<u32x4_t*>(d_) = q0_;                                                     \
     *reinterpret_cast<u32x4_t*>(d_ + 1024) = q1_;                                              \
-    *reinterpret_cast<u32x4_t*>(d_ + 2048) = q2_;                                              \
   }
   TN3_LOAD(ra, TM, g.A, g.lda, m0, g.M, kbeg)
   TN3_LOAD(rb, TN, g.B, g.ldb, n0, g.N, kbeg)
@@ -280,16 +302,19 @@ __device__ __forceinline__ void tn_p3_body(const GemmArgs& g, const unsigned bid
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int p = 0; p < 3; ++p)
-          pa[i][p] = *reinterpret_cast<const bf16x8*>(sA + ((((wm >> 5) + i) * 2 + s) * 3 + p) * 1024 + lane * 16);
+          if (p < 2 || np3)
+            pa[i][p] = *reinterpret_cast<const bf16x8*>(sA + ((((wm >> 5) + i) * 2 + s) * 3 + p) * 1024 + lane * 16);
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int p = 0; p < 3; ++p)
-          pb[j][p] = *reinterpret_cast<const bf16x8*>(sB + ((((wn >> 5) + j) * 2 + s) * 3 + p) * 1024 + lane * 16);
+          if (p < 2 || np3)
+            pb[j][p] = *reinterpret_cast<const bf16x8*>(sB + ((((wn >> 5) + j) * 2 + s) * 3 + p) * 1024 + lane * 16);
 #define S2T_P3_TERM(PA, PB)                                                                     \
   _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i][PA], pb[j][PB], acc[i][j], 0, 0, 0);
-      S2T_P3_TERM(2, 0) S2T_P3_TERM(1, 1) S2T_P3_TERM(0, 2) S2T_P3_TERM(1, 0) S2T_P3_TERM(0, 1)
+      if (np3) { S2T_P3_TERM(2, 0) S2T_P3_TERM(1, 1) S2T_P3_TERM(0, 2) }
+      S2T_P3_TERM(1, 0) S2T_P3_TERM(0, 1)
       S2T_P3_TERM(0, 0)
 #undef S2T_P3_TERM
     }
@@ -366,6 +391,7 @@ __device__ __forceinline__ void tn_w_body(const GemmArgs& g, const unsigned bid,
   if (kbeg >= kend) return;
   const int nchunk = (kend - kbeg + BK - 1) / BK;
   const bool want_csum = g.colsum != nullptr && tn == 0;
+  const bool np3 = g.np != 2;            // (uniform: three pieces / six products, or two / three)
 
   // ---- producer state
   TnwUnit un[NSLOT];
@@ -447,15 +473,23 @@ __device__ __forceinline__ void tn_w_body(const GemmArgs& g, const unsigned bid,
           if (want_csum && t.isA)
             cs[j][mi] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
           unsigned a0, a1, a2, b0, b1, b2, c0, c1, c2, d0, d1, d2;
-          split_pair(v[0], v[1], a0, a1, a2);
-          split_pair(v[2], v[3], b0, b1, b2);
-          split_pair(v[4], v[5], c0, c1, c2);
-          split_pair(v[6], v[7], d0, d1, d2);
-          const u32x4_t q0 = {a0, b0, c0, d0}, q1 = {a1, b1, c1, d1}, q2 = {a2, b2, c2, d2};
           unsigned char* const d = buf + t.dst + ((((t.a + 2 * mi) & 7) + 8 * mi) << 4);
+          if (np3) {
+            split_pair(v[0], v[1], a0, a1, a2);
+            split_pair(v[2], v[3], b0, b1, b2);
+            split_pair(v[4], v[5], c0, c1, c2);
+            split_pair(v[6], v[7], d0, d1, d2);
+            const u32x4_t q2 = {a2, b2, c2, d2};
+            *reinterpret_cast<u32x4_t*>(d + 2048) = q2;
+          } else {
+            split_pair2(v[0], v[1], a0, a1);
+            split_pair2(v[2], v[3], b0, b1);
+            split_pair2(v[4], v[5], c0, c1);
+            split_pair2(v[6], v[7], d0, d1);
+          }
+          const u32x4_t q0 = {a0, b0, c0, d0}, q1 = {a1, b1, c1, d1};
           *reinterpret_cast<u32x4_t*>(d) = q0;
           *reinterpret_cast<u32x4_t*>(d + 1024) = q1;
-          *reinterpret_cast<u32x4_t*>(d + 2048) = q2;
         }
       }
   };
@@ -498,16 +532,19 @@ __device__ __forceinline__ void tn_w_body(const GemmArgs& g, const unsigned bid,
         for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int p = 0; p < 3; ++p)
-            pa[i][p] = *reinterpret_cast<const bf16x8*>(sA + ((((wm >> 5) + i) * 2 + s) * 3 + p) * 1024 + fslot);
+            if (p < 2 || np3)
+              pa[i][p] = *reinterpret_cast<const bf16x8*>(sA + ((((wm >> 5) + i) * 2 + s) * 3 + p) * 1024 + fslot);
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
           for (int p = 0; p < 3; ++p)
-            pb[j][p] = *reinterpret_cast<const bf16x8*>(sB + ((((wn >> 5) + j) * 2 + s) * 3 + p) * 1024 + fslot);
+            if (p < 2 || np3)
+              pb[j][p] = *reinterpret_cast<const bf16x8*>(sB + ((((wn >> 5) + j) * 2 + s) * 3 + p) * 1024 + fslot);
 #define S2T_W_TERM(PA, PB)                                                                       \
   _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < NJ; ++j)  \
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i][PA], pb[j][PB], acc[i][j], 0, 0, 0);
-        S2T_W_TERM(2, 0) S2T_W_TERM(1, 1) S2T_W_TERM(0, 2) S2T_W_TERM(1, 0) S2T_W_TERM(0, 1) S2T_W_TERM(0, 0)
+        if (np3) { S2T_W_TERM(2, 0) S2T_W_TERM(1, 1) S2T_W_TERM(0, 2) }
+        S2T_W_TERM(1, 0) S2T_W_TERM(0, 1) S2T_W_TERM(0, 0)
 #undef S2T_W_TERM
       }
     }
@@ -633,6 +670,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const unsigned bid)
       for (int r = 0; r < BK; ++r) csum += sA[r * TA::LD + threadIdx.x];
     }
     if (X3) {
+      const bool np3 = g.np != 2;        // (uniform)
       const int lo3 = lane & 31, hi3 = lane >> 5;
 #pragma unroll
       for (int s = 0; s < BK / 16; ++s) {
@@ -652,13 +690,20 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const unsigned bid)
             for (int e = 0; e < 8; ++e) v[e] = q[e * ldt];
           }
           uint4 q0, q1, q2;
-          split_pair(v[0], v[1], q0.x, q1.x, q2.x);
-          split_pair(v[2], v[3], q0.y, q1.y, q2.y);
-          split_pair(v[4], v[5], q0.z, q1.z, q2.z);
-          split_pair(v[6], v[7], q0.w, q1.w, q2.w);
+          if (np3) {
+            split_pair(v[0], v[1], q0.x, q1.x, q2.x);
+            split_pair(v[2], v[3], q0.y, q1.y, q2.y);
+            split_pair(v[4], v[5], q0.z, q1.z, q2.z);
+            split_pair(v[6], v[7], q0.w, q1.w, q2.w);
+            out[2] = __builtin_bit_cast(bf16x8, q2);
+          } else {
+            split_pair2(v[0], v[1], q0.x, q1.x);
+            split_pair2(v[2], v[3], q0.y, q1.y);
+            split_pair2(v[4], v[5], q0.z, q1.z);
+            split_pair2(v[6], v[7], q0.w, q1.w);
+          }
           out[0] = __builtin_bit_cast(bf16x8, q0);
           out[1] = __builtin_bit_cast(bf16x8, q1);
-          out[2] = __builtin_bit_cast(bf16x8, q2);
         };
 #pragma unroll
         for (int i = 0; i < TM; ++i) gather(sA, TA::LD, wm + 32 * i + lo3, A_KC, pa[i]);
@@ -667,7 +712,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const unsigned bid)
 #define S2T_X3_TERM(PA, PB)                                                                     \
   _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i][PA], pb[j][PB], acc[i][j], 0, 0, 0);
-        S2T_X3_TERM(2, 0) S2T_X3_TERM(1, 1) S2T_X3_TERM(0, 2) S2T_X3_TERM(1, 0) S2T_X3_TERM(0, 1)
+        if (np3) { S2T_X3_TERM(2, 0) S2T_X3_TERM(1, 1) S2T_X3_TERM(0, 2) }
+        S2T_X3_TERM(1, 0) S2T_X3_TERM(0, 1)
         S2T_X3_TERM(0, 0)
 #undef S2T_X3_TERM
       }
@@ -819,6 +865,7 @@ struct TnProb {
 struct TnGroup {
   int n;
   int debug;
+  int np;                  // pieces per operand (GemmArgs::np)
   unsigned begin[MAXG + 1];
   TnProb p[MAXG];
 };
@@ -830,6 +877,7 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(TnGroup grp) {
   const TnProb& q = grp.p[i];
   GemmArgs g{q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, nullptr, nullptr, 0, nullptr, 0,
              0, 0, 0, q.colsum, 0, q.kper, q.tiles_m, q.tiles_n, q.splits, grp.debug, q.alpha};
+  g.np = grp.np;
   gemm_body<1, TNW, MODE_TN, ACT_NONE, X3, false, P3>(g, blockIdx.x - grp.begin[i]);
 }
 
@@ -841,6 +889,7 @@ __global__ __launch_bounds__(512) void gemm_tn_grouped_w_kernel(TnGroup grp) {
   const TnProb& q = grp.p[i];
   GemmArgs g{q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, nullptr, nullptr, 0, nullptr, 0,
              0, 0, 0, q.colsum, 0, q.kper, q.tiles_m, q.tiles_n, q.splits, grp.debug, q.alpha};
+  g.np = grp.np;
   tn_w_shape<ACT_NONE>(g, q.shape, blockIdx.x - grp.begin[i], tnw_sm);
 }
 template <int PRO>
@@ -957,6 +1006,7 @@ constexpr int KR = 64;   // TN slices are multiples of the deepest chunk
 
 template <int MODE>
 int dispatch(GemmArgs& g, hipStream_t st) {
+  g.np = s2t_gemm_arith();
   int tn_sel = pick_tn(g.N);
   const int pro = MODE == MODE_NT ? g.pro_a : (MODE == MODE_TN ? g.pro_b : 0);
   long tiles_big = (long)((g.M + 127) / 128) * ((g.N + 64 * tn_sel - 1) / (64 * tn_sel));
@@ -1114,6 +1164,7 @@ extern "C" int s2t_gemm_f32_batched(int mode, const float* A, long lda, long sA,
   GemmArgs g{A, lda, B, ldb, C, ldc, M, N, K, nullptr, nullptr, 0, nullptr, 0, 0, 0,
              0, nullptr, 0, 0, 0, 0, 0, 0, 1.f, 0};
   hipStream_t st = (hipStream_t)stream;
+  g.np = s2t_gemm_arith();
   g.tiles_m = (M + 63) / 64;
   g.tiles_n = (N + 63) / 64;
   const int total = g.tiles_m * g.tiles_n;
@@ -1177,6 +1228,7 @@ extern "C" int s2t_conv3x3_gemm(int mode, const float* x, int B, int H, int W, i
   if (mode == 0) {
     GemmArgs g{x, 0, w2_or_g, K9, out, CO, (int)R, CO, K9, bias, nullptr, 0, nullptr, 0, 0, 0,
                0, nullptr, 0, 0, 0, 0, 0, 0, 1.f, 0, 0, 0, pt};
+    g.np = s2t_gemm_arith();
     g.wide_ep = !bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0;
     g.tiles_m = (g.M + 127) / 128;
     g.tiles_n = CO > 64 ? (CO + 127) / 128 : 1;
@@ -1190,6 +1242,7 @@ extern "C" int s2t_conv3x3_gemm(int mode, const float* x, int B, int H, int W, i
   }
   GemmArgs g{w2_or_g, CO, x, 0, out, K9, CO, K9, (int)R, nullptr, nullptr, 0, nullptr, 0, 0, 0,
              0, db, 0, 0, 0, 0, 0, 0, 1.f, 0, 0, 0, pt};
+  g.np = s2t_gemm_arith();
   { static const int dbg = s2t_debug_env("S2T_GEMM_DEBUG"); g.debug = dbg; }
   // the wave-specialised form (tn_w_body) for outputs of >= 128 x 1024 (the conformer's 256 -> 256 conv:
   // 24 tiles of 128 x 192).  The zipformer frontend's 32 -> 128 conv (128 x 288 output over 600 k rows:
@@ -1275,6 +1328,7 @@ extern "C" int s2t_gemm_tn_grouped(int n, const S2tTnProblem* probs, void* strea
   for (int base = 0; base < n && useq; base += MAXG) {
     TnGroup grp;
     { static const int dbg = s2t_debug_env("S2T_GEMM_DEBUG"); grp.debug = dbg; }
+    grp.np = s2t_gemm_arith();
     grp.n = std::min(MAXG, n - base);
     long total_tiles = 0;
     for (int i = 0; i < grp.n; ++i) {
@@ -1314,6 +1368,7 @@ extern "C" int s2t_gemm_tn_grouped(int n, const S2tTnProblem* probs, void* strea
   for (int base = 0; base < n; base += MAXG) {
     TnGroup grp;
     { static const int dbg = s2t_debug_env("S2T_GEMM_DEBUG"); grp.debug = dbg; }
+    grp.np = s2t_gemm_arith();
     grp.n = std::min(MAXG, n - base);
     long total_tiles = 0;
     for (int i = 0; i < grp.n; ++i) {

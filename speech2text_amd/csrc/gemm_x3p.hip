@@ -71,6 +71,30 @@ __device__ __forceinline__ void split8(const f32x4 v0, const f32x4 v1, u32x4& q0
   q2 = u32x4{a2, b2, c2, d2};
 }
 
+// the TWO-piece split of the bf16x2 arithmetic (S2T_GEMM_ARITH=2): x = p0 + p1 + O(2^-18 |x|)
+__device__ __forceinline__ void split_pair2(float x0, float x1, unsigned& p0, unsigned& p1) {
+  f32x2 x = {x0, x1};
+  p0 = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+  f32x2 h = {__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xFFFF0000u)};
+  x = x - h;
+  p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+}
+// NP pieces of 8 values (NP = 3: exact; NP = 2: the two leading pieces)
+template <int NP>
+__device__ __forceinline__ void split8n(const f32x4 v0, const f32x4 v1, u32x4 (&q)[3]) {
+  if (NP == 3) {
+    split8(v0, v1, q[0], q[1], q[2]);
+  } else {
+    unsigned a0, a1, b0, b1, c0, c1, d0, d1;
+    split_pair2(v0.x, v0.y, a0, a1);
+    split_pair2(v0.z, v0.w, b0, b1);
+    split_pair2(v1.x, v1.y, c0, c1);
+    split_pair2(v1.z, v1.w, d0, d1);
+    q[0] = u32x4{a0, b0, c0, d0};
+    q[1] = u32x4{a1, b1, c1, d1};
+  }
+}
+
 enum { ACT_NONE = 0, ACT_SWOOSH_L = 1, ACT_SWOOSH_R = 2 };
 
 #ifndef X3P_STORE_LATE
@@ -403,13 +427,17 @@ __device__ __forceinline__ void x3p_epilogue(const X3P& g, f32x16 (&acc)[TM][TN]
 // and is worth it with >= 2 tiles per workgroup (persistent grid).
 // (waves per SIMD the register allocation must leave room for: 2 / 3 / 4 workgroups per CU for the
 // 2x2 / 1x2, 2x1 / 1x1 tiles -- the epilogue's operand loads are hoisted as far as this allows)
-template <int TM, int TN, bool DIAG = false, int ABL = 0, bool DRIP = false, bool BAL = false>
+// NP: pieces per operand (3: the exact bf16x3 split, six products per term; 2: bf16x2, the three
+// leading products -- the LDS images, the weight-piece copies and the fragment reads shrink to the
+// first NP pieces of every 3-piece group of the plane image, which is the same for both)
+template <int TM, int TN, bool DIAG = false, int ABL = 0, bool DRIP = false, bool BAL = false, int NP = 3>
 __global__ __launch_bounds__(256, (DRIP || DIAG || TM * TN == 4) ? 2 : (TM * TN == 2 ? 3 : 4))
 void x3p_db_kernel(X3P g) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
-  constexpr int A_ST = 2 * TM * 3 * 1024, B_ST = 2 * TN * 3 * 1024, ST = A_ST + B_ST;
+  constexpr int A_ST = 2 * TM * NP * 1024, B_ST = 2 * TN * NP * 1024, ST = A_ST + B_ST;
   constexpr int NAU = (128 * TM + 255) / 256;       // A units (8 k of one row) per thread and stage
-  constexpr int NBU = (384 * TN + 255) / 256;       // B 16-byte pieces per thread and stage
+  constexpr int NBP = 2 * TN * NP * 64;             // B 16-byte pieces per stage
+  constexpr int NBU = (NBP + 255) / 256;            // ... per thread
   constexpr int SCR = 4 * 16 * 36 * 4;              // epilogue scratch (DRIP: its own region)
   constexpr int NSL = 2 * TM * TN;                  // epilogue slices per wave and tile
   __shared__ __attribute__((aligned(1024))) unsigned char smem[DRIP ? 2 * ST + SCR : (2 * ST > SCR ? 2 * ST : SCR)];
@@ -442,17 +470,17 @@ void x3p_db_kernel(X3P g) {
     const int r = (uu & 15) + 16 * (uu >> 5), kq = (uu >> 4) & 1;
     a_r[i] = r;
     a_k[i] = 8 * kq;
-    a_dst[i] = (unsigned)((((r >> 5) * 3) * 64 + kq * 32 + (r & 31)) * 16);
+    a_dst[i] = (unsigned)((((r >> 5) * NP) * 64 + kq * 32 + (r & 31)) * 16);
   }
   int b_seg[NBU], b_off[NBU];
   bool b_on[NBU];
 #pragma unroll
   for (int i = 0; i < NBU; ++i) {
     const int idx = tid + 256 * i;
-    b_on[i] = idx < 384 * TN;
+    b_on[i] = idx < NBP;
     const int ii = b_on[i] ? idx : 0;
-    b_seg[i] = ii / 192;
-    b_off[i] = ii - b_seg[i] * 192;
+    b_seg[i] = ii / (64 * NP);                      // 32-column block; the first NP KB of its 3 KB chunk
+    b_off[i] = ii - b_seg[i] * (64 * NP);
   }
   const float* asrc[NAU];
   const u32x4* bsrc[NBU];
@@ -479,7 +507,7 @@ void x3p_db_kernel(X3P g) {
   constexpr int NS = DRIP ? 1 : 2;
   f32x4 ra[NS][NAU][2];
   u32x4 rb[NS][NBU];
-  u32x4 qa[NAU][3];
+  u32x4 qa[NAU][3];                                 // (NP of them used)
   // global -> registers, unconditional (past the end the last stage again; a k tail is read from
   // the row's start and zeroed when it is split): nothing here waits for the data
 #define X3P_LOAD(SET, S)                                                                     \
@@ -502,7 +530,7 @@ void x3p_db_kernel(X3P g) {
     _Pragma("unroll") for (int i = 0; i < NAU; ++i) {                                        \
       const bool v_ = 16 * ss_ + a_k[i] < g.K;                                               \
       const f32x4 z_ = {0.f, 0.f, 0.f, 0.f};                                                 \
-      split8(v_ ? ra[SET][i][0] : z_, v_ ? ra[SET][i][1] : z_, qa[i][0], qa[i][1], qa[i][2]); \
+      split8n<NP>(v_ ? ra[SET][i][0] : z_, v_ ? ra[SET][i][1] : z_, qa[i]);                  \
     }                                                                                        \
   }
 #define X3P_STORE(SET, BUF)                                                                  \
@@ -511,12 +539,11 @@ void x3p_db_kernel(X3P g) {
     unsigned char* const sb_ = sa_ + A_ST;                                                   \
     _Pragma("unroll") for (int i = 0; i < NAU; ++i)                                          \
       if (NAU * 256 == 128 * TM || a_on[i]) {                                                \
-        *reinterpret_cast<u32x4*>(sa_ + a_dst[i]) = qa[i][0];                                \
-        *reinterpret_cast<u32x4*>(sa_ + a_dst[i] + 1024) = qa[i][1];                         \
-        *reinterpret_cast<u32x4*>(sa_ + a_dst[i] + 2048) = qa[i][2];                         \
+        _Pragma("unroll") for (int p = 0; p < NP; ++p)                                       \
+          *reinterpret_cast<u32x4*>(sa_ + a_dst[i] + 1024 * p) = qa[i][p];                   \
       }                                                                                      \
     _Pragma("unroll") for (int i = 0; i < NBU; ++i)                                          \
-      if (NBU * 256 == 384 * TN || b_on[i])                                                  \
+      if (NBU * 256 == NBP || b_on[i])                                                       \
         *reinterpret_cast<u32x4*>(sb_ + (tid + 256 * i) * 16) = rb[SET][i];                  \
   }
 #define X3P_TERM(PA, PB)                                                                        \
@@ -543,11 +570,11 @@ void x3p_db_kernel(X3P g) {
     if (NS == 2 && !(ABL & 1)) X3P_LOAD(NXT, (KB) + 2)                                       \
     const unsigned char* const sa = smem + ((KB) & 1) * ST;                                  \
     const unsigned char* const sb = sa + A_ST;                                               \
-    bf16x8 fa[TM][3], fb[TN][3];                                                             \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int p = 0; p < 3; ++p) \
-      fa[i][p] = *reinterpret_cast<const bf16x8*>(sa + (((wrb + i) * 3 + p) * 64 + lane) * 16); \
-    _Pragma("unroll") for (int j = 0; j < TN; ++j) _Pragma("unroll") for (int p = 0; p < 3; ++p) \
-      fb[j][p] = *reinterpret_cast<const bf16x8*>(sb + (((wcb + j) * 3 + p) * 64 + lane) * 16); \
+    bf16x8 fa[TM][NP], fb[TN][NP];                                                           \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int p = 0; p < NP; ++p) \
+      fa[i][p] = *reinterpret_cast<const bf16x8*>(sa + (((wrb + i) * NP + p) * 64 + lane) * 16); \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) _Pragma("unroll") for (int p = 0; p < NP; ++p) \
+      fb[j][p] = *reinterpret_cast<const bf16x8*>(sb + (((wcb + j) * NP + p) * 64 + lane) * 16); \
     if (DIAG) {                                                                              \
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     \
       t2_ = __builtin_amdgcn_s_memtime();                                                    \
@@ -556,12 +583,12 @@ void x3p_db_kernel(X3P g) {
     /* (1) the two smallest product groups with the split of stage KB+1's A registers in the  \
        MFMAs' shadow (an MFMA holds the SIMD's issue for 8 of its 32 cycles) */              \
     if (!(ABL & 4)) X3P_SPLIT(CUR, (KB) + 1)                                                 \
-    if (!(ABL & 8)) { X3P_TERM(2, 0) X3P_TERM(1, 1) }                                        \
+    if (!(ABL & 8)) { if (NP == 3) { X3P_TERM(NP - 1, 0) X3P_TERM(1, 1) } else { X3P_TERM(1, 0) } } \
     if (DIAG) t3_ = __builtin_amdgcn_s_memtime();                                            \
     __builtin_amdgcn_sched_barrier(0);                                                       \
     if (X3P_STORE_LATE) {                                                                    \
       /* all 24 products queued before this wave waits for stage KB+1's global loads */      \
-      if (!(ABL & 8)) { X3P_TERM(0, 2) X3P_TERM(1, 0) X3P_TERM(0, 1) X3P_TERM(0, 0) }        \
+      if (!(ABL & 8)) { if (NP == 3) { X3P_TERM(0, NP - 1) X3P_TERM(1, 0) } X3P_TERM(0, 1) X3P_TERM(0, 0) } \
       if (DIAG) t4_ = __builtin_amdgcn_s_memtime();                                          \
       __builtin_amdgcn_sched_barrier(0);                                                     \
       if (!(ABL & 2)) X3P_STORE(CUR, ((KB) + 1) & 1)                                         \
@@ -570,11 +597,11 @@ void x3p_db_kernel(X3P g) {
       /* (2) stage KB+1 into the other LDS buffer, stage KB+2 requested */                   \
       if (!(ABL & 2)) X3P_STORE(CUR, ((KB) + 1) & 1)                                         \
       if (NS == 1 && !(ABL & 1)) X3P_LOAD(NXT, (KB) + 2)                                     \
-      if (!(ABL & 8)) { X3P_TERM(0, 2) }                                                     \
+      if (!(ABL & 8)) { if (NP == 3) { X3P_TERM(0, NP - 1) } else { X3P_TERM(0, 1) } }       \
       if (DIAG) t4_ = __builtin_amdgcn_s_memtime();                                          \
       __builtin_amdgcn_sched_barrier(0);                                                     \
       /* (3) the rest of the products */                                                     \
-      if (!(ABL & 8)) { X3P_TERM(1, 0) X3P_TERM(0, 1) X3P_TERM(0, 0) }                       \
+      if (!(ABL & 8)) { if (NP == 3) { X3P_TERM(1, 0) X3P_TERM(0, 1) } X3P_TERM(0, 0) }      \
     }                                                                                        \
     if (DIAG) {                                                                              \
       t5_ = __builtin_amdgcn_s_memtime();                                                    \
@@ -716,14 +743,21 @@ __device__ __forceinline__ unsigned x3p_lds_addr(const void* p) {
   return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
 }
 
-template <int TM, int TN, int WPC, bool MAP = false>
+// NP: pieces per operand (3 | 2, as x3p_db_kernel).  KS: 16-deep sub-stages per barrier interval
+// (1 | 2): with two pieces a 16-deep stage holds only 12 MFMAs per wave (2 x 2 tile) between two
+// barriers; KS = 2 stages 32 k at a time -- the same 24 MFMAs per barrier as the three-piece form,
+// half the barriers, waits and address arithmetic per product.
+template <int TM, int TN, int WPC, bool MAP = false, int NP = 3, int KS = 1, bool BAL = false>
 __global__ __launch_bounds__(256, WPC) void x3p_dma_kernel(X3P g) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
-  constexpr int A_ST = 2 * TM * 3 * 1024, B_ST = 2 * TN * 3 * 1024, ST = A_ST + B_ST;
-  constexpr int NAU = (128 * TM + 255) / 256;       // A units (8 k of one row) per thread and stage
-  constexpr int NBW = (6 * TN + 3) / 4;             // B DMA wave-instructions (1 KB each) per wave and stage
+  constexpr int A_SUB = 2 * TM * NP * 1024, B_SUB = 2 * TN * NP * 1024;   // one 16-deep sub-stage
+  constexpr int A_ST = KS * A_SUB, B_ST = KS * B_SUB, ST = A_ST + B_ST;
+  constexpr int NAU = (128 * TM * KS + 255) / 256;  // A units (8 k of one row) per thread and stage
+  constexpr int NRUN = 2 * TN * KS * NP;            // B: 1 KB runs (one wave-instruction each) per stage
+  constexpr int NBW = (NRUN + 3) / 4;               // ... per wave
   constexpr int SCR = 4 * 16 * 36 * 4;
-  static_assert(128 * TM % 256 == 0 || TM == 1, "A units");
+  static_assert(128 * TM * KS % 256 == 0 || (TM == 1 && KS == 1), "A units");
+  static_assert(!MAP || KS == 1, "implicit operands: 16-deep stages");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * ST > SCR ? 2 * ST : SCR];
   const unsigned lds0 = x3p_lds_addr(smem);
 
@@ -736,31 +770,36 @@ __global__ __launch_bounds__(256, WPC) void x3p_dma_kernel(X3P g) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wrb = (wave >> 1) * TM, wcb = (wave & 1) * TN;
 
+  // A unit u = (sub-stage, row r, k half kq): 16 consecutive lanes store 16 consecutive fragment slots
   int a_r[NAU], a_k[NAU];
   unsigned a_dst[NAU];
   bool a_on[NAU];
 #pragma unroll
   for (int i = 0; i < NAU; ++i) {
     const int u = tid + 256 * i;
-    a_on[i] = u < 128 * TM;
+    a_on[i] = u < 128 * TM * KS;
     const int uu = a_on[i] ? u : 0;
-    const int r = (uu & 15) + 16 * (uu >> 5), kq = (uu >> 4) & 1;
+    const int sub = uu / (128 * TM), v = uu - sub * (128 * TM);
+    const int r = (v & 15) + 16 * (v >> 5), kq = (v >> 4) & 1;
     a_r[i] = r;
-    a_k[i] = 8 * kq;
-    a_dst[i] = (unsigned)((((r >> 5) * 3) * 64 + kq * 32 + (r & 31)) * 16);
+    a_k[i] = 16 * sub + 8 * kq;
+    a_dst[i] = (unsigned)(sub * A_SUB + (((r >> 5) * NP) * 64 + kq * 32 + (r & 31)) * 16);
   }
-  // B: wave-instruction q of this wave moves the 1 KB run pw = wave + 4 q = (32-column block) * 3 +
-  // piece of the stage's 6 TN KB (a wave past the end repeats the last run: same bytes to the same
-  // place, no branch); a block's 16-deep chunk is 3 KB = 1536 bf16 of the plane image
-  const int nst = (g.K + 15) >> 4;
+  // B: wave-instruction q of this wave moves the 1 KB run pw = wave + 4 q = ((32-column block) KS +
+  // sub-stage) NP + piece of the stage (a wave past the end repeats the last run: same bytes to the
+  // same place, no branch); a block's 16-deep chunk is 3 KB = 1536 bf16 of the plane image, of which
+  // the first NP KB are read
+  const int nst = (g.K + 15) >> 4;                  // 16-deep stages (the pieces are zero beyond K)
+  const int nss = (nst + KS - 1) / KS;              // barrier intervals
   const int lane8 = lane * 8;                       // (bf16 elements: 16 bytes per lane)
   const float* asrc[NAU];
   const unsigned short* bsrc[NBW];
   unsigned b_dst[NBW];
 #pragma unroll
   for (int q = 0; q < NBW; ++q) {
-    const int pw = min(wave + 4 * q, 6 * TN - 1);
-    b_dst[q] = (unsigned)(A_ST + pw * 1024);
+    const int pw = min(wave + 4 * q, NRUN - 1);
+    const int blk = pw / (KS * NP), rem = pw - blk * (KS * NP), sub = rem / NP, pc = rem - sub * NP;
+    b_dst[q] = (unsigned)(A_ST + sub * B_SUB + (blk * NP + pc) * 1024);
   }
   int m0, n0;
 #define XD_TILE(LOC)                                                                         \
@@ -771,57 +810,63 @@ __global__ __launch_bounds__(256, WPC) void x3p_dma_kernel(X3P g) {
     n0 = tn_ * BN;                                                                           \
     _Pragma("unroll") for (int i = 0; i < NAU; ++i)                                          \
       asrc[i] = g.A + (MAP ? x3p_maprow(g.amap, min(m0 + a_r[i], g.M - 1))                   \
-                           : (long)min(m0 + a_r[i], g.M - 1) * g.lda) + a_k[i];              \
+                           : (long)min(m0 + a_r[i], g.M - 1) * g.lda);                       \
     _Pragma("unroll") for (int q = 0; q < NBW; ++q) {                                        \
-      const int pw_ = min(wave + 4 * q, 6 * TN - 1);                                         \
-      const int nt_ = min((n0 >> 5) + pw_ / 3, g.NT - 1);     /* 32-column block, piece */   \
-      bsrc[q] = g.Bp + (long)nt_ * g.KB * 1536 + (pw_ % 3) * 512;                            \
+      const int pw_ = min(wave + 4 * q, NRUN - 1);                                           \
+      const int blk_ = pw_ / (KS * NP), rem_ = pw_ - blk_ * (KS * NP);                       \
+      const int sub_ = rem_ / NP, pc_ = rem_ - sub_ * NP;                                    \
+      const int nt_ = min((n0 >> 5) + blk_, g.NT - 1);        /* 32-column block */          \
+      bsrc[q] = g.Bp + (long)nt_ * g.KB * 1536 + sub_ * 1536 + pc_ * 512;                    \
     }                                                                                        \
   }
   f32x4 ra[NAU][2];
   u32x4 qa[NAU][3];
 #define XD_LOAD_A(S)                                                                         \
   {                                                                                          \
-    const int ss_ = min((S), nst - 1);                                                       \
-    long ko_ = 16L * ss_;                                                                    \
+    const int ss_ = min((S), nss - 1);                                                       \
+    long ko_ = 16L * KS * ss_;                                                               \
     if (MAP) {                         /* stage -> (segment, offset inside it): uniform */    \
       const int sg_ = ss_ / g.seg16;                                                         \
       ko_ = g.segoff[sg_] + 16L * (ss_ - sg_ * g.seg16);                                     \
     }                                                                                        \
     _Pragma("unroll") for (int i = 0; i < NAU; ++i) {                                        \
-      gf32p p_ = (gf32p)(asrc[i] + ((16 * ss_ + a_k[i] < g.K) ? ko_ : 0L));                 \
+      /* (a k tail is read from the row's start and zeroed when it is split) */              \
+      gf32p p_ = (gf32p)(asrc[i] + ((16 * KS * ss_ + a_k[i] < g.K) ? ko_ + a_k[i] : 0L));    \
       ra[i][0] = *reinterpret_cast<gf32x4p>(p_);                                             \
       ra[i][1] = *reinterpret_cast<gf32x4p>(p_ + 4);                                         \
     }                                                                                        \
   }
 #define XD_DMA_B(S, BUF)                                                                     \
   {                                                                                          \
-    const int ss_ = min((S), nst - 1);                                                       \
+    const int ss_ = min((S), nss - 1);                                                       \
     _Pragma("unroll") for (int q = 0; q < NBW; ++q)                                          \
-      x3p_glds16(bsrc[q] + (long)ss_ * 1536 + lane8, lds0 + (BUF) * ST + b_dst[q]);          \
+      x3p_glds16(bsrc[q] + (long)ss_ * (KS * 1536) + lane8, lds0 + (BUF) * ST + b_dst[q]);   \
   }
 #define XD_SPLIT(S)                                                                          \
   {                                                                                          \
-    const int ss_ = min((S), nst - 1);                                                       \
+    const int ss_ = min((S), nss - 1);                                                       \
     _Pragma("unroll") for (int i = 0; i < NAU; ++i) {                                        \
-      const bool v_ = 16 * ss_ + a_k[i] < g.K;                                               \
+      const bool v_ = 16 * KS * ss_ + a_k[i] < g.K;                                          \
       const f32x4 z_ = {0.f, 0.f, 0.f, 0.f};                                                 \
-      split8(v_ ? ra[i][0] : z_, v_ ? ra[i][1] : z_, qa[i][0], qa[i][1], qa[i][2]);          \
+      split8n<NP>(v_ ? ra[i][0] : z_, v_ ? ra[i][1] : z_, qa[i]);                            \
     }                                                                                        \
   }
 #define XD_STORE_A(BUF)                                                                      \
   {                                                                                          \
     unsigned char* const sa_ = smem + (BUF) * ST;                                            \
     _Pragma("unroll") for (int i = 0; i < NAU; ++i)                                          \
-      if (NAU * 256 == 128 * TM || a_on[i]) {                                                \
-        *reinterpret_cast<u32x4*>(sa_ + a_dst[i]) = qa[i][0];                                \
-        *reinterpret_cast<u32x4*>(sa_ + a_dst[i] + 1024) = qa[i][1];                         \
-        *reinterpret_cast<u32x4*>(sa_ + a_dst[i] + 2048) = qa[i][2];                         \
+      if (NAU * 256 == 128 * TM * KS || a_on[i]) {                                           \
+        _Pragma("unroll") for (int p = 0; p < NP; ++p)                                       \
+          *reinterpret_cast<u32x4*>(sa_ + a_dst[i] + 1024 * p) = qa[i][p];                   \
       }                                                                                      \
   }
-#define XD_TERM(PA, PB)                                                                         \
+#define XD_TERM(SUB, PA, PB)                                                                    \
   _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA], fb[j][PB], acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SUB][i][PA], fb[SUB][j][PB], acc[i][j], 0, 0, 0);
+  // the products of sub-stage SUB that follow its first group (smallest pieces first)
+#define XD_REST(SUB)                                                                         \
+  if (NP == 3) { XD_TERM(SUB, 0, NP - 1) XD_TERM(SUB, 1, 0) XD_TERM(SUB, 0, 1) XD_TERM(SUB, 0, 0) } \
+  else { XD_TERM(SUB, 0, 1) XD_TERM(SUB, 0, 0) }
 
   for (;;) {
     XD_TILE(loc)
@@ -838,41 +883,47 @@ __global__ __launch_bounds__(256, WPC) void x3p_dma_kernel(X3P g) {
     XD_SPLIT(0)
     XD_STORE_A(0)
     XD_LOAD_A(1)
-    for (int kb = 0; kb < nst; ++kb) {
+    for (int kb = 0; kb < nss; ++kb) {
       // B(kb) landed (its DMAs are older than the 2 NAU loads of A(kb+1), which stay in flight);
       // stage kb's A pieces were stored before this barrier by every wave
       asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * NAU) : "memory");
       __syncthreads();
       const unsigned char* const sa = smem + (kb & 1) * ST;
       const unsigned char* const sb = sa + A_ST;
-      bf16x8 fa[TM][3], fb[TN][3];
+      bf16x8 fa[KS][TM][NP], fb[KS][TN][NP];
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int u = 0; u < KS; ++u) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
-          fa[i][p] = *reinterpret_cast<const bf16x8*>(sa + (((wrb + i) * 3 + p) * 64 + lane) * 16);
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+          for (int p = 0; p < NP; ++p)
+            fa[u][i][p] = *reinterpret_cast<const bf16x8*>(sa + u * A_SUB + (((wrb + i) * NP + p) * 64 + lane) * 16);
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
-          fb[j][p] = *reinterpret_cast<const bf16x8*>(sb + (((wcb + j) * 3 + p) * 64 + lane) * 16);
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int p = 0; p < NP; ++p)
+            fb[u][j][p] = *reinterpret_cast<const bf16x8*>(sb + u * B_SUB + (((wcb + j) * NP + p) * 64 + lane) * 16);
+      }
       __builtin_amdgcn_sched_barrier(0);
       XD_SPLIT(kb + 1)                 // (the compiler's wait for A(kb+1): nothing else is in flight)
       __builtin_amdgcn_sched_barrier(0);
       XD_DMA_B(kb + 1, (kb + 1) & 1)   // every wave is past this iteration's barrier: the buffer's readers are done
       XD_LOAD_A(kb + 2)                // (the registers are free again: their values sit in qa)
-      XD_TERM(2, 0) XD_TERM(1, 1)
+      if (NP == 3) { XD_TERM(0, NP - 1, 0) XD_TERM(0, 1, 1) } else { XD_TERM(0, 1, 0) }
       __builtin_amdgcn_sched_barrier(0);
       XD_STORE_A((kb + 1) & 1)
-      XD_TERM(0, 2)
-      __builtin_amdgcn_sched_barrier(0);
-      XD_TERM(1, 0) XD_TERM(0, 1) XD_TERM(0, 0)
+      XD_REST(0)
+      if (KS == 2) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (NP == 3) { XD_TERM(KS - 1, NP - 1, 0) XD_TERM(KS - 1, 1, 1) } else { XD_TERM(KS - 1, 1, 0) }
+        XD_REST(KS - 1)
+      }
     }
     // the trailing (dummy) DMA and loads must have landed before the stage buffers become the
     // epilogue's scratch / the next tile's stages
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (MAP && g.cmap.on) x3p_epilogue<TM, TN, true, false, true>(g, acc, smem, m0, n0, wrb, wcb, wave, lane, true);
-    else x3p_epilogue<TM, TN, true>(g, acc, smem, m0, n0, wrb, wcb, wave, lane, true);
+    else x3p_epilogue<TM, TN, true, BAL>(g, acc, smem, m0, n0, wrb, wcb, wave, lane, true);
     loc += stride;
     if (!(loc < per_xcd && xcd * per_xcd + loc < total)) break;
     __syncthreads();
@@ -883,6 +934,7 @@ __global__ __launch_bounds__(256, WPC) void x3p_dma_kernel(X3P g) {
 #undef XD_SPLIT
 #undef XD_STORE_A
 #undef XD_TERM
+#undef XD_REST
 }
 
 // ---- the weights' pieces, all matrices of a model in one launch.  Descriptor d covers blocks
@@ -938,25 +990,28 @@ __global__ __launch_bounds__(256) void x3p_split_kernel(const float* __restrict_
   } while (0)
 
 // LDS-DMA form: WPC workgroups per CU (the register allocation is bounded accordingly)
-template <int TM, int TN, int WPC>
+template <int TM, int TN, int WPC, int NP = 3, int KS = 1>
 void launch_x3p_dma(X3P& g, hipStream_t st) {
   g.tiles_m = (g.M + 64 * TM - 1) / (64 * TM);
   g.tiles_n = (g.N + 64 * TN - 1) / (64 * TN);
   const int total = g.tiles_m * g.tiles_n;
   const int grid = std::min(((total + 7) / 8) * 8, 256 * WPC);
-  X3P_LAUNCH((x3p_dma_kernel<TM, TN, WPC>), grid, 256, 0);
+  if (NP == 2 && g.bal_stats)
+    X3P_LAUNCH((x3p_dma_kernel<TM, TN, WPC, false, NP, KS, (NP == 2)>), grid, 256, 0);
+  else
+    X3P_LAUNCH((x3p_dma_kernel<TM, TN, WPC, false, NP, KS>), grid, 256, 0);
 }
 
-template <int TM, int TN, int WPC>
+template <int TM, int TN, int WPC, int NP = 3>
 void launch_x3p_map(X3P& g, hipStream_t st) {
   g.tiles_m = (g.M + 64 * TM - 1) / (64 * TM);
   g.tiles_n = (g.N + 64 * TN - 1) / (64 * TN);
   const int total = g.tiles_m * g.tiles_n;
   const int grid = std::min(((total + 7) / 8) * 8, 256 * WPC);
-  X3P_LAUNCH((x3p_dma_kernel<TM, TN, WPC, true>), grid, 256, 0);
+  X3P_LAUNCH((x3p_dma_kernel<TM, TN, WPC, true, NP>), grid, 256, 0);
 }
 
-template <int TM, int TN>
+template <int TM, int TN, int NP = 3>
 void launch_x3p(X3P& g, hipStream_t st) {
   g.tiles_m = (g.M + 64 * TM - 1) / (64 * TM);
   g.tiles_n = (g.N + 64 * TN - 1) / (64 * TN);
@@ -968,13 +1023,13 @@ void launch_x3p(X3P& g, hipStream_t st) {
     const int per_cu = wgs > 0 ? wgs : g.wgs_per_cu > 0 ? g.wgs_per_cu : (TM * TN >= 4 ? 2 : TM * TN >= 2 ? 3 : 4);
     const int cap = 256 * per_cu;
     const int grid = std::min(((total + 7) / 8) * 8, cap);
-    const bool drip = g.drip == 1 && ((g.K + 15) >> 4) >= 2 * TM * TN && grid < total;
+    const bool drip = NP == 3 && g.drip == 1 && ((g.K + 15) >> 4) >= 2 * TM * TN && grid < total;
     if (g.bal_stats)
-      X3P_LAUNCH((x3p_db_kernel<TM, TN, false, 0, false, true>), grid, 256, 0);
+      X3P_LAUNCH((x3p_db_kernel<TM, TN, false, 0, false, true, NP>), grid, 256, 0);
     else if (drip)
-      X3P_LAUNCH((x3p_db_kernel<TM, TN, false, 0, true>), grid, 256, 0);
+      X3P_LAUNCH((x3p_db_kernel<TM, TN, false, 0, (NP == 3)>), grid, 256, 0);
     else
-      X3P_LAUNCH((x3p_db_kernel<TM, TN>), grid, 256, 0);
+      X3P_LAUNCH((x3p_db_kernel<TM, TN, false, 0, false, false, NP>), grid, 256, 0);
   }
 }
 
@@ -995,8 +1050,30 @@ int pick_tile(int M, int N) {
 }  // namespace
 
 static unsigned long long* g_stamps = nullptr;
+static int g_arith_forced = 0;
 
 extern "C" {
+
+// ---- the arithmetic of the bf16 GEMMs (this file, the weight-gradient and NT / NN kernels of
+// gemm.hip): 3 = every fp32 operand as the EXACT sum of three bf16 pieces, six piece products per
+// term (fp32-level error, <= 2e-6 of max); 2 = two pieces per operand, the three leading products
+// a_hi b_hi + a_hi b_lo + a_lo b_hi (error ~ 2^-17 per term: torch's float32 matmul precision
+// "high"; the reference trains with the looser "medium", build_task.py:79).  Read PER CALL:
+// S2T_GEMM_ARITH=3 | 2 (also "bf16x3" / "bf16x2"), unless s2t_gemm_arith_set pinned it (0 = follow
+// the environment again).
+int s2t_gemm_arith(void) {
+  if (g_arith_forced) return g_arith_forced;
+  const char* e = getenv("S2T_GEMM_ARITH");
+  if (!e || !*e) return S2T_GEMM_ARITH_DEFAULT;
+  const char* x = strchr(e, 'x');        // "2", "3", "bf16x2", "bf16x3", "bf16x2/3", "bf16x3/6"
+  const char c = x ? x[1] : e[0];
+  return c == '2' ? 2 : c == '3' ? 3 : S2T_GEMM_ARITH_DEFAULT;
+}
+int s2t_gemm_arith_set(int arith) {
+  if (arith != 0 && arith != 2 && arith != 3) return -1;
+  g_arith_forced = arith;
+  return 0;
+}
 
 // diagnostics: buf (DEVICE, >= 8 * grid u64) or NULL -- later s2t_gemm_x3p launches record
 // per-workgroup s_memtime stamps {start, first stage staged, main loop done, epilogue issued,
@@ -1041,7 +1118,7 @@ struct Sampler {
   int every = 0;
   long count = 0, launches = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pool, used;
-  double bytes = 0.0, flops = 0.0;
+  double bytes = 0.0, flops = 0.0, bytes_min = 0.0;
 } g_samp;
 }  // namespace
 static long g_x3p_calls = 0;
@@ -1056,14 +1133,18 @@ int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int 
     return -1;
   // tile = 1000 drip + 100 wgs + (10 tm + tn): drip = epilogue slices under the next tile, wgs =
   // persistent workgroups per CU (0 = default)
-  // (2000 + tm tn: the LDS-DMA form at its own occupancy: 3 / 4 / 4 / 5 workgroups per CU)
+  // (2000 + 100 ks + tm tn: the LDS-DMA form at its own occupancy; ks = 2: 32-deep barrier intervals,
+  //  two-piece arithmetic only)
+  const int arith = s2t_gemm_arith();
   int dma = tile / 1000 == 2;
   const int drip = dma ? 0 : tile / 1000;
   const int wgs = (tile / 100) % 10;
   tile %= 100;
   if ((tile != 0 && tile != 11 && tile != 12 && tile != 21 && tile != 22 && tile != 33) || wgs < 0 || wgs > 8 ||
-      drip < 0 || drip > 1 || (dma && (tile == 0 || tile == 33)))
+      drip < 0 || drip > 1 || (dma && (tile == 0 || tile == 33 || wgs > 2)))
     return -1;
+  if (dma && wgs == 2 && arith != 2) return -2;      // (the plan's candidate list follows the arithmetic)
+  if (drip && arith != 3) return -2;
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   if ((K & 7) || (N & 3) || (lda & 3) || (ldc & 3) || !al16(A) || !al16(Bp) || !al16(C) ||
       (bias && !al16(bias)) || (resid && (!al16(resid) || (ldr & 3))) ||
@@ -1122,13 +1203,34 @@ int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int 
       s2t_prof_start = pr.first;
       s2t_prof_stop = pr.second;
       const int extra = (resid != nullptr) + (act_src != nullptr) + (C2 != nullptr) + (resid_b != nullptr);
-      g_samp.bytes += 4.0 * M * ((double)N + K + (double)extra * N) + 6.0 * (double)N * K;
+      g_samp.bytes += 4.0 * M * ((double)N + K + (double)extra * N) + 2.0 * arith * (double)N * K;
+      g_samp.bytes_min += 4.0 * M * ((double)N + K) + 2.0 * arith * (double)N * K;
       g_samp.flops += 2.0 * (double)M * N * K;
       ++g_samp.launches;
     }
   }
   if (tile == 33) return -2;                        // (the producer / consumer form: removed in round 5)
-  if (dma && g.bal_stats) dma = 0;       // (the Balancer epilogue lives in the register-staged form)
+  if (dma && g.bal_stats && arith != 2) dma = 0;    // (three pieces: the Balancer epilogue lives in the register-staged form)
+  if (dma && arith == 2 && wgs == 2) {              // 32-deep intervals: 64 / 48 / 48 / 32 KB of LDS
+    switch (tile) {
+      case 22: launch_x3p_dma<2, 2, 2, 2, 2>(g, st); break;
+      case 21: launch_x3p_dma<2, 1, 3, 2, 2>(g, st); break;
+      case 12: launch_x3p_dma<1, 2, 3, 2, 2>(g, st); break;
+      default: launch_x3p_dma<1, 1, 4, 2, 2>(g, st); break;
+    }
+    S2T_CHECK_LAUNCH();
+    return 0;
+  }
+  if (dma && arith == 2) {
+    switch (tile) {
+      case 22: launch_x3p_dma<2, 2, 3, 2>(g, st); break;
+      case 21: launch_x3p_dma<2, 1, 4, 2>(g, st); break;
+      case 12: launch_x3p_dma<1, 2, 4, 2>(g, st); break;
+      default: launch_x3p_dma<1, 1, 5, 2>(g, st); break;
+    }
+    S2T_CHECK_LAUNCH();
+    return 0;
+  }
   if (dma) {
     switch (tile) {
       case 22: launch_x3p_dma<2, 2, 3>(g, st); break;
@@ -1140,6 +1242,16 @@ int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int 
     return 0;
   }
   if (tile == 0) tile = pick_tile(M, N);
+  if (arith == 2) {
+    switch (tile) {
+      case 22: launch_x3p<2, 2, 2>(g, st); break;
+      case 21: launch_x3p<2, 1, 2>(g, st); break;
+      case 12: launch_x3p<1, 2, 2>(g, st); break;
+      default: launch_x3p<1, 1, 2>(g, st); break;
+    }
+    S2T_CHECK_LAUNCH();
+    return 0;
+  }
   switch (tile) {
     case 22: launch_x3p<2, 2>(g, st); break;
     case 21: launch_x3p<2, 1>(g, st); break;
@@ -1159,7 +1271,14 @@ int s2t_x3p_sample_begin(int every) {
   g_samp.used.clear();
   g_samp.every = every > 0 ? every : 0;
   g_samp.count = g_samp.launches = 0;
-  g_samp.bytes = g_samp.flops = 0.0;
+  g_samp.bytes = g_samp.flops = g_samp.bytes_min = 0.0;
+  return 0;
+}
+// bytes the sampled products must move at the least (A, C and the weight pieces read: no epilogue
+// operands, no second output) -- of the sample s2t_x3p_sample_end closed last
+int s2t_x3p_sample_min_bytes(double* bytes_min) {
+  if (!bytes_min) return -1;
+  *bytes_min = g_samp.bytes_min;
   return 0;
 }
 int s2t_x3p_sample_end(long* launches, double* total_ms, double* bytes, double* flops) {
@@ -1212,6 +1331,16 @@ int s2t_gemm_x3p_map(const float* A, const S2tRowMap* amap, int seg, int nseg, c
   for (int i = 0; i < nseg; ++i) g.segoff[i] = segoff[i];
   hipStream_t st = (hipStream_t)stream;
   ++g_x3p_calls;
+  if (s2t_gemm_arith() == 2) {
+    switch (tile) {
+      case 21: launch_x3p_map<2, 1, 4, 2>(g, st); break;
+      case 12: launch_x3p_map<1, 2, 4, 2>(g, st); break;
+      case 11: launch_x3p_map<1, 1, 5, 2>(g, st); break;
+      default: launch_x3p_map<2, 2, 3, 2>(g, st); break;
+    }
+    S2T_CHECK_LAUNCH();
+    return 0;
+  }
   switch (tile) {
     case 21: launch_x3p_map<2, 1, 4>(g, st); break;
     case 12: launch_x3p_map<1, 2, 4>(g, st); break;

@@ -73,10 +73,13 @@ hipEvent_t ring_event() {
 // ---- plan table: {mode, half-octave of rows, N, K} -> (library ms, own ms | < 0, tile)
 struct Base { double t_lib, t_own; int tile; };
 std::unordered_map<uint64_t, Base> g_plans;
+// (mode: bit 0 = forward / data gradient, bits 4-5 = the arithmetic the bucket was timed under,
+//  s2t_gemm_arith(): the candidates and their times differ between three and two pieces)
 uint64_t plan_key(int mode, int ho, int N, int K) {
-  return ((uint64_t)(mode & 1) << 63) | ((uint64_t)(ho & 0xFF) << 48) | ((uint64_t)(N & 0xFFFFFF) << 24) |
-         (uint64_t)(K & 0xFFFFFF);
+  return ((uint64_t)(mode & 1) << 63) | ((uint64_t)((mode >> 4) & 3) << 56) | ((uint64_t)(ho & 0xFF) << 48) |
+         ((uint64_t)(N & 0xFFFFFF) << 24) | (uint64_t)(K & 0xFFFFFF);
 }
+int plan_mode(int mode) { return (mode & 1) | (s2t_gemm_arith() << 4); }
 int half_octave(long m) {            // floor(2 log2 m), as zip_kernels._half_octave
   if (m < 1) m = 1;
   int b = 63 - __builtin_clzll((unsigned long long)m);
@@ -190,7 +193,7 @@ int plan_missing(const Ctx& c, int mode, long R, const S2tZlLin& L) {
   if (!c.c.x3p_on || R == 0) return 0;
   const unsigned short* pp = mode == 0 ? L.pf : L.pb;
   if (!pp) return 0;
-  return g_plans.find(plan_key(mode, half_octave(R), L.N, L.K)) == g_plans.end();
+  return g_plans.find(plan_key(plan_mode(mode), half_octave(R), L.N, L.K)) == g_plans.end();
 }
 
 int balancer_bwd(Ctx& c, const S2tZlBal& b, const float* x, long ldx, const float* g, long ldg, long R,
@@ -205,7 +208,7 @@ int lt_matmul(Ctx& c, int mode, const float* x, long ldx, long R, const S2tZlLin
   bool own = false;
   int tile = 0;
   if (c.c.x3p_on && R > 0 && pp) {
-    auto it = g_plans.find(plan_key(mode, half_octave(R), L.N, L.K));
+    auto it = g_plans.find(plan_key(plan_mode(mode), half_octave(R), L.N, L.K));
     if (it == g_plans.end()) {
       if (!c.dry) return fail(-5, "lt_matmul: shape bucket not timed yet");
       own = true;

@@ -1405,7 +1405,7 @@ def x3p_matmul(mode, x2, w2, bias=None, resid2=None, act_src=None, act_kind=None
         return out if out2 is None else (out, out2)
     if N._Prof.target is not None:
         extra = sum(t is not None for t in (resid2, act_src, out2, resid_b))
-        N.profile_note("s2t_gemm_x3p", 4.0 * R * (Nf + Kf + extra * cols) + 6.0 * Nf * Kf,
+        N.profile_note("s2t_gemm_x3p", 4.0 * R * (Nf + Kf + extra * cols) + 2.0 * gemm_arith() * Nf * Kf,
                        2.0 * R * Nf * Kf)             # (_native.SELF_NOTING: not behind N.PROF)
     if bal is not None:
         # Balancer on act_src in the epilogue: its column statistics first (one read of act_src)
@@ -1440,7 +1440,21 @@ _BASE = {}           # shape bucket -> (library ms, best own ms | None, its tile
 # workgroups per CU; 2000 + tile = the LDS-DMA form (weight pieces global -> LDS directly) at 3 / 4 /
 # 4 workgroups per CU (S2T_X3P_DMA=1 adds them: same-box A/B at C3 38.6 ms/step with and without)
 _X3P_TILES = (222, 321, 312, 411) + ((2022, 2021, 2012) if os.environ.get("S2T_X3P_DMA", "0") == "1" else ())
+# two-piece arithmetic (S2T_GEMM_ARITH=2): the same tiles of the register-staged form, the LDS-DMA form
+# at 16-deep stages (2000 +) and at 32-deep barrier intervals (2200 +)
+_X3P_TILES2 = tuple(int(t) for t in os.environ.get(
+    "S2T_X3P_TILES2", "222,321,312,411,2022,2021,2012,2222,2221,2212,2211").split(","))
 PLAN_STATS = {"timed": 0}
+
+
+def gemm_arith():
+    """Pieces per fp32 operand of the bf16 matrix-core GEMMs, as the library reads it for the next call
+    (3: bf16x3, six products, fp32-exact; 2: bf16x2, three products) -- include/s2t_mi355.h."""
+    return int(N.lib().s2t_gemm_arith())
+
+
+def gemm_arith_name(a=None):
+    return {3: "bf16x3/6", 2: "bf16x2/3"}[gemm_arith() if a is None else a]
 
 
 def _half_octave(m):
@@ -1503,7 +1517,8 @@ def lt_matmul(mode, x2, w2, bias=None, resid2=None, act_src=None, act_kind=None,
     pp = planes.pieces(w2, mode) if (X3P["on"] and x2.shape[0]) else None
     if pp is None:
         return lib()
-    base = (mode, _half_octave(x2.shape[0]), w2.shape[0], w2.shape[1])
+    arith = N.lib().s2t_gemm_arith()     # (read per call by the library: the buckets of the two arithmetics are apart)
+    base = (mode | (arith << 4), _half_octave(x2.shape[0]), w2.shape[0], w2.shape[1])
     key = base + (bias is not None, resid2 is not None, act_src is not None, act2, resid_b is not None,
                   bal is not None)
     plan = _PLANS.get(key)
@@ -1522,7 +1537,7 @@ def lt_matmul(mode, x2, w2, bias=None, resid2=None, act_src=None, act_kind=None,
                 torch.cuda.synchronize()       # side streams idle: candidates are compared alone
                 t_lib = _time_call(lambda: _lt_matmul_lib(mode, x2, w2, bias, resid2))
                 t_own, tile = None, 0
-                for t in _X3P_TILES:
+                for t in (_X3P_TILES2 if arith == 2 else _X3P_TILES):
                     if x3p_matmul(mode, x2, w2, bias, resid2, tile=t) is None:
                         break
                     ms = _time_call(lambda: x3p_matmul(mode, x2, w2, bias, resid2, tile=t))

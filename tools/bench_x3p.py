@@ -24,7 +24,11 @@ FWD = [(31680, 272, 192), (31680, 432, 192), (31680, 192, 144), (31680, 48, 192)
        (3968, 256, 960), (3968, 512, 256), (3968, 256, 256)]
 
 
-CFGS = [int(c) for c in os.environ.get("X3P_CFGS", "0,222,321,312,411,2022,2021,2012,2011").split(",")]
+# the arithmetic is the library's (S2T_GEMM_ARITH, read per call); the default candidate list follows it
+ARITH = zk.gemm_arith()
+CFGS = [int(c) for c in os.environ.get(
+    "X3P_CFGS", "0,222,321,312,411,2022,2021,2012,2011" if ARITH == 3 else
+    "0,222,321,312,411,322,2022,2021,2012,2011,2222,2221,2212,2211").split(",")]
 
 
 def main():
@@ -40,7 +44,7 @@ def main():
     store = flat.FlatStore(plist)
     print(f"{'mode':>4} {'M':>6} {'N':>5} {'K':>5} | {'lt us':>7} {'TF':>5} | x3p: auto  t22    t21    t12    t11  | best TF  speedup | err x3p / lt")
     tot_lt = tot_x = tot_auto = 0.0
-    print("x3p configs (100 wgs/CU + tile):", CFGS)
+    print("arithmetic:", zk.gemm_arith_name(), "x3p configs (100 wgs/CU + tile; 2000 + (200) + tile: LDS-DMA form (32-deep)):", CFGS)
     for mode in (0, 1):
         for (M, Nn, K) in shapes:
             W, b = ws[(Nn, K)]
