@@ -438,10 +438,14 @@ BF16X2_CEILING_TFLOPS = 2500.0 / 3.0
 
 
 def gemm_arith():
-    """(name, ceiling TFLOP/s fp32-equivalent) of the arithmetic the library's bf16 GEMMs run in."""
+    """(policy, ceiling TFLOP/s fp32-equivalent) of the arithmetic the library's bf16 GEMMs run in:
+    'bf16x3/6' | 'bf16x2/3' when every class of product (forward, data gradient, weight gradient,
+    statistics: include/s2t_mi355.h) runs the same, else the four listed.  The ceiling is that of the
+    forward / data-gradient classes (what s2t_gemm_x3p serves); when those two differ, the HIGHER one
+    (fewer products), so that the reported fraction is never flattered."""
     from speech2text_amd import zip_kernels as zk
-    a = zk.gemm_arith()
-    return zk.gemm_arith_name(a), (BF16X3_CEILING_TFLOPS if a == 3 else BF16X2_CEILING_TFLOPS)
+    fd = min(zk.gemm_arith(zk.CLS_F), zk.gemm_arith(zk.CLS_D))
+    return zk.gemm_arith_policy(), (BF16X3_CEILING_TFLOPS if fd == 3 else BF16X2_CEILING_TFLOPS)
 BF16X3_ENTRIES = ("s2t_gemm_x3p", "s2t_gemm_x3p_bal", "s2t_gemm_x3p_map", "s2t_gemm_tn_grouped", "s2t_gemm_f32", "s2t_gemm_f32_sq",
                   "s2t_gemm_xtx", "s2t_conv3x3_gemm")
 

@@ -705,11 +705,21 @@ int s2t_predictor_ctx_bwd(const int* tokens, const float* emb, const float* w, c
  *   2 ("bf16x2/3"): x ~ p0 + p1 (2^-18 relative), the products a0 b0 + a0 b1 + a1 b0: ~ 2^-17 per
  *       term -- torch's float32 matmul precision "high"; the reference trains under the looser
  *       "medium" (reference build_task.py:79, inference.py:58).
- * s2t_gemm_arith() is consulted PER CALL by every such entry point: s2t_gemm_arith_set's value
- * (2 | 3) if one is pinned (0 = unpinned), else the environment's S2T_GEMM_ARITH ("2" | "3" |
- * "bf16x2" | "bf16x3" | "bf16x2/3" | "bf16x3/6"), else the built-in default.  The weights' piece
- * image (s2t_x3p_split) is the same for both: two-piece launches read its first two pieces. */
+ * The arithmetic is a POLICY over four classes of product -- 0 F forward (y = x W^T, conv forward,
+ * W0 @ x), 1 D data gradient (dx = g W and the batched products of backward), 2 W weight gradient
+ * (dW += g^T x: every TN launch), 3 S statistics (Whiten's x^T x and its penalty product x dcov) --
+ * consulted PER CALL: s2t_gemm_arith_set's value (2 | 3) for every class if one is pinned (0 =
+ * unpinned); else the environment's S2T_GEMM_ARITH_F / _D / _W / _S for that class, else
+ * S2T_GEMM_ARITH for all ("2" | "3" | "bf16x2" | "bf16x3" | "bf16x2/3" | "bf16x3/6"), else the
+ * built-in default of the class.  s2t_gemm_arith_of(cls) = that value (cls outside 0..3: the base
+ * value).  Entry points whose class is implied take it (TN launches: W; s2t_gemm_xtx: S; the 3x3
+ * conv forward: F); s2t_gemm_x3p*, s2t_gemm_f32 (NT / NN) and s2t_gemm_f32_batched run in the class
+ * the calling THREAD declared last with s2t_gemm_class_set(cls) (returns the previous one; -1 = none:
+ * the base value) -- s2t_gemm_arith() is that class's value.  The weights' piece image (s2t_x3p_split)
+ * is the same for both arithmetics: two-piece launches read its first two pieces. */
 int s2t_gemm_arith(void);
+int s2t_gemm_arith_of(int cls);
+int s2t_gemm_class_set(int cls);
 int s2t_gemm_arith_set(int arith);
 typedef struct {
   long src_off;

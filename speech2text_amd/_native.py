@@ -47,7 +47,8 @@ class _Prof:
     count = {}           # of times per step would otherwise pay two event records per launch)
 
 
-_NO_LAUNCH = ("s2t_side_stream", "s2t_stream_order", "s2t_balancer_next_parity",
+_NO_LAUNCH = ("s2t_side_stream", "s2t_stream_order", "s2t_balancer_next_parity", "s2t_gemm_arith",
+              "s2t_gemm_arith_of", "s2t_gemm_class_set", "s2t_gemm_arith_set",
               "s2t_zip_layer_info", "s2t_zip_layer_error", "s2t_zip_layer_plans_missing", "s2t_zl_plan_put")   # stream plumbing, nothing to time
 SELF_NOTING = ("s2t_gemm_x3p",)   # entries whose call site calls profile_note() whenever a profile is active
 PROF = [False]   # True while profile_begin() is active: call sites write `N.PROF[0] and

@@ -25,8 +25,22 @@ static inline int s2t_debug_env(const char* name) {
 
 // arithmetic of the bf16 GEMMs: pieces per fp32 operand, 3 (six products, fp32-exact) or 2 (three
 // products); read per call from S2T_GEMM_ARITH (csrc/gemm_x3p.hip)
+// per class of product: F forward (0), D data gradient (1), W weight gradient (2), S statistics (3: the
+// Whiten covariance and penalty products); s2t_gemm_arith() = the calling thread's current class
+// (s2t_gemm_class_set; none: the base value)
 #define S2T_GEMM_ARITH_DEFAULT 3
+#define S2T_GEMM_ARITH_DEFAULT_F 3
+#define S2T_GEMM_ARITH_DEFAULT_D 3
+#define S2T_GEMM_ARITH_DEFAULT_W 3
+#define S2T_GEMM_ARITH_DEFAULT_S 3
 extern "C" int s2t_gemm_arith(void);
+extern "C" int s2t_gemm_arith_of(int cls);
+extern "C" int s2t_gemm_class_set(int cls);
+struct S2tGemmClass {                     // scope guard: the class of the products issued inside
+  int prev;
+  explicit S2tGemmClass(int cls) : prev(s2t_gemm_class_set(cls)) {}
+  ~S2tGemmClass() { s2t_gemm_class_set(prev); }
+};
 
 #define S2T_WAVE 64
 #define S2T_NEG_INF (-__builtin_huge_valf())

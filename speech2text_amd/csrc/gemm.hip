@@ -1006,7 +1006,8 @@ constexpr int KR = 64;   // TN slices are multiples of the deepest chunk
 
 template <int MODE>
 int dispatch(GemmArgs& g, hipStream_t st) {
-  g.np = s2t_gemm_arith();
+  // weight gradients are class W whatever the caller's scope says; the symmetric x^T x is a statistic
+  g.np = MODE == MODE_TN ? s2t_gemm_arith_of(g.sym_cg > 0 ? 3 : 2) : s2t_gemm_arith();
   int tn_sel = pick_tn(g.N);
   const int pro = MODE == MODE_NT ? g.pro_a : (MODE == MODE_TN ? g.pro_b : 0);
   long tiles_big = (long)((g.M + 127) / 128) * ((g.N + 64 * tn_sel - 1) / (64 * tn_sel));
@@ -1164,7 +1165,7 @@ extern "C" int s2t_gemm_f32_batched(int mode, const float* A, long lda, long sA,
   GemmArgs g{A, lda, B, ldb, C, ldc, M, N, K, nullptr, nullptr, 0, nullptr, 0, 0, 0,
              0, nullptr, 0, 0, 0, 0, 0, 0, 1.f, 0};
   hipStream_t st = (hipStream_t)stream;
-  g.np = s2t_gemm_arith();
+  g.np = s2t_gemm_arith();              // (products of two activations: the caller's class, all three layouts)
   g.tiles_m = (M + 63) / 64;
   g.tiles_n = (N + 63) / 64;
   const int total = g.tiles_m * g.tiles_n;
@@ -1228,7 +1229,7 @@ extern "C" int s2t_conv3x3_gemm(int mode, const float* x, int B, int H, int W, i
   if (mode == 0) {
     GemmArgs g{x, 0, w2_or_g, K9, out, CO, (int)R, CO, K9, bias, nullptr, 0, nullptr, 0, 0, 0,
                0, nullptr, 0, 0, 0, 0, 0, 0, 1.f, 0, 0, 0, pt};
-    g.np = s2t_gemm_arith();
+    g.np = s2t_gemm_arith_of(0);
     g.wide_ep = !bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0;
     g.tiles_m = (g.M + 127) / 128;
     g.tiles_n = CO > 64 ? (CO + 127) / 128 : 1;
@@ -1242,7 +1243,7 @@ extern "C" int s2t_conv3x3_gemm(int mode, const float* x, int B, int H, int W, i
   }
   GemmArgs g{w2_or_g, CO, x, 0, out, K9, CO, K9, (int)R, nullptr, nullptr, 0, nullptr, 0, 0, 0,
              0, db, 0, 0, 0, 0, 0, 0, 1.f, 0, 0, 0, pt};
-  g.np = s2t_gemm_arith();
+  g.np = s2t_gemm_arith_of(2);
   { static const int dbg = s2t_debug_env("S2T_GEMM_DEBUG"); g.debug = dbg; }
   // the wave-specialised form (tn_w_body) for outputs of >= 128 x 1024 (the conformer's 256 -> 256 conv:
   // 24 tiles of 128 x 192).  The zipformer frontend's 32 -> 128 conv (128 x 288 output over 600 k rows:
@@ -1328,7 +1329,7 @@ extern "C" int s2t_gemm_tn_grouped(int n, const S2tTnProblem* probs, void* strea
   for (int base = 0; base < n && useq; base += MAXG) {
     TnGroup grp;
     { static const int dbg = s2t_debug_env("S2T_GEMM_DEBUG"); grp.debug = dbg; }
-    grp.np = s2t_gemm_arith();
+    grp.np = s2t_gemm_arith_of(2);
     grp.n = std::min(MAXG, n - base);
     long total_tiles = 0;
     for (int i = 0; i < grp.n; ++i) {
@@ -1368,7 +1369,7 @@ extern "C" int s2t_gemm_tn_grouped(int n, const S2tTnProblem* probs, void* strea
   for (int base = 0; base < n; base += MAXG) {
     TnGroup grp;
     { static const int dbg = s2t_debug_env("S2T_GEMM_DEBUG"); grp.debug = dbg; }
-    grp.np = s2t_gemm_arith();
+    grp.np = s2t_gemm_arith_of(2);
     grp.n = std::min(MAXG, n - base);
     long total_tiles = 0;
     for (int i = 0; i < grp.n; ++i) {

@@ -1058,17 +1058,33 @@ extern "C" {
 // gemm.hip): 3 = every fp32 operand as the EXACT sum of three bf16 pieces, six piece products per
 // term (fp32-level error, <= 2e-6 of max); 2 = two pieces per operand, the three leading products
 // a_hi b_hi + a_hi b_lo + a_lo b_hi (error ~ 2^-17 per term: torch's float32 matmul precision
-// "high"; the reference trains with the looser "medium", build_task.py:79).  Read PER CALL:
-// S2T_GEMM_ARITH=3 | 2 (also "bf16x3" / "bf16x2"), unless s2t_gemm_arith_set pinned it (0 = follow
-// the environment again).
-int s2t_gemm_arith(void) {
-  if (g_arith_forced) return g_arith_forced;
-  const char* e = getenv("S2T_GEMM_ARITH");
-  if (!e || !*e) return S2T_GEMM_ARITH_DEFAULT;
+// "high"; the reference trains with the looser "medium", build_task.py:79).  Read PER CALL, per
+// CLASS of product (include/s2t_mi355.h): S2T_GEMM_ARITH=3 | 2 (also "bf16x3" / "bf16x2") for every
+// class, S2T_GEMM_ARITH_F / _D / _W / _S for one (forward, data gradient, weight gradient,
+// statistics), unless s2t_gemm_arith_set pinned one value for all (0 = follow the environment again).
+static int arith_parse(const char* e, int dflt) {
+  if (!e || !*e) return dflt;
   const char* x = strchr(e, 'x');        // "2", "3", "bf16x2", "bf16x3", "bf16x2/3", "bf16x3/6"
   const char c = x ? x[1] : e[0];
-  return c == '2' ? 2 : c == '3' ? 3 : S2T_GEMM_ARITH_DEFAULT;
+  return c == '2' ? 2 : c == '3' ? 3 : dflt;
 }
+static thread_local int g_cls = -1;
+int s2t_gemm_class_set(int cls) {
+  const int prev = g_cls;
+  g_cls = (cls >= 0 && cls <= 3) ? cls : -1;
+  return prev;
+}
+int s2t_gemm_arith_of(int cls) {
+  if (g_arith_forced) return g_arith_forced;
+  static const char* const kEnv[4] = {"S2T_GEMM_ARITH_F", "S2T_GEMM_ARITH_D", "S2T_GEMM_ARITH_W", "S2T_GEMM_ARITH_S"};
+  static const int kDefault[4] = {S2T_GEMM_ARITH_DEFAULT_F, S2T_GEMM_ARITH_DEFAULT_D, S2T_GEMM_ARITH_DEFAULT_W,
+                                  S2T_GEMM_ARITH_DEFAULT_S};
+  const char* all = getenv("S2T_GEMM_ARITH");
+  const bool has_all = all && *all;
+  if (cls < 0 || cls > 3) return arith_parse(all, S2T_GEMM_ARITH_DEFAULT);
+  return arith_parse(getenv(kEnv[cls]), has_all ? arith_parse(all, kDefault[cls]) : kDefault[cls]);
+}
+int s2t_gemm_arith(void) { return s2t_gemm_arith_of(g_cls); }
 int s2t_gemm_arith_set(int arith) {
   if (arith != 0 && arith != 2 && arith != 3) return -1;
   g_arith_forced = arith;

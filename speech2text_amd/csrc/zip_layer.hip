@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "../../include/s2t_mi355.h"
+#include "common.h"
 
 namespace {
 
@@ -79,7 +80,7 @@ uint64_t plan_key(int mode, int ho, int N, int K) {
   return ((uint64_t)(mode & 1) << 63) | ((uint64_t)((mode >> 4) & 3) << 56) | ((uint64_t)(ho & 0xFF) << 48) |
          ((uint64_t)(N & 0xFFFFFF) << 24) | (uint64_t)(K & 0xFFFFFF);
 }
-int plan_mode(int mode) { return (mode & 1) | (s2t_gemm_arith() << 4); }
+int plan_mode(int mode) { return (mode & 1) | (s2t_gemm_arith_of(mode & 1) << 4); }
 int half_octave(long m) {            // floor(2 log2 m), as zip_kernels._half_octave
   if (m < 1) m = 1;
   int b = 63 - __builtin_clzll((unsigned long long)m);
@@ -201,6 +202,7 @@ int balancer_bwd(Ctx& c, const S2tZlBal& b, const float* x, long ldx, const floa
 
 int lt_matmul(Ctx& c, int mode, const float* x, long ldx, long R, const S2tZlLin& L, const Epi& e,
               float* out) {
+  const S2tGemmClass cls(mode);        // the arithmetic of forward (0) / data-gradient (1) products
   const int cols = mode == 0 ? L.N : L.K, inner = mode == 0 ? L.K : L.N;
   const long n = R * cols;
   const unsigned short* pp = mode == 0 ? L.pf : L.pb;
@@ -345,6 +347,7 @@ int whiten_bwd(Ctx& c, int site, const S2tZlWh& w, WStat& s, const float* x, lon
   float* o = c.ar.alloc(R * C);
   if (c.dry) return 0;
   RUN(s2t_whiten_dcov(s.cov, s.mean, s.scal, s.G, s.cg, dcov, bias, sums, (void*)c.st));
+  const S2tGemmClass cls(3);           // the penalty's product x dcov: a statistic
   bool done = false;
   const S2tZlWhScratch* sc = wh_scratch(c, C);
   if (c.c.whiten_x3p && c.c.x3p_on && R >= c.c.whiten_x3p_rows && sc && sc->buf && C >= 16 && (C & 7) == 0) {
@@ -507,7 +510,7 @@ int na_fwd(Ctx& c, const float* x_in, const float** x_out) {
   sv.xs = c.ar.alloc(R * C);
   RUN(s2t_nonlin_gate_fwd(sv.u, T, B, C, sv.xs, (void*)c.st));
   sv.z = c.ar.alloc(R * C);
-  TRY(bmm(c, 1, c.s.W, sv.xs, sv.z, B, T, C, T));                 // W0 @ x
+  { const S2tGemmClass cls(0); TRY(bmm(c, 1, c.s.W, sv.xs, sv.z, B, T, C, T)); }   // W0 @ x
   sv.o = c.ar.alloc(R * C);
   RUN(s2t_nonlin_out_fwd(sv.z, sv.u, T, B, C, sv.o, (void*)c.st));
   sv.st1.on = 0;
@@ -727,6 +730,7 @@ int na_bwd(Ctx& c, const float* x_in, const float* g, const float** g_out) {
   float* du = c.ar.alloc(R * 3 * C);
   RUN(s2t_nonlin_out_bwd(dout, sv.z, sv.u, T, B, C, dz, du, (void*)c.st));
   float* dxs = c.ar.alloc(R * C);
+  const S2tGemmClass cls_d(1);
   TRY(bmm(c, 2, c.s.W, dz, dxs, B, T, C, T));                     // W0^T @ dz
   c.s.dW0 = c.ar.alloc((long)B * T * T);
   TRY(bmm(c, 0, dz, sv.xs, c.s.dW0, B, T, T, C));                 // dz @ x^T

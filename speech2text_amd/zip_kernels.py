@@ -429,11 +429,16 @@ def whiten_backward(x, g, stats, limit, grad_scale):
     if _WHITEN_X3P and X3P["on"] and xf.stride(1) == 1 and xf.shape[0] >= _WHITEN_X3P_ROWS:
         pp = planes.adhoc_pieces(dcov, 1)
         if pp is not None:
-            pg = x3p_matmul(1, xf, dcov, bias, pp=pp)
+            pg = x3p_matmul(1, xf, dcov, bias, pp=pp, cls=CLS_S)
     g2 = g.contiguous().float()
     if g2.data_ptr() % 16:
         g2 = g2.clone()
     out = torch.empty_like(g2)
+    with gemm_class(CLS_S):                        # (the penalty's product x dcov: a statistic)
+        return _whiten_penalty(xf, g2, dcov, bias, sums, pg, out, C, shp, grad_scale, dev)
+
+
+def _whiten_penalty(xf, g2, dcov, bias, sums, pg, out, C, shp, grad_scale, dev):
     if pg is None:
         # (our NN kernel with the bias in its epilogue: the same calls csrc/zip_layer.hip makes);
         # first the form that takes the two norms of (g, pg) while pg leaves the accumulators
@@ -1383,7 +1388,7 @@ def _vp(t):
 
 
 def x3p_matmul(mode, x2, w2, bias=None, resid2=None, act_src=None, act_kind=None, act2=None, tile=0,
-               resid_b=None, pp=None, bal=None):
+               resid_b=None, pp=None, bal=None, cls=None):
     """The same products as lt_matmul on our bf16x3 kernel with pre-split weight pieces
     (csrc/gemm_x3p.hip, planes.py): mode 0: x2 (R,K) w2 (N,K)^T (+bias) -> (R,N); mode 1: x2 (R,N)
     w2 (N,K) -> (R,K); then (* act'(act_src)) (+ resid2); with act2 a second output act2(result).
@@ -1405,8 +1410,19 @@ def x3p_matmul(mode, x2, w2, bias=None, resid2=None, act_src=None, act_kind=None
         return out if out2 is None else (out, out2)
     if N._Prof.target is not None:
         extra = sum(t is not None for t in (resid2, act_src, out2, resid_b))
-        N.profile_note("s2t_gemm_x3p", 4.0 * R * (Nf + Kf + extra * cols) + 2.0 * gemm_arith() * Nf * Kf,
+        N.profile_note("s2t_gemm_x3p", 4.0 * R * (Nf + Kf + extra * cols)
+                       + 2.0 * gemm_arith(cls if cls is not None else mode) * Nf * Kf,
                        2.0 * R * Nf * Kf)             # (_native.SELF_NOTING: not behind N.PROF)
+    prev_cls = N.lib().s2t_gemm_class_set(cls if cls is not None else mode)
+    try:
+        return _x3p_launch(mode, x2, w2, bias, resid2, act_src, act_kind, act2, tile, resid_b, pp, bal,
+                           R, Nf, Kf, cols, inner, out, out2)
+    finally:
+        N.lib().s2t_gemm_class_set(prev_cls)
+
+
+def _x3p_launch(mode, x2, w2, bias, resid2, act_src, act_kind, act2, tile, resid_b, pp, bal, R, Nf, Kf, cols,
+                inner, out, out2):
     if bal is not None:
         # Balancer on act_src in the epilogue: its column statistics first (one read of act_src)
         if act_src is None or bias is not None or out2 is not None or resid_b is not None or cols > 1024:
@@ -1447,14 +1463,42 @@ _X3P_TILES2 = tuple(int(t) for t in os.environ.get(
 PLAN_STATS = {"timed": 0}
 
 
-def gemm_arith():
-    """Pieces per fp32 operand of the bf16 matrix-core GEMMs, as the library reads it for the next call
+CLS_F, CLS_D, CLS_W, CLS_S = 0, 1, 2, 3     # classes of product (include/s2t_mi355.h s2t_gemm_arith_of)
+
+
+def gemm_arith(cls=-1):
+    """Pieces per fp32 operand of the bf16 matrix-core GEMMs of class `cls` (forward, data gradient,
+    weight gradient, statistics; -1: the base value), as the library reads it for the next call
     (3: bf16x3, six products, fp32-exact; 2: bf16x2, three products) -- include/s2t_mi355.h."""
-    return int(N.lib().s2t_gemm_arith())
+    return int(N.lib().s2t_gemm_arith_of(cls))
 
 
 def gemm_arith_name(a=None):
     return {3: "bf16x3/6", 2: "bf16x2/3"}[gemm_arith() if a is None else a]
+
+
+def gemm_arith_policy():
+    """'bf16x2/3' | 'bf16x3/6' when every class runs the same arithmetic, else e.g.
+    'F bf16x3/6, D bf16x2/3, W bf16x2/3, S bf16x3/6'."""
+    v = [gemm_arith(c) for c in (CLS_F, CLS_D, CLS_W, CLS_S)]
+    if len(set(v)) == 1:
+        return gemm_arith_name(v[0])
+    return ", ".join(f"{n} {gemm_arith_name(a)}" for n, a in zip("FDWS", v))
+
+
+class gemm_class:
+    """with gemm_class(CLS_D): ... -- the class of the x3p / NT / NN / batched products issued inside
+    (the calling thread's, s2t_gemm_class_set)."""
+
+    def __init__(self, cls):
+        self.cls = cls
+
+    def __enter__(self):
+        self.prev = N.lib().s2t_gemm_class_set(self.cls)
+
+    def __exit__(self, *exc):
+        N.lib().s2t_gemm_class_set(self.prev)
+        return False
 
 
 def _half_octave(m):
@@ -1517,7 +1561,7 @@ def lt_matmul(mode, x2, w2, bias=None, resid2=None, act_src=None, act_kind=None,
     pp = planes.pieces(w2, mode) if (X3P["on"] and x2.shape[0]) else None
     if pp is None:
         return lib()
-    arith = N.lib().s2t_gemm_arith()     # (read per call by the library: the buckets of the two arithmetics are apart)
+    arith = N.lib().s2t_gemm_arith_of(mode)   # (read per call, per class of product: the buckets of the two arithmetics are apart)
     base = (mode | (arith << 4), _half_octave(x2.shape[0]), w2.shape[0], w2.shape[1])
     key = base + (bias is not None, resid2 is not None, act_src is not None, act2, resid_b is not None,
                   bal is not None)
@@ -1586,6 +1630,14 @@ def _lt_matmul_lib(mode, x2, w2, bias=None, resid2=None, out_shape=None):
         return out
     w2 = w2 if (w2.stride(1) == 1 and w2.stride(0) >= w2.shape[1]) else w2.contiguous()
     ws = _lt_workspace(x2.device)
+    prev_cls = N.lib().s2t_gemm_class_set(mode)    # (the plan cache may pick our NT / NN kernel: forward / data-gradient class)
+    try:
+        return _lt_lib_launch(mode, x2, w2, bias, resid2, out, ws, R, Nf, Kf, cols)
+    finally:
+        N.lib().s2t_gemm_class_set(prev_cls)
+
+
+def _lt_lib_launch(mode, x2, w2, bias, resid2, out, ws, R, Nf, Kf, cols):
     N.PROF[0] and N.profile_note("s2t_linear_lt", 4.0 * (R * (Nf + Kf) + Nf * Kf + (R * cols if resid2 is not None else 0)),
                    2.0 * R * Nf * Kf)
     rc = N.lib().s2t_linear_lt(mode, N.raw(x2, torch.float32), x2.stride(0),

@@ -375,7 +375,8 @@ def _na_fwd(m, dec, x_in, W, T, B):
     N.PROF[0] and N.profile_note("s2t_nonlin_gate_fwd", 12.0 * T * B * C)
     N.check(L.s2t_nonlin_gate_fwd(N.fp(sv.u), T, B, C, N.fp(sv.xs), st), "nonlin_gate_fwd")
     sv.wm = W[0]                                                             # (B,T,T)
-    sv.z = zk.batched_matmul(1, sv.wm, sv.xs)                                # W0 @ x, (B,T,C)
+    with zk.gemm_class(zk.CLS_F):
+        sv.z = zk.batched_matmul(1, sv.wm, sv.xs)                            # W0 @ x, (B,T,C)
     sv.o = _e(T * B, C, dev)
     N.PROF[0] and N.profile_note("s2t_nonlin_out_fwd", 12.0 * T * B * C)
     N.check(L.s2t_nonlin_out_fwd(N.fp(sv.z), N.fp(sv.u), T, B, C, N.fp(sv.o), st),
@@ -408,8 +409,9 @@ def _na_bwd(m, post, dec, sv, x_in, g, T, B):
     N.PROF[0] and N.profile_note("s2t_nonlin_out_bwd", 20.0 * T * B * C)
     N.check(L.s2t_nonlin_out_bwd(N.fp(do), N.fp(sv.z), N.fp(sv.u), T, B, C, N.fp(dz), N.fp(du), st),
             "nonlin_out_bwd")
-    dxs = zk.batched_matmul(2, sv.wm, dz)                                    # W0^T @ dz, (B,T,C)
-    dW0 = zk.batched_matmul(0, dz, sv.xs)                                    # dz @ x^T, (B,T,T)
+    with zk.gemm_class(zk.CLS_D):
+        dxs = zk.batched_matmul(2, sv.wm, dz)                                # W0^T @ dz, (B,T,C)
+        dW0 = zk.batched_matmul(0, dz, sv.xs)                                # dz @ x^T, (B,T,T)
     N.PROF[0] and N.profile_note("s2t_nonlin_gate_bwd", 20.0 * T * B * C)
     N.check(L.s2t_nonlin_gate_bwd(N.fp(dxs), N.fp(sv.u), T, B, C, N.fp(du), st), "nonlin_gate_bwd")
     if fb:

@@ -207,6 +207,9 @@ def test_lt_plan_cache_survives_dynamic_batching(dev):
     import time
     from speech2text_amd import _native as N
     from speech2text_amd import zip_kernels as zk
+    if ARITH[0] != 3:
+        pytest.skip("host-side plan cache of the library path: the same cache whatever the arithmetic "
+                    "(the first parametrisation filled it)")
     g = torch.Generator().manual_seed(0)
     nk = [(576, 256), (768, 256), (960, 256), (256, 576), (256, 768), (256, 960), (272, 256),
           (512, 256), (256, 256), (48, 256)]
