@@ -439,13 +439,21 @@ BF16X2_CEILING_TFLOPS = 2500.0 / 3.0
 
 def gemm_arith():
     """(policy, ceiling TFLOP/s fp32-equivalent) of the arithmetic the library's bf16 GEMMs run in:
-    'bf16x3/6' | 'bf16x2/3' when every class of product (forward, data gradient, weight gradient,
-    statistics: include/s2t_mi355.h) runs the same, else the four listed.  The ceiling is that of the
+    'bf16x3/6' | 'bf16x2/3' when the forward, data-gradient and weight-gradient classes of product
+    (include/s2t_mi355.h) run the same, else the three listed; the statistics class (Whiten's
+    covariance and penalty products: six products by default) is in config.gemm_arith_classes.  The ceiling is that of the
     forward / data-gradient classes (what s2t_gemm_x3p serves); when those two differ, the HIGHER one
     (fewer products), so that the reported fraction is never flattered."""
     from speech2text_amd import zip_kernels as zk
     fd = min(zk.gemm_arith(zk.CLS_F), zk.gemm_arith(zk.CLS_D))
-    return zk.gemm_arith_policy(), (BF16X3_CEILING_TFLOPS if fd == 3 else BF16X2_CEILING_TFLOPS)
+    return zk.gemm_arith_policy()[0], (BF16X3_CEILING_TFLOPS if fd == 3 else BF16X2_CEILING_TFLOPS)
+
+
+def gemm_arith_classes():
+    """{'F': .., 'D': .., 'W': .., 'S': ..}: the arithmetic of each class of product (forward, data
+    gradient, weight gradient, statistics)."""
+    from speech2text_amd import zip_kernels as zk
+    return zk.gemm_arith_policy()[1]
 BF16X3_ENTRIES = ("s2t_gemm_x3p", "s2t_gemm_x3p_bal", "s2t_gemm_x3p_map", "s2t_gemm_tn_grouped", "s2t_gemm_f32", "s2t_gemm_f32_sq",
                   "s2t_gemm_xtx", "s2t_conv3x3_gemm")
 
@@ -790,6 +798,7 @@ def main(argv=None):
                        "ddp_forced_on_one_rank": args.ddp_force,
                        "gemm_paths": gemm_paths(),
                        "gemm_arith": gemm_arith()[0],
+                       "gemm_arith_classes": gemm_arith_classes(),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "utterance_seconds": args.seconds, "labels_per_utt": args.labels,
                        "parallelism": f"dp{world}", "final_loss": final_loss},

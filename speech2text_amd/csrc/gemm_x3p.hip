@@ -1079,6 +1079,8 @@ int s2t_gemm_arith_of(int cls) {
   static const char* const kEnv[4] = {"S2T_GEMM_ARITH_F", "S2T_GEMM_ARITH_D", "S2T_GEMM_ARITH_W", "S2T_GEMM_ARITH_S"};
   static const int kDefault[4] = {S2T_GEMM_ARITH_DEFAULT_F, S2T_GEMM_ARITH_DEFAULT_D, S2T_GEMM_ARITH_DEFAULT_W,
                                   S2T_GEMM_ARITH_DEFAULT_S};
+  // S2T_GEMM_ARITH sets EVERY class (also the statistics: "3" is the all-six-product step of rounds
+  // 3-5, "2" the all-three-product one); the per-class variables override it
   const char* all = getenv("S2T_GEMM_ARITH");
   const bool has_all = all && *all;
   if (cls < 0 || cls > 3) return arith_parse(all, S2T_GEMM_ARITH_DEFAULT);

@@ -347,7 +347,10 @@ int whiten_bwd(Ctx& c, int site, const S2tZlWh& w, WStat& s, const float* x, lon
   float* o = c.ar.alloc(R * C);
   if (c.dry) return 0;
   RUN(s2t_whiten_dcov(s.cov, s.mean, s.scal, s.G, s.cg, dcov, bias, sums, (void*)c.st));
-  const S2tGemmClass cls(3);           // the penalty's product x dcov: a statistic
+  // the penalty's product x dcov: class S (statistics) -- S2T_WHITEN_PG_CLS=1 files it under the data
+  // gradients instead (experiment: which of the two statistics products needs the six-product form)
+  static const int pg_cls = [] { const char* e = getenv("S2T_WHITEN_PG_CLS"); return e ? atoi(e) : 3; }();
+  const S2tGemmClass cls(pg_cls);
   bool done = false;
   const S2tZlWhScratch* sc = wh_scratch(c, C);
   if (c.c.whiten_x3p && c.c.x3p_on && R >= c.c.whiten_x3p_rows && sc && sc->buf && C >= 16 && (C & 7) == 0) {

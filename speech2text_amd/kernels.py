@@ -194,7 +194,12 @@ class _SimpleRnntLoss(torch.autograd.Function):
         N.check(L.s2t_rnnt_row_exp(N.fp(am), B * T, C, N.fp(am_p), N.fp(am_max), st), "row_exp")
         N.check(L.s2t_rnnt_row_exp(N.fp(lm), B * (S + 1), C, N.fp(lm_p), N.fp(lm_max), st),
                 "row_exp")
-        nrm = torch.bmm(lm_p, am_p.transpose(1, 2)).contiguous()        # plain GEMM: rocBLAS
+        # the normaliser product exp(lm) exp(am)^T (reference model/joiner/joiner.py:100-108 ->
+        # k2.rnnt_loss_smoothed) and its two gradients below: our batched kernel (csrc/gemm.hip), no
+        # library launch on the loss path
+        from . import zip_kernels as zk
+        with zk.gemm_class(zk.CLS_F):
+            nrm = zk.batched_matmul(0, lm_p, am_p)                       # (B,S+1,T)
         px = torch.empty((B, S, T + 1), dtype=torch.float32, device=dev)
         py = torch.empty((B, S + 1, T), dtype=torch.float32, device=dev)
         N.check(L.s2t_rnnt_simple_pxpy(N.fp(am), N.fp(lm), N.fp(am_max), N.fp(lm_max),
@@ -217,8 +222,10 @@ class _SimpleRnntLoss(torch.autograd.Function):
         W = torch.empty_like(nrm)
         N.check(L.s2t_rnnt_simple_w(N.fp(gx), N.fp(gy), N.fp(nrm), N.fp(gscale), B, S, T,
                                     N.fp(W), st), "simple_w")
-        G_am = torch.bmm(W.transpose(1, 2), lm_p)     # (B,T,C)
-        G_lm = torch.bmm(W, am_p)                     # (B,S+1,C)
+        from . import zip_kernels as zk
+        with zk.gemm_class(zk.CLS_D):
+            G_am = zk.batched_matmul(2, W, lm_p, own_tn=True)     # W^T @ exp(lm): (B,T,C)
+            G_lm = zk.batched_matmul(1, W, am_p)                  # W @ exp(am):   (B,S+1,C)
         d_am = torch.empty_like(am_p)
         d_lm = torch.empty_like(lm_p)
         N.check(L.s2t_rnnt_simple_bwd(N.fp(am_p), N.fp(lm_p), N.fp(G_am), N.fp(G_lm), N.fp(gx),

@@ -402,6 +402,9 @@ _WHITEN_SQ = os.environ.get("S2T_WHITEN_SQ", "1") == "1"
 _WHITEN_X3P_ROWS = int(os.environ.get("S2T_WHITEN_X3P_ROWS", "24000"))
 
 
+_WHITEN_PG_CLS = int(os.environ.get("S2T_WHITEN_PG_CLS", "3"))   # class of the penalty product (csrc/zip_layer.hip whiten_bwd)
+
+
 def whiten_backward(x, g, stats, limit, grad_scale):
     """Closed form of reference scaling.py:949-1028.  Returns (grad, penalty_was_active).
     d metric/d x = 2 (x - mean) dcov  (the centring's own Jacobian vanishes because the centred
@@ -429,12 +432,12 @@ def whiten_backward(x, g, stats, limit, grad_scale):
     if _WHITEN_X3P and X3P["on"] and xf.stride(1) == 1 and xf.shape[0] >= _WHITEN_X3P_ROWS:
         pp = planes.adhoc_pieces(dcov, 1)
         if pp is not None:
-            pg = x3p_matmul(1, xf, dcov, bias, pp=pp, cls=CLS_S)
+            pg = x3p_matmul(1, xf, dcov, bias, pp=pp, cls=_WHITEN_PG_CLS)
     g2 = g.contiguous().float()
     if g2.data_ptr() % 16:
         g2 = g2.clone()
     out = torch.empty_like(g2)
-    with gemm_class(CLS_S):                        # (the penalty's product x dcov: a statistic)
+    with gemm_class(_WHITEN_PG_CLS):               # (the penalty's product x dcov: a statistic)
         return _whiten_penalty(xf, g2, dcov, bias, sums, pg, out, C, shp, grad_scale, dev)
 
 
@@ -1253,7 +1256,7 @@ def wgrad_into(wparam, bparam, g2, a2, pro=0, notify=False):
 _BMM_OWN = os.environ.get("S2T_BMM_OWN", "1") == "1"
 
 
-def batched_matmul(mode, a, b):
+def batched_matmul(mode, a, b, own_tn=False):
     """Batch of independent fp32 products (the nonlinear attention's attn_weights[0] @ x and its
     two gradients, reference zipformer.py:2438-2483), contiguous 3-D operands:
       mode 0: a (n,M,K) b (n,N,K) -> a @ b^T;  mode 1: a (n,M,K) b (n,K,N) -> a @ b;
@@ -1270,10 +1273,14 @@ def batched_matmul(mode, a, b):
     # measured at the C3 shapes (tools/debug/bmm_test.py, 64 x 248 x 248 x 192): a @ b 26 us against
     # 55, a @ b^T 21 against 69; the a^T @ b form (split contraction + atomics) 120 against 55 --
     # that one stays with the library, as do the shapes the kernel's alignment rules refuse
-    if (_BMM_OWN and mode != 2 and K % 4 == 0 and (mode == 0 or Nn % 4 == 0) and min(M, Nn, K) >= 4
-            and a.is_cuda and a.dtype is torch.float32 and b.dtype is torch.float32
+    # own_tn: the a^T @ b form on our kernel as well -- for SHORT contractions (the simple loss's
+    # W^T @ exp(lm): K = S + 1 = 51, one slice, no split) it needs no second pass; its tiles are ADDED
+    # to the output, which therefore starts as zeros
+    tn_ok = own_tn and mode == 2 and M % 4 == 0 and Nn % 4 == 0
+    if (_BMM_OWN and (mode != 2 or tn_ok) and (mode == 2 or K % 4 == 0) and (mode == 0 or Nn % 4 == 0)
+            and min(M, Nn, K) >= 4 and a.is_cuda and a.dtype is torch.float32 and b.dtype is torch.float32
             and a.is_contiguous() and b.is_contiguous() and n > 0):
-        out = torch.empty((n, M, Nn), dtype=torch.float32, device=a.device)
+        out = (torch.zeros if mode == 2 else torch.empty)((n, M, Nn), dtype=torch.float32, device=a.device)
         N.PROF[0] and N.profile_note("s2t_gemm_f32_batched", 4.0 * (a.numel() + b.numel() + out.numel()),
                                      2.0 * n * M * Nn * K)
         rc = N.lib().s2t_gemm_f32_batched(mode, N.fp(a), a.stride(1), a.stride(0), N.fp(b), b.stride(1),
@@ -1478,12 +1485,14 @@ def gemm_arith_name(a=None):
 
 
 def gemm_arith_policy():
-    """'bf16x2/3' | 'bf16x3/6' when every class runs the same arithmetic, else e.g.
-    'F bf16x3/6, D bf16x2/3, W bf16x2/3, S bf16x3/6'."""
-    v = [gemm_arith(c) for c in (CLS_F, CLS_D, CLS_W, CLS_S)]
-    if len(set(v)) == 1:
-        return gemm_arith_name(v[0])
-    return ", ".join(f"{n} {gemm_arith_name(a)}" for n, a in zip("FDWS", v))
+    """(name, per-class dict): name = 'bf16x2/3' | 'bf16x3/6' when the forward, data-gradient and
+    weight-gradient products run the same arithmetic (the statistics class is listed in the dict), else
+    e.g. 'F bf16x3/6, D bf16x2/3, W bf16x2/3'."""
+    v = {n: gemm_arith(c) for n, c in zip("FDWS", (CLS_F, CLS_D, CLS_W, CLS_S))}
+    classes = {n: gemm_arith_name(a) for n, a in v.items()}
+    if v["F"] == v["D"] == v["W"]:
+        return gemm_arith_name(v["F"]), classes
+    return ", ".join(f"{n} {classes[n]}" for n in "FDW"), classes
 
 
 class gemm_class:

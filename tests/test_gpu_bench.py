@@ -31,10 +31,14 @@ def test_bench_line_contract_and_roofline_rows(dev, cfg, arith):
     assert d["unit"] == "audio-seconds/sec" and d["n_gpus"] == 1 and d["steps"] == 3
     assert d["dtype"] == "f32" and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert "workload" in d["config"] and "model" not in d["config"]
-    pol = d["config"]["gemm_arith"]            # one name, or "F .., D .., W .., S .." when the classes differ
+    pol = d["config"]["gemm_arith"]            # one name, or "F .., D .., W .." when those classes differ
     assert pol in ("bf16x3/6", "bf16x2/3") or pol.startswith("F bf16x")
-    if arith:
-        assert pol == arith
+    cls = d["config"]["gemm_arith_classes"]
+    assert set(cls) == set("FDWS") and all(v in ("bf16x3/6", "bf16x2/3") for v in cls.values())
+    if arith:                                  # S2T_GEMM_ARITH sets every class, the statistics included
+        assert pol == arith and set(cls.values()) == {arith}
+    else:                                      # the built-in policy: the statistics on six products
+        assert pol == "bf16x2/3" and cls["S"] == "bf16x3/6"
     products = 3.0 if ("F bf16x2" in pol or "D bf16x2" in pol or pol == "bf16x2/3") else 6.0
     assert isinstance(d["cpu_baseline"], dict) and d["cpu_baseline"]["kind"] == "port"
     rf = d["roofline"]
