@@ -572,3 +572,60 @@ def test_attn_apply_both_ways(dev, T, B, H, dv):
         ref = torch.matmul(Wd, v.double().reshape(T, B, H, dv).permute(2, 1, 0, 3))
         ref = ref.permute(2, 1, 0, 3).reshape(T, B, H * dv)
         np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), atol=2e-5, rtol=1e-4)
+
+
+def _balancer_ref64(x, g, min_mean, max_mean, min_rms, max_rms, grad_scale, swoosh):
+    """reference model/layer/scaling.py:741-789 in closed form (as zk.balancer_backward's torch path), fp64."""
+    x, g = x.double(), g.double()
+    if swoosh is not None:
+        g = g * (torch.sigmoid(x - (4.0 if swoosh else 1.0)) - 0.08)
+    n = x.shape[0]
+    mean = x.mean(0, keepdim=True)
+    uvar = (x * x).mean(0, keepdim=True)
+    var = (uvar - mean * mean).clamp(min=1.0e-20)
+    std, rms = var.sqrt(), uvar.clamp(min=1.0e-20).sqrt()
+    m = mean / std
+    s_m = torch.sign(m - m.clamp(min=min_mean, max=max_mean))
+    s_r = -torch.sign((rms.clamp(min=min_rms, max=max_rms) / rms).log())
+    a = s_m / n * (1.0 / std + mean * mean / (std * var))
+    b = -s_m / n * mean / (std * var) + s_r / n / (rms * rms)
+    lg_rms = (a * a + 2 * a * b * mean + b * b * uvar).clamp(min=0).sqrt().clamp(min=1.0e-20)
+    return g + g.abs() * (a + b * x) * (grad_scale / lg_rms)
+
+
+@pytest.mark.parametrize("rows,C", [(31680, 192), (15872, 576), (7936, 960), (3968, 1024), (1000, 100), (37, 256),
+                                    (5000, 260)])
+@pytest.mark.parametrize("swoosh", [None, True])
+def test_balancer_backward_16_byte_form(dev, rows, C, swoosh):
+    """s2t_balancer_bwd (reference model/layer/scaling.py:741-789 in closed form): the 16-byte form of
+    its two passes (a wave owns whole rows; column statistics + fused update) against the fp64 closed
+    form and against the 4-byte form, which operands that are not 16-byte aligned still take: channels
+    on both sides of every clamp (|mean| / std <= 8: the fp32 statistics' var = E[x^2] - mean^2 keeps
+    four digits), row counts that leave ragged tails, channel counts with partly filled quad slots."""
+    from speech2text_amd import zip_kernels as zk
+    g0 = torch.Generator().manual_seed(rows + C)
+    x = (torch.randn(rows, C, generator=g0) * torch.logspace(-0.7, 1.0, C) + torch.linspace(-1.5, 1.5, C)).to(dev)
+    g = torch.randn(rows, C, generator=g0).to(dev)
+    cfg = (-0.05, 0.6, 0.3, 4.0, 0.04)
+    out = zk.balancer_backward(x, g, *cfg, 1, swoosh_l=swoosh)
+    ref = _balancer_ref64(x, g, *cfg, swoosh)
+    scale = ref.abs().max().item()
+    upd = (out.double() - ref).abs().max().item()
+    size = (ref - (g.double() * ((torch.sigmoid(x.double() - 4.0) - 0.08) if swoosh else 1.0))).abs().max().item()
+    assert size > 1e-3 * scale                                               # the update is really there
+    assert upd <= 2e-3 * size + 2e-6 * scale, (upd, size, scale)
+    # the 4-byte form: the same values at an address that is not a multiple of 16
+    bx = torch.empty(rows * C + 1, device=dev)
+    bg = torch.empty(rows * C + 1, device=dev)
+    xm, gm = bx[1:].view(rows, C), bg[1:].view(rows, C)
+    xm.copy_(x)
+    gm.copy_(g)
+    assert xm.data_ptr() % 16 != 0
+    out4 = zk.balancer_backward(xm, gm, *cfg, 1, swoosh_l=swoosh)
+    assert (out4.double() - ref).abs().max().item() <= 2e-3 * size + 2e-6 * scale
+    assert (out - out4).abs().max().item() <= 2e-3 * size + 2e-6 * scale
+    # a row-strided slice of a wider tensor (the gate third of the nonlinear attention's projection)
+    wide = torch.randn(rows, 3 * C, generator=g0).to(dev)
+    wide[:, C:2 * C] = x
+    outs = zk.balancer_backward(wide[:, C:2 * C], g, *cfg, 1, swoosh_l=swoosh)
+    assert (outs.double() - ref).abs().max().item() <= 2e-3 * size + 2e-6 * scale
