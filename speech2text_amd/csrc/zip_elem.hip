@@ -346,6 +346,10 @@ __global__ __launch_bounds__(256) void norm_bypass_bwd_kernel(
 // ---------------------------------------------------------------- column statistics
 // x viewed as [rows][ld] with C used columns: sum[c] += x, sumsq[c] += x^2 (atomics once per
 // block).  Each thread owns column (threadIdx.x % cols_per_pass) and strides over rows.
+// (Round 6 tried the 16-byte form of this pass and of the update below -- a wave owns whole rows,
+// lane = column quads -- and measured it SLOWER in the step, 34.7 against 34.3 ms, two pairs on one
+// box: at 20-30 us these launches are their fixed parts -- the per-workgroup coefficient prologue,
+// the atomics' tail, the launch itself -- not their loads.  Removed again)
 __global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict__ x, long rows,
                                                         int C, long ld, float* __restrict__ sum,
                                                         float* __restrict__ sumsq) {
@@ -389,75 +393,11 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict_
   }
 }
 
-// The same sums with 16-byte accesses (C % 4 == 0, rows and base 16-byte aligned, C <= 1024): a WAVE
-// owns whole rows -- lane l reads the column quads l, l + 64, ... of its row (one or two 1 KB
-// wave-instructions per row instead of four to fifteen 256-byte ones) -- and strides over the rows
-// with two rows in flight per quad slot; the workgroup's four waves meet in LDS, one atomic pair per
-// column and workgroup.  NQ = ceil(C / 256) quad slots per lane.
-template <int NQ>
-__global__ __launch_bounds__(256) void col_stats4_kernel(const float* __restrict__ x, long rows, int C,
-                                                         long ld, float* __restrict__ sum,
-                                                         float* __restrict__ sumsq) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int CQ = C >> 2;
-  float4 s[NQ], q[NQ];
-#pragma unroll
-  for (int j = 0; j < NQ; ++j) s[j] = q[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-  const long step = (long)gridDim.x * 4;
-  long r = (long)blockIdx.x * 4 + wave;
-#define S2T_CS_ACC(V, J)                                                          \
-  s[J].x += V.x; s[J].y += V.y; s[J].z += V.z; s[J].w += V.w;                    \
-  q[J].x = fmaf(V.x, V.x, q[J].x); q[J].y = fmaf(V.y, V.y, q[J].y);              \
-  q[J].z = fmaf(V.z, V.z, q[J].z); q[J].w = fmaf(V.w, V.w, q[J].w);
-  for (; r + 3 * step < rows; r += 4 * step) {
-    float4 v[4][NQ];
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int j = 0; j < NQ; ++j) {
-        const int cq = lane + 64 * j;
-        v[u][j] = cq < CQ ? *reinterpret_cast<const float4*>(x + (r + u * step) * ld + 4 * cq)
-                          : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int j = 0; j < NQ; ++j) { S2T_CS_ACC(v[u][j], j) }
-  }
-  for (; r < rows; r += step) {
-#pragma unroll
-    for (int j = 0; j < NQ; ++j) {
-      const int cq = lane + 64 * j;
-      if (cq < CQ) {
-        const float4 v = *reinterpret_cast<const float4*>(x + r * ld + 4 * cq);
-        S2T_CS_ACC(v, j)
-      }
-    }
-  }
-#undef S2T_CS_ACC
-  __shared__ float4 sh[2][4][64 * NQ];
-#pragma unroll
-  for (int j = 0; j < NQ; ++j) {
-    sh[0][wave][lane + 64 * j] = s[j];
-    sh[1][wave][lane + 64 * j] = q[j];
-  }
-  __syncthreads();
-  // thread t: column t (+ 256 k) of the sums, then of the sums of squares
-  const float* f0 = reinterpret_cast<const float*>(&sh[0][0][0]);
-  const float* f1 = reinterpret_cast<const float*>(&sh[1][0][0]);
-  constexpr int LDW = 4 * 64 * NQ;                       // floats per wave's copy
-  for (int c = threadIdx.x; c < C; c += 256) {
-    atomicAdd(&sum[c], (f0[c] + f0[LDW + c]) + (f0[2 * LDW + c] + f0[3 * LDW + c]));
-    atomicAdd(&sumsq[c], (f1[c] + f1[LDW + c]) + (f1[2 * LDW + c] + f1[3 * LDW + c]));
-  }
-}
-
 // Balancer backward, second pass: out = g + |g| * (a'[c] + b'[c] x).  Every workgroup first turns
 // the column statistics (sum, sumsq over n rows, from col_stats_kernel) into the coefficients of
 // its own copy in LDS (balancer_coef's formulas; C <= 1024), so no coefficient kernel runs; block 0
 // also clears `stats_next`, the accumulator the NEXT call's statistics pass will add into (the two
 // accumulators alternate, so no fill launch is needed either).
-template <bool VEC>
 __global__ __launch_bounds__(256) void balancer_apply_fused_kernel(
     const float* __restrict__ x, long ldx, const float* __restrict__ g, long ldg,
     const float* __restrict__ stats, float* __restrict__ stats_next, float n, float min_mean,
@@ -465,7 +405,7 @@ __global__ __launch_bounds__(256) void balancer_apply_fused_kernel(
     float* __restrict__ out, long ldo, float act_off) {
   // act_off >= 0: g is the gradient w.r.t. swoosh(x) and is first taken through the activation
   // (g *= sigmoid(x - act_off) - 0.08): Swoosh backward and the Balancer update in one pass
-  __shared__ __attribute__((aligned(16))) float s_a[1024], s_b[1024];
+  __shared__ float s_a[1024], s_b[1024];
   const float inv_n = 1.f / n;
   for (int c = threadIdx.x; c < C; c += 256) {
     const float mean = stats[c] * inv_n, uvar = stats[1024 + c] * inv_n;
@@ -492,46 +432,10 @@ __global__ __launch_bounds__(256) void balancer_apply_fused_kernel(
   if (blockIdx.x == 0 && stats_next != nullptr)   // the whole accumulator: the previous user may have had more channels
     for (int c = threadIdx.x; c < 2 * 1024; c += 256) stats_next[c] = 0.f;
   __syncthreads();
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const long step = (long)gridDim.x * 4;
-  if (VEC) {
-    // 16-byte form: a wave owns whole rows, lane = column quads tx, tx + 64, ...; two rows in flight
-    const int CQ = C >> 2;
-    long r = (long)blockIdx.x * 4 + ty;
-    for (; r < rows; r += 2 * step) {
-      const bool two = r + step < rows;
-      for (int cq = tx; cq < CQ; cq += 64) {
-        const float4 a4 = *reinterpret_cast<const float4*>(&s_a[4 * cq]);
-        const float4 b4 = *reinterpret_cast<const float4*>(&s_b[4 * cq]);
-        float4 gv[2], xv[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const long rr = (u == 0 || two) ? r + u * step : r;
-          gv[u] = *reinterpret_cast<const float4*>(g + rr * ldg + 4 * cq);
-          xv[u] = *reinterpret_cast<const float4*>(x + rr * ldx + 4 * cq);
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          if (u == 1 && !two) break;
-          float4 gg = gv[u];
-          if (act_off >= 0.f) {
-            gg.x *= swoosh_d(xv[u].x, act_off);
-            gg.y *= swoosh_d(xv[u].y, act_off);
-            gg.z *= swoosh_d(xv[u].z, act_off);
-            gg.w *= swoosh_d(xv[u].w, act_off);
-          }
-          const float4 o = make_float4(gg.x + fabsf(gg.x) * fmaf(b4.x, xv[u].x, a4.x),
-                                       gg.y + fabsf(gg.y) * fmaf(b4.y, xv[u].y, a4.y),
-                                       gg.z + fabsf(gg.z) * fmaf(b4.z, xv[u].z, a4.z),
-                                       gg.w + fabsf(gg.w) * fmaf(b4.w, xv[u].w, a4.w));
-          *reinterpret_cast<float4*>(out + (r + u * step) * ldo + 4 * cq) = o;
-        }
-      }
-    }
-    return;
-  }
   // thread = (column within a 64-wide group, row lane): no per-element division, four rows of
   // loads in flight; a workgroup walks all column groups of its rows
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const long step = (long)gridDim.x * 4;
   for (int c0 = 0; c0 < C; c0 += 64) {
     const int c = c0 + tx;
     if (c >= C) continue;
@@ -710,46 +614,6 @@ extern "C" int s2t_biasnorm_bwd_tb(const float* x, const float* bias, const floa
   return biasnorm_bwd_launch(x, bias, scales, g, (long)T * B, D, dx, dbias, dls, T, B, (hipStream_t)stream);
 }
 
-// the two passes of the Balancer update, 16-byte form where the layout allows (S2T_BAL_VEC=0: the
-// 4-byte form everywhere, A/B)
-static bool bal_vec(const float* x, long ldx, const float* g, long ldg, const float* out, long ldo, int C) {
-  static const bool on = [] { const char* e = getenv("S2T_BAL_VEC"); return !e || atoi(e) != 0; }();
-  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-  return on && (C & 3) == 0 && (ldx & 3) == 0 && al(x) && (!g || ((ldg & 3) == 0 && al(g))) &&
-         (!out || ((ldo & 3) == 0 && al(out)));
-}
-static void launch_col_stats(const float* x, long ldx, long rows, int C, float* sum, float* sumsq,
-                             hipStream_t st) {
-  if (bal_vec(x, ldx, nullptr, 0, nullptr, 0, C)) {
-    long gx = (rows + 4 * 8 - 1) / (4 * 8);               // >= 8 rows per wave
-    gx = gx > 1024 ? 1024 : (gx < 1 ? 1 : gx);
-    const int nq = (C + 255) / 256;
-    if (nq <= 1) hipLaunchKernelGGL(col_stats4_kernel<1>, dim3((unsigned)gx), dim3(256), 0, st, x, rows, C, ldx, sum, sumsq);
-    else if (nq == 2) hipLaunchKernelGGL(col_stats4_kernel<2>, dim3((unsigned)gx), dim3(256), 0, st, x, rows, C, ldx, sum, sumsq);
-    else hipLaunchKernelGGL(col_stats4_kernel<4>, dim3((unsigned)gx), dim3(256), 0, st, x, rows, C, ldx, sum, sumsq);
-    return;
-  }
-  int gy = (C + 63) / 64;
-  if (gy > 16) gy = 16;
-  long gx = (rows + 4 * 16 - 1) / (4 * 16);
-  gx = gx > 256 ? 256 : (gx < 1 ? 1 : gx);
-  hipLaunchKernelGGL(col_stats_kernel, dim3((unsigned)gx, gy), dim3(64, 4), 0, st, x, rows, C, ldx, sum, sumsq);
-}
-static void launch_bal_apply(const float* x, long ldx, const float* g, long ldg, const float* stats,
-                             float* stats_next, long rows, int C, float min_mean, float max_mean,
-                             float min_rms, float max_rms, float grad_scale, float* out, long ldo,
-                             float act_off, hipStream_t st) {
-  const dim3 grid((unsigned)std::min<long>((rows + 15) / 16, 2048));
-  if (bal_vec(x, ldx, g, ldg, out, ldo, C))
-    hipLaunchKernelGGL(balancer_apply_fused_kernel<true>, grid, dim3(256), 0, st, x, ldx, g, ldg, stats,
-                       stats_next, (float)rows, min_mean, max_mean, min_rms, max_rms, grad_scale, rows, C,
-                       out, ldo, act_off);
-  else
-    hipLaunchKernelGGL(balancer_apply_fused_kernel<false>, grid, dim3(256), 0, st, x, ldx, g, ldg, stats,
-                       stats_next, (float)rows, min_mean, max_mean, min_rms, max_rms, grad_scale, rows, C,
-                       out, ldo, act_off);
-}
-
 // workspace: two alternating (sum[C], sumsq[C]) accumulators of 2 * BAL_MAXC floats each
 constexpr int BAL_MAXC = 1024;
 extern "C" long s2t_balancer_bwd_workspace_floats(void) { return 4L * BAL_MAXC; }
@@ -763,10 +627,16 @@ extern "C" int s2t_balancer_bwd(const float* x, long ldx, const float* g, long l
   hipStream_t st = (hipStream_t)stream;
   float* cur = workspace + (parity & 1) * 2 * BAL_MAXC;
   float* nxt = workspace + ((parity + 1) & 1) * 2 * BAL_MAXC;
-  launch_col_stats(x, ldx, rows, C, cur, cur + BAL_MAXC, st);
+  int gy = (C + 63) / 64;
+  if (gy > 16) gy = 16;
+  long gx = (rows + 4 * 16 - 1) / (4 * 16);
+  gx = gx > 256 ? 256 : (gx < 1 ? 1 : gx);
+  hipLaunchKernelGGL(col_stats_kernel, dim3((unsigned)gx, gy), dim3(64, 4), 0, st, x, rows, C, ldx,
+                     cur, cur + BAL_MAXC);
   S2T_CHECK_LAUNCH();
-  launch_bal_apply(x, ldx, g, ldg, cur, nxt, rows, C, min_mean, max_mean, min_rms, max_rms, grad_scale, out,
-                   ldo, act_off, st);
+  hipLaunchKernelGGL(balancer_apply_fused_kernel, dim3((unsigned)std::min<long>((rows + 15) / 16, 2048)), dim3(256), 0, st,
+                     x, ldx, g, ldg, cur, nxt, (float)rows, min_mean, max_mean, min_rms, max_rms,
+                     grad_scale, rows, C, out, ldo, act_off);
   S2T_CHECK_LAUNCH();
   return 0;
 }
@@ -778,7 +648,12 @@ extern "C" int s2t_balancer_stats(const float* x, long ldx, long rows, int C, fl
                                   void* stream) {
   if (rows <= 0 || C <= 0) return 0;
   if (C > BAL_MAXC || !stats) return -1;
-  launch_col_stats(x, ldx, rows, C, stats, stats + BAL_MAXC, (hipStream_t)stream);
+  int gy = (C + 63) / 64;
+  if (gy > 16) gy = 16;
+  long gx = (rows + 4 * 16 - 1) / (4 * 16);
+  gx = gx > 256 ? 256 : (gx < 1 ? 1 : gx);
+  hipLaunchKernelGGL(col_stats_kernel, dim3((unsigned)gx, gy), dim3(64, 4), 0, (hipStream_t)stream, x,
+                     rows, C, ldx, stats, stats + BAL_MAXC);
   S2T_CHECK_LAUNCH();
   return 0;
 }
@@ -789,8 +664,10 @@ extern "C" int s2t_balancer_apply(const float* x, long ldx, const float* g, long
                                   const float* stats, float act_off, void* stream) {
   if (rows <= 0 || C <= 0) return 0;
   if (C > BAL_MAXC || !stats) return -1;
-  launch_bal_apply(x, ldx, g, ldg, stats, nullptr, rows, C, min_mean, max_mean, min_rms, max_rms, grad_scale,
-                   out, ldo, act_off, (hipStream_t)stream);
+  hipLaunchKernelGGL(balancer_apply_fused_kernel, dim3((unsigned)std::min<long>((rows + 15) / 16, 2048)),
+                     dim3(256), 0, (hipStream_t)stream, x, ldx, g, ldg, stats, (float*)nullptr,
+                     (float)rows, min_mean, max_mean, min_rms, max_rms, grad_scale, rows, C, out, ldo,
+                     act_off);
   S2T_CHECK_LAUNCH();
   return 0;
 }

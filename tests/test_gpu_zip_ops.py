@@ -596,12 +596,13 @@ def _balancer_ref64(x, g, min_mean, max_mean, min_rms, max_rms, grad_scale, swoo
 @pytest.mark.parametrize("rows,C", [(31680, 192), (15872, 576), (7936, 960), (3968, 1024), (1000, 100), (37, 256),
                                     (5000, 260)])
 @pytest.mark.parametrize("swoosh", [None, True])
-def test_balancer_backward_16_byte_form(dev, rows, C, swoosh):
-    """s2t_balancer_bwd (reference model/layer/scaling.py:741-789 in closed form): the 16-byte form of
-    its two passes (a wave owns whole rows; column statistics + fused update) against the fp64 closed
-    form and against the 4-byte form, which operands that are not 16-byte aligned still take: channels
-    on both sides of every clamp (|mean| / std <= 8: the fp32 statistics' var = E[x^2] - mean^2 keeps
-    four digits), row counts that leave ragged tails, channel counts with partly filled quad slots."""
+def test_balancer_backward_vs_fp64_closed_form(dev, rows, C, swoosh):
+    """s2t_balancer_bwd (reference model/layer/scaling.py:741-789 in closed form; two passes: column
+    statistics, fused update) against the fp64 closed form: channels on both sides of every clamp
+    (|mean| / std <= 8: the fp32 statistics' var = E[x^2] - mean^2 keeps four digits), row counts that
+    leave ragged tails, channel counts that are no multiple of 64, operands at addresses that are no
+    multiple of 16 bytes, a row-strided slice of a wider tensor, with and without the Swoosh derivative
+    in front."""
     from speech2text_amd import zip_kernels as zk
     g0 = torch.Generator().manual_seed(rows + C)
     x = (torch.randn(rows, C, generator=g0) * torch.logspace(-0.7, 1.0, C) + torch.linspace(-1.5, 1.5, C)).to(dev)
@@ -614,7 +615,7 @@ def test_balancer_backward_16_byte_form(dev, rows, C, swoosh):
     size = (ref - (g.double() * ((torch.sigmoid(x.double() - 4.0) - 0.08) if swoosh else 1.0))).abs().max().item()
     assert size > 1e-3 * scale                                               # the update is really there
     assert upd <= 2e-3 * size + 2e-6 * scale, (upd, size, scale)
-    # the 4-byte form: the same values at an address that is not a multiple of 16
+    # the same values at an address that is not a multiple of 16
     bx = torch.empty(rows * C + 1, device=dev)
     bg = torch.empty(rows * C + 1, device=dev)
     xm, gm = bx[1:].view(rows, C), bg[1:].view(rows, C)
