@@ -696,9 +696,8 @@ int s2t_predictor_ctx_bwd(const int* tokens, const float* emb, const float* w, c
  *   16-byte aligned (else -2).  tile = 0 (from the shape) | 11 | 12 | 21 | 22: block tile
  *   (64 tm) x (64 tn); + 100 w: w persistent workgroups per CU; + 1000: a tile's output is
  *   stored in slices under the next tile's multiplications (persistent grids, three pieces only);
- *   2000 + tm tn: the form that moves the weight pieces global -> LDS directly, + 200 / + 300 (two-piece
- *   arithmetic only): 32-deep barrier intervals / those multiplied by v_mfma_f32_16x16x32_bf16.  -2: a
- *   tile code the current arithmetic has not. */
+ *   2000 + tm tn: the form that moves the weight pieces global -> LDS directly, + 200 (two-piece
+ *   arithmetic only): 32-deep barrier intervals.  -2: a tile code the current arithmetic has not. */
 /* ---- the arithmetic of every bf16 matrix-core GEMM of the library (s2t_gemm_x3p*, the weight-gradient /
  * NT / NN / batched kernels of csrc/gemm.hip): pieces per fp32 operand.
  *   3 ("bf16x3/6"): x = p0 + p1 + p2 exactly, six piece products per term: fp32-level error

@@ -1464,9 +1464,9 @@ _BASE = {}           # shape bucket -> (library ms, best own ms | None, its tile
 # 4 workgroups per CU (S2T_X3P_DMA=1 adds them: same-box A/B at C3 38.6 ms/step with and without)
 _X3P_TILES = (222, 321, 312, 411) + ((2022, 2021, 2012) if os.environ.get("S2T_X3P_DMA", "0") == "1" else ())
 # two-piece arithmetic (S2T_GEMM_ARITH=2): the same tiles of the register-staged form, the LDS-DMA form
-# at 16-deep stages (2000 +), at 32-deep barrier intervals (2200 +) and those on 16x16x32 products (2300 +)
+# at 16-deep stages (2000 +) and at 32-deep barrier intervals (2200 +)
 _X3P_TILES2 = tuple(int(t) for t in os.environ.get(
-    "S2T_X3P_TILES2", "222,321,312,411,2022,2021,2012,2222,2221,2212,2211,2322,2321,2312,2311").split(","))
+    "S2T_X3P_TILES2", "222,321,312,411,2022,2021,2012,2222,2221,2212,2211").split(","))
 PLAN_STATS = {"timed": 0}
 
 

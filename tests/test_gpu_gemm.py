@@ -38,12 +38,11 @@ def arith(request):
 
 def _x3p_tiles(drip=True):
     """Tile codes of s2t_gemm_x3p the current arithmetic serves: block tiles, workgroups per CU, the
-    sliced epilogue (three pieces only), the LDS-DMA form, its 32-deep intervals and their 16x16x32 products
-    (two pieces only)."""
+    sliced epilogue (three pieces only), the LDS-DMA form and its 32-deep intervals (two pieces only)."""
     base = [0, 22, 21, 12, 11, 2022, 2021, 2012, 2011]
     if ARITH[0] == 3:
         return base + ([1111, 1112, 1121, 1122, 1211] if drip else [])
-    return base + [322, 2222, 2221, 2212, 2211, 2322, 2321, 2312, 2311]
+    return base + [322, 2222, 2221, 2212, 2211]
 
 
 def _gemm(mode, A, B, C, M, Nn, K, bias=None, resid=None, act_src=None, act_kind=0, pro_a=0, pro_b=0,

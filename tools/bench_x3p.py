@@ -28,7 +28,7 @@ FWD = [(31680, 272, 192), (31680, 432, 192), (31680, 192, 144), (31680, 48, 192)
 ARITH = zk.gemm_arith()
 CFGS = [int(c) for c in os.environ.get(
     "X3P_CFGS", "0,222,321,312,411,2022,2021,2012,2011" if ARITH == 3 else
-    "0,222,321,312,411,322,2022,2021,2012,2011,2222,2221,2212,2211,2322,2321,2312,2311").split(",")]
+    "0,222,321,312,411,322,2022,2021,2012,2011,2222,2221,2212,2211").split(",")]
 
 
 def main():
