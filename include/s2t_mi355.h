@@ -234,6 +234,18 @@ int s2t_linear_wgrad(const float* g, long ldg, const float* a, long lda, int R, 
  * with a plain GEMM; s2t_whiten_apply writes out = g + pg * grad_scale * |g| / (|pg| + 1e-20). */
 int s2t_whiten_metric(float* xtx, float* colsum, long n, int G, int cg, float* cov, float* mean,
                       float* scal, float* host_metric, float* workspace, void* stream);
+/* The fused form of the backward (round 6): s2t_whiten_prep = s2t_whiten_dcov's dcov / bias AND
+ * sums[1] = ||x dcov + bias||_F^2 in closed form, tr(dcov cov dcov) (sums[0] = 0) -- everything that
+ * depends on x only, so it runs in FORWARD on the statistics' stream, followed there by s2t_x3p_split of
+ * dcov into a per-site piece buffer.  Backward is then s2t_sumsq (sums[0] += ||g||^2) and ONE product,
+ * s2t_gemm_x3p_whiten: out = g + (x dcov + bias) * grad_scale ||g|| / (||pg|| + 1e-20), the norms read
+ * from the device.  -2: shapes outside the kernels' rules (the caller keeps the three-launch form). */
+int s2t_whiten_prep(const float* cov, const float* mean, const float* scal, int G, int cg, float* dcov,
+                    float* bias, float* sums, void* stream);
+int s2t_sumsq(const float* a, long numel, float* sum, void* stream);
+int s2t_gemm_x3p_whiten(const float* A, long lda, const unsigned short* Bp, int C, float* out, long ldc,
+                        int M, const float* bias, const float* g, long ldg, const float* sums,
+                        float grad_scale, int tile, void* stream);
 int s2t_whiten_dcov(const float* cov, const float* mean, const float* scal, int G, int cg,
                     float* dcov, float* bias, float* sums, void* stream);
 int s2t_whiten_apply(const float* g, const float* pg, long numel, float grad_scale, float* sums,
@@ -921,7 +933,7 @@ typedef struct S2tZipLayerCall {
   long lt_ws_bytes;
   int x3p_on, x3p_tile;
   float x3p_margin;
-  int whiten_x3p;
+  int whiten_x3p;                  /* Whiten backward: 2 fused (forward-side prep + one product), 1 split on the spot, 0 NN kernel */
   long whiten_x3p_rows;
   int conv_w_side, conv_fused, stats_side, wgrad_side, bmm_own;
   int bal_epi;                     /* hidden Balancers in the dgrad epilogue (s2t_gemm_x3p_bal) */

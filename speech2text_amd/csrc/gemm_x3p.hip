@@ -157,6 +157,11 @@ struct X3P {
   // sums / sums of squares of S over bal_n rows, or NULL
   const float* bal_stats;
   float bal_n, bal_min_mean, bal_max_mean, bal_min_rms, bal_max_rms, bal_gs;
+  // Whiten update in the epilogue (s2t_gemm_x3p_whiten): the product (+ bias) is the penalty gradient
+  // pg; it leaves scaled by alpha_gs ||g|| / (||pg|| + 1e-20) with alpha_sums = (||g||^2, ||pg||^2) read
+  // from DEVICE memory (scaling.py:1024-1027), before the residual operand (= g) is added; or NULL
+  const float* alpha_sums;
+  float alpha_gs;
   // implicit operands (s2t_gemm_x3p_map, the 3x3 convolutions of model/encoder/conformer.py:47-57):
   // row r of A / C is not at r * ld but at map(r) = base + b sb + i sh + j sw with r = (b, i, j) over a
   // (hw = rows per image, w = columns per image row) grid, and the K axis of A is nseg segments of seg16
@@ -308,6 +313,10 @@ __device__ __forceinline__ void x3p_epi_xform(const X3P& g, f32x16& a, float* sc
   for (int q = 0; q < 2; ++q) {
     f32x4 v = *reinterpret_cast<const f32x4*>(scr + (er + 8 * q) * 36 + ec);
     v += bq;
+    if (g.alpha_sums) {                                // (uniform)
+      const float al = g.alpha_gs * (sqrtf(g.alpha_sums[0]) / (sqrtf(g.alpha_sums[1]) + 1.0e-20f));
+      v *= al;
+    }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const f32x4 x = o.v[q][k];
@@ -1126,6 +1135,11 @@ struct BalArm {
   float n = 0.f, min_mean = 0.f, max_mean = 0.f, min_rms = 0.f, max_rms = 0.f, gs = 0.f;
 };
 static thread_local BalArm g_bal;        // armed by s2t_gemm_x3p_bal for the one launch it makes
+struct AlphaArm {
+  const float* sums = nullptr;
+  float gs = 0.f;
+};
+static thread_local AlphaArm g_alpha;    // armed by s2t_gemm_x3p_whiten for the one launch it makes
 
 // ---- sampled kernel-attached timing of this entry point, kept HERE so that launches issued by the
 // native layer executor (csrc/zip_layer.hip) and by the Python call sites are sampled alike: while a
@@ -1177,8 +1191,8 @@ int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int 
   if (act_src && resid && resid_b) return -2;        // two operand slots
   X3P g{A, lda, Bp, (N + 31) / 32, 2 * ((K + 31) / 32), C, ldc, M, N, K, bias, {nullptr, nullptr},
         {0, 0}, {0, 0}, act_kind, C2, ldc2, act2, 0, 0, wgs, 0, g_stamps, drip, 0,
-        nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, X3PMap{0, 1, 1, 0, 0, 0, 0}, X3PMap{0, 1, 1, 0, 0, 0, 0}, 1, 1,
-        {0, 0, 0, 0}, 0};
+        nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, g_alpha.sums, g_alpha.gs, X3PMap{0, 1, 1, 0, 0, 0, 0},
+        X3PMap{0, 1, 1, 0, 0, 0, 0}, 1, 1, {0, 0, 0, 0}, 0};
   if (g_bal.stats) {
     if (!act_src || N > 1024 || tile == 33 || drip) return -2;
     g.bal_stats = g_bal.stats;
@@ -1342,7 +1356,7 @@ int s2t_gemm_x3p_map(const float* A, const S2tRowMap* amap, int seg, int nseg, c
   const int K = seg * nseg;
   X3P g{A, 0, Bp, (N + 31) / 32, 2 * ((K + 31) / 32), C, ldc, M, N, K, bias, {nullptr, nullptr},
         {0, 0}, {0, 0}, 0, nullptr, 0, 0, 0, 0, 0, 0, nullptr, 0, 0,
-        nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
+        nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, nullptr, 0.f,
         X3PMap{1, amap->hw, amap->w, amap->sb, amap->sh, amap->sw, amap->base},
         cmap ? X3PMap{1, cmap->hw, cmap->w, cmap->sb, cmap->sh, cmap->sw, cmap->base} : X3PMap{0, 1, 1, 0, 0, 0, 0},
         seg / 16, nseg, {0, 0, 0, 0}, c_elems};
@@ -1390,6 +1404,22 @@ int s2t_gemm_x3p_bal(const float* A, long lda, const unsigned short* Bp, int N, 
   const int rc = s2t_gemm_x3p(A, lda, Bp, N, K, C, ldc, M, nullptr, resid, ldr, act_src, ld_act, act_kind, nullptr,
                               0, 0, nullptr, 0, tile, stream);
   g_bal.stats = nullptr;
+  return rc;
+}
+
+// Whiten's backward as ONE product (reference model/layer/scaling.py:994-1028 in closed form):
+//   out = g + (x dcov + bias) * grad_scale ||g|| / (||x dcov + bias|| + 1e-20)
+// A = x, Bp = the pieces of dcov (symmetric), resid = g, sums = DEVICE (||g||^2, ||pg||^2): the second
+// from s2t_whiten_prep (forward), the first from s2t_sumsq over g just before this launch.
+int s2t_gemm_x3p_whiten(const float* A, long lda, const unsigned short* Bp, int C, float* out, long ldc,
+                        int M, const float* bias, const float* g, long ldg, const float* sums,
+                        float grad_scale, int tile, void* stream) {
+  if (!sums || !g || !bias) return -1;
+  g_alpha.sums = sums;
+  g_alpha.gs = grad_scale;
+  const int rc = s2t_gemm_x3p(A, lda, Bp, C, C, out, ldc, M, bias, g, ldg, nullptr, 0, 0, nullptr, 0, 0, nullptr,
+                              0, tile, stream);
+  g_alpha.sums = nullptr;
   return rc;
 }
 

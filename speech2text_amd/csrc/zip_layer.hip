@@ -92,6 +92,9 @@ struct WStat {
   float *cov, *mean, *scal, *host;
   hipEvent_t ev;
   int G, cg;
+  // fused backward (whiten_x3p == 2): written in forward on the statistics' stream
+  float *dcov, *bias, *sums;
+  unsigned short* pieces;
 };
 struct FfS { float *h, *a, *y; WStat st; };
 struct SaS { float *v, *o, *y; WStat st; int dv; };
@@ -307,6 +310,19 @@ int whiten_stats(Ctx& c, WStat& s, const float* x, long ldx, long R, int C, int 
   s.cov = c.ar.alloc((long)groups * s.cg * s.cg);
   s.mean = c.ar.alloc(C);
   s.scal = c.ar.alloc(4);
+  // fused backward: d metric / d cov, its bias row, ||pg||^2 and dcov's bf16 pieces are taken NOW, on
+  // the statistics' stream (they depend on x only): backward's chain is a sum of squares over g and
+  // one product with the update in its epilogue
+  const S2tZlWhScratch* sc0 = wh_scratch(c, C);
+  const bool fused = c.c.whiten_x3p == 2 && c.c.x3p_on && C >= 16 && (C & 7) == 0 && s.cg <= 1024 &&
+                     R >= 4 && R * C * 4 < 0x7FFFFF00L && R * ldx * 4 < 0x7FFFFF00L && sc0 && sc0->tab;
+  s.pieces = nullptr;
+  if (fused) {
+    s.dcov = c.ar.alloc((long)C * C);
+    s.bias = c.ar.alloc(C);
+    s.sums = c.ar.alloc(2);
+    s.pieces = reinterpret_cast<unsigned short*>(c.ar.alloc((s2t_x3p_plane_elems(C, C) + 1) / 2));
+  }
   if (c.dry) return 0;
   const S2tZlWhScratch* sc = wh_scratch(c, C);
   if (!sc) return fail(-1, "whiten_stats: no scratch for this channel count");
@@ -324,6 +340,12 @@ int whiten_stats(Ctx& c, WStat& s, const float* x, long ldx, long R, int C, int 
   float* colsum = sc->acc + (long)C * C;
   RUN(s2t_gemm_xtx(x, ldx, (int)R, C, s.cg, xtx, C, colsum, (void*)q));
   RUN(s2t_whiten_metric(xtx, colsum, R, groups, s.cg, s.cov, s.mean, s.scal, s.host, sc->ws, (void*)q));
+  if (s.pieces) {
+    RUN(s2t_whiten_prep(s.cov, s.mean, s.scal, s.G, s.cg, s.dcov, s.bias, s.sums, (void*)q));
+    RUN(s2t_x3p_split(s.dcov, sc->tab, 1, sc->blocks, s.pieces, (void*)q));
+  }
+  // (backward waits for this event on the host before it reads the metric: everything above is then
+  //  complete, whichever stream it ran on)
   HIPRUN(hipEventRecord(s.ev, q));
   return 0;
 }
@@ -340,6 +362,20 @@ int whiten_bwd(Ctx& c, int site, const S2tZlWh& w, WStat& s, const float* x, lon
   c.s.wh_active[site] = active ? 1 : 0;
   *out = g;
   if (!active) return 0;
+  if (s.pieces && (reinterpret_cast<uintptr_t>(g) & 15) == 0) {
+    // (the prep launches were issued on the side stream in forward: the main stream joined it at the
+    //  end of that pass, long before this call)
+    float* o = c.ar.alloc(R * C);
+    if (c.dry) return 0;
+    static const int pg_cls = [] { const char* e = getenv("S2T_WHITEN_PG_CLS"); return e ? atoi(e) : 3; }();
+    const S2tGemmClass cls(pg_cls);
+    RUN(s2t_sumsq(g, R * C, s.sums, (void*)c.st));
+    const int rc = s2t_gemm_x3p_whiten(x, ldx, s.pieces, C, o, C, (int)R, s.bias, g, C, s.sums, w.grad_scale,
+                                       c.c.x3p_tile, (void*)c.st);
+    if (rc != 0) return fail(rc, "s2t_gemm_x3p_whiten");     // (the shape rules were checked in forward)
+    *out = o;
+    return 0;
+  }
   float* dcov = c.ar.alloc((long)C * C);
   float* bias = c.ar.alloc(C);
   float* sums = c.ar.alloc(2);
@@ -353,7 +389,7 @@ int whiten_bwd(Ctx& c, int site, const S2tZlWh& w, WStat& s, const float* x, lon
   const S2tGemmClass cls(pg_cls);
   bool done = false;
   const S2tZlWhScratch* sc = wh_scratch(c, C);
-  if (c.c.whiten_x3p && c.c.x3p_on && R >= c.c.whiten_x3p_rows && sc && sc->buf && C >= 16 && (C & 7) == 0) {
+  if (c.c.whiten_x3p == 1 && c.c.x3p_on && R >= c.c.whiten_x3p_rows && sc && sc->buf && C >= 16 && (C & 7) == 0) {
     RUN(s2t_x3p_split(dcov, sc->tab, 1, sc->blocks, sc->buf, (void*)c.st));
     const int rc = s2t_gemm_x3p(x, ldx, sc->buf, C, C, pg, C, (int)R, bias, nullptr, 0, nullptr, 0, 0, nullptr,
                                 0, 0, nullptr, 0, c.c.x3p_tile, (void*)c.st);

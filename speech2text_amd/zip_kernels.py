@@ -375,11 +375,31 @@ class WhitenStats:
                                           ctypes.c_void_p(self.host.data_ptr()), N.fp(ws),
                                           side if side is not None else N.stream()),
                 "s2t_whiten_metric")
+        # The fused backward (csrc/zip_layer.hip whiten_stats / whiten_bwd, include/s2t_mi355.h
+        # s2t_whiten_prep): d metric / d cov, its bias row, ||pg||^2 in closed form and dcov's bf16
+        # pieces depend on x only -- taken now, on the statistics' stream
+        self.pieces = None
+        ent = planes.adhoc_entry(C, C, 1, dev) if (_WHITEN_X3P == 2 and X3P["on"] and _tn_ok(xf) and C % 8 == 0
+                                                    and cg <= 1024 and n >= 4
+                                                    and n * max(C, xf.stride(0)) * 4 < 0x7FFFFF00) else None
+        if ent is not None:
+            q = side if side is not None else N.stream()
+            self.dcov = torch.empty((C, C), dtype=torch.float32, device=dev)
+            self.bias = torch.empty((C,), dtype=torch.float32, device=dev)
+            self.sums = torch.empty((2,), dtype=torch.float32, device=dev)
+            self.pieces = torch.empty_like(ent[1])
+            N.PROF[0] and N.profile_note("s2t_whiten_prep", 4.0 * (C * cg * cg + C * C))
+            N.check(N.lib().s2t_whiten_prep(N.fp(self.cov), N.fp(self.mean), N.fp(self.scal), G, cg,
+                                            N.fp(self.dcov), N.fp(self.bias), N.fp(self.sums), q), "s2t_whiten_prep")
+            N.PROF[0] and N.profile_note("s2t_x3p_split", 4.0 * C * C + 2.0 * self.pieces.numel())
+            N.check(N.lib().s2t_x3p_split(self.dcov.data_ptr(), ent[0].data_ptr(), 1, ent[2],
+                                          self.pieces.data_ptr(), q), "s2t_x3p_split")
         if side is not None:
             # the side stream may still be reading x / writing the statistics when this object (or
             # a float() temporary of x) dies -- e.g. a forward under train() with no backward: the
             # caching allocator must not hand the memory to main-stream work before the join
-            _Side.keep.append((xf, self.cov, self.mean, self.scal))
+            _Side.keep.append((xf, self.cov, self.mean, self.scal) +
+                              ((self.dcov, self.bias, self.sums, self.pieces) if self.pieces is not None else ()))
         self.event = torch.cuda.Event()
         if side is not None:
             self.event.record(N._launch_stream((side,)))
@@ -394,7 +414,10 @@ class WhitenStats:
 
 # (round 5: off -- the NN kernel that takes the two norms in its epilogue (below) beats the bf16x3
 # product + a separate norm pass also for the 31 680-row activations: 37.61 against 37.72 ms/step)
-_WHITEN_X3P = os.environ.get("S2T_WHITEN_X3P", "0") == "1"
+# (round 6: 2 = the fused form -- dcov, its pieces and ||pg||^2 taken in forward on the statistics' stream,
+# backward = a sum of squares over g + ONE product with the update in its epilogue; 1 = the round-5
+# on-the-spot split + plain product; 0 = the NN kernel with the norms in its epilogue)
+_WHITEN_X3P = int(os.environ.get("S2T_WHITEN_X3P", "2"))
 # the norms of (g, x dcov) taken in the product's epilogue (s2t_gemm_f32_sq) instead of by a pass over both
 _WHITEN_SQ = os.environ.get("S2T_WHITEN_SQ", "1") == "1"
 # measured (tools/bench_side.py whiten): 73 against 94 us at 31 680 x 192, but 62 against 58 at
@@ -416,6 +439,22 @@ def whiten_backward(x, g, stats, limit, grad_scale):
     C = shp[-1]
     G, cg = stats.num_groups, stats.cg
     dev = x.device
+    if getattr(stats, "pieces", None) is not None:
+        xf = x.reshape(-1, C)
+        g2 = g.contiguous().float()
+        if xf.dtype is torch.float32 and xf.stride(1) == 1 and g2.data_ptr() % 16 == 0:
+            out = torch.empty_like(g2)
+            N.PROF[0] and N.profile_note("s2t_sumsq", 4.0 * g2.numel())
+            N.check(N.lib().s2t_sumsq(N.fp(g2), g2.numel(), N.fp(stats.sums), N.stream()), "s2t_sumsq")
+            N.PROF[0] and N.profile_note("s2t_gemm_x3p_whiten", 4.0 * (xf.numel() + 2 * g2.numel()) + 6.0 * C * C,
+                                         2.0 * xf.shape[0] * C * C)
+            with gemm_class(_WHITEN_PG_CLS):
+                rc = N.lib().s2t_gemm_x3p_whiten(N.raw(xf, torch.float32), xf.stride(0),
+                                                 ctypes.c_void_p(stats.pieces.data_ptr()), C, N.fp(out), C,
+                                                 xf.shape[0], N.fp(stats.bias), N.fp(g2), C, N.fp(stats.sums),
+                                                 float(grad_scale), X3P["tile"], N.stream())
+            N.check(rc, "s2t_gemm_x3p_whiten")
+            return out.view(shp), True
     dcov = torch.empty((C, C), dtype=torch.float32, device=dev)
     bias = torch.empty((C,), dtype=torch.float32, device=dev)
     sums = torch.empty((2,), dtype=torch.float32, device=dev)
@@ -429,7 +468,7 @@ def whiten_backward(x, g, stats, limit, grad_scale):
     # pg = x dcov + bias: for long activations on our bf16x3 kernel, with dcov's pieces written on the
     # spot; the library's fp32 kernels otherwise
     pg = None
-    if _WHITEN_X3P and X3P["on"] and xf.stride(1) == 1 and xf.shape[0] >= _WHITEN_X3P_ROWS:
+    if _WHITEN_X3P == 1 and X3P["on"] and xf.stride(1) == 1 and xf.shape[0] >= _WHITEN_X3P_ROWS:
         pp = planes.adhoc_pieces(dcov, 1)
         if pp is not None:
             pg = x3p_matmul(1, xf, dcov, bias, pp=pp, cls=_WHITEN_PG_CLS)

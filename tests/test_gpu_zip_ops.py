@@ -505,16 +505,21 @@ def test_downsample_and_upsampled_bypass_vs_torch(dev, T, B, C, ds):
 
 @pytest.mark.parametrize("R,C,G", [(700, 192, 1), (1000, 128, 4), (333, 96, 2), (2000, 512, 1),
                                    (500, 256, 8), (260, 64, 1)])
-@pytest.mark.parametrize("sq", [True, False])
-def test_whiten_backward_vs_oracle(dev, monkeypatch, R, C, G, sq):
+@pytest.mark.parametrize("form", ["fused", "sq", "pass"])
+def test_whiten_backward_vs_oracle(dev, monkeypatch, R, C, G, form):
     """Whiten (scaling.py:949-1095): x^T x comes from the symmetric TN GEMM (only the 64x64 tiles on /
     above the diagonal with same-group pairs; cg = 48 straddles tiles), the metric kernel mirrors
-    them; the backward term against the oracle's autograd-in-backward statement.  sq: the norms of
-    (g, x dcov) from the product's epilogue (s2t_gemm_f32_sq) or from the pass over both tensors."""
+    them; the backward term against the oracle's autograd-in-backward statement.  form: "fused" = dcov,
+    its bf16 pieces and ||pg||^2 = tr(dcov cov dcov) taken in forward, backward = a sum of squares over g
+    + one product with the update in its epilogue (s2t_whiten_prep / s2t_gemm_x3p_whiten: the default);
+    "sq" = the norms of (g, x dcov) from the NN product's epilogue (s2t_gemm_f32_sq); "pass" = from a
+    pass over both tensors."""
     import random
     from speech2text_amd import zip_kernels as zkm
     from speech2text_amd.model.layer.scaling import Whiten
-    monkeypatch.setattr(zkm, "_WHITEN_SQ", sq)
+    monkeypatch.setattr(zkm, "_WHITEN_X3P", 2 if form == "fused" else 0)
+    monkeypatch.setattr(zkm, "_WHITEN_SQ", form == "sq")
+    fused0 = int(N_lib().s2t_gemm_x3p_calls())
     torch.manual_seed(R + C)
     x = torch.randn(R, C) @ (torch.eye(C) + 0.3 * torch.randn(C, C))      # correlated channels
     x = x + 0.5 * torch.randn(C)
@@ -533,6 +538,8 @@ def test_whiten_backward_vs_oracle(dev, monkeypatch, R, C, G, sq):
         r = (xc.grad - w).numpy()
         assert np.abs(r).max() > 0, "metric below the limit: the test would be vacuous"
         np.testing.assert_allclose(d, r, atol=2e-3 * np.abs(r).max(), rtol=2e-3)
+    # the fused form really ran (C % 8 == 0 everywhere here): one s2t_gemm_x3p launch per backward
+    assert int(N_lib().s2t_gemm_x3p_calls()) - fused0 == (2 if form == "fused" else 0)
 
 
 def test_whiten_backward_rank_one_input_stays_finite(dev, monkeypatch):
@@ -572,6 +579,11 @@ def test_attn_apply_both_ways(dev, T, B, H, dv):
         ref = torch.matmul(Wd, v.double().reshape(T, B, H, dv).permute(2, 1, 0, 3))
         ref = ref.permute(2, 1, 0, 3).reshape(T, B, H * dv)
         np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), atol=2e-5, rtol=1e-4)
+
+
+def N_lib():
+    from speech2text_amd import _native
+    return _native.lib()
 
 
 def _balancer_ref64(x, g, min_mean, max_mean, min_rms, max_rms, grad_scale, swoosh):
