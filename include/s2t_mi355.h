@@ -234,18 +234,19 @@ int s2t_linear_wgrad(const float* g, long ldg, const float* a, long lda, int R, 
  * with a plain GEMM; s2t_whiten_apply writes out = g + pg * grad_scale * |g| / (|pg| + 1e-20). */
 int s2t_whiten_metric(float* xtx, float* colsum, long n, int G, int cg, float* cov, float* mean,
                       float* scal, float* host_metric, float* workspace, void* stream);
-/* The fused form of the backward (round 6): s2t_whiten_prep = s2t_whiten_dcov's dcov / bias AND
- * sums[1] = ||x dcov + bias||_F^2 in closed form, tr(dcov cov dcov) (sums[0] = 0) -- everything that
- * depends on x only, so it runs in FORWARD on the statistics' stream, followed there by s2t_x3p_split of
- * dcov into a per-site piece buffer.  Backward is then s2t_sumsq (sums[0] += ||g||^2) and ONE product,
- * s2t_gemm_x3p_whiten: out = g + (x dcov + bias) * grad_scale ||g|| / (||pg|| + 1e-20), the norms read
- * from the device.  -2: shapes outside the kernels' rules (the caller keeps the three-launch form). */
+/* The round-6 form of the backward: s2t_whiten_prep = s2t_whiten_dcov's dcov / bias, and sums64 = the
+ * [2][64] partial-sum slots of the two norms zeroed -- everything that depends on x only, so it runs in
+ * FORWARD on the statistics' stream, followed there by s2t_x3p_split of dcov into a per-site piece
+ * buffer.  Backward is then s2t_gemm_x3p_sq (pg = x dcov + bias from dcov's pieces, with ||g||^2 and
+ * ||pg||^2 taken in its epilogue: the norms are those of the pg actually computed, as the reference
+ * takes them) and s2t_whiten_combine64 (out = g + pg * grad_scale ||g|| / (||pg|| + 1e-20)). */
 int s2t_whiten_prep(const float* cov, const float* mean, const float* scal, int G, int cg, float* dcov,
-                    float* bias, float* sums, void* stream);
-int s2t_sumsq(const float* a, long numel, float* sum, void* stream);
-int s2t_gemm_x3p_whiten(const float* A, long lda, const unsigned short* Bp, int C, float* out, long ldc,
-                        int M, const float* bias, const float* g, long ldg, const float* sums,
-                        float grad_scale, int tile, void* stream);
+                    float* bias, float* sums64, void* stream);
+int s2t_gemm_x3p_sq(const float* A, long lda, const unsigned short* Bp, int N, int K, float* C, long ldc,
+                    int M, const float* bias, const float* other, long ld_other, float* sums, int tile,
+                    void* stream);
+int s2t_whiten_combine64(const float* g, const float* pg, long numel, float grad_scale,
+                         const float* sums64, float* out, void* stream);
 int s2t_whiten_dcov(const float* cov, const float* mean, const float* scal, int G, int cg,
                     float* dcov, float* bias, float* sums, void* stream);
 int s2t_whiten_apply(const float* g, const float* pg, long numel, float grad_scale, float* sums,

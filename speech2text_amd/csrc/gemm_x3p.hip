@@ -157,11 +157,12 @@ struct X3P {
   // sums / sums of squares of S over bal_n rows, or NULL
   const float* bal_stats;
   float bal_n, bal_min_mean, bal_max_mean, bal_min_rms, bal_max_rms, bal_gs;
-  // Whiten update in the epilogue (s2t_gemm_x3p_whiten): the product (+ bias) is the penalty gradient
-  // pg; it leaves scaled by alpha_gs ||g|| / (||pg|| + 1e-20) with alpha_sums = (||g||^2, ||pg||^2) read
-  // from DEVICE memory (scaling.py:1024-1027), before the residual operand (= g) is added; or NULL
-  const float* alpha_sums;
-  float alpha_gs;
+  // sums of squares taken while C leaves (s2t_gemm_x3p_sq: Whiten's backward needs ||g||^2 and ||pg||^2
+  // before it can combine them, scaling.py:1024-1027): sq_sums = DEVICE [2][64] partial sums -- slot
+  // (workgroup, wave) & 63 of row 0 gets the squares of the role-4 operand (read for this purpose only,
+  // not added), of row 1 those of C as stored; or NULL
+  float* sq_sums;
+  float sq_pad_;
   // implicit operands (s2t_gemm_x3p_map, the 3x3 convolutions of model/encoder/conformer.py:47-57):
   // row r of A / C is not at r * ld but at map(r) = base + b sb + i sh + j sw with r = (b, i, j) over a
   // (hw = rows per image, w = columns per image row) grid, and the K axis of A is nseg segments of seg16
@@ -313,10 +314,6 @@ __device__ __forceinline__ void x3p_epi_xform(const X3P& g, f32x16& a, float* sc
   for (int q = 0; q < 2; ++q) {
     f32x4 v = *reinterpret_cast<const f32x4*>(scr + (er + 8 * q) * 36 + ec);
     v += bq;
-    if (g.alpha_sums) {                                // (uniform)
-      const float al = g.alpha_gs * (sqrtf(g.alpha_sums[0]) / (sqrtf(g.alpha_sums[1]) + 1.0e-20f));
-      v *= al;
-    }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const f32x4 x = o.v[q][k];
@@ -345,10 +342,13 @@ __device__ __forceinline__ void x3p_epi_xform(const X3P& g, f32x16& a, float* sc
 }
 
 // phase 2 of one slice: the two row pieces leave (out-of-matrix lanes: dropped by the buffer check)
+struct EpiSq {                // this lane's running sums of squares (s2t_gemm_x3p_sq): operand, C
+  float o = 0.f, c = 0.f;
+};
 template <bool CMAP = false>
 __device__ __forceinline__ void x3p_epi_store(const X3P& g, const EpiRs& rs, const f32x16& a,
                                               const EpiOps& o, int i, int j, int h, int m0, int n0,
-                                              int wrb, int wcb, int lane) {
+                                              int wrb, int wcb, int lane, EpiSq& sq) {
   const int er = lane >> 3, ec = (lane & 7) * 4;
   const int col = n0 + 32 * (wcb + j) + ec;
 #pragma unroll
@@ -361,6 +361,11 @@ __device__ __forceinline__ void x3p_epi_store(const X3P& g, const EpiRs& rs, con
       continue;
     }
     x3p_bstore(rs.c, ok ? (unsigned)(row * (int)g.ldc + col) * 4u : kOob, v);
+    if (g.sq_sums && ok) {                           // (operands of lanes outside the matrix were read as 0)
+      sq.c += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      const f32x4 t = g.role[0] == 4 ? o.v[q][0] : o.v[q][1];
+      sq.o += (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w);
+    }
     if (g.act2 == 3) {                               // C2 = C + the role-3 operand (still in its slot)
       const f32x4 u = v + (g.role[0] == 3 ? o.v[q][0] : o.v[q][1]);
       x3p_bstore(rs.c2, ok ? (unsigned)(row * (int)g.ldc2 + col) * 4u : kOob, u);
@@ -384,6 +389,18 @@ __device__ __forceinline__ void x3p_epilogue(const X3P& g, f32x16 (&acc)[TM][TN]
   float* scr = reinterpret_cast<float*>(smem) + wave * (16 * 36);
   EpiRs rs = x3p_epi_rsrc(g);
   if (CMAP) rs.c = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (int)(g.c_elems * 4), 0x00020000);
+  EpiSq sq;
+  // this tile's sums of squares: one atomic pair per wave into one of 64 slots (the same two words for
+  // every wave of the chip would serialise)
+  auto sq_commit = [&]() {
+    if (!g.sq_sums) return;                          // (uniform)
+    const float so = wave_sum(sq.o), sc = wave_sum(sq.c);
+    if (lane == 0) {
+      const int slot = (blockIdx.x * 4 + wave) & 63;
+      atomicAdd(g.sq_sums + slot, so);
+      atomicAdd(g.sq_sums + 64 + slot, sc);
+    }
+  };
   if (LEAN) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -396,9 +413,10 @@ __device__ __forceinline__ void x3p_epilogue(const X3P& g, f32x16 (&acc)[TM][TN]
           EpiOps o;
           x3p_epi_load(g, rs, o, i, j, h, m0, n0, wrb, wcb, lane);
           x3p_epi_xform<BAL>(g, acc[i][j], scr, o, bqj, h, lane, balj);
-          x3p_epi_store<CMAP>(g, rs, acc[i][j], o, i, j, h, m0, n0, wrb, wcb, lane);
+          x3p_epi_store<CMAP>(g, rs, acc[i][j], o, i, j, h, m0, n0, wrb, wcb, lane, sq);
         }
     }
+    sq_commit();
     return;
   }
   f32x4 bq[TN];
@@ -413,9 +431,10 @@ __device__ __forceinline__ void x3p_epilogue(const X3P& g, f32x16 (&acc)[TM][TN]
     for (int t = 0; t < 2 * TN; ++t) x3p_epi_xform(g, acc[i][t / 2], scr, ops[t], bq[t / 2], t & 1, lane);
 #pragma unroll
     for (int t = 0; t < 2 * TN; ++t)
-      x3p_epi_store(g, rs, acc[i][t / 2], ops[t], i, t / 2, t & 1, m0, n0, wrb, wcb, lane);
+      x3p_epi_store(g, rs, acc[i][t / 2], ops[t], i, t / 2, t & 1, m0, n0, wrb, wcb, lane, sq);
     __builtin_amdgcn_sched_barrier(0);               // (the next row block's loads stay behind these stores)
   }
+  sq_commit();
 }
 
 // (the first form of this kernel -- one LDS stage, two barriers per 32-deep chunk -- and the ablation /
@@ -637,7 +656,8 @@ void x3p_db_kernel(X3P g) {
     f32x16& a_ = pacc[DRIP ? (SL) / (2 * TN) : 0][DRIP ? ((SL) / 2) % TN : 0];               \
     x3p_epi_load(g, rs_, o_, (SL) / (2 * TN), ((SL) / 2) % TN, (SL) & 1, pm0, pn0, wrb, wcb, lane); \
     x3p_epi_xform(g, a_, scr_w, o_, x3p_epi_bias(g, ((SL) / 2) % TN, pn0, wcb, lane), (SL) & 1, lane); \
-    x3p_epi_store(g, rs_, a_, o_, (SL) / (2 * TN), ((SL) / 2) % TN, (SL) & 1, pm0, pn0, wrb, wcb, lane); \
+    EpiSq sq_;                               /* (the sliced form does not take sums: drip refuses sq_sums) */ \
+    x3p_epi_store(g, rs_, a_, o_, (SL) / (2 * TN), ((SL) / 2) % TN, (SL) & 1, pm0, pn0, wrb, wcb, lane, sq_); \
   }
   for (;;) {
     f32x16 acc[TM][TN];
@@ -1135,11 +1155,12 @@ struct BalArm {
   float n = 0.f, min_mean = 0.f, max_mean = 0.f, min_rms = 0.f, max_rms = 0.f, gs = 0.f;
 };
 static thread_local BalArm g_bal;        // armed by s2t_gemm_x3p_bal for the one launch it makes
-struct AlphaArm {
-  const float* sums = nullptr;
-  float gs = 0.f;
+struct SqArm {
+  float* sums = nullptr;
+  const float* other = nullptr;
+  long ld = 0;
 };
-static thread_local AlphaArm g_alpha;    // armed by s2t_gemm_x3p_whiten for the one launch it makes
+static thread_local SqArm g_sq;          // armed by s2t_gemm_x3p_sq for the one launch it makes
 
 // ---- sampled kernel-attached timing of this entry point, kept HERE so that launches issued by the
 // native layer executor (csrc/zip_layer.hip) and by the Python call sites are sampled alike: while a
@@ -1191,7 +1212,7 @@ int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int 
   if (act_src && resid && resid_b) return -2;        // two operand slots
   X3P g{A, lda, Bp, (N + 31) / 32, 2 * ((K + 31) / 32), C, ldc, M, N, K, bias, {nullptr, nullptr},
         {0, 0}, {0, 0}, act_kind, C2, ldc2, act2, 0, 0, wgs, 0, g_stamps, drip, 0,
-        nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, g_alpha.sums, g_alpha.gs, X3PMap{0, 1, 1, 0, 0, 0, 0},
+        nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, g_sq.sums, 0.f, X3PMap{0, 1, 1, 0, 0, 0, 0},
         X3PMap{0, 1, 1, 0, 0, 0, 0}, 1, 1, {0, 0, 0, 0}, 0};
   if (g_bal.stats) {
     if (!act_src || N > 1024 || tile == 33 || drip) return -2;
@@ -1208,6 +1229,10 @@ int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int 
     if (act_src) { g.op[k] = act_src; g.ldop[k] = ld_act; g.role[k++] = 1; }
     if (resid) { g.op[k] = resid; g.ldop[k] = ldr; g.role[k++] = 2; }
     if (resid_b) { g.op[k] = resid_b; g.ldop[k] = ldrb; g.role[k++] = 3; }
+    if (g_sq.sums) {                     // the companion matrix: read for its squares only (role 4)
+      if (k > 1 || drip || !g_sq.other) return -2;
+      g.op[k] = g_sq.other; g.ldop[k] = g_sq.ld; g.role[k++] = 4;
+    }
   }
   {
     static int stg = -1;       // S2T_X3P_STAGGER: start delay per workgroup slot, units of 64 cycles
@@ -1407,19 +1432,24 @@ int s2t_gemm_x3p_bal(const float* A, long lda, const unsigned short* Bp, int N, 
   return rc;
 }
 
-// Whiten's backward as ONE product (reference model/layer/scaling.py:994-1028 in closed form):
-//   out = g + (x dcov + bias) * grad_scale ||g|| / (||x dcov + bias|| + 1e-20)
-// A = x, Bp = the pieces of dcov (symmetric), resid = g, sums = DEVICE (||g||^2, ||pg||^2): the second
-// from s2t_whiten_prep (forward), the first from s2t_sumsq over g just before this launch.
-int s2t_gemm_x3p_whiten(const float* A, long lda, const unsigned short* Bp, int C, float* out, long ldc,
-                        int M, const float* bias, const float* g, long ldg, const float* sums,
-                        float grad_scale, int tile, void* stream) {
-  if (!sums || !g || !bias) return -1;
-  g_alpha.sums = sums;
-  g_alpha.gs = grad_scale;
-  const int rc = s2t_gemm_x3p(A, lda, Bp, C, C, out, ldc, M, bias, g, ldg, nullptr, 0, 0, nullptr, 0, 0, nullptr,
-                              0, tile, stream);
-  g_alpha.sums = nullptr;
+// s2t_gemm_x3p (+ bias) that ALSO adds, while C leaves the accumulators, the squares of C and of a
+// companion matrix `other` (M, N; rows ld_other apart; read for this purpose only) into sums =
+// DEVICE [2][64] partial sums (row 0: other, row 1: C; zeroed by the caller; the totals are the
+// sums over a row's 64 slots).  Whiten's backward (reference model/layer/scaling.py:994-1028): A = x,
+// Bp = pieces of dcov, C = pg = x dcov + bias, other = g; s2t_whiten_combine64 then forms
+// g + pg * grad_scale ||g|| / (||pg|| + 1e-20) from the two norms.
+int s2t_gemm_x3p_sq(const float* A, long lda, const unsigned short* Bp, int N, int K, float* C, long ldc,
+                    int M, const float* bias, const float* other, long ld_other, float* sums, int tile,
+                    void* stream) {
+  if (!sums || !other) return -1;
+  if ((reinterpret_cast<uintptr_t>(other) & 15) || (ld_other & 3) || (long)M * ld_other * 4 >= 0x7FFFFF00L)
+    return -2;
+  g_sq.sums = sums;
+  g_sq.other = other;
+  g_sq.ld = ld_other;
+  const int rc = s2t_gemm_x3p(A, lda, Bp, N, K, C, ldc, M, bias, nullptr, 0, nullptr, 0, 0, nullptr, 0, 0, nullptr,
+                              0, tile / 1000 == 1 ? tile % 1000 : tile, stream);      // (no sliced epilogue here)
+  g_sq.sums = nullptr;
   return rc;
 }
 

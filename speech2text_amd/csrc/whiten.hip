@@ -157,88 +157,6 @@ __global__ __launch_bounds__(256) void whiten_dcov_kernel(const float* __restric
   }
 }
 
-// whiten_dcov_kernel's outputs (dcov, bias) AND the squared Frobenius norm of the penalty gradient they
-// stand for, without forming it: pg = x dcov + 1 bias^T = (x - mean) dcov, so
-//   ||pg||_F^2 = tr(dcov (x - mean)^T (x - mean) dcov) = sum_i sum_j (dcov cov)_ij dcov_ij
-// with cov the UNNORMALISED centred covariance the metric kernel wrote (block diagonal, as dcov).
-// Workgroup = row ci: its dcov row goes to LDS, thread j forms (dcov cov)_{ci j} over the row's group
-// (coalesced reads of cov's rows) and multiplies by dcov_{ci j}; one atomic per workgroup into sums[1]
-// (zeroed by the caller together with sums[0], which the backward pass adds ||g||^2 into).  All of it
-// depends on x only: it runs in FORWARD, on the statistics' stream, so that backward's Whiten chain is
-// one sum of squares over g and ONE product with the update in its epilogue (s2t_gemm_x3p_whiten).
-__global__ __launch_bounds__(256) void whiten_prep_kernel(const float* __restrict__ cov,
-                                                          const float* __restrict__ mean,
-                                                          const float* __restrict__ scal, int G, int cg,
-                                                          float* __restrict__ dcov, float* __restrict__ bias,
-                                                          float* __restrict__ sums) {
-  __shared__ float s_red[2][4];
-  __shared__ float s_d[1024];
-  const int C = G * cg;
-  const int ci = blockIdx.x;
-  const float md = scal[0], covsq = scal[1], denom = scal[2];
-  const float k = 4.f / (float)C;
-  const float a = 1.f / denom, d = covsq * md / (denom * denom);
-  const int g = ci / cg;
-  const float* covg = cov + (long)g * cg * cg;
-  const float* crow = covg + (long)(ci - g * cg) * cg;
-  float acc = 0.f;
-  for (int cj = threadIdx.x; cj < C; cj += 256) {
-    float v = 0.f;
-    if (cj / cg == g) {
-      v = crow[cj - g * cg] * a;
-      if (ci == cj) v -= d;
-      v *= k;
-      s_d[cj - g * cg] = v;
-    }
-    dcov[(long)ci * C + cj] = v;
-    acc = fmaf(mean[cj], v, acc);
-  }
-  __syncthreads();
-  float t = 0.f;
-  for (int j = threadIdx.x; j < cg; j += 256) {
-    float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
-    int kk = 0;
-    for (; kk + 3 < cg; kk += 4) {
-      r0 = fmaf(s_d[kk], covg[(long)kk * cg + j], r0);
-      r1 = fmaf(s_d[kk + 1], covg[(long)(kk + 1) * cg + j], r1);
-      r2 = fmaf(s_d[kk + 2], covg[(long)(kk + 2) * cg + j], r2);
-      r3 = fmaf(s_d[kk + 3], covg[(long)(kk + 3) * cg + j], r3);
-    }
-    for (; kk < cg; ++kk) r0 = fmaf(s_d[kk], covg[(long)kk * cg + j], r0);
-    t = fmaf((r0 + r1) + (r2 + r3), s_d[j], t);
-  }
-  acc = wave_sum(acc);
-  t = wave_sum(t);
-  if ((threadIdx.x & 63) == 0) {
-    s_red[0][threadIdx.x >> 6] = acc;
-    s_red[1][threadIdx.x >> 6] = t;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    bias[ci] = -((s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]));
-    atomicAdd(&sums[1], (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]));
-  }
-}
-
-// sum[0] += ||a||_F^2
-__global__ __launch_bounds__(256) void sumsq1_kernel(const float* __restrict__ a, long n,
-                                                     float* __restrict__ sum) {
-  __shared__ float s_a[4];
-  float sa = 0.f;
-  const long n4 = n >> 2;
-  const float4* a4 = reinterpret_cast<const float4*>(a);
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
-    const float4 x = a4[e];
-    sa += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
-  }
-  if (blockIdx.x == 0)
-    for (long e = (n4 << 2) + threadIdx.x; e < n; e += 256) sa = fmaf(a[e], a[e], sa);
-  sa = wave_sum(sa);
-  if ((threadIdx.x & 63) == 0) s_a[threadIdx.x >> 6] = sa;
-  __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(sum, (s_a[0] + s_a[1]) + (s_a[2] + s_a[3]));
-}
-
 __global__ __launch_bounds__(256) void sumsq2_kernel(const float* __restrict__ a,
                                                      const float* __restrict__ b, long n,
                                                      float* __restrict__ sums) {
@@ -288,6 +206,33 @@ __global__ __launch_bounds__(256) void whiten_apply_kernel(const float* __restri
     for (long e = (n4 << 2) + threadIdx.x; e < n; e += 256) out[e] = fmaf(pg[e], scale, g[e]);
 }
 
+// out = g + pg * grad_scale * |g| / (|pg| + 1e-20) with the two squared norms given as [2][64] partial
+// sums (s2t_gemm_x3p_sq's slots): every workgroup adds them up for itself (128 floats)
+__global__ __launch_bounds__(256) void whiten_apply64_kernel(const float* __restrict__ g,
+                                                             const float* __restrict__ pg, long n,
+                                                             float grad_scale,
+                                                             const float* __restrict__ sums64,
+                                                             float* __restrict__ out) {
+  __shared__ float s_sc;
+  if (threadIdx.x < 64) {
+    const float a = wave_sum(sums64[threadIdx.x]), b = wave_sum(sums64[64 + threadIdx.x]);
+    if (threadIdx.x == 0) s_sc = grad_scale * (sqrtf(a) / (sqrtf(b) + 1.0e-20f));
+  }
+  __syncthreads();
+  const float scale = s_sc;
+  const long n4 = n >> 2;
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  const float4* p4 = reinterpret_cast<const float4*>(pg);
+  float4* o4 = reinterpret_cast<float4*>(out);
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
+    const float4 x = g4[e], y = p4[e];
+    o4[e] = make_float4(fmaf(y.x, scale, x.x), fmaf(y.y, scale, x.y), fmaf(y.z, scale, x.z),
+                        fmaf(y.w, scale, x.w));
+  }
+  if (blockIdx.x == 0)
+    for (long e = (n4 << 2) + threadIdx.x; e < n; e += 256) out[e] = fmaf(pg[e], scale, g[e]);
+}
+
 // limit_param_value backward: flip the sign of gradient entries that push an out-of-range
 // parameter further out (first the lower bound, then the upper bound on the updated value)
 __global__ __launch_bounds__(256) void limit_param_grad_kernel(const float* __restrict__ x,
@@ -324,25 +269,30 @@ extern "C" int s2t_whiten_dcov(const float* cov, const float* mean, const float*
   return 0;
 }
 
-// dcov / bias as s2t_whiten_dcov plus sums[1] = ||x dcov + bias||_F^2 in closed form (sums[0] = 0): see
-// whiten_prep_kernel.  -2: a group wider than the kernel's LDS row (cg > 1024).
+// s2t_whiten_dcov for the form whose backward is s2t_gemm_x3p_sq + s2t_whiten_combine64: dcov / bias
+// as there, and sums64 = the [2][64] partial-sum slots of the two norms, zeroed.  Everything here
+// depends on x only: the caller runs it in FORWARD, on the statistics' stream, followed by s2t_x3p_split
+// of dcov -- backward's chain is then two launches on the data-gradient stream instead of three.
 extern "C" int s2t_whiten_prep(const float* cov, const float* mean, const float* scal, int G, int cg,
-                               float* dcov, float* bias, float* sums, void* stream) {
-  if (G <= 0 || cg <= 0 || !sums) return -1;
-  if (cg > 1024) return -2;
-  if (hipMemsetAsync(sums, 0, 2 * sizeof(float), (hipStream_t)stream) != hipSuccess) return -3;
-  hipLaunchKernelGGL(whiten_prep_kernel, dim3(G * cg), dim3(256), 0, (hipStream_t)stream, cov, mean,
-                     scal, G, cg, dcov, bias, sums);
+                               float* dcov, float* bias, float* sums64, void* stream) {
+  if (G <= 0 || cg <= 0 || !sums64) return -1;
+  if (hipMemsetAsync(sums64, 0, 128 * sizeof(float), (hipStream_t)stream) != hipSuccess) return -3;
+  hipLaunchKernelGGL(whiten_dcov_kernel, dim3(G * cg), dim3(256), 0, (hipStream_t)stream, cov, mean,
+                     scal, G, cg, dcov, bias, sums64);
   S2T_CHECK_LAUNCH();
   return 0;
 }
 
-// sum[0] += ||a||_F^2 over numel floats (a 16-byte aligned)
-extern "C" int s2t_sumsq(const float* a, long numel, float* sum, void* stream) {
+extern "C" int s2t_whiten_combine64(const float* g, const float* pg, long numel, float grad_scale,
+                                    const float* sums64, float* out, void* stream) {
   if (numel <= 0) return 0;
-  if (!a || !sum || (reinterpret_cast<uintptr_t>(a) & 15)) return -1;
-  const unsigned blocks = (unsigned)std::min<long>(512, std::max<long>(1, ((numel >> 2) + 255) / 256));
-  hipLaunchKernelGGL(sumsq1_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, numel, sum);
+  if (!sums64 || ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(pg) |
+                   reinterpret_cast<uintptr_t>(out)) & 15))
+    return -1;
+  const long n4 = numel >> 2;
+  const unsigned blocks = (unsigned)std::min<long>(2048, std::max<long>(1, (n4 + 255) / 256));
+  hipLaunchKernelGGL(whiten_apply64_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, pg,
+                     numel, grad_scale, sums64, out);
   S2T_CHECK_LAUNCH();
   return 0;
 }

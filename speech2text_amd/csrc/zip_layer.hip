@@ -92,7 +92,7 @@ struct WStat {
   float *cov, *mean, *scal, *host;
   hipEvent_t ev;
   int G, cg;
-  // fused backward (whiten_x3p == 2): written in forward on the statistics' stream
+  // round-6 form (whiten_x3p == 2): written in forward on the statistics' stream; sums = [2][64] slots
   float *dcov, *bias, *sums;
   unsigned short* pieces;
 };
@@ -310,9 +310,9 @@ int whiten_stats(Ctx& c, WStat& s, const float* x, long ldx, long R, int C, int 
   s.cov = c.ar.alloc((long)groups * s.cg * s.cg);
   s.mean = c.ar.alloc(C);
   s.scal = c.ar.alloc(4);
-  // fused backward: d metric / d cov, its bias row, ||pg||^2 and dcov's bf16 pieces are taken NOW, on
-  // the statistics' stream (they depend on x only): backward's chain is a sum of squares over g and
-  // one product with the update in its epilogue
+  // round-6 form: d metric / d cov, its bias row and dcov's bf16 pieces are taken NOW, on the statistics'
+  // stream (they depend on x only): backward's chain is the penalty product on the pre-split-weight kernel
+  // with the two norms in its epilogue, and the combining pass
   const S2tZlWhScratch* sc0 = wh_scratch(c, C);
   const bool fused = c.c.whiten_x3p == 2 && c.c.x3p_on && C >= 16 && (C & 7) == 0 && s.cg <= 1024 &&
                      R >= 4 && R * C * 4 < 0x7FFFFF00L && R * ldx * 4 < 0x7FFFFF00L && sc0 && sc0->tab;
@@ -320,7 +320,7 @@ int whiten_stats(Ctx& c, WStat& s, const float* x, long ldx, long R, int C, int 
   if (fused) {
     s.dcov = c.ar.alloc((long)C * C);
     s.bias = c.ar.alloc(C);
-    s.sums = c.ar.alloc(2);
+    s.sums = c.ar.alloc(128);
     s.pieces = reinterpret_cast<unsigned short*>(c.ar.alloc((s2t_x3p_plane_elems(C, C) + 1) / 2));
   }
   if (c.dry) return 0;
@@ -365,14 +365,15 @@ int whiten_bwd(Ctx& c, int site, const S2tZlWh& w, WStat& s, const float* x, lon
   if (s.pieces && (reinterpret_cast<uintptr_t>(g) & 15) == 0) {
     // (the prep launches were issued on the side stream in forward: the main stream joined it at the
     //  end of that pass, long before this call)
+    float* pg = c.ar.alloc(R * C);
     float* o = c.ar.alloc(R * C);
     if (c.dry) return 0;
     static const int pg_cls = [] { const char* e = getenv("S2T_WHITEN_PG_CLS"); return e ? atoi(e) : 3; }();
     const S2tGemmClass cls(pg_cls);
-    RUN(s2t_sumsq(g, R * C, s.sums, (void*)c.st));
-    const int rc = s2t_gemm_x3p_whiten(x, ldx, s.pieces, C, o, C, (int)R, s.bias, g, C, s.sums, w.grad_scale,
-                                       c.c.x3p_tile, (void*)c.st);
-    if (rc != 0) return fail(rc, "s2t_gemm_x3p_whiten");     // (the shape rules were checked in forward)
+    const int rc = s2t_gemm_x3p_sq(x, ldx, s.pieces, C, C, pg, C, (int)R, s.bias, g, C, s.sums, c.c.x3p_tile,
+                                   (void*)c.st);
+    if (rc != 0) return fail(rc, "s2t_gemm_x3p_sq(whiten)");      // (the shape rules were checked in forward)
+    RUN(s2t_whiten_combine64(g, pg, R * C, w.grad_scale, s.sums, o, (void*)c.st));
     *out = o;
     return 0;
   }

@@ -375,9 +375,9 @@ class WhitenStats:
                                           ctypes.c_void_p(self.host.data_ptr()), N.fp(ws),
                                           side if side is not None else N.stream()),
                 "s2t_whiten_metric")
-        # The fused backward (csrc/zip_layer.hip whiten_stats / whiten_bwd, include/s2t_mi355.h
-        # s2t_whiten_prep): d metric / d cov, its bias row, ||pg||^2 in closed form and dcov's bf16
-        # pieces depend on x only -- taken now, on the statistics' stream
+        # The round-6 form of the backward (csrc/zip_layer.hip whiten_stats / whiten_bwd,
+        # include/s2t_mi355.h s2t_whiten_prep): d metric / d cov, its bias row and dcov's bf16 pieces
+        # depend on x only -- taken now, on the statistics' stream
         self.pieces = None
         ent = planes.adhoc_entry(C, C, 1, dev) if (_WHITEN_X3P == 2 and X3P["on"] and _tn_ok(xf) and C % 8 == 0
                                                     and cg <= 1024 and n >= 4
@@ -386,7 +386,7 @@ class WhitenStats:
             q = side if side is not None else N.stream()
             self.dcov = torch.empty((C, C), dtype=torch.float32, device=dev)
             self.bias = torch.empty((C,), dtype=torch.float32, device=dev)
-            self.sums = torch.empty((2,), dtype=torch.float32, device=dev)
+            self.sums = torch.empty((128,), dtype=torch.float32, device=dev)     # [2][64] partial-sum slots
             self.pieces = torch.empty_like(ent[1])
             N.PROF[0] and N.profile_note("s2t_whiten_prep", 4.0 * (C * cg * cg + C * C))
             N.check(N.lib().s2t_whiten_prep(N.fp(self.cov), N.fp(self.mean), N.fp(self.scal), G, cg,
@@ -414,9 +414,9 @@ class WhitenStats:
 
 # (round 5: off -- the NN kernel that takes the two norms in its epilogue (below) beats the bf16x3
 # product + a separate norm pass also for the 31 680-row activations: 37.61 against 37.72 ms/step)
-# (round 6: 2 = the fused form -- dcov, its pieces and ||pg||^2 taken in forward on the statistics' stream,
-# backward = a sum of squares over g + ONE product with the update in its epilogue; 1 = the round-5
-# on-the-spot split + plain product; 0 = the NN kernel with the norms in its epilogue)
+# (round 6: 2 = dcov and its pieces taken in forward on the statistics' stream, backward = the penalty
+# product on the pre-split-weight kernel with the two norms in its epilogue + the combining pass; 1 = the
+# round-5 on-the-spot split + plain product; 0 = the NN kernel with the norms in its epilogue)
 _WHITEN_X3P = int(os.environ.get("S2T_WHITEN_X3P", "2"))
 # the norms of (g, x dcov) taken in the product's epilogue (s2t_gemm_f32_sq) instead of by a pass over both
 _WHITEN_SQ = os.environ.get("S2T_WHITEN_SQ", "1") == "1"
@@ -444,16 +444,18 @@ def whiten_backward(x, g, stats, limit, grad_scale):
         g2 = g.contiguous().float()
         if xf.dtype is torch.float32 and xf.stride(1) == 1 and g2.data_ptr() % 16 == 0:
             out = torch.empty_like(g2)
-            N.PROF[0] and N.profile_note("s2t_sumsq", 4.0 * g2.numel())
-            N.check(N.lib().s2t_sumsq(N.fp(g2), g2.numel(), N.fp(stats.sums), N.stream()), "s2t_sumsq")
-            N.PROF[0] and N.profile_note("s2t_gemm_x3p_whiten", 4.0 * (xf.numel() + 2 * g2.numel()) + 6.0 * C * C,
+            pg = torch.empty_like(g2)
+            N.PROF[0] and N.profile_note("s2t_gemm_x3p_sq", 4.0 * (xf.numel() + 2 * g2.numel()) + 6.0 * C * C,
                                          2.0 * xf.shape[0] * C * C)
             with gemm_class(_WHITEN_PG_CLS):
-                rc = N.lib().s2t_gemm_x3p_whiten(N.raw(xf, torch.float32), xf.stride(0),
-                                                 ctypes.c_void_p(stats.pieces.data_ptr()), C, N.fp(out), C,
-                                                 xf.shape[0], N.fp(stats.bias), N.fp(g2), C, N.fp(stats.sums),
-                                                 float(grad_scale), X3P["tile"], N.stream())
-            N.check(rc, "s2t_gemm_x3p_whiten")
+                rc = N.lib().s2t_gemm_x3p_sq(N.raw(xf, torch.float32), xf.stride(0),
+                                             ctypes.c_void_p(stats.pieces.data_ptr()), C, C, N.fp(pg), C,
+                                             xf.shape[0], N.fp(stats.bias), N.fp(g2), C, N.fp(stats.sums),
+                                             X3P["tile"], N.stream())
+            N.check(rc, "s2t_gemm_x3p_sq")
+            N.PROF[0] and N.profile_note("s2t_whiten_combine64", 12.0 * g2.numel())
+            N.check(N.lib().s2t_whiten_combine64(N.fp(g2), N.fp(pg), g2.numel(), float(grad_scale),
+                                                 N.fp(stats.sums), N.fp(out), N.stream()), "s2t_whiten_combine64")
             return out.view(shp), True
     dcov = torch.empty((C, C), dtype=torch.float32, device=dev)
     bias = torch.empty((C,), dtype=torch.float32, device=dev)

@@ -509,9 +509,10 @@ def test_downsample_and_upsampled_bypass_vs_torch(dev, T, B, C, ds):
 def test_whiten_backward_vs_oracle(dev, monkeypatch, R, C, G, form):
     """Whiten (scaling.py:949-1095): x^T x comes from the symmetric TN GEMM (only the 64x64 tiles on /
     above the diagonal with same-group pairs; cg = 48 straddles tiles), the metric kernel mirrors
-    them; the backward term against the oracle's autograd-in-backward statement.  form: "fused" = dcov,
-    its bf16 pieces and ||pg||^2 = tr(dcov cov dcov) taken in forward, backward = a sum of squares over g
-    + one product with the update in its epilogue (s2t_whiten_prep / s2t_gemm_x3p_whiten: the default);
+    them; the backward term against the oracle's autograd-in-backward statement.  form: "fused" = dcov
+    and its bf16 pieces taken in forward, backward = the penalty product on the pre-split-weight kernel
+    with the two norms in its epilogue + the combining pass (s2t_whiten_prep / s2t_gemm_x3p_sq /
+    s2t_whiten_combine64: the default);
     "sq" = the norms of (g, x dcov) from the NN product's epilogue (s2t_gemm_f32_sq); "pass" = from a
     pass over both tensors."""
     import random
