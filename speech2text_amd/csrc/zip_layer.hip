@@ -368,9 +368,16 @@ int whiten_bwd(Ctx& c, int site, const S2tZlWh& w, WStat& s, const float* x, lon
     float* pg = c.ar.alloc(R * C);
     float* o = c.ar.alloc(R * C);
     if (c.dry) return 0;
-    static const int pg_cls = [] { const char* e = getenv("S2T_WHITEN_PG_CLS"); return e ? atoi(e) : 3; }();
+    // the penalty product is a data-gradient-like product (class D: two pieces by default -- measured:
+    // every C3 gradient stays where the six-product step has it; it is the covariance x^T x
+    // that needs the six products); S2T_WHITEN_PG_CLS=3 files it under the statistics
+    static const int pg_cls = [] { const char* e = getenv("S2T_WHITEN_PG_CLS"); return e ? atoi(e) : 1; }();
     const S2tGemmClass cls(pg_cls);
-    const int rc = s2t_gemm_x3p_sq(x, ldx, s.pieces, C, C, pg, C, (int)R, s.bias, g, C, s.sums, c.c.x3p_tile,
+    // block tile by the output width (the plan table has no bucket for these C x C products): 128-wide
+    // column tiles where C is a multiple of 128, 64-wide otherwise; the 32-deep LDS-DMA form with two pieces
+    const bool two = s2t_gemm_arith_of(pg_cls) == 2;
+    const int tile = c.c.x3p_tile ? c.c.x3p_tile : ((C & 127) == 0 ? (two ? 2212 : 312) : (two ? 2221 : 321));
+    const int rc = s2t_gemm_x3p_sq(x, ldx, s.pieces, C, C, pg, C, (int)R, s.bias, g, C, s.sums, tile,
                                    (void*)c.st);
     if (rc != 0) return fail(rc, "s2t_gemm_x3p_sq(whiten)");      // (the shape rules were checked in forward)
     RUN(s2t_whiten_combine64(g, pg, R * C, w.grad_scale, s.sums, o, (void*)c.st));

@@ -425,7 +425,8 @@ _WHITEN_SQ = os.environ.get("S2T_WHITEN_SQ", "1") == "1"
 _WHITEN_X3P_ROWS = int(os.environ.get("S2T_WHITEN_X3P_ROWS", "24000"))
 
 
-_WHITEN_PG_CLS = int(os.environ.get("S2T_WHITEN_PG_CLS", "3"))   # class of the penalty product (csrc/zip_layer.hip whiten_bwd)
+_WHITEN_PG_CLS = int(os.environ.get("S2T_WHITEN_PG_CLS", "3"))   # class of the penalty product, three-launch form (csrc/zip_layer.hip whiten_bwd)
+_WHITEN_PG2_CLS = int(os.environ.get("S2T_WHITEN_PG_CLS", "1"))  # ... on the pre-split-weight kernel (round-6 form): data gradient
 
 
 def whiten_backward(x, g, stats, limit, grad_scale):
@@ -447,11 +448,15 @@ def whiten_backward(x, g, stats, limit, grad_scale):
             pg = torch.empty_like(g2)
             N.PROF[0] and N.profile_note("s2t_gemm_x3p_sq", 4.0 * (xf.numel() + 2 * g2.numel()) + 6.0 * C * C,
                                          2.0 * xf.shape[0] * C * C)
-            with gemm_class(_WHITEN_PG_CLS):
+            # (class and block tile as csrc/zip_layer.hip whiten_bwd: a data-gradient-like product, two
+            #  pieces by default; 128-wide column tiles where C is a multiple of 128, 64-wide otherwise)
+            two = gemm_arith(_WHITEN_PG2_CLS) == 2
+            tile = X3P["tile"] or ((2212 if two else 312) if C % 128 == 0 else (2221 if two else 321))
+            with gemm_class(_WHITEN_PG2_CLS):
                 rc = N.lib().s2t_gemm_x3p_sq(N.raw(xf, torch.float32), xf.stride(0),
                                              ctypes.c_void_p(stats.pieces.data_ptr()), C, C, N.fp(pg), C,
                                              xf.shape[0], N.fp(stats.bias), N.fp(g2), C, N.fp(stats.sums),
-                                             X3P["tile"], N.stream())
+                                             tile, N.stream())
             N.check(rc, "s2t_gemm_x3p_sq")
             N.PROF[0] and N.profile_note("s2t_whiten_combine64", 12.0 * g2.numel())
             N.check(N.lib().s2t_whiten_combine64(N.fp(g2), N.fp(pg), g2.numel(), float(grad_scale),
