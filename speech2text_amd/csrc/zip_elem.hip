@@ -393,6 +393,127 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict_
   }
 }
 
+// Few channels (the frontend's first convolutions: C = 8 and 32 over 5.1 M / 1.2 M rows): the kernel
+// above gives a lane a COLUMN of a 64-wide group, so at C = 8 one lane in eight works.  Here the
+// (rows, C) matrix is contiguous (ld == C, C a power of two <= 32) and read flat, 16 bytes per lane:
+// quad i of the stream holds channels 4 (i mod C/4) ... + 3; a lane's quads all belong to one channel
+// quad (the grid stride is a multiple of 64 lanes), so it sums in registers, lanes of the same channel
+// quad meet by shuffles, one atomic pair per channel and workgroup.
+__global__ __launch_bounds__(256) void col_stats_small_kernel(const float* __restrict__ x, long nquads, int C,
+                                                              float* __restrict__ sum,
+                                                              float* __restrict__ sumsq) {
+  const int cq = C >> 2;                                   // channel quads: 1, 2, 4 or 8
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  const long step = (long)gridDim.x * 256;
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * step < nquads; i += 4 * step) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = x4[i + u * step];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w;
+      q.x = fmaf(v[u].x, v[u].x, q.x); q.y = fmaf(v[u].y, v[u].y, q.y);
+      q.z = fmaf(v[u].z, v[u].z, q.z); q.w = fmaf(v[u].w, v[u].w, q.w);
+    }
+  }
+  for (; i < nquads; i += step) {
+    const float4 v = x4[i];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    q.x = fmaf(v.x, v.x, q.x); q.y = fmaf(v.y, v.y, q.y); q.z = fmaf(v.z, v.z, q.z); q.w = fmaf(v.w, v.w, q.w);
+  }
+  // lanes l, l + cq, l + 2 cq, ... hold the same channel quad
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    if (o >= cq) {
+      s.x += __shfl_xor(s.x, o, 64); s.y += __shfl_xor(s.y, o, 64);
+      s.z += __shfl_xor(s.z, o, 64); s.w += __shfl_xor(s.w, o, 64);
+      q.x += __shfl_xor(q.x, o, 64); q.y += __shfl_xor(q.y, o, 64);
+      q.z += __shfl_xor(q.z, o, 64); q.w += __shfl_xor(q.w, o, 64);
+    }
+  }
+  __shared__ float4 sh[2][4][8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane < cq) {
+    sh[0][wave][lane] = s;
+    sh[1][wave][lane] = q;
+  }
+  __syncthreads();
+  if (threadIdx.x < C) {
+    const int c = threadIdx.x;
+    const float* f0 = reinterpret_cast<const float*>(&sh[0][0][0]);
+    const float* f1 = reinterpret_cast<const float*>(&sh[1][0][0]);
+    atomicAdd(&sum[c], (f0[c] + f0[32 + c]) + (f0[64 + c] + f0[96 + c]));
+    atomicAdd(&sumsq[c], (f1[c] + f1[32 + c]) + (f1[64 + c] + f1[96 + c]));
+  }
+}
+
+// the update for the same layouts: flat 16-byte stream, the channel quad's coefficients from LDS
+__global__ __launch_bounds__(256) void balancer_apply_small_kernel(
+    const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ stats,
+    float* __restrict__ stats_next, float n, float min_mean, float max_mean, float min_rms, float max_rms,
+    float grad_scale, long nquads, int C, float* __restrict__ out, float act_off) {
+  __shared__ __attribute__((aligned(16))) float s_a[32], s_b[32];
+  const float inv_n = 1.f / n;
+  if (threadIdx.x < C) {                                   // (formulas and clamps of balancer_apply_fused_kernel)
+    const int c = threadIdx.x;
+    const float mean = stats[c] * inv_n, uvar = stats[1024 + c] * inv_n;
+    const float raw_var = uvar - mean * mean;
+    const bool live_v = raw_var > 1.0e-20f, live_r = uvar > 1.0e-20f;
+    const float var = fmaxf(raw_var, 1.0e-20f);
+    const float sd = sqrtf(var);
+    const float rms = sqrtf(fmaxf(uvar, 1.0e-20f));
+    const float m = mean / sd;
+    const float mc = fminf(fmaxf(m, min_mean), max_mean);
+    const float s_m = (m > mc) ? 1.f : ((m < mc) ? -1.f : 0.f);
+    const float rc = fminf(fmaxf(rms, min_rms), max_rms);
+    const float lq = logf(rc / rms);
+    const float s_r = (lq > 0.f) ? -1.f : ((lq < 0.f) ? 1.f : 0.f);
+    const float a = s_m * inv_n * (live_v ? (1.f / sd + mean * mean / (sd * var)) : 1.f / sd);
+    const float b = (live_v ? -s_m * inv_n * mean / (sd * var) : 0.f) +
+                    (live_r ? s_r * inv_n / (rms * rms) : 0.f);
+    const float lg_rms =
+        fmaxf(sqrtf(fmaxf(a * a + 2.f * a * b * mean + b * b * uvar, 0.f)), 1.0e-20f);
+    const float coef = grad_scale / lg_rms;
+    s_a[c] = a * coef;
+    s_b[c] = b * coef;
+  }
+  if (blockIdx.x == 0 && stats_next != nullptr)
+    for (int c = threadIdx.x; c < 2 * 1024; c += 256) stats_next[c] = 0.f;
+  __syncthreads();
+  const int cq = C >> 2;
+  const float4 a4 = *reinterpret_cast<const float4*>(&s_a[4 * (threadIdx.x & (cq - 1))]);
+  const float4 b4 = *reinterpret_cast<const float4*>(&s_b[4 * (threadIdx.x & (cq - 1))]);
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  float4* o4 = reinterpret_cast<float4*>(out);
+  const long step = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nquads; i += 2 * step) {
+    const bool two = i + step < nquads;
+    float4 xv[2], gv[2];
+    xv[0] = x4[i];
+    gv[0] = g4[i];
+    xv[1] = x4[two ? i + step : i];
+    gv[1] = g4[two ? i + step : i];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (u == 1 && !two) break;
+      float4 gg = gv[u];
+      if (act_off >= 0.f) {
+        gg.x *= swoosh_d(xv[u].x, act_off);
+        gg.y *= swoosh_d(xv[u].y, act_off);
+        gg.z *= swoosh_d(xv[u].z, act_off);
+        gg.w *= swoosh_d(xv[u].w, act_off);
+      }
+      o4[i + u * step] = make_float4(gg.x + fabsf(gg.x) * fmaf(b4.x, xv[u].x, a4.x),
+                                     gg.y + fabsf(gg.y) * fmaf(b4.y, xv[u].y, a4.y),
+                                     gg.z + fabsf(gg.z) * fmaf(b4.z, xv[u].z, a4.z),
+                                     gg.w + fabsf(gg.w) * fmaf(b4.w, xv[u].w, a4.w));
+    }
+  }
+}
+
 // Balancer backward, second pass: out = g + |g| * (a'[c] + b'[c] x).  Every workgroup first turns
 // the column statistics (sum, sumsq over n rows, from col_stats_kernel) into the coefficients of
 // its own copy in LDS (balancer_coef's formulas; C <= 1024), so no coefficient kernel runs; block 0
@@ -614,6 +735,16 @@ extern "C" int s2t_biasnorm_bwd_tb(const float* x, const float* bias, const floa
   return biasnorm_bwd_launch(x, bias, scales, g, (long)T * B, D, dx, dbias, dls, T, B, (hipStream_t)stream);
 }
 
+// the flat forms for few channels: C in {4, 8, 16, 32}, every matrix contiguous (ld == C) and 16-byte aligned
+static bool bal_small(int C, const float* x, long ldx, const float* g, long ldg, const float* out, long ldo) {
+  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  return (C == 4 || C == 8 || C == 16 || C == 32) && ldx == C && al(x) && (!g || (ldg == C && al(g))) &&
+         (!out || (ldo == C && al(out)));
+}
+static unsigned bal_small_grid(long nquads) {
+  return (unsigned)std::min<long>(2048, std::max<long>(1, (nquads + 256 * 8 - 1) / (256 * 8)));
+}
+
 // workspace: two alternating (sum[C], sumsq[C]) accumulators of 2 * BAL_MAXC floats each
 constexpr int BAL_MAXC = 1024;
 extern "C" long s2t_balancer_bwd_workspace_floats(void) { return 4L * BAL_MAXC; }
@@ -627,6 +758,16 @@ extern "C" int s2t_balancer_bwd(const float* x, long ldx, const float* g, long l
   hipStream_t st = (hipStream_t)stream;
   float* cur = workspace + (parity & 1) * 2 * BAL_MAXC;
   float* nxt = workspace + ((parity + 1) & 1) * 2 * BAL_MAXC;
+  if (bal_small(C, x, ldx, g, ldg, out, ldo)) {
+    const long nq = rows * C / 4;
+    hipLaunchKernelGGL(col_stats_small_kernel, dim3(bal_small_grid(nq)), dim3(256), 0, st, x, nq, C, cur,
+                       cur + BAL_MAXC);
+    S2T_CHECK_LAUNCH();
+    hipLaunchKernelGGL(balancer_apply_small_kernel, dim3(bal_small_grid(nq)), dim3(256), 0, st, x, g, cur, nxt,
+                       (float)rows, min_mean, max_mean, min_rms, max_rms, grad_scale, nq, C, out, act_off);
+    S2T_CHECK_LAUNCH();
+    return 0;
+  }
   int gy = (C + 63) / 64;
   if (gy > 16) gy = 16;
   long gx = (rows + 4 * 16 - 1) / (4 * 16);
@@ -648,6 +789,13 @@ extern "C" int s2t_balancer_stats(const float* x, long ldx, long rows, int C, fl
                                   void* stream) {
   if (rows <= 0 || C <= 0) return 0;
   if (C > BAL_MAXC || !stats) return -1;
+  if (bal_small(C, x, ldx, nullptr, 0, nullptr, 0)) {
+    const long nq = rows * C / 4;
+    hipLaunchKernelGGL(col_stats_small_kernel, dim3(bal_small_grid(nq)), dim3(256), 0, (hipStream_t)stream, x,
+                       nq, C, stats, stats + BAL_MAXC);
+    S2T_CHECK_LAUNCH();
+    return 0;
+  }
   int gy = (C + 63) / 64;
   if (gy > 16) gy = 16;
   long gx = (rows + 4 * 16 - 1) / (4 * 16);
@@ -664,6 +812,14 @@ extern "C" int s2t_balancer_apply(const float* x, long ldx, const float* g, long
                                   const float* stats, float act_off, void* stream) {
   if (rows <= 0 || C <= 0) return 0;
   if (C > BAL_MAXC || !stats) return -1;
+  if (bal_small(C, x, ldx, g, ldg, out, ldo)) {
+    const long nq = rows * C / 4;
+    hipLaunchKernelGGL(balancer_apply_small_kernel, dim3(bal_small_grid(nq)), dim3(256), 0, (hipStream_t)stream,
+                       x, g, stats, (float*)nullptr, (float)rows, min_mean, max_mean, min_rms, max_rms, grad_scale,
+                       nq, C, out, act_off);
+    S2T_CHECK_LAUNCH();
+    return 0;
+  }
   hipLaunchKernelGGL(balancer_apply_fused_kernel, dim3((unsigned)std::min<long>((rows + 15) / 16, 2048)),
                      dim3(256), 0, (hipStream_t)stream, x, ldx, g, ldg, stats, (float*)nullptr,
                      (float)rows, min_mean, max_mean, min_rms, max_rms, grad_scale, rows, C, out, ldo,

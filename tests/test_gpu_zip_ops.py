@@ -607,13 +607,14 @@ def _balancer_ref64(x, g, min_mean, max_mean, min_rms, max_rms, grad_scale, swoo
 
 
 @pytest.mark.parametrize("rows,C", [(31680, 192), (15872, 576), (7936, 960), (3968, 1024), (1000, 100), (37, 256),
-                                    (5000, 260)])
+                                    (5000, 260), (300001, 8), (50001, 32), (4097, 16), (333, 4)])
 @pytest.mark.parametrize("swoosh", [None, True])
 def test_balancer_backward_vs_fp64_closed_form(dev, rows, C, swoosh):
     """s2t_balancer_bwd (reference model/layer/scaling.py:741-789 in closed form; two passes: column
     statistics, fused update) against the fp64 closed form: channels on both sides of every clamp
     (|mean| / std <= 8: the fp32 statistics' var = E[x^2] - mean^2 keeps four digits), row counts that
-    leave ragged tails, channel counts that are no multiple of 64, operands at addresses that are no
+    leave ragged tails, channel counts that are no multiple of 64, few channels (C = 4 ... 32 contiguous:
+    the flat 16-byte form the frontend's first convolutions take), operands at addresses that are no
     multiple of 16 bytes, a row-strided slice of a wider tensor, with and without the Swoosh derivative
     in front."""
     from speech2text_amd import zip_kernels as zk
