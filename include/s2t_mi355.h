@@ -707,8 +707,7 @@ int s2t_predictor_ctx_bwd(const int* tokens, const float* emb, const float* w, c
  *   C2 = C + resid_b instead (C itself without resid_b: a module's output and the residual
  *   stream after it from one launch).  K % 8 == 0, N % 4 == 0, rows
  *   16-byte aligned (else -2).  tile = 0 (from the shape) | 11 | 12 | 21 | 22: block tile
- *   (64 tm) x (64 tn); + 100 w: w persistent workgroups per CU; + 1000: a tile's output is
- *   stored in slices under the next tile's multiplications (persistent grids, three pieces only);
+ *   (64 tm) x (64 tn); + 100 w: w persistent workgroups per CU;
  *   2000 + tm tn: the form that moves the weight pieces global -> LDS directly, + 200 (two-piece
  *   arithmetic only): 32-deep barrier intervals.  -2: a tile code the current arithmetic has not. */
 /* ---- the arithmetic of every bf16 matrix-core GEMM of the library (s2t_gemm_x3p*, the weight-gradient /
@@ -741,7 +740,6 @@ typedef struct {
   unsigned blk_begin;
   int pad_;
 } S2tPlaneDesc;
-int s2t_x3p_debug_stamps(void* buf);   /* diagnostics: per-workgroup phase stamps (tools/x3p_stamps.py) */
 long s2t_x3p_plane_elems(int N, int K);
 long s2t_x3p_split_blocks(int N, int K);
 int s2t_x3p_split(const float* base, const void* tab, int n, int total_blocks, unsigned short* dst,
@@ -934,8 +932,7 @@ typedef struct S2tZipLayerCall {
   long lt_ws_bytes;
   int x3p_on, x3p_tile;
   float x3p_margin;
-  int whiten_x3p;                  /* Whiten backward: 2 fused (forward-side prep + one product), 1 split on the spot, 0 NN kernel */
-  long whiten_x3p_rows;
+  int whiten_x3p;                  /* Whiten backward: 2 = dcov + its pieces in forward, product on the pre-split-weight kernel (round 6); 0 = the NN kernel, three launches */
   int conv_w_side, conv_fused, stats_side, wgrad_side, bmm_own;
   int bal_epi;                     /* hidden Balancers in the dgrad epilogue (s2t_gemm_x3p_bal) */
   int whiten_sq;                   /* Whiten's norms in the x dcov product's epilogue (s2t_gemm_f32_sq) */

@@ -97,10 +97,6 @@ __device__ __forceinline__ void split8n(const f32x4 v0, const f32x4 v1, u32x4 (&
 
 enum { ACT_NONE = 0, ACT_SWOOSH_L = 1, ACT_SWOOSH_R = 2 };
 
-#ifndef X3P_STORE_LATE
-#define X3P_STORE_LATE 0     // 1: LDS stores of the next stage after ALL of a stage's products (A/B: slower)
-#endif
-
 __device__ __forceinline__ float log1p_fast(float e) {   // as zip_elem.hip
   const float u = 1.f + e;
   return u == 1.f ? e : __logf(u) * __fdividef(e, u - 1.f);
@@ -148,9 +144,6 @@ struct X3P {
   int tiles_m, tiles_n;
   int wgs_per_cu;             // persistent form: workgroups per CU (0 = default)
   int prio;                   // 1: wave priority by the workgroup's slot on its CU (see x3p_set_prio)
-  unsigned long long* stamps; // diagnostics (s2t_x3p_debug_stamps): [block][8] s_memtime stamps, or NULL
-  int drip;                   // 1: epilogue of tile t stored in slices under tile t+1 (x3p_db_kernel DRIP)
-  int stagger;                // > 0: workgroup slot s of a CU starts its k loop s * stagger * 64 cycles late
   // Balancer update in the epilogue (s2t_gemm_x3p_bal): C = act'(S) (A Bm^T) is the gradient w.r.t. S
   // coming through the activation, and the Balancer on S (scaling.py:741-789 in closed form, as
   // zip_elem.hip balancer_apply_fused_kernel) adds |C| (a[c] + b[c] S): bal_stats = [2][1024] column
@@ -172,12 +165,6 @@ struct X3P {
   long segoff[4];
   long c_elems;               // elements of the mapped C buffer (its buffer resource)
 };
-
-// diagnostics: lane 0 of wave 0 records the shader clock at a phase boundary of its workgroup
-__device__ __forceinline__ void x3p_stamp(const X3P& g, int slot) {
-  if (g.stamps && threadIdx.x == 0)
-    g.stamps[(long)blockIdx.x * 8 + slot] = __builtin_amdgcn_s_memtime();
-}
 
 // The workgroups of a one-round grid start together and, left alone, run in lockstep: all of a CU's
 // workgroups multiply at the same time (sharing the matrix pipe) and then all store at the same
@@ -437,39 +424,29 @@ __device__ __forceinline__ void x3p_epilogue(const X3P& g, f32x16 (&acc)[TM][TN]
   sq_commit();
 }
 
-// (the first form of this kernel -- one LDS stage, two barriers per 32-deep chunk -- and the ablation /
-// stamp instantiations of the form below were removed in round 5: their measurements are DESIGN 3f)
-// ---- software-pipelined form: k stages of 16, TWO LDS stages, one barrier per stage.  Iteration kb
-// {barrier; split + store the staged registers (stage kb+1) into the other buffer; request stage
-// kb+2 from global memory; multiply stage kb} -- a wave's staging VALU / LDS stores and its MFMAs
-// belong to the same barrier interval, so the matrix pipe of a SIMD is fed by every resident wave
-// all the time instead of by whichever workgroup happens to be in its "multiply" phase (the
-// two-barrier form above runs the workgroups of a CU in lockstep: all stage, then all multiply).
-// ABL (diagnostics, wrong results): 1 = no global loads inside the k loop, 2 = no LDS stores inside
-// it, 4 = no split arithmetic, 8 = no MFMAs, 16 = no output stores, 32 / 64 = no B / no A loads
-// inside the k loop
-// DRIP: the finished accumulators of tile t are copied aside and stored in SLICES during the first
-// 2 TM TN stages of tile t+1 (one slice = 16 rows of one 32 x 32 sub-tile per wave and stage): the
-// output stores -- a third of a tile's life when every workgroup of the chip stores at once -- drain
-// under the next tile's MFMAs instead of between two main loops.  Needs >= 2 TM TN stages per tile
-// and is worth it with >= 2 tiles per workgroup (persistent grid).
+// ---- register-staged, software-pipelined form: k stages of 16, TWO LDS stages, one barrier per stage.
+// Iteration kb {barrier; split + store the staged registers (stage kb+1) into the other buffer; request
+// stage kb+2 from global memory; multiply stage kb} -- a wave's staging VALU / LDS stores and its MFMAs
+// belong to the same barrier interval, so the matrix pipe of a SIMD is fed by every resident wave all
+// the time instead of by whichever workgroup happens to be in its "multiply" phase.
+// (Round 6 removed this kernel's diagnostic and experimental instantiations -- per-iteration clock
+// stamps, ablation builds, the start stagger, the sliced epilogue under the next tile: their
+// measurements are DESIGN 3f; `git log -- speech2text_amd/csrc/gemm_x3p.hip` has the code.)
 // (waves per SIMD the register allocation must leave room for: 2 / 3 / 4 workgroups per CU for the
 // 2x2 / 1x2, 2x1 / 1x1 tiles -- the epilogue's operand loads are hoisted as far as this allows)
 // NP: pieces per operand (3: the exact bf16x3 split, six products per term; 2: bf16x2, the three
 // leading products -- the LDS images, the weight-piece copies and the fragment reads shrink to the
 // first NP pieces of every 3-piece group of the plane image, which is the same for both)
-template <int TM, int TN, bool DIAG = false, int ABL = 0, bool DRIP = false, bool BAL = false, int NP = 3>
-__global__ __launch_bounds__(256, (DRIP || DIAG || TM * TN == 4) ? 2 : (TM * TN == 2 ? 3 : 4))
+template <int TM, int TN, bool BAL = false, int NP = 3>
+__global__ __launch_bounds__(256, TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 : 4))
 void x3p_db_kernel(X3P g) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   constexpr int A_ST = 2 * TM * NP * 1024, B_ST = 2 * TN * NP * 1024, ST = A_ST + B_ST;
   constexpr int NAU = (128 * TM + 255) / 256;       // A units (8 k of one row) per thread and stage
   constexpr int NBP = 2 * TN * NP * 64;             // B 16-byte pieces per stage
   constexpr int NBU = (NBP + 255) / 256;            // ... per thread
-  constexpr int SCR = 4 * 16 * 36 * 4;              // epilogue scratch (DRIP: its own region)
-  constexpr int NSL = 2 * TM * TN;                  // epilogue slices per wave and tile
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[DRIP ? 2 * ST + SCR : (2 * ST > SCR ? 2 * ST : SCR)];
-  unsigned char* const epi_smem = DRIP ? smem + 2 * ST : smem;
+  constexpr int SCR = 4 * 16 * 36 * 4;              // epilogue scratch
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * ST > SCR ? 2 * ST : SCR];
 
   // PERSISTENT workgroups: the grid is (a multiple of 8, at most) what the chip holds at once; a
   // workgroup walks tiles loc, loc + stride, ... of its XCD's contiguous range (n fastest: the
@@ -528,29 +505,23 @@ void x3p_db_kernel(X3P g) {
   }
 
   const int nst = (g.K + 15) >> 4;                  // stages (the pieces are zero beyond K)
-  // Staging registers.  Two sets (NS = 2): stage kb+2 is requested at the TOP of iteration kb into
-  // the set iteration kb-1 emptied, a whole iteration before its data is touched (same-box A/B:
-  // 3 % faster than one set).  DRIP keeps the previous tile's sums in registers and has one set:
-  // stage kb+2 is requested right after stage kb+1 left the registers for LDS.
-  constexpr int NS = DRIP ? 1 : 2;
-  f32x4 ra[NS][NAU][2];
-  u32x4 rb[NS][NBU];
+  // Two sets of staging registers: stage kb+2 is requested at the TOP of iteration kb into the set
+  // iteration kb-1 emptied, a whole iteration before its data is touched (same-box A/B: 3 % faster
+  // than one set).
+  f32x4 ra[2][NAU][2];
+  u32x4 rb[2][NBU];
   u32x4 qa[NAU][3];                                 // (NP of them used)
   // global -> registers, unconditional (past the end the last stage again; a k tail is read from
   // the row's start and zeroed when it is split): nothing here waits for the data
 #define X3P_LOAD(SET, S)                                                                     \
   {                                                                                          \
     const int ss_ = min((S), nst - 1);                                                       \
-    if (!(ABL & 64) || (S) < 2) {                                                            \
-      _Pragma("unroll") for (int i = 0; i < NAU; ++i) {                                      \
-        gf32p p_ = (gf32p)(asrc[i] + ((16 * ss_ + a_k[i] < g.K) ? 16 * ss_ : 0));           \
-        ra[SET][i][0] = *reinterpret_cast<gf32x4p>(p_);                                 \
-        ra[SET][i][1] = *reinterpret_cast<gf32x4p>(p_ + 4);                             \
-      }                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < NAU; ++i) {                                        \
+      gf32p p_ = (gf32p)(asrc[i] + ((16 * ss_ + a_k[i] < g.K) ? 16 * ss_ : 0));              \
+      ra[SET][i][0] = *reinterpret_cast<gf32x4p>(p_);                                        \
+      ra[SET][i][1] = *reinterpret_cast<gf32x4p>(p_ + 4);                                    \
     }                                                                                        \
-    if (!(ABL & 32) || (S) < 2) {                                                            \
-      _Pragma("unroll") for (int i = 0; i < NBU; ++i) rb[SET][i] = ((gu32x4p)bsrc[i])[(long)ss_ * 192]; \
-    }                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < NBU; ++i) rb[SET][i] = ((gu32x4p)bsrc[i])[(long)ss_ * 192]; \
   }
 #define X3P_SPLIT(SET, S)                                                                    \
   {                                                                                          \
@@ -578,24 +549,10 @@ void x3p_db_kernel(X3P g) {
   _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA], fb[j][PB], acc[i][j], 0, 0, 0);
   // one stage: CUR = the register set that holds stage KB+1, NXT = the set stage KB+2 goes into
-  // DIAG: per-wave sums of the shader-clock intervals of an iteration {waiting at the barrier, load
-  // issue + fragment reads landed, products 1, stores + products 2, products 3}; the six stamps of
-  // an iteration are consumed after the NEXT barrier (SMEM results share lgkmcnt with LDS)
-  unsigned long long dg[5] = {0, 0, 0, 0, 0}, ts[6] = {0, 0, 0, 0, 0, 0};
-  bool have_ts = false;
 #define X3P_ITER(KB, CUR, NXT)                                                               \
   {                                                                                          \
-    unsigned long long t0_ = 0, t1_ = 0, t2_ = 0, t3_ = 0, t4_ = 0, t5_ = 0;                 \
-    if (DIAG) t0_ = __builtin_amdgcn_s_memtime();                                            \
     __syncthreads(); /* stage KB is in LDS for everyone; the other buffer's readers are done */ \
-    if (DIAG) {                                                                              \
-      if (have_ts) {                                                                         \
-        dg[0] += ts[1] - ts[0]; dg[1] += ts[2] - ts[1]; dg[2] += ts[3] - ts[2];             \
-        dg[3] += ts[4] - ts[3]; dg[4] += ts[5] - ts[4];                                      \
-      }                                                                                      \
-      t1_ = __builtin_amdgcn_s_memtime();                                                    \
-    }                                                                                        \
-    if (NS == 2 && !(ABL & 1)) X3P_LOAD(NXT, (KB) + 2)                                       \
+    X3P_LOAD(NXT, (KB) + 2)                                                                  \
     const unsigned char* const sa = smem + ((KB) & 1) * ST;                                  \
     const unsigned char* const sb = sa + A_ST;                                               \
     bf16x8 fa[TM][NP], fb[TN][NP];                                                           \
@@ -603,62 +560,22 @@ void x3p_db_kernel(X3P g) {
       fa[i][p] = *reinterpret_cast<const bf16x8*>(sa + (((wrb + i) * NP + p) * 64 + lane) * 16); \
     _Pragma("unroll") for (int j = 0; j < TN; ++j) _Pragma("unroll") for (int p = 0; p < NP; ++p) \
       fb[j][p] = *reinterpret_cast<const bf16x8*>(sb + (((wcb + j) * NP + p) * 64 + lane) * 16); \
-    if (DIAG) {                                                                              \
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     \
-      t2_ = __builtin_amdgcn_s_memtime();                                                    \
-    }                                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                       \
-    /* (1) the two smallest product groups with the split of stage KB+1's A registers in the  \
+    /* (1) the smallest product groups with the split of stage KB+1's A registers in the      \
        MFMAs' shadow (an MFMA holds the SIMD's issue for 8 of its 32 cycles) */              \
-    if (!(ABL & 4)) X3P_SPLIT(CUR, (KB) + 1)                                                 \
-    if (!(ABL & 8)) { if (NP == 3) { X3P_TERM(NP - 1, 0) X3P_TERM(1, 1) } else { X3P_TERM(1, 0) } } \
-    if (DIAG) t3_ = __builtin_amdgcn_s_memtime();                                            \
+    X3P_SPLIT(CUR, (KB) + 1)                                                                 \
+    if (NP == 3) { X3P_TERM(NP - 1, 0) X3P_TERM(1, 1) } else { X3P_TERM(1, 0) }              \
     __builtin_amdgcn_sched_barrier(0);                                                       \
-    if (X3P_STORE_LATE) {                                                                    \
-      /* all 24 products queued before this wave waits for stage KB+1's global loads */      \
-      if (!(ABL & 8)) { if (NP == 3) { X3P_TERM(0, NP - 1) X3P_TERM(1, 0) } X3P_TERM(0, 1) X3P_TERM(0, 0) } \
-      if (DIAG) t4_ = __builtin_amdgcn_s_memtime();                                          \
-      __builtin_amdgcn_sched_barrier(0);                                                     \
-      if (!(ABL & 2)) X3P_STORE(CUR, ((KB) + 1) & 1)                                         \
-      if (NS == 1 && !(ABL & 1)) X3P_LOAD(NXT, (KB) + 2)                                     \
-    } else {                                                                                 \
-      /* (2) stage KB+1 into the other LDS buffer, stage KB+2 requested */                   \
-      if (!(ABL & 2)) X3P_STORE(CUR, ((KB) + 1) & 1)                                         \
-      if (NS == 1 && !(ABL & 1)) X3P_LOAD(NXT, (KB) + 2)                                     \
-      if (!(ABL & 8)) { if (NP == 3) { X3P_TERM(0, NP - 1) } else { X3P_TERM(0, 1) } }       \
-      if (DIAG) t4_ = __builtin_amdgcn_s_memtime();                                          \
-      __builtin_amdgcn_sched_barrier(0);                                                     \
-      /* (3) the rest of the products */                                                     \
-      if (!(ABL & 8)) { if (NP == 3) { X3P_TERM(1, 0) X3P_TERM(0, 1) } X3P_TERM(0, 0) }      \
-    }                                                                                        \
-    if (DIAG) {                                                                              \
-      t5_ = __builtin_amdgcn_s_memtime();                                                    \
-      ts[0] = t0_; ts[1] = t1_; ts[2] = t2_; ts[3] = t3_; ts[4] = t4_; ts[5] = t5_;         \
-      have_ts = true;                                                                        \
-    }                                                                                        \
-  }
-  x3p_stamp(g, 0);
-  if (g.stamps && threadIdx.x == 0) {
-    g.stamps[(long)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_getreg(((16 - 1) << 11) | (4 << 6) | 4);   // HW_ID[19:4]
-    g.stamps[(long)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);   // XCC_ID
+    /* (2) stage KB+1 into the other LDS buffer */                                           \
+    X3P_STORE(CUR, ((KB) + 1) & 1)                                                           \
+    if (NP == 3) { X3P_TERM(0, NP - 1) } else { X3P_TERM(0, 1) }                             \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    /* (3) the rest of the products */                                                       \
+    if (NP == 3) { X3P_TERM(1, 0) X3P_TERM(0, 1) }                                           \
+    X3P_TERM(0, 0)                                                                           \
   }
   X3P_TILE(loc)
   X3P_LOAD(0, 0)
-  int tile_no = 0;
-  f32x16 pacc[DRIP ? TM : 1][DRIP ? TN : 1];        // DRIP: the previous tile's sums, being stored
-  int pm0 = 0, pn0 = 0;
-  bool pend = false;
-  float* const scr_w = reinterpret_cast<float*>(epi_smem) + wave * (16 * 36);
-#define X3P_SLICE(SL)                                                                        \
-  if (DRIP && pend) {                                                                        \
-    EpiOps o_;                                                                               \
-    const EpiRs rs_ = x3p_epi_rsrc(g);                                                       \
-    f32x16& a_ = pacc[DRIP ? (SL) / (2 * TN) : 0][DRIP ? ((SL) / 2) % TN : 0];               \
-    x3p_epi_load(g, rs_, o_, (SL) / (2 * TN), ((SL) / 2) % TN, (SL) & 1, pm0, pn0, wrb, wcb, lane); \
-    x3p_epi_xform(g, a_, scr_w, o_, x3p_epi_bias(g, ((SL) / 2) % TN, pn0, wcb, lane), (SL) & 1, lane); \
-    EpiSq sq_;                               /* (the sliced form does not take sums: drip refuses sq_sums) */ \
-    x3p_epi_store(g, rs_, a_, o_, (SL) / (2 * TN), ((SL) / 2) % TN, (SL) & 1, pm0, pn0, wrb, wcb, lane, sq_); \
-  }
   for (;;) {
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -670,31 +587,10 @@ void x3p_db_kernel(X3P g) {
     X3P_SPLIT(0, 0)
     X3P_STORE(0, 0)
     X3P_LOAD(0, 1)
-    if (tile_no == 0 && g.stagger > 0) {
-      // The workgroups of a CU share its matrix pipes and, started together, run in LOCKSTEP.  A
-      // one-off delay by the workgroup's slot on its CU (HW_ID.TG_ID) puts them out of phase
-      // (diagnostics: S2T_X3P_STAGGER; measured: the delay is simply added, 0 ... 38 k cycles)
-      const int tg = (int)(__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (16 << 6) | 4) & 15u);
-      for (int i = 0; i < tg * g.stagger; ++i) __builtin_amdgcn_s_sleep(1);
+    for (int kb = 0; kb < nst; kb += 2) {
+      X3P_ITER(kb, 0, 1)
+      if (kb + 1 < nst) X3P_ITER(kb + 1, 1, 0)
     }
-    if (tile_no == 0) x3p_stamp(g, 1);
-    int kb = 0;
-    if (DRIP) {                              // the first NSL stages carry the previous tile's slices
-#pragma unroll
-      for (int sl = 0; sl < NSL; sl += 2) {
-        X3P_ITER(kb, 0, NS - 1)
-        X3P_SLICE(sl)
-        X3P_ITER(kb + 1, NS - 1, 0)
-        X3P_SLICE(sl + 1)
-        kb += 2;
-      }
-      pend = false;
-    }
-    for (; kb < nst; kb += 2) {
-      X3P_ITER(kb, 0, NS - 1)
-      if (kb + 1 < nst) X3P_ITER(kb + 1, NS - 1, 0)
-    }
-    if (tile_no == 0) x3p_stamp(g, 2);
     // next tile: its stage 0 is requested before this tile's stores go out
     const int em0 = m0, en0 = n0;
     loc += stride;
@@ -703,38 +599,9 @@ void x3p_db_kernel(X3P g) {
       X3P_TILE(loc)
       X3P_LOAD(0, 0)
     }
-    if (DRIP && more) {                      // stored while the next tile is multiplied
-#pragma unroll
-      for (int i = 0; i < (DRIP ? TM : 0); ++i)
-#pragma unroll
-        for (int j = 0; j < (DRIP ? TN : 0); ++j) pacc[i][j] = acc[i][j];
-      pm0 = em0;
-      pn0 = en0;
-      pend = true;
-    } else if (!(ABL & 16)) x3p_epilogue<TM, TN, BAL || (TM == 1 && TN == 2), BAL>(g, acc, epi_smem, em0, en0, wrb, wcb, wave, lane, !DRIP);
-    else {                                   // keep every product alive
-      float chk = 0.f;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) chk += acc[i][j][r];
-      if (chk == 12345.678f) g.C[0] = chk;
-    }
-    if (tile_no == 0) x3p_stamp(g, 3);
-    ++tile_no;
+    x3p_epilogue<TM, TN, BAL || (TM == 1 && TN == 2), BAL>(g, acc, smem, em0, en0, wrb, wcb, wave, lane, true);
     if (!more) break;
-    __syncthreads();     // stage buffers (and, without DRIP, the epilogue scratch in them) are free
-  }
-#undef X3P_SLICE
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  x3p_stamp(g, 4);
-  if (DIAG && g.stamps && lane == 0) {
-    unsigned long long* d = g.stamps + ((long)gridDim.x + (long)blockIdx.x * 4 + wave) * 8;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) d[k] = dg[k];
-    d[5] = (unsigned long long)tile_no * nst;      // iterations measured (+1: the last is not folded)
+    __syncthreads();     // the stage buffers (and the epilogue scratch in them) are free
   }
 #undef X3P_ITER
 #undef X3P_TERM
@@ -1052,13 +919,10 @@ void launch_x3p(X3P& g, hipStream_t st) {
     const int per_cu = wgs > 0 ? wgs : g.wgs_per_cu > 0 ? g.wgs_per_cu : (TM * TN >= 4 ? 2 : TM * TN >= 2 ? 3 : 4);
     const int cap = 256 * per_cu;
     const int grid = std::min(((total + 7) / 8) * 8, cap);
-    const bool drip = NP == 3 && g.drip == 1 && ((g.K + 15) >> 4) >= 2 * TM * TN && grid < total;
     if (g.bal_stats)
-      X3P_LAUNCH((x3p_db_kernel<TM, TN, false, 0, false, true, NP>), grid, 256, 0);
-    else if (drip)
-      X3P_LAUNCH((x3p_db_kernel<TM, TN, false, 0, (NP == 3)>), grid, 256, 0);
+      X3P_LAUNCH((x3p_db_kernel<TM, TN, true, NP>), grid, 256, 0);
     else
-      X3P_LAUNCH((x3p_db_kernel<TM, TN, false, 0, false, false, NP>), grid, 256, 0);
+      X3P_LAUNCH((x3p_db_kernel<TM, TN, false, NP>), grid, 256, 0);
   }
 }
 
@@ -1078,7 +942,6 @@ int pick_tile(int M, int N) {
 
 }  // namespace
 
-static unsigned long long* g_stamps = nullptr;
 static int g_arith_forced = 0;
 
 extern "C" {
@@ -1119,14 +982,6 @@ int s2t_gemm_arith(void) { return s2t_gemm_arith_of(g_cls); }
 int s2t_gemm_arith_set(int arith) {
   if (arith != 0 && arith != 2 && arith != 3) return -1;
   g_arith_forced = arith;
-  return 0;
-}
-
-// diagnostics: buf (DEVICE, >= 8 * grid u64) or NULL -- later s2t_gemm_x3p launches record
-// per-workgroup s_memtime stamps {start, first stage staged, main loop done, epilogue issued,
-// stores drained, -, HW_ID[19:4], XCC_ID} (tools/x3p_stamps.py)
-int s2t_x3p_debug_stamps(void* buf) {
-  g_stamps = reinterpret_cast<unsigned long long*>(buf);
   return 0;
 }
 
@@ -1184,20 +1039,18 @@ int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int 
   if (act_kind < 0 || act_kind > 2 || act2 < 0 || act2 > 3 || (act_src && act_kind == 0) ||
       (C2 && act2 == 0) || (act2 == 3 && (!C2 || !resid_b)))
     return -1;
-  // tile = 1000 drip + 100 wgs + (10 tm + tn): drip = epilogue slices under the next tile, wgs =
-  // persistent workgroups per CU (0 = default)
-  // (2000 + 100 ks + tm tn: the LDS-DMA form at its own occupancy; ks = 2: 32-deep barrier intervals,
-  //  two-piece arithmetic only)
+  // tile = 100 wgs + (10 tm + tn): the register-staged form, wgs = persistent workgroups per CU (0 =
+  // default); 2000 + 100 ks + tm tn: the LDS-DMA form at its own occupancy, ks = 2: 32-deep barrier
+  // intervals (two-piece arithmetic only)
   const int arith = s2t_gemm_arith();
+  if (tile < 0 || (tile >= 1000 && tile < 2000) || tile >= 3000) return -1;
   int dma = tile / 1000 == 2;
-  const int drip = dma ? 0 : tile / 1000;
   const int wgs = (tile / 100) % 10;
   tile %= 100;
-  if ((tile != 0 && tile != 11 && tile != 12 && tile != 21 && tile != 22 && tile != 33) || wgs < 0 || wgs > 8 ||
-      drip < 0 || drip > 1 || (dma && (tile == 0 || tile == 33 || wgs > 2)))
+  if ((tile != 0 && tile != 11 && tile != 12 && tile != 21 && tile != 22) || wgs > 8 ||
+      (dma && (tile == 0 || wgs > 2)))
     return -1;
   if (dma && wgs == 2 && arith != 2) return -2;      // (the plan's candidate list follows the arithmetic)
-  if (drip && arith != 3) return -2;
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   if ((K & 7) || (N & 3) || (lda & 3) || (ldc & 3) || !al16(A) || !al16(Bp) || !al16(C) ||
       (bias && !al16(bias)) || (resid && (!al16(resid) || (ldr & 3))) ||
@@ -1211,11 +1064,11 @@ int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int 
     return -2;
   if (act_src && resid && resid_b) return -2;        // two operand slots
   X3P g{A, lda, Bp, (N + 31) / 32, 2 * ((K + 31) / 32), C, ldc, M, N, K, bias, {nullptr, nullptr},
-        {0, 0}, {0, 0}, act_kind, C2, ldc2, act2, 0, 0, wgs, 0, g_stamps, drip, 0,
+        {0, 0}, {0, 0}, act_kind, C2, ldc2, act2, 0, 0, wgs, 0,
         nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, g_sq.sums, 0.f, X3PMap{0, 1, 1, 0, 0, 0, 0},
         X3PMap{0, 1, 1, 0, 0, 0, 0}, 1, 1, {0, 0, 0, 0}, 0};
   if (g_bal.stats) {
-    if (!act_src || N > 1024 || tile == 33 || drip) return -2;
+    if (!act_src || N > 1024) return -2;
     g.bal_stats = g_bal.stats;
     g.bal_n = g_bal.n;
     g.bal_min_mean = g_bal.min_mean;
@@ -1230,14 +1083,9 @@ int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int 
     if (resid) { g.op[k] = resid; g.ldop[k] = ldr; g.role[k++] = 2; }
     if (resid_b) { g.op[k] = resid_b; g.ldop[k] = ldrb; g.role[k++] = 3; }
     if (g_sq.sums) {                     // the companion matrix: read for its squares only (role 4)
-      if (k > 1 || drip || !g_sq.other) return -2;
+      if (k > 1 || !g_sq.other) return -2;
       g.op[k] = g_sq.other; g.ldop[k] = g_sq.ld; g.role[k++] = 4;
     }
-  }
-  {
-    static int stg = -1;       // S2T_X3P_STAGGER: start delay per workgroup slot, units of 64 cycles
-    if (stg < 0) { const char* e = getenv("S2T_X3P_STAGGER"); stg = e ? atoi(e) : 0; }
-    g.stagger = stg;
   }
   {
     static int prio = -1;      // S2T_X3P_PRIO=0: no slot priority
@@ -1266,7 +1114,6 @@ int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int 
       ++g_samp.launches;
     }
   }
-  if (tile == 33) return -2;                        // (the producer / consumer form: removed in round 5)
   if (dma && g.bal_stats && arith != 2) dma = 0;    // (three pieces: the Balancer epilogue lives in the register-staged form)
   if (dma && arith == 2 && wgs == 2) {              // 32-deep intervals: 64 / 48 / 48 / 32 KB of LDS
     switch (tile) {
@@ -1380,7 +1227,7 @@ int s2t_gemm_x3p_map(const float* A, const S2tRowMap* amap, int seg, int nseg, c
     if (segoff[i] & 3) return -2;
   const int K = seg * nseg;
   X3P g{A, 0, Bp, (N + 31) / 32, 2 * ((K + 31) / 32), C, ldc, M, N, K, bias, {nullptr, nullptr},
-        {0, 0}, {0, 0}, 0, nullptr, 0, 0, 0, 0, 0, 0, nullptr, 0, 0,
+        {0, 0}, {0, 0}, 0, nullptr, 0, 0, 0, 0, 0, 0,
         nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, nullptr, 0.f,
         X3PMap{1, amap->hw, amap->w, amap->sb, amap->sh, amap->sw, amap->base},
         cmap ? X3PMap{1, cmap->hw, cmap->w, cmap->sb, cmap->sh, cmap->sw, cmap->base} : X3PMap{0, 1, 1, 0, 0, 0, 0},
@@ -1448,7 +1295,7 @@ int s2t_gemm_x3p_sq(const float* A, long lda, const unsigned short* Bp, int N, i
   g_sq.other = other;
   g_sq.ld = ld_other;
   const int rc = s2t_gemm_x3p(A, lda, Bp, N, K, C, ldc, M, bias, nullptr, 0, nullptr, 0, 0, nullptr, 0, 0, nullptr,
-                              0, tile / 1000 == 1 ? tile % 1000 : tile, stream);      // (no sliced epilogue here)
+                              0, tile, stream);
   g_sq.sums = nullptr;
   return rc;
 }

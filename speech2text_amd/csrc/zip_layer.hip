@@ -395,16 +395,7 @@ int whiten_bwd(Ctx& c, int site, const S2tZlWh& w, WStat& s, const float* x, lon
   // gradients instead (experiment: which of the two statistics products needs the six-product form)
   static const int pg_cls = [] { const char* e = getenv("S2T_WHITEN_PG_CLS"); return e ? atoi(e) : 3; }();
   const S2tGemmClass cls(pg_cls);
-  bool done = false;
-  const S2tZlWhScratch* sc = wh_scratch(c, C);
-  if (c.c.whiten_x3p == 1 && c.c.x3p_on && R >= c.c.whiten_x3p_rows && sc && sc->buf && C >= 16 && (C & 7) == 0) {
-    RUN(s2t_x3p_split(dcov, sc->tab, 1, sc->blocks, sc->buf, (void*)c.st));
-    const int rc = s2t_gemm_x3p(x, ldx, sc->buf, C, C, pg, C, (int)R, bias, nullptr, 0, nullptr, 0, 0, nullptr,
-                                0, 0, nullptr, 0, c.c.x3p_tile, (void*)c.st);
-    if (rc == 0) done = true;
-    else if (rc != -2) return fail(rc, "s2t_gemm_x3p(whiten)");
-  }
-  if (!done && c.c.whiten_sq) {      // the two norms of (g, pg) from the product's own epilogue
+  if (c.c.whiten_sq) {               // the two norms of (g, pg) from the product's own epilogue
     const int rc = s2t_gemm_f32_sq(1, x, ldx, dcov, C, pg, C, (int)R, C, C, bias, g, C, sums, (void*)c.st);
     if (rc == 0) {
       RUN(s2t_whiten_combine(g, pg, R * C, w.grad_scale, sums, o, (void*)c.st));
@@ -413,9 +404,8 @@ int whiten_bwd(Ctx& c, int site, const S2tZlWh& w, WStat& s, const float* x, lon
     }
     if (rc != -2) return fail(rc, "s2t_gemm_f32_sq(whiten)");
   }
-  if (!done)
-    RUN(s2t_gemm_f32(1, x, ldx, dcov, C, pg, C, (int)R, C, C, bias, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, 0,
-                     (void*)c.st));
+  RUN(s2t_gemm_f32(1, x, ldx, dcov, C, pg, C, (int)R, C, C, bias, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, 0,
+                   (void*)c.st));
   RUN(s2t_whiten_apply(g, pg, R * C, w.grad_scale, sums, o, (void*)c.st));
   *out = o;
   return 0;

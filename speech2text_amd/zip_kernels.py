@@ -415,14 +415,11 @@ class WhitenStats:
 # (round 5: off -- the NN kernel that takes the two norms in its epilogue (below) beats the bf16x3
 # product + a separate norm pass also for the 31 680-row activations: 37.61 against 37.72 ms/step)
 # (round 6: 2 = dcov and its pieces taken in forward on the statistics' stream, backward = the penalty
-# product on the pre-split-weight kernel with the two norms in its epilogue + the combining pass; 1 = the
-# round-5 on-the-spot split + plain product; 0 = the NN kernel with the norms in its epilogue)
+# product on the pre-split-weight kernel with the two norms in its epilogue + the combining pass; 0 = the
+# three-launch form on the NN kernel -- also what shapes outside the pre-split kernel's rules take)
 _WHITEN_X3P = int(os.environ.get("S2T_WHITEN_X3P", "2"))
 # the norms of (g, x dcov) taken in the product's epilogue (s2t_gemm_f32_sq) instead of by a pass over both
 _WHITEN_SQ = os.environ.get("S2T_WHITEN_SQ", "1") == "1"
-# measured (tools/bench_side.py whiten): 73 against 94 us at 31 680 x 192, but 62 against 58 at
-# 15 872 x 256 (the piece-split launch costs what the faster product saves)
-_WHITEN_X3P_ROWS = int(os.environ.get("S2T_WHITEN_X3P_ROWS", "24000"))
 
 
 _WHITEN_PG_CLS = int(os.environ.get("S2T_WHITEN_PG_CLS", "3"))   # class of the penalty product, three-launch form (csrc/zip_layer.hip whiten_bwd)
@@ -472,13 +469,7 @@ def whiten_backward(x, g, stats, limit, grad_scale):
     xf = x.reshape(-1, C)
     if xf.dtype != torch.float32:
         xf = xf.float()
-    # pg = x dcov + bias: for long activations on our bf16x3 kernel, with dcov's pieces written on the
-    # spot; the library's fp32 kernels otherwise
     pg = None
-    if _WHITEN_X3P == 1 and X3P["on"] and xf.stride(1) == 1 and xf.shape[0] >= _WHITEN_X3P_ROWS:
-        pp = planes.adhoc_pieces(dcov, 1)
-        if pp is not None:
-            pg = x3p_matmul(1, xf, dcov, bias, pp=pp, cls=_WHITEN_PG_CLS)
     g2 = g.contiguous().float()
     if g2.data_ptr() % 16:
         g2 = g2.clone()

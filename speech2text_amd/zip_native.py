@@ -88,7 +88,7 @@ class Call(ctypes.Structure):
                 ("bal_ws", c_fp), ("layer_acc", c_fp), ("wh", WhScratch * 8), ("nwh", ctypes.c_int),
                 ("lt_ws", c_fp), ("lt_ws_bytes", ctypes.c_long),
                 ("x3p_on", ctypes.c_int), ("x3p_tile", ctypes.c_int), ("x3p_margin", ctypes.c_float),
-                ("whiten_x3p", ctypes.c_int), ("whiten_x3p_rows", ctypes.c_long),
+                ("whiten_x3p", ctypes.c_int),
                 ("conv_w_side", ctypes.c_int), ("conv_fused", ctypes.c_int), ("stats_side", ctypes.c_int),
                 ("wgrad_side", ctypes.c_int), ("bmm_own", ctypes.c_int), ("bal_epi", ctypes.c_int),
                 ("whiten_sq", ctypes.c_int)]
@@ -343,7 +343,7 @@ def _fill_call(L, T, B, D, chunk_size, x0, pos2, a8, k8, fm, dec, dev):
     ws = zk._lt_workspace(dev)
     c.lt_ws, c.lt_ws_bytes = ws.data_ptr(), ws.numel()
     c.x3p_on, c.x3p_tile, c.x3p_margin = int(zk.X3P["on"]), int(zk.X3P["tile"]), float(zk.X3P["margin"])
-    c.whiten_x3p, c.whiten_x3p_rows = int(zk._WHITEN_X3P), int(zk._WHITEN_X3P_ROWS)
+    c.whiten_x3p = int(zk._WHITEN_X3P)
     side = zk._Side.enabled
     c.conv_w_side = int(zk._CONV_W_SIDE and side)
     c.conv_fused = 0                      # (the one-kernel conv backward: removed in round 5)

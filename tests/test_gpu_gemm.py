@@ -36,13 +36,14 @@ def arith(request):
     L.s2t_gemm_arith_set(0)
 
 
-def _x3p_tiles(drip=True):
-    """Tile codes of s2t_gemm_x3p the current arithmetic serves: block tiles, workgroups per CU, the
-    sliced epilogue (three pieces only), the LDS-DMA form and its 32-deep intervals (two pieces only)."""
-    base = [0, 22, 21, 12, 11, 2022, 2021, 2012, 2011]
+def _x3p_tiles():
+    """Tile codes of s2t_gemm_x3p the current arithmetic serves: block tiles of the register-staged form
+    (+ 100 w: w workgroups per CU), the LDS-DMA form (2000 +) and its 32-deep intervals (2200 +: two
+    pieces only)."""
+    base = [0, 22, 21, 12, 11, 322, 2022, 2021, 2012, 2011]
     if ARITH[0] == 3:
-        return base + ([1111, 1112, 1121, 1122, 1211] if drip else [])
-    return base + [322, 2222, 2221, 2212, 2211]
+        return base
+    return base + [2222, 2221, 2212, 2211]
 
 
 def _gemm(mode, A, B, C, M, Nn, K, bias=None, resid=None, act_src=None, act_kind=0, pro_a=0, pro_b=0,
@@ -376,9 +377,8 @@ def test_x3p_gemm_has_fp32_accuracy(dev, M, K, N):
     for mode, a, bias, res, ref, lib in ((0, x, b, r0, ref0, lib0), (1, gy, None, r1, ref1, lib1)):
         scale = ref.abs().max().item()
         e_lib = (lib - ref).abs().max().item() / scale
-        # (1000 + 100 w + tile: w persistent workgroups per CU, the output of a tile stored in
-        # slices under the next tile's multiplications -- active where a workgroup gets > 1 tile)
-        # 2000 + tile: the LDS-DMA form (weight pieces global -> LDS directly; 3 / 4 / 4 / 5 workgroups per CU)
+        # (100 w + tile: w persistent workgroups per CU; 2000 + tile: the LDS-DMA form, weight pieces
+        #  global -> LDS directly, 3 / 4 / 4 / 5 workgroups per CU; 2200 + tile: its 32-deep intervals)
         for tile in _x3p_tiles():
             y = zk.x3p_matmul(mode, a, W, bias, res, tile=tile)
             kc = N if mode == 1 else K
@@ -398,8 +398,7 @@ def test_x3p_fused_epilogues(dev):
     M, K, N = 3001, 256, 768
     g, W, b, store = _x3p_case(dev, M, K, N)
     x = torch.randn(M, K, generator=g).to(dev)
-    # every epilogue feature through the sliced (drip) epilogue too: M large enough for > 1 tile
-    # per workgroup at one workgroup per CU
+    # every epilogue feature with > 1 tile per persistent workgroup too (M = 40 000)
     Mb = 40000
     xb = torch.randn(Mb, K, generator=g).to(dev)
     rb = torch.randn(Mb, N, generator=g).to(dev)
@@ -600,7 +599,7 @@ def test_x3p_balancer_epilogue_matches_two_pass_update(dev, kind):
                                   stats.data_ptr(), off, Nt.stream()), "apply")
     assert (ref - plain).abs().max() > 1e-3 * plain.abs().max()     # the update is really there
     pp = planes.pieces(Wt, 1)
-    for tile in _x3p_tiles(drip=False):
+    for tile in _x3p_tiles():
         y = torch.empty_like(plain)
         rc = L.s2t_gemm_x3p_bal(gy.data_ptr(), K, ctypes.c_void_p(pp), N, K, y.data_ptr(), N, M, None, 0,
                                 h.data_ptr(), N, 1 if kind == "swoosh_l" else 2, tile, stats.data_ptr(), *cfg,

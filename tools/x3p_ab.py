@@ -11,7 +11,7 @@ from tools.bench_gemm import timeit
 dev = torch.device("cuda")
 SH = [(31680, 512, 192), (31680, 192, 512), (15872, 768, 256), (15872, 256, 768), (15872, 256, 256),
       (7936, 768, 256), (7936, 256, 768), (3968, 768, 256), (3968, 256, 960)]
-CF = [int(t) for t in os.environ.get("X3P_CF", "0,222,321,312,411,1212,1221,1211").split(",")]
+CF = [int(t) for t in os.environ.get("X3P_CF", "0,222,321,312,411,2022,2021,2012").split(",")]
 torch.manual_seed(0)
 ws = {(n, k): torch.nn.Parameter(torch.randn(n, k, device=dev) * 0.1) for (_, n, k) in SH}
 store = flat.FlatStore(list(ws.values()))
