@@ -31,7 +31,7 @@ cat gpurun_out/${TAG}_fetch_calibration.txt
 rm -rf gpurun_out/cal_FETCH_SIZE gpurun_out/cal_WRITE_SIZE
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_${TAG}_$C
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_$C -o pmc -- python3 bench.py --config $CFG --steps 1 --warmup 5 --sample-every 1 --roofline-kernel s2t_gemm_x3p --no-cpu-baseline --profile-steps 0 > gpurun_out/pmc_${TAG}_$C.json 2> gpurun_out/pmc_${TAG}_$C.err
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_$C -o pmc -- python3 bench.py --config $CFG --steps 2 --warmup 5 --sample-every 1 --roofline-kernel s2t_gemm_x3p --no-cpu-baseline --profile-steps 0 > gpurun_out/pmc_${TAG}_$C.json 2> gpurun_out/pmc_${TAG}_$C.err
   echo "$C rc=$?"
   find gpurun_out/pmc_${TAG}_$C -name "*kernel_trace.csv" -delete
 done
