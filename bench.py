@@ -454,8 +454,12 @@ def gemm_arith_classes():
     gradient, weight gradient, statistics)."""
     from speech2text_amd import zip_kernels as zk
     return zk.gemm_arith_policy()[1]
-BF16X3_ENTRIES = ("s2t_gemm_x3p", "s2t_gemm_x3p_bal", "s2t_gemm_x3p_map", "s2t_gemm_tn_grouped", "s2t_gemm_f32", "s2t_gemm_f32_sq",
-                  "s2t_gemm_xtx", "s2t_conv3x3_gemm")
+BF16X3_ENTRIES = ("s2t_gemm_x3p", "s2t_gemm_x3p_bal", "s2t_gemm_x3p_map", "s2t_gemm_x3p_sq", "s2t_gemm_tn_grouped",
+                  "s2t_gemm_f32", "s2t_gemm_f32_sq", "s2t_gemm_xtx", "s2t_conv3x3_gemm", "s2t_gemm_f32_batched")
+# the class of product an entry (mostly) serves -- its ceiling is that class's arithmetic (the x3p entries
+# serve forward AND data-gradient products: the higher ceiling of the two, gemm_arith())
+ENTRY_CLASS = {"s2t_gemm_xtx": "S", "s2t_gemm_f32_sq": "S", "s2t_gemm_tn_grouped": "W", "s2t_gemm_f32": "W",
+               "s2t_conv3x3_gemm": "W", "s2t_gemm_x3p_sq": "D"}
 
 
 def _bound(p):
@@ -469,6 +473,14 @@ def roofline_report(prof_timed, prof_all, want, step_flops, ms_per_step, sampled
     `prof_all`: every hand-written entry point, timed over extra (untimed) steps."""
     table = []
     arith_name, ceiling = gemm_arith()
+    classes = gemm_arith_classes()
+
+    def ceiling_of(entry):
+        c = ENTRY_CLASS.get(entry)
+        if c is None:
+            return ceiling
+        return BF16X3_CEILING_TFLOPS if classes[c] == "bf16x3/6" else BF16X2_CEILING_TFLOPS
+
     for name, p in sorted(prof_all.items(), key=lambda kv: -kv[1]["total_ms"]):
         row = {"entry": name, "launches_per_step": p["launches_per_step"],
                "ms_per_step": p["ms_per_step"], "avg_us": 1000.0 * p["avg_ms"]}
@@ -479,7 +491,7 @@ def roofline_report(prof_timed, prof_all, want, step_flops, ms_per_step, sampled
                 tf = p["algo_flops"] / (p["total_ms"] * 1e-3) / 1e12
                 row.update(alg_TFLOPs=tf, frac_mfma=tf / MFMA_F32_PEAK_TFLOPS)
                 if name in BF16X3_ENTRIES:
-                    row.update(frac_bf16_ceiling=tf / ceiling)
+                    row.update(frac_bf16_ceiling=tf / ceiling_of(name))
         table.append(row)
     out = {"bound": "hbm", "kernel": want, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": None, "traffic": None}
