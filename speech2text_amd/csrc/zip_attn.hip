@@ -1211,233 +1211,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_mfma_kernel(AttnArgs a,
   }
 }
 
-// ---- dq, dp, dk and the dpos partials of one (b, h) slab in ONE pass over W (round 6; reference
-// model/encoder/zipformer.py:1966-2066 under loss.backward()).  The pair above reads every W tile (and
-// head 0's dW tile) twice and forms dS twice -- once per owner (query rows / keys).  Here a workgroup
-// of 8 waves owns the whole slab: wave w walks the key blocks for query block 8 pass + w exactly as
-// attn_bwd_q_mfma_kernel does (K / V / position window staged once per key block for all eight
-// waves), and the tile's dS -- still in its accumulator registers -- is ALSO the A operand of
-// dk[j] += dS^T q_i, whose 32 x 32 result is added into the slab's dk held in LDS (T x 33 floats:
-// ds_add_f32; eight waves add into the same key block at the same moment, which the LDS unit
-// serialises: 128 instructions per key-block step against 8 x 44 MFMAs).  One read of W, NS + 32
-// MFMAs per tile instead of 2 NS + 32.  dk leaves once, when the slab is done.  Needs the slab's dk
-// in LDS: 128 < T <= 512 (the T = 495 / 248 stacks; shorter sequences leave most of the eight waves
-// idle and keep the pair, longer ones too).  LDS is carved from one dynamic array (> 64 KB).
-constexpr int SLAB_NW = 4;            // waves per slab workgroup (see the kernel's header)
-template <int PD>
-constexpr int slab_lds_floats(int T32) {
-  return 2 * 32 * 33 + (SLAB_NW * 32 + 32) * PD + SLAB_NW * 32 * 33 + SLAB_NW * 32 * PD + SLAB_NW * 32 +
-         SLAB_NW * 32 * (AM_MAXT / 32) + T32 * 33;
-}
-template <int NS, int PD>
-__global__ __launch_bounds__(64 * SLAB_NW, 1) void attn_bwd_slab_kernel(AttnArgs a, const float* __restrict__ W,
-                                                              const float* __restrict__ delta,
-                                                              float* __restrict__ dqkp, float* __restrict__ ws,
-                                                              float* __restrict__ zero_buf, int zero_n) {
-  constexpr int NSA = NS > 0 ? NS : 1;
-  constexpr int NW = SLAB_NW, NT = 64 * NW, QR = 32 * NW, WIN = QR + 32;
-  constexpr int NPQ = (WIN * PD + NT - 1) / NT, NKV = 32 * 32 / NT;
-  extern __shared__ __attribute__((aligned(16))) unsigned char slab_sm[];
-  float* cur = reinterpret_cast<float*>(slab_sm);
-  float (*s_K)[33] = reinterpret_cast<float (*)[33]>(cur);                 cur += 32 * 33;   // K[j0+jj][d]
-  float (*s_V)[33] = reinterpret_cast<float (*)[33]>(cur);                 cur += 32 * 33;   // V_cat[j0+jj][k]
-  float (*s_pos)[PD] = reinterpret_cast<float (*)[PD]>(cur);               cur += WIN * PD;  // pos window
-  float (*s_t)[32][33] = reinterpret_cast<float (*)[32][33]>(cur);         cur += NW * 32 * 33;   // per-wave dS tile
-  float (*s_P)[32][PD] = reinterpret_cast<float (*)[32][PD]>(cur);         cur += NW * 32 * PD;   // per-wave p rows
-  float (*s_ndl)[32] = reinterpret_cast<float (*)[32]>(cur);               cur += NW * 32;
-  unsigned (*s_mq)[32][AM_MAXT / 32] = reinterpret_cast<unsigned (*)[32][AM_MAXT / 32]>(cur);
-  cur += NW * 32 * (AM_MAXT / 32);
-  float* const s_dk = cur;                                                 // [T32][33]
-  // the position-gradient accumulator of the reduce pass that follows is cleared here (not read by this kernel)
-  for (int i = blockIdx.x * NT + threadIdx.x; i < zero_n; i += gridDim.x * NT) zero_buf[i] = 0.f;
-  const int slab = blockIdx.x;
-  if (slab >= a.B * a.H) return;
-  const int b = slab % a.B, h = slab / a.B;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
-  const float* Wb = W + ((long)h * a.B + b) * a.T * a.T;
-  const float* dWb = a.dW ? a.dW + ((long)h * a.B + b) * a.T * a.T : nullptr;
-  const float* dW0b = (a.dW0 && h == 0) ? a.dW0 + (long)b * a.T * a.T : nullptr;
-  const float* dlb = delta + ((long)h * a.B + b) * a.T;
-  const int qd = a.qd, pd = a.pd;
-  const int nj = (a.T + 31) / 32;
-  const bool want_pos = a.pos != nullptr;
-  const bool mbit = a.amask != nullptr && a.T <= AM_MAXT;
-  const int Dp = a.H * (2 * qd + pd);
-  for (int i = tid; i < nj * 32 * 33; i += NT) s_dk[i] = 0.f;
-  for (int pass = 0; pass * QR < a.T; ++pass) {
-    const int ib0 = pass * QR;
-    const int i0 = ib0 + wave * 32;
-    const bool live = i0 < a.T;
-    // ---- this wave's query block: dO rows (A fragments of the dW recompute), -delta, p rows, mask bits,
-    // q values in the B-operand layout of the dk product (row acc_row(r, hi), column lo)
-    float af[NSA], qv[16];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) af[s] = pair_elem(a, a.pdO, i0 + lo, b, h, hi + 2 * s);
-    if (lane < 32) s_ndl[wave][lane] = -dlb[min(i0 + lane, a.T - 1)];
-    for (int idx = lane; idx < 32 * PD; idx += 64) {
-      const int rr = idx / PD, d = idx % PD;
-      s_P[wave][rr][d] = (i0 + rr < a.T && d < pd) ? p_row(a, i0 + rr, b, h)[d] : 0.f;
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = i0 + acc_row(r, hi);
-      qv[r] = (i < a.T && lo < qd) ? q_row(a, i, b, h)[lo] : 0.f;
-    }
-    if (mbit && live) {
-      for (int rr = 0; rr < 32; rr += 2) {
-        const unsigned char* am0 = a.amask + (long)min(i0 + rr, a.T - 1) * a.T;
-        const unsigned char* am1 = a.amask + (long)min(i0 + rr + 1, a.T - 1) * a.T;
-        unsigned char m0[AM_MAXT / 64], m1[AM_MAXT / 64];
-#pragma unroll
-        for (int q = 0; q < AM_MAXT / 64; ++q) {
-          m0[q] = am0[min(64 * q + lane, a.T - 1)];
-          m1[q] = am1[min(64 * q + lane, a.T - 1)];
-        }
-#pragma unroll
-        for (int q = 0; q < AM_MAXT / 64; ++q) {
-          const unsigned long long b0 = __ballot(m0[q] != 0), b1 = __ballot(m1[q] != 0);
-          if (lane == 0) {
-            s_mq[wave][rr][2 * q] = (unsigned)b0;
-            s_mq[wave][rr][2 * q + 1] = (unsigned)(b0 >> 32);
-            s_mq[wave][rr + 1][2 * q] = (unsigned)b1;
-            s_mq[wave][rr + 1][2 * q + 1] = (unsigned)(b1 >> 32);
-          }
-        }
-      }
-    }
-    f32x16 zq = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float dp[PD], dacc[PD];
-#pragma unroll
-    for (int d = 0; d < PD; ++d) dp[d] = dacc[d] = 0.f;
-    // register staging of the next key block
-    float rk[NKV], rv[NKV], rp[NPQ], wn[16];
-    auto fetch = [&](int j0) {
-#pragma unroll
-      for (int q = 0; q < NKV; ++q) {
-        const int idx = tid + NT * q, jj = idx >> 5, d = idx & 31;
-        rk[q] = (j0 + jj < a.T && d < qd) ? k_row(a, j0 + jj, b, h)[d] : 0.f;
-        rv[q] = (NS > 0 && d < 2 * NS) ? pair_elem(a, a.pV, j0 + jj, b, h, d) : 0.f;
-      }
-      if (want_pos) {
-        // window entry w <-> rel (T-1) - (ib0 + QR - 1) + j0 + w
-        const int base = (a.T - 1) - (ib0 + QR - 1) + j0;
-#pragma unroll
-        for (int q = 0; q < NPQ; ++q) {
-          const int idx = tid + NT * q, w = idx / PD, d = idx % PD;
-          const int rel = base + w;
-          rp[q] = (w < WIN && d < pd && rel >= 0 && rel < 2 * a.T - 1)
-                      ? a.pos[(long)rel * a.H * pd + h * pd + d] : 0.f;
-        }
-      }
-      if (live) load_tile16(Wb, a.T, i0, j0, lo, hi, wn);
-    };
-    fetch(0);
-    float* wsb = nullptr;
-    if (ws && live)
-      wsb = ws + ((((long)b * a.H + h) * nj + (i0 >> 5)) * (nj + 1)) * 32 * pd;
-    for (int jb = 0; jb < nj; ++jb) {
-      const int j0 = jb * 32;
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < NKV; ++q) {
-        const int idx = tid + NT * q, jj = idx >> 5, d = idx & 31;
-        s_K[jj][d] = rk[q];
-        s_V[jj][d] = rv[q];
-      }
-      if (want_pos) {
-#pragma unroll
-        for (int q = 0; q < NPQ; ++q) {
-          const int idx = tid + NT * q;
-          if (idx < WIN * PD) s_pos[idx / PD][idx % PD] = rp[q];
-        }
-      }
-      __syncthreads();
-      f32x16 ds;
-      if (live) {
-        float bf[NSA];
-#pragma unroll
-        for (int s = 0; s < NS; ++s) bf[s] = s_V[lo][hi + 2 * s];
-        f32x16 ndl;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ndl[r] = s_ndl[wave][acc_row(r, hi)];
-        ds = ds_tile<NS>(a, dWb, dW0b, b, i0, j0, lo, hi, af, bf, wn, ndl,
-                         mbit ? &s_mq[wave][0][min(jb, AM_MAXT / 32 - 1)] : nullptr, AM_MAXT / 32);
-      }
-      if (jb + 1 < nj) fetch(j0 + 32);   // lands while this tile's products run
-      if (!live) continue;
-      // dk[j][d] += sum_i dS[i][j] q[i][d]: A = dS registers (k = query row), B[k][n = d] = qv; into LDS
-      {
-        f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 16; ++s) z = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[s], qv[s], z, 0, 0, 0);
-        if (lo < qd) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) atomicAdd(&s_dk[(j0 + acc_row(r, hi)) * 33 + lo], z[r]);
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s_t[wave][acc_row(r, hi)][lo] = ds[r];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      float at[16];   // dS[i = lo][j = hi + 2s]
-#pragma unroll
-      for (int s = 0; s < 16; ++s) at[s] = s_t[wave][lo][hi + 2 * s];
-#pragma unroll
-      for (int s = 0; s < 16; ++s)
-        zq = __builtin_amdgcn_mfma_f32_32x32x2f32(at[s], s_K[hi + 2 * s][lo], zq, 0, 0, 0);
-      if (want_pos) {
-        // dp[i][d] += dS[i][j] pos[(T-1) - i + j][d]; window row = (QR - 1) - (i - ib0) + (j - j0)
-        const int w0 = (QR - 1) - (wave * 32 + lo) + hi;
-#pragma unroll 4
-        for (int s = 0; s < 16; ++s) {
-#pragma unroll
-          for (int d = 0; d < PD; ++d) dp[d] = fmaf(at[s], s_pos[w0 + 2 * s][d], dp[d]);
-        }
-        // dpos partial: lane u owns the diagonal j - i + 31 = u of this tile
-#pragma unroll 4
-        for (int ii = 0; ii < 32; ++ii) {
-          const int jj = ii + lane - 31;
-          float v = s_t[wave][ii][min(max(jj, 0), 31)];
-          v = (jj >= 0 && jj < 32) ? v : 0.f;
-#pragma unroll
-          for (int d = 0; d < PD; ++d) dacc[d] = fmaf(v, s_P[wave][ii][d], dacc[d]);
-        }
-        if (wsb) {
-          if (lane < 32)
-            for (int d = 0; d < pd; ++d) wsb[((long)jb * 32 + lane) * pd + d] = dacc[d];
-#pragma unroll
-          for (int d = 0; d < PD; ++d) {
-            const float up = __shfl(dacc[d], (lane + 32) & 63, 64);
-            dacc[d] = lane < 32 ? up : 0.f;
-          }
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-    }
-    if (live) {
-      if (want_pos && wsb && lane < 32)
-        for (int d = 0; d < pd; ++d) wsb[((long)nj * 32 + lane) * pd + d] = dacc[d];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = i0 + acc_row(r, hi);
-        if (i < a.T && lo < qd) dqkp[((long)i * a.B + b) * Dp + h * qd + lo] = zq[r];
-      }
-#pragma unroll
-      for (int d = 0; d < PD; ++d) dp[d] += __shfl_xor(dp[d], 32, 64);
-      if (hi == 0 && i0 + lo < a.T) {
-        float* o = dqkp + ((long)(i0 + lo) * a.B + b) * Dp + 2 * a.H * qd + h * pd;
-        for (int d = 0; d < pd; ++d) o[d] = want_pos ? dp[d] : 0.f;
-      }
-    }
-  }
-  __syncthreads();                                    // every wave's adds into s_dk are done
-  for (int idx = tid; idx < a.T * 32; idx += NT) {
-    const int j = idx >> 5, d = idx & 31;
-    if (d < qd) dqkp[((long)j * a.B + b) * Dp + a.H * qd + h * qd + d] = s_dk[j * 33 + d];
-  }
-}
-
 // dpos[rel][h][d] += sum over (b, query block) of the partial rows that map to rel
 __global__ __launch_bounds__(256) void attn_dpos_reduce_kernel(const float* __restrict__ ws, int T,
                                                                int B, int H, int pd,
@@ -1474,38 +1247,9 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict
   if (lane == 0) delta[row] = acc;
 }
 
-template <int NS, int PD>
-int launch_attn_bwd_slab(const AttnArgs& a, const float* W, const float* delta, float* dqkp, float* dpos,
-                         float* ws, hipStream_t st) {
-  const int T32 = ((a.T + 31) / 32) * 32;
-  const int lds = slab_lds_floats<PD>(T32) * (int)sizeof(float);
-  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_slab_kernel<NS, PD>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-  if (!ok || lds > 160 * 1024) return -3;
-  const int nz = (a.pos && a.pd > 0) ? (2 * a.T - 1) * a.H * a.pd : 0;
-  hipLaunchKernelGGL((attn_bwd_slab_kernel<NS, PD>), dim3(a.B * a.H), dim3(64 * SLAB_NW), lds, st, a, W, delta, dqkp,
-                     a.pos ? ws : nullptr, dpos, nz);
-  S2T_CHECK_LAUNCH();
-  if (a.pos && a.pd > 0) {
-    const int n = (2 * a.T - 1) * a.pd;
-    hipLaunchKernelGGL(attn_dpos_reduce_kernel, dim3((n + 255) / 256, a.H, a.B < 32 ? a.B : 32),
-                       dim3(256), 0, st, ws, a.T, a.B, a.H, a.pd, dpos);
-    S2T_CHECK_LAUNCH();
-  }
-  return 0;
-}
-
 template <int NS>
 int launch_attn_bwd_mfma(const AttnArgs& a, const float* W, const float* delta, float* dqkp,
                          float* dpos, float* ws, hipStream_t st) {
-  // one pass over W per (b, h) slab where its dk fits in LDS and the sequence gives the four waves a
-  // query block each (S2T_ATTN_BWD_SLAB=0: the two-kernel form everywhere, A/B and tests)
-  static const bool slab_on = [] { const char* e = getenv("S2T_ATTN_BWD_SLAB"); return !e || atoi(e) != 0; }();
-  if (slab_on && a.T > 96 && a.T <= 512) {
-    const int rc = a.pd <= 4 ? launch_attn_bwd_slab<NS, 4>(a, W, delta, dqkp, dpos, ws, st)
-                             : launch_attn_bwd_slab<NS, 8>(a, W, delta, dqkp, dpos, ws, st);
-    if (rc != -3) return rc;
-  }
   const dim3 gq(slab_grid((a.T + 127) / 128, a.B * a.H)), gk(slab_grid((a.T + 31) / 32, a.B * a.H));
   if (a.pd <= 4)
     hipLaunchKernelGGL((attn_bwd_q_mfma_kernel<NS, 4>), gq, dim3(256), 0, st, a, W, delta, dqkp,

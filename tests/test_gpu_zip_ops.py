@@ -263,14 +263,14 @@ def _attn_ref(qkp, pos, H, qd, pd, amask, kpm):
     (50, 2, 4, 8, 4, (12,), False, True), (130, 3, 4, 32, 4, (12, 12), True, False),
     (530, 2, 2, 32, 4, (16, 16), True, False), (77, 2, 4, 24, 4, (12, 12), True, True),
     (1, 2, 2, 8, 4, (12,), True, False), (33, 1, 8, 4, 4, (4, 12), False, False),
-    # the one-pass slab kernel (96 < T <= 512): the C3 stacks' shapes, ragged last passes, masks, pd 8
+    # the C3 stacks' shapes, ragged last passes, masks, pd 8
     (495, 2, 4, 32, 4, (12, 12), True, False), (248, 2, 4, 32, 4, (12, 12), True, True),
     (124, 2, 4, 32, 4, (12, 12), True, False), (300, 2, 8, 32, 8, (12, 12), False, True),
     (512, 1, 2, 16, 3, (16, 16), True, False), (97, 3, 2, 32, 4, (12,), True, True)])
 def test_relpos_attention_backward_factored(dev, T, B, H, qd, pd, dvs, use_dw0, use_am):
     """s2t_relpos_attn_bwd with dW given as factors (dO_c, V_c) + head-0 term + delta, against the
-    float64 autograd of the composed op with the same dW materialised.  T <= 96 and T > 512 take the
-    two-kernel form (query-owner + key-owner), the sequences between the one-pass slab kernel."""
+    float64 autograd of the composed op with the same dW materialised.  Two kernels (query-owner +
+    key-owner) at every length."""
     from speech2text_amd import zip_kernels as zk
     torch.manual_seed(T + 7)
     Dp = H * (2 * qd + pd)
