@@ -752,12 +752,14 @@ int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int 
  * in the epilogue (the hidden Balancer of FeedforwardModule / ConvolutionModule / ConvNeXt,
  * model/encoder/zipformer.py:2372-2378, 2643-2695, model/layer/subsampling.py:106-132; update rule
  * model/layer/scaling.py:741-789): C = act'(act_src) (A Bm^T) (+ resid), then C += |C| (a[c] + b[c]
- * act_src) with a, b derived from bal_stats = column sums [0..N) and sums of squares [1024..1024+N) of
- * act_src over its M rows (s2t_balancer_stats into a zeroed buffer).  Replaces the separate
- * s2t_balancer_apply pass over the (M, N) gradient.  -2: shape / tile outside the kernel's rules. */
+ * act_src) with a, b derived from bal_stats = 4096 floats: column sums [0..N) and sums of squares
+ * [1024..1024+N) of act_src over its M rows (s2t_balancer_stats into a zeroed buffer); the call writes
+ * the per-column a, b into [2048..) and [3072..) with one small launch before the product (N <= 1024).
+ * Replaces the separate s2t_balancer_apply pass over the (M, N) gradient.  -2: shape / tile outside the
+ * kernel's rules. */
 int s2t_gemm_x3p_bal(const float* A, long lda, const unsigned short* Bp, int N, int K, float* C, long ldc,
                      int M, const float* resid, long ldr, const float* act_src, long ld_act, int act_kind,
-                     int tile, const float* bal_stats, float min_mean, float max_mean, float min_rms,
+                     int tile, float* bal_stats, float min_mean, float max_mean, float min_rms,
                      float max_rms, float grad_scale, void* stream);
 
 /* s2t_gemm_x3p with IMPLICIT operands: C = A' Bm^T (+ bias[N]) where row r of A' is `nseg` (<= 4) segments

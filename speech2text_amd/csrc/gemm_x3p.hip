@@ -146,7 +146,7 @@ struct X3P {
   int prio;                   // 1: wave priority by the workgroup's slot on its CU (see x3p_set_prio)
   // Balancer update in the epilogue (s2t_gemm_x3p_bal): C = act'(S) (A Bm^T) is the gradient w.r.t. S
   // coming through the activation, and the Balancer on S (scaling.py:741-789 in closed form, as
-  // zip_elem.hip balancer_apply_fused_kernel) adds |C| (a[c] + b[c] S): bal_stats = [2][1024] column
+  // zip_elem.hip balancer_apply_fused_kernel) adds |C| (a[c] + b[c] S): bal_stats = [4][1024]: column
   // sums / sums of squares of S over bal_n rows, or NULL
   const float* bal_stats;
   float bal_n, bal_min_mean, bal_max_mean, bal_min_rms, bal_max_rms, bal_gs;
@@ -255,35 +255,45 @@ struct BalQ {
   f32x4 a, b;
 };
 __device__ __forceinline__ BalQ x3p_epi_balcoef(const X3P& g, int j, int n0, int wcb, int lane) {
+  // the per-column (a, b) of the update, computed once per launch by bal_coef_kernel into the
+  // second half of the caller's buffer (a tile computing them itself spent more cycles on the
+  // sqrt / log / divisions of its 64 columns than on a K = 128 main loop: the ConvNeXt data
+  // gradient took 1130 us with the Balancer against 570 without)
   BalQ r;
   r.a = r.b = f32x4{0.f, 0.f, 0.f, 0.f};
   const int col = n0 + 32 * (wcb + j) + (lane & 7) * 4;
   if (col >= g.N) return r;
-  const f32x4 sm = *reinterpret_cast<const f32x4*>(g.bal_stats + col);
-  const f32x4 sq = *reinterpret_cast<const f32x4*>(g.bal_stats + 1024 + col);
-  const float inv_n = 1.f / g.bal_n;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const float mean = sm[c] * inv_n, uvar = sq[c] * inv_n;
-    const float raw_var = uvar - mean * mean;
-    const bool live_v = raw_var > 1.0e-20f, live_r = uvar > 1.0e-20f;
-    const float var = fmaxf(raw_var, 1.0e-20f);
-    const float sd = sqrtf(var);
-    const float rms = sqrtf(fmaxf(uvar, 1.0e-20f));
-    const float m = mean / sd;
-    const float mc = fminf(fmaxf(m, g.bal_min_mean), g.bal_max_mean);
-    const float s_m = (m > mc) ? 1.f : ((m < mc) ? -1.f : 0.f);
-    const float rc = fminf(fmaxf(rms, g.bal_min_rms), g.bal_max_rms);
-    const float lq = logf(rc / rms);
-    const float s_r = (lq > 0.f) ? -1.f : ((lq < 0.f) ? 1.f : 0.f);
-    const float a = s_m * inv_n * (live_v ? (1.f / sd + mean * mean / (sd * var)) : 1.f / sd);
-    const float b = (live_v ? -s_m * inv_n * mean / (sd * var) : 0.f) + (live_r ? s_r * inv_n / (rms * rms) : 0.f);
-    const float lg_rms = fmaxf(sqrtf(fmaxf(a * a + 2.f * a * b * mean + b * b * uvar, 0.f)), 1.0e-20f);
-    const float coef = g.bal_gs / lg_rms;
-    r.a[c] = a * coef;
-    r.b[c] = b * coef;
-  }
+  r.a = *reinterpret_cast<const f32x4*>(g.bal_stats + 2048 + col);
+  r.b = *reinterpret_cast<const f32x4*>(g.bal_stats + 3072 + col);
   return r;
+}
+
+// stats [2][1024] (column sums | sums of squares over n rows) -> coefficients [2][1024] (a | b) of
+// model/layer/scaling.py:741-789 in closed form (zip_elem.hip balancer_apply_fused_kernel)
+__global__ __launch_bounds__(256) void bal_coef_kernel(const float* __restrict__ stats, float* __restrict__ coef,
+                                                        int N, float n, float min_mean, float max_mean,
+                                                        float min_rms, float max_rms, float gs) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= N) return;
+  const float inv_n = 1.f / n;
+  const float mean = stats[c] * inv_n, uvar = stats[1024 + c] * inv_n;
+  const float raw_var = uvar - mean * mean;
+  const bool live_v = raw_var > 1.0e-20f, live_r = uvar > 1.0e-20f;
+  const float var = fmaxf(raw_var, 1.0e-20f);
+  const float sd = sqrtf(var);
+  const float rms = sqrtf(fmaxf(uvar, 1.0e-20f));
+  const float m = mean / sd;
+  const float mc = fminf(fmaxf(m, min_mean), max_mean);
+  const float s_m = (m > mc) ? 1.f : ((m < mc) ? -1.f : 0.f);
+  const float rc = fminf(fmaxf(rms, min_rms), max_rms);
+  const float lq = logf(rc / rms);
+  const float s_r = (lq > 0.f) ? -1.f : ((lq < 0.f) ? 1.f : 0.f);
+  const float a = s_m * inv_n * (live_v ? (1.f / sd + mean * mean / (sd * var)) : 1.f / sd);
+  const float b = (live_v ? -s_m * inv_n * mean / (sd * var) : 0.f) + (live_r ? s_r * inv_n / (rms * rms) : 0.f);
+  const float lg_rms = fmaxf(sqrtf(fmaxf(a * a + 2.f * a * b * mean + b * b * uvar, 0.f)), 1.0e-20f);
+  const float k = gs / lg_rms;
+  coef[c] = a * k;
+  coef[1024 + c] = b * k;
 }
 
 // phase 1 of one slice: a[8 h .. 8 h + 7] (MFMA layout) -> the final values of this lane's two row
@@ -723,7 +733,9 @@ __global__ __launch_bounds__(256, WPC) void x3p_dma_kernel(X3P g) {
     long ko_ = 16L * KS * ss_;                                                               \
     if (MAP) {                         /* stage -> (segment, offset inside it): uniform */    \
       const int sg_ = ss_ / g.seg16;                                                         \
-      ko_ = g.segoff[sg_] + 16L * (ss_ - sg_ * g.seg16);                                     \
+      /* (selects, not g.segoff[sg_]: a dynamic index would put the array in scratch) */      \
+      const long so_ = sg_ == 0 ? g.segoff[0] : sg_ == 1 ? g.segoff[1] : sg_ == 2 ? g.segoff[2] : g.segoff[3]; \
+      ko_ = so_ + 16L * (ss_ - sg_ * g.seg16);                                               \
     }                                                                                        \
     _Pragma("unroll") for (int i = 0; i < NAU; ++i) {                                        \
       /* (a k tail is read from the row's start and zeroed when it is split) */              \
@@ -1258,14 +1270,16 @@ int s2t_gemm_x3p_map(const float* A, const S2tRowMap* amap, int seg, int nseg, c
 // s2t_gemm_x3p for the data gradient through an activation WITH the Balancer that sits on the
 // activation's input folded into the epilogue: C = act'(S) (A Bm^T), then C += |C| (a[c] + b[c] S)
 // with the per-channel a, b of model/layer/scaling.py:741-789 (closed form, zip_elem.hip) derived in
-// the epilogue from bal_stats = [2][1024] column sums / sums of squares of S over its M rows
-// (s2t_balancer_stats).  Replaces s2t_balancer_apply's pass over the (M, N) gradient.  act_src (= S)
+// the epilogue from bal_stats = [4][1024] floats: rows 0-1 column sums / sums of squares of S over its M
+// rows (s2t_balancer_stats), rows 2-3 written HERE (the per-column a, b: one small launch before the product).  Replaces s2t_balancer_apply's pass over the (M, N) gradient.  act_src (= S)
 // is required; N <= 1024.
 int s2t_gemm_x3p_bal(const float* A, long lda, const unsigned short* Bp, int N, int K, float* C, long ldc,
                      int M, const float* resid, long ldr, const float* act_src, long ld_act, int act_kind,
-                     int tile, const float* bal_stats, float min_mean, float max_mean, float min_rms,
+                     int tile, float* bal_stats, float min_mean, float max_mean, float min_rms,
                      float max_rms, float grad_scale, void* stream) {
-  if (!bal_stats || !act_src) return -1;
+  if (!bal_stats || !act_src || N > 1024) return -1;
+  hipLaunchKernelGGL(bal_coef_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, bal_stats,
+                     bal_stats + 2048, N, (float)M, min_mean, max_mean, min_rms, max_rms, grad_scale);
   g_bal.stats = bal_stats;
   g_bal.n = (float)M;
   g_bal.min_mean = min_mean;

@@ -231,7 +231,7 @@ int lt_matmul(Ctx& c, int mode, const float* x, long ldx, long R, const S2tZlLin
     }
   }
   if (e.bal && !c.c.bal_epi) own = false;          // (A/B switch: plain product + the two-pass update)
-  float* bstats = (e.bal && own) ? c.ar.alloc(2048) : nullptr;
+  float* bstats = (e.bal && own) ? c.ar.alloc(4096) : nullptr;      // sums | squares | a | b (s2t_gemm_x3p_bal)
   if (own && !c.dry && e.bal) {
     if (cols <= 1024) {
       HIPRUN(hipMemsetAsync(bstats, 0, 2048 * sizeof(float), c.st));

@@ -1471,7 +1471,7 @@ def _x3p_launch(mode, x2, w2, bias, resid2, act_src, act_kind, act2, tile, resid
         # Balancer on act_src in the epilogue: its column statistics first (one read of act_src)
         if act_src is None or bias is not None or out2 is not None or resid_b is not None or cols > 1024:
             return None
-        stats = torch.zeros(2048, dtype=torch.float32, device=x2.device)
+        stats = torch.zeros(4096, dtype=torch.float32, device=x2.device)      # sums | squares | a | b
         N.PROF[0] and N.profile_note("s2t_balancer_stats", 4.0 * act_src.numel())
         N.PROF[0] and N.profile_note("s2t_gemm_x3p_bal", 4.0 * R * (Nf + Kf + cols) + 6.0 * Nf * Kf, 2.0 * R * Nf * Kf)
         N.check(N.lib().s2t_balancer_stats(_vp(act_src), act_src.stride(0), R, cols, _vp(stats), N.stream()),
@@ -1950,7 +1950,10 @@ class _Conv3x3Nhwc(torch.autograd.Function):
             dwmat, db = linear_wgrad(g, xc, has_bias)                            # (Cout, 9C)
             dweight = dwmat.view(Cout, 3, 3, C).permute(0, 3, 1, 2)
         dx = None
-        if ctx.needs_input_grad[0] and ctx.implicit and 9 * C * Cout >= (1 << 18):
+        if ctx.needs_input_grad[0] and ctx.implicit and _CONV_MAP_DGRAD and (sh, sw) == (1, 2) and Cout % 16 == 0 \
+                and C >= 16 and g.numel() * 5 < (1 << 31):
+            dx = _conv3x3_s12_dgrad_map(g.view(B, Ho, Wo, Cout), weight.detach(), H, W)
+        elif ctx.needs_input_grad[0] and ctx.implicit and 9 * C * Cout >= (1 << 18):
             # wide channel counts (the conformer's 256 -> 256 stride-2 conv): the patch-space form
             # below would write and re-read a (rows, 9C) matrix (1.4 GB at C2) -- the library's
             # NHWC implicit-GEMM backward-data kernel serves this one product (measured: C2 step
@@ -1969,6 +1972,39 @@ class _Conv3x3Nhwc(torch.autograd.Function):
             N.check(N.lib().s2t_col2im3x3_nhwc(N.fp(dc), B, H, W, C, Ho, Wo, sh, sw, N.fp(dx),
                                                N.stream()), "s2t_col2im3x3_nhwc")
         return dx, dweight, db, None, None
+
+
+_CONV_MAP_DGRAD = os.environ.get("S2T_CONV_MAP_DGRAD", "1") == "1"
+_CONV_MAP_DGRAD_TILE = int(os.environ.get("S2T_CONV_MAP_DGRAD_TILE", "21"))
+
+
+def _conv3x3_s12_dgrad_map(g, wd, H, W):
+    """Data gradient of a 3x3 / stride-(1, 2) convolution on a channel-last map (the frontend's 32 -> 128
+    convolution, reference model/encoder/zipformer.py Conv2dSubsampling) in GATHER form on the implicit-
+    operand GEMM (s2t_gemm_x3p_map): no (rows, 9 C) patch-space matrix, no col2im pass.  Input pixels by
+    the parity of their column: an even column w = 2 jc receives the taps kw = 2 (from output column
+    jc - 1) and kw = 0 (from jc) of every kh -- two ADJACENT pixels of the zero-bordered gradient, one run
+    of 2 Cout floats per kh; an odd column receives kw = 1 (from jc), one run of Cout floats per kh.  One
+    launch per class: rows = (b, h, jc), K = 3 runs, output scattered to every second pixel of dx."""
+    B, Ho, Wo, Cout = g.shape
+    C = wd.shape[1]
+    gp = F.pad(g, (0, 0, 1, 1, 2, 2))                                      # rows -2 .. Ho + 1, columns -1 .. Wo
+    Wp = Wo + 2
+    dx = torch.empty((B, H, W, C), dtype=torch.float32, device=g.device)
+    for pw in (0, 1):
+        kws = (2, 0) if pw == 0 else (1,)
+        # (Cin, 3 * len(kws) * Cout): column (kh, kw, cout) = W[cout, cin, kh, kw]
+        bc = torch.cat([wd[:, :, kh, kw].t() for kh in (0, 1, 2) for kw in kws], dim=1).contiguous()
+        pp = planes.adhoc_pieces(bc, 0)
+        if pp is None:
+            raise RuntimeError("conv3x3 (map, stride 1x2): class weight outside the piece kernel's rules")
+        Wc = (W - pw + 1) // 2
+        amap = RowMap(H * Wc, Wc, (Ho + 4) * Wp * Cout, Wp * Cout, Cout, (2 * Wp + 1) * Cout)
+        segoff = [(-kh * Wp - (1 if pw == 0 else 0)) * Cout for kh in (0, 1, 2)]
+        cmap = RowMap(H * Wc, Wc, H * W * C, W * C, 2 * C, pw * C)
+        N.check(_x3p_map(gp, amap, len(kws) * Cout, segoff, pp, C, dx, C, cmap, dx.numel(), B * H * Wc, None,
+                         tile=_CONV_MAP_DGRAD_TILE), "s2t_gemm_x3p_map(dgrad 1x2)")
+    return dx
 
 
 class RowMap(ctypes.Structure):

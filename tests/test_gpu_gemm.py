@@ -592,7 +592,7 @@ def test_x3p_balancer_epilogue_matches_two_pass_update(dev, kind):
     L = Nt.lib()
     plain = zk.x3p_matmul(1, gy, Wt)
     assert plain is not None
-    stats = torch.zeros(2048, device=dev)
+    stats = torch.zeros(4096, device=dev)                 # sums | squares | a | b
     Nt.check(L.s2t_balancer_stats(h.data_ptr(), N, M, N, stats.data_ptr(), Nt.stream()), "stats")
     ref = torch.empty_like(plain)
     Nt.check(L.s2t_balancer_apply(h.data_ptr(), N, plain.data_ptr(), N, M, N, *cfg, ref.data_ptr(), N,

@@ -397,6 +397,7 @@ def test_linear_wgrad(dev, R, Nf, Mf, bias, stride_pad, request):
 
 
 @pytest.mark.parametrize("N_,H,W,C,K", [(3, 37, 19, 128, 7), (2, 9, 5, 70, 7), (5, 130, 19, 64, 3),
+                                        (2, 12, 8, 16, 3),    # (even width: the gather-form dgrad's last column)
                                         (1, 3, 5, 8, 3)])     # (one patch row per stride-2 conv: fallback paths)
 def test_dwconv2d_and_conv3x3_nhwc_vs_torch(dev, N_, H, W, C, K):
     """Channel-last frontend convolutions (zip_front.hip: depthwise stencil, its two-stage weight
@@ -449,9 +450,10 @@ def test_dwconv2d_and_conv3x3_nhwc_vs_torch(dev, N_, H, W, C, K):
         torch.testing.assert_close(wg.grad.cpu().double(), wr.grad, atol=2e-3, rtol=2e-4)
         torch.testing.assert_close(bg.grad.cpu().double(), br.grad, atol=2e-3, rtol=2e-4)
     # 3x3 conv: implicit-im2col MFMA GEMM forward / weight gradient (s2t_conv3x3_gemm), col2im
-    # gather for the input gradient; (6, 10): channel counts that take the materialised fallback
+    # gather for the input gradient -- stride (1, 2) with >= 16 input channels: the gather-form GEMM by
+    # column parity (s2t_gemm_x3p_map, no patch-space matrix); (6, 10): the materialised fallback
     for Cin, Cout, stride in ((8, 16, (1, 1)), (8, 16, (2, 2)), (8, 16, (1, 2)), (32, 128, (1, 2)),
-                              (6, 10, (1, 1))):
+                              (16, 48, (1, 2)), (6, 10, (1, 1))):
         x3 = torch.randn(N_, H, W, Cin, generator=g)
         w3 = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.2
         b3 = torch.randn(Cout, generator=g)
