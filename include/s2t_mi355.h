@@ -391,8 +391,12 @@ int s2t_tn_x3(int set);
 /* Kernel form of the bf16-split TN products (round 5): 1 (default, or S2T_TN_W=1) = wave-specialised
  * 128x128 / 128x192 / 192x128 tiles (producer waves load 16-byte runs and split, consumer waves run
  * the MFMAs; aligned non-symmetric problems: s2t_gemm_f32 mode 2, s2t_gemm_tn_grouped, and
- * s2t_conv3x3_gemm mode 2 with its implicit patch operand); 0 = the 64x64 form.  Same arithmetic,
- * different summation order.  set >= 0 selects, set < 0 queries; returns the form. */
+ * s2t_conv3x3_gemm mode 2 with its implicit patch operand); 0 = the all-waves form (every wave splits
+ * what it staged and multiplies it: 64x64 tiles under six products, 128x128 under three).  Same
+ * arithmetic, different summation order.  With no setting (S2T_TN_W unset, or set == 2) the form
+ * follows the weight-gradient class's arithmetic (s2t_gemm_arith_of(2)): six products -> 1, three -> 0
+ * (round 6: measured per step; the implicit-patch product stays on the W form).  set = 0 / 1
+ * forces, set = 2 returns to automatic, set < 0 queries; returns the form now in effect. */
 int s2t_tn_w(int set);
 /* the same switch for the NT / NN products of s2t_gemm_f32 (default 1) */
 int s2t_nn_x3(int set);

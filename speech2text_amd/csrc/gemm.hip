@@ -870,7 +870,7 @@ struct TnGroup {
   TnProb p[MAXG];
 };
 
-template <bool X3, int TNW = 1, bool P3 = false>
+template <bool X3, int TNW = 1, bool P3 = false, int TMW = 1>
 __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(TnGroup grp) {
   int i = 0;
   while (i + 1 < grp.n && blockIdx.x >= grp.begin[i + 1]) ++i;
@@ -878,7 +878,7 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(TnGroup grp) {
   GemmArgs g{q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, nullptr, nullptr, 0, nullptr, 0,
              0, 0, 0, q.colsum, 0, q.kper, q.tiles_m, q.tiles_n, q.splits, grp.debug, q.alpha};
   g.np = grp.np;
-  gemm_body<1, TNW, MODE_TN, ACT_NONE, X3, false, P3>(g, blockIdx.x - grp.begin[i]);
+  gemm_body<TMW, TNW, MODE_TN, ACT_NONE, X3, false, P3>(g, blockIdx.x - grp.begin[i]);
 }
 
 // the grouped launch on the W form (tiles_m / tiles_n of the problems count that problem's tiles)
@@ -926,11 +926,18 @@ static bool tn_p3() {
 }
 // S2T_TN_W=0: weight gradients on the 64 x 64 form instead of the wave-specialised "W" form;
 // S2T_TN_W_BLOCKS: workgroups a W launch aims at (one is resident per CU)
-static int g_tn_w = -1;
-static bool tn_w() {
-  if (g_tn_w < 0) { const char* e = getenv("S2T_TN_W"); g_tn_w = e ? atoi(e) : 1; }
-  return g_tn_w == 1;
+// Round 6: with no setting the form follows the weight gradients' arithmetic -- six products: the W form
+// (round 5: 0.65 ms per step better than the all-waves form); three products: the all-waves form on
+// 128 x 128 tiles (the split and the MFMAs both shrank, the producer / consumer imbalance did not:
+// 33.80-33.90 against 33.33-33.46 ms per step, three pairs on one box).
+static int g_tn_w = -1;      // -1: not asked yet; 2: automatic; 0 / 1: forced (S2T_TN_W, s2t_tn_w)
+static bool tn_w_forced() {
+  if (g_tn_w < 0) { const char* e = getenv("S2T_TN_W"); g_tn_w = e ? (atoi(e) ? 1 : 0) : 2; }
+  return g_tn_w != 2;
 }
+static bool tn_w() { return tn_w_forced() ? g_tn_w == 1 : s2t_gemm_arith_of(2) != 2; }
+// the 3x3 convolution's implicit-patch weight gradient has no 128 x 128 all-waves instantiation: W unless forced off
+static bool tn_w_patch() { return tn_w_forced() ? g_tn_w == 1 : true; }
 static long tn_w_blocks() {
   static long v = -1;
   if (v < 0) { const char* e = getenv("S2T_TN_W_BLOCKS"); v = e ? atol(e) : 512; }
@@ -1052,8 +1059,10 @@ int dispatch(GemmArgs& g, hipStream_t st) {
       else hipLaunchKernelGGL((gemm_tn_w_kernel<ACT_SWOOSH_R>), dim3(grid), dim3(512), lds, st, g, shape);
       return (int)hipGetLastError();
     }
-    const int ttm = (force > 0 && !g.sym_cg) ? force / 10 : 1;
-    const int ttn = g.sym_cg ? 1 : (force > 0 ? force % 10 : (g.N >= 512 ? 2 : 1));
+    // (no forced tile: 128 x 128 under the three-product arithmetic -- see tn_w_forced -- else 64 x 64 / 64 x 128)
+    const bool big = force <= 0 && !g.sym_cg && g.np == 2 && tn_x3() && tn_p3();
+    const int ttm = (force > 0 && !g.sym_cg) ? force / 10 : (big ? 2 : 1);
+    const int ttn = g.sym_cg ? 1 : (force > 0 ? force % 10 : (big ? 2 : (g.N >= 512 ? 2 : 1)));
     const long tiles = (long)((g.M + 64 * ttm - 1) / (64 * ttm)) * ((g.N + 64 * ttn - 1) / (64 * ttn));
     static int xtx_blocks = -2;   // S2T_XTX_BLOCKS: workgroup target of the symmetric x^T x
     if (xtx_blocks == -2) { const char* e = getenv("S2T_XTX_BLOCKS"); xtx_blocks = e ? atoi(e) : -1; }
@@ -1249,7 +1258,7 @@ extern "C" int s2t_conv3x3_gemm(int mode, const float* x, int B, int H, int W, i
   // 24 tiles of 128 x 192).  The zipformer frontend's 32 -> 128 conv (128 x 288 output over 600 k rows:
   // 2 tiles, 256 slices) lasts 1.16 ms on it against 0.48 ms on the 64 x 64 form; the STEP is the same
   // either way (37.64 / 37.66 ms, three pairs), so the shorter launch is kept.
-  if (tn_w() && tn_x3() && tn_p3() && CO >= 128 && K9 >= 1024) {
+  if (tn_w_patch() && tn_x3() && tn_p3() && CO >= 128 && K9 >= 1024) {
     const int shape = tn_w_shape_of(g.M, g.N, g.tiles_m, g.tiles_n);
     const long tiles = (long)g.tiles_m * g.tiles_n;
     int splits = (int)((tn_w_blocks() + tiles - 1) / tiles);
@@ -1280,7 +1289,7 @@ extern "C" int s2t_conv3x3_gemm(int mode, const float* x, int B, int H, int W, i
 }
 
 extern "C" int s2t_tn_w(int set) {
-  if (set >= 0) g_tn_w = set ? 1 : 0;
+  if (set >= 0) g_tn_w = set >= 2 ? 2 : (set ? 1 : 0);
   return tn_w() ? 1 : 0;
 }
 extern "C" int s2t_tn_x3(int set) {
@@ -1313,8 +1322,18 @@ extern "C" int s2t_gemm_tn_grouped(int n, const S2tTnProblem* probs, void* strea
     target = e ? atol(e) : 6144;
     if (target < 8) target = 8;
   }
-  static int tnw = -1;      // output tile 64 x (64 tnw): S2T_TN_GROUP_TILE = 11 | 12
-  if (tnw < 0) { const char* e = getenv("S2T_TN_GROUP_TILE"); tnw = (e && atoi(e) == 12) ? 2 : 1; }
+  // output tile (64 tmw) x (64 tnw): S2T_TN_GROUP_TILE = 11 | 12 | 22; unset: 22 under the three-product
+  // arithmetic (1536 workgroups per group unless S2T_TN_GROUP_BLOCKS says otherwise), else 11
+  static int gtile = -1;
+  static bool user_target = false;
+  if (gtile < 0) {
+    const char* e = getenv("S2T_TN_GROUP_TILE");
+    gtile = e ? atoi(e) : 0;
+    user_target = getenv("S2T_TN_GROUP_BLOCKS") != nullptr;
+  }
+  const int gt = gtile > 0 ? gtile : ((s2t_gemm_arith_of(2) == 2 && tn_x3() && tn_p3()) ? 22 : 11);
+  const int tmw = gt == 22 ? 2 : 1, tnw = (gt == 12 || gt == 22) ? 2 : 1;
+  const long gtarget = (gt == 22 && !user_target) ? 1536 : target;
   const long qtarget = tn_w_blocks();
   bool useq = tn_w() && tn_x3() && tn_p3();
   for (int i = 0; i < n && useq; ++i) {
@@ -1378,16 +1397,16 @@ extern "C" int s2t_gemm_tn_grouped(int n, const S2tTnProblem* probs, void* strea
           (reinterpret_cast<uintptr_t>(s.A) & 15) || (reinterpret_cast<uintptr_t>(s.B) & 15) ||
           s.lda > INT32_MAX || s.ldb > INT32_MAX || s.ldc > INT32_MAX)
         return -2;
-      total_tiles += (long)((s.M + 63) / 64) * ((s.N + 64 * tnw - 1) / (64 * tnw));
+      total_tiles += (long)((s.M + 64 * tmw - 1) / (64 * tmw)) * ((s.N + 64 * tnw - 1) / (64 * tnw));
     }
-    int want = (int)((target + total_tiles - 1) / total_tiles);
+    int want = (int)((gtarget + total_tiles - 1) / total_tiles);
     want = std::max(8, ((want + 4) / 8) * 8);
     unsigned blocks = 0;
     for (int i = 0; i < grp.n; ++i) {
       const S2tTnProblem& s = probs[base + i];
       TnProb& q = grp.p[i];
       q = TnProb{s.A, s.B, s.C, s.colsum, (int)s.lda, (int)s.ldb, (int)s.ldc, s.M, s.N, s.K,
-                 0, (s.M + 63) / 64, (s.N + 64 * tnw - 1) / (64 * tnw), 0, s.alpha};
+                 0, (s.M + 64 * tmw - 1) / (64 * tmw), (s.N + 64 * tnw - 1) / (64 * tnw), 0, s.alpha};
       const long tiles = (long)q.tiles_m * q.tiles_n;
       const int maxs = (s.K + 2 * KR - 1) / (2 * KR);
       int splits = std::max(1, std::min(want, maxs));
@@ -1399,7 +1418,9 @@ extern "C" int s2t_gemm_tn_grouped(int n, const S2tTnProblem* probs, void* strea
       blocks += (unsigned)(8 * tiles * ((q.splits + 7) / 8));
     }
     grp.begin[grp.n] = blocks;
-    if (tn_x3() && tn_p3() && tnw == 2)
+    if (tn_x3() && tn_p3() && tmw == 2)
+      hipLaunchKernelGGL((gemm_tn_grouped_kernel<true, 2, true, 2>), dim3(blocks), dim3(256), 0, st, grp);
+    else if (tn_x3() && tn_p3() && tnw == 2)
       hipLaunchKernelGGL((gemm_tn_grouped_kernel<true, 2, true>), dim3(blocks), dim3(256), 0, st, grp);
     else if (tn_x3() && tn_p3())
       hipLaunchKernelGGL((gemm_tn_grouped_kernel<true, 1, true>), dim3(blocks), dim3(256), 0, st, grp);

@@ -306,14 +306,13 @@ def test_tn_wave_specialised_form(dev, R, Nf, Mf, pro):
                             None, None, 0, None, 0, 0, 0, pro, Nt.fp(db), 0, Nt.stream())
         assert rc == 0
         return dW.double() - 0.25, db.double() - 0.25
-    was = L.s2t_tn_w(-1)
     try:
         assert L.s2t_tn_w(1) == 1
         dW, db = run()
         assert L.s2t_tn_w(0) == 0
         dW2, db2 = run()
     finally:
-        L.s2t_tn_w(was)
+        L.s2t_tn_w(2)               # back to automatic (S2T_TN_W, or by the weight gradients' arithmetic)
     scale = ref.abs().max().item()
     for a, c in ((dW, db), (dW2, db2)):
         assert (a - ref).abs().max().item() / scale < _b(2e-6)

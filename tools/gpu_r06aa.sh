@@ -1,0 +1,17 @@
+#!/bin/bash
+# round 6, visit aa: weight-gradient form by arithmetic (default) against the W form, all configs; GEMM tests
+TAG=${1:-r06aa}
+mkdir -p gpurun_out
+export TAG
+. tools/gpu_step.sh
+step tests bash -c "timeout -k 10 900 python -m pytest tests/test_gpu_gemm.py -q -x > gpurun_out/${TAG}_tests.log 2>&1; tail -3 gpurun_out/${TAG}_tests.log"
+b() {
+  local name=$1; local cfg=$2; shift; shift
+  step bench_$name bash -c "$* timeout -k 10 600 python bench.py --config $cfg --steps 20 --warmup 5 --no-cpu-baseline --profile-steps 0 2>> gpurun_out/${TAG}_bench.err | tail -1 | python -c \"import json,sys; d=json.loads(sys.stdin.read()); print('$name', round(d['ms_per_step'],2))\" | tee -a gpurun_out/${TAG}_ab.txt"
+}
+for r in 1 2; do
+for c in C2 C4 C5 C3; do
+b ${c}_auto_$r $c
+b ${c}_W_$r $c S2T_TN_W=1
+done
+done
