@@ -208,11 +208,13 @@ constexpr int bk_of(int tm, int tn, int mode) {
 // is {3 ds_read_b128 per fragment, 6 MFMAs}, no VALU.  Same tiles, chunks, barriers, slices and
 // atomics as the X3 form; the bias gradient (column sums of A) is taken from the staged registers.
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-template <int TM, int TN, int PRO>
+// NP: pieces the LDS image holds (3: either arithmetic, chosen by g.np; 2: the three-product arithmetic
+// only, in two thirds of the LDS -- its own kernels, gemm_tn_p2_kernel / gemm_tn_grouped_p2_kernel)
+template <int TM, int TN, int PRO, int NP = 3>
 __device__ __forceinline__ void tn_p3_body(const GemmArgs& g, const unsigned bid) {
   constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32;
-  __shared__ __attribute__((aligned(16))) unsigned char sA[BM * BK * 6];
-  __shared__ __attribute__((aligned(16))) unsigned char sB[BN * BK * 6];
+  __shared__ __attribute__((aligned(16))) unsigned char sA[BM * BK * 2 * NP];
+  __shared__ __attribute__((aligned(16))) unsigned char sB[BN * BK * 2 * NP];
   const int total = g.tiles_m * g.tiles_n;
   const int q = (int)(bid >> 3);
   const int zslice = (int)(bid & 7) + 8 * (q / total);
@@ -230,7 +232,7 @@ __device__ __forceinline__ void tn_p3_body(const GemmArgs& g, const unsigned bid
   const int kend = min(g.K, kbeg + g.kper);
   if (kbeg >= kend) return;
   const bool want_csum = g.colsum != nullptr && tn == csum_tn;
-  const bool np3 = g.np != 2;            // (uniform: three pieces / six products, or two / three)
+  const bool np3 = NP == 3 && g.np != 2;  // (uniform: three pieces / six products, or two / three)
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -242,7 +244,7 @@ __device__ __forceinline__ void tn_p3_body(const GemmArgs& g, const unsigned bid
 
   // staging: output so of each 64-column unit, contraction rows 8 kg .. 8 kg + 7 of the chunk
   const int so = threadIdx.x & 63, kg = threadIdx.x >> 6;
-  const unsigned sdst = (unsigned)(((((so >> 5) * 2 + (kg >> 1)) * 3) * 64 + (kg & 1) * 32 + (so & 31)) * 16);
+  const unsigned sdst = (unsigned)(((((so >> 5) * 2 + (kg >> 1)) * NP) * 64 + (kg & 1) * 32 + (so & 31)) * 16);
   float ra[TM][8], rb[TN][8];
   float csum[TM];
 #pragma unroll
@@ -265,7 +267,7 @@ __device__ __forceinline__ void tn_p3_body(const GemmArgs& g, const unsigned bid
     }                                                                                          \
     if (CSUM) csum[u] += ((v_[0] + v_[1]) + (v_[2] + v_[3])) + ((v_[4] + v_[5]) + (v_[6] + v_[7])); \
     unsigned a0_, a1_, a2_, b0_, b1_, b2_, c0_, c1_, c2_, d0_, d1_, d2_;                       \
-    unsigned char* d_ = (S) + u * (2 * 2 * 3 * 1024) + sdst;                                   \
+    unsigned char* d_ = (S) + u * (2 * 2 * NP * 1024) + sdst;                                   \
     if (np3) {                                                                                 \
       split_pair(v_[0], v_[1], a0_, a1_, a2_);                                                 \
       split_pair(v_[2], v_[3], b0_, b1_, b2_);                                                 \
@@ -303,13 +305,13 @@ __device__ __forceinline__ void tn_p3_body(const GemmArgs& g, const unsigned bid
 #pragma unroll
         for (int p = 0; p < 3; ++p)
           if (p < 2 || np3)
-            pa[i][p] = *reinterpret_cast<const bf16x8*>(sA + ((((wm >> 5) + i) * 2 + s) * 3 + p) * 1024 + lane * 16);
+            pa[i][p] = *reinterpret_cast<const bf16x8*>(sA + ((((wm >> 5) + i) * 2 + s) * NP + p) * 1024 + lane * 16);
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int p = 0; p < 3; ++p)
           if (p < 2 || np3)
-            pb[j][p] = *reinterpret_cast<const bf16x8*>(sB + ((((wn >> 5) + j) * 2 + s) * 3 + p) * 1024 + lane * 16);
+            pb[j][p] = *reinterpret_cast<const bf16x8*>(sB + ((((wn >> 5) + j) * 2 + s) * NP + p) * 1024 + lane * 16);
 #define S2T_P3_TERM(PA, PB)                                                                     \
   _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i][PA], pb[j][PB], acc[i][j], 0, 0, 0);
@@ -881,6 +883,22 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(TnGroup grp) {
   gemm_body<TMW, TNW, MODE_TN, ACT_NONE, X3, false, P3>(g, blockIdx.x - grp.begin[i]);
 }
 
+// the all-waves form with a two-piece LDS image (three-product arithmetic only: 32 KB at 128 x 128)
+template <int TM, int TN, int PRO>
+__global__ __launch_bounds__(256) void gemm_tn_p2_kernel(GemmArgs g) {
+  tn_p3_body<TM, TN, PRO, 2>(g, blockIdx.x);
+}
+template <int TMW, int TNW>
+__global__ __launch_bounds__(256) void gemm_tn_grouped_p2_kernel(TnGroup grp) {
+  int i = 0;
+  while (i + 1 < grp.n && blockIdx.x >= grp.begin[i + 1]) ++i;
+  const TnProb& q = grp.p[i];
+  GemmArgs g{q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, nullptr, nullptr, 0, nullptr, 0,
+             0, 0, 0, q.colsum, 0, q.kper, q.tiles_m, q.tiles_n, q.splits, grp.debug, q.alpha};
+  g.np = 2;
+  tn_p3_body<TMW, TNW, ACT_NONE, 2>(g, blockIdx.x - grp.begin[i]);
+}
+
 // the grouped launch on the W form (tiles_m / tiles_n of the problems count that problem's tiles)
 __global__ __launch_bounds__(512) void gemm_tn_grouped_w_kernel(TnGroup grp) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char tnw_sm[];
@@ -976,6 +994,13 @@ int launch(GemmArgs& g, int splits, hipStream_t st) {
   const int total = g.tiles_m * g.tiles_n;
   g.splits = splits;
   const int grid = MODE == MODE_TN ? 8 * total * ((splits + 7) / 8) : ((total + 7) / 8) * 8;
+  static const bool p2 = [] { const char* e = getenv("S2T_TN_P2"); return !e || atoi(e) != 0; }();
+  if constexpr (MODE == MODE_TN && TM == 2 && TN == 2) {
+    if (tn_x3() && tn_p3() && g.np == 2 && p2) {
+      hipLaunchKernelGGL((gemm_tn_p2_kernel<TM, TN, PRO>), dim3(grid), dim3(256), 0, st, g);
+      return (int)hipGetLastError();
+    }
+  }
   if (MODE == MODE_TN && tn_x3() && tn_p3())
     hipLaunchKernelGGL((gemm_kernel<TM, TN, MODE, PRO, true, false, (MODE == MODE_TN)>), dim3(grid), dim3(256), 0, st, g);
   else if (MODE == MODE_TN ? tn_x3() : nn_x3())
@@ -1418,7 +1443,10 @@ extern "C" int s2t_gemm_tn_grouped(int n, const S2tTnProblem* probs, void* strea
       blocks += (unsigned)(8 * tiles * ((q.splits + 7) / 8));
     }
     grp.begin[grp.n] = blocks;
-    if (tn_x3() && tn_p3() && tmw == 2)
+    static const bool p2 = [] { const char* e = getenv("S2T_TN_P2"); return !e || atoi(e) != 0; }();
+    if (tn_x3() && tn_p3() && tmw == 2 && grp.np == 2 && p2)
+      hipLaunchKernelGGL((gemm_tn_grouped_p2_kernel<2, 2>), dim3(blocks), dim3(256), 0, st, grp);
+    else if (tn_x3() && tn_p3() && tmw == 2)
       hipLaunchKernelGGL((gemm_tn_grouped_kernel<true, 2, true, 2>), dim3(blocks), dim3(256), 0, st, grp);
     else if (tn_x3() && tn_p3() && tnw == 2)
       hipLaunchKernelGGL((gemm_tn_grouped_kernel<true, 2, true>), dim3(blocks), dim3(256), 0, st, grp);
