@@ -173,6 +173,7 @@ struct X3P {
 // stores drain under the other slots' MFMAs, and so on down the slots.
 __device__ __forceinline__ void x3p_set_prio(int on) {
   if (!on) return;
+  if (on == 2) { __builtin_amdgcn_s_setprio(3); return; }   // every wave above the other kernels on the CU
   const unsigned tg = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (16 << 6) | 4) & 15u;   // HW_ID.TG_ID
   if (tg == 0) __builtin_amdgcn_s_setprio(3);
   else if (tg == 1) __builtin_amdgcn_s_setprio(2);
@@ -675,6 +676,7 @@ __global__ __launch_bounds__(256, WPC) void x3p_dma_kernel(X3P g) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wrb = (wave >> 1) * TM, wcb = (wave & 1) * TN;
+  if (g.prio >= 2) x3p_set_prio(g.prio);
 
   // A unit u = (sub-stage, row r, k half kq): 16 consecutive lanes store 16 consecutive fragment slots
   int a_r[NAU], a_k[NAU];
@@ -1100,8 +1102,11 @@ int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int 
     }
   }
   {
-    static int prio = -1;      // S2T_X3P_PRIO=0: no slot priority
-    if (prio < 0) { const char* e = getenv("S2T_X3P_PRIO"); prio = e ? atoi(e) : 1; }
+    // S2T_X3P_PRIO: 0 = none; 1 = by the workgroup's slot on its CU (register-staged form; round 4);
+    // 2 (default, round 6) = every wave of these main-stream kernels above the side stream's kernels
+    // on the same CU (33.29 / 33.16 / 33.09 -> 33.07 / 33.17 / 32.92 ms per step, one box)
+    static int prio = -1;
+    if (prio < 0) { const char* e = getenv("S2T_X3P_PRIO"); prio = e ? atoi(e) : 2; }
     g.prio = prio;
   }
   hipStream_t st = (hipStream_t)stream;

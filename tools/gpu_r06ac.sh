@@ -1,0 +1,15 @@
+#!/bin/bash
+# round 6, visit ac: GEMM plans timed in company (weight-gradient launches on the side stream) against timed alone
+TAG=${1:-r06ac}
+mkdir -p gpurun_out
+export TAG
+. tools/gpu_step.sh
+b() {
+  local name=$1; local cfg=$2; shift; shift
+  step bench_$name bash -c "$* timeout -k 10 600 python bench.py --config $cfg --steps 20 --warmup 5 --no-cpu-baseline --profile-steps 0 2>> gpurun_out/${TAG}_bench.err | tail -1 | python -c \"import json,sys; d=json.loads(sys.stdin.read()); print('$name', round(d['ms_per_step'],2))\" | tee -a gpurun_out/${TAG}_ab.txt"
+}
+for r in 1 2 3; do
+b C3_alone_$r C3
+b C3_load4_$r C3 S2T_PLAN_LOAD=4
+b C3_load8_$r C3 S2T_PLAN_LOAD=8
+done
