@@ -210,7 +210,9 @@ constexpr int bk_of(int tm, int tn, int mode) {
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 // NP: pieces the LDS image holds (3: either arithmetic, chosen by g.np; 2: the three-product arithmetic
 // only, in two thirds of the LDS -- its own kernels, gemm_tn_p2_kernel / gemm_tn_grouped_p2_kernel)
-template <int TM, int TN, int PRO, int NP = 3>
+// PATCH: B is the implicit patch matrix of g.pt (a 3x3 convolution's weight gradient: row k = output
+// pixel, 9 C columns in three runs of 3 C contiguous floats of the channel-last map)
+template <int TM, int TN, int PRO, int NP = 3, bool PATCH = false>
 __device__ __forceinline__ void tn_p3_body(const GemmArgs& g, const unsigned bid) {
   constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32;
   __shared__ __attribute__((aligned(16))) unsigned char sA[BM * BK * 2 * NP];
@@ -285,8 +287,35 @@ __device__ __forceinline__ void tn_p3_body(const GemmArgs& g, const unsigned bid
     *reinterpret_cast<u32x4_t*>(d_) = q0_;                                                     \
     *reinterpret_cast<u32x4_t*>(d_ + 1024) = q1_;                                              \
   }
+  // the patch operand: this thread's column offsets inside a patch (fixed), and per chunk ONE
+  // (image, row, column) decomposition of its first pixel, then steps of one pixel (pixels past the
+  // slice's end repeat its last one; they are zeroed when stored)
+  int pcol[TN];
+#pragma unroll
+  for (int u = 0; u < TN; ++u) pcol[u] = PATCH ? patch_col(g.pt, min(n0 + 64 * u + so, g.N - 1)) : 0;
+#define TN3_LOAD_PATCH(K0)                                                                     \
+  {                                                                                            \
+    int k_ = min((K0) + 8 * kg, kend - 1);                                                     \
+    const int rows_ = g.pt.hw / g.pt.wo;                                                       \
+    const int b_ = k_ / g.pt.hw, q_ = k_ - b_ * g.pt.hw;                                       \
+    int ho_ = q_ / g.pt.wo, wo_ = q_ - ho_ * g.pt.wo;                                          \
+    int off_ = b_ * g.pt.sb + ho_ * g.pt.sh + wo_ * g.pt.sw;                                   \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                            \
+      _Pragma("unroll") for (int u = 0; u < TN; ++u) rb[u][e] = g.B[off_ + pcol[u]];           \
+      if (k_ + 1 < kend) {                                                                     \
+        ++k_;                                                                                  \
+        if (++wo_ == g.pt.wo) {                                                                \
+          wo_ = 0;                                                                             \
+          off_ += g.pt.sh - (g.pt.wo - 1) * g.pt.sw;                                           \
+          if (++ho_ == rows_) { ho_ = 0; off_ += g.pt.sb - rows_ * g.pt.sh; }                  \
+        } else {                                                                               \
+          off_ += g.pt.sw;                                                                     \
+        }                                                                                      \
+      }                                                                                        \
+    }                                                                                          \
+  }
   TN3_LOAD(ra, TM, g.A, g.lda, m0, g.M, kbeg)
-  TN3_LOAD(rb, TN, g.B, g.ldb, n0, g.N, kbeg)
+  if (PATCH) { TN3_LOAD_PATCH(kbeg) } else { TN3_LOAD(rb, TN, g.B, g.ldb, n0, g.N, kbeg) }
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
     __syncthreads();                       // previous chunk fully consumed
     if (want_csum) { TN3_STORE(ra, TM, sA, m0, g.M, k0, ACT_NONE, true) }
@@ -295,7 +324,7 @@ __device__ __forceinline__ void tn_p3_body(const GemmArgs& g, const unsigned bid
     __syncthreads();
     if (k0 + BK < kend) {                  // next chunk's global loads fly under the MFMAs
       TN3_LOAD(ra, TM, g.A, g.lda, m0, g.M, k0 + BK)
-      TN3_LOAD(rb, TN, g.B, g.ldb, n0, g.N, k0 + BK)
+      if (PATCH) { TN3_LOAD_PATCH(k0 + BK) } else { TN3_LOAD(rb, TN, g.B, g.ldb, n0, g.N, k0 + BK) }
     }
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
@@ -322,6 +351,7 @@ __device__ __forceinline__ void tn_p3_body(const GemmArgs& g, const unsigned bid
     }
   }
 #undef TN3_LOAD
+#undef TN3_LOAD_PATCH
 #undef TN3_STORE
   if (want_csum) {                         // the four row groups' partial sums -> one add per column
     __syncthreads();
@@ -888,6 +918,10 @@ template <int TM, int TN, int PRO>
 __global__ __launch_bounds__(256) void gemm_tn_p2_kernel(GemmArgs g) {
   tn_p3_body<TM, TN, PRO, 2>(g, blockIdx.x);
 }
+template <int TM, int TN, int NP>
+__global__ __launch_bounds__(256) void gemm_tn_patch_kernel(GemmArgs g) {
+  tn_p3_body<TM, TN, ACT_NONE, NP, true>(g, blockIdx.x);
+}
 template <int TMW, int TNW>
 __global__ __launch_bounds__(256) void gemm_tn_grouped_p2_kernel(TnGroup grp) {
   int i = 0;
@@ -1283,7 +1317,12 @@ extern "C" int s2t_conv3x3_gemm(int mode, const float* x, int B, int H, int W, i
   // 24 tiles of 128 x 192).  The zipformer frontend's 32 -> 128 conv (128 x 288 output over 600 k rows:
   // 2 tiles, 256 slices) lasts 1.16 ms on it against 0.48 ms on the 64 x 64 form; the STEP is the same
   // either way (37.64 / 37.66 ms, three pairs), so the shorter launch is kept.
-  if (tn_w_patch() && tn_x3() && tn_p3() && CO >= 128 && K9 >= 1024) {
+  // Round 6: under the three-product arithmetic every size runs on the all-waves form below with the patch
+  // operand (C3 33.24-33.42 -> 33.02-33.15 ms per step against the fragment-splitting 64 x 64 form, C2
+  // 19.30-19.42 -> 18.89-19.10 against the W form; S2T_CONV_W_P3=0: the round-5 forms)
+  static const int p3mode = [] { const char* e = getenv("S2T_CONV_W_P3"); return e ? atoi(e) : 1; }();
+  const bool allw = p3mode && tn_x3() && tn_p3();
+  if (!(allw && g.np == 2) && tn_w_patch() && tn_x3() && tn_p3() && CO >= 128 && K9 >= 1024) {
     const int shape = tn_w_shape_of(g.M, g.N, g.tiles_m, g.tiles_n);
     const long tiles = (long)g.tiles_m * g.tiles_n;
     int splits = (int)((tn_w_blocks() + tiles - 1) / tiles);
@@ -1296,6 +1335,25 @@ extern "C" int s2t_conv3x3_gemm(int mode, const float* x, int B, int H, int W, i
     static const bool ok = tn_w_prepare(gemm_tn_w_patch_kernel);
     if (!ok) return -3;
     hipLaunchKernelGGL(gemm_tn_w_patch_kernel, dim3(grid), dim3(512), shape ? TNW_LDS : TNW_LDS0, st, g, shape);
+    return (int)hipGetLastError();
+  }
+  // the all-waves form that splits once, at staging (tn_p3_body with the patch operand): 64 TM x 128 tiles
+  if (allw) {
+    const int tmm = CO > 64 ? 2 : 1;
+    g.tiles_m = (CO + 64 * tmm - 1) / (64 * tmm);
+    g.tiles_n = (K9 + 127) / 128;
+    const long tiles = (long)g.tiles_m * g.tiles_n;
+    int splits = (int)((768 + tiles - 1) / tiles);
+    splits = std::max(1, std::min(splits, (g.K + 2 * KR - 1) / (2 * KR)));
+    int kper = (g.K + splits - 1) / splits;
+    kper = ((kper + KR - 1) / KR) * KR;
+    g.kper = kper;
+    g.splits = (g.K + kper - 1) / kper;
+    const int grid = (int)(8 * tiles * ((g.splits + 7) / 8));
+    if (g.np == 2 && tmm == 2) hipLaunchKernelGGL((gemm_tn_patch_kernel<2, 2, 2>), dim3(grid), dim3(256), 0, st, g);
+    else if (g.np == 2) hipLaunchKernelGGL((gemm_tn_patch_kernel<1, 2, 2>), dim3(grid), dim3(256), 0, st, g);
+    else if (tmm == 2) hipLaunchKernelGGL((gemm_tn_patch_kernel<2, 2, 3>), dim3(grid), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_tn_patch_kernel<1, 2, 3>), dim3(grid), dim3(256), 0, st, g);
     return (int)hipGetLastError();
   }
   g.tiles_m = (CO + 63) / 64;
