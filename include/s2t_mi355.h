@@ -713,7 +713,10 @@ int s2t_predictor_ctx_bwd(const int* tokens, const float* emb, const float* w, c
  *   16-byte aligned (else -2).  tile = 0 (from the shape) | 11 | 12 | 21 | 22: block tile
  *   (64 tm) x (64 tn); + 100 w: w persistent workgroups per CU;
  *   2000 + tm tn: the form that moves the weight pieces global -> LDS directly, + 200 (two-piece
- *   arithmetic only): 32-deep barrier intervals.  -2: a tile code the current arithmetic has not. */
+ *   arithmetic only): 32-deep barrier intervals; 3000 + tm tn (22 | 21 | 12), + 200 (22 | 12): the
+ *   same form on 8-wave workgroups, block tile (128 tm) x (64 tn), two-piece arithmetic, no Balancer
+ *   epilogue (measured, not in the default plan: DESIGN 3i).  -2: a tile code the current
+ *   arithmetic has not. */
 /* ---- the arithmetic of every bf16 matrix-core GEMM of the library (s2t_gemm_x3p*, the weight-gradient /
  * NT / NN / batched kernels of csrc/gemm.hip): pieces per fp32 operand.
  *   3 ("bf16x3/6"): x = p0 + p1 + p2 exactly, six piece products per term: fp32-level error

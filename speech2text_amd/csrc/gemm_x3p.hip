@@ -654,16 +654,20 @@ __device__ __forceinline__ unsigned x3p_lds_addr(const void* p) {
 // (1 | 2): with two pieces a 16-deep stage holds only 12 MFMAs per wave (2 x 2 tile) between two
 // barriers; KS = 2 stages 32 k at a time -- the same 24 MFMAs per barrier as the three-piece form,
 // half the barriers, waits and address arithmetic per product.
-template <int TM, int TN, int WPC, bool MAP = false, int NP = 3, int KS = 1, bool BAL = false>
-__global__ __launch_bounds__(256, WPC) void x3p_dma_kernel(X3P g) {
-  constexpr int BM = 64 * TM, BN = 64 * TN;
-  constexpr int A_SUB = 2 * TM * NP * 1024, B_SUB = 2 * TN * NP * 1024;   // one 16-deep sub-stage
+// WM: waves along M (2: the 4-wave workgroup, block tile 64 TM x 64 TN; 4: an 8-wave workgroup, block
+// tile 128 TM x 64 TN -- every wave keeps its 32 TM x 32 TN, a weight stage is shared by twice the
+// rows: 0.75 of the global -> LDS bytes per product at TM = TN = 2)
+template <int TM, int TN, int WPC, bool MAP = false, int NP = 3, int KS = 1, bool BAL = false, int WM = 2>
+__global__ __launch_bounds__(128 * WM, WPC * WM / 2) void x3p_dma_kernel(X3P g) {   // (HIP: waves per SIMD)
+  constexpr int NT = 128 * WM, NWV = 2 * WM;        // threads, waves
+  constexpr int BM = 32 * WM * TM, BN = 64 * TN;
+  constexpr int A_SUB = WM * TM * NP * 1024, B_SUB = 2 * TN * NP * 1024;   // one 16-deep sub-stage
   constexpr int A_ST = KS * A_SUB, B_ST = KS * B_SUB, ST = A_ST + B_ST;
-  constexpr int NAU = (128 * TM * KS + 255) / 256;  // A units (8 k of one row) per thread and stage
+  constexpr int NAU = (2 * BM * KS + NT - 1) / NT;  // A units (8 k of one row) per thread and stage
   constexpr int NRUN = 2 * TN * KS * NP;            // B: 1 KB runs (one wave-instruction each) per stage
-  constexpr int NBW = (NRUN + 3) / 4;               // ... per wave
-  constexpr int SCR = 4 * 16 * 36 * 4;
-  static_assert(128 * TM * KS % 256 == 0 || (TM == 1 && KS == 1), "A units");
+  constexpr int NBW = (NRUN + NWV - 1) / NWV;       // ... per wave
+  constexpr int SCR = NWV * 16 * 36 * 4;
+  static_assert(2 * BM * KS % NT == 0 || (TM == 1 && KS == 1), "A units");
   static_assert(!MAP || KS == 1, "implicit operands: 16-deep stages");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * ST > SCR ? 2 * ST : SCR];
   const unsigned lds0 = x3p_lds_addr(smem);
@@ -684,16 +688,16 @@ __global__ __launch_bounds__(256, WPC) void x3p_dma_kernel(X3P g) {
   bool a_on[NAU];
 #pragma unroll
   for (int i = 0; i < NAU; ++i) {
-    const int u = tid + 256 * i;
-    a_on[i] = u < 128 * TM * KS;
+    const int u = tid + NT * i;
+    a_on[i] = u < 2 * BM * KS;
     const int uu = a_on[i] ? u : 0;
-    const int sub = uu / (128 * TM), v = uu - sub * (128 * TM);
+    const int sub = uu / (2 * BM), v = uu - sub * (2 * BM);
     const int r = (v & 15) + 16 * (v >> 5), kq = (v >> 4) & 1;
     a_r[i] = r;
     a_k[i] = 16 * sub + 8 * kq;
     a_dst[i] = (unsigned)(sub * A_SUB + (((r >> 5) * NP) * 64 + kq * 32 + (r & 31)) * 16);
   }
-  // B: wave-instruction q of this wave moves the 1 KB run pw = wave + 4 q = ((32-column block) KS +
+  // B: wave-instruction q of this wave moves the 1 KB run pw = wave + NWV q = ((32-column block) KS +
   // sub-stage) NP + piece of the stage (a wave past the end repeats the last run: same bytes to the
   // same place, no branch); a block's 16-deep chunk is 3 KB = 1536 bf16 of the plane image, of which
   // the first NP KB are read
@@ -705,7 +709,7 @@ __global__ __launch_bounds__(256, WPC) void x3p_dma_kernel(X3P g) {
   unsigned b_dst[NBW];
 #pragma unroll
   for (int q = 0; q < NBW; ++q) {
-    const int pw = min(wave + 4 * q, NRUN - 1);
+    const int pw = min(wave + NWV * q, NRUN - 1);
     const int blk = pw / (KS * NP), rem = pw - blk * (KS * NP), sub = rem / NP, pc = rem - sub * NP;
     b_dst[q] = (unsigned)(A_ST + sub * B_SUB + (blk * NP + pc) * 1024);
   }
@@ -720,7 +724,7 @@ __global__ __launch_bounds__(256, WPC) void x3p_dma_kernel(X3P g) {
       asrc[i] = g.A + (MAP ? x3p_maprow(g.amap, min(m0 + a_r[i], g.M - 1))                   \
                            : (long)min(m0 + a_r[i], g.M - 1) * g.lda);                       \
     _Pragma("unroll") for (int q = 0; q < NBW; ++q) {                                        \
-      const int pw_ = min(wave + 4 * q, NRUN - 1);                                           \
+      const int pw_ = min(wave + NWV * q, NRUN - 1);                                         \
       const int blk_ = pw_ / (KS * NP), rem_ = pw_ - blk_ * (KS * NP);                       \
       const int sub_ = rem_ / NP, pc_ = rem_ - sub_ * NP;                                    \
       const int nt_ = min((n0 >> 5) + blk_, g.NT - 1);        /* 32-column block */          \
@@ -765,7 +769,7 @@ __global__ __launch_bounds__(256, WPC) void x3p_dma_kernel(X3P g) {
   {                                                                                          \
     unsigned char* const sa_ = smem + (BUF) * ST;                                            \
     _Pragma("unroll") for (int i = 0; i < NAU; ++i)                                          \
-      if (NAU * 256 == 128 * TM * KS || a_on[i]) {                                           \
+      if (NAU * NT == 2 * BM * KS || a_on[i]) {                                              \
         _Pragma("unroll") for (int p = 0; p < NP; ++p)                                       \
           *reinterpret_cast<u32x4*>(sa_ + a_dst[i] + 1024 * p) = qa[i][p];                   \
       }                                                                                      \
@@ -912,6 +916,16 @@ void launch_x3p_dma(X3P& g, hipStream_t st) {
     X3P_LAUNCH((x3p_dma_kernel<TM, TN, WPC, false, NP, KS>), grid, 256, 0);
 }
 
+// the 8-wave workgroup (WM = 4): block tile 128 TM x 64 TN, 512 threads
+template <int TM, int TN, int WPC, int NP, int KS>
+void launch_x3p_dma8(X3P& g, hipStream_t st) {
+  g.tiles_m = (g.M + 128 * TM - 1) / (128 * TM);
+  g.tiles_n = (g.N + 64 * TN - 1) / (64 * TN);
+  const int total = g.tiles_m * g.tiles_n;
+  const int grid = std::min(((total + 7) / 8) * 8, 256 * WPC);
+  X3P_LAUNCH((x3p_dma_kernel<TM, TN, WPC, false, NP, KS, false, 4>), grid, 512, 0);
+}
+
 template <int TM, int TN, int WPC, int NP = 3>
 void launch_x3p_map(X3P& g, hipStream_t st) {
   g.tiles_m = (g.M + 64 * TM - 1) / (64 * TM);
@@ -1056,15 +1070,19 @@ int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int 
   // tile = 100 wgs + (10 tm + tn): the register-staged form, wgs = persistent workgroups per CU (0 =
   // default); 2000 + 100 ks + tm tn: the LDS-DMA form at its own occupancy, ks = 2: 32-deep barrier
   // intervals (two-piece arithmetic only)
+  // 3000 + 100 ks + tm tn: the LDS-DMA form with 8-wave workgroups (block tile 128 tm x 64 tn; two-piece
+  // arithmetic, no Balancer epilogue)
   const int arith = s2t_gemm_arith();
-  if (tile < 0 || (tile >= 1000 && tile < 2000) || tile >= 3000) return -1;
-  int dma = tile / 1000 == 2;
+  if (tile < 0 || (tile >= 1000 && tile < 2000) || tile >= 4000) return -1;
+  const bool w8 = tile / 1000 == 3;
+  int dma = tile / 1000 == 2 || w8;
   const int wgs = (tile / 100) % 10;
   tile %= 100;
   if ((tile != 0 && tile != 11 && tile != 12 && tile != 21 && tile != 22) || wgs > 8 ||
-      (dma && (tile == 0 || wgs > 2)))
+      (dma && (tile == 0 || wgs > 2)) || (w8 && (tile == 11 || (wgs != 0 && wgs != 2) || (wgs == 2 && tile == 21))))
     return -1;
   if (dma && wgs == 2 && arith != 2) return -2;      // (the plan's candidate list follows the arithmetic)
+  if (w8 && (arith != 2 || g_bal.stats)) return -2;
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   if ((K & 7) || (N & 3) || (lda & 3) || (ldc & 3) || !al16(A) || !al16(Bp) || !al16(C) ||
       (bias && !al16(bias)) || (resid && (!al16(resid) || (ldr & 3))) ||
@@ -1130,6 +1148,17 @@ int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int 
       g_samp.flops += 2.0 * (double)M * N * K;
       ++g_samp.launches;
     }
+  }
+  if (w8) {
+    switch (100 * wgs + tile) {
+      case 22: launch_x3p_dma8<2, 2, 2, 2, 1>(g, st); break;
+      case 21: launch_x3p_dma8<2, 1, 2, 2, 1>(g, st); break;
+      case 12: launch_x3p_dma8<1, 2, 2, 2, 1>(g, st); break;
+      case 222: launch_x3p_dma8<2, 2, 1, 2, 2>(g, st); break;
+      default: launch_x3p_dma8<1, 2, 2, 2, 2>(g, st); break;     // 212
+    }
+    S2T_CHECK_LAUNCH();
+    return 0;
   }
   if (dma && g.bal_stats && arith != 2) dma = 0;    // (three pieces: the Balancer epilogue lives in the register-staged form)
   if (dma && arith == 2 && wgs == 2) {              // 32-deep intervals: 64 / 48 / 48 / 32 KB of LDS

@@ -46,6 +46,11 @@ def _x3p_tiles():
     return base + [2222, 2221, 2212, 2211]
 
 
+def _x3p_tiles8():
+    """The 8-wave workgroups of the LDS-DMA form (3000 +; two pieces, no Balancer epilogue)."""
+    return [3022, 3021, 3012, 3222, 3212] if ARITH[0] == 2 else []
+
+
 def _gemm(mode, A, B, C, M, Nn, K, bias=None, resid=None, act_src=None, act_kind=0, pro_a=0, pro_b=0,
           colsum=None, accumulate=0):
     return N.lib().s2t_gemm_f32(mode, N.raw(A), A.stride(0), N.raw(B), B.stride(0), N.fp(C), C.stride(0),
@@ -378,7 +383,7 @@ def test_x3p_gemm_has_fp32_accuracy(dev, M, K, N):
         e_lib = (lib - ref).abs().max().item() / scale
         # (100 w + tile: w persistent workgroups per CU; 2000 + tile: the LDS-DMA form, weight pieces
         #  global -> LDS directly, 3 / 4 / 4 / 5 workgroups per CU; 2200 + tile: its 32-deep intervals)
-        for tile in _x3p_tiles():
+        for tile in _x3p_tiles() + _x3p_tiles8():
             y = zk.x3p_matmul(mode, a, W, bias, res, tile=tile)
             kc = N if mode == 1 else K
             if kc % 8:
@@ -401,7 +406,7 @@ def test_x3p_fused_epilogues(dev):
     Mb = 40000
     xb = torch.randn(Mb, K, generator=g).to(dev)
     rb = torch.randn(Mb, N, generator=g).to(dev)
-    for tile in _x3p_tiles()[1:]:
+    for tile in _x3p_tiles()[1:] + _x3p_tiles8():
         y, y2 = zk.x3p_matmul(0, xb, W, b, None, act2="add", resid_b=rb, tile=tile)
         yref = torch.nn.functional.linear(xb.double(), W.detach().double(), b.detach().double())
         _close(y, yref)

@@ -81,6 +81,18 @@ def main(src, tag, steps, ms_per_step):
         for k, (d, n) in sorted(agg.items(), key=lambda x: -x[1][0])[:70]:
             f.write(f"{d/steps/1e6:8.3f} ms/step {100*d/tot:5.1f}% {n/steps:8.1f} calls/step "
                     f"{d/n/1e3:9.1f} us avg  {k[:140]}\n")
+        if qkey:
+            # what the second-busiest queue (the side stream) runs
+            qs = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0]))
+            for r in sel:
+                a = qs[r[qkey]][r["Kernel_Name"]]
+                a[0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+                a[1] += 1
+            order = sorted(qs.items(), key=lambda kv: -sum(v[1] for v in kv[1].values()))
+            for q, ks in order[1:2]:
+                f.write(f"# ---- {qkey} {q} (side stream) by kernel\n")
+                for k, (d, n) in sorted(ks.items(), key=lambda x: -x[1][0])[:25]:
+                    f.write(f"#   {d/steps/1e6:8.3f} ms/step {n/steps:8.1f} calls/step {d/n/1e3:9.1f} us avg  {k[:120]}\n")
     print("wrote", out)
 
 
