@@ -1978,6 +1978,9 @@ _CONV_MAP_DGRAD = os.environ.get("S2T_CONV_MAP_DGRAD", "1") == "1"
 _CONV_MAP_DGRAD_TILE = int(os.environ.get("S2T_CONV_MAP_DGRAD_TILE", "21"))
 
 
+_PAD_BUF = {}
+
+
 def _conv3x3_s12_dgrad_map(g, wd, H, W):
     """Data gradient of a 3x3 / stride-(1, 2) convolution on a channel-last map (the frontend's 32 -> 128
     convolution, reference model/encoder/zipformer.py Conv2dSubsampling) in GATHER form on the implicit-
@@ -1988,7 +1991,15 @@ def _conv3x3_s12_dgrad_map(g, wd, H, W):
     launch per class: rows = (b, h, jc), K = 3 runs, output scattered to every second pixel of dx."""
     B, Ho, Wo, Cout = g.shape
     C = wd.shape[1]
-    gp = F.pad(g, (0, 0, 1, 1, 2, 2))                                      # rows -2 .. Ho + 1, columns -1 .. Wo
+    # rows -2 .. Ho + 1, columns -1 .. Wo of the gradient with a zero border: a buffer per shape whose border
+    # is zeroed ONCE (only the interior is ever written; the launches below are enqueued on this stream before
+    # the next backward's copy) -- F.pad filled 343 MB per step for the sake of 3 MB of border
+    key = (B, Ho, Wo, Cout, g.device.index)
+    gp = _PAD_BUF.get(key)
+    if gp is None:
+        _PAD_BUF.clear()
+        gp = _PAD_BUF[key] = torch.zeros((B, Ho + 4, Wo + 2, Cout), dtype=torch.float32, device=g.device)
+    gp[:, 2:Ho + 2, 1:Wo + 1].copy_(g)
     Wp = Wo + 2
     dx = torch.empty((B, H, W, C), dtype=torch.float32, device=g.device)
     for pw in (0, 1):
