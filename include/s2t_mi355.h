@@ -777,7 +777,11 @@ int s2t_gemm_x3p_bal(const float* A, long lda, const unsigned short* Bp, int N, 
  * stride-2 convolution of the conformer's Subsampling (model/encoder/conformer.py:47-57, 114-126)
  * without a patch matrix: forward (3 segments of 3 C floats per output position of the channel-last
  * map) and the data gradient (one launch per input-pixel parity class gathering 1 / 2 / 2 / 4 taps of
- * the zero-bordered output gradient and writing every second pixel).  tile: 22 (default) 21 12 11. */
+ * the zero-bordered output gradient and writing every second pixel), and the zipformer frontend's 32 -> 128
+ * stride-(1, 2) convolution (model/layer/subsampling.py:277-319): forward and the data gradient by column
+ * parity (even columns: one run of 2 Cout floats per kh, odd: Cout).  tile: 22 (default) 21 12 11; + 200:
+ * 32-deep barrier intervals (two-piece arithmetic, seg a multiple of 32: else -2) -- a row's 128 bytes per
+ * interval are one cache line fetched once. */
 typedef struct S2tRowMap {
   int hw, w;
   long sb, sh, sw, base;

@@ -668,7 +668,7 @@ __global__ __launch_bounds__(128 * WM, WPC * WM / 2) void x3p_dma_kernel(X3P g) 
   constexpr int NBW = (NRUN + NWV - 1) / NWV;       // ... per wave
   constexpr int SCR = NWV * 16 * 36 * 4;
   static_assert(2 * BM * KS % NT == 0 || (TM == 1 && KS == 1), "A units");
-  static_assert(!MAP || KS == 1, "implicit operands: 16-deep stages");
+  // (implicit operands with KS = 2: a segment is a whole number of 32-deep intervals, checked by the entry point)
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * ST > SCR ? 2 * ST : SCR];
   const unsigned lds0 = x3p_lds_addr(smem);
 
@@ -738,10 +738,11 @@ __global__ __launch_bounds__(128 * WM, WPC * WM / 2) void x3p_dma_kernel(X3P g) 
     const int ss_ = min((S), nss - 1);                                                       \
     long ko_ = 16L * KS * ss_;                                                               \
     if (MAP) {                         /* stage -> (segment, offset inside it): uniform */    \
-      const int sg_ = ss_ / g.seg16;                                                         \
+      const int spi_ = g.seg16 / KS;                       /* intervals per segment */        \
+      const int sg_ = ss_ / spi_;                                                            \
       /* (selects, not g.segoff[sg_]: a dynamic index would put the array in scratch) */      \
       const long so_ = sg_ == 0 ? g.segoff[0] : sg_ == 1 ? g.segoff[1] : sg_ == 2 ? g.segoff[2] : g.segoff[3]; \
-      ko_ = so_ + 16L * (ss_ - sg_ * g.seg16);                                               \
+      ko_ = so_ + 16L * KS * (ss_ - sg_ * spi_);                                             \
     }                                                                                        \
     _Pragma("unroll") for (int i = 0; i < NAU; ++i) {                                        \
       /* (a k tail is read from the row's start and zeroed when it is split) */              \
@@ -926,13 +927,13 @@ void launch_x3p_dma8(X3P& g, hipStream_t st) {
   X3P_LAUNCH((x3p_dma_kernel<TM, TN, WPC, false, NP, KS, false, 4>), grid, 512, 0);
 }
 
-template <int TM, int TN, int WPC, int NP = 3>
+template <int TM, int TN, int WPC, int NP = 3, int KS = 1>
 void launch_x3p_map(X3P& g, hipStream_t st) {
   g.tiles_m = (g.M + 64 * TM - 1) / (64 * TM);
   g.tiles_n = (g.N + 64 * TN - 1) / (64 * TN);
   const int total = g.tiles_m * g.tiles_n;
   const int grid = std::min(((total + 7) / 8) * 8, 256 * WPC);
-  X3P_LAUNCH((x3p_dma_kernel<TM, TN, WPC, true, NP>), grid, 256, 0);
+  X3P_LAUNCH((x3p_dma_kernel<TM, TN, WPC, true, NP, KS>), grid, 256, 0);
 }
 
 template <int TM, int TN, int NP = 3>
@@ -1281,6 +1282,19 @@ int s2t_gemm_x3p_map(const float* A, const S2tRowMap* amap, int seg, int nseg, c
   for (int i = 0; i < nseg; ++i) g.segoff[i] = segoff[i];
   hipStream_t st = (hipStream_t)stream;
   ++g_x3p_calls;
+  // tile + 200: 32-deep barrier intervals (two-piece arithmetic; segments of whole 32-deep intervals) -- a
+  // row's 128 bytes per interval are one cache line, fetched once (16-deep stages fetch every line twice)
+  if (tile >= 200) {
+    if (s2t_gemm_arith() != 2 || (seg & 31)) return -2;
+    switch (tile - 200) {
+      case 21: launch_x3p_map<2, 1, 3, 2, 2>(g, st); break;
+      case 12: launch_x3p_map<1, 2, 3, 2, 2>(g, st); break;
+      case 11: launch_x3p_map<1, 1, 4, 2, 2>(g, st); break;
+      default: launch_x3p_map<2, 2, 2, 2, 2>(g, st); break;
+    }
+    S2T_CHECK_LAUNCH();
+    return 0;
+  }
   if (s2t_gemm_arith() == 2) {
     switch (tile) {
       case 21: launch_x3p_map<2, 1, 4, 2>(g, st); break;

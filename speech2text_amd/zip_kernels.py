@@ -1975,7 +1975,7 @@ class _Conv3x3Nhwc(torch.autograd.Function):
 
 
 _CONV_MAP_DGRAD = os.environ.get("S2T_CONV_MAP_DGRAD", "1") == "1"
-_CONV_MAP_DGRAD_TILE = int(os.environ.get("S2T_CONV_MAP_DGRAD_TILE", "21"))
+_CONV_MAP_DGRAD_TILE = int(os.environ.get("S2T_CONV_MAP_DGRAD_TILE", "221"))    # (128 x 64 block, 32-deep intervals)
 
 
 _PAD_BUF = {}
@@ -2024,7 +2024,13 @@ class RowMap(ctypes.Structure):
                 ("sw", ctypes.c_long), ("base", ctypes.c_long)]
 
 
-def _x3p_map(a, amap, seg, segoff, pp, ncols, out, ldc, cmap, c_elems, M, bias, tile=22):
+_CONV_MAP_TILE = int(os.environ.get("S2T_CONV_MAP_TILE", "22"))
+
+
+def _x3p_map(a, amap, seg, segoff, pp, ncols, out, ldc, cmap, c_elems, M, bias, tile=None):
+    tile = _CONV_MAP_TILE if tile is None else tile
+    if tile >= 200 and (seg % 32 or N.lib().s2t_gemm_arith() != 2):
+        tile -= 200                        # (32-deep intervals: two pieces, segments of whole intervals)
     so = (ctypes.c_long * len(segoff))(*segoff)
     N.PROF[0] and N.profile_note("s2t_gemm_x3p_map", 4.0 * (a.numel() + out.numel()) + 6.0 * ncols * seg * len(segoff),
                                  2.0 * M * ncols * seg * len(segoff))
