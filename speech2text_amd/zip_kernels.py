@@ -514,6 +514,7 @@ def limit_param_grad(x, g, lo, hi):
     _dev(x, g)
     xc, gc = x.contiguous().float(), g.contiguous().float()
     out = torch.empty_like(gc)
+    N.PROF[0] and N.profile_note("s2t_limit_param_grad", 12.0 * gc.numel())
     N.check(N.lib().s2t_limit_param_grad(N.fp(xc), N.fp(gc), float(lo), float(hi), gc.numel(),
                                          N.fp(out), N.stream()), "s2t_limit_param_grad")
     return out.view(g.shape)
