@@ -949,6 +949,7 @@ typedef struct S2tZipLayerCall {
   int conv_w_side, conv_fused, stats_side, wgrad_side, bmm_own;
   int bal_epi;                     /* hidden Balancers in the dgrad epilogue (s2t_gemm_x3p_bal) */
   int whiten_sq;                   /* Whiten's norms in the x dcov product's epilogue (s2t_gemm_f32_sq) */
+  int bal_fwd_side;                /* firing Balancers' column statistics taken in forward on the side stream (round 6) */
 } S2tZipLayerCall;
 long s2t_zip_layer_state_bytes(void);
 long s2t_zip_layer_ws_floats(const S2tZipLayerDesc* desc, const S2tZipLayerCall* call, int backward);

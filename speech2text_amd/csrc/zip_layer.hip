@@ -87,6 +87,7 @@ int half_octave(long m) {            // floor(2 log2 m), as zip_kernels._half_oc
   return 2 * b + (((double)m * (double)m >= std::ldexp(1.0, 2 * b + 1)) ? 1 : 0);
 }
 
+constexpr int kBalSites = 15;
 struct WStat {
   int on;
   float *cov, *mean, *scal, *host;
@@ -114,6 +115,13 @@ struct State {
   SaS sa[2];
   CvS cv[2];
   int fm_fused;
+  // column statistics of the firing Balancers' inputs, taken in FORWARD on the side stream (round 6):
+  // sites 0-2 ff.post, 3-5 ff.hidden, 6-7 conv.bal1, 8-9 conv.bal2, 10 na.post, 11 na.bal, 12 bal1,
+  // 13 bal2, 14 bal_keys; NULL = backward takes them itself.  bal_ev: recorded on the side stream after
+  // the layer's last statistics launch; backward's stream waits for it once.
+  float* bst[kBalSites];
+  hipEvent_t bal_ev;
+  int bal_fwd;
   // backward
   int wh_active[S2T_ZL_NWHITEN];
   int pen_active;
@@ -189,6 +197,7 @@ struct Epi {
   float* out2 = nullptr;
   const float* resid_b = nullptr;
   const S2tZlBal* bal = nullptr;     // Balancer on act_src, folded into the epilogue (s2t_gemm_x3p_bal)
+  float* bal_stats = nullptr;        // its column statistics if forward took them (4096 floats), else NULL
 };
 constexpr float kSwOff[3] = {0.f, 4.0f, 1.0f};
 constexpr float kSwC[3] = {0.f, 0.035f, 0.313261687f};
@@ -201,7 +210,7 @@ int plan_missing(const Ctx& c, int mode, long R, const S2tZlLin& L) {
 }
 
 int balancer_bwd(Ctx& c, const S2tZlBal& b, const float* x, long ldx, const float* g, long ldg, long R,
-                 int C, float* out, long ldo, float act_off);
+                 int C, float* out, long ldo, float act_off, const float* stats = nullptr);
 
 int lt_matmul(Ctx& c, int mode, const float* x, long ldx, long R, const S2tZlLin& L, const Epi& e,
               float* out) {
@@ -231,11 +240,13 @@ int lt_matmul(Ctx& c, int mode, const float* x, long ldx, long R, const S2tZlLin
     }
   }
   if (e.bal && !c.c.bal_epi) own = false;          // (A/B switch: plain product + the two-pass update)
-  float* bstats = (e.bal && own) ? c.ar.alloc(4096) : nullptr;      // sums | squares | a | b (s2t_gemm_x3p_bal)
+  float* bstats = e.bal_stats ? e.bal_stats : ((e.bal && own) ? c.ar.alloc(4096) : nullptr);   // sums | squares | a | b
   if (own && !c.dry && e.bal) {
     if (cols <= 1024) {
-      HIPRUN(hipMemsetAsync(bstats, 0, 2048 * sizeof(float), c.st));
-      RUN(s2t_balancer_stats(e.act_src, cols, R, cols, bstats, (void*)c.st));
+      if (!e.bal_stats) {
+        HIPRUN(hipMemsetAsync(bstats, 0, 2048 * sizeof(float), c.st));
+        RUN(s2t_balancer_stats(e.act_src, cols, R, cols, bstats, (void*)c.st));
+      }
       const int rc = s2t_gemm_x3p_bal(x, ldx, pp, cols, inner, out, cols, (int)R, e.resid2, cols, e.act_src, cols,
                                       e.act_kind, tile, bstats, e.bal->min_mean, e.bal->max_mean, e.bal->min_rms,
                                       e.bal->max_rms, e.bal->grad_scale, (void*)c.st);
@@ -253,7 +264,7 @@ int lt_matmul(Ctx& c, int mode, const float* x, long ldx, long R, const S2tZlLin
     float* t = c.ar.alloc(n);
     Epi plain;
     TRY(lt_matmul(c, mode, x, ldx, R, L, plain, t));
-    return balancer_bwd(c, *e.bal, e.act_src, cols, t, cols, R, cols, out, cols, kSwOff[e.act_kind]);
+    return balancer_bwd(c, *e.bal, e.act_src, cols, t, cols, R, cols, out, cols, kSwOff[e.act_kind], e.bal_stats);
   }
   float* y = out;
   float* tmp = nullptr;
@@ -412,8 +423,13 @@ int whiten_bwd(Ctx& c, int site, const S2tZlWh& w, WStat& s, const float* x, lon
 }
 
 int balancer_bwd(Ctx& c, const S2tZlBal& b, const float* x, long ldx, const float* g, long ldg, long R,
-                 int C, float* out, long ldo, float act_off) {
+                 int C, float* out, long ldo, float act_off, const float* stats) {
   if (c.dry) return 0;
+  if (stats) {                       // forward took the column statistics (side stream): the update alone
+    RUN(s2t_balancer_apply(x, ldx, g, ldg, R, C, b.min_mean, b.max_mean, b.min_rms, b.max_rms, b.grad_scale, out,
+                           ldo, stats, act_off, (void*)c.st));
+    return 0;
+  }
   const int parity = s2t_balancer_next_parity();
   RUN(s2t_balancer_bwd(x, ldx, g, ldg, R, C, b.min_mean, b.max_mean, b.min_rms, b.max_rms, b.grad_scale,
                        out, ldo, c.c.bal_ws, parity, act_off, (void*)c.st));
@@ -439,6 +455,23 @@ int wgrad(Ctx& c, const S2tZlLin& L, const float* g2, long ldg, const float* a2,
 
 int copy2d(Ctx& c, float* dst, long ldd, const float* src, long lds, int cols, long rows) {
   HIPRUN(hipMemcpy2DAsync(dst, ldd * 4, src, lds * 4, (size_t)cols * 4, (size_t)rows, hipMemcpyDeviceToDevice, c.st));
+  return 0;
+}
+
+// Column statistics of a firing Balancer's input where the input is produced: the side stream, ordered
+// after the producer; backward then runs only the update on the data-gradient chain (the statistics pass
+// was 54 launches per step on that chain: 0.8 ms).  n = 4096 for a Balancer whose update may ride in a
+// data-gradient GEMM's epilogue (s2t_gemm_x3p_bal writes its coefficients into the second half).
+int bal_stats_fwd(Ctx& c, int site, const float* x, long ldx, long R, int C, int n = 2048) {
+  c.s.bst[site] = nullptr;
+  if (!c.c.bal_fwd_side || (!c.dry && !c.side) || C > 1024) return 0;   // (the dry run has no streams: it sizes for the side form)
+  float* st = c.ar.alloc(n);
+  c.s.bst[site] = st;
+  if (c.dry) return 0;
+  TRY(fork_side(c));
+  HIPRUN(hipMemsetAsync(st, 0, 2048 * sizeof(float), c.side));
+  RUN(s2t_balancer_stats(x, ldx, R, C, st, (void*)c.side));
+  c.s.bal_fwd = 1;
   return 0;
 }
 
@@ -475,8 +508,12 @@ int ff_fwd(Ctx& c, int i, int d0, const float* x_in, const float** x_out) {
   e.act2 = 1;
   e.out2 = sv.a;
   TRY(lt_matmul(c, 0, x_in, c.d.D, R, m.in, e, sv.h));
+  c.s.bst[3 + i] = nullptr;
+  if (dec(c, d0)) TRY(bal_stats_fwd(c, 3 + i, sv.h, F, R, F, 4096));
   float* out;
   TRY(out_proj(c, m.out, sv.a, R, x_in, fw || fp, &sv.y, &out));
+  c.s.bst[i] = nullptr;
+  if (fp) TRY(bal_stats_fwd(c, i, sv.y, c.d.D, R, c.d.D));
   sv.st.on = 0;
   if (fw) TRY(whiten_stats(c, sv.st, sv.y, c.d.D, R, c.d.D, m.out_wh.groups));
   *x_out = out;
@@ -515,12 +552,15 @@ int conv_fwd(Ctx& c, int i, int d0, const float* x_in, const float** x_out) {
   Epi e;
   e.bias = m.in.b;
   TRY(lt_matmul(c, 0, x_in, D, R, m.in, e, sv.u));
+  c.s.bst[6 + i] = c.s.bst[8 + i] = nullptr;
+  if (dec(c, d0)) TRY(bal_stats_fwd(c, 6 + i, sv.u + D, 2 * D, R, D));
   sv.chunk = (c.c.chunk_size < 0 || c.c.chunk_size > T) ? T : c.c.chunk_size;
   sv.y = c.ar.alloc(R * D);
   sv.a = c.ar.alloc(R * D);
   // (SwooshR(y) leaves with the conv's output tile: no activation pass)
   RUN(s2t_zipconv_fwd_act(sv.u, 2 * D, D, c.c.k8, T, B, D, m.K, sv.chunk, m.wc, m.bc, m.wk, m.bk, m.scale, sv.y,
                           sv.a, 2, (void*)c.st));
+  if (dec(c, d0 + 1)) TRY(bal_stats_fwd(c, 8 + i, sv.y, D, R, D, 4096));
   sv.st.on = 0;
   if (fw) TRY(whiten_stats(c, sv.st, sv.y, D, R, D, m.wh.groups));
   float* out = c.ar.alloc(R * D);
@@ -544,6 +584,8 @@ int na_fwd(Ctx& c, const float* x_in, const float** x_out) {
   Epi e;
   e.bias = m.in.b;
   TRY(lt_matmul(c, 0, x_in, D, R, m.in, e, sv.u));
+  c.s.bst[10] = c.s.bst[11] = nullptr;
+  if (dec(c, 7)) TRY(bal_stats_fwd(c, 11, sv.u, 3 * C, R, C));
   sv.xs = c.ar.alloc(R * C);
   RUN(s2t_nonlin_gate_fwd(sv.u, T, B, C, sv.xs, (void*)c.st));
   sv.z = c.ar.alloc(R * C);
@@ -554,6 +596,7 @@ int na_fwd(Ctx& c, const float* x_in, const float** x_out) {
   if (fw1) TRY(whiten_stats(c, sv.st1, sv.u + C, 3 * C, R, C, m.wh1.groups));
   float* out;
   TRY(out_proj(c, m.out, sv.o, R, x_in, fw2 || fp, &sv.y, &out));
+  if (fp) TRY(bal_stats_fwd(c, 10, sv.y, D, R, D));
   sv.st2.on = 0;
   if (fw2) TRY(whiten_stats(c, sv.st2, sv.y, D, R, D, m.wh2.groups));
   *x_out = out;
@@ -571,6 +614,8 @@ int layer_fwd(Ctx& c) {
   s.B = B;
   s.nprob = 0;
   s.x[0] = c.c.x0;
+  s.bal_fwd = 0;
+  for (int i = 0; i < kBalSites; ++i) s.bst[i] = nullptr;
   // attention weights (zipformer.py:1966-2066)
   s.qkp = c.ar.alloc(R * Dp);
   {
@@ -578,6 +623,7 @@ int layer_fwd(Ctx& c) {
     e.bias = d.attn_in.b;
     TRY(lt_matmul(c, 0, s.x[0], D, R, d.attn_in, e, s.qkp));
   }
+  if (dec(c, 0)) TRY(bal_stats_fwd(c, 14, s.qkp + H * qd, Dp, R, H * qd));
   s.kst.on = 0;
   if (dec(c, 1)) TRY(whiten_stats(c, s.kst, s.qkp + H * qd, Dp, R, H * qd, d.wh_keys.groups));
   s.posp = nullptr;
@@ -613,6 +659,7 @@ int layer_fwd(Ctx& c) {
   TRY(sa_fwd(c, 1, 19, s.x[6], &s.x[7]));
   TRY(conv_fwd(c, 1, 20, s.x[7], &s.x[8]));
   TRY(ff_fwd(c, 2, 23, s.x[8], &s.x[9]));
+  if (dec(c, 26)) TRY(bal_stats_fwd(c, 12, s.x[9], D, R, D));
   s.nscales = c.ar.alloc(R);
   s.x[10] = nullptr;                     // norm(x9) is never stored: backward recomputes x9 * nscales
   s.x[11] = c.c.out;
@@ -621,8 +668,14 @@ int layer_fwd(Ctx& c) {
   s.fm_fused = c.c.fm != nullptr && !(dec(c, 30) || dec(c, 29));
   RUN(s2t_norm_bypass_fwd(s.x[9], d.norm_bias.x, d.norm_ls.x, s.x[0], d.byp.x, s.fm_fused ? c.c.fm : nullptr, B, R,
                           D, c.c.out, s.nscales, (void*)c.st));
+  if (dec(c, 29)) TRY(bal_stats_fwd(c, 13, c.c.out, D, R, D));
   s.wst.on = 0;
   if (dec(c, 30)) TRY(whiten_stats(c, s.wst, c.c.out, D, R, D, d.wh_out.groups));
+  if (s.bal_fwd && !c.dry) {             // backward's stream waits for this once (layer_bwd)
+    s.bal_ev = ring_event();
+    if (!s.bal_ev) return fail(-1, "balancer statistics event");
+    HIPRUN(hipEventRecord(s.bal_ev, c.side));
+  }
   return 0;
 }
 
@@ -637,7 +690,7 @@ int ff_bwd(Ctx& c, int i, int d0, const float* x_in, const float* g, const float
   const float* gy = g;
   if (fp) {
     float* o = c.ar.alloc(R * D);
-    TRY(balancer_bwd(c, m.post, sv.y, D, gy, D, R, D, o, D, -1.0f));
+    TRY(balancer_bwd(c, m.post, sv.y, D, gy, D, R, D, o, D, -1.0f, c.s.bst[i]));
     gy = o;
   }
   if (fw) TRY(whiten_bwd(c, site, m.out_wh, sv.st, sv.y, D, R, D, gy, &gy));
@@ -648,6 +701,7 @@ int ff_bwd(Ctx& c, int i, int d0, const float* x_in, const float* g, const float
     e.act_src = sv.h;
     e.act_kind = 1;
     e.bal = &m.hidden;
+    e.bal_stats = c.s.bst[3 + i];
     TRY(lt_matmul(c, 1, gy, D, R, m.out, e, dh));
   } else {                                   // ... or in the data-gradient GEMM's epilogue
     Epi e;
@@ -705,6 +759,7 @@ int conv_bwd(Ctx& c, int i, int d0, const float* x_in, const float* g, const flo
     e.act_src = sv.y;
     e.act_kind = 2;
     e.bal = &m.bal2;
+    e.bal_stats = c.s.bst[8 + i];
     TRY(lt_matmul(c, 1, g, D, R, m.out, e, o));
     dy = o;
   } else {                                   // ... or in the data-gradient GEMM's epilogue
@@ -717,7 +772,7 @@ int conv_bwd(Ctx& c, int i, int d0, const float* x_in, const float* g, const flo
     if (fw) TRY(whiten_bwd(c, i == 0 ? 5 : 8, m.wh, sv.st, sv.y, D, R, D, dy, &dy));
     if (fb2) {
       float* o = c.ar.alloc(R * D);
-      TRY(balancer_bwd(c, m.bal2, sv.y, D, dy, D, R, D, o, D, -1.0f));
+      TRY(balancer_bwd(c, m.bal2, sv.y, D, dy, D, R, D, o, D, -1.0f, c.s.bst[8 + i]));
       dy = o;
     }
   }
@@ -734,7 +789,7 @@ int conv_bwd(Ctx& c, int i, int d0, const float* x_in, const float* g, const flo
     RUN(s2t_zipconv_bwd(sv.u, 2 * D, D, c.c.k8, T, B, D, m.K, sv.chunk, m.wc, m.wk, m.bk, m.scale, dy, du, m.gwc,
                         m.gbc, m.gwk, m.gbk, m.gscale, ws, (void*)c.st));
   }
-  if (fb1) TRY(balancer_bwd(c, m.bal1, sv.u + D, 2 * D, du + D, 2 * D, R, D, du + D, 2 * D, -1.0f));
+  if (fb1) TRY(balancer_bwd(c, m.bal1, sv.u + D, 2 * D, du + D, 2 * D, R, D, du + D, 2 * D, -1.0f, c.s.bst[6 + i]));
   TRY(wgrad(c, m.in, du, 2 * D, x_in, D, R));
   float* gx = c.ar.alloc(R * D);
   Epi e;
@@ -753,7 +808,7 @@ int na_bwd(Ctx& c, const float* x_in, const float* g, const float** g_out) {
   const float* gy = g;
   if (fp) {
     float* o = c.ar.alloc(R * D);
-    TRY(balancer_bwd(c, m.post, sv.y, D, gy, D, R, D, o, D, -1.0f));
+    TRY(balancer_bwd(c, m.post, sv.y, D, gy, D, R, D, o, D, -1.0f, c.s.bst[10]));
     gy = o;
   }
   if (fw2) TRY(whiten_bwd(c, 3, m.wh2, sv.st2, sv.y, D, R, D, gy, &gy));
@@ -772,7 +827,7 @@ int na_bwd(Ctx& c, const float* x_in, const float* g, const float** g_out) {
   c.s.dW0 = c.ar.alloc((long)B * T * T);
   TRY(bmm(c, 0, dz, sv.xs, c.s.dW0, B, T, T, C));                 // dz @ x^T
   RUN(s2t_nonlin_gate_bwd(dxs, sv.u, T, B, C, du, (void*)c.st));
-  if (fb) TRY(balancer_bwd(c, m.bal, sv.u, 3 * C, du, 3 * C, R, C, du, 3 * C, -1.0f));
+  if (fb) TRY(balancer_bwd(c, m.bal, sv.u, 3 * C, du, 3 * C, R, C, du, 3 * C, -1.0f, c.s.bst[11]));
   if (fw1) {
     float* gc = c.ar.alloc(R * C);
     TRY(copy2d(c, gc, C, du + C, 3 * C, C, R));
@@ -801,6 +856,7 @@ int layer_bwd(Ctx& c, int phase) {
     s.nprob = 0;
     for (int i = 0; i < S2T_ZL_NWHITEN; ++i) s.wh_active[i] = -1;
     s.pen_active = 0;
+    if (s.bal_fwd) HIPRUN(hipStreamWaitEvent(c.st, s.bal_ev, 0));   // forward's Balancer statistics (side stream)
     if (dec(c, 3) && !c.dry) {
       if (hipEventSynchronize(s.pen_ev) != hipSuccess) return fail(-1, "penalty flag event");
       s.pen_active = *reinterpret_cast<volatile float*>(s.pen_slot) != 0.f;
@@ -810,7 +866,7 @@ int layer_bwd(Ctx& c, int phase) {
     if (dec(c, 30)) TRY(whiten_bwd(c, 10, d.wh_out, s.wst, x11, D, R, D, g, &g));
     if (dec(c, 29)) {
       float* o = c.ar.alloc(R * D);
-      TRY(balancer_bwd(c, d.bal2, x11, D, g, D, R, D, o, D, -1.0f));
+      TRY(balancer_bwd(c, d.bal2, x11, D, g, D, R, D, o, D, -1.0f, s.bst[13]));
       g = o;
     }
     // per-channel parameter gradients: [bypass scale | bypass_mid scale | norm bias | log_scale]
@@ -822,7 +878,7 @@ int layer_bwd(Ctx& c, int phase) {
     const float* g9 = g9w;
     if (dec(c, 26)) {
       float* o = c.ar.alloc(R * D);
-      TRY(balancer_bwd(c, d.bal1, s.x[9], D, g9, D, R, D, o, D, -1.0f));
+      TRY(balancer_bwd(c, d.bal1, s.x[9], D, g9, D, R, D, o, D, -1.0f, s.bst[12]));
       g9 = o;
     }
     const float *g8, *g7, *g6, *g4, *g3, *g2, *g1, *g0;
@@ -872,7 +928,7 @@ int layer_bwd(Ctx& c, int phase) {
     if (dec(c, 1)) TRY(whiten_bwd(c, 0, d.wh_keys, s.kst, s.qkp + Ck, Dp, R, Ck, cur, &cur));
     if (dec(c, 0)) {
       float* o = c.ar.alloc(R * Ck);
-      TRY(balancer_bwd(c, d.bal_keys, s.qkp + Ck, Dp, cur, Ck, R, Ck, o, Ck, -1.0f));
+      TRY(balancer_bwd(c, d.bal_keys, s.qkp + Ck, Dp, cur, Ck, R, Ck, o, Ck, -1.0f, s.bst[14]));
       cur = o;
     }
     TRY(copy2d(c, dqkp + Ck, Dp, cur, Ck, Ck, R));

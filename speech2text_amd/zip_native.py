@@ -20,6 +20,7 @@ from . import planes
 from . import zip_kernels as zk
 
 ENABLED = os.environ.get("S2T_LAYER_NATIVE", "1") == "1"
+_BAL_FWD_SIDE = os.environ.get("S2T_BAL_FWD_SIDE", "1") == "1"   # Balancer column statistics in forward, side stream
 CALLS = [0, 0]           # forward / backward calls served natively (tests assert the path really ran)
 _F32 = torch.float32
 NDEC, NWHITEN = 32, 11
@@ -91,7 +92,7 @@ class Call(ctypes.Structure):
                 ("whiten_x3p", ctypes.c_int),
                 ("conv_w_side", ctypes.c_int), ("conv_fused", ctypes.c_int), ("stats_side", ctypes.c_int),
                 ("wgrad_side", ctypes.c_int), ("bmm_own", ctypes.c_int), ("bal_epi", ctypes.c_int),
-                ("whiten_sq", ctypes.c_int)]
+                ("whiten_sq", ctypes.c_int), ("bal_fwd_side", ctypes.c_int)]
 
 
 def _dp(t):
@@ -352,6 +353,7 @@ def _fill_call(L, T, B, D, chunk_size, x0, pos2, a8, k8, fm, dec, dev):
     c.bmm_own = int(zk._BMM_OWN)
     c.bal_epi = int(zk._BAL_EPI)
     c.whiten_sq = int(zk._WHITEN_SQ)
+    c.bal_fwd_side = int(_BAL_FWD_SIDE and side)
     return c
 
 
@@ -403,8 +405,8 @@ class _NativeLayerFn(torch.autograd.Function):
                                        N.stream(), _side_handle())
         if rc != 0:
             _err(rc, "s2t_zip_layer_fwd")
-        if call.stats_side and (d.k_wh or d.ff1[1] or d.na[1] or d.na[2] or d.sa1 or d.cv1[2] or d.ff2[1]
-                                or d.sa2 or d.cv2[2] or d.ff3[1] or d.wh_out):
+        if call.bal_fwd_side or (call.stats_side and (d.k_wh or d.ff1[1] or d.na[1] or d.na[2] or d.sa1 or d.cv1[2]
+                                                      or d.ff2[1] or d.sa2 or d.cv2[2] or d.ff3[1] or d.wh_out)):
             # the side stream may still be reading the workspace / the output when this object dies
             # without a backward pass (a forward under train()): keep them until the join
             zk._Side.keep.append((wsf, x11, x0))
