@@ -762,8 +762,13 @@ int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int 
  * act_src) with a, b derived from bal_stats = 4096 floats: column sums [0..N) and sums of squares
  * [1024..1024+N) of act_src over its M rows (s2t_balancer_stats into a zeroed buffer); the call writes
  * the per-column a, b into [2048..) and [3072..) with one small launch before the product (N <= 1024).
+ * s2t_balancer_coef is that small launch as its own call, for a caller that takes the statistics early
+ * (forward pass, side stream): it then passes tile | S2T_X3P_BAL_COEF_READY.
  * Replaces the separate s2t_balancer_apply pass over the (M, N) gradient.  -2: shape / tile outside the
  * kernel's rules. */
+#define S2T_X3P_BAL_COEF_READY (1 << 20)   /* or-ed into `tile`: s2t_balancer_coef already filled [2048..4096) */
+int s2t_balancer_coef(float* bal_stats, int N, long rows, float min_mean, float max_mean, float min_rms,
+                      float max_rms, float grad_scale, void* stream);
 int s2t_gemm_x3p_bal(const float* A, long lda, const unsigned short* Bp, int N, int K, float* C, long ldc,
                      int M, const float* resid, long ldr, const float* act_src, long ld_act, int act_kind,
                      int tile, float* bal_stats, float min_mean, float max_mean, float min_rms,

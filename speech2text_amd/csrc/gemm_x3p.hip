@@ -1326,8 +1326,11 @@ int s2t_gemm_x3p_bal(const float* A, long lda, const unsigned short* Bp, int N, 
                      int tile, float* bal_stats, float min_mean, float max_mean, float min_rms,
                      float max_rms, float grad_scale, void* stream) {
   if (!bal_stats || !act_src || N > 1024) return -1;
-  hipLaunchKernelGGL(bal_coef_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, bal_stats,
-                     bal_stats + 2048, N, (float)M, min_mean, max_mean, min_rms, max_rms, grad_scale);
+  const bool have_coef = (tile & S2T_X3P_BAL_COEF_READY) != 0;    // (s2t_balancer_coef ran where the statistics were taken)
+  tile &= ~S2T_X3P_BAL_COEF_READY;
+  if (!have_coef)
+    hipLaunchKernelGGL(bal_coef_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, bal_stats,
+                       bal_stats + 2048, N, (float)M, min_mean, max_mean, min_rms, max_rms, grad_scale);
   g_bal.stats = bal_stats;
   g_bal.n = (float)M;
   g_bal.min_mean = min_mean;
@@ -1339,6 +1342,18 @@ int s2t_gemm_x3p_bal(const float* A, long lda, const unsigned short* Bp, int N, 
                               0, 0, nullptr, 0, tile, stream);
   g_bal.stats = nullptr;
   return rc;
+}
+
+// The coefficient pass of s2t_gemm_x3p_bal as its own call: bal_stats [0..2048) (s2t_balancer_stats over
+// `rows` rows) -> [2048..4096).  A caller that takes the statistics early (forward pass, side stream) runs
+// this there too and passes tile | S2T_X3P_BAL_COEF_READY to s2t_gemm_x3p_bal.
+int s2t_balancer_coef(float* bal_stats, int N, long rows, float min_mean, float max_mean, float min_rms,
+                      float max_rms, float grad_scale, void* stream) {
+  if (!bal_stats || N <= 0 || N > 1024 || rows <= 0) return -1;
+  hipLaunchKernelGGL(bal_coef_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, bal_stats,
+                     bal_stats + 2048, N, (float)rows, min_mean, max_mean, min_rms, max_rms, grad_scale);
+  S2T_CHECK_LAUNCH();
+  return 0;
 }
 
 // s2t_gemm_x3p (+ bias) that ALSO adds, while C leaves the accumulators, the squares of C and of a

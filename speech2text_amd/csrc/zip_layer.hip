@@ -248,7 +248,8 @@ int lt_matmul(Ctx& c, int mode, const float* x, long ldx, long R, const S2tZlLin
         RUN(s2t_balancer_stats(e.act_src, cols, R, cols, bstats, (void*)c.st));
       }
       const int rc = s2t_gemm_x3p_bal(x, ldx, pp, cols, inner, out, cols, (int)R, e.resid2, cols, e.act_src, cols,
-                                      e.act_kind, tile, bstats, e.bal->min_mean, e.bal->max_mean, e.bal->min_rms,
+                                      e.act_kind, tile | (e.bal_stats ? S2T_X3P_BAL_COEF_READY : 0), bstats,
+                                      e.bal->min_mean, e.bal->max_mean, e.bal->min_rms,
                                       e.bal->max_rms, e.bal->grad_scale, (void*)c.st);
       if (rc == 0) return 0;
       if (rc != -2) return fail(rc, "s2t_gemm_x3p_bal");
@@ -462,7 +463,8 @@ int copy2d(Ctx& c, float* dst, long ldd, const float* src, long lds, int cols, l
 // after the producer; backward then runs only the update on the data-gradient chain (the statistics pass
 // was 54 launches per step on that chain: 0.8 ms).  n = 4096 for a Balancer whose update may ride in a
 // data-gradient GEMM's epilogue (s2t_gemm_x3p_bal writes its coefficients into the second half).
-int bal_stats_fwd(Ctx& c, int site, const float* x, long ldx, long R, int C, int n = 2048) {
+int bal_stats_fwd(Ctx& c, int site, const float* x, long ldx, long R, int C, int n = 2048,
+                  const S2tZlBal* coef = nullptr) {
   c.s.bst[site] = nullptr;
   if (!c.c.bal_fwd_side || (!c.dry && !c.side) || C > 1024) return 0;   // (the dry run has no streams: it sizes for the side form)
   float* st = c.ar.alloc(n);
@@ -471,6 +473,9 @@ int bal_stats_fwd(Ctx& c, int site, const float* x, long ldx, long R, int C, int
   TRY(fork_side(c));
   HIPRUN(hipMemsetAsync(st, 0, 2048 * sizeof(float), c.side));
   RUN(s2t_balancer_stats(x, ldx, R, C, st, (void*)c.side));
+  if (coef)                          // (the epilogue form's per-column coefficients, off the data-gradient chain too)
+    RUN(s2t_balancer_coef(st, C, R, coef->min_mean, coef->max_mean, coef->min_rms, coef->max_rms, coef->grad_scale,
+                          (void*)c.side));
   c.s.bal_fwd = 1;
   return 0;
 }
@@ -509,7 +514,7 @@ int ff_fwd(Ctx& c, int i, int d0, const float* x_in, const float** x_out) {
   e.out2 = sv.a;
   TRY(lt_matmul(c, 0, x_in, c.d.D, R, m.in, e, sv.h));
   c.s.bst[3 + i] = nullptr;
-  if (dec(c, d0)) TRY(bal_stats_fwd(c, 3 + i, sv.h, F, R, F, 4096));
+  if (dec(c, d0)) TRY(bal_stats_fwd(c, 3 + i, sv.h, F, R, F, 4096, &m.hidden));
   float* out;
   TRY(out_proj(c, m.out, sv.a, R, x_in, fw || fp, &sv.y, &out));
   c.s.bst[i] = nullptr;
@@ -560,7 +565,7 @@ int conv_fwd(Ctx& c, int i, int d0, const float* x_in, const float** x_out) {
   // (SwooshR(y) leaves with the conv's output tile: no activation pass)
   RUN(s2t_zipconv_fwd_act(sv.u, 2 * D, D, c.c.k8, T, B, D, m.K, sv.chunk, m.wc, m.bc, m.wk, m.bk, m.scale, sv.y,
                           sv.a, 2, (void*)c.st));
-  if (dec(c, d0 + 1)) TRY(bal_stats_fwd(c, 8 + i, sv.y, D, R, D, 4096));
+  if (dec(c, d0 + 1)) TRY(bal_stats_fwd(c, 8 + i, sv.y, D, R, D, 4096, &m.bal2));
   sv.st.on = 0;
   if (fw) TRY(whiten_stats(c, sv.st, sv.y, D, R, D, m.wh.groups));
   float* out = c.ar.alloc(R * D);
