@@ -239,12 +239,16 @@ int s2t_whiten_metric(float* xtx, float* colsum, long n, int G, int cg, float* c
  * FORWARD on the statistics' stream, followed there by s2t_x3p_split of dcov into a per-site piece
  * buffer.  Backward is then s2t_gemm_x3p_sq (pg = x dcov + bias from dcov's pieces, with ||g||^2 and
  * ||pg||^2 taken in its epilogue: the norms are those of the pg actually computed, as the reference
- * takes them) and s2t_whiten_combine64 (out = g + pg * grad_scale ||g|| / (||pg|| + 1e-20)). */
+ * takes them) and s2t_whiten_combine64 (out = g + pg * grad_scale ||g|| / (||pg|| + 1e-20)).
+ * Late round 6: pg does not depend on the gradient either -- s2t_gemm_x3p_sq with other == NULL (only
+ * ||pg||^2 is taken) runs in FORWARD after the split, on the statistics' stream; backward's chain is
+ * s2t_sumsq64 (||g||^2 into row 0 of the same slots) + s2t_whiten_combine64. */
 int s2t_whiten_prep(const float* cov, const float* mean, const float* scal, int G, int cg, float* dcov,
                     float* bias, float* sums64, void* stream);
 int s2t_gemm_x3p_sq(const float* A, long lda, const unsigned short* Bp, int N, int K, float* C, long ldc,
                     int M, const float* bias, const float* other, long ld_other, float* sums, int tile,
                     void* stream);
+int s2t_sumsq64(const float* g, long numel, float* sums64, void* stream);
 int s2t_whiten_combine64(const float* g, const float* pg, long numel, float grad_scale,
                          const float* sums64, float* out, void* stream);
 int s2t_whiten_dcov(const float* cov, const float* mean, const float* scal, int G, int cg,
@@ -955,6 +959,7 @@ typedef struct S2tZipLayerCall {
   int bal_epi;                     /* hidden Balancers in the dgrad epilogue (s2t_gemm_x3p_bal) */
   int whiten_sq;                   /* Whiten's norms in the x dcov product's epilogue (s2t_gemm_f32_sq) */
   int bal_fwd_side;                /* firing Balancers' column statistics taken in forward on the side stream (round 6) */
+  int whiten_fwd_pg;               /* Whiten's penalty product x dcov taken in forward on the statistics' stream (round 6) */
 } S2tZipLayerCall;
 long s2t_zip_layer_state_bytes(void);
 long s2t_zip_layer_ws_floats(const S2tZipLayerDesc* desc, const S2tZipLayerCall* call, int backward);

@@ -1115,8 +1115,8 @@ int s2t_gemm_x3p(const float* A, long lda, const unsigned short* Bp, int N, int 
     if (act_src) { g.op[k] = act_src; g.ldop[k] = ld_act; g.role[k++] = 1; }
     if (resid) { g.op[k] = resid; g.ldop[k] = ldr; g.role[k++] = 2; }
     if (resid_b) { g.op[k] = resid_b; g.ldop[k] = ldrb; g.role[k++] = 3; }
-    if (g_sq.sums) {                     // the companion matrix: read for its squares only (role 4)
-      if (k > 1 || !g_sq.other) return -2;
+    if (g_sq.sums && g_sq.other) {       // the companion matrix: read for its squares only (role 4)
+      if (k > 1) return -2;
       g.op[k] = g_sq.other; g.ldop[k] = g_sq.ld; g.role[k++] = 4;
     }
   }
@@ -1365,8 +1365,10 @@ int s2t_balancer_coef(float* bal_stats, int N, long rows, float min_mean, float 
 int s2t_gemm_x3p_sq(const float* A, long lda, const unsigned short* Bp, int N, int K, float* C, long ldc,
                     int M, const float* bias, const float* other, long ld_other, float* sums, int tile,
                     void* stream) {
-  if (!sums || !other) return -1;
-  if ((reinterpret_cast<uintptr_t>(other) & 15) || (ld_other & 3) || (long)M * ld_other * 4 >= 0x7FFFFF00L)
+  if (!sums) return -1;
+  // other == NULL: only C's squares are taken (sums row 1) -- the form Whiten's forward uses: x dcov does not
+  // depend on the gradient, so it runs where the statistics run; backward adds ||g||^2 with s2t_sumsq64
+  if (other && ((reinterpret_cast<uintptr_t>(other) & 15) || (ld_other & 3) || (long)M * ld_other * 4 >= 0x7FFFFF00L))
     return -2;
   g_sq.sums = sums;
   g_sq.other = other;

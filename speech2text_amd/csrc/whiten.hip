@@ -283,6 +283,34 @@ extern "C" int s2t_whiten_prep(const float* cov, const float* mean, const float*
   return 0;
 }
 
+// sums64[slot] += partial sums of g^2 (64 slots: the same layout s2t_gemm_x3p_sq's epilogue adds into)
+namespace {
+__global__ __launch_bounds__(256) void sumsq64_kernel(const float* __restrict__ g, long numel,
+                                                      float* __restrict__ sums64) {
+  const long n4 = numel >> 2;
+  const long stride = (long)gridDim.x * blockDim.x;
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 v = g4[i];
+    acc += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += stride) acc += g[i] * g[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) atomicAdd(sums64 + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 63), acc);
+}
+}  // namespace
+
+extern "C" int s2t_sumsq64(const float* g, long numel, float* sums64, void* stream) {
+  if (numel <= 0) return 0;
+  if (!g || !sums64 || (reinterpret_cast<uintptr_t>(g) & 15)) return -1;
+  const long n4 = numel >> 2;
+  const unsigned blocks = (unsigned)std::min<long>(1024, std::max<long>(1, (n4 + 255) / 256));
+  hipLaunchKernelGGL(sumsq64_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, numel, sums64);
+  S2T_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int s2t_whiten_combine64(const float* g, const float* pg, long numel, float grad_scale,
                                     const float* sums64, float* out, void* stream) {
   if (numel <= 0) return 0;

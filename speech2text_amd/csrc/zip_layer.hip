@@ -96,6 +96,7 @@ struct WStat {
   // round-6 form (whiten_x3p == 2): written in forward on the statistics' stream; sums = [2][64] slots
   float *dcov, *bias, *sums;
   unsigned short* pieces;
+  float* pg;                 // x dcov + bias, taken in forward as well (whiten_fwd_pg), or NULL
 };
 struct FfS { float *h, *a, *y; WStat st; };
 struct SaS { float *v, *o, *y; WStat st; int dv; };
@@ -335,6 +336,9 @@ int whiten_stats(Ctx& c, WStat& s, const float* x, long ldx, long R, int C, int 
     s.sums = c.ar.alloc(128);
     s.pieces = reinterpret_cast<unsigned short*>(c.ar.alloc((s2t_x3p_plane_elems(C, C) + 1) / 2));
   }
+  // the penalty product itself depends on x only: on the statistics' stream too (backward then adds
+  // ||g||^2 and combines: the product was 35 us per firing Whiten on the data-gradient chain)
+  s.pg = (fused && c.c.whiten_fwd_pg) ? c.ar.alloc(R * C) : nullptr;
   if (c.dry) return 0;
   const S2tZlWhScratch* sc = wh_scratch(c, C);
   if (!sc) return fail(-1, "whiten_stats: no scratch for this channel count");
@@ -355,6 +359,14 @@ int whiten_stats(Ctx& c, WStat& s, const float* x, long ldx, long R, int C, int 
   if (s.pieces) {
     RUN(s2t_whiten_prep(s.cov, s.mean, s.scal, s.G, s.cg, s.dcov, s.bias, s.sums, (void*)q));
     RUN(s2t_x3p_split(s.dcov, sc->tab, 1, sc->blocks, s.pieces, (void*)q));
+    if (s.pg) {
+      static const int pg_cls = [] { const char* e = getenv("S2T_WHITEN_PG_CLS"); return e ? atoi(e) : 1; }();
+      const S2tGemmClass cls(pg_cls);
+      const bool two = s2t_gemm_arith_of(pg_cls) == 2;
+      const int tile = c.c.x3p_tile ? c.c.x3p_tile : ((C & 127) == 0 ? (two ? 2212 : 312) : (two ? 2221 : 321));
+      const int rc = s2t_gemm_x3p_sq(x, ldx, s.pieces, C, C, s.pg, C, (int)R, s.bias, nullptr, 0, s.sums, tile, (void*)q);
+      if (rc != 0) return fail(rc, "s2t_gemm_x3p_sq(whiten, forward)");
+    }
   }
   // (backward waits for this event on the host before it reads the metric: everything above is then
   //  complete, whichever stream it ran on)
@@ -374,6 +386,15 @@ int whiten_bwd(Ctx& c, int site, const S2tZlWh& w, WStat& s, const float* x, lon
   c.s.wh_active[site] = active ? 1 : 0;
   *out = g;
   if (!active) return 0;
+  if (s.pieces && s.pg && (reinterpret_cast<uintptr_t>(g) & 15) == 0) {
+    // pg and ||pg||^2 were taken in forward (the host wait on s.ev above covers them): ||g||^2, then combine
+    float* o = c.ar.alloc(R * C);
+    if (c.dry) return 0;
+    RUN(s2t_sumsq64(g, R * C, s.sums, (void*)c.st));
+    RUN(s2t_whiten_combine64(g, s.pg, R * C, w.grad_scale, s.sums, o, (void*)c.st));
+    *out = o;
+    return 0;
+  }
   if (s.pieces && (reinterpret_cast<uintptr_t>(g) & 15) == 0) {
     // (the prep launches were issued on the side stream in forward: the main stream joined it at the
     //  end of that pass, long before this call)

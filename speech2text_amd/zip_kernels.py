@@ -379,6 +379,7 @@ class WhitenStats:
         # include/s2t_mi355.h s2t_whiten_prep): d metric / d cov, its bias row and dcov's bf16 pieces
         # depend on x only -- taken now, on the statistics' stream
         self.pieces = None
+        self.pg = None
         ent = planes.adhoc_entry(C, C, 1, dev) if (_WHITEN_X3P == 2 and X3P["on"] and _tn_ok(xf) and C % 8 == 0
                                                     and cg <= 1024 and n >= 4
                                                     and n * max(C, xf.stride(0)) * 4 < 0x7FFFFF00) else None
@@ -394,12 +395,25 @@ class WhitenStats:
             N.PROF[0] and N.profile_note("s2t_x3p_split", 4.0 * C * C + 2.0 * self.pieces.numel())
             N.check(N.lib().s2t_x3p_split(self.dcov.data_ptr(), ent[0].data_ptr(), 1, ent[2],
                                           self.pieces.data_ptr(), q), "s2t_x3p_split")
+            if _WHITEN_FWD_PG:
+                # the penalty product x dcov + bias depends on x only as well: here, with ||pg||^2 from its
+                # epilogue (csrc/zip_layer.hip whiten_stats makes the same calls); backward adds ||g||^2
+                self.pg = torch.empty((n, C), dtype=torch.float32, device=dev)
+                N.PROF[0] and N.profile_note("s2t_gemm_x3p_sq", 4.0 * (xf.numel() + self.pg.numel()) + 6.0 * C * C,
+                                             2.0 * n * C * C)
+                two = gemm_arith(_WHITEN_PG2_CLS) == 2
+                tile = X3P["tile"] or ((2212 if two else 312) if C % 128 == 0 else (2221 if two else 321))
+                with gemm_class(_WHITEN_PG2_CLS):
+                    rc = N.lib().s2t_gemm_x3p_sq(N.raw(xf, torch.float32), xf.stride(0),
+                                                 ctypes.c_void_p(self.pieces.data_ptr()), C, C, N.fp(self.pg), C, n,
+                                                 N.fp(self.bias), None, 0, N.fp(self.sums), tile, q)
+                N.check(rc, "s2t_gemm_x3p_sq(forward)")
         if side is not None:
             # the side stream may still be reading x / writing the statistics when this object (or
             # a float() temporary of x) dies -- e.g. a forward under train() with no backward: the
             # caching allocator must not hand the memory to main-stream work before the join
             _Side.keep.append((xf, self.cov, self.mean, self.scal) +
-                              ((self.dcov, self.bias, self.sums, self.pieces) if self.pieces is not None else ()))
+                              ((self.dcov, self.bias, self.sums, self.pieces, self.pg) if self.pieces is not None else ()))
         self.event = torch.cuda.Event()
         if side is not None:
             self.event.record(N._launch_stream((side,)))
@@ -420,6 +434,11 @@ class WhitenStats:
 _WHITEN_X3P = int(os.environ.get("S2T_WHITEN_X3P", "2"))
 # the norms of (g, x dcov) taken in the product's epilogue (s2t_gemm_f32_sq) instead of by a pass over both
 _WHITEN_SQ = os.environ.get("S2T_WHITEN_SQ", "1") == "1"
+# the penalty product x dcov itself in forward, on the statistics' stream (late round 6; parity-tested).  OFF:
+# measured 33.49 / 33.46 / 33.12 against 32.78 / 32.79 / 32.63 ms per step with the product in backward -- a
+# GEMM with a 48-64 KB / 130-200 register footprint on the side stream costs forward's own GEMMs more than
+# the 25 us per firing Whiten it takes off backward's chain
+_WHITEN_FWD_PG = os.environ.get("S2T_WHITEN_FWD_PG", "0") == "1"
 
 
 _WHITEN_PG_CLS = int(os.environ.get("S2T_WHITEN_PG_CLS", "3"))   # class of the penalty product, three-launch form (csrc/zip_layer.hip whiten_bwd)
@@ -440,6 +459,15 @@ def whiten_backward(x, g, stats, limit, grad_scale):
     if getattr(stats, "pieces", None) is not None:
         xf = x.reshape(-1, C)
         g2 = g.contiguous().float()
+        if stats.pg is not None and g2.data_ptr() % 16 == 0:
+            # the product and ||pg||^2 were taken in forward (stats.metric() waited for their stream)
+            out = torch.empty_like(g2)
+            N.PROF[0] and N.profile_note("s2t_sumsq64", 4.0 * g2.numel())
+            N.check(N.lib().s2t_sumsq64(N.fp(g2), g2.numel(), N.fp(stats.sums), N.stream()), "s2t_sumsq64")
+            N.PROF[0] and N.profile_note("s2t_whiten_combine64", 12.0 * g2.numel())
+            N.check(N.lib().s2t_whiten_combine64(N.fp(g2), N.fp(stats.pg), g2.numel(), float(grad_scale),
+                                                 N.fp(stats.sums), N.fp(out), N.stream()), "s2t_whiten_combine64")
+            return out.view(shp), True
         if xf.dtype is torch.float32 and xf.stride(1) == 1 and g2.data_ptr() % 16 == 0:
             out = torch.empty_like(g2)
             pg = torch.empty_like(g2)

@@ -92,7 +92,7 @@ class Call(ctypes.Structure):
                 ("whiten_x3p", ctypes.c_int),
                 ("conv_w_side", ctypes.c_int), ("conv_fused", ctypes.c_int), ("stats_side", ctypes.c_int),
                 ("wgrad_side", ctypes.c_int), ("bmm_own", ctypes.c_int), ("bal_epi", ctypes.c_int),
-                ("whiten_sq", ctypes.c_int), ("bal_fwd_side", ctypes.c_int)]
+                ("whiten_sq", ctypes.c_int), ("bal_fwd_side", ctypes.c_int), ("whiten_fwd_pg", ctypes.c_int)]
 
 
 def _dp(t):
@@ -354,6 +354,7 @@ def _fill_call(L, T, B, D, chunk_size, x0, pos2, a8, k8, fm, dec, dev):
     c.bal_epi = int(zk._BAL_EPI)
     c.whiten_sq = int(zk._WHITEN_SQ)
     c.bal_fwd_side = int(_BAL_FWD_SIDE and side)
+    c.whiten_fwd_pg = int(zk._WHITEN_FWD_PG)
     return c
 
 

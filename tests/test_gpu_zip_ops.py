@@ -512,11 +512,13 @@ def test_downsample_and_upsampled_bypass_vs_torch(dev, T, B, C, ds):
 
 @pytest.mark.parametrize("R,C,G", [(700, 192, 1), (1000, 128, 4), (333, 96, 2), (2000, 512, 1),
                                    (500, 256, 8), (260, 64, 1)])
-@pytest.mark.parametrize("form", ["fused", "sq", "pass"])
+@pytest.mark.parametrize("form", ["fwdpg", "fused", "sq", "pass"])
 def test_whiten_backward_vs_oracle(dev, monkeypatch, R, C, G, form):
     """Whiten (scaling.py:949-1095): x^T x comes from the symmetric TN GEMM (only the 64x64 tiles on /
     above the diagonal with same-group pairs; cg = 48 straddles tiles), the metric kernel mirrors
-    them; the backward term against the oracle's autograd-in-backward statement.  form: "fused" = dcov
+    them; the backward term against the oracle's autograd-in-backward statement.  form: "fwdpg" (built
+    late in round 6, measured slower in the step, off by default) = the penalty product x dcov taken in FORWARD too, with ||pg||^2 from its epilogue; backward =
+    s2t_sumsq64 (||g||^2) + s2t_whiten_combine64; "fused" = dcov
     and its bf16 pieces taken in forward, backward = the penalty product on the pre-split-weight kernel
     with the two norms in its epilogue + the combining pass (s2t_whiten_prep / s2t_gemm_x3p_sq /
     s2t_whiten_combine64: the default);
@@ -525,7 +527,8 @@ def test_whiten_backward_vs_oracle(dev, monkeypatch, R, C, G, form):
     import random
     from speech2text_amd import zip_kernels as zkm
     from speech2text_amd.model.layer.scaling import Whiten
-    monkeypatch.setattr(zkm, "_WHITEN_X3P", 2 if form == "fused" else 0)
+    monkeypatch.setattr(zkm, "_WHITEN_X3P", 2 if form in ("fused", "fwdpg") else 0)
+    monkeypatch.setattr(zkm, "_WHITEN_FWD_PG", form == "fwdpg")
     monkeypatch.setattr(zkm, "_WHITEN_SQ", form == "sq")
     fused0 = int(N_lib().s2t_gemm_x3p_calls())
     torch.manual_seed(R + C)
@@ -547,7 +550,7 @@ def test_whiten_backward_vs_oracle(dev, monkeypatch, R, C, G, form):
         assert np.abs(r).max() > 0, "metric below the limit: the test would be vacuous"
         np.testing.assert_allclose(d, r, atol=2e-3 * np.abs(r).max(), rtol=2e-3)
     # the fused form really ran (C % 8 == 0 everywhere here): one s2t_gemm_x3p launch per backward
-    assert int(N_lib().s2t_gemm_x3p_calls()) - fused0 == (2 if form == "fused" else 0)
+    assert int(N_lib().s2t_gemm_x3p_calls()) - fused0 == (2 if form in ("fused", "fwdpg") else 0)
 
 
 def test_whiten_backward_rank_one_input_stays_finite(dev, monkeypatch):
