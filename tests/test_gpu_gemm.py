@@ -611,6 +611,17 @@ def test_x3p_balancer_epilogue_matches_two_pass_update(dev, kind):
         assert rc == 0, (tile, rc)
         err = (y - ref).abs().max().item() / ref.abs().max().item()
         assert err < 5e-6, (tile, err)
+    # the coefficient pass as its own call (what a caller that takes the statistics in forward runs there):
+    # the product launched with S2T_X3P_BAL_COEF_READY must not recompute them -- poison the statistics
+    # after s2t_balancer_coef, the result must not move
+    Nt.check(L.s2t_balancer_coef(stats.data_ptr(), N, M, *cfg, Nt.stream()), "coef")
+    stats[:2048].fill_(float("nan"))
+    y = torch.empty_like(plain)
+    rc = L.s2t_gemm_x3p_bal(gy.data_ptr(), K, ctypes.c_void_p(pp), N, K, y.data_ptr(), N, M, None, 0,
+                            h.data_ptr(), N, 1 if kind == "swoosh_l" else 2, 0 | (1 << 20), stats.data_ptr(), *cfg,
+                            Nt.stream())
+    assert rc == 0
+    assert (y - ref).abs().max().item() / ref.abs().max().item() < 5e-6
     # and through lt_matmul (plan cache: our kernel with its own statistics pass, or the library +
     # the two-pass update): agreement to the statistics' own reproducibility
     y = zk.lt_matmul(1, gy, Wt, act_src=h, act_kind=kind, bal=cfg + (1,))
