@@ -27,6 +27,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
+#include <functional>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -87,6 +89,10 @@ int half_octave(long m) {            // floor(2 log2 m), as zip_kernels._half_oc
   return 2 * b + (((double)m * (double)m >= std::ldexp(1.0, 2 * b + 1)) ? 1 : 0);
 }
 
+std::atomic<uint64_t> g_bal_seq{0};
+uint64_t g_bal_waited = 0;            // (backward runs on one thread at a time: the autograd engine's)
+void* g_bal_waited_on = nullptr;
+
 constexpr int kBalSites = 15;
 struct WStat {
   int on;
@@ -123,6 +129,7 @@ struct State {
   float* bst[kBalSites];
   hipEvent_t bal_ev;
   int bal_fwd;
+  uint64_t bal_seq;          // order of bal_ev among the process's records on the side stream
   // backward
   int wh_active[S2T_ZL_NWHITEN];
   int pen_active;
@@ -151,6 +158,8 @@ struct Ctx {
   hipStream_t st, side;
   bool dry;
   long R;
+  // side-stream launches of this pass that wait for its ONE fork (side_run / flush_side below)
+  std::vector<std::function<int()>> later;
 };
 
 int fail(int rc, const char* what) {
@@ -182,6 +191,34 @@ inline bool dec(const Ctx& c, int i) { return c.c.dec[i] != 0; }
 // ---- streams
 int fork_side(Ctx& c) {              // side stream ordered after the work enqueued so far on the main one
   RUN(s2t_stream_order((void*)c.st, (void*)c.side));
+  return 0;
+}
+
+// A fork is an event record on the MAIN stream, i.e. a barrier packet of its own between two kernels: the
+// queue runs nothing for 6-7 us around it (kernel trace of the C3 step: ~210 such gaps, 1.8 ms per step,
+// every one of them at a fork).  Nothing on the main stream waits for the side stream's work inside a
+// pass -- forward's statistics are read by backward, backward's parameter gradients by the optimizer -- so
+// the side-stream launches of a pass are collected and leave behind ONE fork at its end (their operands
+// live in the pass's workspace, which the caller keeps until the join).  S2T_SIDE_DEFER=0: a fork per site.
+// (bits: 1 forward's statistics, 2 backward's parameter gradients, 4 backward's implied event waits)
+int defer_bits() {
+  static const int bits = [] { const char* e = getenv("S2T_SIDE_DEFER"); return e ? atoi(e) : 7; }();
+  return bits;
+}
+template <class F>
+int side_run(Ctx& c, int bit, F&& f) {   // f(): launches on c.side, ordered after the main stream's work so far
+  if (defer_bits() & bit) {
+    c.later.emplace_back(std::forward<F>(f));
+    return 0;
+  }
+  TRY(fork_side(c));
+  return f();
+}
+int flush_side(Ctx& c) {
+  if (c.later.empty()) return 0;
+  TRY(fork_side(c));
+  for (auto& f : c.later) TRY(f());
+  c.later.clear();
   return 0;
 }
 
@@ -347,31 +384,31 @@ int whiten_stats(Ctx& c, WStat& s, const float* x, long ldx, long R, int C, int 
   s.host = pinned_slot();
   s.ev = ring_event();
   if (!s.host || !s.ev) return fail(-1, "whiten_stats: pinned slot / event");
-  hipStream_t q = c.st;
-  if (c.c.stats_side && c.side) {
-    TRY(fork_side(c));
-    q = c.side;
-  }
-  float* xtx = sc->acc;
-  float* colsum = sc->acc + (long)C * C;
-  RUN(s2t_gemm_xtx(x, ldx, (int)R, C, s.cg, xtx, C, colsum, (void*)q));
-  RUN(s2t_whiten_metric(xtx, colsum, R, groups, s.cg, s.cov, s.mean, s.scal, s.host, sc->ws, (void*)q));
-  if (s.pieces) {
-    RUN(s2t_whiten_prep(s.cov, s.mean, s.scal, s.G, s.cg, s.dcov, s.bias, s.sums, (void*)q));
-    RUN(s2t_x3p_split(s.dcov, sc->tab, 1, sc->blocks, s.pieces, (void*)q));
-    if (s.pg) {
-      static const int pg_cls = [] { const char* e = getenv("S2T_WHITEN_PG_CLS"); return e ? atoi(e) : 1; }();
-      const S2tGemmClass cls(pg_cls);
-      const bool two = s2t_gemm_arith_of(pg_cls) == 2;
-      const int tile = c.c.x3p_tile ? c.c.x3p_tile : ((C & 127) == 0 ? (two ? 2212 : 312) : (two ? 2221 : 321));
-      const int rc = s2t_gemm_x3p_sq(x, ldx, s.pieces, C, C, s.pg, C, (int)R, s.bias, nullptr, 0, s.sums, tile, (void*)q);
-      if (rc != 0) return fail(rc, "s2t_gemm_x3p_sq(whiten, forward)");
+  const bool on_side = c.c.stats_side && c.side;
+  auto launch = [&c, &s, sc, x, ldx, R, C, groups, on_side]() -> int {
+    hipStream_t q = on_side ? c.side : c.st;
+    float* xtx = sc->acc;
+    float* colsum = sc->acc + (long)C * C;
+    RUN(s2t_gemm_xtx(x, ldx, (int)R, C, s.cg, xtx, C, colsum, (void*)q));
+    RUN(s2t_whiten_metric(xtx, colsum, R, groups, s.cg, s.cov, s.mean, s.scal, s.host, sc->ws, (void*)q));
+    if (s.pieces) {
+      RUN(s2t_whiten_prep(s.cov, s.mean, s.scal, s.G, s.cg, s.dcov, s.bias, s.sums, (void*)q));
+      RUN(s2t_x3p_split(s.dcov, sc->tab, 1, sc->blocks, s.pieces, (void*)q));
+      if (s.pg) {
+        static const int pg_cls = [] { const char* e = getenv("S2T_WHITEN_PG_CLS"); return e ? atoi(e) : 1; }();
+        const S2tGemmClass cls(pg_cls);
+        const bool two = s2t_gemm_arith_of(pg_cls) == 2;
+        const int tile = c.c.x3p_tile ? c.c.x3p_tile : ((C & 127) == 0 ? (two ? 2212 : 312) : (two ? 2221 : 321));
+        const int rc = s2t_gemm_x3p_sq(x, ldx, s.pieces, C, C, s.pg, C, (int)R, s.bias, nullptr, 0, s.sums, tile, (void*)q);
+        if (rc != 0) return fail(rc, "s2t_gemm_x3p_sq(whiten, forward)");
+      }
     }
-  }
-  // (backward waits for this event on the host before it reads the metric: everything above is then
-  //  complete, whichever stream it ran on)
-  HIPRUN(hipEventRecord(s.ev, q));
-  return 0;
+    // (backward waits for this event on the host before it reads the metric: everything above is then
+    //  complete, whichever stream it ran on)
+    HIPRUN(hipEventRecord(s.ev, q));
+    return 0;
+  };
+  return on_side ? side_run(c, 1, launch) : launch();
 }
 
 // zip_kernels.whiten_backward: g (R,C) dense -> *out (g itself when the penalty is inactive)
@@ -491,14 +528,15 @@ int bal_stats_fwd(Ctx& c, int site, const float* x, long ldx, long R, int C, int
   float* st = c.ar.alloc(n);
   c.s.bst[site] = st;
   if (c.dry) return 0;
-  TRY(fork_side(c));
-  HIPRUN(hipMemsetAsync(st, 0, 2048 * sizeof(float), c.side));
-  RUN(s2t_balancer_stats(x, ldx, R, C, st, (void*)c.side));
-  if (coef)                          // (the epilogue form's per-column coefficients, off the data-gradient chain too)
-    RUN(s2t_balancer_coef(st, C, R, coef->min_mean, coef->max_mean, coef->min_rms, coef->max_rms, coef->grad_scale,
-                          (void*)c.side));
   c.s.bal_fwd = 1;
-  return 0;
+  return side_run(c, 1, [&c, st, x, ldx, R, C, coef]() -> int {
+    HIPRUN(hipMemsetAsync(st, 0, 2048 * sizeof(float), c.side));
+    RUN(s2t_balancer_stats(x, ldx, R, C, st, (void*)c.side));
+    if (coef)                        // (the epilogue form's per-column coefficients, off the data-gradient chain too)
+      RUN(s2t_balancer_coef(st, C, R, coef->min_mean, coef->max_mean, coef->min_rms, coef->max_rms, coef->grad_scale,
+                            (void*)c.side));
+    return 0;
+  });
 }
 
 // the module's last projection: plain (+ residual) or the module's own output as well
@@ -697,10 +735,12 @@ int layer_fwd(Ctx& c) {
   if (dec(c, 29)) TRY(bal_stats_fwd(c, 13, c.c.out, D, R, D));
   s.wst.on = 0;
   if (dec(c, 30)) TRY(whiten_stats(c, s.wst, c.c.out, D, R, D, d.wh_out.groups));
-  if (s.bal_fwd && !c.dry) {             // backward's stream waits for this once (layer_bwd)
+  TRY(flush_side(c));                    // the pass's side-stream launches, behind one fork
+  if (s.bal_fwd && !c.dry) {             // backward's stream waits for this (layer_bwd)
     s.bal_ev = ring_event();
     if (!s.bal_ev) return fail(-1, "balancer statistics event");
     HIPRUN(hipEventRecord(s.bal_ev, c.side));
+    s.bal_seq = ++g_bal_seq;
   }
   return 0;
 }
@@ -808,9 +848,12 @@ int conv_bwd(Ctx& c, int i, int d0, const float* x_in, const float* g, const flo
   if (c.c.conv_w_side && c.side && !c.c.conv_fused) {
     RUN(s2t_zipconv_bwd_data(sv.u, 2 * D, D, c.c.k8, T, B, D, m.K, sv.chunk, m.wc, m.wk, m.bk, m.scale, dy, du,
                              (void*)c.st));
-    TRY(fork_side(c));
-    RUN(s2t_zipconv_bwd_params(sv.u, 2 * D, D, c.c.k8, T, B, D, m.K, sv.chunk, m.wc, m.wk, m.bk, m.scale, dy,
-                               m.gwc, m.gbc, m.gwk, m.gbk, m.gscale, ws, (void*)c.side));
+    if (!c.dry)
+      TRY(side_run(c, 2, [&c, &m, &sv, dy, ws, T, B, D]() -> int {
+        RUN(s2t_zipconv_bwd_params(sv.u, 2 * D, D, c.c.k8, T, B, D, m.K, sv.chunk, m.wc, m.wk, m.bk, m.scale, dy,
+                                   m.gwc, m.gbc, m.gwk, m.gbk, m.gscale, ws, (void*)c.side));
+        return 0;
+      }));
   } else {
     RUN(s2t_zipconv_bwd(sv.u, 2 * D, D, c.c.k8, T, B, D, m.K, sv.chunk, m.wc, m.wk, m.bk, m.scale, dy, du, m.gwc,
                         m.gbc, m.gwk, m.gbk, m.gscale, ws, (void*)c.st));
@@ -882,7 +925,14 @@ int layer_bwd(Ctx& c, int phase) {
     s.nprob = 0;
     for (int i = 0; i < S2T_ZL_NWHITEN; ++i) s.wh_active[i] = -1;
     s.pen_active = 0;
-    if (s.bal_fwd) HIPRUN(hipStreamWaitEvent(c.st, s.bal_ev, 0));   // forward's Balancer statistics (side stream)
+    // forward's Balancer statistics (side stream).  The side stream runs in order: once this stream has
+    // waited for a LATER layer's event -- backward visits the layers in reverse -- the wait (a barrier packet
+    // of its own) is implied
+    if (s.bal_fwd && !c.dry && !((defer_bits() & 4) && g_bal_waited_on == (void*)c.st && s.bal_seq <= g_bal_waited)) {
+      HIPRUN(hipStreamWaitEvent(c.st, s.bal_ev, 0));
+      g_bal_waited_on = (void*)c.st;
+      g_bal_waited = s.bal_seq;
+    }
     if (dec(c, 3) && !c.dry) {
       if (hipEventSynchronize(s.pen_ev) != hipSuccess) return fail(-1, "penalty flag event");
       s.pen_active = *reinterpret_cast<volatile float*>(s.pen_slot) != 0.f;
@@ -937,6 +987,7 @@ int layer_bwd(Ctx& c, int phase) {
     s.d0m = d0m;
     if (phase == 1 || (phase == 0 && s.pen_active)) {
       s.bwd_off = c.ar.off;
+      TRY(flush_side(c));
       return s.pen_active ? 1 : 0;
     }
     float* aws = nullptr;
@@ -968,14 +1019,16 @@ int layer_bwd(Ctx& c, int phase) {
     TRY(lt_matmul(c, 1, dqkp, Dp, R, d.attn_in, e, c.c.gx));
   }
   if (!c.dry && s.nprob > 0) {
-    hipStream_t q = c.st;
     if (c.c.wgrad_side && c.side) {
-      TRY(fork_side(c));
-      q = c.side;
+      TRY(side_run(c, 2, [&c, &s]() -> int {
+        RUN(s2t_gemm_tn_grouped(s.nprob, s.probs, (void*)c.side));
+        return 0;
+      }));
+    } else {
+      RUN(s2t_gemm_tn_grouped(s.nprob, s.probs, (void*)c.st));
     }
-    RUN(s2t_gemm_tn_grouped(s.nprob, s.probs, (void*)q));
   }
-  return 0;
+  return flush_side(c);
 }
 
 }  // namespace

@@ -438,7 +438,9 @@ class _NativeLayerFn(torch.autograd.Function):
         wsb = torch.empty(n, dtype=_F32, device=dev)
         # registers the end-of-backward join of the side stream and keeps the operands of its
         # kernels (weight gradients, conv parameter gradients) alive until then
-        side = zk._side_launch_stream(wsb, wsf, g, x0, out, pos2) if zk._Side.enabled else None
+        # (k8 / a8 too: the stack's masks die with its first layer's backward, and the conv modules'
+        #  parameter-gradient kernels -- which read the padding mask -- leave at the END of this call)
+        side = zk._side_launch_stream(wsb, wsf, g, x0, out, pos2, k8, a8) if zk._Side.enabled else None
         lib = N.lib()
         rc = lib.s2t_zip_layer_bwd(ctypes.byref(L.desc), ctypes.byref(call), state, wsb.data_ptr(), n, 0,
                                    N.stream(), side)
