@@ -686,7 +686,8 @@ extern "C" int s2t_norm_bypass_bwd(const float* x, const float* bias, const floa
   if (rows <= 0) return 0;
   if (D <= 0 || D > 1024 || B <= 0) return -1;
   hipStream_t st = (hipStream_t)stream;
-  const unsigned nb = std::min(grid_for(rows, 4 * 8), 1024u);
+  static const unsigned cap = [] { const char* e = getenv("S2T_NB_BWD_BLOCKS"); return e ? (unsigned)atoi(e) : 1024u; }();
+  const unsigned nb = std::min(grid_for(rows, 4 * 8), cap);
 #define NB_BWD(CPL)                                                                                    \
   hipLaunchKernelGGL(norm_bypass_bwd_kernel<CPL>, dim3(nb), dim3(256), 0, st, x, bias, scales, orig,   \
                      bypass_scale, g, fm, B, rows, D, dx, d_orig, d_bypass_scale, dbias, dls)

@@ -409,6 +409,77 @@ __global__ __launch_bounds__(256) void bypass_up_bwd_kernel(const float* __restr
   }
 }
 
+// 16-byte form (C % 4 == 0, up = UP): an item = 4 channels of one (source frame, utterance) pair -- its UP
+// gradient / orig pieces and the source piece are requested together (2 UP + 1 loads of 16 bytes in flight
+// per lane; the scalar form above has one 4-byte load chain per channel: 1.2 TB/s at the C3 shapes), the
+// grid's stride is a multiple of C / 4 so that a lane keeps its channels and d_scale stays in registers.
+template <int UP, int IU>
+__global__ __launch_bounds__(256) void bypass_up_bwd4_kernel(const float4* __restrict__ o4,
+                                                             const float4* __restrict__ s4,
+                                                             const float4* __restrict__ sc4,
+                                                             const float4* __restrict__ g4, int T, long F,
+                                                             int C4, long n, float4* __restrict__ do4,
+                                                             float4* __restrict__ ds4,
+                                                             float* __restrict__ d_scale) {
+  __shared__ float s_acc[1024];
+  for (int i = threadIdx.x; i < 4 * C4; i += 256) s_acc[i] = 0.f;
+  __syncthreads();
+  const long stride = (long)gridDim.x * 256;
+  const long w0 = (long)blockIdx.x * 256 + threadIdx.x;
+  const int c4 = (int)(w0 % C4);
+  const float4 k = sc4[c4];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (long wb = w0; wb < n; wb += stride * IU) {
+    float4 sv[IU], gv[IU][UP], ov[IU][UP];
+#pragma unroll
+    for (int j = 0; j < IU; ++j) {                 // every request of IU items first
+      const long w = wb + j * stride < n ? wb + j * stride : wb;
+      const long tt = w / F, e = w - tt * F;
+      sv[j] = s4[w];
+#pragma unroll
+      for (int u = 0; u < UP; ++u) {
+        const long t = tt * UP + u;
+        const long i = (t < T ? t : tt * UP) * F + e;
+        gv[j][u] = g4[i];
+        ov[j][u] = o4[i];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < IU; ++j) {
+      const long w = wb + j * stride;
+      if (w < n) {
+        const long tt = w / F, e = w - tt * F;
+        float4 ds = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < UP; ++u) {
+          const long t = tt * UP + u;
+          if (t < T) {
+            const float4 gq = gv[j][u], oq = ov[j][u], sq = sv[j];
+            do4[t * F + e] =
+                make_float4(gq.x * (1.f - k.x), gq.y * (1.f - k.y), gq.z * (1.f - k.z), gq.w * (1.f - k.w));
+            ds = make_float4(fmaf(gq.x, k.x, ds.x), fmaf(gq.y, k.y, ds.y), fmaf(gq.z, k.z, ds.z),
+                             fmaf(gq.w, k.w, ds.w));
+            acc = make_float4(fmaf(gq.x, sq.x - oq.x, acc.x), fmaf(gq.y, sq.y - oq.y, acc.y),
+                              fmaf(gq.z, sq.z - oq.z, acc.z), fmaf(gq.w, sq.w - oq.w, acc.w));
+          }
+        }
+        ds4[w] = ds;
+      }
+    }
+  }
+  // d_scale: through LDS, then ONE atomic per channel and workgroup -- and few workgroups: atomics on one
+  // address serialise (the grid is capped in the launcher: 2 000 workgroups spent 30 us of a 59 us launch here)
+  atomicAdd(&s_acc[4 * c4 + 0], acc.x);
+  atomicAdd(&s_acc[4 * c4 + 1], acc.y);
+  atomicAdd(&s_acc[4 * c4 + 2], acc.z);
+  atomicAdd(&s_acc[4 * c4 + 3], acc.w);
+  __syncthreads();
+  for (int i = threadIdx.x; i < 4 * C4; i += 256) {
+    const float v = s_acc[i];
+    if (v != 0.f) atomicAdd(d_scale + i, v);
+  }
+}
+
 // u (T,B,3C) = [s | x | y]  ->  xs (B,T,C) = x * tanh(s)
 __global__ __launch_bounds__(256) void nonlin_gate_fwd_kernel(const float* __restrict__ u, int T,
                                                               int B, int C,
@@ -644,6 +715,33 @@ extern "C" int s2t_bypass_up_bwd(const float* orig, const float* src, const floa
   if (T <= 0 || B <= 0) return 0;
   if (C <= 0 || up < 1) return -1;
   const int Ts = (T + up - 1) / up;
+  const uintptr_t al = reinterpret_cast<uintptr_t>(orig) | reinterpret_cast<uintptr_t>(src) |
+                       reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(g) |
+                       reinterpret_cast<uintptr_t>(d_orig) | reinterpret_cast<uintptr_t>(d_src);
+  static const bool form16 = [] { const char* e = getenv("S2T_BYPASS_UP_BWD16"); return !e || e[0] != '0'; }();
+  if (form16 && (C & 3) == 0 && C <= 1024 && (al & 15) == 0 && (up == 2 || up == 4 || up == 8)) {
+    const int C4 = C / 4;
+    const long F = (long)B * C4, n = (long)Ts * F;
+    // the grid's stride (256 x blocks) must be a multiple of C4: blocks in multiples of C4 / gcd(256, C4)
+    int gc = C4, r = 256;
+    while (r) { const int t = gc % r; gc = r; r = t; }
+    const long m = C4 / gc;
+    static const long cap = [] { const char* e = getenv("S2T_BUP_BLOCKS"); return e ? atol(e) : 256L; }();
+    long nb = (n + 255) / 256;
+    if (nb > cap) nb = cap;
+    nb = (nb + m - 1) / m * m;
+#define BUP4(UP, IU)                                                                                          \
+  hipLaunchKernelGGL((bypass_up_bwd4_kernel<UP, IU>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream,  \
+                     reinterpret_cast<const float4*>(orig), reinterpret_cast<const float4*>(src),             \
+                     reinterpret_cast<const float4*>(scale), reinterpret_cast<const float4*>(g), T, F, C4, n, \
+                     reinterpret_cast<float4*>(d_orig), reinterpret_cast<float4*>(d_src), d_scale)
+    if (up == 2) BUP4(2, 4);
+    else if (up == 4) BUP4(4, 2);
+    else BUP4(8, 1);
+#undef BUP4
+    S2T_CHECK_LAUNCH();
+    return 0;
+  }
   hipLaunchKernelGGL(bypass_up_bwd_kernel, dim3(Ts, (B + 15) / 16), dim3(256), 0,
                      (hipStream_t)stream, orig, src, scale, g, up, T, B, C, d_orig, d_src, d_scale);
   S2T_CHECK_LAUNCH();

@@ -1,0 +1,56 @@
+"""Kernels whose tail is one atomic per column and workgroup (s2t_norm_bypass_bwd, s2t_bypass_up_bwd):
+time per launch at the C3 shapes, operands rotated over NSET buffer sets (the step never finds them in
+the infinity cache).  Grid caps are read from the environment by the library (S2T_NB_BWD_BLOCKS,
+S2T_BUP_BLOCKS, S2T_BYPASS_UP_BWD16)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from speech2text_amd import _native as N
+dev = torch.device("cuda")
+L = N.lib()
+NSET = 6
+
+
+def timeit(fn, n=30):
+    for i in range(6):
+        fn(i)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(n):
+        fn(i)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+B = 64
+for T, D in [(495, 192), (248, 256), (124, 256), (62, 256)]:
+    R = T * B
+    sets = [[torch.randn(R, D, device=dev) for _ in range(3)] + [torch.empty(R, D, device=dev) for _ in range(2)]
+            for _ in range(NSET)]
+    bias, bsc = torch.zeros(D, device=dev), torch.full((D,), 0.5, device=dev)
+    scales = torch.rand(R, device=dev) + 0.5
+    acc = torch.zeros(4 * D, device=dev)
+
+    def nb(i):
+        x, o, g, dx, d0 = sets[i % NSET]
+        N.check(L.s2t_norm_bypass_bwd(N.fp(x), N.fp(bias), N.fp(scales), N.fp(o), N.fp(bsc), N.fp(g), None, B, R, D,
+                                      N.fp(dx), N.fp(d0), N.fp(acc), N.fp(acc[2 * D:]), N.fp(acc[3 * D:]), N.stream()),
+                "nb")
+    us = timeit(nb)
+    print(f"norm_bypass_bwd {T}x{B}x{D}: {us:7.1f} us  {20.0 * R * D / us / 1e3:6.0f} GB/s", flush=True)
+for T, D, up in [(495, 256, 2), (495, 256, 4), (495, 256, 8), (248, 256, 2)]:
+    Ts = (T + up - 1) // up
+    sets = [[torch.randn(T, B, D, device=dev), torch.randn(Ts, B, D, device=dev), torch.randn(T, B, D, device=dev),
+             torch.empty(T, B, D, device=dev), torch.empty(Ts, B, D, device=dev)] for _ in range(NSET)]
+    sc = torch.full((D,), 0.5, device=dev)
+    dsc = torch.zeros(D, device=dev)
+
+    def bu(i):
+        o, s, g, do, ds = sets[i % NSET]
+        N.check(L.s2t_bypass_up_bwd(N.fp(o), N.fp(s), N.fp(sc), N.fp(g), up, T, B, D, N.fp(do), N.fp(ds), N.fp(dsc),
+                                    N.stream()), "bu")
+    us = timeit(bu)
+    nbytes = 4.0 * T * B * D * (3 + 2.0 / up)
+    print(f"bypass_up_bwd {T}x{B}x{D} up={up}: {us:7.1f} us  {nbytes / us / 1e3:6.0f} GB/s", flush=True)
