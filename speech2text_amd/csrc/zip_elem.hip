@@ -343,6 +343,137 @@ __global__ __launch_bounds__(256) void norm_bypass_bwd_kernel(
   }
 }
 
+// The same pass in a 16-byte form (D % 4 == 0): lane = float4 chunks lane, lane + 64, ... of a row, RT rows
+// requested together (3 Q RT loads of 16 bytes in flight per lane; the scalar form above issues 4-byte loads
+// and needs ~1000 workgroups of them -- whose per-column atomics then serialise at the end: 2.5 TB/s at the
+// C3 shapes).  Per-element arithmetic as above; the two row sums are taken in another order (last bits).
+template <int Q, int RT>
+__global__ __launch_bounds__(256) void norm_bypass_bwd16_kernel(
+    const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ scales,
+    const float* __restrict__ orig, const float* __restrict__ bscale, const float* __restrict__ g,
+    const float* __restrict__ fm, int B, long rows, int D, float* __restrict__ dx,
+    float* __restrict__ d_orig, float* __restrict__ d_bscale, float* __restrict__ dbias,
+    float* __restrict__ dls) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long wave = (long)blockIdx.x * 4 + wv;
+  const long nwaves = (long)gridDim.x * 4;
+  const int D4 = D >> 2;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  const float4* o4 = reinterpret_cast<const float4*>(orig);
+  const float4* f4 = reinterpret_cast<const float4*>(fm);
+  float4 b[Q], k[Q], db[Q], dk[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int cq = lane + 64 * q;
+    b[q] = cq < D4 ? reinterpret_cast<const float4*>(bias)[cq] : z4;
+    k[q] = cq < D4 ? reinterpret_cast<const float4*>(bscale)[cq] : z4;
+    db[q] = z4;
+    dk[q] = z4;
+  }
+  float dl = 0.f;
+  for (long r0 = wave; r0 < rows; r0 += RT * nwaves) {
+    float4 xv[RT][Q], gv[RT][Q], ov[RT][Q];
+    float sc[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+      const long row = r0 + i * nwaves;
+      const long rr = row < rows ? row : r0;
+      sc[i] = scales[rr];
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const int cq = lane + 64 * q;
+        const bool ok = cq < D4;
+        const long idx = rr * D4 + (ok ? cq : 0);
+        xv[i][q] = x4[idx];
+        gv[i][q] = g4[idx];
+        ov[i][q] = o4[idx];
+        if (fm) {
+          const float4 m = f4[(rr % B) * D4 + (ok ? cq : 0)];
+          gv[i][q].x *= m.x; gv[i][q].y *= m.y; gv[i][q].z *= m.z; gv[i][q].w *= m.w;
+        }
+        if (!ok) { xv[i][q] = z4; gv[i][q] = z4; ov[i][q] = z4; }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+      const long row = r0 + i * nwaves;
+      if (row >= rows) break;                       // (wave-uniform)
+      const float s = sc[i];
+      float A = 0.f, ss = 0.f;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const int cq = lane + 64 * q;
+        float* xe = reinterpret_cast<float*>(&xv[i][q]);
+        float* ge = reinterpret_cast<float*>(&gv[i][q]);
+        const float* oe = reinterpret_cast<const float*>(&ov[i][q]);
+        const float* ke = reinterpret_cast<const float*>(&k[q]);
+        const float* be = reinterpret_cast<const float*>(&b[q]);
+        float* dke = reinterpret_cast<float*>(&dk[q]);
+        float4 d0;
+        float* d0e = reinterpret_cast<float*>(&d0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          // the bypass: this row's share of d_scale, the gradient that stays on orig, and g10
+          const float t = mul_rounded(ge[e], ke[e]);          // (g10 as the separate bypass pass stores it)
+          dke[e] = fmaf(ge[e], mul_rounded(xe[e], s) - oe[e], dke[e]);
+          d0e[e] = fmaf(-ge[e], ke[e], ge[e]);                // (g - g k, contracted as the separate pass has it)
+          ge[e] = t;
+          A = fmaf(t, xe[e], A);
+          const float d = xe[e] - be[e];
+          ss = fmaf(d, d, ss);
+        }
+        if (cq < D4) reinterpret_cast<float4*>(d_orig)[row * D4 + cq] = d0;
+      }
+      A = wave_sum(A);
+      ss = wave_sum(ss);
+      const float coef = s * A / ss;                // ss = D * mean((x - b)^2)
+      dl += A * s;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const int cq = lane + 64 * q;
+        const float* xe = reinterpret_cast<const float*>(&xv[i][q]);
+        const float* ge = reinterpret_cast<const float*>(&gv[i][q]);
+        const float* be = reinterpret_cast<const float*>(&b[q]);
+        float* dbe = reinterpret_cast<float*>(&db[q]);
+        float4 o;
+        float* oe = reinterpret_cast<float*>(&o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float t = coef * (xe[e] - be[e]);
+          oe[e] = s * ge[e] - t;
+          dbe[e] += t;
+        }
+        if (cq < D4) reinterpret_cast<float4*>(dx)[row * D4 + cq] = o;
+      }
+    }
+  }
+  // one atomic per column per WORKGROUP (the four waves add up through LDS first), few workgroups
+  __shared__ float4 s_db[4][64 * Q], s_dk[4][64 * Q];
+  __shared__ float s_dl[4];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    s_db[wv][lane + 64 * q] = db[q];
+    s_dk[wv][lane + 64 * q] = dk[q];
+  }
+  if (lane == 0) s_dl[wv] = dl;
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 256) {
+    const float* p0 = reinterpret_cast<const float*>(&s_db[0][0]);
+    const float* p1 = reinterpret_cast<const float*>(&s_dk[0][0]);
+    const int W = 256 * Q;
+    const float t = (p0[c] + p0[W + c]) + (p0[2 * W + c] + p0[3 * W + c]);
+    const float u = (p1[c] + p1[W + c]) + (p1[2 * W + c] + p1[3 * W + c]);
+    if (t != 0.f) atomicAdd(&dbias[c], t);
+    if (u != 0.f) atomicAdd(&d_bscale[c], u);
+  }
+  if (threadIdx.x == 0) {
+    const float tl = (s_dl[0] + s_dl[1]) + (s_dl[2] + s_dl[3]);
+    if (tl != 0.f) atomicAdd(dls, tl);
+  }
+}
+
 // ---------------------------------------------------------------- column statistics
 // x viewed as [rows][ld] with C used columns: sum[c] += x, sumsq[c] += x^2 (atomics once per
 // block).  Each thread owns column (threadIdx.x % cols_per_pass) and strides over rows.
@@ -686,8 +817,28 @@ extern "C" int s2t_norm_bypass_bwd(const float* x, const float* bias, const floa
   if (rows <= 0) return 0;
   if (D <= 0 || D > 1024 || B <= 0) return -1;
   hipStream_t st = (hipStream_t)stream;
-  static const unsigned cap = [] { const char* e = getenv("S2T_NB_BWD_BLOCKS"); return e ? (unsigned)atoi(e) : 1024u; }();
-  const unsigned nb = std::min(grid_for(rows, 4 * 8), cap);
+  static const int form16 = [] { const char* e = getenv("S2T_NB_BWD16"); return e ? atoi(e) : 1; }();
+  const uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(bias) |
+                       reinterpret_cast<uintptr_t>(orig) | reinterpret_cast<uintptr_t>(bypass_scale) |
+                       reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(fm) |
+                       reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(d_orig);
+  if (form16 && (D & 3) == 0 && (al & 15) == 0) {
+    static const unsigned cap16 = [] { const char* e = getenv("S2T_NB_BWD_BLOCKS"); return e ? (unsigned)atoi(e) : 512u; }();
+    // workgroups: ~16 rows per wave (four trips of four; 8 below 8 192 rows), at most 512 -- measured at the C3 shapes
+    // (tools/bench_atomics.py): more workgroups lengthen the atomics' tail, fewer starve the loads
+    static const int rpw = [] { const char* e = getenv("S2T_NB_BWD_RPW"); return e ? atoi(e) : 16; }();
+    const unsigned nb16 = std::min(grid_for(rows, 4 * std::max(1, rows >= 8192 ? rpw : rpw / 2)), cap16);
+#define NB_BWD16(Q, RT)                                                                                  \
+  hipLaunchKernelGGL((norm_bypass_bwd16_kernel<Q, RT>), dim3(nb16), dim3(256), 0, st, x, bias, scales,   \
+                     orig, bypass_scale, g, fm, B, rows, D, dx, d_orig, d_bypass_scale, dbias, dls)
+    if (D <= 256) NB_BWD16(1, 4);
+    else if (D <= 512) NB_BWD16(2, 2);
+    else NB_BWD16(4, 1);
+#undef NB_BWD16
+    S2T_CHECK_LAUNCH();
+    return 0;
+  }
+  const unsigned nb = std::min(grid_for(rows, 4 * 8), 1024u);
 #define NB_BWD(CPL)                                                                                    \
   hipLaunchKernelGGL(norm_bypass_bwd_kernel<CPL>, dim3(nb), dim3(256), 0, st, x, bias, scales, orig,   \
                      bypass_scale, g, fm, B, rows, D, dx, d_orig, d_bypass_scale, dbias, dls)

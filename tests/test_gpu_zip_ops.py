@@ -156,8 +156,9 @@ def test_layout_carrying_passes_keep_values_and_save_the_copy(dev, B, T, D):
                                          (9, 1, 512, True)])
 def test_norm_and_bypass_in_one_pass(dev, T, B, D, masked):
     """s2t_norm_bypass_fwd / _bwd (the end of a zipformer layer: BiasNorm, then the bypass, then the
-    stack's feature mask) against the separate entry points they replace: outputs and data gradients
-    bit for bit, the per-channel parameter gradients to summation order."""
+    stack's feature mask) against the separate entry points they replace: outputs and the bypass's data
+    gradient bit for bit, BiasNorm's data gradient and the per-channel parameter gradients to summation
+    order."""
     import ctypes
     from speech2text_amd import _native as Nt
     L, st = Nt.lib(), Nt.stream()
@@ -196,7 +197,9 @@ def test_norm_and_bypass_in_one_pass(dev, T, B, D, masked):
     assert L.s2t_norm_bypass_bwd(Nt.fp(x), Nt.fp(bias), Nt.fp(sc1), Nt.fp(orig), Nt.fp(k), Nt.fp(gy), Nt.fp(fm),
                                  B, R, D, Nt.fp(dx1), Nt.fp(d1), Nt.fp(dk1), Nt.fp(db1), Nt.fp(dl1), st) == 0
     assert torch.equal(sc0, sc1) and torch.equal(out0, out1)
-    assert torch.equal(d0, d1) and torch.equal(dx0, dx1)
+    assert torch.equal(d0, d1)
+    # (the 16-byte form of the fused backward takes the two sums over a row in another order: last bits)
+    assert (dx0 - dx1).abs().max().item() <= 2e-6 * max(1.0, dx0.abs().max().item())
     for a, b in ((dk0, dk1), (db0, db1), (dl0, dl1)):
         assert (a - b).abs().max().item() <= 2e-5 * max(1.0, a.abs().max().item())
 

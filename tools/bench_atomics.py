@@ -2,7 +2,7 @@
 time per launch at the C3 shapes, operands rotated over NSET buffer sets (the step never finds them in
 the infinity cache).  Grid caps are read from the environment by the library (S2T_NB_BWD_BLOCKS,
 S2T_BUP_BLOCKS, S2T_BYPASS_UP_BWD16)."""
-import os, sys
+import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from speech2text_amd import _native as N
@@ -54,3 +54,19 @@ for T, D, up in [(495, 256, 2), (495, 256, 4), (495, 256, 8), (248, 256, 2)]:
     us = timeit(bu)
     nbytes = 4.0 * T * B * D * (3 + 2.0 / up)
     print(f"bypass_up_bwd {T}x{B}x{D} up={up}: {us:7.1f} us  {nbytes / us / 1e3:6.0f} GB/s", flush=True)
+# the Balancer's update pass (balancer_apply_fused_kernel) at the step's standalone sites
+for R, C, ld in [(31680, 192, 192), (31680, 192, 384), (15872, 256, 256), (15872, 256, 512), (15872, 256, 768),
+                 (7936, 256, 256), (3968, 256, 256)]:
+    sets = [[torch.randn(R, ld, device=dev), torch.randn(R, ld, device=dev), torch.empty(R, ld, device=dev)]
+            for _ in range(NSET)]
+    stats = torch.zeros(4096, device=dev)
+    stats[:C] = torch.randn(C, device=dev) * R * 0.1
+    stats[1024:1024 + C] = (torch.rand(C, device=dev) + 0.5) * R
+
+    def ba(i):
+        x, g, o = sets[i % NSET]
+        N.check(L.s2t_balancer_apply(N.fp(x), ld, N.fp(g), ld, R, C, -0.4, 0.4,
+                                     0.2, 4.0, 0.04, N.fp(o), ld,
+                                     N.fp(stats), -1.0, N.stream()), "ba")
+    us = timeit(ba)
+    print(f"balancer_apply R={R} C={C} ld={ld}: {us:7.1f} us  {12.0 * R * C / us / 1e3:6.0f} GB/s", flush=True)
