@@ -688,10 +688,12 @@ static int downsample_bwd_impl(const float* src, const float* w, const float* g,
     S2T_CHECK_LAUNCH();
     return 0;
   }
-  // (frames, row slices): ~1024 workgroups, each finishing with ds atomics on the same words
-  int gy = (int)std::min<long>((rowlen / 4 + 255) / 256, std::max<long>(1, 1024 / dT));
+  // (frames, row slices): at most `cap` workgroups, each finishing with ds atomics on the SAME words --
+  // those serialise (~25 ns each): with ~1000 workgroups the launch took 26 us whatever its size
+  static const long cap = [] { const char* e = getenv("S2T_DS_BWD_BLOCKS"); return e ? std::max(1L, atol(e)) : 512L; }();
+  int gy = (int)std::min<long>((rowlen / 4 + 255) / 256, std::max<long>(1, cap / dT));
   if (gy < 1) gy = 1;
-  const int gx = dT < 1024 ? dT : 1024;
+  const int gx = (int)std::min<long>(dT, std::max<long>(1, cap / gy));
   hipLaunchKernelGGL(downsample_bwd_kernel, dim3(gx, gy), dim3(256), 0,
                      (hipStream_t)stream, src, w, g, ds, T, dT, rowlen, d_src, dw, bt ? C / 4 : 0);
   S2T_CHECK_LAUNCH();

@@ -70,3 +70,17 @@ for R, C, ld in [(31680, 192, 192), (31680, 192, 384), (15872, 256, 256), (15872
                                      N.fp(stats), -1.0, N.stream()), "ba")
     us = timeit(ba)
     print(f"balancer_apply R={R} C={C} ld={ld}: {us:7.1f} us  {12.0 * R * C / us / 1e3:6.0f} GB/s", flush=True)
+# SimpleDownsample's backward: every workgroup ends with `ds` atomics on the same words
+for T, D, ds in [(495, 256, 2), (495, 256, 4), (495, 256, 8), (248, 256, 2)]:
+    dT = (T + ds - 1) // ds
+    sets = [[torch.randn(T, B, D, device=dev), torch.randn(dT, B, D, device=dev), torch.empty(T, B, D, device=dev)]
+            for _ in range(NSET)]
+    w = torch.full((ds,), 1.0 / ds, device=dev)
+    dw = torch.zeros(ds, device=dev)
+
+    def dsb(i):
+        src, g, dsrc = sets[i % NSET]
+        N.check(L.s2t_downsample_bwd(N.fp(src), N.fp(w), N.fp(g), ds, T, B, D, N.fp(dsrc), N.fp(dw), N.stream()), "ds")
+    us = timeit(dsb)
+    print(f"downsample_bwd {T}x{B}x{D} ds={ds}: {us:7.1f} us  {4.0 * T * B * D * (2 + 1.0 / ds) / us / 1e3:6.0f} GB/s",
+          flush=True)
