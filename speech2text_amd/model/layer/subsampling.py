@@ -131,8 +131,7 @@ class Conv2dSubsampling(nn.Module):
         x = self.convnext(x)                                    # (N,T',F',C)
         b, t, f, c = x.shape
         # reference flattens (c,f) c-major: out.weight columns are indexed c*F' + f
-        w = self.out.weight.view(-1, c, f).permute(0, 2, 1).reshape(-1, f * c)
-        x = zk.linear(x.reshape(b, t, f * c), w, self.out.bias)
+        x = zk.linear_col_perm(x.reshape(b, t, f * c), self.out.weight, self.out.bias, f, c)
         x = self.out_whiten(x)
         nm = self.out_norm
         if x.is_cuda and x.dim() == 3:

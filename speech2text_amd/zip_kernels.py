@@ -1864,6 +1864,47 @@ def ffn_block(x, w1, b1, w2, b2, residual=None, balancer_cfg=None):
     return _FfnBlock.apply(x, w1, b1, w2, b2, residual, balancer_cfg)
 
 
+class _LinearColPerm(torch.autograd.Function):
+    """y = x Wp^T + b with Wp = the parameter's columns re-ordered from (c, f) to (f, c) -- the frontend's
+    output Linear (reference model/layer/subsampling.py:312-319 flattens (N, C, T, F) c-major; our map is
+    channel-LAST, so its rows are f-major).  As its own node so that the weight gradient -- a 30 GFLOP
+    product over 31 680 rows that only feeds the optimizer -- leaves the data-gradient chain: side stream,
+    added into the flat-store `.grad` views there (side_param_grads).  Through `linear` on a permuted copy
+    of the weight it was a main-stream launch of 375 us plus autograd's permute-back and two accumulates."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, f, c):
+        wp = weight.detach().view(-1, c, f).permute(0, 2, 1).reshape(-1, f * c)
+        x2 = _rows(x)
+        y = lt_matmul(0, x2, wp, bias)
+        ctx.save_for_backward(x2, wp)
+        ctx.params = (weight, bias)
+        ctx.cfg = (x.shape, f, c)
+        return y.view(x.shape[:-1] + (wp.shape[0],))
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, wp = ctx.saved_tensors
+        weight, bias = ctx.params
+        xshape, f, c = ctx.cfg
+        g2 = _rows(g)
+        dx = lt_matmul(1, g2, wp).view(xshape) if ctx.needs_input_grad[0] else None
+
+        def compute():
+            dwp, db = linear_wgrad(g2, x2, bias is not None)
+            return [dwp.view(-1, f, c).permute(0, 2, 1).reshape(weight.shape), db]
+        dw, db = side_param_grads((weight, bias), compute, keep=(g2, x2), allow=bool(_FRONT_SIDE & 4))
+        return dx, dw, db, None, None
+
+
+def linear_col_perm(x, weight, bias, f, c):
+    """F.linear(x, weight.view(-1, c, f).permute(0, 2, 1).reshape(-1, f * c), bias) for x whose last dim is
+    (f, c)-ordered; see _LinearColPerm."""
+    if not x.is_cuda:
+        raise RuntimeError("speech2text_amd.linear_col_perm needs device tensors (HIP path only)")
+    return _LinearColPerm.apply(x, weight, bias, f, c)
+
+
 def linear_pass(x, weight, bias=None):
     """-> (F.linear(x, weight, bias), alias of x for the residual branch)."""
     return _LinearPass.apply(x, weight, bias)
