@@ -1236,7 +1236,7 @@ _WGRAD_SIDE = os.environ.get("S2T_WGRAD_SIDE_MORE", "1") == "1"
 
 
 # which of the FRONTEND's parameter gradients fork to the side stream (bits: 1 = the 7x7 depthwise,
-# 2 = the 3x3 convs' implicit-im2col products, 4 = the 600 k-row Linears).  Its backward is a run of
+# 2 = the 3x3 convs' implicit-im2col products, 4 = the 600 k-row Linears and the output Linear).  Its backward is a run of
 # HBM-bound passes over 300-900 MB maps: two of them at once share the same bandwidth.
 _FRONT_SIDE = int(os.environ.get("S2T_FRONT_W_SIDE", "7"))
 
