@@ -823,11 +823,10 @@ extern "C" int s2t_norm_bypass_bwd(const float* x, const float* bias, const floa
                        reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(fm) |
                        reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(d_orig);
   if (form16 && (D & 3) == 0 && (al & 15) == 0) {
-    static const unsigned cap16 = [] { const char* e = getenv("S2T_NB_BWD_BLOCKS"); return e ? (unsigned)atoi(e) : 512u; }();
+    constexpr unsigned cap16 = 512u;
     // workgroups: ~16 rows per wave (four trips of four; 8 below 8 192 rows), at most 512 -- measured at the C3 shapes
     // (tools/bench_atomics.py): more workgroups lengthen the atomics' tail, fewer starve the loads
-    static const int rpw = [] { const char* e = getenv("S2T_NB_BWD_RPW"); return e ? atoi(e) : 16; }();
-    const unsigned nb16 = std::min(grid_for(rows, 4 * std::max(1, rows >= 8192 ? rpw : rpw / 2)), cap16);
+    const unsigned nb16 = std::min(grid_for(rows, 4 * (rows >= 8192 ? 16 : 8)), cap16);
 #define NB_BWD16(Q, RT)                                                                                  \
   hipLaunchKernelGGL((norm_bypass_bwd16_kernel<Q, RT>), dim3(nb16), dim3(256), 0, st, x, bias, scales,   \
                      orig, bypass_scale, g, fm, B, rows, D, dx, d_orig, d_bypass_scale, dbias, dls)

@@ -731,12 +731,12 @@ extern "C" int s2t_conv3x3_c1(int mode, const float* x, const float* w, const fl
   if (mode == 0)
     hipLaunchKernelGGL(conv3x3_c1_fwd_kernel<8>, dim3(grid_c1((long)B * Ho * Wo)), dim3(256), 0, st,
                        x, w, bias, B, H, W, pw, Ho, Wo, y);
-  else if (mode == 1) {
-    // (every workgroup ends with 80 atomics on the same 80 words: few workgroups)
-    static const int nb = [] { const char* e = getenv("S2T_C1_WGRAD_BLOCKS"); return e ? std::max(1, atoi(e)) : 1024; }();
-    hipLaunchKernelGGL(conv3x3_c1_wgrad_kernel<8>, dim3(nb), dim3(256), 0, st, x, g, B, H, W, pw,
+  else if (mode == 1)
+    // (1 024 workgroups, measured: every workgroup ends with 80 atomics on the same 80 words, which serialise
+    //  -- 2 048 / 4 096 workgroups take 161 / 215 us against 128 -- but the scalar tap loads need the waves:
+    //  512 / 256 take 164 / 250)
+    hipLaunchKernelGGL(conv3x3_c1_wgrad_kernel<8>, dim3(1024), dim3(256), 0, st, x, g, B, H, W, pw,
                        Ho, Wo, dw, db);
-  }
   else if (mode == 2)
     hipLaunchKernelGGL(conv3x3_c1_dgrad_kernel<8>, dim3(grid_c1((long)B * H * W)), dim3(256), 0, st,
                        g, w, B, H, W, pw, Ho, Wo, dx);

@@ -690,7 +690,7 @@ static int downsample_bwd_impl(const float* src, const float* w, const float* g,
   }
   // (frames, row slices): at most `cap` workgroups, each finishing with ds atomics on the SAME words --
   // those serialise (~25 ns each): with ~1000 workgroups the launch took 26 us whatever its size
-  static const long cap = [] { const char* e = getenv("S2T_DS_BWD_BLOCKS"); return e ? std::max(1L, atol(e)) : 512L; }();
+  constexpr long cap = 512;          // (1 024: 27-29 us, 512: 23-25, 256: 24-27, 128: 30-41 at the C3 shapes)
   int gy = (int)std::min<long>((rowlen / 4 + 255) / 256, std::max<long>(1, cap / dT));
   if (gy < 1) gy = 1;
   const int gx = (int)std::min<long>(dT, std::max<long>(1, cap / gy));
@@ -728,7 +728,7 @@ extern "C" int s2t_bypass_up_bwd(const float* orig, const float* src, const floa
     int gc = C4, r = 256;
     while (r) { const int t = gc % r; gc = r; r = t; }
     const long m = C4 / gc;
-    static const long cap = [] { const char* e = getenv("S2T_BUP_BLOCKS"); return e ? atol(e) : 256L; }();
+    constexpr long cap = 256;        // (128: 28-33 us, 192 / 256 / 384: 25-30, 512: 30-34, 1 024: 38-40, 2 048: 38-60)
     long nb = (n + 255) / 256;
     if (nb > cap) nb = cap;
     nb = (nb + m - 1) / m * m;

@@ -1,7 +1,7 @@
 """Kernels whose tail is one atomic per column and workgroup (s2t_norm_bypass_bwd, s2t_bypass_up_bwd):
 time per launch at the C3 shapes, operands rotated over NSET buffer sets (the step never finds them in
-the infinity cache).  Grid caps are read from the environment by the library (S2T_NB_BWD_BLOCKS,
-S2T_BUP_BLOCKS, S2T_BYPASS_UP_BWD16)."""
+the infinity cache).  S2T_BYPASS_UP_BWD16=0 / S2T_NB_BWD16=0 select the scalar forms; the grid caps of the
+16-byte forms were environment knobs while they were tuned and are constants now."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
