@@ -191,6 +191,7 @@ class _SimpleRnntLoss(torch.autograd.Function):
         lm_p = torch.empty_like(lm)
         am_max = torch.empty((B, T), dtype=torch.float32, device=dev)
         lm_max = torch.empty((B, S + 1), dtype=torch.float32, device=dev)
+        N.PROF[0] and N.profile_note("s2t_rnnt_row_exp", 8.0 * (am.numel() + lm.numel()) + 4.0 * B * (T + S + 1))
         N.check(L.s2t_rnnt_row_exp(N.fp(am), B * T, C, N.fp(am_p), N.fp(am_max), st), "row_exp")
         N.check(L.s2t_rnnt_row_exp(N.fp(lm), B * (S + 1), C, N.fp(lm_p), N.fp(lm_max), st),
                 "row_exp")
@@ -202,6 +203,8 @@ class _SimpleRnntLoss(torch.autograd.Function):
             nrm = zk.batched_matmul(0, lm_p, am_p)                       # (B,S+1,T)
         px = torch.empty((B, S, T + 1), dtype=torch.float32, device=dev)
         py = torch.empty((B, S + 1, T), dtype=torch.float32, device=dev)
+        N.PROF[0] and N.profile_note("s2t_rnnt_simple_pxpy", 4.0 * (am.numel() + lm.numel() + nrm.numel() + px.numel()
+                                                                    + py.numel()))
         N.check(L.s2t_rnnt_simple_pxpy(N.fp(am), N.fp(lm), N.fp(am_max), N.fp(lm_max),
                                        N.fp(nrm), N.lp(symbols), N.lp(boundary), B, S, T, C,
                                        int(blank), N.fp(px), N.fp(py), st), "simple_pxpy")
@@ -220,6 +223,7 @@ class _SimpleRnntLoss(torch.autograd.Function):
         st = N.stream()
         gscale = (-g_loss).contiguous().float()       # d loss / d score = -g
         W = torch.empty_like(nrm)
+        N.PROF[0] and N.profile_note("s2t_rnnt_simple_w", 4.0 * (gx.numel() + gy.numel() + 2 * nrm.numel()))
         N.check(L.s2t_rnnt_simple_w(N.fp(gx), N.fp(gy), N.fp(nrm), N.fp(gscale), B, S, T,
                                     N.fp(W), st), "simple_w")
         from . import zip_kernels as zk
@@ -228,6 +232,8 @@ class _SimpleRnntLoss(torch.autograd.Function):
             G_lm = zk.batched_matmul(1, W, am_p)                  # W @ exp(am):   (B,S+1,C)
         d_am = torch.empty_like(am_p)
         d_lm = torch.empty_like(lm_p)
+        N.PROF[0] and N.profile_note("s2t_rnnt_simple_bwd", 12.0 * (am_p.numel() + lm_p.numel())
+                                     + 4.0 * (gx.numel() + gy.numel()))
         N.check(L.s2t_rnnt_simple_bwd(N.fp(am_p), N.fp(lm_p), N.fp(G_am), N.fp(G_lm), N.fp(gx),
                                       N.fp(gy), N.fp(gscale), N.lp(symbols), B, S, T, C,
                                       ctx.blank, N.fp(d_am), N.fp(d_lm), 0, st), "simple_bwd")
@@ -410,6 +416,7 @@ class _PredictorContext(torch.autograd.Function):
         tok = tokens.to(torch.int32).contiguous()
         e, wk = emb.contiguous().float(), w.reshape(D, K).contiguous().float()
         out = torch.empty((B, L - K + 1, D), dtype=torch.float32, device=emb.device)
+        N.PROF[0] and N.profile_note("s2t_predictor_ctx_fwd", 4.0 * (K + 1) * out.numel() + 4.0 * tok.numel())
         N.check(N.lib().s2t_predictor_ctx_fwd(N.ip(tok), N.fp(e), N.fp(wk), B, L, K, D, V, N.fp(out),
                                               N.stream()), "s2t_predictor_ctx_fwd")
         ctx.save_for_backward(tok, e, wk)
@@ -425,6 +432,7 @@ class _PredictorContext(torch.autograd.Function):
         g = g.contiguous().float()
         de = torch.zeros_like(e) if ctx.needs_input_grad[1] else None
         dw = torch.zeros_like(wk) if ctx.needs_input_grad[2] else None
+        N.PROF[0] and N.profile_note("s2t_predictor_ctx_bwd", 4.0 * (2 * K + 1) * g.numel() + 4.0 * tok.numel())
         N.check(N.lib().s2t_predictor_ctx_bwd(N.ip(tok), N.fp(e), N.fp(wk), N.fp(g), B, L, K, D, V,
                                               N.fp(de), N.fp(dw), N.stream()), "s2t_predictor_ctx_bwd")
         return None, de, (None if dw is None else dw.view(ctx.wshape))

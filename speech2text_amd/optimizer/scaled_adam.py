@@ -150,6 +150,8 @@ class ScaledAdam(Optimizer):
             k = h["k"]
             cs = group["clipping_scale"]
             period = group["clipping_update_period"]
+            N.profile_note("s2t_scaled_adam_coef", 4.0 * (self._partial.numel() + self._segstat.numel()
+                                                          + self._segc.numel()))
             N.check(L.s2t_scaled_adam_coef(
                 N.fp(self._partial), N.ip(tb["seg_chunk_begin"]), N.ip(tb["seg_len"]),
                 tb["nchunks"], s["lo"], s["hi"], float(group["lr"]), h["beta1"], h["beta2"],

@@ -470,8 +470,9 @@ class _LayerFn(torch.autograd.Function):
             s.pos2 = pos_emb.reshape(2 * T - 1, -1).contiguous().float()
             s.posp = zk.lt_matmul(0, s.pos2, sa.linear_pos.weight, None)
         W = torch.empty((H, B, T, T), dtype=_F32, device=dev)
-        N.PROF[0] and N.profile_note("s2t_relpos_attn_fwd", 4.0 * (s.qkp.numel() + W.numel()),
-                       2.0 * W.numel() * (qd + (pd if d.use_pos else 0)))
+        N.PROF[0] and N.profile_note("s2t_relpos_attn_fwd_flag" if d.penalize else "s2t_relpos_attn_fwd",
+                                     4.0 * (s.qkp.numel() + W.numel()),
+                                     2.0 * W.numel() * (qd + (pd if d.use_pos else 0)))
         s.pen_slot = s.pen_event = None
         if d.penalize:
             # the penalty has a gradient only where |score| > 25: the kernel raises a host-visible
