@@ -203,8 +203,8 @@ class _SimpleRnntLoss(torch.autograd.Function):
             nrm = zk.batched_matmul(0, lm_p, am_p)                       # (B,S+1,T)
         px = torch.empty((B, S, T + 1), dtype=torch.float32, device=dev)
         py = torch.empty((B, S + 1, T), dtype=torch.float32, device=dev)
-        N.PROF[0] and N.profile_note("s2t_rnnt_simple_pxpy", 4.0 * (am.numel() + lm.numel() + nrm.numel() + px.numel()
-                                                                    + py.numel()))
+        # (two gathered operands per lattice arc -- am / lm at the arc's symbol or at blank -- the normaliser once)
+        N.PROF[0] and N.profile_note("s2t_rnnt_simple_pxpy", 4.0 * (3 * px.numel() + 3 * py.numel() + nrm.numel()))
         N.check(L.s2t_rnnt_simple_pxpy(N.fp(am), N.fp(lm), N.fp(am_max), N.fp(lm_max),
                                        N.fp(nrm), N.lp(symbols), N.lp(boundary), B, S, T, C,
                                        int(blank), N.fp(px), N.fp(py), st), "simple_pxpy")
