@@ -657,3 +657,92 @@ def test_balancer_backward_vs_fp64_closed_form(dev, rows, C, swoosh):
     wide[:, C:2 * C] = x
     outs = zk.balancer_backward(wide[:, C:2 * C], g, *cfg, 1, swoosh_l=swoosh)
     assert (outs.double() - ref).abs().max().item() <= 2e-3 * size + 2e-6 * scale
+
+
+@pytest.mark.parametrize("T,B,C,up", [(495, 64, 256, 2), (495, 64, 256, 4), (495, 64, 192, 8), (248, 64, 384, 2),
+                                      (131, 7, 64, 4)])
+def test_upsampled_bypass_backward_16_byte_form_full_size(dev, T, B, C, up):
+    """s2t_bypass_up_bwd at the C3 sizes -- the 16-byte form's multi-item loop, its capped grid (a lane
+    keeps its channels only because the grid's stride is a multiple of C / 4: C = 192 / 384 are the
+    cases where that needs a rounded grid) and the ragged last source frame -- against the closed
+    form in fp64 on the device (zipformer.py:1253-1283, 1523-1555)."""
+    from speech2text_amd import _native as Nt
+    L, st = Nt.lib(), Nt.stream()
+    g = torch.Generator().manual_seed(T + C + up)
+    Ts = (T + up - 1) // up
+    orig = torch.randn(T, B, C, generator=g).to(dev)
+    src = torch.randn(Ts, B, C, generator=g).to(dev)
+    k = torch.rand(C, generator=g).to(dev)
+    gy = torch.randn(T, B, C, generator=g).to(dev)
+    d_orig, d_src, d_k = torch.empty_like(orig), torch.empty_like(src), torch.zeros_like(k)
+    assert L.s2t_bypass_up_bwd(Nt.fp(orig), Nt.fp(src), Nt.fp(k), Nt.fp(gy), up, T, B, C, Nt.fp(d_orig),
+                               Nt.fp(d_src), Nt.fp(d_k), st) == 0
+    gd, od, kd = gy.double(), orig.double(), k.double()
+    sup = src.double().repeat_interleave(up, dim=0)[:T]
+    r_orig = gd * (1.0 - kd)
+    gpad = torch.cat((gd, torch.zeros(Ts * up - T, B, C, dtype=torch.float64, device=dev)), dim=0)
+    r_src = (gpad * kd).reshape(Ts, up, B, C).sum(dim=1)
+    r_k = (gd * (sup - od)).sum(dim=(0, 1))
+    assert (d_orig.double() - r_orig).abs().max().item() <= 1e-6 * r_orig.abs().max().item()
+    assert (d_src.double() - r_src).abs().max().item() <= 2e-6 * r_src.abs().max().item()
+    assert (d_k.double() - r_k).abs().max().item() <= 2e-5 * r_k.abs().max().item()
+
+
+@pytest.mark.parametrize("R,B,D,masked", [(31680, 64, 192, True), (15872, 64, 256, False), (3968, 64, 384, True),
+                                          (997, 1, 1024, True), (130, 5, 68, False)])
+def test_norm_bypass_backward_16_byte_form_full_size(dev, R, B, D, masked):
+    """s2t_norm_bypass_bwd at the C3 sizes (one, two and four 16-byte chunks per lane; rows that do not
+    fill the last trip of four) against autograd through the closed form of BiasNorm + bypass + feature
+    mask in fp64 (model/layer/scaling.py:412-476, zipformer.py:1523-1555, 1330-1337)."""
+    from speech2text_amd import _native as Nt
+    L, st = Nt.lib(), Nt.stream()
+    g = torch.Generator().manual_seed(R + D)
+    R = (R // B) * B
+    x = (torch.randn(R, D, generator=g) * 2).to(dev)
+    orig = torch.randn(R, D, generator=g).to(dev)
+    bias = (torch.randn(D, generator=g) * 0.1).to(dev)
+    ls = torch.tensor([0.3], device=dev)
+    k = torch.rand(D, generator=g).to(dev)
+    fm = (torch.rand(B, D, generator=g) > 0.3).float().to(dev) if masked else None
+    gy = torch.randn(R, D, generator=g).to(dev)
+    out, sc = torch.empty(R, D, device=dev), torch.empty(R, device=dev)
+    assert L.s2t_norm_bypass_fwd(Nt.fp(x), Nt.fp(bias), Nt.fp(ls), Nt.fp(orig), Nt.fp(k), Nt.fp(fm), B, R, D,
+                                 Nt.fp(out), Nt.fp(sc), st) == 0
+    dx, d0 = torch.empty(R, D, device=dev), torch.empty(R, D, device=dev)
+    dk, db, dl = torch.zeros(D, device=dev), torch.zeros(D, device=dev), torch.zeros(1, device=dev)
+    assert L.s2t_norm_bypass_bwd(Nt.fp(x), Nt.fp(bias), Nt.fp(sc), Nt.fp(orig), Nt.fp(k), Nt.fp(gy), Nt.fp(fm), B,
+                                 R, D, Nt.fp(dx), Nt.fp(d0), Nt.fp(dk), Nt.fp(db), Nt.fp(dl), st) == 0
+    xr, orr, br, lr, kr = (t.double().requires_grad_(True) for t in (x, orig, bias, ls, k))
+    scale = ((xr - br) ** 2).mean(dim=1, keepdim=True) ** -0.5 * lr.exp()
+    y = orr + (xr * scale - orr) * kr
+    if masked:
+        y = y * fm.double().repeat(R // B, 1)
+    assert (out.double() - y.detach()).abs().max().item() <= 2e-6 * y.detach().abs().max().item()
+    y.backward(gy.double())
+    for name, got, ref, tol in (("dx", dx, xr.grad, 5e-6), ("d_orig", d0, orr.grad, 2e-6), ("d_scale", dk, kr.grad, 5e-5),
+                                ("d_bias", db, br.grad, 5e-5), ("d_log_scale", dl, lr.grad, 5e-5)):
+        err = (got.double() - ref).abs().max().item()
+        assert err <= tol * max(1.0, ref.abs().max().item()), (name, err)
+
+
+def test_frontend_output_linear_on_permuted_columns(dev):
+    """zk.linear_col_perm (Conv2dSubsampling.out on the channel-last map, reference
+    model/layer/subsampling.py:312-319): output, data gradient and the parameter gradients -- returned
+    as tensors for parameters outside a flat store -- against F.linear on the permuted weight, fp64."""
+    from speech2text_amd import zip_kernels as zk
+    g = torch.Generator().manual_seed(5)
+    b, t, f, c, n = 3, 50, 19, 128, 192
+    x = torch.randn(b, t, f * c, generator=g)
+    w = torch.randn(n, c * f, generator=g) * 0.05
+    bias = torch.randn(n, generator=g)
+    wy = torch.randn(b, t, n, generator=g)
+    xr, wr, br = (v.double().requires_grad_(True) for v in (x, w, bias))
+    yr = torch.nn.functional.linear(xr, wr.view(n, c, f).permute(0, 2, 1).reshape(n, f * c), br)
+    (yr * wy.double()).sum().backward()
+    xg, wg, bg = (v.to(dev).requires_grad_(True) for v in (x, w, bias))
+    y = zk.linear_col_perm(xg, wg, bg, f, c)
+    (y * wy.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    for got, ref, tol in ((y.detach(), yr.detach(), 1e-4), (xg.grad, xr.grad, 1e-4), (wg.grad, wr.grad, 2e-4),
+                          (bg.grad, br.grad, 2e-4)):
+        assert (got.cpu().double() - ref).abs().max().item() <= tol * ref.abs().max().item()
